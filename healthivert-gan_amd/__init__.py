@@ -1,0 +1,9 @@
+"""MI355X-native hot path of HealthiVert-GAN (generator / discriminator train + inference loop).
+
+The directory name contains a hyphen, so import it with
+``importlib.import_module("healthivert-gan_amd")`` or through the ``hvgan`` alias module at the
+repo root.  The HIP library is loaded lazily (``lib.get()``) and every operator raises if it is
+missing -- there is no CPU fallback in the product path.
+"""
+__version__ = "0.1.0"
+from . import synth  # noqa: E402,F401  (numpy only)

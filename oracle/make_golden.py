@@ -1,0 +1,256 @@
+"""Generate tests/golden/*.npz by importing the REFERENCE (builder container only).
+
+Usage:  python oracle/make_golden.py [--ref /root/reference] [--out tests/golden]
+
+The reference is pure Python/PyTorch; it imports here once `torchvision` is stubbed (it is an
+unused import at models/inpaint_networks.py:10-11 and models/edge_operator.py:8-9) and
+`.cuda()` is neutralised (models/pix2pix_model.py:104-105 and the `use_cuda` branches of
+models/inpaint_networks.py hard-code it).  Nothing of the reference is copied: the fixtures hold
+only inputs, seeds, (mini-config) weights and outputs.  TEST INFRASTRUCTURE ONLY.
+"""
+import argparse
+import os
+import sys
+import types
+from argparse import Namespace
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def import_reference(ref):
+    for name in ('torchvision', 'torchvision.transforms', 'torchvision.utils'):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.save_image = lambda *a, **k: None
+            sys.modules[name] = m
+    sys.modules['torchvision'].transforms = sys.modules['torchvision.transforms']
+    sys.modules['torchvision'].utils = sys.modules['torchvision.utils']
+    torch.nn.Module.cuda = lambda self, device=None: self
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    sys.path.insert(0, ref)
+    import models.inpaint_networks as inp
+    import models.networks as nets
+    import models.edge_operator as edge
+    import models.UnetG_CT_mask as unet
+    import models.pix2pix_model as p2p
+    return inp, nets, edge, unet, p2p
+
+
+def np_sd(sd):
+    return {k: v.detach().cpu().numpy().copy() for k, v in sd.items()}
+
+
+def _np(v):
+    return v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+
+
+def save(out, name, **arrs):
+    flat = {}
+    for k, v in arrs.items():
+        if isinstance(v, dict):
+            for kk, vv in v.items():
+                flat['%s::%s' % (k, kk)] = _np(vv)
+        else:
+            flat[k] = _np(v)
+    path = os.path.join(out, name + '.npz')
+    np.savez_compressed(path, **flat)
+    print('%-28s %8.1f KB' % (name, os.path.getsize(path) / 1024.))
+
+
+def mini_inputs(B, S, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(B, 1, S, S, generator=g) * 2 - 1
+    mask = torch.zeros(B, 1, S, S)
+    for i in range(B):
+        r0 = S // 2 - S // 8 + 3 * i
+        mask[i, :, r0:r0 + S // 4, :] = 1
+    x = x * (1 - mask) - mask
+    cam = torch.rand(B, 1, S, S, generator=g)
+    ratio = torch.rand(B, generator=g, dtype=torch.float64) * 0.8
+    return x, mask, cam, ratio
+
+
+def g1_generator(inp, out):
+    """G1: Generator ngf=4 @64^2 B=2, train + eval forward, SN buffers, grads of a scalar loss."""
+    torch.manual_seed(101)
+    net = inp.Generator({'input_dim': 1, 'ngf': 4}, False)
+    sd0 = np_sd(net.state_dict())
+    x, mask, cam, ratio = mini_inputs(2, 64, 7)
+    g = torch.Generator().manual_seed(11)
+    coef = [torch.randn(2, 1, 64, 64, generator=g) for _ in range(4)] + [torch.randn(2, 1, generator=g) for _ in range(2)]
+    net.train()
+    o = net(x, mask, cam, ratio)
+    outs = [o[0], o[1], o[2], o[3], o[5], o[6]]
+    loss = sum((a * c).sum() for a, c in zip(outs, coef))
+    loss.backward()
+    grads = {k: p.grad.numpy().copy() for k, p in net.named_parameters()}
+    sd1 = np_sd(net.state_dict())
+    bufs = {k: v for k, v in sd1.items() if k.endswith('weight_u') or k.endswith('weight_v')}
+    net.eval()
+    with torch.no_grad():
+        oe = net(x, mask, cam, ratio)
+    save(out, 'g1_generator_mini', sd=sd0, x=x, mask=mask, cam=cam, ratio=ratio,
+         coef={str(i): c for i, c in enumerate(coef)},
+         train={n: t for n, t in zip(('coarse_seg', 'fine_seg', 'x_stage1', 'x_stage2', 'pred1_h', 'pred2_h'), outs)},
+         flow_train=o[4], loss=loss.detach(), grads=grads, bufs_after=bufs,
+         eval={n: t for n, t in zip(('coarse_seg', 'fine_seg', 'x_stage1', 'x_stage2', 'pred1_h', 'pred2_h'),
+                                    [oe[0], oe[1], oe[2], oe[3], oe[5], oe[6]])}, flow_eval=oe[4])
+
+
+def g2_attention(inp, out):
+    """G2: ContextualAttention C=8, 16x16 features, B=2 with DIFFERENT masks (pins the batch-0 quirk)."""
+    g = torch.Generator().manual_seed(5)
+    f = torch.randn(2, 8, 16, 16, generator=g).relu_().requires_grad_(True)
+    mask = torch.zeros(2, 1, 64, 64)
+    mask[0, :, 24:40, :] = 1
+    mask[1, :, 8:24, :] = 1
+    ca = inp.ContextualAttention(False, ksize=3, stride=1, rate=2, fuse_k=3, softmax_scale=10, fuse=True)
+    y, flow = ca(f, f, mask)
+    coef = torch.randn(y.shape, generator=g)
+    (y * coef).sum().backward()
+    save(out, 'g2_attention', f=f.detach(), mask=mask, y=y.detach(), flow=flow, coef=coef, grad_f=f.grad)
+
+
+def g3_discriminator(nets, out):
+    """G3: define_D(1, 8, 'basic', 3, norm) @64^2: forward, grads, BN running stats after 3 calls."""
+    for norm in ('batch', 'instance'):
+        torch.manual_seed(202)
+        net = nets.define_D(1, 8, 'basic', 3, norm, 'normal', 0.02, [])
+        sd0 = np_sd(net.state_dict())
+        g = torch.Generator().manual_seed(3)
+        xs = [torch.rand(2, 1, 64, 64, generator=g) * 2 - 1 for _ in range(3)]
+        net.train()
+        x0 = xs[0].clone().requires_grad_(True)
+        y0 = net(x0)
+        loss = torch.nn.BCEWithLogitsLoss()(y0, torch.ones_like(y0))
+        loss.backward()
+        grads = {k: p.grad.numpy().copy() for k, p in net.named_parameters()}
+        ys = [y0.detach()] + [net(x).detach() for x in xs[1:]]
+        sd3 = np_sd(net.state_dict())
+        net.eval()
+        ye = net(xs[0]).detach()
+        save(out, 'g3_disc_%s' % norm, sd=sd0, x={str(i): x for i, x in enumerate(xs)},
+             y={str(i): y for i, y in enumerate(ys)}, loss=loss.detach(), grads=grads, grad_x=x0.grad,
+             sd_after={k: v for k, v in sd3.items() if 'running' in k or 'tracked' in k}, y_eval=ye)
+
+
+def g4_small_ops(edge, nets, p2p, out):
+    """G4: Sobel, diceCoeff, GANLoss on hand-built inputs."""
+    g = torch.Generator().manual_seed(9)
+    m = (torch.rand(2, 1, 32, 32, generator=g) > 0.6).float()
+    soft = torch.rand(2, 1, 32, 32, generator=g)
+    sob = edge.Sobel(requires_grad=False)
+    pred = torch.randn(2, 1, 6, 6, generator=g)
+    res = dict(m=m, soft=soft, sobel_m=sob(m), sobel_soft=sob(soft.clone()), pred=pred,
+               dice=p2p.diceCoeff(soft, m, activation='none'))
+    for mode in ('vanilla', 'lsgan'):
+        crit = nets.GANLoss(mode)
+        res['gan_%s_real' % mode] = crit(pred, True)
+        res['gan_%s_fake' % mode] = crit(pred, False)
+    save(out, 'g4_small_ops', **res)
+
+
+def g6_unet(unet, out):
+    """G6: UnetG_CT_mask.define_G(3,1,4,...) @64^2, use_dropout=False, train + eval."""
+    torch.manual_seed(303)
+    net = unet.define_G(3, 1, 4, 'unet_256', 'batch', False, 'normal', 0.02, [])
+    sd0 = np_sd(net.state_dict())
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+    tgt = torch.rand(2, 1, 64, 64, generator=g) * 2 - 1
+    net.train()
+    ct, mk = net(x)
+    loss = torch.nn.L1Loss()(ct, tgt) + (mk * tgt).mean()
+    loss.backward()
+    grads = {k: p.grad.numpy().copy() for k, p in net.named_parameters()}
+    sd1 = np_sd(net.state_dict())
+    net.eval()
+    with torch.no_grad():
+        cte, mke = net(x)
+    save(out, 'g6_unet_mini', sd=sd0, x=x, tgt=tgt, ct=ct.detach(), mk=mk.detach(), loss=loss.detach(), grads=grads,
+         sd_after={k: v for k, v in sd1.items() if 'running' in k or 'tracked' in k}, ct_eval=cte, mk_eval=mke)
+
+
+def make_opt(**kw):
+    o = Namespace(gpu_ids=[], isTrain=True, checkpoints_dir='/tmp/hv_ckpt', name='golden', preprocess='none',
+                  input_nc=1, output_nc=1, ngf=64, ndf=64, netD='basic', netG='unet_256', n_layers_D=3, norm='batch',
+                  init_type='normal', init_gain=0.02, no_dropout=True, gan_mode='vanilla', lr=2e-4, beta1=0.5,
+                  lambda_L1=200.0, direction='BtoA', lr_policy='linear', epoch_count=1, n_epochs=100,
+                  n_epochs_decay=100, continue_train=False, load_iter=0, epoch='latest', verbose=False)
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def sparse(t, step=8):
+    return t.detach()[..., ::step, ::step].contiguous()
+
+
+def g5_full_step(p2p, out, synth):
+    """G5: Pix2PixModel (norm=batch, vanilla, lambda 200, BtoA) B=2 @256^2, seed 1234: two consecutive
+    optimize_parameters.  Stores the 12 losses per step, every-8th-pixel samples, per-tensor L2 norms
+    of all parameters after each step and the checksum of the seeded initial weights."""
+    torch.manual_seed(1234)
+    model = p2p.Pix2PixModel(make_opt())
+    init = {}
+    for n in ('G', 'D_1', 'D_2', 'D_3'):
+        sd = getattr(model, 'net' + n).state_dict()
+        init[n] = np.array([float(v.double().sum()) for v in sd.values()] + [float(sum(v.double().abs().sum() for v in sd.values()))])
+    res = dict(init=init)
+    for step in range(2):
+        batch = synth.make_batch(2, 256, seed=1234 + step)
+        model.set_input(batch)
+        model.optimize_parameters()
+        losses = model.get_current_losses()
+        res['losses%d' % step] = {k: np.float64(v) for k, v in losses.items()}
+        res['samples%d' % step] = {k: sparse(getattr(model, k)) for k in
+                                   ('fake_B', 'fake_B_coarse', 'x_stage1', 'fake_B_raw', 'fake_B_mask_sigmoid',
+                                    'coarse_seg_sigmoid', 'fake_B_local', 'fake_edges', 'real_edges')}
+        res['pred_h%d' % step] = torch.cat([model.pred1_h, model.pred2_h]).detach()
+        norms = {}
+        for n in ('G', 'D_1', 'D_2', 'D_3'):
+            for k, v in getattr(model, 'net' + n).state_dict().items():
+                norms['%s/%s' % (n, k)] = np.float64(v.double().norm())
+        res['norms%d' % step] = norms
+    save(out, 'g5_full_step', **res)
+    return model
+
+
+def g7_inference(inp, out, synth):
+    """G7: eval-mode Generator ngf=16 @256^2 bs=1 (the eval_3d_sagittal_twostage.py:100-101 call), seed 77."""
+    torch.manual_seed(77)
+    net = inp.Generator({'input_dim': 1, 'ngf': 16}, False).eval()
+    b = synth.to_model_inputs(synth.make_batch(1, 256, seed=77))
+    with torch.no_grad():
+        o = net(b['real_A'], b['mask'], 1 - b['CAM'], b['slice_ratio'])
+    sdsum = np.array([float(v.double().sum()) for v in net.state_dict().values()])
+    save(out, 'g7_inference', init=sdsum, fine_seg=sparse(o[1], 4), x_stage1=sparse(o[2], 4), x_stage2=sparse(o[3], 4),
+         coarse_seg=sparse(o[0], 4), pred1_h=o[5], pred2_h=o[6])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--ref', default='/root/reference')
+    ap.add_argument('--out', default=os.path.join(ROOT, 'tests', 'golden'))
+    args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
+    sys.path.insert(0, ROOT)
+    import hvgan  # noqa: F401  (alias of healthivert-gan_amd; only its numpy synth module is used)
+    from hvgan import synth
+    torch.set_num_threads(8)
+    inp, nets, edge, unet, p2p = import_reference(args.ref)
+    g1_generator(inp, args.out)
+    g2_attention(inp, args.out)
+    g3_discriminator(nets, args.out)
+    g4_small_ops(edge, nets, p2p, args.out)
+    g6_unet(unet, args.out)
+    g7_inference(inp, args.out, synth)
+    g5_full_step(p2p, args.out, synth)
+
+
+if __name__ == '__main__':
+    main()

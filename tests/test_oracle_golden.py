@@ -1,0 +1,116 @@
+"""The CPU oracle (oracle/restate.py) against the golden vectors the reference produced
+(oracle/make_golden.py).  CPU only; this is what pins the oracle."""
+import torch
+
+from oracle import restate as R
+from conftest import load_golden
+
+TOL = 2e-5
+
+
+def close(a, b, tol=TOL):
+    a, b = a.double(), b.double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = (a - b).abs().max().item()
+    assert err <= tol * max(1.0, b.abs().max().item()), err
+
+
+def test_g1_generator_train_eval_and_grads():
+    g = load_golden('g1_generator_mini')
+    sd = {k: v.clone() for k, v in g['sd'].items()}
+    params = [k for k in sd if k.endswith('weight_orig') or k.endswith('.bias') or k.endswith('fc_height.weight')]
+    for k in params:
+        sd[k].requires_grad_(True)
+    outs, upd = R.generator_forward(sd, g['x'], g['mask'], g['cam'], g['ratio'], training=True)
+    names = ('coarse_seg', 'fine_seg', 'x_stage1', 'x_stage2', 'pred1_h', 'pred2_h')
+    for n, o in zip(names, outs):
+        close(o.detach(), g['train'][n])
+    loss = sum((o * g['coef'][str(i)]).sum() for i, o in enumerate(outs))
+    close(loss.detach(), g['loss'], 1e-5)
+    loss.backward()
+    for k in params:
+        ref = g['grads'][k]
+        err = (sd[k].grad - ref).abs().max().item()
+        assert err <= 2e-4 * max(1.0, ref.abs().max().item()), (k, err)
+    for k, v in upd.items():
+        close(v, g['bufs_after'][k], 1e-5)
+    sd2 = {k: v.detach().clone() for k, v in sd.items()}
+    sd2.update({k: v for k, v in g['bufs_after'].items()})
+    with torch.no_grad():
+        oute, upde = R.generator_forward(sd2, g['x'], g['mask'], g['cam'], g['ratio'], training=False)
+    assert not upde
+    for n, o in zip(names, oute):
+        close(o, g['eval'][n])
+
+
+def test_g2_attention_batch0_mask_quirk_and_grad():
+    g = load_golden('g2_attention')
+    f = g['f'].clone().requires_grad_(True)
+    y = R.contextual_attention(f, f, g['mask'])
+    close(y.detach(), g['y'])
+    (y * g['coef']).sum().backward()
+    close(f.grad, g['grad_f'], 1e-4)
+
+
+def test_g3_discriminator():
+    for norm in ('batch', 'instance'):
+        g = load_golden('g3_disc_%s' % norm)
+        sd = {k: v.clone() for k, v in g['sd'].items()}
+        params = [k for k in sd if k.endswith('.weight') or k.endswith('.bias')]
+        for k in params:
+            sd[k].requires_grad_(True)
+        x0 = g['x']['0'].clone().requires_grad_(True)
+        y0, upd = R.disc_forward(sd, x0, norm, True)
+        close(y0.detach(), g['y']['0'])
+        loss = R.gan_loss(y0, True)
+        close(loss.detach(), g['loss'])
+        loss.backward()
+        for k in params:
+            close(sd[k].grad, g['grads'][k], 1e-4)
+        close(x0.grad, g['grad_x'], 1e-4)
+        with torch.no_grad():
+            for k, v in upd.items():
+                sd[k] = v
+            for i in (1, 2):
+                y, upd = R.disc_forward(sd, g['x'][str(i)], norm, True)
+                close(y, g['y'][str(i)])
+                for k, v in upd.items():
+                    sd[k] = v
+            for k, v in g.get('sd_after', {}).items():
+                close(sd[k].double(), v.double(), 1e-5)
+            ye, _ = R.disc_forward(sd, g['x']['0'], norm, False)
+            close(ye, g['y_eval'])
+
+
+def test_g4_small_ops():
+    g = load_golden('g4_small_ops')
+    close(R.sobel(g['m']), g['sobel_m'])
+    close(R.sobel(g['soft']), g['sobel_soft'])
+    close(R.dice_coeff(g['soft'], g['m']), g['dice'])
+    for mode in ('vanilla', 'lsgan'):
+        close(R.gan_loss(g['pred'], True, mode), g['gan_%s_real' % mode])
+        close(R.gan_loss(g['pred'], False, mode), g['gan_%s_fake' % mode])
+
+
+def test_g6_unet():
+    g = load_golden('g6_unet_mini')
+    sd = {k: v.clone() for k, v in g['sd'].items()}
+    params = [k for k in sd if (k.endswith('.weight') or k.endswith('.bias'))]
+    for k in params:
+        sd[k].requires_grad_(True)
+    (ct, mk), upd = R.unet_forward(sd, g['x'], 5, True)
+    close(ct.detach(), g['ct'])
+    close(mk.detach(), g['mk'])
+    loss = (ct - g['tgt']).abs().mean() + (mk * g['tgt']).mean()
+    close(loss.detach(), g['loss'])
+    loss.backward()
+    for k in params:
+        close(sd[k].grad, g['grads'][k], 2e-4)
+    with torch.no_grad():
+        for k, v in upd.items():
+            sd[k] = v
+        for k, v in g['sd_after'].items():
+            close(sd[k].double(), v.double(), 1e-5)
+        (cte, mke), _ = R.unet_forward(sd, g['x'], 5, False)
+        close(cte, g['ct_eval'])
+        close(mke, g['mk_eval'])
