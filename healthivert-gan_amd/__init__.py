@@ -7,3 +7,5 @@ missing -- there is no CPU fallback in the product path.
 """
 __version__ = "0.1.0"
 from . import synth  # noqa: E402,F401  (numpy only)
+from . import lib  # noqa: E402,F401  (ctypes binding; loads libhvgan.so lazily)
+from . import ops  # noqa: E402,F401

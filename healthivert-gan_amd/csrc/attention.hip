@@ -1,0 +1,315 @@
+// Memory-bound stages of the contextual-attention block (reference models/inpaint_networks.py:247-410).
+// The two large contractions (patch matching, patch pasting) and their gradients run through
+// hv_conv2d with per-sample filters; the kernels here build those filters from the feature map
+// (patch matrices), fuse / mask / soft-max the L x L score matrix, and scatter gradients back.
+// Score matrices are stored [b][p][l]: p = foreground position (row), l = background patch (contiguous).
+#include "hv_common.h"
+
+static int at_grid(long long n, int cap = 16384) { long long b = (n + 255) / 256; return (int)(b > cap ? cap : (b < 1 ? 1 : b)); }
+#define AT_LOOP(i, n) for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long long)gridDim.x * blockDim.x)
+
+// ---- downsample + 3x3 patch matrix (+ transposed copy) ------------------------------------------------
+__global__ void ca_down_kernel(const float* __restrict__ f, float* __restrict__ fd, int H, int W, int C, int f_ld, long long n) {
+    const int h = H / 2, w = W / 2;
+    AT_LOOP(i, n) {
+        const int c = (int)(i % C);
+        long long r = i / C;
+        const int x = (int)(r % w); r /= w;
+        const int y = (int)(r % h);
+        const long long b = r / h;
+        fd[i] = f[((b * H + 2 * y) * W + 2 * x) * f_ld + c];
+    }
+}
+__global__ void ca_wp_kernel(const float* __restrict__ fd, float* __restrict__ wp, float* __restrict__ wpT, int h, int w, int C, long long n) {
+    const int L = h * w;
+    AT_LOOP(i, n) {  // i over wp order (b, l, tap, c)
+        const int c = (int)(i % C);
+        long long r = i / C;
+        const int tap = (int)(r % 9); r /= 9;
+        const int l = (int)(r % L);
+        const long long b = r / L;
+        const int y = l / w + tap / 3 - 1, x = l % w + tap % 3 - 1;
+        float v = 0.f;
+        if ((unsigned)y < (unsigned)h && (unsigned)x < (unsigned)w) v = fd[((b * h + y) * w + x) * C + c];
+        wp[i] = v;
+        if (wpT) wpT[(b * 9 * C + tap * C + c) * L + l] = v;
+    }
+}
+__global__ __launch_bounds__(64) void ca_norm_kernel(const float* __restrict__ wp, float* __restrict__ norm, float* __restrict__ rnorm, int K) {
+    const long long row = blockIdx.x;
+    float s = 0.f;
+    for (int k = threadIdx.x; k < K; k += 64) { const float v = wp[row * K + k]; s += v * v; }
+    s = hv_wave_sum(s);
+    if (threadIdx.x == 0) {
+        const float nv = fmaxf(sqrtf(s), 1e-4f);
+        norm[row] = nv;
+        rnorm[row] = 1.f / nv;
+    }
+}
+// 4x4 stride-2 'same' patches (pad 1 top/left): raw[b][l][tap][c] and/or rawT[b][c][tap][l]
+__global__ void ca_raw_kernel(const float* __restrict__ f, float* __restrict__ raw, float* __restrict__ rawT, int H, int W, int C, int f_ld, long long n) {
+    const int h = H / 2, w = W / 2, L = h * w;
+    AT_LOOP(i, n) {  // i over rawT order (b, c, tap, l): coalesced writes of the larger-stride copy
+        const int l = (int)(i % L);
+        long long r = i / L;
+        const int tap = (int)(r % 16); r /= 16;
+        const int c = (int)(r % C);
+        const long long b = r / C;
+        const int y = 2 * (l / w) - 1 + tap / 4, x = 2 * (l % w) - 1 + tap % 4;
+        float v = 0.f;
+        if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) v = f[((b * H + y) * W + x) * f_ld + c];
+        if (rawT) rawT[i] = v;
+        if (raw) raw[((b * L + l) * 16 + tap) * C + c] = v;
+    }
+}
+
+extern "C" int hv_ca_patches(const float* f, int B, int H, int W, int C, int f_ld, float* fd, float* wp, float* wpT, float* norm,
+                             float* rnorm, void* stream) {
+    if (!f || !fd || !wp || !norm || !rnorm || B <= 0 || H <= 0 || W <= 0 || C <= 0 || ((H | W) & 1) || f_ld < C) return HV_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int h = H / 2, w = W / 2;
+    long long n = (long long)B * h * w * C;
+    hipLaunchKernelGGL(ca_down_kernel, dim3(at_grid(n)), dim3(256), 0, s, f, fd, H, W, C, f_ld, n);
+    HV_LAUNCH_CHECK();
+    n *= 9;
+    hipLaunchKernelGGL(ca_wp_kernel, dim3(at_grid(n)), dim3(256), 0, s, fd, wp, wpT, h, w, C, n);
+    HV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ca_norm_kernel, dim3(B * h * w), dim3(64), 0, s, wp, norm, rnorm, 9 * C);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+extern "C" int hv_ca_raw_patches(const float* f, int B, int H, int W, int C, int f_ld, float* raw, float* rawT, void* stream) {
+    if (!f || (!raw && !rawT) || B <= 0 || H <= 0 || W <= 0 || C <= 0 || ((H | W) & 1) || f_ld < C) return HV_ERR_ARG;
+    const long long n = (long long)B * C * 16 * (H / 2) * (W / 2);
+    hipLaunchKernelGGL(ca_raw_kernel, dim3(at_grid(n)), dim3(256), 0, (hipStream_t)stream, f, raw, rawT, H, W, C, f_ld, n);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+
+// ---- mask of valid background patches (sample 0 only) ------------------------------------------------
+__global__ void ca_mask_kernel(const float* __restrict__ mask, int Himg, int Wimg, int h, int w, float* __restrict__ mm) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= h * w) return;
+    const int sy = Himg / h, sx = Wimg / w;
+    float s = 0.f;
+    for (int t = 0; t < 9; ++t) {
+        const int y = l / w + t / 3 - 1, x = l % w + t % 3 - 1;
+        if ((unsigned)y < (unsigned)h && (unsigned)x < (unsigned)w) s += mask[(long long)(y * sy) * Wimg + x * sx];
+    }
+    mm[l] = (s / 9.f == 0.f) ? 1.f : 0.f;
+}
+extern "C" int hv_ca_mask(const float* mask, int Himg, int Wimg, int h, int w, float* mm, void* stream) {
+    if (!mask || !mm || h <= 0 || w <= 0 || Himg % h || Wimg % w) return HV_ERR_ARG;
+    hipLaunchKernelGGL(ca_mask_kernel, dim3(hv_cdiv(h * w, 256)), dim3(256), 0, (hipStream_t)stream, mask, Himg, Wimg, h, w, mm);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+
+// ---- score fusion ----------------------------------------------------------------------------------------
+__device__ __forceinline__ int tr_idx(int l, int h, int w) { return (l % w) * h + l / w; }  // (lh,lw) -> lw*h+lh
+__global__ void ca_fuse_kernel(const float* __restrict__ S, float* __restrict__ out, int h, int w, int adjoint, long long n) {
+    const int L = h * w;
+    AT_LOOP(i, n) {
+        const int l = (int)(i % L);
+        long long r = i / L;
+        const int p = (int)(r % L);
+        const float* Sb = S + (r / L) * (long long)L * L;
+        float acc = 0.f;
+        if (!adjoint) {
+            const int tp = tr_idx(p, h, w), tl = tr_idx(l, h, w);
+#pragma unroll
+            for (int d = -1; d <= 1; ++d) {
+                const int a = tp + d, b = tl + d;
+                if ((unsigned)a >= (unsigned)L || (unsigned)b >= (unsigned)L) continue;
+                const int pa = tr_idx(a, w, h), lb = tr_idx(b, w, h);  // inverse transpose
+#pragma unroll
+                for (int e = -1; e <= 1; ++e) {
+                    const int pp = pa + e, ll = lb + e;
+                    if ((unsigned)pp < (unsigned)L && (unsigned)ll < (unsigned)L) acc += Sb[(long long)pp * L + ll];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int e = -1; e <= 1; ++e) {
+                const int pe = p + e, le = l + e;
+                if ((unsigned)pe >= (unsigned)L || (unsigned)le >= (unsigned)L) continue;
+                const int tp = tr_idx(pe, h, w), tl = tr_idx(le, h, w);
+#pragma unroll
+                for (int d = -1; d <= 1; ++d) {
+                    const int a = tp + d, b = tl + d;
+                    if ((unsigned)a < (unsigned)L && (unsigned)b < (unsigned)L) acc += Sb[(long long)tr_idx(a, w, h) * L + tr_idx(b, w, h)];
+                }
+            }
+        }
+        out[i] = acc;
+    }
+}
+extern "C" int hv_ca_fuse(const float* S, float* out, int B, int h, int w, int adjoint, void* stream) {
+    if (!S || !out || S == out || B <= 0 || h <= 0 || w <= 0) return HV_ERR_ARG;
+    const long long L = (long long)h * w, n = (long long)B * L * L;
+    hipLaunchKernelGGL(ca_fuse_kernel, dim3(at_grid(n, 65536)), dim3(256), 0, (hipStream_t)stream, S, out, h, w, adjoint, n);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+
+// ---- masked scaled softmax over l (one 256-thread block per row) -------------------------------------
+__global__ __launch_bounds__(256) void ca_softmax_kernel(const float* __restrict__ S, const float* __restrict__ mm, float* __restrict__ A, int L,
+                                                         float scale, int* __restrict__ argmax) {
+    __shared__ float red[8];
+    __shared__ int redi[8];
+    const long long row = blockIdx.x;
+    const float* s = S + row * L;
+    float* a = A + row * L;
+    const int tid = threadIdx.x;
+    float mx = -3.0e38f;
+    for (int l = tid; l < L; l += 256) mx = fmaxf(mx, s[l] * mm[l] * scale);
+    mx = hv_wave_max(mx);
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int l = tid; l < L; l += 256) sum += expf(s[l] * mm[l] * scale - mx);
+    sum = hv_wave_sum(sum);
+    __syncthreads();
+    if ((tid & 63) == 0) red[4 + (tid >> 6)] = sum;
+    __syncthreads();
+    sum = red[4] + red[5] + red[6] + red[7];
+    float best = -1.f;
+    int bi = 0x7fffffff;
+    for (int l = tid; l < L; l += 256) {
+        const float v = expf(s[l] * mm[l] * scale - mx) / sum * mm[l];
+        a[l] = v;
+        if (v > best) { best = v; bi = l; }
+    }
+    if (argmax) {  // first index of the maximum (torch.argmax tie rule on CPU)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        __syncthreads();
+        if ((tid & 63) == 0) { red[tid >> 6] = best; redi[tid >> 6] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int k = 1; k < 4; ++k)
+                if (red[k] > best || (red[k] == best && redi[k] < bi)) { best = red[k]; bi = redi[k]; }
+            argmax[row] = bi;
+        }
+    }
+}
+extern "C" int hv_ca_softmax(const float* S, const float* mm, float* A, int B, int L, float scale, int* argmax, void* stream) {
+    if (!S || !mm || !A || B <= 0 || L <= 0) return HV_ERR_ARG;
+    hipLaunchKernelGGL(ca_softmax_kernel, dim3(B * L), dim3(256), 0, (hipStream_t)stream, S, mm, A, L, scale, argmax);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+// dS[p][l] = scale*mm[l]*A[p][l]*(dA[p][l] - sum_l' dA[p][l']*A[p][l'])   (A already carries the mask)
+__global__ __launch_bounds__(256) void ca_softmax_bwd_kernel(const float* __restrict__ dA, const float* __restrict__ A, const float* __restrict__ mm,
+                                                             float* __restrict__ dS, int L, float scale) {
+    __shared__ float red[20];
+    const long long row = blockIdx.x;
+    const float* a = A + row * L;
+    const float* g = dA + row * L;
+    float dot = 0.f;
+    for (int l = threadIdx.x; l < L; l += 256) dot += g[l] * a[l];
+    dot = hv_block_sum(dot, red);
+    for (int l = threadIdx.x; l < L; l += 256) dS[row * L + l] = scale * mm[l] * a[l] * (g[l] - dot);
+}
+extern "C" int hv_ca_softmax_backward(const float* dA, const float* A, const float* mm, float* dS, int B, int L, float scale, void* stream) {
+    if (!dA || !A || !mm || !dS || B <= 0 || L <= 0) return HV_ERR_ARG;
+    hipLaunchKernelGGL(ca_softmax_bwd_kernel, dim3(B * L), dim3(256), 0, (hipStream_t)stream, dA, A, mm, dS, L, scale);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+
+// ---- batched transpose (32x32 LDS tiles) ----------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int C) {
+    __shared__ float t[32][33];
+    const long long b = blockIdx.z;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int k = ty; k < 32; k += 8)
+        if (r0 + k < R && c0 + tx < C) t[k][tx] = src[(b * R + r0 + k) * C + c0 + tx];
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8)
+        if (c0 + k < C && r0 + tx < R) dst[(b * C + c0 + k) * R + r0 + tx] = t[tx][k];
+}
+extern "C" int hv_transpose_batched(const float* src, float* dst, int B, int R, int C, void* stream) {
+    if (!src || !dst || B <= 0 || R <= 0 || C <= 0) return HV_ERR_ARG;
+    hipLaunchKernelGGL(transpose_kernel, dim3(hv_cdiv(C, 32), hv_cdiv(R, 32), B), dim3(256), 0, (hipStream_t)stream, src, dst, R, C);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+
+// ---- backward of the matching scores -------------------------------------------------------------------
+// Gs[b][i][j] = dS[b][j][i]*rnorm[b][i] + dS[b][i][j]*rnorm[b][j]
+__global__ __launch_bounds__(256) void ca_gs_kernel(const float* __restrict__ dS, const float* __restrict__ rnorm, float* __restrict__ Gs, int L) {
+    __shared__ float t[32][33];
+    const long long b = blockIdx.z;
+    const int j0 = blockIdx.x * 32, i0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* D = dS + b * (long long)L * L;
+    for (int k = ty; k < 32; k += 8) t[k][tx] = D[(long long)(j0 + k) * L + i0 + tx];   // t[jj][ii] = dS[j0+jj][i0+ii]
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int i = i0 + k, j = j0 + tx;
+        Gs[(b * L + i) * L + j] = t[tx][k] * rnorm[b * L + i] + D[(long long)i * L + j] * rnorm[b * L + j];
+    }
+}
+// coef[b][l] = -(sum_p dS[p][l]*S0[p][l]) / norm[l]^2   (0 where the norm was clamped)
+__global__ void ca_coef_kernel(const float* __restrict__ dS, const float* __restrict__ S0, const float* __restrict__ norm, float* __restrict__ coef, int L) {
+    const long long b = blockIdx.y;
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= L) return;
+    const float* D = dS + b * (long long)L * L;
+    const float* S = S0 + b * (long long)L * L;
+    float s = 0.f;
+    for (int p = 0; p < L; ++p) s += D[(long long)p * L + l] * S[(long long)p * L + l];
+    const float nv = norm[b * L + l];
+    coef[b * L + l] = nv > 1e-4f ? -s / (nv * nv) : 0.f;
+}
+extern "C" int hv_ca_score_backward_prep(const float* dS, const float* S0, const float* norm, const float* rnorm, float* Gs, float* coef,
+                                         int B, int L, void* stream) {
+    if (!dS || !S0 || !norm || !rnorm || !Gs || !coef || B <= 0 || L <= 0 || (L & 31)) return HV_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(ca_gs_kernel, dim3(L / 32, L / 32, B), dim3(256), 0, s, dS, rnorm, Gs, L);
+    HV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ca_coef_kernel, dim3(hv_cdiv(L, 128), B), dim3(128), 0, s, dS, S0, norm, coef, L);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+
+// ---- col2im of the patch-matrix gradient, scattered to the even positions of the full map ------------
+__global__ void ca_patches_bwd_kernel(const float* __restrict__ dwp, const float* __restrict__ wp, const float* __restrict__ coef,
+                                      float* __restrict__ df, int H, int W, int C, int df_ld, int acc, long long n) {
+    const int h = H / 2, w = W / 2, L = h * w;
+    AT_LOOP(i, n) {
+        const int c = (int)(i % C);
+        long long r = i / C;
+        const int X = (int)(r % W); r /= W;
+        const int Y = (int)(r % H);
+        const long long b = r / H;
+        float v = 0.f;
+        if (!((X | Y) & 1)) {
+            const int y = Y / 2, x = X / 2;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ly = y - (tap / 3 - 1), lx = x - (tap % 3 - 1);
+                if ((unsigned)ly < (unsigned)h && (unsigned)lx < (unsigned)w) {
+                    const long long l = (long long)ly * w + lx;
+                    const long long o = ((b * L + l) * 9 + tap) * C + c;
+                    v += dwp[o] + coef[b * L + l] * wp[o];
+                }
+            }
+        }
+        float* d = df + ((b * H + Y) * W + X) * df_ld + c;
+        *d = acc ? *d + v : v;
+    }
+}
+extern "C" int hv_ca_patches_backward(const float* dwp, const float* wp, const float* coef, float* df, int B, int H, int W, int C, int df_ld,
+                                      int accumulate, void* stream) {
+    if (!dwp || !wp || !coef || !df || B <= 0 || H <= 0 || W <= 0 || C <= 0 || ((H | W) & 1) || df_ld < C) return HV_ERR_ARG;
+    const long long n = (long long)B * H * W * C;
+    hipLaunchKernelGGL(ca_patches_bwd_kernel, dim3(at_grid(n)), dim3(256), 0, (hipStream_t)stream, dwp, wp, coef, df, H, W, C, df_ld, accumulate, n);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}

@@ -1,0 +1,63 @@
+"""Build libhvgan.so (gfx950) in-tree with hipcc; cross-compiles without a GPU.
+
+    python healthivert-gan_amd/csrc/build.py [--force]
+
+Objects are rebuilt only when their source (or a header) is newer.  The .so lands next to the
+package (healthivert-gan_amd/libhvgan.so) so it travels with the tree to the GPU box.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+ROOT = os.path.dirname(PKG)
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+SOURCES = ['conv_igemm.hip', 'prep.hip', 'norm.hip', 'pointwise.hip', 'attention.hip']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wno-unused-result']
+OUT = os.path.join(PKG, 'libhvgan.so')
+
+
+def _newer(src, dst, deps):
+    if not os.path.exists(dst):
+        return True
+    t = os.path.getmtime(dst)
+    return any(os.path.getmtime(p) > t for p in [src] + deps)
+
+
+def build(force=False, verbose=True):
+    objdir = os.path.join(HERE, 'build')
+    os.makedirs(objdir, exist_ok=True)
+    deps = [os.path.join(HERE, 'hv_common.h'), os.path.join(ROOT, 'include', 'hvgan.h')]
+    jobs = []
+    for s in SOURCES:
+        src, obj = os.path.join(HERE, s), os.path.join(objdir, s.replace('.hip', '.o'))
+        if force or _newer(src, obj, deps):
+            jobs.append((src, obj))
+
+    def cc(job):
+        src, obj = job
+        cmd = [HIPCC] + FLAGS + ['-c', src, '-o', obj]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('hipcc failed for %s:\n%s' % (src, r.stderr[-4000:]))
+        return r.stderr
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(cc, jobs))
+    objs = [os.path.join(objdir, s.replace('.hip', '.o')) for s in SOURCES]
+    if jobs or force or not os.path.exists(OUT):
+        cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('link failed:\n%s' % r.stderr[-4000:])
+    return OUT
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv))

@@ -1,0 +1,665 @@
+// Implicit-GEMM convolution family on MFMA for gfx950 (MI355X).
+//
+//   hv_conv2d        : conv2d and the gather form of conv_transpose2d / data-gradient
+//   hv_conv2d_wgrad  : weight gradient (contraction over pixels, split over pixel chunks)
+//
+// GEMM view (forward):  D[co][pix] = sum_k W[co][k] * X[pix][k],  k = (tap, ci) flattened.
+// One 256-thread workgroup (4 waves) owns a BM(pixels) x BN(channels) tile; per 32-deep K step the
+// input pixels of the current tap(s) are gathered from NHWC global memory (16 B per lane, coalesced
+// along channels), rounded to the compute type and staged in LDS next to the weight tile; each
+// wave then reads 8 contiguous k per lane for its 16x16 MFMA blocks.  Weights are the MFMA A
+// operand (rows = channels) so each lane ends up with 4 consecutive output channels of one pixel
+// and the epilogue (scale, bias, activation, accumulate) stores 16 B per lane.
+//
+// Precision: float -> v_mfma_f32_16x16x4_f32 (exact fp32, the parity mode);
+//            _Float16 -> v_mfma_f32_16x16x32_f16 with fp32 accumulation.
+#include "hv_common.h"
+
+#define HV_MAX_TAPS 25
+#define HV_BK 32
+
+struct ConvCls {
+    int ph, pw, Hc, Wc, ntaps, Ktot, m0, mcount;
+    uint32_t taps[HV_MAX_TAPS];  // dh(int8) | dw(int8)<<8 | widx<<16
+};
+struct ConvK {
+    const float* x; const float* w; const float* bias; const float* scale; float* y;
+    long long w_bs, scale_bs;
+    int B, Hl, Wl, in_shift, Wp, img_stride, x_ld, x_coff, Cin;
+    int Cout, w_row, y_ld, y_coff, Ho, Wo;
+    int bstep, boff, ostep;
+    float alpha; int act, accumulate, vec_store, ncls;
+    ConvCls cls[4];
+};
+
+template <typename T> struct Stage;
+template <> struct Stage<float> {
+    static constexpr int LD = HV_BK + 4;
+    static __device__ __forceinline__ void st4(float* dst, float4 v) { *reinterpret_cast<float4*>(dst) = v; }
+};
+template <> struct Stage<_Float16> {
+    static constexpr int LD = HV_BK + 8;
+    static __device__ __forceinline__ void st4(_Float16* dst, float4 v) {
+        f16x4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+        *reinterpret_cast<f16x4*>(dst) = h;
+    }
+};
+
+template <typename T, int MT, int NT> struct Frags;
+template <int MT, int NT> struct Frags<float, MT, NT> {
+    float4 w[NT][2], x[MT][2];
+    __device__ __forceinline__ void load(const float* Bs, const float* As, int wrow0, int xrow0, int lane) {
+        const int off = (lane & 15) * Stage<float>::LD + (lane >> 4) * 8;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const float* p = Bs + (wrow0 + n * 16) * Stage<float>::LD + off;
+            w[n][0] = *reinterpret_cast<const float4*>(p);
+            w[n][1] = *reinterpret_cast<const float4*>(p + 4);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const float* p = As + (xrow0 + m * 16) * Stage<float>::LD + off;
+            x[m][0] = *reinterpret_cast<const float4*>(p);
+            x[m][1] = *reinterpret_cast<const float4*>(p + 4);
+        }
+    }
+    __device__ __forceinline__ void mma(f32x4 (&acc)[NT][MT]) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                f32x4 a = acc[n][m];
+                a = __builtin_amdgcn_mfma_f32_16x16x4f32(w[n][0].x, x[m][0].x, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x4f32(w[n][0].y, x[m][0].y, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x4f32(w[n][0].z, x[m][0].z, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x4f32(w[n][0].w, x[m][0].w, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x4f32(w[n][1].x, x[m][1].x, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x4f32(w[n][1].y, x[m][1].y, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x4f32(w[n][1].z, x[m][1].z, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x4f32(w[n][1].w, x[m][1].w, a, 0, 0, 0);
+                acc[n][m] = a;
+            }
+    }
+};
+template <int MT, int NT> struct Frags<_Float16, MT, NT> {
+    f16x8 w[NT], x[MT];
+    __device__ __forceinline__ void load(const _Float16* Bs, const _Float16* As, int wrow0, int xrow0, int lane) {
+        const int off = (lane & 15) * Stage<_Float16>::LD + (lane >> 4) * 8;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) w[n] = *reinterpret_cast<const f16x8*>(Bs + (wrow0 + n * 16) * Stage<_Float16>::LD + off);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) x[m] = *reinterpret_cast<const f16x8*>(As + (xrow0 + m * 16) * Stage<_Float16>::LD + off);
+    }
+    __device__ __forceinline__ void mma(f32x4 (&acc)[NT][MT]) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[n], x[m], acc[n][m], 0, 0, 0);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ forward / transposed
+template <typename T, int BM, int BN, int WM, int WN, bool ASC>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
+    constexpr int LD = Stage<T>::LD;
+    constexpr int APASS = BM / 32;                  // 32 rows x 8 chunks of 4 floats per pass
+    constexpr int BPASS = (BN + 31) / 32;
+    constexpr int TMW = BM / WM, TNW = BN / WN;     // per-wave tile
+    constexpr int MT = TMW / 16, NT = TNW / 16;
+    static_assert(WM * WN == 4 && MT >= 1 && NT >= 1, "bad tile");
+    __shared__ __attribute__((aligned(16))) T As[BM * LD];
+    __shared__ __attribute__((aligned(16))) T Bs[BN * LD];
+    __shared__ uint32_t taps_s[32];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int ci = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (i < p.ncls && (int)blockIdx.x >= p.cls[i].m0) ci = i;
+    const ConvCls& C = p.cls[ci];
+    const int ntaps = C.ntaps, Ktot = C.Ktot, Hc = C.Hc, Wc = C.Wc, Mc = C.mcount, ph = C.ph, pw = C.pw;
+    if (tid < ntaps) taps_s[tid] = C.taps[tid];
+    const int m_base = ((int)blockIdx.x - C.m0) * BM;
+    const int n_base = blockIdx.y * BN;
+    const int HWc = Hc * Wc;
+
+    // ---- per-thread gather rows
+    const int chunk = tid & 7, prow = tid >> 3;
+    int a_nb[APASS], a_hw[APASS];   // image base offset, packed (bh<<16)|(bw&0xffff)
+    const int sample0 = m_base / HWc;  // only meaningful for per-sample weights (tile within one image)
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) {
+        const int m = m_base + prow + i * 32;
+        int bh = -20000, bw = -20000, nb = 0;
+        if (m < Mc) {
+            const int n = m / HWc, rem = m - n * HWc;
+            const int ii = rem / Wc, jj = rem - ii * Wc;
+            bh = ii * p.bstep + p.boff;
+            bw = jj * p.bstep + p.boff;
+            nb = n * p.img_stride;
+        }
+        a_nb[i] = nb;
+        a_hw[i] = (int)(((uint32_t)bh << 16) | ((uint32_t)bw & 0xffffu));
+    }
+    const float* wbase = p.w + (p.w_bs ? (long long)sample0 * p.w_bs : 0ll);
+    const int nk = (Ktot + HV_BK - 1) / HV_BK;
+
+    float4 ra[APASS], rb[BPASS];
+    auto gload = [&](int kt) {
+        const int kg = kt * HV_BK + chunk * 4;
+        if (!ASC) {
+            const bool kok = kg < Ktot;
+            int tapi = 0, c = 0, dh = 0, dw = 0, widx = 0;
+            if (kok) {
+                tapi = kg / p.Cin;
+                c = kg - tapi * p.Cin;
+                const uint32_t e = taps_s[tapi];
+                dh = (int)(int8_t)(e & 0xff);
+                dw = (int)(int8_t)((e >> 8) & 0xff);
+                widx = (int)(e >> 16);
+            }
+#pragma unroll
+            for (int i = 0; i < APASS; ++i) {
+                const int hi = (a_hw[i] >> 16) + dh, wi = (int)(int16_t)(a_hw[i] & 0xffff) + dw;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (kok && (unsigned)hi < (unsigned)p.Hl && (unsigned)wi < (unsigned)p.Wl) {
+                    const int off = a_nb[i] + ((hi >> p.in_shift) * p.Wp + (wi >> p.in_shift)) * p.x_ld + p.x_coff + c;
+                    v = *reinterpret_cast<const float4*>(p.x + off);
+                }
+                ra[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < BPASS; ++i) {
+                const int r = prow + i * 32, n = n_base + r;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (kok && r < BN && n < p.Cout) v = *reinterpret_cast<const float4*>(wbase + (long long)n * p.w_row + widx * p.Cin + c);
+                rb[i] = v;
+            }
+        } else {
+            int dh[4], dw[4], wo[4], cc[4];
+            bool kok[4];
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) {
+                const int k = kg + e4;
+                kok[e4] = k < Ktot;
+                const int tapi = kok[e4] ? k / p.Cin : 0;
+                cc[e4] = k - tapi * p.Cin;
+                const uint32_t e = taps_s[tapi];
+                dh[e4] = (int)(int8_t)(e & 0xff);
+                dw[e4] = (int)(int8_t)((e >> 8) & 0xff);
+                wo[e4] = (int)(e >> 16) * p.Cin + cc[e4];
+            }
+#pragma unroll
+            for (int i = 0; i < APASS; ++i) {
+                float v[4];
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    const int hi = (a_hw[i] >> 16) + dh[e4], wi = (int)(int16_t)(a_hw[i] & 0xffff) + dw[e4];
+                    v[e4] = 0.f;
+                    if (kok[e4] && (unsigned)hi < (unsigned)p.Hl && (unsigned)wi < (unsigned)p.Wl)
+                        v[e4] = p.x[a_nb[i] + ((hi >> p.in_shift) * p.Wp + (wi >> p.in_shift)) * p.x_ld + p.x_coff + cc[e4]];
+                }
+                ra[i] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+#pragma unroll
+            for (int i = 0; i < BPASS; ++i) {
+                const int r = prow + i * 32, n = n_base + r;
+                float v[4];
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) v[e4] = (kok[e4] && r < BN && n < p.Cout) ? wbase[(long long)n * p.w_row + wo[e4]] : 0.f;
+                rb[i] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < APASS; ++i) Stage<T>::st4(As + (prow + i * 32) * LD + chunk * 4, ra[i]);
+#pragma unroll
+        for (int i = 0; i < BPASS; ++i) {
+            const int r = prow + i * 32;
+            if (r < BN) Stage<T>::st4(Bs + r * LD + chunk * 4, rb[i]);
+        }
+    };
+
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int wm = wave / WN, wn = wave % WN;
+    __syncthreads();  // taps_s visible
+    if (nk > 0) {
+        gload(0);
+        lstore();
+    }
+    __syncthreads();
+    Frags<T, MT, NT> fr;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) gload(kt + 1);
+        fr.load(Bs, As, wn * TNW, wm * TMW, lane);
+        fr.mma(acc);
+        __syncthreads();
+        if (more) lstore();
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds channels ch0..ch0+3 of pixel (lane & 15)
+    const float* scale = p.scale ? p.scale + (p.scale_bs ? (long long)sample0 * p.scale_bs : 0ll) : nullptr;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int mm = m_base + wm * TMW + m * 16 + (lane & 15);
+        if (mm >= Mc) continue;
+        const int n = mm / HWc, rem = mm - n * HWc;
+        const int ii = rem / Wc, jj = rem - ii * Wc;
+        const int ho = ph + ii * p.ostep, wo = pw + jj * p.ostep;
+        float* yp = p.y + ((long long)(n * p.Ho + ho) * p.Wo + wo) * p.y_ld + p.y_coff;
+#pragma unroll
+        for (int nn = 0; nn < NT; ++nn) {
+            const int ch0 = n_base + wn * TNW + nn * 16 + (lane >> 4) * 4;
+            if (ch0 >= p.Cout) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float t = acc[nn][m][r] * p.alpha;
+                const int ch = ch0 + r;
+                if (ch < p.Cout) {
+                    if (scale) t *= scale[ch];
+                    if (p.bias) t += p.bias[ch];
+                    if (p.accumulate == 2) t += yp[ch];   // pre-activation accumulate (split-K over concatenated inputs)
+                }
+                v[r] = hv_act(t, p.act);
+            }
+            if (p.vec_store && ch0 + 3 < p.Cout) {
+                float4 o = make_float4(v[0], v[1], v[2], v[3]);
+                if (p.accumulate == 1) {
+                    const float4 old = *reinterpret_cast<const float4*>(yp + ch0);
+                    o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+                }
+                *reinterpret_cast<float4*>(yp + ch0) = o;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (ch0 + r < p.Cout) yp[ch0 + r] = p.accumulate == 1 ? yp[ch0 + r] + v[r] : v[r];
+            }
+        }
+    }
+}
+
+template <typename T, int BM, int BN, int WM, int WN, bool ASC>
+static int launch_conv(const ConvK& k, int mtiles, hipStream_t s) {
+    dim3 grid(mtiles, hv_cdiv(k.Cout, BN));
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN, ASC>), grid, dim3(256), 0, s, k);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+
+template <typename T, bool ASC>
+static int dispatch_conv(ConvK& k, hipStream_t s) {
+    // tile choice: BN = smallest tile covering Cout (<=128); BM 256 for narrow outputs, 128 otherwise,
+    // 64 when the launch would not fill the chip.
+    long long M = 0;
+    for (int c = 0; c < k.ncls; ++c) M += k.cls[c].mcount;
+    int BM, BN;
+    if (k.Cout <= 16) { BN = 16; BM = 256; }
+    else if (k.Cout <= 32) { BN = 32; BM = 256; }
+    else if (k.Cout <= 64) { BN = 64; BM = 128; }
+    else { BN = 128; BM = 128; }
+    if (BN >= 64) {
+        long long tiles = ((M + BM - 1) / BM) * ((k.Cout + BN - 1) / BN);
+        if (tiles < 512) { BM = 64; BN = 64; }
+    }
+    if (k.w_bs || k.scale_bs) {  // per-sample operands: a tile must stay inside one image
+        for (int c = 0; c < k.ncls; ++c)
+            if ((k.cls[c].Hc * k.cls[c].Wc) % BM) {
+                if ((k.cls[c].Hc * k.cls[c].Wc) % 64 == 0 && BN >= 64) { BM = 64; BN = 64; }
+                else return HV_ERR_UNSUPPORTED;
+            }
+    }
+    int mt = 0;
+    for (int c = 0; c < k.ncls; ++c) {
+        k.cls[c].m0 = mt;
+        mt += hv_cdiv(k.cls[c].mcount, BM);
+    }
+    if (mt <= 0) return HV_OK;
+    if (BM == 256 && BN == 16) return launch_conv<T, 256, 16, 4, 1, ASC>(k, mt, s);
+    if (BM == 256 && BN == 32) return launch_conv<T, 256, 32, 4, 1, ASC>(k, mt, s);
+    if (BM == 128 && BN == 64) return launch_conv<T, 128, 64, 2, 2, ASC>(k, mt, s);
+    if (BM == 128 && BN == 128) return launch_conv<T, 128, 128, 2, 2, ASC>(k, mt, s);
+    return launch_conv<T, 64, 64, 2, 2, ASC>(k, mt, s);
+}
+
+extern "C" int hv_conv2d(const hv_conv_desc* d, void* stream) {
+    if (!d || !d->x || !d->w || !d->y) return HV_ERR_ARG;
+    if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->KH <= 0 || d->KW <= 0 ||
+        d->stride <= 0 || d->dil <= 0 || d->pad < 0 || d->Ho <= 0 || d->Wo <= 0)
+        return HV_ERR_ARG;
+    if (d->KH * d->KW > HV_MAX_TAPS || d->in_shift < 0 || d->in_shift > 1) return HV_ERR_UNSUPPORTED;
+    if (d->in_shift && ((d->H | d->W) & 1)) return HV_ERR_UNSUPPORTED;
+    if (d->x_ld < d->x_coff + d->Cin || d->y_ld < d->y_coff + d->Cout) return HV_ERR_ARG;
+    if (d->act < HV_ACT_NONE || d->act > HV_ACT_CLAMP) return HV_ERR_ARG;
+    if (d->precision != HV_F32 && d->precision != HV_F16) return HV_ERR_ARG;
+    const int Hp = d->H >> d->in_shift, Wp = d->W >> d->in_shift;
+    if ((long long)d->B * Hp * Wp * d->x_ld >= (1ll << 31) || (long long)d->B * d->Ho * d->Wo * d->y_ld >= (1ll << 31))
+        return HV_ERR_UNSUPPORTED;
+    if (d->H > 16000 || d->W > 16000 || (d->KH - 1) * d->dil > 120 || (d->KW - 1) * d->dil > 120) return HV_ERR_UNSUPPORTED;
+
+    ConvK k;
+    k.x = d->x; k.w = d->w; k.bias = d->bias; k.scale = d->ch_scale; k.y = d->y;
+    k.w_bs = d->w_bstride; k.scale_bs = d->ch_scale ? d->ch_scale_bstride : 0;
+    k.B = d->B; k.Hl = d->H; k.Wl = d->W; k.in_shift = d->in_shift; k.Wp = Wp; k.img_stride = Hp * Wp * d->x_ld;
+    k.x_ld = d->x_ld; k.x_coff = d->x_coff; k.Cin = d->Cin;
+    k.Cout = d->Cout; k.w_row = d->KH * d->KW * d->Cin; k.y_ld = d->y_ld; k.y_coff = d->y_coff; k.Ho = d->Ho; k.Wo = d->Wo;
+    k.alpha = d->alpha; k.act = d->act; k.accumulate = d->accumulate;
+    k.vec_store = ((d->y_ld & 3) == 0 && (d->y_coff & 3) == 0 && ((uintptr_t)d->y & 15) == 0) ? 1 : 0;
+    if (!d->transposed) {
+        const int eh = (d->H + 2 * d->pad - d->dil * (d->KH - 1) - 1) / d->stride + 1;
+        const int ew = (d->W + 2 * d->pad - d->dil * (d->KW - 1) - 1) / d->stride + 1;
+        if (eh != d->Ho || ew != d->Wo) return HV_ERR_ARG;
+        k.ncls = 1; k.bstep = d->stride; k.boff = -d->pad; k.ostep = 1;
+        ConvCls& c = k.cls[0];
+        c.ph = c.pw = 0; c.Hc = d->Ho; c.Wc = d->Wo; c.ntaps = d->KH * d->KW; c.Ktot = c.ntaps * d->Cin;
+        c.mcount = d->B * d->Ho * d->Wo;
+        for (int r = 0; r < d->KH; ++r)
+            for (int s = 0; s < d->KW; ++s) {
+                const int t = r * d->KW + s;
+                c.taps[t] = (uint32_t)(uint8_t)(int8_t)(r * d->dil) | ((uint32_t)(uint8_t)(int8_t)(s * d->dil) << 8) | ((uint32_t)t << 16);
+            }
+    } else {
+        if (d->stride > 2) return HV_ERR_UNSUPPORTED;
+        k.bstep = 1; k.boff = 0; k.ostep = d->stride; k.ncls = 0;
+        for (int ph = 0; ph < d->stride; ++ph)
+            for (int pw = 0; pw < d->stride; ++pw) {
+                ConvCls& c = k.cls[k.ncls];
+                c.ph = ph; c.pw = pw;
+                c.Hc = (d->Ho - ph + d->stride - 1) / d->stride;
+                c.Wc = (d->Wo - pw + d->stride - 1) / d->stride;
+                if (c.Hc <= 0 || c.Wc <= 0) continue;
+                c.ntaps = 0;
+                for (int r = 0; r < d->KH; ++r) {
+                    const int vh = ph + d->pad - r * d->dil;
+                    if (((vh % d->stride) + d->stride) % d->stride) continue;
+                    for (int s = 0; s < d->KW; ++s) {
+                        const int vw = pw + d->pad - s * d->dil;
+                        if (((vw % d->stride) + d->stride) % d->stride) continue;
+                        const int dh = vh / d->stride, dw = vw / d->stride;
+                        if (dh < -127 || dh > 127 || dw < -127 || dw > 127) return HV_ERR_UNSUPPORTED;
+                        c.taps[c.ntaps++] = (uint32_t)(uint8_t)(int8_t)dh | ((uint32_t)(uint8_t)(int8_t)dw << 8) |
+                                            ((uint32_t)(r * d->KW + s) << 16);
+                    }
+                }
+                c.Ktot = c.ntaps * d->Cin;
+                c.mcount = d->B * c.Hc * c.Wc;
+                ++k.ncls;
+            }
+        if (k.ncls == 0) return HV_ERR_ARG;
+    }
+    const bool vec_in = (d->Cin & 3) == 0 && (d->x_ld & 3) == 0 && (d->x_coff & 3) == 0 && ((uintptr_t)d->x & 15) == 0 &&
+                        ((uintptr_t)d->w & 15) == 0 && (d->w_bstride & 3) == 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (d->precision == HV_F32) return vec_in ? dispatch_conv<float, false>(k, s) : dispatch_conv<float, true>(k, s);
+    return vec_in ? dispatch_conv<_Float16, false>(k, s) : dispatch_conv<_Float16, true>(k, s);
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+// D[co][j] = sum_pix G[pix][co] * X[pix(tap_j)][c_j],  j = (tap, ci) flattened.  A workgroup owns a BN x BC tile
+// of dW and one chunk of pixels; every thread stages 8 consecutive pixels x 4 channels per step.
+struct WgradK {
+    const float* x; const float* g; float* out;
+    int B, Hl, Wl, in_shift, Wp, img_stride, x_ld, x_coff, Cin;
+    int Ho, Wo, g_ld, g_coff, Cout;
+    int KW, stride, pad, dil, J /* taps*Cin */, M /* B*Ho*Wo */, chunk;
+    long long slab;  // Cout*J floats per split
+};
+
+template <typename T, int BN, int BC, int WN, int WC>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradK p) {
+    constexpr int KT = 32;                      // pixels per step
+    constexpr bool F16 = sizeof(T) == 2;
+    // fp32: [pixel][ch] (ch contiguous, +4 pad); fp16: [ch][pixel] (pixel contiguous, +8 pad) so that a lane
+    // reads 8 contiguous k (= pixels) for the 16x16x32 MFMA.
+    // fp32 rows are padded so that row stride = 16 (mod 32) banks: the two 16-lane halves of a ds_read_b32
+    // (pixels k and k+1) then hit disjoint banks.
+    constexpr int LDG = F16 ? (KT + 8) : (BN + ((BN % 32 == 16) ? 0 : 16));
+    constexpr int LDX = F16 ? (KT + 8) : (BC + ((BC % 32 == 16) ? 0 : 16));
+    __shared__ __attribute__((aligned(16))) T Gs[F16 ? BN * LDG : KT * LDG];
+    __shared__ __attribute__((aligned(16))) T Xs[F16 ? BC * LDX : KT * LDX];
+    constexpr int TNW = BN / WN, TCW = BC / WC, NT = TNW / 16, CT = TCW / 16;
+    static_assert(WN * WC == 4 && NT >= 1 && CT >= 1, "bad tile");
+    constexpr int GTHREADS = BN;                // (BN/4 channel groups) x 4 pixel runs
+    constexpr int XTHREADS = BC;
+    static_assert(GTHREADS + XTHREADS <= 256 || (GTHREADS <= 256 && XTHREADS <= 256), "tile too wide");
+    constexpr bool TWO_PASS = GTHREADS + XTHREADS > 256;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_base = blockIdx.y * BN, j_base = blockIdx.z * BC;
+    const int pix_begin = blockIdx.x * p.chunk;
+    const int pix_end = min(p.M, pix_begin + p.chunk);
+    const int HWo = p.Ho * p.Wo;
+
+    // role of this thread in staging
+    const bool is_g = TWO_PASS ? true : tid < GTHREADS;
+    const int t2 = TWO_PASS ? tid : (is_g ? tid : tid - GTHREADS);
+    // G role
+    const int g_cg = t2 % (BN / 4), g_run = t2 / (BN / 4);
+    // X role
+    const int x_cg = t2 % (BC / 4), x_run = t2 / (BC / 4);
+    const int jx = j_base + x_cg * 4;
+    const bool jok = jx < p.J;
+    int dh = 0, dw = 0, cx = 0;
+    if (jok) {
+        const int tap = jx / p.Cin;
+        cx = jx - tap * p.Cin;
+        const int r = tap / p.KW, s = tap - r * p.KW;
+        dh = r * p.dil - p.pad;
+        dw = s * p.dil - p.pad;
+    }
+    const int gch = n_base + g_cg * 4;
+    const bool gok = gch < p.Cout;  // Cout % 4 == 0 is guaranteed by the host
+
+    float4 rg[8], rx[8];
+    auto decode = [&](int m, int& n, int& ho, int& wo) {
+        n = m / HWo;
+        const int rem = m - n * HWo;
+        ho = rem / p.Wo;
+        wo = rem - ho * p.Wo;
+    };
+    auto load_g = [&](int pix0, int run) {
+        int m = pix0 + run * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e, ++m) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gok && m < pix_end) v = *reinterpret_cast<const float4*>(p.g + (long long)m * p.g_ld + p.g_coff + gch);
+            rg[e] = v;
+        }
+    };
+    auto load_x = [&](int pix0, int run) {
+        int m = pix0 + run * 8, n, ho, wo;
+        decode(m, n, ho, wo);
+#pragma unroll
+        for (int e = 0; e < 8; ++e, ++m) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int hi = ho * p.stride + dh, wi = wo * p.stride + dw;
+            if (jok && m < pix_end && (unsigned)hi < (unsigned)p.Hl && (unsigned)wi < (unsigned)p.Wl)
+                v = *reinterpret_cast<const float4*>(p.x + n * p.img_stride + ((hi >> p.in_shift) * p.Wp + (wi >> p.in_shift)) * p.x_ld + p.x_coff + cx);
+            rx[e] = v;
+            if (++wo == p.Wo) { wo = 0; if (++ho == p.Ho) { ho = 0; ++n; } }
+        }
+    };
+    auto store = [&](T* dst, int ld, const float4* r, int cg, int run) {
+        if (F16) {
+            // transpose 8 pixels x 4 channels -> 4 rows of 8 halfs
+            const float* f = reinterpret_cast<const float*>(r);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                f16x8 h;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) h[e] = (_Float16)f[e * 4 + c];
+                *reinterpret_cast<f16x8*>(reinterpret_cast<_Float16*>(dst) + (cg * 4 + c) * ld + run * 8) = h;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) *reinterpret_cast<float4*>(reinterpret_cast<float*>(dst) + (run * 8 + e) * ld + cg * 4) = r[e];
+        }
+    };
+
+    f32x4 acc[NT][CT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[n][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int wn = wave / WC, wc = wave % WC;
+
+    for (int pix0 = pix_begin; pix0 < pix_end; pix0 += KT) {
+        if (TWO_PASS) {
+            if (tid < GTHREADS) load_g(pix0, g_run);
+            if (tid < XTHREADS) load_x(pix0, x_run);
+        } else {
+            if (is_g) load_g(pix0, g_run);
+            else if (t2 < XTHREADS) load_x(pix0, x_run);
+        }
+        __syncthreads();  // previous step's MFMA reads done
+        if (TWO_PASS) {
+            if (tid < GTHREADS) store(Gs, LDG, rg, g_cg, g_run);
+            if (tid < XTHREADS) store(Xs, LDX, rx, x_cg, x_run);
+        } else {
+            if (is_g) store(Gs, LDG, rg, g_cg, g_run);
+            else if (t2 < XTHREADS) store(Xs, LDX, rx, x_cg, x_run);
+        }
+        __syncthreads();
+        if (F16) {
+            const _Float16* G16 = reinterpret_cast<const _Float16*>(Gs);
+            const _Float16* X16 = reinterpret_cast<const _Float16*>(Xs);
+            f16x8 a[NT], b[CT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) a[n] = *reinterpret_cast<const f16x8*>(G16 + (wn * TNW + n * 16 + (lane & 15)) * LDG + (lane >> 4) * 8);
+#pragma unroll
+            for (int c = 0; c < CT; ++c) b[c] = *reinterpret_cast<const f16x8*>(X16 + (wc * TCW + c * 16 + (lane & 15)) * LDX + (lane >> 4) * 8);
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int c = 0; c < CT; ++c) acc[n][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[n], b[c], acc[n][c], 0, 0, 0);
+        } else {
+            const float* G32 = reinterpret_cast<const float*>(Gs);
+            const float* X32 = reinterpret_cast<const float*>(Xs);
+#pragma unroll
+            for (int k4 = 0; k4 < KT / 4; ++k4) {
+                const int pk = k4 * 4 + (lane >> 4);
+                float a[NT], b[CT];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) a[n] = G32[pk * LDG + wn * TNW + n * 16 + (lane & 15)];
+#pragma unroll
+                for (int c = 0; c < CT; ++c) b[c] = X32[pk * LDX + wc * TCW + c * 16 + (lane & 15)];
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) acc[n][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[n], b[c], acc[n][c], 0, 0, 0);
+            }
+        }
+    }
+    // D layout: row (= co) = (lane>>4)*4 + r, col (= j) = lane & 15
+    float* out = p.out + (long long)blockIdx.x * p.slab;
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const int j = j_base + wc * TCW + c * 16 + (lane & 15);
+            if (j >= p.J) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = n_base + wn * TNW + n * 16 + (lane >> 4) * 4 + r;
+                if (co < p.Cout) out[(long long)co * p.J + j] = acc[n][c][r];
+            }
+        }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, long long n, int splits, int accumulate) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += slabs[(long long)k * n + i];
+    dw[i] = accumulate ? dw[i] + s : s;
+}
+
+struct WgradPlan { int BN, BC, splits, chunk; };
+static int wgrad_plan(const hv_wgrad_desc* d, WgradPlan* pl) {
+    const int J = d->KH * d->KW * d->Cin;
+    const long long M = (long long)d->B * d->Ho * d->Wo;
+    int BN, BC;
+    if (d->Cout <= 16) { BN = 16; BC = 128; }
+    else if (d->Cout <= 32) { BN = 32; BC = 128; }
+    else if (d->Cout <= 64) { BN = 64; BC = 64; }
+    else { BN = 128; BC = 64; }
+    const long long tiles = (long long)hv_cdiv(d->Cout, BN) * hv_cdiv(J, BC);
+    long long want = (1536 + tiles - 1) / tiles;          // aim for ~6 workgroups per CU
+    long long maxs = (M + 255) / 256;                     // at least 256 pixels per split
+    long long splits = want < 1 ? 1 : want;
+    if (splits > maxs) splits = maxs;
+    if (splits < 1) splits = 1;
+    long long chunk = (M + splits - 1) / splits;
+    chunk = (chunk + 31) / 32 * 32;
+    splits = (M + chunk - 1) / chunk;
+    pl->BN = BN; pl->BC = BC; pl->splits = (int)splits; pl->chunk = (int)chunk;
+    return HV_OK;
+}
+
+static int wgrad_validate(const hv_wgrad_desc* d) {
+    if (!d || !d->x || !d->g || !d->dw) return HV_ERR_ARG;
+    if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->KH <= 0 || d->KW <= 0 || d->stride <= 0 ||
+        d->dil <= 0 || d->pad < 0 || d->Ho <= 0 || d->Wo <= 0)
+        return HV_ERR_ARG;
+    if ((d->Cin & 3) || (d->Cout & 3) || (d->x_ld & 3) || (d->x_coff & 3) || (d->g_ld & 3) || (d->g_coff & 3)) return HV_ERR_UNSUPPORTED;
+    if (((uintptr_t)d->x & 15) || ((uintptr_t)d->g & 15)) return HV_ERR_UNSUPPORTED;
+    if (d->in_shift < 0 || d->in_shift > 1) return HV_ERR_UNSUPPORTED;
+    if (d->precision != HV_F32 && d->precision != HV_F16) return HV_ERR_ARG;
+    const int Hp = d->H >> d->in_shift, Wp = d->W >> d->in_shift;
+    if ((long long)d->B * Hp * Wp * d->x_ld >= (1ll << 31) || (long long)d->B * d->Ho * d->Wo * d->g_ld >= (1ll << 31)) return HV_ERR_UNSUPPORTED;
+    return HV_OK;
+}
+
+extern "C" size_t hv_conv2d_wgrad_workspace_bytes(const hv_wgrad_desc* d) {
+    if (wgrad_validate(d) != HV_OK) return 0;
+    WgradPlan pl;
+    wgrad_plan(d, &pl);
+    if (pl.splits <= 1 && !d->accumulate) return 0;
+    return (size_t)pl.splits * d->Cout * d->KH * d->KW * d->Cin * sizeof(float);
+}
+
+template <typename T>
+static int launch_wgrad(const WgradK& k, const WgradPlan& pl, hipStream_t s) {
+    dim3 grid(pl.splits, hv_cdiv(k.Cout, pl.BN), hv_cdiv(k.J, pl.BC));
+    if (pl.BN == 16) hipLaunchKernelGGL((wgrad_kernel<T, 16, 128, 1, 4>), grid, dim3(256), 0, s, k);
+    else if (pl.BN == 32) hipLaunchKernelGGL((wgrad_kernel<T, 32, 128, 1, 4>), grid, dim3(256), 0, s, k);
+    else if (pl.BN == 64) hipLaunchKernelGGL((wgrad_kernel<T, 64, 64, 2, 2>), grid, dim3(256), 0, s, k);
+    else hipLaunchKernelGGL((wgrad_kernel<T, 128, 64, 2, 2>), grid, dim3(256), 0, s, k);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+
+extern "C" int hv_conv2d_wgrad(const hv_wgrad_desc* d, void* stream) {
+    int rc = wgrad_validate(d);
+    if (rc != HV_OK) return rc;
+    WgradPlan pl;
+    wgrad_plan(d, &pl);
+    const long long nW = (long long)d->Cout * d->KH * d->KW * d->Cin;
+    const bool direct = pl.splits <= 1 && !d->accumulate;
+    if (!direct) {
+        if (!d->workspace || d->workspace_bytes < (size_t)pl.splits * nW * sizeof(float)) return HV_ERR_WORKSPACE;
+    }
+    WgradK k;
+    k.x = d->x; k.g = d->g; k.out = direct ? d->dw : d->workspace;
+    k.B = d->B; k.Hl = d->H; k.Wl = d->W; k.in_shift = d->in_shift; k.Wp = d->W >> d->in_shift;
+    k.img_stride = (d->H >> d->in_shift) * k.Wp * d->x_ld; k.x_ld = d->x_ld; k.x_coff = d->x_coff; k.Cin = d->Cin;
+    k.Ho = d->Ho; k.Wo = d->Wo; k.g_ld = d->g_ld; k.g_coff = d->g_coff; k.Cout = d->Cout;
+    k.KW = d->KW; k.stride = d->stride; k.pad = d->pad; k.dil = d->dil; k.J = d->KH * d->KW * d->Cin;
+    k.M = d->B * d->Ho * d->Wo; k.chunk = pl.chunk; k.slab = nW;
+    hipStream_t s = (hipStream_t)stream;
+    rc = d->precision == HV_F32 ? launch_wgrad<float>(k, pl, s) : launch_wgrad<_Float16>(k, pl, s);
+    if (rc != HV_OK) return rc;
+    if (!direct) {
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(hv_cdiv(nW, 256)), dim3(256), 0, s, d->workspace, d->dw, nW, pl.splits, d->accumulate);
+        HV_LAUNCH_CHECK();
+    }
+    return HV_OK;
+}

@@ -1,0 +1,453 @@
+// HBM-bound operators around the convolutions: layout changes, channel copies with nearest
+// resampling, generator input assembly, pooled height head, Sobel, SHRM compositing, losses and
+// their gradient seeds.  One pass over the data each, 16 B per lane where the layout allows.
+#include "hv_common.h"
+
+static int pw_grid(long long n, int cap = 8192) { long long b = (n + 255) / 256; return (int)(b > cap ? cap : (b < 1 ? 1 : b)); }
+#define PW_LOOP(i, n) for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long long)gridDim.x * blockDim.x)
+
+// ------------------------------------------------------------------------------------------------ layout
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int HW, int dst_ld, int dst_coff, long long n) {
+    PW_LOOP(i, n) {  // i over dst order (b, p, c)
+        const int c = (int)(i % C);
+        const long long bp = i / C;
+        const long long b = bp / HW, p = bp - b * HW;
+        dst[bp * dst_ld + dst_coff + c] = src[(b * C + c) * HW + p];
+    }
+}
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int HW, int src_ld, int src_coff, int acc, long long n) {
+    PW_LOOP(i, n) {  // i over dst order (b, c, p)
+        const long long p = i % HW;
+        const long long bc = i / HW;
+        const long long b = bc / C;
+        const int c = (int)(bc - b * C);
+        const float v = src[(b * HW + p) * src_ld + src_coff + c];
+        dst[i] = acc ? dst[i] + v : v;
+    }
+}
+extern "C" int hv_nchw_to_nhwc(const float* src, float* dst, int B, int C, int H, int W, int dst_ld, int dst_coff, void* stream) {
+    if (!src || !dst || B <= 0 || C <= 0 || H <= 0 || W <= 0 || dst_ld < dst_coff + C) return HV_ERR_ARG;
+    const long long n = (long long)B * C * H * W;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(pw_grid(n)), dim3(256), 0, (hipStream_t)stream, src, dst, C, H * W, dst_ld, dst_coff, n);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+extern "C" int hv_nhwc_to_nchw(const float* src, float* dst, int B, int C, int H, int W, int src_ld, int src_coff, int accumulate, void* stream) {
+    if (!src || !dst || B <= 0 || C <= 0 || H <= 0 || W <= 0 || src_ld < src_coff + C) return HV_ERR_ARG;
+    const long long n = (long long)B * C * H * W;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(pw_grid(n)), dim3(256), 0, (hipStream_t)stream, src, dst, C, H * W, src_ld, src_coff, accumulate, n);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+
+// mode 0 same size; 1 src half size (nearest x2 up); 2 src double size (nearest x1/2: even indices);
+// 3 dst(half) (+)= sum of the 2x2 block of src(full)  [adjoint of 1];  4 dst(full) (+)= src(half) at even idx else 0 [adjoint of 2]
+template <int V>
+__global__ void copy_channels_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int W, int C, int src_ld, int src_coff,
+                                     int dst_ld, int dst_coff, int mode, int acc, long long n) {
+    const int CV = C / V;
+    PW_LOOP(i, n) {
+        const int cg = (int)(i % CV);
+        long long r = i / CV;
+        const int w = (int)(r % W); r /= W;
+        const int h = (int)(r % H);
+        const long long b = r / H;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        auto rd = [&](long long pix) {
+            const float* s = src + pix * src_ld + src_coff + cg * V;
+            if (V == 4) { const float4 t = *reinterpret_cast<const float4*>(s); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+            else v[0] += s[0];
+        };
+        if (mode == 0) rd((b * H + h) * W + w);
+        else if (mode == 1) rd((b * (H >> 1) + (h >> 1)) * (W >> 1) + (w >> 1));
+        else if (mode == 2) rd((b * (H * 2) + 2 * h) * (W * 2) + 2 * w);
+        else if (mode == 3) {
+            const long long p = (b * (H * 2) + 2 * h) * (W * 2) + 2 * w;
+            rd(p); rd(p + 1); rd(p + 2 * W); rd(p + 2 * W + 1);
+        } else {
+            if (!((h | w) & 1)) rd((b * (H >> 1) + (h >> 1)) * (W >> 1) + (w >> 1));
+        }
+        float* d = dst + ((b * H + h) * W + w) * dst_ld + dst_coff + cg * V;
+        if (V == 4) {
+            float4 o = make_float4(v[0], v[1], v[2], v[3]);
+            if (acc) { const float4 t = *reinterpret_cast<float4*>(d); o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
+            *reinterpret_cast<float4*>(d) = o;
+        } else {
+            d[0] = acc ? d[0] + v[0] : v[0];
+        }
+    }
+}
+extern "C" int hv_copy_channels(const float* src, float* dst, int B, int H, int W, int C, int src_ld, int src_coff, int dst_ld,
+                                int dst_coff, int mode, int accumulate, void* stream) {
+    if (!src || !dst || B <= 0 || H <= 0 || W <= 0 || C <= 0 || mode < 0 || mode > 4) return HV_ERR_ARG;
+    if (src_ld < src_coff + C || dst_ld < dst_coff + C) return HV_ERR_ARG;
+    if ((mode == 1 || mode == 4) && ((H | W) & 1)) return HV_ERR_UNSUPPORTED;
+    const bool vec = !(C & 3) && !(src_ld & 3) && !(src_coff & 3) && !(dst_ld & 3) && !(dst_coff & 3) && !((uintptr_t)src & 15) && !((uintptr_t)dst & 15);
+    const long long n = (long long)B * H * W * (vec ? C / 4 : C);
+    if (vec) hipLaunchKernelGGL((copy_channels_kernel<4>), dim3(pw_grid(n)), dim3(256), 0, (hipStream_t)stream, src, dst, H, W, C, src_ld, src_coff, dst_ld, dst_coff, mode, accumulate, n);
+    else hipLaunchKernelGGL((copy_channels_kernel<1>), dim3(pw_grid(n)), dim3(256), 0, (hipStream_t)stream, src, dst, H, W, C, src_ld, src_coff, dst_ld, dst_coff, mode, accumulate, n);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ generator input
+__global__ void gen_input_kernel(const float* __restrict__ x, const float* __restrict__ seg, const float* __restrict__ mask,
+                                 const double* __restrict__ ratio, float* __restrict__ dst, int HW, int CP, int order, long long n) {
+    PW_LOOP(i, n) {
+        const long long b = i / HW;
+        const float r = (float)ratio[b];
+        float* d = dst + i * CP;
+        float c0 = x[i], c1, c2, c3 = 0.f;
+        if (order == 0) { c1 = r; c2 = mask[i]; }
+        else { c1 = seg[i]; c2 = mask[i]; c3 = r; }
+        *reinterpret_cast<float4*>(d) = make_float4(c0, c1, c2, c3);
+        for (int c = 4; c < CP; ++c) d[c] = 0.f;
+    }
+}
+extern "C" int hv_gen_input(const float* x, const float* seg, const float* mask, const double* slice_ratio, float* dst, int B, int H,
+                            int W, int CP, int order, void* stream) {
+    if (!x || !mask || !slice_ratio || !dst || B <= 0 || H <= 0 || W <= 0 || CP < 4 || (CP & 3) || (order == 1 && !seg)) return HV_ERR_ARG;
+    const long long n = (long long)B * H * W;
+    hipLaunchKernelGGL(gen_input_kernel, dim3(pw_grid(n)), dim3(256), 0, (hipStream_t)stream, x, seg, mask, slice_ratio, dst, H * W, CP, order, n);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ pooled height head
+#define GAP_CHUNKS 32
+__global__ __launch_bounds__(256) void gap_partial_kernel(const float* __restrict__ x, int HW, int C, int x_ld, float* __restrict__ part) {
+    __shared__ float sh[256];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int c = tid % C, rp = tid / C, rstep = 256 / C;
+    const int rows = (HW + GAP_CHUNKS - 1) / GAP_CHUNKS;
+    const int r0 = blockIdx.x * rows, r1 = min(HW, r0 + rows);
+    float s = 0.f;
+    for (int r = r0 + rp; r < r1; r += rstep) s += x[((long long)b * HW + r) * x_ld + c];
+    sh[tid] = s;
+    __syncthreads();
+    if (tid < C) {
+        float t = 0.f;
+        for (int k = tid; k < 256; k += C) t += sh[k];
+        part[((long long)b * GAP_CHUNKS + blockIdx.x) * C + tid] = t;
+    }
+}
+__global__ void gap_fc_kernel(const float* __restrict__ part, int HW, int C, const float* __restrict__ w, const float* __restrict__ bias,
+                              float* __restrict__ pooled, float* __restrict__ pred) {
+    __shared__ float red[20];
+    const int b = blockIdx.x, c = threadIdx.x;
+    float t = 0.f;
+    if (c < C) {
+        for (int k = 0; k < GAP_CHUNKS; ++k) t += part[((long long)b * GAP_CHUNKS + k) * C + c];
+        t /= (float)HW;
+        pooled[(long long)b * C + c] = t;
+        t *= w[c];
+    }
+    const float s = hv_block_sum(t, red);
+    if (c == 0) pred[b] = 1.f / (1.f + expf(-(s + bias[0])));
+}
+extern "C" size_t hv_gap_fc_workspace_bytes(int B, int C) { return (size_t)B * GAP_CHUNKS * C * sizeof(float); }
+extern "C" int hv_gap_fc_sigmoid(const float* x, int B, int HW, int C, int x_ld, const float* fc_w, const float* fc_b, float* pooled,
+                                 float* pred, float* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !fc_w || !fc_b || !pooled || !pred || B <= 0 || HW <= 0 || C <= 0 || x_ld < C) return HV_ERR_ARG;
+    if (C > 256 || (C & (C - 1))) return HV_ERR_UNSUPPORTED;
+    if (!workspace || workspace_bytes < hv_gap_fc_workspace_bytes(B, C)) return HV_ERR_WORKSPACE;
+    hipLaunchKernelGGL(gap_partial_kernel, dim3(GAP_CHUNKS, B), dim3(256), 0, (hipStream_t)stream, x, HW, C, x_ld, workspace);
+    HV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gap_fc_kernel, dim3(B), dim3(C < 64 ? 64 : C), 0, (hipStream_t)stream, workspace, HW, C, fc_w, fc_b, pooled, pred);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+__global__ void gap_bwd_dx_kernel(const float* __restrict__ dpred, const float* __restrict__ pred, const float* __restrict__ w, float* __restrict__ dx,
+                                  int HW, int C, int dx_ld, long long n) {
+    PW_LOOP(i, n) {
+        const int c = (int)(i % C);
+        const long long bp = i / C;
+        const long long b = bp / HW;
+        const float p = pred[b];
+        dx[bp * dx_ld + c] += dpred[b] * p * (1.f - p) * w[c] / (float)HW;
+    }
+}
+__global__ void gap_bwd_param_kernel(const float* __restrict__ dpred, const float* __restrict__ pred, const float* __restrict__ pooled, int B, int C,
+                                     float* dw, float* db, int acc) {
+    const int c = threadIdx.x;
+    float sw = 0.f, sb = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float p = pred[b], dl = dpred[b] * p * (1.f - p);
+        sb += dl;
+        if (c < C) sw += dl * pooled[(long long)b * C + c];
+    }
+    if (c < C) dw[c] = acc ? dw[c] + sw : sw;
+    if (c == 0) db[0] = acc ? db[0] + sb : sb;
+}
+extern "C" int hv_gap_fc_sigmoid_backward(const float* dpred, const float* pred, const float* pooled, const float* fc_w, float* dx, int B,
+                                          int HW, int C, int dx_ld, float* dw, float* db, int accumulate, void* stream) {
+    if (!dpred || !pred || !pooled || !fc_w || !dx || !dw || !db || B <= 0 || HW <= 0 || C <= 0 || C > 1024) return HV_ERR_ARG;
+    const long long n = (long long)B * HW * C;
+    hipLaunchKernelGGL(gap_bwd_dx_kernel, dim3(pw_grid(n)), dim3(256), 0, (hipStream_t)stream, dpred, pred, fc_w, dx, HW, C, dx_ld, n);
+    HV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gap_bwd_param_kernel, dim3(1), dim3(C < 64 ? 64 : C), 0, (hipStream_t)stream, dpred, pred, pooled, B, C, dw, db, accumulate);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ Sobel
+__global__ void sobel_kernel(const float* __restrict__ img, float* __restrict__ out, int H, int W, long long n) {
+    PW_LOOP(i, n) {
+        const int w = (int)(i % W);
+        const long long r = i / W;
+        const int h = (int)(r % H);
+        const float* p = img + (r - h) * W;  // image base
+        const int hm = max(h - 1, 0), hp = min(h + 1, H - 1), wm = max(w - 1, 0), wp = min(w + 1, W - 1);
+        const float a = p[hm * W + wm], b = p[hm * W + w], c = p[hm * W + wp];
+        const float d = p[h * W + wm], f = p[h * W + wp];
+        const float g = p[hp * W + wm], hh = p[hp * W + w], k = p[hp * W + wp];
+        const float gx = (c - a) + 2.f * (f - d) + (k - g);
+        const float gy = (a + 2.f * b + c) - (g + 2.f * hh + k);
+        out[i] = fminf(sqrtf(gx * gx + gy * gy), 1.f);
+    }
+}
+extern "C" int hv_sobel(const float* img, float* out, int B, int H, int W, void* stream) {
+    if (!img || !out || B <= 0 || H <= 0 || W <= 0) return HV_ERR_ARG;
+    const long long n = (long long)B * H * W;
+    hipLaunchKernelGGL(sobel_kernel, dim3(pw_grid(n)), dim3(256), 0, (hipStream_t)stream, img, out, H, W, n);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ SHRM compositing
+struct Rows { int xu, xb, sh; };
+__device__ __forceinline__ Rows shrm_rows(float pred_scaled, long long height, long long x1) {
+    long long h = (long long)ceilf(pred_scaled);
+    if (h < height) h = height;
+    const long long d = h - height;
+    Rows r;
+    r.sh = (int)(d / 2);
+    r.xu = (int)(x1 - d / 2);
+    r.xb = r.xu + (int)h;
+    return r;
+}
+__device__ __forceinline__ float shrm_pick(const float* gen_img, const float* real_img, int row, int col, int W, const Rows& r, int x2) {
+    if (row < r.xu) return real_img[(row + r.sh) * W + col];
+    if (row < r.xb) return gen_img[row * W + col];
+    return real_img[(x2 + row - r.xb) * W + col];
+}
+
+__global__ void post_generator_kernel(const hv_postg_desc d, long long n) {
+    const int HW = d.H * d.W, c0 = d.W / 2 - d.half_band, c1 = d.W / 2 + d.half_band;
+    PW_LOOP(i, n) {
+        const int b = (int)(i / HW), p = (int)(i - (long long)b * HW);
+        const int row = p / d.W, col = p - row * d.W;
+        const float mh = (float)d.maxheight[b];
+        const float p1 = d.pred1[b] * mh, p2 = d.pred2[b] * mh;
+        const Rows r2 = shrm_rows(p2, d.height[b], d.x1[b]), r1 = shrm_rows(p1, d.height[b], d.x1[b]);
+        const int x2 = (int)d.x2[b];
+        const float* real = d.real_B + (long long)b * HW;
+        const float fb = shrm_pick(d.x_stage2 + (long long)b * HW, real, row, col, d.W, r2, x2);
+        const float fc = shrm_pick(d.x_stage1 + (long long)b * HW, real, row, col, d.W, r1, x2);
+        d.fake_B[i] = fb;
+        d.fake_B_coarse[i] = fc;
+        const float band = (col >= c0 && col < c1) ? 1.f : 0.f;
+        const float m = d.mask[i];
+        d.fake_B_local[i] = m * fb * band;
+        d.real_B_local[i] = m * real[p] * band;
+        d.fine_bin[i] = d.fine_seg[i] > 0.5f ? 1.f : 0.f;
+        d.coarse_bin[i] = d.coarse_seg[i] > 0.5f ? 1.f : 0.f;
+        if (p == 0) {
+            d.pred1_h[b] = p1;
+            d.pred2_h[b] = p2;
+            d.rows[b * 4 + 0] = r2.xu; d.rows[b * 4 + 1] = r2.xb; d.rows[b * 4 + 2] = r1.xu; d.rows[b * 4 + 3] = r1.xb;
+        }
+    }
+}
+extern "C" int hv_post_generator(const hv_postg_desc* d, void* stream) {
+    if (!d || !d->real_B || !d->mask || !d->x_stage1 || !d->x_stage2 || !d->fine_seg || !d->coarse_seg || !d->pred1 || !d->pred2 ||
+        !d->height || !d->x1 || !d->x2 || !d->maxheight || !d->fake_B || !d->fake_B_coarse || !d->fake_B_local || !d->real_B_local ||
+        !d->fine_bin || !d->coarse_bin || !d->pred1_h || !d->pred2_h || !d->rows || d->B <= 0 || d->H <= 0 || d->W <= 0)
+        return HV_ERR_ARG;
+    const long long n = (long long)d->B * d->H * d->W;
+    hipLaunchKernelGGL(post_generator_kernel, dim3(pw_grid(n)), dim3(256), 0, (hipStream_t)stream, *d, n);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+
+__global__ void shrm_composite_kernel(const float* __restrict__ gen, const float* __restrict__ real, const float* __restrict__ pred_scaled,
+                                      const long long* __restrict__ height, const long long* __restrict__ x1, const long long* __restrict__ x2,
+                                      float* __restrict__ out, int* rows, int H, int W, long long n) {
+    const int HW = H * W;
+    PW_LOOP(i, n) {
+        const int b = (int)(i / HW), p = (int)(i - (long long)b * HW);
+        const int row = p / W, col = p - row * W;
+        const Rows r = shrm_rows(pred_scaled[b], height[b], x1[b]);
+        out[i] = shrm_pick(gen + (long long)b * HW, real + (long long)b * HW, row, col, W, r, (int)x2[b]);
+        if (p == 0 && rows) { rows[b * 2] = r.xu; rows[b * 2 + 1] = r.xb; }
+    }
+}
+extern "C" int hv_shrm_composite(const float* gen, const float* real, const float* pred_scaled, const long long* height, const long long* x1,
+                                 const long long* x2, float* out, int* rows, int B, int H, int W, void* stream) {
+    if (!gen || !real || !pred_scaled || !height || !x1 || !x2 || !out || B <= 0 || H <= 0 || W <= 0) return HV_ERR_ARG;
+    const long long n = (long long)B * H * W;
+    hipLaunchKernelGGL(shrm_composite_kernel, dim3(pw_grid(n)), dim3(256), 0, (hipStream_t)stream, gen, real, pred_scaled, height, x1, x2, out, rows, H, W, n);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+
+__global__ void shrm_backward_kernel(const float* __restrict__ d_fake, const float* __restrict__ d_local, const float* __restrict__ mask,
+                                     const int* __restrict__ rows, int which, float* __restrict__ d_gen, int H, int W, int half_band, int acc, long long n) {
+    const int HW = H * W, c0 = W / 2 - half_band, c1 = W / 2 + half_band;
+    PW_LOOP(i, n) {
+        const int b = (int)(i / HW), p = (int)(i - (long long)b * HW);
+        const int row = p / W, col = p - row * W;
+        const int xu = rows[b * 4 + which * 2], xb = rows[b * 4 + which * 2 + 1];
+        float g = 0.f;
+        if (row >= xu && row < xb) {
+            g = d_fake ? d_fake[i] : 0.f;
+            if (d_local && col >= c0 && col < c1) g += d_local[i] * mask[i];
+        }
+        d_gen[i] = acc ? d_gen[i] + g : g;
+    }
+}
+extern "C" int hv_shrm_backward(const float* d_fake, const float* d_local, const float* mask, const int* rows, int which, float* d_gen,
+                                int B, int H, int W, int half_band, int accumulate, void* stream) {
+    if (!rows || !d_gen || (d_local && !mask) || which < 0 || which > 1 || B <= 0 || H <= 0 || W <= 0) return HV_ERR_ARG;
+    const long long n = (long long)B * H * W;
+    hipLaunchKernelGGL(shrm_backward_kernel, dim3(pw_grid(n)), dim3(256), 0, (hipStream_t)stream, d_fake, d_local, mask, rows, which, d_gen, H, W, half_band, accumulate, n);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ GAN loss (PatchGAN logits, small n)
+__global__ __launch_bounds__(1024) void gan_loss_kernel(const float* __restrict__ z, long long n, float t, int mode, float lw, float* loss, int lacc,
+                                                        float gw, float* __restrict__ dz) {
+    __shared__ float red[20];
+    float s = 0.f;
+    for (long long i = threadIdx.x; i < n; i += 1024) {
+        const float v = z[i];
+        float l, g;
+        if (mode == 0) {
+            l = fmaxf(v, 0.f) - v * t + log1pf(expf(-fabsf(v)));
+            g = 1.f / (1.f + expf(-v)) - t;
+        } else {
+            l = (v - t) * (v - t);
+            g = 2.f * (v - t);
+        }
+        s += l;
+        if (dz) dz[i] = gw * g / (float)n;
+    }
+    s = hv_block_sum(s, red);
+    if (threadIdx.x == 0 && loss) {
+        const float v = lw * s / (float)n;
+        loss[0] = lacc ? loss[0] + v : v;
+    }
+}
+extern "C" int hv_gan_loss(const float* z, long long n, int target_is_real, int mode, float loss_weight, float* loss, int loss_accumulate,
+                           float grad_weight, float* dz, void* stream) {
+    if (!z || n <= 0 || mode < 0 || mode > 1) return HV_ERR_ARG;
+    hipLaunchKernelGGL(gan_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, z, n, target_is_real ? 1.f : 0.f, mode, loss_weight, loss,
+                       loss_accumulate, grad_weight, dz);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ generator losses
+#define GL_CHUNKS 32
+#define GL_NQ 10   // S1,S2,cnt,tpf,spf,sgf,tpc,spc,sgc,E
+__global__ __launch_bounds__(256) void gloss_partial_kernel(const hv_gloss_desc d, double* __restrict__ part) {
+    __shared__ double sh[4][GL_NQ];
+    const int b = blockIdx.y, HW = d.H * d.W, tid = threadIdx.x;
+    const int per = (HW + GL_CHUNKS - 1) / GL_CHUNKS;
+    const int p0 = blockIdx.x * per, p1 = min(HW, p0 + per);
+    float q[GL_NQ];
+#pragma unroll
+    for (int k = 0; k < GL_NQ; ++k) q[k] = 0.f;
+    for (int p = p0 + tid; p < p1; p += 256) {
+        const long long i = (long long)b * HW + p;
+        const float rb = d.real_B[i];
+        q[0] += fabsf(d.fake_B[i] - rb);
+        q[1] += fabsf(d.fake_B_coarse[i] - rb);
+        q[2] += d.mask[i] != 0.f ? 1.f : 0.f;
+        const float pf = d.fine_seg[i], gf = d.real_B_mask[i], pc = d.coarse_seg[i], gc = d.normal_vert[i];
+        q[3] += gf * pf; q[4] += pf; q[5] += gf;
+        q[6] += gc * pc; q[7] += pc; q[8] += gc;
+        const float e = d.fake_edges[i] - d.real_edges[i];
+        q[9] += e * e;
+    }
+#pragma unroll
+    for (int k = 0; k < GL_NQ; ++k) {
+        const float s = hv_wave_sum(q[k]);
+        if ((tid & 63) == 0) sh[tid >> 6][k] = (double)s;
+    }
+    __syncthreads();
+    if (tid < GL_NQ) part[((long long)b * GL_CHUNKS + blockIdx.x) * GL_NQ + tid] = sh[0][tid] + sh[1][tid] + sh[2][tid] + sh[3][tid];
+}
+// coef layout (floats): [0] coefL1; [1+4b..] per sample {fine: A=(sp+sg+eps), T=(2tp+eps); coarse: A, T}
+__global__ void gloss_finalize_kernel(const hv_gloss_desc d, const double* __restrict__ part, float* __restrict__ coef) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int B = d.B;
+    const double N = (double)B * d.H * d.W, eps = 1e-5;
+    double S1 = 0, S2 = 0, cnt = 0, E = 0, dice_f = 0, dice_c = 0;
+    for (int b = 0; b < B; ++b) {
+        double q[GL_NQ];
+        for (int k = 0; k < GL_NQ; ++k) q[k] = 0;
+        for (int c = 0; c < GL_CHUNKS; ++c)
+            for (int k = 0; k < GL_NQ; ++k) q[k] += part[((long long)b * GL_CHUNKS + c) * GL_NQ + k];
+        S1 += q[0]; S2 += q[1]; cnt += q[2]; E += q[9];
+        const double Af = q[4] + q[5] + eps, Tf = 2 * q[3] + eps, Ac = q[7] + q[8] + eps, Tc = 2 * q[6] + eps;
+        dice_f += Tf / Af;
+        dice_c += Tc / Ac;
+        coef[1 + 4 * b + 0] = (float)Af; coef[1 + 4 * b + 1] = (float)Tf; coef[1 + 4 * b + 2] = (float)Ac; coef[1 + 4 * b + 3] = (float)Tc;
+    }
+    const double scale = 0.5 * d.lambda_L1 * ((double)d.W * d.W / cnt) * 2.0;
+    const float l1 = (float)((S1 / N + S2 / N) * scale);
+    coef[0] = (float)(scale / N);
+    const float ldice = (float)((1.0 - dice_f / B) * 15.0), lcd = (float)((1.0 - dice_c / B) * 10.0);
+    const float ledge = (float)(E / N * 800.0);
+    double hsum = 0;
+    for (int b = 0; b < B; ++b) {
+        const float h = (float)d.height[b], mh = (float)d.maxheight[b];
+        const float a1 = d.pred1_h[b] - h, a2 = d.pred2_h[b] - h;
+        hsum += (double)(fabsf(a1) / h * 40.f + fabsf(a2) / h * 40.f);
+        const float s1 = a1 > 0.f ? 1.f : (a1 < 0.f ? -1.f : 0.f), s2 = a2 > 0.f ? 1.f : (a2 < 0.f ? -1.f : 0.f);
+        if (d.d_pred1) d.d_pred1[b] = 40.f * s1 / h * mh / (float)B;
+        if (d.d_pred2) d.d_pred2[b] = 40.f * s2 / h * mh / (float)B;
+    }
+    const float lh = (float)(hsum / B);
+    d.losses[0] = l1; d.losses[1] = ldice; d.losses[2] = lcd; d.losses[3] = ledge; d.losses[4] = lh;
+    d.losses[5] = l1 + ldice + lcd + ledge + lh;
+}
+__global__ void gloss_seed_kernel(const hv_gloss_desc d, const float* __restrict__ coef, long long n) {
+    const int HW = d.H * d.W;
+    const float cl1 = coef[0], invB = 1.f / (float)d.B;
+    PW_LOOP(i, n) {
+        const int b = (int)(i / HW);
+        const float rb = d.real_B[i];
+        const float e1 = d.fake_B[i] - rb, e2 = d.fake_B_coarse[i] - rb;
+        d.d_fake_B[i] = cl1 * (e1 > 0.f ? 1.f : (e1 < 0.f ? -1.f : 0.f));
+        d.d_fake_B_coarse[i] = cl1 * (e2 > 0.f ? 1.f : (e2 < 0.f ? -1.f : 0.f));
+        const float Af = coef[1 + 4 * b], Tf = coef[2 + 4 * b], Ac = coef[3 + 4 * b], Tc = coef[4 + 4 * b];
+        d.d_fine_seg[i] = -15.f * invB * (2.f * d.real_B_mask[i] * Af - Tf) / (Af * Af);
+        d.d_coarse_seg[i] = -10.f * invB * (2.f * d.normal_vert[i] * Ac - Tc) / (Ac * Ac);
+    }
+}
+extern "C" size_t hv_generator_losses_workspace_bytes(int B) {
+    return (size_t)B * GL_CHUNKS * GL_NQ * sizeof(double) + (size_t)(1 + 4 * B) * sizeof(float) + 64;
+}
+extern "C" int hv_generator_losses(const hv_gloss_desc* d, void* stream) {
+    if (!d || !d->fake_B || !d->fake_B_coarse || !d->real_B || !d->mask || !d->fine_seg || !d->coarse_seg || !d->real_B_mask ||
+        !d->normal_vert || !d->fake_edges || !d->real_edges || !d->pred1_h || !d->pred2_h || !d->height || !d->maxheight || !d->losses ||
+        d->B <= 0 || d->H <= 0 || d->W <= 0)
+        return HV_ERR_ARG;
+    if (!d->workspace || d->workspace_bytes < hv_generator_losses_workspace_bytes(d->B) || ((uintptr_t)d->workspace & 7)) return HV_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    double* part = (double*)d->workspace;
+    float* coef = (float*)((char*)d->workspace + (size_t)d->B * GL_CHUNKS * GL_NQ * sizeof(double));
+    hipLaunchKernelGGL(gloss_partial_kernel, dim3(GL_CHUNKS, d->B), dim3(256), 0, s, *d, part);
+    HV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gloss_finalize_kernel, dim3(1), dim3(64), 0, s, *d, part, coef);
+    HV_LAUNCH_CHECK();
+    if (d->d_fake_B && d->d_fake_B_coarse && d->d_fine_seg && d->d_coarse_seg) {
+        const long long n = (long long)d->B * d->H * d->W;
+        hipLaunchKernelGGL(gloss_seed_kernel, dim3(pw_grid(n)), dim3(256), 0, s, *d, coef, n);
+        HV_LAUNCH_CHECK();
+    }
+    return HV_OK;
+}

@@ -1,0 +1,317 @@
+// Weight preparation (spectral norm + layout), its backward, activation/bias gradient, Adam, fills.
+// All HBM-bound or latency-bound; the spectral-norm kernels are batched over layers (one workgroup per
+// layer) so a whole generator needs one launch instead of 47.
+#include "hv_common.h"
+
+#define SN_EPS 1e-12f
+#define PREP_THREADS 512
+#define PREP_MAXK 4608   // v vector staged in LDS
+#define PREP_MAXCO 1024
+
+// logical weight W(co, ci, tap) in the torch source layout
+__device__ __forceinline__ long long wsrc_index(const hv_wprep_layer& L, int co, int ci, int tap) {
+    return L.transposed_src ? ((long long)ci * L.Cout + co) * L.taps + tap : ((long long)co * L.Cin + ci) * L.taps + tap;
+}
+
+__global__ __launch_bounds__(PREP_THREADS) void weight_prep_kernel(const hv_wprep_layer* __restrict__ layers) {
+    const hv_wprep_layer L = layers[blockIdx.x];
+    __shared__ float v_s[PREP_MAXK];
+    __shared__ float u_s[PREP_MAXCO];
+    __shared__ float red[20];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = PREP_THREADS / 64;
+    const int K = L.Cin * L.taps;
+    float sigma = 1.f;
+    if (L.sn) {
+        const float* W = L.w_orig;  // [Cout][K]
+        for (int i = tid; i < L.Cout; i += PREP_THREADS) u_s[i] = L.u[i];
+        for (int i = tid; i < K; i += PREP_THREADS) v_s[i] = L.v[i];
+        __syncthreads();
+        if (L.power_iter) {
+            // v = normalize(W^T u)
+            float ss = 0.f;
+            for (int k = tid; k < K; k += PREP_THREADS) {
+                float t = 0.f;
+                for (int co = 0; co < L.Cout; ++co) t += W[(long long)co * K + k] * u_s[co];
+                v_s[k] = t;
+                ss += t * t;
+            }
+            ss = hv_block_sum(ss, red);
+            const float nv = fmaxf(sqrtf(ss), SN_EPS);
+            __syncthreads();
+            for (int k = tid; k < K; k += PREP_THREADS) v_s[k] = v_s[k] / nv;
+            __syncthreads();
+        }
+        // s = W v  (one wave per row)
+        float ss = 0.f;
+        for (int co = wave; co < L.Cout; co += nwave) {
+            float t = 0.f;
+            for (int k = lane; k < K; k += 64) t += W[(long long)co * K + k] * v_s[k];
+            t = hv_wave_sum(t);
+            if (lane == 0) {
+                if (L.power_iter) {
+                    ss += t * t;
+                    u_s[co] = t;  // raw s = W v, normalised below
+                } else {
+                    ss += u_s[co] * t;  // sigma = u . (W v) with the stored u
+                }
+            }
+        }
+        ss = hv_block_sum(ss, red);
+        if (L.power_iter) {
+            const float nu = fmaxf(sqrtf(ss), SN_EPS);
+            __syncthreads();
+            float sg = 0.f;
+            for (int i = tid; i < L.Cout; i += PREP_THREADS) {
+                const float s = u_s[i], un = s / nu;
+                u_s[i] = un;
+                sg += un * s;
+            }
+            sigma = hv_block_sum(sg, red);
+            for (int i = tid; i < L.Cout; i += PREP_THREADS) L.u[i] = u_s[i];
+            for (int i = tid; i < K; i += PREP_THREADS) L.v[i] = v_s[i];
+        } else {
+            sigma = ss;
+        }
+    }
+    if (tid == 0 && L.sigma) L.sigma[0] = sigma;
+    // layouts (rows/channels beyond the real extent are written as zero)
+    const long long nf = (long long)L.CoutF * L.taps * L.CinP;
+    for (long long i = tid; i < nf; i += PREP_THREADS) {
+        const int ci = (int)(i % L.CinP);
+        const long long r = i / L.CinP;
+        const int tap = (int)(r % L.taps), co = (int)(r / L.taps);
+        float val = 0.f;
+        if (co < L.Cout && ci < L.Cin) val = L.w_orig[wsrc_index(L, co, ci, tap)] / sigma;
+        L.w_fwd[i] = val;
+    }
+    if (L.w_bwd) {
+        const long long nb = (long long)L.CinB * L.taps * L.CoutP;
+        for (long long i = tid; i < nb; i += PREP_THREADS) {
+            const int co = (int)(i % L.CoutP);
+            const long long r = i / L.CoutP;
+            const int tap = (int)(r % L.taps), ci = (int)(r / L.taps);
+            float val = 0.f;
+            if (co < L.Cout && ci < L.Cin) val = L.w_orig[wsrc_index(L, co, ci, tap)] / sigma;
+            L.w_bwd[i] = val;
+        }
+    }
+}
+
+extern "C" int hv_weight_prep(const hv_wprep_layer* d_layers, int n_layers, void* stream) {
+    if (!d_layers || n_layers <= 0) return HV_ERR_ARG;
+    hipLaunchKernelGGL(weight_prep_kernel, dim3(n_layers), dim3(PREP_THREADS), 0, (hipStream_t)stream, d_layers);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+
+__global__ __launch_bounds__(PREP_THREADS) void weight_prep_bwd_kernel(const hv_wprep_bwd_layer* __restrict__ layers) {
+    const hv_wprep_bwd_layer L = layers[blockIdx.x];
+    __shared__ float red[20];
+    const int tid = threadIdx.x;
+    const long long n = (long long)L.Cout * L.taps * L.CinP;
+    float dot = 0.f, sigma = 1.f;
+    if (L.sn) {
+        for (long long i = tid; i < n; i += PREP_THREADS) dot += L.dw_ohwi[i] * L.w_fwd[i];
+        dot = hv_block_sum(dot, red);
+        sigma = L.sigma[0];
+    }
+    const long long no = (long long)L.Cout * L.Cin * L.taps;
+    for (long long i = tid; i < no; i += PREP_THREADS) {
+        int co, ci, tap;
+        tap = (int)(i % L.taps);
+        const long long r = i / L.taps;
+        if (L.transposed_src) { co = (int)(r % L.Cout); ci = (int)(r / L.Cout); }
+        else { ci = (int)(r % L.Cin); co = (int)(r / L.Cin); }
+        float g = L.dw_ohwi[((long long)co * L.taps + tap) * L.CinP + ci];
+        if (L.sn) g = (g - dot * L.u[co] * L.v[ci * L.taps + tap]) / sigma;
+        L.dw_orig[i] = L.accumulate ? L.dw_orig[i] + g : g;
+    }
+}
+
+extern "C" int hv_weight_prep_backward(const hv_wprep_bwd_layer* d_layers, int n_layers, void* stream) {
+    if (!d_layers || n_layers <= 0) return HV_ERR_ARG;
+    hipLaunchKernelGGL(weight_prep_bwd_kernel, dim3(n_layers), dim3(PREP_THREADS), 0, (hipStream_t)stream, d_layers);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ activation gradient
+// vector path: C % 4 == 0 and C/4 a power of two <= 256: thread owns one 4-channel group, rows strided.
+template <bool VEC>
+__global__ __launch_bounds__(256) void act_bwd_kernel(float* __restrict__ dy, const float* __restrict__ y, long long npix, int C,
+                                                      int dy_ld, int dy_coff, int y_ld, int y_coff, int act,
+                                                      float* __restrict__ part, int rows_per_block) {
+    __shared__ float sh[256 * 4];
+    const int tid = threadIdx.x;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = min(npix, r0 + rows_per_block);
+    if (VEC) {
+        const int C4 = C >> 2, cg = tid % C4, rp = tid / C4, rstep = 256 / C4;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (long long r = r0 + rp; r < r1; r += rstep) {
+            float4 g = *reinterpret_cast<float4*>(dy + r * dy_ld + dy_coff + cg * 4);
+            const float4 o = *reinterpret_cast<const float4*>(y + r * y_ld + y_coff + cg * 4);
+            g.x *= hv_act_grad_from_out(o.x, act); g.y *= hv_act_grad_from_out(o.y, act);
+            g.z *= hv_act_grad_from_out(o.z, act); g.w *= hv_act_grad_from_out(o.w, act);
+            *reinterpret_cast<float4*>(dy + r * dy_ld + dy_coff + cg * 4) = g;
+            s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
+        }
+        if (part) {
+            reinterpret_cast<float4*>(sh)[tid] = s;
+            __syncthreads();
+            if (tid < C4) {
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int k = tid; k < 256; k += C4) {
+                    const float4 q = reinterpret_cast<float4*>(sh)[k];
+                    t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w;
+                }
+                *reinterpret_cast<float4*>(part + (long long)blockIdx.x * C + tid * 4) = t;
+            }
+        }
+    } else {  // scalar path: C a power of two <= 256
+        const int c = tid % C, rp = tid / C, rstep = 256 / C;
+        float s = 0.f;
+        for (long long r = r0 + rp; r < r1; r += rstep) {
+            float g = dy[r * dy_ld + dy_coff + c] * hv_act_grad_from_out(y[r * y_ld + y_coff + c], act);
+            dy[r * dy_ld + dy_coff + c] = g;
+            s += g;
+        }
+        if (part) {
+            sh[tid] = s;
+            __syncthreads();
+            if (tid < C) {
+                float t = 0.f;
+                for (int k = tid; k < 256; k += C) t += sh[k];
+                part[(long long)blockIdx.x * C + tid] = t;
+            }
+        }
+    }
+}
+
+__global__ void colsum_finalize_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += (double)part[(long long)b * C + c];
+    out[c] = accumulate ? out[c] + (float)s : (float)s;
+}
+
+static bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+static bool act_vec_ok(int C) { return (C % 4 == 0) && pow2(C / 4) && C / 4 <= 256; }
+
+// rows handled per block (multiple of the row step of the thread mapping) and the block count
+static int act_bwd_blocks(long long npix, int C, int* rows_per_block) {
+    const int rstep = act_vec_ok(C) ? 256 / (C / 4) : 256 / C;
+    long long rpb = (long long)rstep * 16;
+    long long nb = (npix + rpb - 1) / rpb;
+    if (nb > 2048) {
+        rpb = (npix + 2047) / 2048;
+        rpb = (rpb + rstep - 1) / rstep * rstep;
+        nb = (npix + rpb - 1) / rpb;
+    }
+    *rows_per_block = (int)rpb;
+    return (int)nb;
+}
+
+extern "C" size_t hv_act_backward_workspace_bytes(long long npix, int C) {
+    if (npix <= 0 || C <= 0 || !(act_vec_ok(C) || (pow2(C) && C <= 256))) return 0;
+    int rpb;
+    return (size_t)act_bwd_blocks(npix, C, &rpb) * C * sizeof(float);
+}
+
+extern "C" int hv_act_backward(float* dy, const float* y, long long npix, int C, int dy_ld, int dy_coff, int y_ld, int y_coff,
+                               int act, float* dbias, int dbias_accumulate, float* workspace, size_t workspace_bytes, void* stream) {
+    if (!dy || !y || npix <= 0 || C <= 0) return HV_ERR_ARG;
+    const bool aligned = !(dy_ld & 3) && !(dy_coff & 3) && !(y_ld & 3) && !(y_coff & 3) && !((uintptr_t)dy & 15) && !((uintptr_t)y & 15);
+    if (!(act_vec_ok(C) && aligned) && !(pow2(C) && C <= 256)) return HV_ERR_UNSUPPORTED;
+    // the block plan depends only on C (the workspace query must agree), the code path also on alignment
+    const bool vec = act_vec_ok(C) && aligned;
+    int rpb;
+    const int nb = act_bwd_blocks(npix, C, &rpb);
+    if (!vec && act_vec_ok(C)) return HV_ERR_UNSUPPORTED;  // vector-shaped C on unaligned views is not needed by the path
+    if (dbias && (!workspace || workspace_bytes < (size_t)nb * C * sizeof(float))) return HV_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    if (vec)
+        hipLaunchKernelGGL((act_bwd_kernel<true>), dim3(nb), dim3(256), 0, s, dy, y, npix, C, dy_ld, dy_coff, y_ld, y_coff, act,
+                           dbias ? workspace : nullptr, rpb);
+    else
+        hipLaunchKernelGGL((act_bwd_kernel<false>), dim3(nb), dim3(256), 0, s, dy, y, npix, C, dy_ld, dy_coff, y_ld, y_coff, act,
+                           dbias ? workspace : nullptr, rpb);
+    HV_LAUNCH_CHECK();
+    if (dbias) {
+        hipLaunchKernelGGL(colsum_finalize_kernel, dim3(hv_cdiv(C, 64)), dim3(64), 0, s, workspace, nb, C, dbias, dbias_accumulate);
+        HV_LAUNCH_CHECK();
+    }
+    return HV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ Adam
+__global__ void adam_tick_kernel(float* step) { step[0] += 1.f; }
+
+__global__ __launch_bounds__(256) void adam_kernel(const hv_adam_tensor* __restrict__ ts, const float* __restrict__ lr_p, float beta1,
+                                                   float beta2, float eps, const float* __restrict__ step_p) {
+    const hv_adam_tensor t = ts[blockIdx.y];
+    const long long base = (long long)blockIdx.x * 1024;
+    if (base >= t.n) return;
+    const float step = step_p[0], lr = lr_p[0];
+    const float bc1 = 1.f - powf(beta1, step), bc2 = 1.f - powf(beta2, step);
+    const float step_size = lr / bc1, bc2_sqrt = sqrtf(bc2);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long long i = base + k * 256 + threadIdx.x;
+        if (i < t.n) {
+            const float g = t.g[i];
+            const float m = t.m[i] + (g - t.m[i]) * (1.f - beta1);
+            const float v = t.v[i] * beta2 + (1.f - beta2) * g * g;
+            t.m[i] = m;
+            t.v[i] = v;
+            const float denom = sqrtf(v) / bc2_sqrt + eps;
+            t.p[i] = t.p[i] - step_size * (m / denom);
+        }
+    }
+}
+
+extern "C" int hv_adam_step(const hv_adam_tensor* d_tensors, int n_tensors, long long max_numel, const float* d_lr, float beta1,
+                            float beta2, float eps, float* d_step, void* stream) {
+    if (!d_tensors || n_tensors <= 0 || max_numel <= 0 || !d_lr || !d_step) return HV_ERR_ARG;
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, d_step);
+    HV_LAUNCH_CHECK();
+    dim3 grid(hv_cdiv(max_numel, 1024), n_tensors);
+    hipLaunchKernelGGL(adam_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_tensors, d_lr, beta1, beta2, eps, d_step);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ fills
+__global__ void fill_kernel(float* p, long long n, float v) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long st = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += st) p[i] = v;
+}
+__global__ void axpy_kernel(float* y, const float* x, long long n, float a, int assign) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long st = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += st) y[i] = assign ? a * x[i] : y[i] + a * x[i];
+}
+static int ew_grid(long long n) { long long b = (n + 255) / 256; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
+extern "C" int hv_fill(float* p, long long n, float value, void* stream) {
+    if (!p || n <= 0) return HV_ERR_ARG;
+    hipLaunchKernelGGL(fill_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, n, value);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+extern "C" int hv_axpy(float* y, const float* x, long long n, float a, void* stream) {
+    if (!y || !x || n <= 0) return HV_ERR_ARG;
+    hipLaunchKernelGGL(axpy_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, y, x, n, a, 0);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+extern "C" int hv_scale_rows(float* y, const float* x, long long n, float a, void* stream) {
+    if (!y || !x || n <= 0) return HV_ERR_ARG;
+    hipLaunchKernelGGL(axpy_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, y, x, n, a, 1);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+
+extern "C" int hv_version(void) { return 100; }
+extern "C" const char* hv_arch(void) { return "gfx950"; }

@@ -1,0 +1,301 @@
+"""Python-side operator wrappers over the C ABI (include/hvgan.h).
+
+Plumbing only: torch supplies device memory and the current HIP stream; all arithmetic happens in
+libhvgan.so.  Activations are NHWC fp32 views (`Act`) with an explicit channel stride/offset so
+convolutions read and write channel slices of concat buffers in place.
+"""
+import ctypes
+import os
+
+import torch
+
+from . import lib as _lib
+from .lib import ACT, NORM, F16, F32, ptr, stream
+
+_PRECISION = {'fp32': F32, 'f32': F32, 'fp16': F16, 'f16': F16}
+
+
+def default_precision():
+    """HV_PRECISION=fp32 (exact fp32 MFMA, parity mode) | fp16 (fp16 MFMA operands, fp32 accumulate)."""
+    return _PRECISION[os.environ.get('HV_PRECISION', 'fp32').lower()]
+
+
+def precision_id(p):
+    if p is None:
+        return default_precision()
+    if isinstance(p, str):
+        return _PRECISION[p.lower()]
+    return int(p)
+
+
+def rup(v, m):
+    return (v + m - 1) // m * m
+
+
+class Act:
+    """NHWC fp32 activation view: tensor [B,H,W,ld], channels [coff, coff+C)."""
+    __slots__ = ('t', 'B', 'H', 'W', 'C', 'ld', 'coff')
+
+    def __init__(self, t, C=None, coff=0):
+        assert t.dim() == 4 and t.dtype == torch.float32 and t.is_contiguous(), (t.shape, t.dtype)
+        _lib.require_gpu(t)
+        self.t = t
+        self.B, self.H, self.W, self.ld = t.shape
+        self.coff = coff
+        self.C = self.ld - coff if C is None else C
+        assert 0 < self.C and self.coff + self.C <= self.ld
+
+    @staticmethod
+    def empty(B, H, W, C, device, ld=None, zero=False):
+        ld = C if ld is None else ld
+        t = (torch.zeros if zero else torch.empty)(B, H, W, ld, dtype=torch.float32, device=device)
+        return Act(t, C, 0)
+
+    def slice(self, coff, C):
+        return Act(self.t, C, self.coff + coff)
+
+    def like(self, zero=False):
+        return Act.empty(self.B, self.H, self.W, self.ld, self.t.device, zero=zero).slice(self.coff, self.C) \
+            if (self.coff or self.C != self.ld) else Act.empty(self.B, self.H, self.W, self.C, self.t.device, zero=zero)
+
+    @property
+    def npix(self):
+        return self.B * self.H * self.W
+
+    def nchw(self):
+        """Copy out as a (B,C,H,W) tensor (API edge).  C == 1 is a free view."""
+        if self.C == 1 and self.ld == 1:
+            return self.t.view(self.B, 1, self.H, self.W)
+        out = torch.empty(self.B, self.C, self.H, self.W, dtype=torch.float32, device=self.t.device)
+        L = _lib.get()
+        L.call('hv_nhwc_to_nchw', ptr(self.t), ptr(out), self.B, self.C, self.H, self.W, self.ld, self.coff, 0, stream())
+        return out
+
+
+def from_nchw(x, CP=None):
+    """(B,C,H,W) tensor -> NHWC Act (C == 1 is a free view; CP pads the channel stride with zeros)."""
+    _lib.require_gpu(x)
+    x = x.contiguous().float()
+    B, C, H, W = x.shape
+    if C == 1 and CP in (None, 1):
+        return Act(x.view(B, H, W, 1))
+    ld = C if CP is None else CP
+    a = Act.empty(B, H, W, C, x.device, ld=ld, zero=ld != C)
+    _lib.get().call('hv_nchw_to_nhwc', ptr(x), ptr(a.t), B, C, H, W, ld, 0, stream())
+    return a
+
+
+# ------------------------------------------------------------------------------------------------ workspace
+class _Workspace:
+    def __init__(self):
+        self.buf = {}
+
+    def get(self, nbytes, device, slot=0):
+        key = (device, slot)
+        b = self.buf.get(key)
+        if b is None or b.numel() < nbytes:
+            b = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+            self.buf[key] = b
+        return b
+
+
+WS = _Workspace()
+
+
+def _ws(nbytes, device, slot=0):
+    b = WS.get(nbytes + 64, device, slot)
+    return b, ctypes.c_size_t(b.numel())
+
+
+# ------------------------------------------------------------------------------------------------ convolution
+def conv_out_size(n, k, stride, pad, dil):
+    return (n + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+
+def conv2d(x, w, y, k, stride=1, pad=0, dil=1, bias=None, act='none', transposed=False, in_shift=0, alpha=1.0,
+           accumulate=0, ch_scale=None, w_bstride=0, ch_scale_bstride=0, precision=None, cin=None, cout=None):
+    """y = act(alpha*ch_scale*conv(x, w) + bias).  x,y: Act; w: prepared [CoutF][k*k][CinP] tensor (or [B][...] with
+    w_bstride).  cin/cout default to the view widths (x.C consumed, y.C produced)."""
+    L = _lib.get()
+    d = L.hv_conv_desc()
+    kh, kw = (k, k) if isinstance(k, int) else k
+    d.x = ptr(x.t).value
+    d.B, d.H, d.W = x.B, x.H << in_shift, x.W << in_shift
+    d.in_shift, d.x_ld, d.x_coff, d.Cin = in_shift, x.ld, x.coff, (x.C if cin is None else cin)
+    d.w = ptr(w).value
+    d.w_bstride = w_bstride
+    d.Cout, d.KH, d.KW, d.stride, d.pad, d.dil, d.transposed = (y.C if cout is None else cout), kh, kw, stride, pad, dil, int(transposed)
+    d.bias = None if bias is None else ptr(bias).value
+    d.ch_scale = None if ch_scale is None else ptr(ch_scale).value
+    d.ch_scale_bstride = ch_scale_bstride
+    d.alpha, d.act, d.accumulate = alpha, ACT[act], int(accumulate)
+    d.y = ptr(y.t).value
+    d.Ho, d.Wo, d.y_ld, d.y_coff = y.H, y.W, y.ld, y.coff
+    d.precision = precision_id(precision)
+    L.call('hv_conv2d', ctypes.byref(d), stream())
+    return y
+
+
+def conv2d_wgrad(x, g, dw, k, stride=1, pad=0, dil=1, in_shift=0, accumulate=False, precision=None, cin=None, cout=None):
+    """dw[Cout][k*k][Cin] = sum_pixels g (x) x.  x: conv input view, g: gradient wrt the conv output."""
+    L = _lib.get()
+    d = L.hv_wgrad_desc()
+    kh, kw = (k, k) if isinstance(k, int) else k
+    d.x = ptr(x.t).value
+    d.B, d.H, d.W, d.in_shift = x.B, x.H << in_shift, x.W << in_shift, in_shift
+    d.x_ld, d.x_coff, d.Cin = x.ld, x.coff, (x.C if cin is None else cin)
+    d.g = ptr(g.t).value
+    d.Ho, d.Wo, d.g_ld, d.g_coff, d.Cout = g.H, g.W, g.ld, g.coff, (g.C if cout is None else cout)
+    d.KH, d.KW, d.stride, d.pad, d.dil = kh, kw, stride, pad, dil
+    d.dw = ptr(dw).value
+    d.accumulate = int(accumulate)
+    d.precision = precision_id(precision)
+    d.workspace, d.workspace_bytes = None, 0
+    need = L.size('hv_conv2d_wgrad_workspace_bytes', ctypes.byref(d))
+    if need:
+        b, _ = _ws(need, x.t.device)
+        d.workspace, d.workspace_bytes = ptr(b).value, b.numel()
+    L.call('hv_conv2d_wgrad', ctypes.byref(d), stream())
+    return dw
+
+
+# ------------------------------------------------------------------------------------------------ weight prep tables
+class LayerTable:
+    """Device array of per-layer descriptors for the batched weight-prep kernels.  Rebuilt when a
+    parameter's storage moves (e.g. after .to(device) / load_state_dict on a fresh module)."""
+
+    def __init__(self, struct_name):
+        self.struct_name = struct_name
+        self.key = None
+        self.dev = None
+        self.n = 0
+
+    def update(self, rows, key, device):
+        """rows: list of dicts field -> value (tensors are converted to pointers)."""
+        if key == self.key:
+            return
+        L = _lib.get()
+        S = getattr(L, self.struct_name)
+        arr = (S * len(rows))()
+        for i, r in enumerate(rows):
+            for f, v in r.items():
+                if torch.is_tensor(v):
+                    v = ptr(v).value
+                setattr(arr[i], f, v)
+        raw = bytes(arr)
+        host = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+        self.dev = host.to(device)
+        self.key, self.n = key, len(rows)
+
+    def ptr(self):
+        return ptr(self.dev)
+
+
+def weight_prep(table):
+    _lib.get().call('hv_weight_prep', ctypes.cast(table.ptr(), ctypes.POINTER(_lib.get().hv_wprep_layer)), table.n, stream())
+
+
+def weight_prep_backward(table):
+    _lib.get().call('hv_weight_prep_backward', ctypes.cast(table.ptr(), ctypes.POINTER(_lib.get().hv_wprep_bwd_layer)), table.n, stream())
+
+
+# ------------------------------------------------------------------------------------------------ pointwise
+def act_backward(dy, y, act, dbias=None, dbias_accumulate=False):
+    """In place: dy *= act'(y); dbias (+)= column sums."""
+    L = _lib.get()
+    need = L.size('hv_act_backward_workspace_bytes', ctypes.c_longlong(dy.npix), dy.C) if dbias is not None else 0
+    b, nb = _ws(need, dy.t.device)
+    L.call('hv_act_backward', ptr(dy.t), ptr(y.t), ctypes.c_longlong(dy.npix), dy.C, dy.ld, dy.coff, y.ld, y.coff, ACT[act],
+           ptr(dbias), int(dbias_accumulate), ptr(b), nb, stream())
+
+
+def copy_channels(src, dst, mode=0, accumulate=False):
+    """dst (+)= resample(src); H,W of dst rule (mode: 0 same, 1 up x2, 2 down x1/2, 3 adjoint of 1, 4 adjoint of 2)."""
+    assert src.C == dst.C
+    _lib.get().call('hv_copy_channels', ptr(src.t), ptr(dst.t), dst.B, dst.H, dst.W, dst.C, src.ld, src.coff, dst.ld, dst.coff,
+                    mode, int(accumulate), stream())
+
+
+def fill(t, value=0.0):
+    _lib.get().call('hv_fill', ptr(t), ctypes.c_longlong(t.numel()), ctypes.c_float(value), stream())
+
+
+def axpy(y, x, a=1.0):
+    assert y.numel() == x.numel()
+    _lib.get().call('hv_axpy', ptr(y), ptr(x), ctypes.c_longlong(y.numel()), ctypes.c_float(a), stream())
+
+
+def gen_input(x, seg, mask, ratio, dst, order):
+    _lib.get().call('hv_gen_input', ptr(x), ptr(seg), ptr(mask), ptr(ratio), ptr(dst.t), dst.B, dst.H, dst.W, dst.ld, order, stream())
+
+
+def gap_fc_sigmoid(x, fc_w, fc_b, pooled, pred):
+    L = _lib.get()
+    need = L.size('hv_gap_fc_workspace_bytes', x.B, x.C)
+    b, nb = _ws(need, x.t.device)
+    L.call('hv_gap_fc_sigmoid', ptr(x.t), x.B, x.H * x.W, x.C, x.ld, ptr(fc_w), ptr(fc_b), ptr(pooled), ptr(pred), ptr(b), nb, stream())
+
+
+def gap_fc_sigmoid_backward(dpred, pred, pooled, fc_w, dx, dw, db, accumulate=False):
+    _lib.get().call('hv_gap_fc_sigmoid_backward', ptr(dpred), ptr(pred), ptr(pooled), ptr(fc_w), ptr(dx.t), dx.B, dx.H * dx.W, dx.C,
+                    dx.ld, ptr(dw), ptr(db), int(accumulate), stream())
+
+
+def sobel(img, out=None):
+    """img: (B,1,H,W) tensor."""
+    out = torch.empty_like(img) if out is None else out
+    B, _, H, W = img.shape
+    _lib.get().call('hv_sobel', ptr(img), ptr(out), B, H, W, stream())
+    return out
+
+
+def gan_loss(z, target_is_real, mode='vanilla', loss=None, loss_weight=1.0, loss_accumulate=False, dz=None, grad_weight=1.0):
+    m = {'vanilla': 0, 'lsgan': 1}[mode]
+    _lib.get().call('hv_gan_loss', ptr(z), ctypes.c_longlong(z.numel()), int(bool(target_is_real)), m, ctypes.c_float(loss_weight),
+                    ptr(loss), int(loss_accumulate), ctypes.c_float(grad_weight), ptr(dz), stream())
+
+
+def adam_step(table, max_numel, lr_dev, beta1, beta2, eps, step_dev):
+    L = _lib.get()
+    L.call('hv_adam_step', ctypes.cast(table.ptr(), ctypes.POINTER(L.hv_adam_tensor)), table.n, ctypes.c_longlong(max_numel),
+           ptr(lr_dev), ctypes.c_float(beta1), ctypes.c_float(beta2), ctypes.c_float(eps), ptr(step_dev), stream())
+
+
+# ------------------------------------------------------------------------------------------------ norm + activation
+def norm_act_forward(x, y, norm, training, stats, gamma=None, beta=None, running_mean=None, running_var=None, nbt=None,
+                     act='lrelu', post_sigmoid=False, eps=1e-5, momentum=0.1):
+    L = _lib.get()
+    d = L.hv_norm_desc()
+    d.x, d.y = ptr(x.t).value, ptr(y.t).value
+    d.B, d.HW, d.C = x.B, x.H * x.W, x.C
+    d.x_ld, d.x_coff, d.y_ld, d.y_coff = x.ld, x.coff, y.ld, y.coff
+    d.norm, d.training, d.eps, d.momentum = NORM[norm], int(training), eps, momentum
+    for f, v in (('gamma', gamma), ('beta', beta), ('running_mean', running_mean), ('running_var', running_var),
+                 ('num_batches_tracked', nbt), ('stats', stats)):
+        setattr(d, f, None if v is None else ptr(v).value)
+    d.act, d.post_sigmoid = ACT[act], int(post_sigmoid)
+    need = L.size('hv_norm_workspace_bytes', x.B, x.H * x.W, x.C)
+    b, _ = _ws(need, x.t.device)
+    d.workspace, d.workspace_bytes = ptr(b).value, b.numel()
+    L.call('hv_norm_act_forward', ctypes.byref(d), stream())
+
+
+def norm_act_backward(dy, y, x, dx, norm, training, stats, gamma=None, act='lrelu', post_sigmoid=False, dgamma=None, dbeta=None,
+                      param_accumulate=False):
+    L = _lib.get()
+    d = L.hv_norm_bwd_desc()
+    d.dy, d.y, d.x, d.dx = ptr(dy.t).value, ptr(y.t).value, ptr(x.t).value, ptr(dx.t).value
+    d.B, d.HW, d.C = x.B, x.H * x.W, x.C
+    d.dy_ld, d.dy_coff, d.y_ld, d.y_coff = dy.ld, dy.coff, y.ld, y.coff
+    d.x_ld, d.x_coff, d.dx_ld, d.dx_coff = x.ld, x.coff, dx.ld, dx.coff
+    d.norm, d.training = NORM[norm], int(training)
+    d.gamma = None if gamma is None else ptr(gamma).value
+    d.stats = ptr(stats).value
+    d.act, d.post_sigmoid = ACT[act], int(post_sigmoid)
+    d.dgamma = None if dgamma is None else ptr(dgamma).value
+    d.dbeta = None if dbeta is None else ptr(dbeta).value
+    d.param_accumulate = int(param_accumulate)
+    need = L.size('hv_norm_workspace_bytes', x.B, x.H * x.W, x.C)
+    b, _ = _ws(need, x.t.device)
+    d.workspace, d.workspace_bytes = ptr(b).value, b.numel()
+    L.call('hv_norm_act_backward', ctypes.byref(d), stream())

@@ -1,0 +1,249 @@
+/* hvgan.h -- C ABI of libhvgan.so: hand-written gfx950 (MI355X) kernels for the HealthiVert-GAN
+ * generator / discriminator train + inference hot path.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless named h_*; every tensor is fp32, NHWC, dense in W/H with an
+ *     explicit channel stride `*_ld` (elements per pixel) and channel offset `*_coff` so a conv can read or
+ *     write a channel slice of a wider (concat) buffer.  A (B,1,H,W) NCHW tensor is bit-identical in NHWC, so
+ *     all image-level inputs/outputs of the reference API cross the boundary without a copy.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  No entry point allocates, frees or
+ *     synchronises: the caller owns every buffer, including workspaces sized by the *_workspace_bytes calls,
+ *     so every call is legal inside a hipGraph capture.
+ *   - return value: 0 = ok; HV_ERR_* (negative) = rejected before launch; <= -1000 = -(hipError_t) - 1000.
+ *     Nothing throws across the ABI.  The Python host (healthivert-gan_amd/lib.py) turns non-zero into
+ *     RuntimeError; there is no CPU fallback.
+ *   - `precision`: HV_F32 = exact fp32 MFMA (v_mfma_f32_16x16x4_f32; the |d| <= 1e-3 parity mode),
+ *     HV_F16 = operands rounded to fp16 when staged into LDS, fp32 accumulate (v_mfma_f32_16x16x32_f16).
+ *
+ * Each entry point names the reference code it replaces (paths relative to the reference root).
+ */
+#ifndef HVGAN_H
+#define HVGAN_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HV_OK 0
+#define HV_ERR_ARG (-1)         /* null pointer / non-positive size / bad enum */
+#define HV_ERR_UNSUPPORTED (-2) /* shape outside what the kernels are built for */
+#define HV_ERR_WORKSPACE (-3)   /* workspace too small */
+
+enum { HV_F32 = 0, HV_F16 = 1 };
+enum { HV_ACT_NONE = 0, HV_ACT_ELU = 1, HV_ACT_RELU = 2, HV_ACT_LRELU = 3, HV_ACT_SIGMOID = 4, HV_ACT_CLAMP = 5 };
+enum { HV_NORM_NONE = 0, HV_NORM_BATCH = 1, HV_NORM_INSTANCE = 2 };
+
+int hv_version(void);
+const char* hv_arch(void); /* "gfx950" */
+
+/* ---------------------------------------------------------------- convolution (implicit GEMM on MFMA)
+ * Replaces F.conv2d / F.conv_transpose2d as called by Conv2dBlock.forward (models/inpaint_networks.py:494-503),
+ * NLayerDiscriminator (models/networks.py:575-602), Down/UpsampleBlock (models/UnetG_CT_mask.py:69-100), the
+ * matching and pasting convolutions of ContextualAttention (models/inpaint_networks.py:348,379) and -- with
+ * transposed=1 -- their autograd data-gradients.
+ *
+ *   y[n,ho,wo,co] (op)= act( alpha * ch_scale[co] * sum_{r,s,ci} x[n,hi,wi,ci] * w[co,(r,s),ci] + bias[co] )
+ *   transposed=0: hi = ho*stride - pad + r*dil
+ *   transposed=1: hi = (ho + pad - r*dil)/stride where divisible (gather form of conv_transpose2d / dgrad)
+ *   in_shift=1 reads x through a fused nearest x2 upsample (physical index = logical >> 1).
+ *   w is [Cout][KH*KW][Cin] ("OHWI"); w_bstride != 0 selects per-sample filters (contextual attention).
+ */
+typedef struct {
+    const float* x; int B, H, W;      /* logical input size (after the fused upsample) */
+    int in_shift; int x_ld, x_coff, Cin;
+    const float* w; long long w_bstride;
+    int Cout, KH, KW, stride, pad, dil, transposed;
+    const float* bias;                /* [Cout] or NULL */
+    const float* ch_scale;            /* [Cout] or NULL */
+    long long ch_scale_bstride;
+    float alpha; int act; int accumulate;   /* accumulate: 0 y = r; 1 y += r (after act); 2 y = act(r + y) */
+    float* y; int Ho, Wo, y_ld, y_coff;
+    int precision;
+} hv_conv_desc;
+int hv_conv2d(const hv_conv_desc* d, void* stream);
+
+/* Weight gradient: dw[co][(r,s)][ci] = sum_{n,ho,wo} g[n,ho,wo,co] * x[n, ho*stride-pad+r*dil, ..., ci].
+ * (autograd of the convs above; for a transposed conv swap the roles of x and g on the caller side).
+ * Split over pixel chunks; partial slabs go to `workspace` and are summed in a fixed order (deterministic). */
+typedef struct {
+    const float* x; int B, H, W; int in_shift; int x_ld, x_coff, Cin;
+    const float* g; int Ho, Wo, g_ld, g_coff, Cout;
+    int KH, KW, stride, pad, dil;
+    float* dw; int accumulate;
+    float* workspace; size_t workspace_bytes;
+    int precision;
+} hv_wgrad_desc;
+size_t hv_conv2d_wgrad_workspace_bytes(const hv_wgrad_desc* d);
+int hv_conv2d_wgrad(const hv_wgrad_desc* d, void* stream);
+
+/* ---------------------------------------------------------------- weight preparation / spectral norm
+ * Batched over layers: one workgroup per layer.  Replaces torch.nn.utils.spectral_norm's forward pre-hook
+ * (used at models/inpaint_networks.py:449-450,491-492): optional power iteration (in-place u,v), sigma,
+ * W/sigma, written directly in the kernels' OHWI layouts (forward: [Cout][taps][CinP]; data-gradient:
+ * [CinP'][taps][Cout'] ...).  With sn=0 it is a pure layout transform (discriminator / U-Net weights). */
+typedef struct {
+    const float* w_orig;  /* [Cout][Cin][KH][KW] (torch layout); for conv_transpose [Cin][Cout][KH][KW] with transposed_src=1 */
+    float* u; float* v;   /* [Cout], [Cin*KH*KW]; NULL when sn=0 */
+    float* sigma;         /* [1] out (1.0 when sn=0) */
+    float* w_fwd;         /* [CoutF][taps][CinP]  rows >= Cout and channels >= Cin are zero */
+    float* w_bwd;         /* [CinB][taps][CoutP]  or NULL */
+    int Cout, Cin, taps, CinP, CoutF, CoutP, CinB;
+    int sn, power_iter, transposed_src;
+} hv_wprep_layer;
+int hv_weight_prep(const hv_wprep_layer* d_layers, int n_layers, void* stream); /* d_layers: DEVICE array */
+
+/* Backward of the above: dw_orig = (dWsn - <dWsn, Wsn> u v^T) / sigma  (sn=1) or a layout transform (sn=0).
+ * dw_ohwi is the hv_conv2d_wgrad output [Cout][taps][CinP]. */
+typedef struct {
+    const float* dw_ohwi; const float* w_fwd; const float* u; const float* v; const float* sigma;
+    float* dw_orig; int Cout, Cin, taps, CinP, sn, transposed_src, accumulate;
+} hv_wprep_bwd_layer;
+int hv_weight_prep_backward(const hv_wprep_bwd_layer* d_layers, int n_layers, void* stream);
+
+/* ---------------------------------------------------------------- activation gradient + bias gradient
+ * g[p,c] = dy[p,c] * act'(y[p,c]) in place over dy; dbias[c] (+)= sum_p g[p,c] when dbias != NULL.
+ * (autograd of nn.ELU/ReLU/Sigmoid/clamp after the conv, models/inpaint_networks.py:459-474,115,230). */
+int hv_act_backward(float* dy, const float* y, long long npix, int C, int dy_ld, int dy_coff, int y_ld, int y_coff,
+                    int act, float* dbias, int dbias_accumulate, float* workspace, size_t workspace_bytes, void* stream);
+size_t hv_act_backward_workspace_bytes(long long npix, int C);
+
+/* ---------------------------------------------------------------- normalisation + activation (discriminator, U-Net)
+ * BatchNorm2d (train: batch statistics + running-stat update, eval: running stats) or InstanceNorm2d (no affine)
+ * followed by LeakyReLU(0.2)/ReLU/none (+ optional sigmoid), models/networks.py:18-36,583-595 and
+ * models/UnetG_CT_mask.py:73-100.  `stats` (2*G*C floats: mean, rstd; G = 1 for batch, B for instance) is kept
+ * for the backward. */
+typedef struct {
+    const float* x; float* y; int B, HW, C; int x_ld, x_coff, y_ld, y_coff;
+    int norm; int training; float eps, momentum;
+    const float* gamma; const float* beta; float* running_mean; float* running_var; long long* num_batches_tracked;
+    float* stats; int act; int post_sigmoid;
+    float* workspace; size_t workspace_bytes;
+} hv_norm_desc;
+size_t hv_norm_workspace_bytes(int B, int HW, int C);
+int hv_norm_act_forward(const hv_norm_desc* d, void* stream);
+/* dx from dy (gradient wrt the activation output y); dgamma/dbeta (+)= when non-NULL. */
+typedef struct {
+    const float* dy; const float* y; const float* x; float* dx; int B, HW, C;
+    int dy_ld, dy_coff, y_ld, y_coff, x_ld, x_coff, dx_ld, dx_coff;
+    int norm; int training; const float* gamma; const float* stats;
+    int act; int post_sigmoid;
+    float* dgamma; float* dbeta; int param_accumulate;
+    float* workspace; size_t workspace_bytes;
+} hv_norm_bwd_desc;
+int hv_norm_act_backward(const hv_norm_bwd_desc* d, void* stream);
+
+/* ---------------------------------------------------------------- layout / resampling helpers
+ * NCHW <-> NHWC (API edge only), nearest x2 upsample + channel concat (F.interpolate + torch.cat,
+ * models/inpaint_networks.py:97-99,105-106), channel copies, zero fill. */
+int hv_nchw_to_nhwc(const float* src, float* dst, int B, int C, int H, int W, int dst_ld, int dst_coff, void* stream);
+int hv_nhwc_to_nchw(const float* src, float* dst, int B, int C, int H, int W, int src_ld, int src_coff, int accumulate, void* stream);
+/* Copies C channels into a channel slice of dst; H,W are the dst size.  mode 0: same size; 1: src is half size
+ * (nearest x2 upsample); 2: src is double size (nearest x1/2 downsample, even indices); 3: dst(half) (+)= sum of the
+ * 2x2 block of src(full) [adjoint of 1]; 4: dst(full) (+)= src(half) at even indices, 0 elsewhere [adjoint of 2]. */
+int hv_copy_channels(const float* src, float* dst, int B, int H, int W, int C, int src_ld, int src_coff, int dst_ld,
+                     int dst_coff, int mode, int accumulate, void* stream);
+
+/* ---------------------------------------------------------------- generator heads and inputs
+ * cat[x, ratio-plane, mask] / cat[x, coarse_seg, mask, ratio-plane] (models/inpaint_networks.py:71-77,173-179)
+ * written as a CP-channel NHWC buffer (pad channels zero).  order: 0 = coarse, 1 = fine. */
+int hv_gen_input(const float* x, const float* seg, const float* mask, const double* slice_ratio, float* dst,
+                 int B, int H, int W, int CP, int order, void* stream);
+/* AdaptiveAvgPool2d(1) -> Linear(C,1) -> sigmoid (models/inpaint_networks.py:90-93,211-214). */
+size_t hv_gap_fc_workspace_bytes(int B, int C);
+int hv_gap_fc_sigmoid(const float* x, int B, int HW, int C, int x_ld, const float* fc_w, const float* fc_b,
+                      float* pooled /*[B][C]*/, float* pred /*[B]*/, float* workspace, size_t workspace_bytes, void* stream);
+/* backward: dx[n,p,c] += dpred[n]*pred(1-pred)*w[c]/HW ; dw[c] (+)= sum_n dl_n*pooled[n,c]; db (+)= sum_n dl_n */
+int hv_gap_fc_sigmoid_backward(const float* dpred, const float* pred, const float* pooled, const float* fc_w,
+                               float* dx, int B, int HW, int C, int dx_ld, float* dw, float* db, int accumulate,
+                               void* stream);
+
+/* ---------------------------------------------------------------- contextual attention pieces
+ * (models/inpaint_networks.py:247-410).  The two big contractions (patch matching :348, patch pasting :379) and
+ * their gradients go through hv_conv2d with per-sample filters; these are the memory-bound stages around them.
+ * Score matrices are [b][p][l]: p = foreground position, l = background patch (contiguous), L = (H/2)*(W/2). */
+/* x1/2 nearest downsample fd[B][h][w][C]; 3x3 zero-padded patches wp[B][L][9][C] (+ transposed wpT[B][9*C][L]);
+ * norm[B][L] = max(||patch||, 1e-4) and rnorm = 1/norm  (:282-294, :341-345). */
+int hv_ca_patches(const float* f, int B, int H, int W, int C, int f_ld, float* fd, float* wp, float* wpT, float* norm,
+                  float* rnorm, void* stream);
+/* 4x4 stride-2 'same' patches of a full-resolution map (:270-277): raw[B][L][16][C] and/or rawT[B][C][16][L]. */
+int hv_ca_raw_patches(const float* f, int B, int H, int W, int C, int f_ld, float* raw, float* rawT, void* stream);
+/* mm[l] = 1 iff the 3x3 patch of the x1/8-downsampled mask of SAMPLE 0 is all zero (:304-317). */
+int hv_ca_mask(const float* mask, int Himg, int Wimg, int h, int w, float* mm, void* stream);
+/* score fusion (two diagonal 3-tap sums with the (h,w)<->(w,h) transposes, :352-361); adjoint=1 applies the
+ * transposed operator (backward).  h == w required. */
+int hv_ca_fuse(const float* S, float* out, int B, int h, int w, int adjoint, void* stream);
+/* A[b][p][l] = softmax_l(S*mm*scale)*mm (:364-366); optional argmax over l -> argmax[b*L+p] (:368). */
+int hv_ca_softmax(const float* S, const float* mm, float* A, int B, int L, float scale, int* argmax, void* stream);
+int hv_ca_softmax_backward(const float* dA, const float* A, const float* mm, float* dS, int B, int L, float scale, void* stream);
+int hv_transpose_batched(const float* src, float* dst, int B, int R, int C, void* stream); /* dst[b][c][r] = src[b][r][c] */
+/* Gs[b][i][j] = dS[b][j][i]*rnorm[b][i] + dS[b][i][j]*rnorm[b][j];  coef[b][l] = -(sum_p dS[p][l]*S0[p][l])/norm[l]^2 */
+int hv_ca_score_backward_prep(const float* dS, const float* S0, const float* norm, const float* rnorm, float* Gs, float* coef,
+                              int B, int L, void* stream);
+/* col2im of (dwp + coef*wp) back to the even positions of the full-resolution map (adjoint of hv_ca_patches). */
+int hv_ca_patches_backward(const float* dwp, const float* wp, const float* coef, float* df, int B, int H, int W, int C,
+                           int df_ld, int accumulate, void* stream);
+
+/* ---------------------------------------------------------------- step-level fused operators (Pix2PixModel)
+ * Sobel edge magnitude (models/edge_operator.py:29-49). */
+int hv_sobel(const float* img, float* out, int B, int H, int W, void* stream);
+/* Everything Pix2PixModel.forward does after netG (models/pix2pix_model.py:191-264), one launch, no host sync:
+ * pred_h = pred*maxheight; seg thresholds; SHRM compositing of fake_B / fake_B_coarse with per-sample row
+ * bounds computed on the device; local crops; writes rows[B][4] = {xu2, xb2, xu1, xb1}. */
+typedef struct {
+    const float* real_B; const float* mask; const float* x_stage1; const float* x_stage2;
+    const float* fine_seg; const float* coarse_seg; const float* pred1; const float* pred2;
+    const long long* height; const long long* x1; const long long* x2; const long long* maxheight;
+    float* fake_B; float* fake_B_coarse; float* fake_B_local; float* real_B_local;
+    float* fine_bin; float* coarse_bin; float* pred1_h; float* pred2_h; int* rows;
+    int B, H, W, half_band;
+} hv_postg_desc;
+int hv_post_generator(const hv_postg_desc* d, void* stream);
+/* Generic SHRM compositing of one image set (train.py:81-99, eval_3d_sagittal_twostage.py:103-130). */
+int hv_shrm_composite(const float* gen, const float* real, const float* pred_scaled, const long long* height,
+                      const long long* x1, const long long* x2, float* out, int* rows, int B, int H, int W, void* stream);
+
+/* GAN loss on PatchGAN logits (models/networks.py:212-278): loss (+)= weight*mean(l(z,t)); dz = weight_grad * dl/dz / n
+ * mode 0 vanilla (BCE with logits), 1 lsgan (MSE). loss may be NULL (gradient only) and dz may be NULL. */
+int hv_gan_loss(const float* z, long long n, int target_is_real, int mode, float loss_weight, float* loss, int loss_accumulate,
+                float grad_weight, float* dz, void* stream);
+
+/* Generator losses and their gradient seeds (models/pix2pix_model.py:331-353): writes
+ * losses[0..5] = {G_maskL1, G_Dice, coarse_Dice, edge, h, sum of those five} and the seeds
+ * d_fake_B (L1 part), d_fake_B_coarse, d_fine_seg, d_coarse_seg, d_pred1 (raw sigmoid output), d_pred2. */
+typedef struct {
+    const float* fake_B; const float* fake_B_coarse; const float* real_B; const float* mask;
+    const float* fine_seg; const float* coarse_seg; const float* real_B_mask; const float* normal_vert;
+    const float* fake_edges; const float* real_edges; const float* pred1_h; const float* pred2_h;
+    const long long* height; const long long* maxheight;
+    float lambda_L1;
+    float* losses; float* d_fake_B; float* d_fake_B_coarse; float* d_fine_seg; float* d_coarse_seg;
+    float* d_pred1; float* d_pred2;
+    int B, H, W;
+    float* workspace; size_t workspace_bytes;
+} hv_gloss_desc;
+size_t hv_generator_losses_workspace_bytes(int B);
+int hv_generator_losses(const hv_gloss_desc* d, void* stream);
+/* Gradient of the compositing + local crop: d_gen[row] = (d_fake[row] + d_local[row]*mask*band) for xu<=row<xb else 0.
+ * which: 0 -> rows[b][0..1] (stage 2), 1 -> rows[b][2..3] (stage 1). */
+int hv_shrm_backward(const float* d_fake, const float* d_local, const float* mask, const int* rows, int which,
+                     float* d_gen, int B, int H, int W, int half_band, int accumulate, void* stream);
+
+/* ---------------------------------------------------------------- optimiser
+ * Multi-tensor Adam, torch.optim.Adam semantics (models/pix2pix_model.py:127-130): one launch per optimiser.
+ * `state[0]` holds the step count as float (incremented by the kernel), lr is read from d_lr[0] so a captured
+ * graph follows the scheduler. */
+typedef struct { float* p; const float* g; float* m; float* v; long long n; } hv_adam_tensor;
+int hv_adam_step(const hv_adam_tensor* d_tensors, int n_tensors, long long max_numel, const float* d_lr, float beta1,
+                 float beta2, float eps, float* d_step, void* stream);
+
+/* misc */
+int hv_fill(float* p, long long n, float value, void* stream);
+int hv_axpy(float* y, const float* x, long long n, float a, void* stream); /* y += a*x */
+int hv_scale_rows(float* y, const float* x, long long n, float a, void* stream); /* y = a*x */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,156 @@
+"""hv_conv2d / hv_conv2d_wgrad (through the C ABI) against torch CPU fp32 convolutions.
+
+Tolerances: HV_F32 path (exact fp32 MFMA) |d| <= 1e-4 * scale (far inside the 1e-3 north-star gate);
+HV_F16 path (fp16 operands, fp32 accumulate) |d| <= 4e-3 * scale, reported only.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # B, H, W, Cin, CinP, Cout, k, stride, pad, dil, act
+    (2, 32, 32, 16, 16, 16, 3, 1, 1, 1, 'elu'),
+    (2, 32, 32, 3, 4, 16, 5, 1, 2, 1, 'elu'),
+    (2, 32, 32, 16, 16, 32, 3, 2, 1, 1, 'elu'),
+    (1, 64, 64, 64, 64, 64, 3, 1, 16, 16, 'elu'),
+    (2, 32, 32, 64, 64, 64, 3, 1, 4, 4, 'relu'),
+    (2, 32, 32, 1, 1, 64, 4, 2, 1, 1, 'lrelu'),
+    (2, 32, 32, 8, 8, 1, 3, 1, 1, 1, 'sigmoid'),
+    (2, 32, 32, 9, 12, 1, 3, 1, 1, 1, 'clamp'),
+    (2, 32, 32, 65, 68, 64, 3, 1, 1, 1, 'elu'),
+    (3, 31, 31, 128, 128, 256, 4, 1, 1, 1, 'none'),
+    (2, 16, 16, 256, 256, 1, 4, 1, 1, 1, 'none'),
+    (16, 64, 64, 64, 64, 128, 4, 2, 1, 1, 'none'),
+]
+
+
+def _mk(case, seed=0):
+    B, H, W, Cin, CinP, Cout, k, s, p, d, act = case
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    return x, w, b
+
+
+def _ref_act(y, act):
+    return {'elu': F.elu, 'relu': F.relu, 'lrelu': lambda t: F.leaky_relu(t, 0.2), 'sigmoid': torch.sigmoid,
+            'clamp': lambda t: t.clamp(-1, 1), 'none': lambda t: t}[act](y)
+
+
+@pytest.mark.parametrize('prec,tol', [('fp32', 1e-4), ('fp16', 4e-3)])
+@pytest.mark.parametrize('case', CASES)
+def test_conv_forward(case, prec, tol):
+    from hvtest import to_act, from_act, ohwi, dev, maxerr
+    from hvgan import ops
+    B, H, W, Cin, CinP, Cout, k, s, p, d, act = case
+    x, w, b = _mk(case)
+    ref = _ref_act(F.conv2d(x, w, b, stride=s, padding=p, dilation=d), act)
+    xa = to_act(x, CinP)
+    xa = ops.Act(xa.t, CinP, 0) if CinP % 4 == 0 else xa
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    ya = ops.Act.empty(B, Ho, Wo, Cout, dev())
+    ops.conv2d(xa, ohwi(w, CinP), ya, k, s, p, d, bias=b.to(dev()), act=act, precision=prec)
+    torch.cuda.synchronize()
+    err = maxerr(from_act(ya), ref)
+    assert err <= tol * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize('prec,tol', [('fp32', 1e-4), ('fp16', 4e-3)])
+@pytest.mark.parametrize('case', CASES)
+def test_conv_dgrad_is_transposed_gather(case, prec, tol):
+    """d/dx of conv == hv_conv2d(transposed=1) with the [Cin][taps][Cout] filter layout."""
+    from hvtest import to_act, from_act, ohwi_T, dev, maxerr
+    from hvgan import ops
+    B, H, W, Cin, CinP, Cout, k, s, p, d, act = case
+    x, w, b = _mk(case)
+    x.requires_grad_(True)
+    y = F.conv2d(x, w, None, stride=s, padding=p, dilation=d)
+    g = torch.randn(y.shape, generator=torch.Generator().manual_seed(1))
+    y.backward(g)
+    CoutP = (Cout + 3) // 4 * 4
+    ga = to_act(g, CoutP)
+    ga = ops.Act(ga.t, CoutP, 0)
+    dxa = ops.Act.empty(B, H, W, Cin, dev())
+    ops.conv2d(ga, ohwi_T(w, CoutP), dxa, k, s, p, d, transposed=True, precision=prec)
+    torch.cuda.synchronize()
+    err = maxerr(from_act(dxa), x.grad)
+    assert err <= tol * max(1.0, x.grad.abs().max().item()), err
+
+
+@pytest.mark.parametrize('prec,tol', [('fp32', 2e-4), ('fp16', 6e-3)])
+@pytest.mark.parametrize('case', CASES)
+def test_conv_wgrad(case, prec, tol):
+    from hvtest import to_act, ohwi, dev, maxerr
+    from hvgan import ops
+    B, H, W, Cin, CinP, Cout, k, s, p, d, act = case
+    x, w, b = _mk(case)
+    w.requires_grad_(True)
+    y = F.conv2d(x, w, None, stride=s, padding=p, dilation=d)
+    g = torch.randn(y.shape, generator=torch.Generator().manual_seed(2))
+    y.backward(g)
+    CinP4, CoutP = (CinP + 3) // 4 * 4, (Cout + 3) // 4 * 4
+    xa = to_act(x, CinP4)
+    xa = ops.Act(xa.t, CinP4, 0)
+    ga = to_act(g, CoutP)
+    ga = ops.Act(ga.t, CoutP, 0)
+    dw = torch.empty(CoutP, k * k, CinP4, device=dev())
+    ops.conv2d_wgrad(xa, ga, dw, k, s, p, d, precision=prec)
+    torch.cuda.synchronize()
+    got = dw[:Cout, :, :Cin].cpu().reshape(Cout, k, k, Cin).permute(0, 3, 1, 2)
+    err = maxerr(got, w.grad)
+    assert err <= tol * max(1.0, w.grad.abs().max().item()), err
+
+
+def test_conv_upsample_fused_and_transposed_conv_layer():
+    """in_shift=1 == conv(F.interpolate(x, 2)); transposed=1 == F.conv_transpose2d (k4 s2 p1)."""
+    from hvtest import to_act, from_act, ohwi, dev, maxerr
+    from hvgan import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 32, 16, 16, generator=g)
+    w = torch.randn(16, 32, 3, 3, generator=g) / 17.
+    ref = F.conv2d(F.interpolate(x, scale_factor=2, mode='nearest'), w, None, padding=1)
+    ya = ops.Act.empty(2, 32, 32, 16, dev())
+    ops.conv2d(to_act(x), ohwi(w), ya, 3, 1, 1, 1, in_shift=1, precision='fp32')
+    assert maxerr(from_act(ya), ref) <= 1e-4
+    wt = torch.randn(32, 8, 4, 4, generator=g) / 10.      # ConvTranspose2d weight [Cin][Cout][kh][kw]
+    ref = F.conv_transpose2d(x, wt, None, stride=2, padding=1)
+    wl = torch.zeros(8, 16, 32)
+    wl[:] = wt.permute(1, 2, 3, 0).reshape(8, 16, 32)
+    ya = ops.Act.empty(2, 32, 32, 8, dev())
+    ops.conv2d(to_act(x), wl.to(dev()), ya, 4, 2, 1, 1, transposed=True, precision='fp32')
+    assert maxerr(from_act(ya), ref) <= 1e-4
+
+
+def test_conv_per_sample_filters_and_accumulate_modes():
+    from hvtest import to_act, from_act, ohwi, dev, maxerr
+    from hvgan import ops
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 16, 16, 16, generator=g)
+    ws = [torch.randn(64, 16, 3, 3, generator=g) / 12. for _ in range(2)]
+    sc = torch.rand(2, 64, generator=g) + 0.5
+    ref = torch.cat([F.conv2d(x[i:i + 1], ws[i], None, padding=1) * sc[i].view(1, -1, 1, 1) for i in range(2)])
+    wb = torch.stack([ohwi(w) for w in ws]).contiguous()
+    ya = ops.Act.empty(2, 16, 16, 64, dev())
+    ops.conv2d(to_act(x), wb, ya, 3, 1, 1, 1, w_bstride=wb[0].numel(), ch_scale=sc.to(dev()), ch_scale_bstride=64, precision='fp32')
+    assert maxerr(from_act(ya), ref) <= 1e-4
+    # accumulate=1 adds after the activation; accumulate=2 before it
+    base = torch.randn(2, 64, 16, 16, generator=g)
+    ya = to_act(base)
+    ops.conv2d(to_act(x), ohwi(ws[0]), ya, 3, 1, 1, 1, accumulate=1, precision='fp32')
+    assert maxerr(from_act(ya), base + F.conv2d(x, ws[0], None, padding=1)) <= 1e-4
+    ya = to_act(base)
+    ops.conv2d(to_act(x), ohwi(ws[0]), ya, 3, 1, 1, 1, accumulate=2, act='elu', precision='fp32')
+    assert maxerr(from_act(ya), F.elu(base + F.conv2d(x, ws[0], None, padding=1))) <= 1e-4
+
+
+def test_conv_rejects_bad_arguments():
+    from hvtest import to_act, ohwi, dev
+    from hvgan import ops
+    x = torch.randn(1, 8, 8, 8)
+    w = torch.randn(8, 8, 3, 3)
+    ya = ops.Act.empty(1, 7, 8, 8, dev())            # wrong output height
+    with pytest.raises(RuntimeError):
+        ops.conv2d(to_act(x), ohwi(w), ya, 3, 1, 1, 1)
