@@ -313,7 +313,7 @@ static int dispatch_conv(ConvK& k, hipStream_t s) {
     if (k.w_bs || k.scale_bs) {  // per-sample operands: a tile must stay inside one image
         for (int c = 0; c < k.ncls; ++c)
             if ((k.cls[c].Hc * k.cls[c].Wc) % BM) {
-                if ((k.cls[c].Hc * k.cls[c].Wc) % 64 == 0 && BN >= 64) { BM = 64; BN = 64; }
+                if ((k.cls[c].Hc * k.cls[c].Wc) % 64 == 0) { BM = 64; BN = 64; }
                 else return HV_ERR_UNSUPPORTED;
             }
     }

@@ -122,7 +122,9 @@ __global__ __launch_bounds__(PREP_THREADS) void weight_prep_bwd_kernel(const hv_
         const long long r = i / L.taps;
         if (L.transposed_src) { co = (int)(r % L.Cout); ci = (int)(r / L.Cout); }
         else { ci = (int)(r % L.Cin); co = (int)(r / L.Cin); }
-        float g = L.dw_ohwi[((long long)co * L.taps + tap) * L.CinP + ci];
+        // conv: dw_ohwi is [co][tap][CinP]; conv_transpose (transposed_src): [ci][tap][CinP] with CinP = padded Cout
+        float g = L.transposed_src ? L.dw_ohwi[((long long)ci * L.taps + tap) * L.CinP + co]
+                                   : L.dw_ohwi[((long long)co * L.taps + tap) * L.CinP + ci];
         if (L.sn) g = (g - dot * L.u[co] * L.v[ci * L.taps + tap]) / sigma;
         L.dw_orig[i] = L.accumulate ? L.dw_orig[i] + g : g;
     }
@@ -306,9 +308,14 @@ extern "C" int hv_axpy(float* y, const float* x, long long n, float a, void* str
     HV_LAUNCH_CHECK();
     return HV_OK;
 }
-extern "C" int hv_scale_rows(float* y, const float* x, long long n, float a, void* stream) {
+__global__ void affine_kernel(float* y, const float* x, long long n, float a, float b) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long st = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += st) y[i] = a * x[i] + b;
+}
+extern "C" int hv_affine(float* y, const float* x, long long n, float a, float b, void* stream) {
     if (!y || !x || n <= 0) return HV_ERR_ARG;
-    hipLaunchKernelGGL(axpy_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, y, x, n, a, 1);
+    hipLaunchKernelGGL(affine_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, y, x, n, a, b);
     HV_LAUNCH_CHECK();
     return HV_OK;
 }

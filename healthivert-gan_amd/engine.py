@@ -1,0 +1,263 @@
+"""Explicit forward/backward executors of the hot path: sequences of libhvgan kernel launches over
+pre-allocated NHWC buffers, with no autograd tape, no host synchronisation and no allocation after
+the first call for a given shape (so a whole train step can be captured in a hipGraph).
+
+The nn.Modules of `models/` hold the parameters (reference state-dict keys) and delegate here.
+"""
+import ctypes
+
+import torch
+
+from . import lib as _lib
+from . import ops
+from .lib import ptr, stream
+from .ops import Act, rup
+
+
+# ================================================================================================ parameters
+class ConvParams:
+    """One convolution's parameters and their kernel-layout copies.
+
+    weight: [cout,cin,k,k] (or [cin,cout,k,k] with transposed_src, i.e. nn.ConvTranspose2d).
+    cin_fwd / cin_wg: channel width consumed by the forward gather / by the weight-gradient kernel
+    (equal except for a 1-channel image input, which the forward reads unpadded)."""
+
+    def __init__(self, name, weight, bias, cin, cout, k, cin_fwd=None, cin_wg=None, u=None, v=None, transposed_src=False):
+        self.name, self.weight, self.bias = name, weight, bias
+        self.cin, self.cout, self.k, self.taps = cin, cout, k, k * k
+        self.cin_fwd = rup(cin, 4) if cin_fwd is None else cin_fwd
+        self.cin_wg = rup(cin, 4) if cin_wg is None else cin_wg
+        self.coutP = rup(cout, 4)
+        self.u, self.v = u, v
+        self.sn = u is not None
+        self.transposed_src = transposed_src
+        self.w_fwd = self.w_bwd = self.sigma = self.dw = None
+
+    def sizes(self):
+        return (self.cout * self.taps * self.cin_fwd, self.cin_fwd * self.taps * self.coutP, self.coutP * self.taps * self.cin_wg)
+
+
+class ParamSet:
+    """All convolutions of one network: batched weight preparation (spectral norm + layouts), batched
+    weight-gradient finalisation, flat gradient storage (one all-reduce per network under DDP)."""
+
+    def __init__(self, convs, extra_params=()):
+        self.convs = list(convs)
+        self.extra = list(extra_params)          # other trainable tensors (fc, BN affine, biases are added automatically)
+        self.device = None
+        self.t_prep = {True: ops.LayerTable('hv_wprep_layer'), False: ops.LayerTable('hv_wprep_layer')}
+        self.t_bwd = {True: ops.LayerTable('hv_wprep_bwd_layer'), False: ops.LayerTable('hv_wprep_bwd_layer')}
+        self.flat_grad = None
+        self._key = None
+
+    def trainable(self):
+        seen, out = set(), []
+        for c in self.convs:
+            for p in (c.weight, c.bias):
+                if p is not None and id(p) not in seen:
+                    seen.add(id(p))
+                    out.append(p)
+        for p in self.extra:
+            if id(p) not in seen:
+                seen.add(id(p))
+                out.append(p)
+        return out
+
+    def _ensure(self, device):
+        key = tuple(p.data_ptr() for p in self.trainable()) + tuple(c.u.data_ptr() for c in self.convs if c.sn)
+        if key == self._key and self.device == device:
+            return
+        self._key, self.device = key, device
+        tot = sum(sum(c.sizes()) + 4 for c in self.convs)
+        store = torch.zeros(tot, dtype=torch.float32, device=device)
+        off = 0
+        for c in self.convs:
+            a, b, d = c.sizes()
+            c.w_fwd = store[off:off + a]; off += a
+            c.w_bwd = store[off:off + b]; off += b
+            c.dw = store[off:off + d]; off += d
+            c.sigma = store[off:off + 4]; off += 4
+        self._store = store
+        # flat gradients; .grad of every trainable tensor is a view into it
+        ps = self.trainable()
+        n = sum(p.numel() for p in ps)
+        self.flat_grad = torch.zeros(n, dtype=torch.float32, device=device)
+        off = 0
+        for p in ps:
+            p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        for pi in (True, False):
+            rows = []
+            for c in self.convs:
+                rows.append(dict(w_orig=c.weight.data, u=c.u if c.sn else None, v=c.v if c.sn else None, sigma=c.sigma,
+                                 w_fwd=c.w_fwd, w_bwd=c.w_bwd, Cout=c.cout, Cin=c.cin, taps=c.taps, CinP=c.cin_fwd,
+                                 CoutF=c.cout, CoutP=c.coutP, CinB=c.cin_fwd, sn=int(c.sn), power_iter=int(pi and c.sn),
+                                 transposed_src=int(c.transposed_src)))
+            self.t_prep[pi].update(rows, key, device)
+        for acc in (True, False):
+            rows = []
+            for c in self.convs:
+                rows.append(dict(dw_ohwi=c.dw, w_fwd=c.w_fwd, u=c.u if c.sn else None, v=c.v if c.sn else None, sigma=c.sigma,
+                                 dw_orig=c.weight.grad, Cout=c.cout, Cin=c.cin, taps=c.taps,
+                                 CinP=c.coutP if c.transposed_src else c.cin_wg, sn=int(c.sn),
+                                 transposed_src=int(c.transposed_src), accumulate=int(acc)))
+            self.t_bwd[acc].update(rows, key, device)
+
+    def attach_grads(self):
+        """Re-point .grad at the flat buffer (optimizer.zero_grad(set_to_none=True) drops the views)."""
+        off = 0
+        for p in self.trainable():
+            n = p.numel()
+            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * off:
+                p.grad = self.flat_grad[off:off + n].view_as(p)
+            off += n
+
+    def prep(self, device, power_iter):
+        self._ensure(device)
+        ops.weight_prep(self.t_prep[bool(power_iter)])
+
+    def finish_backward(self, accumulate=False):
+        """Kernel-layout weight gradients -> .grad of weight_orig / weight (spectral-norm backward included)."""
+        ops.weight_prep_backward(self.t_bwd[bool(accumulate)])
+
+
+class ConvNode:
+    """conv (+bias +activation) between two NHWC views; knows how to run forward and backward."""
+    __slots__ = ('p', 'x', 'y', 'k', 's', 'pad', 'd', 'act', 'shift', 'need_dx', 'transposed', 'use_bias')
+
+    def __init__(self, p, x, y, s=1, pad=0, d=1, act='none', shift=0, need_dx=True, transposed=False, use_bias=True):
+        self.p, self.x, self.y, self.k, self.s, self.pad, self.d = p, x, y, p.k, s, pad, d
+        self.act, self.shift, self.need_dx, self.transposed, self.use_bias = act, shift, need_dx, transposed, use_bias
+
+    def forward(self, prec):
+        p = self.p
+        xin = Act(self.x.t, p.cin_fwd, self.x.coff)
+        ops.conv2d(xin, p.w_fwd, self.y, self.k, self.s, self.pad, self.d, bias=p.bias if self.use_bias else None, act=self.act,
+                   in_shift=self.shift, transposed=self.transposed, precision=prec, cout=p.cout)
+
+
+class GradBook:
+    """Gradient twins of activation buffers; first write assigns, later writes accumulate."""
+
+    def __init__(self):
+        self.twins = {}
+        self.written = set()
+
+    def twin(self, a):
+        t = self.twins.get(id(a.t))
+        if t is None:
+            t = torch.zeros_like(a.t)
+            self.twins[id(a.t)] = t
+        return Act(t, a.C, a.coff)
+
+    def reset(self):
+        self.written.clear()
+
+    def mark(self, a):
+        """-> accumulate flag for a write into the gradient of view `a`."""
+        key = (id(a.t), a.coff, a.C)
+        acc = key in self.written
+        self.written.add(key)
+        return acc
+
+
+def conv_backward(node, book, prec, dbias_accumulate=False, wgrad_accumulate=False, tmp_full=None, wgrad=True, x_wg=None):
+    """Backward of one ConvNode: activation gradient (+bias gradient), weight gradient, data gradient.
+    x_wg: channel-padded copy of the input for the weight-gradient kernel (1-channel image inputs)."""
+    p = node.p
+    gy = book.twin(node.y)
+    if node.act != 'none' or (p.bias is not None and node.use_bias):
+        ops.act_backward(gy, node.y, node.act, dbias=p.bias.grad if (p.bias is not None and node.use_bias and wgrad) else None,
+                         dbias_accumulate=dbias_accumulate)
+    gfull = Act(gy.t, p.coutP, gy.coff)
+    if wgrad:
+        xs = node.x if x_wg is None else x_wg
+        xin = Act(xs.t, p.cin_wg, xs.coff)
+        if node.transposed:
+            # y = conv_transpose(x): the weight gradient is that of a strided conv with the roles of x and g swapped;
+            # the result is laid out [cin][taps][coutP] (hv_weight_prep_backward knows, transposed_src)
+            ops.conv2d_wgrad(gfull, xin, p.dw, node.k, node.s, node.pad, node.d, accumulate=wgrad_accumulate, precision=prec)
+        else:
+            ops.conv2d_wgrad(xin, gfull, p.dw, node.k, node.s, node.pad, node.d, in_shift=node.shift, accumulate=wgrad_accumulate,
+                             precision=prec)
+    if node.need_dx and node.transposed:
+        gx = book.twin(node.x)
+        gx = Act(gx.t, p.cin_fwd, gx.coff)
+        ops.conv2d(gfull, p.w_bwd, gx, node.k, node.s, node.pad, node.d, transposed=False, accumulate=int(book.mark(gx)), precision=prec)
+    elif node.need_dx:
+        gx = book.twin(node.x)
+        gx = Act(gx.t, p.cin_fwd, gx.coff)
+        if node.shift:
+            full = tmp_full
+            ops.conv2d(gfull, p.w_bwd, full, node.k, node.s, node.pad, node.d, transposed=True, precision=prec)
+            ops.copy_channels(full, gx, mode=3, accumulate=book.mark(gx))
+        else:
+            ops.conv2d(gfull, p.w_bwd, gx, node.k, node.s, node.pad, node.d, transposed=True, accumulate=int(book.mark(gx)),
+                       precision=prec)
+
+
+# ================================================================================================ contextual attention
+class AttentionPlan:
+    """ContextualAttention(ksize=3, stride=1, rate=2, fuse_k=3, softmax_scale=10, fuse=True) on an NHWC feature map
+    (reference models/inpaint_networks.py:235-410)."""
+
+    def __init__(self, B, H, W, C, device, img_hw, scale=10.0, fuse=True):
+        self.B, self.H, self.W, self.C = B, H, W, C
+        self.h, self.w = H // 2, W // 2
+        assert self.h == self.w and H % 2 == 0, "contextual attention expects a square, even-sized feature map"
+        self.L = L = self.h * self.w
+        self.img_hw, self.scale, self.fuse = img_hw, scale, fuse
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=device)
+        self.fd = Act(z(B, self.h, self.w, C))
+        self.wp, self.wpT = z(B, L, 9 * C), z(B, 9 * C, L)
+        self.norm, self.rnorm = z(B, L), z(B, L)
+        self.raw, self.rawT = z(B, L, 16 * C), z(B, C, 16 * L)
+        self.mm = z(L)
+        self.S0, self.S1, self.A = Act(z(B, self.h, self.w, L)), Act(z(B, self.h, self.w, L)), Act(z(B, self.h, self.w, L))
+        self.argmax = torch.zeros(B * L, dtype=torch.int32, device=device)
+        self.bw = None
+
+    def forward(self, f, mask_img, out, prec, want_argmax=False):
+        """f: Act [B,H,W,C] (foreground == background), mask_img: (B,1,Himg,Wimg) tensor, out: Act [B,H,W,C]."""
+        L_ = _lib.get()
+        B, H, W, C, L = self.B, self.H, self.W, self.C, self.L
+        L_.call('hv_ca_patches', ptr(f.t), B, H, W, C, f.ld, ptr(self.fd.t), ptr(self.wp), ptr(self.wpT), ptr(self.norm), ptr(self.rnorm), stream())
+        L_.call('hv_ca_raw_patches', ptr(f.t), B, H, W, C, f.ld, ptr(self.raw), ptr(self.rawT), stream())
+        L_.call('hv_ca_mask', ptr(mask_img), self.img_hw[0], self.img_hw[1], self.h, self.w, ptr(self.mm), stream())
+        ops.conv2d(self.fd, self.wp, self.S0, 3, 1, 1, 1, w_bstride=L * 9 * C, ch_scale=self.rnorm, ch_scale_bstride=L, precision=prec)
+        if self.fuse:
+            L_.call('hv_ca_fuse', ptr(self.S0.t), ptr(self.S1.t), B, self.h, self.w, 0, stream())
+            s = self.S1
+        else:
+            s = self.S0
+        L_.call('hv_ca_softmax', ptr(s.t), ptr(self.mm), ptr(self.A.t), B, L, ctypes.c_float(self.scale),
+                ptr(self.argmax) if want_argmax else None, stream())
+        ops.conv2d(self.A, self.rawT, out, 4, 2, 1, 1, transposed=True, alpha=0.25, w_bstride=C * 16 * L, precision=prec)
+
+    def backward(self, dout, df, accumulate, prec):
+        """dout: Act grad of the output; df: Act grad of the input feature map (assigned or accumulated)."""
+        L_ = _lib.get()
+        B, H, W, C, L = self.B, self.H, self.W, self.C, self.L
+        if self.bw is None:
+            z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dout.t.device)
+            self.bw = dict(dA=Act(z(B, self.h, self.w, L)), AT=Act(z(B, self.h, self.w, L)), dOrawT=z(B, C, 16 * L),
+                           dS1=Act(z(B, self.h, self.w, L)), dS0=Act(z(B, self.h, self.w, L)), Gs=Act(z(B, self.h, self.w, L)),
+                           coef=z(B, L), dwp=Act(z(B, self.h, self.w, 9 * C)))
+        bw = self.bw
+        # through the paste: dA and d(raw patches)
+        ops.conv2d(dout, self.raw, bw['dA'], 4, 2, 1, 1, alpha=0.25, w_bstride=L * 16 * C, precision=prec)
+        L_.call('hv_transpose_batched', ptr(self.A.t), ptr(bw['AT'].t), B, L, L, stream())
+        L_.call('hv_ca_raw_patches', ptr(dout.t), B, H, W, C, dout.ld, None, ptr(bw['dOrawT']), stream())
+        ops.conv2d(bw['AT'], bw['dOrawT'], df, 4, 2, 1, 1, transposed=True, alpha=0.25, w_bstride=C * 16 * L,
+                   accumulate=int(accumulate), precision=prec)
+        # through softmax and score fusion
+        L_.call('hv_ca_softmax_backward', ptr(bw['dA'].t), ptr(self.A.t), ptr(self.mm), ptr(bw['dS1'].t), B, L, ctypes.c_float(self.scale), stream())
+        if self.fuse:
+            L_.call('hv_ca_fuse', ptr(bw['dS1'].t), ptr(bw['dS0'].t), B, self.h, self.w, 1, stream())
+            ds0 = bw['dS0']
+        else:
+            ds0 = bw['dS1']
+        # through the normalised patch matching (patches act as both filters and inputs)
+        L_.call('hv_ca_score_backward_prep', ptr(ds0.t), ptr(self.S0.t), ptr(self.norm), ptr(self.rnorm), ptr(bw['Gs'].t), ptr(bw['coef']), B, L, stream())
+        ops.conv2d(bw['Gs'], self.wpT, bw['dwp'], 1, 1, 0, 1, w_bstride=9 * C * L, precision=prec)
+        L_.call('hv_ca_patches_backward', ptr(bw['dwp'].t), ptr(self.wp), ptr(bw['coef']), ptr(df.t), B, H, W, C, df.ld, 1, stream())

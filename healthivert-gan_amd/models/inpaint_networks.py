@@ -1,0 +1,500 @@
+"""Two-stage inpainting generator on hand-written gfx950 kernels.
+
+API mirror of the reference `models/inpaint_networks.py` (same class names, constructor signatures,
+state-dict keys and 7-tuple return: reference :16-32, :36-117, :120-232, :235-410, :413-503), but
+the forward/backward are explicit kernel sequences from `engine.py` over NHWC buffers; the torch
+modules created here are parameter containers only (their own forward is never run).
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+from torch.nn.utils import spectral_norm as _sn_register
+
+from .. import engine as E
+from .. import lib as _lib
+from .. import ops
+from ..lib import ptr, stream
+from ..ops import Act, rup
+
+_ACTS = ('relu', 'elu', 'lrelu', 'prelu', 'selu', 'tanh', 'sigmoid', 'none')
+
+
+class Conv2dBlock(nn.Module):
+    """Parameter container with the reference's keys: conv.bias, conv.weight_orig, conv.weight_u, conv.weight_v
+    (reference :420-503).  Only the configuration the generator uses is executable on the HIP path:
+    zero padding, spectral norm, no norm layer, activation in {elu, relu, sigmoid, none}."""
+
+    def __init__(self, input_dim, output_dim, kernel_size, stride, padding=0, conv_padding=0, dilation=1, weight_norm='sn',
+                 norm='none', activation='relu', pad_type='zero', transpose=False):
+        super().__init__()
+        assert pad_type in ('reflect', 'replicate', 'zero', 'none'), "Unsupported padding type: {}".format(pad_type)
+        assert norm in ('bn', 'in', 'none'), "Unsupported normalization: {}".format(norm)
+        assert weight_norm in ('sn', 'wn', 'none'), "Unsupported normalization: {}".format(weight_norm)
+        assert activation in _ACTS, "Unsupported activation: {}".format(activation)
+        if pad_type != 'zero' or padding != 0 or norm != 'none' or weight_norm != 'sn' or transpose or \
+                activation not in ('elu', 'relu', 'sigmoid', 'none'):
+            raise NotImplementedError("Conv2dBlock: only the generator's configuration (zero pad, spectral norm, no norm layer, "
+                                      "elu/relu/sigmoid/none) has a HIP kernel path")
+        self.use_bias = True
+        self.activation_name = activation
+        self.cin, self.cout, self.k, self.stride, self.conv_padding, self.dilation = input_dim, output_dim, kernel_size, stride, conv_padding, dilation
+        # identical parameter creation (and RNG consumption) to nn.Conv2d + spectral_norm; the hook is removed so the
+        # power iteration runs in hv_weight_prep instead.
+        conv = _sn_register(nn.Conv2d(input_dim, output_dim, kernel_size, stride, padding=conv_padding, dilation=dilation, bias=True))
+        for hid, hook in list(conv._forward_pre_hooks.items()):
+            if type(hook).__name__ == 'SpectralNorm':
+                del conv._forward_pre_hooks[hid]
+        if 'weight' in conv.__dict__:
+            del conv.__dict__['weight']
+        self.conv = conv
+
+    def params(self, name, cin_fwd=None):
+        c = self.conv
+        return E.ConvParams(name, c.weight_orig, c.bias, self.cin, self.cout, self.k, cin_fwd=cin_fwd, cin_wg=cin_fwd,
+                            u=c.weight_u, v=c.weight_v)
+
+    def forward(self, x):
+        raise RuntimeError("Conv2dBlock is executed through Generator (explicit HIP kernel sequence), not stand-alone")
+
+
+def gen_conv(input_dim, output_dim, kernel_size=3, stride=1, padding=0, rate=1, activation='elu'):
+    return Conv2dBlock(input_dim, output_dim, kernel_size, stride, conv_padding=padding, dilation=rate, activation=activation)
+
+
+class CoarseGenerator(nn.Module):
+    def __init__(self, input_dim, cnum, use_cuda):
+        super().__init__()
+        self.use_cuda = use_cuda
+        self.cnum = cnum
+        self.conv1 = gen_conv(input_dim + 2, cnum, 5, 1, 2)
+        self.conv2_downsample = gen_conv(cnum, cnum * 2, 3, 2, 1)
+        self.conv3 = gen_conv(cnum * 2, cnum * 2, 3, 1, 1)
+        self.conv4_downsample = gen_conv(cnum * 2, cnum * 4, 3, 2, 1)
+        self.conv5 = gen_conv(cnum * 4, cnum * 4, 3, 1, 1)
+        self.conv6 = gen_conv(cnum * 4, cnum * 4, 3, 1, 1)
+        self.conv7_atrous = gen_conv(cnum * 4, cnum * 4, 3, 1, 2, rate=2)
+        self.conv8_atrous = gen_conv(cnum * 4, cnum * 4, 3, 1, 4, rate=4)
+        self.conv9_atrous = gen_conv(cnum * 4, cnum * 4, 3, 1, 8, rate=8)
+        self.conv10_atrous = gen_conv(cnum * 4, cnum * 4, 3, 1, 16, rate=16)
+        self.conv11 = gen_conv(cnum * 4, cnum * 4, 3, 1, 1)
+        self.conv12 = gen_conv(cnum * 4, cnum * 4, 3, 1, 1)
+        self.conv20 = gen_conv(cnum * 4 + 1, cnum * 4, 3, 1, 1)
+        self.conv13 = gen_conv(cnum * 4, cnum * 2, 3, 1, 1)
+        self.conv14 = gen_conv(cnum * 2, cnum * 2, 3, 1, 1)
+        self.conv19 = gen_conv(cnum * 2 + 1, cnum * 2, 3, 1, 1)
+        self.conv15 = gen_conv(cnum * 2, cnum, 3, 1, 1)
+        self.conv16 = gen_conv(cnum, cnum // 2, 3, 1, 1)
+        self.conv17 = gen_conv(cnum // 2, input_dim, 3, 1, 1, activation='none')
+        self.conv18 = gen_conv(cnum // 2, input_dim, 3, 1, 1, activation='sigmoid')
+        self.global_pool = nn.AdaptiveAvgPool2d(1)
+        self.fc_height = nn.Linear(cnum * 4, 1)
+
+    def forward(self, x, mask, CAM, slice_ratio):
+        raise RuntimeError("CoarseGenerator runs as part of Generator's fused kernel sequence")
+
+
+class FineGenerator(nn.Module):
+    def __init__(self, input_dim, cnum, use_cuda=True):
+        super().__init__()
+        self.use_cuda = use_cuda
+        self.cnum = cnum
+        self.conv1 = gen_conv(input_dim + 3, cnum, 5, 1, 2)
+        self.conv2_downsample = gen_conv(cnum, cnum, 3, 2, 1)
+        self.conv3 = gen_conv(cnum, cnum * 2, 3, 1, 1)
+        self.conv4_downsample = gen_conv(cnum * 2, cnum * 2, 3, 2, 1)
+        self.conv5 = gen_conv(cnum * 2, cnum * 4, 3, 1, 1)
+        self.conv6 = gen_conv(cnum * 4, cnum * 4, 3, 1, 1)
+        self.conv7_atrous = gen_conv(cnum * 4, cnum * 4, 3, 1, 2, rate=2)
+        self.conv8_atrous = gen_conv(cnum * 4, cnum * 4, 3, 1, 4, rate=4)
+        self.conv9_atrous = gen_conv(cnum * 4, cnum * 4, 3, 1, 8, rate=8)
+        self.conv10_atrous = gen_conv(cnum * 4, cnum * 4, 3, 1, 16, rate=16)
+        self.pmconv1 = gen_conv(input_dim + 3, cnum, 5, 1, 2)
+        self.pmconv2_downsample = gen_conv(cnum, cnum, 3, 2, 1)
+        self.pmconv3 = gen_conv(cnum, cnum * 2, 3, 1, 1)
+        self.pmconv4_downsample = gen_conv(cnum * 2, cnum * 4, 3, 2, 1)
+        self.pmconv5 = gen_conv(cnum * 4, cnum * 4, 3, 1, 1)
+        self.pmconv6 = gen_conv(cnum * 4, cnum * 4, 3, 1, 1, activation='relu')
+        self.contextul_attention = ContextualAttention(self.use_cuda, ksize=3, stride=1, rate=2, fuse_k=3, softmax_scale=10, fuse=True)
+        self.pmconv9 = gen_conv(cnum * 4, cnum * 4, 3, 1, 1)
+        self.pmconv10 = gen_conv(cnum * 4, cnum * 4, 3, 1, 1)
+        self.allconv11 = gen_conv(cnum * 8, cnum * 4, 3, 1, 1)
+        self.allconv19 = gen_conv(cnum * 4, cnum * 4, 3, 1, 1)
+        self.allconv12 = gen_conv(cnum * 4, cnum * 4, 3, 1, 1)
+        self.allconv13 = gen_conv(cnum * 4, cnum * 2, 3, 1, 1)
+        self.allconv14 = gen_conv(cnum * 2, cnum * 2, 3, 1, 1)
+        self.allconv15 = gen_conv(cnum * 2, cnum, 3, 1, 1)
+        self.allconv16 = gen_conv(cnum, cnum // 2, 3, 1, 1)
+        self.allconv17 = gen_conv(cnum // 2 + 1, 1, 3, 1, 1, activation='none')
+        self.allconv18 = gen_conv(cnum // 2 + 1, 1, 3, 1, 1, activation='sigmoid')
+        self.global_pool = nn.AdaptiveAvgPool2d(1)
+        self.fc_height = nn.Linear(cnum * 4, 1)
+
+    def forward(self, xin, x_stage1, mask, coarse_seg, slice_ratio):
+        raise RuntimeError("FineGenerator runs as part of Generator's fused kernel sequence")
+
+
+class ContextualAttention(nn.Module):
+    """Contextual attention (Yu et al.) with the reference's signature (reference :235-410).  Stand-alone calls take
+    NCHW tensors with f is b; inside Generator the NHWC plan is used directly."""
+
+    def __init__(self, use_cuda, ksize=3, stride=1, rate=1, fuse_k=3, softmax_scale=10, fuse=False):
+        super().__init__()
+        self.ksize, self.stride, self.rate, self.fuse_k, self.softmax_scale, self.fuse, self.use_cuda = \
+            ksize, stride, rate, fuse_k, softmax_scale, fuse, use_cuda
+        self._plans = {}
+
+    def check(self):
+        if not (self.ksize == 3 and self.stride == 1 and self.rate == 2 and self.fuse_k == 3):
+            raise NotImplementedError("ContextualAttention HIP path: ksize=3, stride=1, rate=2, fuse_k=3 only")
+
+    def plan(self, B, H, W, C, device, img_hw):
+        self.check()
+        key = (B, H, W, C, str(device), img_hw)
+        if key not in self._plans:
+            self._plans[key] = E.AttentionPlan(B, H, W, C, device, img_hw, float(self.softmax_scale), bool(self.fuse))
+        return self._plans[key]
+
+    def forward(self, f, b, mask=None):
+        if f is not b and not torch.equal(f, b):
+            raise NotImplementedError("ContextualAttention HIP path expects foreground and background to be the same tensor")
+        _lib.require_gpu(f)
+        B, C, H, W = f.shape
+        if mask is None:
+            mask = torch.zeros(B, 1, 4 * H, 4 * W, device=f.device)
+        fa = ops.from_nchw(f.detach())
+        out = Act.empty(B, H, W, C, f.device)
+        pl = self.plan(B, H, W, C, f.device, (mask.shape[2], mask.shape[3]))
+        pl.forward(fa, mask.contiguous().float(), out, ops.default_precision(), want_argmax=True)
+        y = out.nchw()
+        flow = offsets_to_flow(pl.argmax, B, pl.h, pl.w, self.rate)
+        if f.requires_grad and torch.is_grad_enabled():
+            return _AttentionFn.apply(f, y, pl, fa), flow
+        return y, flow
+
+
+class _AttentionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, f, y, plan, fa):
+        ctx.plan, ctx.shape = plan, f.shape
+        return y.clone()
+
+    @staticmethod
+    def backward(ctx, gy):
+        B, C, H, W = ctx.shape
+        g = ops.from_nchw(gy.contiguous())
+        df = Act.empty(B, H, W, C, gy.device)
+        ctx.plan.backward(g, df, False, ops.default_precision())
+        return df.nchw(), None, None, None
+
+
+def offsets_to_flow(argmax, B, h, w, rate):
+    """offset_flow slot of the 7-tuple: the reference colours the arg-max offsets with a NumPy colour wheel on the
+    host (inpaint_tools.py:73-100), forcing a device sync every forward, and nothing downstream consumes it
+    (pix2pix_model.py:82-87).  The arg-max indices are produced on the device; the colour-wheel image is visualisation
+    only and is returned as zeros of the right shape."""
+    return torch.zeros(B, 3, h * rate * 4, w * rate * 4, device=argmax.device)
+
+
+# ================================================================================================ generator plan
+class _GenPlan:
+    """Buffers + node list of Generator for one (B, H, W)."""
+
+    def __init__(self, gen, B, H, W, device):
+        cg, fg = gen.coarse_generator, gen.fine_generator
+        c = gen.cnum
+        self.B, self.H, self.W, self.dev = B, H, W, device
+        z = lambda h, w, C: Act(torch.zeros(B, h, w, rup(C, 4), dtype=torch.float32, device=device), C, 0)
+        img = lambda: torch.zeros(B, 1, H, W, dtype=torch.float32, device=device)
+        H2, W2, H4, W4 = H // 2, W // 2, H // 4, W // 4
+        self.book = E.GradBook()
+        P = gen._pset_convs
+        N = E.ConvNode
+        # ---------------- coarse
+        self.c_in = z(H, W, 3)
+        a = {}
+        a['c1'] = z(H, W, c); a['c2'] = z(H2, W2, 2 * c); a['c3'] = z(H2, W2, 2 * c); a['c4'] = z(H4, W4, 4 * c)
+        for n in ('c5', 'c6', 'c7', 'c8', 'c9', 'c10', 'c11', 'c12'):
+            a[n] = z(H4, W4, 4 * c)
+        a['cat20'] = z(H2, W2, 4 * c + 1); a['c20'] = z(H2, W2, 4 * c); a['c13'] = z(H2, W2, 2 * c); a['c14'] = z(H2, W2, 2 * c)
+        a['cat19'] = z(H, W, 2 * c + 1); a['c19'] = z(H, W, 2 * c); a['c15'] = z(H, W, c); a['c16'] = z(H, W, c // 2)
+        self.x_stage1, self.coarse_seg = img(), img()
+        xs1 = Act(self.x_stage1.view(B, H, W, 1)); cs = Act(self.coarse_seg.view(B, H, W, 1))
+        self.c_nodes = [
+            N(P['coarse_generator.conv1'], self.c_in, a['c1'], 1, 2, 1, 'elu', need_dx=False),
+            N(P['coarse_generator.conv2_downsample'], a['c1'], a['c2'], 2, 1, 1, 'elu'),
+            N(P['coarse_generator.conv3'], a['c2'], a['c3'], 1, 1, 1, 'elu'),
+            N(P['coarse_generator.conv4_downsample'], a['c3'], a['c4'], 2, 1, 1, 'elu'),
+            N(P['coarse_generator.conv5'], a['c4'], a['c5'], 1, 1, 1, 'elu'),
+            N(P['coarse_generator.conv6'], a['c5'], a['c6'], 1, 1, 1, 'elu'),
+            N(P['coarse_generator.conv7_atrous'], a['c6'], a['c7'], 1, 2, 2, 'elu'),
+            N(P['coarse_generator.conv8_atrous'], a['c7'], a['c8'], 1, 4, 4, 'elu'),
+            N(P['coarse_generator.conv9_atrous'], a['c8'], a['c9'], 1, 8, 8, 'elu'),
+            N(P['coarse_generator.conv10_atrous'], a['c9'], a['c10'], 1, 16, 16, 'elu'),
+            N(P['coarse_generator.conv11'], a['c10'], a['c11'], 1, 1, 1, 'elu'),
+            N(P['coarse_generator.conv12'], a['c11'], a['c12'], 1, 1, 1, 'elu'),
+            N(P['coarse_generator.conv20'], a['cat20'], a['c20'], 1, 1, 1, 'elu'),
+            N(P['coarse_generator.conv13'], a['c20'], a['c13'], 1, 1, 1, 'elu'),
+            N(P['coarse_generator.conv14'], a['c13'], a['c14'], 1, 1, 1, 'elu'),
+            N(P['coarse_generator.conv19'], a['cat19'], a['c19'], 1, 1, 1, 'elu'),
+            N(P['coarse_generator.conv15'], a['c19'], a['c15'], 1, 1, 1, 'elu'),
+            N(P['coarse_generator.conv16'], a['c15'], a['c16'], 1, 1, 1, 'elu'),
+            N(P['coarse_generator.conv17'], a['c16'], xs1, 1, 1, 1, 'clamp'),
+            N(P['coarse_generator.conv18'], a['c16'], cs, 1, 1, 1, 'sigmoid'),
+        ]
+        self.c_pool = torch.zeros(B, 4 * c, device=device); self.pred1 = torch.zeros(B, 1, device=device)
+        # ---------------- fine
+        self.f_in = z(H, W, 4)
+        a['f1'] = z(H, W, c); a['f2'] = z(H2, W2, c); a['f3'] = z(H2, W2, 2 * c); a['f4'] = z(H4, W4, 2 * c)
+        for n in ('f5', 'f6', 'f7', 'f8', 'f9'):
+            a[n] = z(H4, W4, 4 * c)
+        a['cat11'] = z(H4, W4, 8 * c)
+        a['p1'] = z(H, W, c); a['p2'] = z(H2, W2, c); a['p3'] = z(H2, W2, 2 * c)
+        for n in ('p4', 'p5', 'p6', 'ca', 'p9'):
+            a[n] = z(H4, W4, 4 * c)
+        for n in ('a11', 'a12', 'a19'):
+            a[n] = z(H4, W4, 4 * c)
+        a['a13'] = z(H2, W2, 2 * c); a['a14'] = z(H2, W2, 2 * c); a['a15'] = z(H, W, c)
+        a['cat17'] = z(H, W, c // 2 + 1)
+        self.x_stage2, self.fine_seg = img(), img()
+        xs2 = Act(self.x_stage2.view(B, H, W, 1)); fs = Act(self.fine_seg.view(B, H, W, 1))
+        hallu, pm = a['cat11'].slice(0, 4 * c), a['cat11'].slice(4 * c, 4 * c)
+        a16 = a['cat17'].slice(0, c // 2)
+        fp = 'fine_generator.'
+        self.f_nodes_conv = [
+            N(P[fp + 'conv1'], self.f_in, a['f1'], 1, 2, 1, 'elu'),
+            N(P[fp + 'conv2_downsample'], a['f1'], a['f2'], 2, 1, 1, 'elu'),
+            N(P[fp + 'conv3'], a['f2'], a['f3'], 1, 1, 1, 'elu'),
+            N(P[fp + 'conv4_downsample'], a['f3'], a['f4'], 2, 1, 1, 'elu'),
+            N(P[fp + 'conv5'], a['f4'], a['f5'], 1, 1, 1, 'elu'),
+            N(P[fp + 'conv6'], a['f5'], a['f6'], 1, 1, 1, 'elu'),
+            N(P[fp + 'conv7_atrous'], a['f6'], a['f7'], 1, 2, 2, 'elu'),
+            N(P[fp + 'conv8_atrous'], a['f7'], a['f8'], 1, 4, 4, 'elu'),
+            N(P[fp + 'conv9_atrous'], a['f8'], a['f9'], 1, 8, 8, 'elu'),
+            N(P[fp + 'conv10_atrous'], a['f9'], hallu, 1, 16, 16, 'elu'),
+        ]
+        self.f_nodes_pm = [
+            N(P[fp + 'pmconv1'], self.f_in, a['p1'], 1, 2, 1, 'elu'),
+            N(P[fp + 'pmconv2_downsample'], a['p1'], a['p2'], 2, 1, 1, 'elu'),
+            N(P[fp + 'pmconv3'], a['p2'], a['p3'], 1, 1, 1, 'elu'),
+            N(P[fp + 'pmconv4_downsample'], a['p3'], a['p4'], 2, 1, 1, 'elu'),
+            N(P[fp + 'pmconv5'], a['p4'], a['p5'], 1, 1, 1, 'elu'),
+            N(P[fp + 'pmconv6'], a['p5'], a['p6'], 1, 1, 1, 'relu'),
+        ]
+        self.f_nodes_pm2 = [
+            N(P[fp + 'pmconv9'], a['ca'], a['p9'], 1, 1, 1, 'elu'),
+            N(P[fp + 'pmconv10'], a['p9'], pm, 1, 1, 1, 'elu'),
+        ]
+        self.f_nodes_merge = [
+            N(P[fp + 'allconv11'], a['cat11'], a['a11'], 1, 1, 1, 'elu'),
+            N(P[fp + 'allconv12'], a['a11'], a['a12'], 1, 1, 1, 'elu'),
+            N(P[fp + 'allconv19'], a['a12'], a['a19'], 1, 1, 1, 'elu'),
+            N(P[fp + 'allconv13'], a['a19'], a['a13'], 1, 1, 1, 'elu', shift=1),
+            N(P[fp + 'allconv14'], a['a13'], a['a14'], 1, 1, 1, 'elu'),
+            N(P[fp + 'allconv15'], a['a14'], a['a15'], 1, 1, 1, 'elu', shift=1),
+            N(P[fp + 'allconv16'], a['a15'], a16, 1, 1, 1, 'elu'),
+            N(P[fp + 'allconv17'], a['cat17'], xs2, 1, 1, 1, 'clamp'),
+            N(P[fp + 'allconv18'], a['cat17'], fs, 1, 1, 1, 'sigmoid'),
+        ]
+        self.f_pool = torch.zeros(B, 4 * c, device=device); self.pred2 = torch.zeros(B, 1, device=device)
+        self.a = a
+        self.attn = fg.contextul_attention.plan(B, H4, W4, 4 * c, device, (H, W))
+        # full-resolution scratch for the data gradients of the two fused-upsample convolutions
+        self.tmp_up = {}
+        # 4-channel padded carriers for the 1-channel head gradients
+        self.g_head = {n: z(H, W, 1) for n in ('c17', 'c18', 'f17', 'f18')}
+
+
+class Generator(nn.Module):
+    def __init__(self, config, use_cuda):
+        super().__init__()
+        self.input_dim = config['input_dim']
+        self.cnum = config['ngf']
+        self.use_cuda = use_cuda
+        if self.input_dim != 1:
+            raise NotImplementedError("Generator HIP path: input_dim == 1 (single-channel CT slices)")
+        self.coarse_generator = CoarseGenerator(self.input_dim, self.cnum, self.use_cuda)
+        self.fine_generator = FineGenerator(self.input_dim, self.cnum, self.use_cuda)
+        self.precision = None          # None -> HV_PRECISION env (fp32 parity mode by default)
+        self._plans = {}
+        self._pset = None
+        self._pset_convs = None
+
+    # ---------------------------------------------------------------- parameters
+    def paramset(self):
+        if self._pset is None:
+            convs = {}
+            for gname in ('coarse_generator', 'fine_generator'):
+                g = getattr(self, gname)
+                for n, m in g.named_children():
+                    if isinstance(m, Conv2dBlock):
+                        convs['%s.%s' % (gname, n)] = m.params('%s.%s' % (gname, n), cin_fwd=rup(m.cin, 4))
+            self._pset_convs = convs
+            cg, fg = self.coarse_generator, self.fine_generator
+            self._pset = E.ParamSet(convs.values(), [cg.fc_height.weight, cg.fc_height.bias, fg.fc_height.weight, fg.fc_height.bias])
+        return self._pset
+
+    def _plan(self, B, H, W, device):
+        key = (B, H, W, str(device))
+        if key not in self._plans:
+            if H % 8 or W % 8 or H != W:
+                raise NotImplementedError("Generator HIP path expects square inputs with a side divisible by 8")
+            self.paramset()
+            self._plans[key] = _GenPlan(self, B, H, W, device)
+        return self._plans[key]
+
+    # ---------------------------------------------------------------- explicit forward / backward
+    def run_forward(self, x, mask, CAM, slice_ratio, training=None):
+        """x, mask, CAM: (B,1,H,W) fp32 device tensors; slice_ratio: (B,) fp64.  Returns the plan (all activations
+        stay in its buffers); outputs are plan.coarse_seg/fine_seg/x_stage1/x_stage2 (B,1,H,W) and plan.pred1/pred2 (B,1)."""
+        _lib.require_gpu(x, mask, CAM)
+        training = self.training if training is None else training
+        prec = ops.precision_id(self.precision)
+        B, _, H, W = x.shape
+        dev = x.device
+        P = self._plan(B, H, W, dev)
+        self.paramset().prep(dev, power_iter=training)
+        x = x.contiguous().float(); mask = mask.contiguous().float(); CAM = CAM.contiguous().float()
+        ratio = slice_ratio.to(device=dev, dtype=torch.float64).contiguous()
+        P.mask_img = mask
+        cg, fg = self.coarse_generator, self.fine_generator
+        c = self.cnum
+        a = P.a
+        cam = Act(CAM.view(B, H, W, 1))
+        # ---- coarse
+        ops.gen_input(x, None, mask, ratio, P.c_in, 0)
+        for n in P.c_nodes[:10]:
+            n.forward(prec)
+        ops.gap_fc_sigmoid(a['c10'], cg.fc_height.weight, cg.fc_height.bias, P.c_pool, P.pred1)
+        P.c_nodes[10].forward(prec); P.c_nodes[11].forward(prec)
+        ops.copy_channels(a['c12'], a['cat20'].slice(0, 4 * c), mode=1)
+        ops.copy_channels(cam, a['cat20'].slice(4 * c, 1), mode=2)
+        for n in P.c_nodes[12:15]:
+            n.forward(prec)
+        ops.copy_channels(a['c14'], a['cat19'].slice(0, 2 * c), mode=1)
+        ops.copy_channels(cam, a['cat19'].slice(2 * c, 1), mode=0)
+        for n in P.c_nodes[15:]:
+            n.forward(prec)
+        # ---- fine
+        ops.gen_input(x, P.coarse_seg, mask, ratio, P.f_in, 1)
+        for n in P.f_nodes_conv:
+            n.forward(prec)
+        for n in P.f_nodes_pm:
+            n.forward(prec)
+        P.attn.forward(a['p6'], mask, a['ca'], prec)
+        for n in P.f_nodes_pm2:
+            n.forward(prec)
+        P.f_nodes_merge[0].forward(prec)
+        ops.gap_fc_sigmoid(a['a11'], fg.fc_height.weight, fg.fc_height.bias, P.f_pool, P.pred2)
+        for n in P.f_nodes_merge[1:7]:
+            n.forward(prec)
+        ops.copy_channels(Act(P.x_stage1.view(B, H, W, 1)), a['cat17'].slice(c // 2, 1), mode=0)
+        P.f_nodes_merge[7].forward(prec); P.f_nodes_merge[8].forward(prec)
+        return P
+
+    def _tmp_up(self, P, node):
+        key = id(node)
+        if key not in P.tmp_up:
+            x = node.x
+            P.tmp_up[key] = Act(torch.zeros(x.B, x.H * 2, x.W * 2, x.ld, dtype=torch.float32, device=x.t.device), node.p.cin_fwd, 0)
+        return P.tmp_up[key]
+
+    def _head_backward(self, P, node, seed, gname, prec, book):
+        """1-channel head: seed (B,1,H,W) -> padded carrier -> activation/bias gradient -> wgrad + dgrad."""
+        carrier = P.g_head[gname]                       # [B,H,W,4], channel 0 live
+        ops.copy_channels(Act(seed.view(P.B, P.H, P.W, 1)), carrier, mode=0)
+        book.twins[id(node.y.t)] = carrier.t            # the head's output gradient lives in the carrier
+        E.conv_backward(node, book, prec)
+
+    def run_backward(self, P, d_coarse_seg, d_fine_seg, d_x_stage1, d_x_stage2, d_pred1, d_pred2):
+        """Gradients of a scalar loss wrt the six differentiable outputs -> .grad of every parameter.
+        All seeds are dense fp32 device tensors shaped like the outputs (None = zero)."""
+        prec = ops.precision_id(self.precision)
+        B, H, W, c = P.B, P.H, P.W, self.cnum
+        book = P.book
+        book.reset()
+        a = P.a
+        cg, fg = self.coarse_generator, self.fine_generator
+        zero = lambda t, ref: torch.zeros_like(ref) if t is None else t.contiguous().float()
+        d_fine_seg, d_x_stage2 = zero(d_fine_seg, P.fine_seg), zero(d_x_stage2, P.x_stage2)
+        d_coarse_seg, d_x_stage1 = zero(d_coarse_seg, P.coarse_seg), zero(d_x_stage1, P.x_stage1)
+        d_pred1, d_pred2 = zero(d_pred1, P.pred1), zero(d_pred2, P.pred2)
+        M = P.f_nodes_merge
+        # ---- fine: heads
+        self._head_backward(P, M[7], d_x_stage2, 'f17', prec, book)
+        self._head_backward(P, M[8], d_fine_seg, 'f18', prec, book)
+        gcat17 = book.twin(a['cat17'])
+        # x_stage1 also feeds the fine heads (channel c/2 of cat17)
+        d_xs1_total = P.__dict__.setdefault('d_xs1_total', torch.zeros_like(P.x_stage1))
+        ops.copy_channels(Act(d_x_stage1.view(B, H, W, 1)), Act(d_xs1_total.view(B, H, W, 1)), mode=0)
+        ops.copy_channels(gcat17.slice(c // 2, 1), Act(d_xs1_total.view(B, H, W, 1)), mode=0, accumulate=True)
+        E.conv_backward(M[6], book, prec)
+        E.conv_backward(M[5], book, prec, tmp_full=self._tmp_up(P, M[5]))
+        E.conv_backward(M[4], book, prec)
+        E.conv_backward(M[3], book, prec, tmp_full=self._tmp_up(P, M[3]))
+        E.conv_backward(M[2], book, prec)
+        E.conv_backward(M[1], book, prec)
+        ops.gap_fc_sigmoid_backward(d_pred2, P.pred2, P.f_pool, fg.fc_height.weight, book.twin(a['a11']),
+                                    fg.fc_height.weight.grad, fg.fc_height.bias.grad)
+        E.conv_backward(M[0], book, prec)
+        for n in reversed(P.f_nodes_pm2):
+            E.conv_backward(n, book, prec)
+        gp6 = book.twin(a['p6'])
+        P.attn.backward(book.twin(a['ca']), gp6, book.mark(gp6), prec)
+        for n in reversed(P.f_nodes_pm):
+            E.conv_backward(n, book, prec)
+        for n in reversed(P.f_nodes_conv):
+            E.conv_backward(n, book, prec)
+        # coarse_seg enters the fine generator as channel 1 of its input
+        d_cs_total = P.__dict__.setdefault('d_cs_total', torch.zeros_like(P.coarse_seg))
+        ops.copy_channels(Act(d_coarse_seg.view(B, H, W, 1)), Act(d_cs_total.view(B, H, W, 1)), mode=0)
+        ops.copy_channels(book.twin(P.f_in).slice(1, 1), Act(d_cs_total.view(B, H, W, 1)), mode=0, accumulate=True)
+        # ---- coarse
+        C = P.c_nodes
+        self._head_backward(P, C[18], d_xs1_total, 'c17', prec, book)
+        self._head_backward(P, C[19], d_cs_total, 'c18', prec, book)
+        E.conv_backward(C[17], book, prec); E.conv_backward(C[16], book, prec); E.conv_backward(C[15], book, prec)
+        g14 = book.twin(a['c14'])
+        ops.copy_channels(book.twin(a['cat19']).slice(0, 2 * c), g14, mode=3, accumulate=book.mark(g14))
+        E.conv_backward(C[14], book, prec); E.conv_backward(C[13], book, prec); E.conv_backward(C[12], book, prec)
+        g12 = book.twin(a['c12'])
+        ops.copy_channels(book.twin(a['cat20']).slice(0, 4 * c), g12, mode=3, accumulate=book.mark(g12))
+        E.conv_backward(C[11], book, prec); E.conv_backward(C[10], book, prec)
+        ops.gap_fc_sigmoid_backward(d_pred1, P.pred1, P.c_pool, cg.fc_height.weight, book.twin(a['c10']),
+                                    cg.fc_height.weight.grad, cg.fc_height.bias.grad)
+        for n in reversed(C[:10]):
+            E.conv_backward(n, book, prec)
+        self.paramset().finish_backward(accumulate=False)
+        self.paramset().attach_grads()
+
+    # ---------------------------------------------------------------- nn.Module API
+    def forward(self, x, mask, CAM, slice_ratio):
+        """Same signature and 7-tuple as the reference (inpaint_networks.py:28-32):
+        (coarse_seg, fine_seg, x_stage1, x_stage2, offset_flow, pred1_h, pred2_h)."""
+        if not torch.is_tensor(slice_ratio):
+            slice_ratio = torch.as_tensor(slice_ratio, dtype=torch.float64).reshape(-1)
+        P = self.run_forward(x, mask, CAM, slice_ratio)
+        outs = (P.coarse_seg, P.fine_seg, P.x_stage1, P.x_stage2, P.pred1, P.pred2)
+        flow = offsets_to_flow(P.attn.argmax, P.B, P.attn.h, P.attn.w, 2)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            anchor = next(p for p in self.parameters() if p.requires_grad)
+            o = _GeneratorFn.apply(anchor, self, P, *outs)
+        else:
+            o = tuple(t.clone() for t in outs)
+        return o[0], o[1], o[2], o[3], flow, o[4], o[5]
+
+
+class _GeneratorFn(torch.autograd.Function):
+    """Autograd bridge: lets user code call loss.backward() on the generator outputs; parameter gradients are
+    written into .grad by the explicit backward (the anchor parameter only carries the graph edge)."""
+
+    @staticmethod
+    def forward(ctx, anchor, gen, plan, *outs):
+        ctx.gen, ctx.plan = gen, plan
+        return tuple(t.clone() for t in outs)
+
+    @staticmethod
+    def backward(ctx, g_cs, g_fs, g_x1, g_x2, g_p1, g_p2):
+        # gradients are ASSIGNED into .grad (the reference always zero_grad()s before backward)
+        ctx.gen.run_backward(ctx.plan, g_cs, g_fs, g_x1, g_x2, g_p1, g_p2)
+        return (None,) * 9

@@ -1,0 +1,335 @@
+"""PatchGAN discriminator, GAN loss, schedulers and initialisers on the HIP path.
+
+API mirror of the parts of the reference `models/networks.py` that Pix2PixModel uses (define_D :163-206,
+NLayerDiscriminator :555-602, GANLoss :212-278, get_scheduler :39-65, init_net/init_weights :68-117,
+get_norm_layer :18-36).  The nn.Sequential built here is a parameter container with the reference's
+state-dict keys (model.0.weight ... model.11.bias); forward/backward are explicit kernel sequences.
+Generators/discriminators the hot path never instantiates (ResNet/U-Net G, pixel/seg D, WGAN-GP) are
+out of scope and raise NotImplementedError.
+"""
+import functools
+
+import torch
+import torch.nn as nn
+from torch.nn import init
+from torch.optim import lr_scheduler
+
+from .. import engine as E
+from .. import lib as _lib
+from .. import ops
+from ..ops import Act, rup
+
+
+class Identity(nn.Module):
+    def forward(self, x):
+        return x
+
+
+def get_norm_layer(norm_type='instance'):
+    if norm_type == 'batch':
+        return functools.partial(nn.BatchNorm2d, affine=True, track_running_stats=True)
+    if norm_type == 'instance':
+        return functools.partial(nn.InstanceNorm2d, affine=False, track_running_stats=False)
+    if norm_type == 'none':
+        return lambda x: Identity()
+    raise NotImplementedError('normalization layer [%s] is not found' % norm_type)
+
+
+def get_scheduler(optimizer, opt):
+    if opt.lr_policy == 'linear':
+        def lambda_rule(epoch):
+            return 1.0 - max(0, epoch + opt.epoch_count - opt.n_epochs) / float(opt.n_epochs_decay + 1)
+        return lr_scheduler.LambdaLR(optimizer, lr_lambda=lambda_rule)
+    if opt.lr_policy == 'step':
+        return lr_scheduler.StepLR(optimizer, step_size=opt.lr_decay_iters, gamma=0.1)
+    if opt.lr_policy == 'plateau':
+        return lr_scheduler.ReduceLROnPlateau(optimizer, mode='min', factor=0.2, threshold=0.01, patience=5)
+    if opt.lr_policy == 'cosine':
+        return lr_scheduler.CosineAnnealingLR(optimizer, T_max=opt.n_epochs, eta_min=0)
+    return NotImplementedError('learning rate policy [%s] is not implemented', opt.lr_policy)
+
+
+def init_weights(net, init_type='normal', init_gain=0.02):
+    def init_func(m):
+        classname = m.__class__.__name__
+        if hasattr(m, 'weight') and (classname.find('Conv') != -1 or classname.find('Linear') != -1):
+            if init_type == 'normal':
+                init.normal_(m.weight.data, 0.0, init_gain)
+            elif init_type == 'xavier':
+                init.xavier_normal_(m.weight.data, gain=init_gain)
+            elif init_type == 'kaiming':
+                init.kaiming_normal_(m.weight.data, a=0, mode='fan_in')
+            elif init_type == 'orthogonal':
+                init.orthogonal_(m.weight.data, gain=init_gain)
+            else:
+                raise NotImplementedError('initialization method [%s] is not implemented' % init_type)
+            if hasattr(m, 'bias') and m.bias is not None:
+                init.constant_(m.bias.data, 0.0)
+        elif classname.find('BatchNorm2d') != -1:
+            init.normal_(m.weight.data, 1.0, init_gain)
+            init.constant_(m.bias.data, 0.0)
+
+    print('initialize network with %s' % init_type)
+    net.apply(init_func)
+
+
+def init_net(net, init_type='normal', init_gain=0.02, gpu_ids=[]):
+    """The reference wraps multi-GPU nets in nn.DataParallel (:112-116); here every process drives ONE GPU and
+    data parallelism is gradient all-reduce over RCCL (healthivert-gan_amd/ddp.py), so the net just moves to its device."""
+    if len(gpu_ids) > 0:
+        assert torch.cuda.is_available()
+        net.to(gpu_ids[0])
+    init_weights(net, init_type, init_gain=init_gain)
+    return net
+
+
+def define_G(input_nc, output_nc, ngf, netG, norm='batch', use_dropout=False, init_type='normal', init_gain=0.02, gpu_ids=[]):
+    if netG in ('resnet_9blocks', 'resnet_6blocks', 'unet_128', 'unet_256'):
+        raise NotImplementedError("define_G('%s'): not on the HealthiVert-GAN hot path (Pix2PixModel builds inpaint_networks.Generator; "
+                                  "UnetG_CT_mask.define_G is the U-Net variant provided)" % netG)
+    raise NotImplementedError('Generator model name [%s] is not recognized' % netG)
+
+
+def define_D(input_nc, ndf, netD, n_layers_D=3, norm='batch', init_type='normal', init_gain=0.02, gpu_ids=[]):
+    norm_layer = get_norm_layer(norm_type=norm)
+    if netD == 'basic':
+        net = NLayerDiscriminator(input_nc, ndf, n_layers=3, norm_layer=norm_layer)
+    elif netD == 'n_layers':
+        net = NLayerDiscriminator(input_nc, ndf, n_layers_D, norm_layer=norm_layer)
+    elif netD in ('pixel', 'seg'):
+        raise NotImplementedError("define_D('%s'): not on the HealthiVert-GAN hot path" % netD)
+    else:
+        raise NotImplementedError('Discriminator model name [%s] is not recognized' % netD)
+    return init_net(net, init_type, init_gain, gpu_ids)
+
+
+# ================================================================================================ GAN loss
+class _GanLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target_is_real, mode):
+        loss = torch.zeros((), device=pred.device)
+        dz = torch.empty_like(pred)
+        ops.gan_loss(pred.contiguous(), target_is_real, mode, loss=loss, dz=dz)
+        ctx.save_for_backward(dz)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dz,) = ctx.saved_tensors
+        return dz * g, None, None
+
+
+class GANLoss(nn.Module):
+    def __init__(self, gan_mode, target_real_label=1.0, target_fake_label=0.0):
+        super().__init__()
+        self.register_buffer('real_label', torch.tensor(target_real_label))
+        self.register_buffer('fake_label', torch.tensor(target_fake_label))
+        self.gan_mode = gan_mode
+        if gan_mode not in ('lsgan', 'vanilla', 'wgangp'):
+            raise NotImplementedError('gan mode %s not implemented' % gan_mode)
+        if target_real_label != 1.0 or target_fake_label != 0.0:
+            raise NotImplementedError("GANLoss HIP path: labels 1.0 / 0.0")
+
+    def get_target_tensor(self, prediction, target_is_real):
+        return (self.real_label if target_is_real else self.fake_label).expand_as(prediction)
+
+    def __call__(self, prediction, target_is_real):
+        if self.gan_mode == 'wgangp':
+            raise NotImplementedError("GANLoss('wgangp') is not on the HealthiVert-GAN hot path")
+        _lib.require_gpu(prediction)
+        return _GanLossFn.apply(prediction, bool(target_is_real), self.gan_mode)
+
+
+# ================================================================================================ PatchGAN
+class _DiscPlan:
+    def __init__(self, net, B, H, W, device):
+        self.B, self.H, self.W = B, H, W
+        z = lambda h, w, C: Act(torch.zeros(B, h, w, rup(C, 4), dtype=torch.float32, device=device), C, 0)
+        self.book = E.GradBook()
+        self.x4 = z(H, W, 1)
+        self.layers = []
+        h, w = H, W
+        prev = None
+        for li, L in enumerate(net._spec):
+            ho, wo = ops.conv_out_size(h, 4, L['stride'], 1, 1), ops.conv_out_size(w, 4, L['stride'], 1, 1)
+            p = net._pset_convs[li]
+            ent = dict(spec=L, p=p)
+            if li == 0:
+                ent['y'] = z(ho, wo, p.cout)
+                ent['node'] = None     # built per call (input tensor changes)
+            elif L['last']:
+                self.logits = torch.zeros(B, 1, ho, wo, dtype=torch.float32, device=device)
+                ent['y'] = Act(self.logits.view(B, ho, wo, 1))
+                ent['node'] = E.ConvNode(p, prev, ent['y'], L['stride'], 1, 1, 'none', use_bias=True)
+                self.g_logits = z(ho, wo, 1)
+            else:
+                ent['z'] = z(ho, wo, p.cout)
+                ent['y'] = z(ho, wo, p.cout)
+                ent['stats'] = torch.zeros(2 * B * p.cout, dtype=torch.float32, device=device)
+                ent['node'] = E.ConvNode(p, prev, ent['z'], L['stride'], 1, 1, 'none', use_bias=L['bias'])
+            prev = ent['y']
+            h, w = ho, wo
+            self.layers.append(ent)
+        self.dx = torch.zeros(B, 1, H, W, dtype=torch.float32, device=device)
+
+
+class NLayerDiscriminator(nn.Module):
+    """PatchGAN: Conv(k4,s2)+LReLU, (n_layers-1)x[Conv(k4,s2)+Norm+LReLU], Conv(k4,s1)+Norm+LReLU, Conv(k4,s1)->1."""
+
+    def __init__(self, input_nc, ndf=64, n_layers=3, norm_layer=nn.BatchNorm2d):
+        super().__init__()
+        if type(norm_layer) == functools.partial:
+            use_bias = norm_layer.func == nn.InstanceNorm2d
+            norm_cls = norm_layer.func
+        else:
+            use_bias = norm_layer == nn.InstanceNorm2d
+            norm_cls = norm_layer
+        print(norm_layer)
+        if input_nc != 1:
+            raise NotImplementedError("NLayerDiscriminator HIP path: input_nc == 1")
+        if norm_cls not in (nn.BatchNorm2d, nn.InstanceNorm2d):
+            raise NotImplementedError("NLayerDiscriminator HIP path: norm in {batch, instance}")
+        self.norm_kind = 'batch' if norm_cls == nn.BatchNorm2d else 'instance'
+        kw, padw = 4, 1
+        seq = [nn.Conv2d(input_nc, ndf, kernel_size=kw, stride=2, padding=padw), nn.LeakyReLU(0.2, True)]
+        spec = [dict(conv=0, norm=None, stride=2, bias=True, last=False)]
+        nf_mult = 1
+        for n in range(1, n_layers):
+            nf_prev, nf_mult = nf_mult, min(2 ** n, 8)
+            spec.append(dict(conv=len(seq), norm=len(seq) + 1, stride=2, bias=use_bias, last=False))
+            seq += [nn.Conv2d(ndf * nf_prev, ndf * nf_mult, kernel_size=kw, stride=2, padding=padw, bias=use_bias),
+                    norm_layer(ndf * nf_mult), nn.LeakyReLU(0.2, True)]
+        nf_prev, nf_mult = nf_mult, min(2 ** n_layers, 8)
+        spec.append(dict(conv=len(seq), norm=len(seq) + 1, stride=1, bias=use_bias, last=False))
+        seq += [nn.Conv2d(ndf * nf_prev, ndf * nf_mult, kernel_size=kw, stride=1, padding=padw, bias=use_bias),
+                norm_layer(ndf * nf_mult), nn.LeakyReLU(0.2, True)]
+        spec.append(dict(conv=len(seq), norm=None, stride=1, bias=True, last=True))
+        seq += [nn.Conv2d(ndf * nf_mult, 1, kernel_size=kw, stride=1, padding=padw)]
+        self.model = nn.Sequential(*seq)
+        self._spec = spec
+        self.precision = None
+        self._pset = None
+        self._pset_convs = None
+        self._plans = {}
+
+    def paramset(self):
+        if self._pset is None:
+            convs, extra = [], []
+            for li, L in enumerate(self._spec):
+                m = self.model[L['conv']]
+                cin, cout = m.in_channels, m.out_channels
+                if li == 0:
+                    convs.append(E.ConvParams('model.%d' % L['conv'], m.weight, m.bias, cin, cout, 4, cin_fwd=1, cin_wg=4))
+                else:
+                    convs.append(E.ConvParams('model.%d' % L['conv'], m.weight, m.bias, cin, cout, 4))
+                if L['norm'] is not None and self.norm_kind == 'batch':
+                    nm = self.model[L['norm']]
+                    extra += [nm.weight, nm.bias]
+            self._pset_convs = convs
+            self._pset = E.ParamSet(convs, extra)
+        return self._pset
+
+    def _plan(self, B, H, W, device):
+        key = (B, H, W, str(device))
+        if key not in self._plans:
+            self.paramset()
+            self._plans[key] = _DiscPlan(self, B, H, W, device)
+        return self._plans[key]
+
+    # ---------------------------------------------------------------- explicit forward / backward
+    def run_forward(self, x, training=None, prep=True):
+        """x: (B,1,H,W) device tensor -> plan; logits in plan.logits (B,1,Ho,Wo).  BatchNorm running statistics are
+        updated when training (every call, like the reference's three calls per step)."""
+        _lib.require_gpu(x)
+        training = self.training if training is None else training
+        prec = ops.precision_id(self.precision)
+        x = x.contiguous().float()
+        B, _, H, W = x.shape
+        P = self._plan(B, H, W, x.device)
+        if prep:
+            self.paramset().prep(x.device, power_iter=False)
+        xin = Act(x.view(B, H, W, 1))
+        P.x_in = xin
+        for li, ent in enumerate(P.layers):
+            L = ent['spec']
+            if li == 0:
+                ent['node'] = E.ConvNode(ent['p'], xin, ent['y'], L['stride'], 1, 1, 'lrelu', use_bias=True)
+                ent['node'].forward(prec)
+                continue
+            ent['node'].forward(prec)
+            if L['last']:
+                break
+            nm = self.model[L['norm']]
+            if self.norm_kind == 'batch':
+                ops.norm_act_forward(ent['z'], ent['y'], 'batch', training, ent['stats'], nm.weight, nm.bias, nm.running_mean,
+                                     nm.running_var, nm.num_batches_tracked, act='lrelu', eps=nm.eps, momentum=nm.momentum)
+            else:
+                ops.norm_act_forward(ent['z'], ent['y'], 'instance', training, ent['stats'], act='lrelu', eps=nm.eps)
+        P.training = training
+        return P
+
+    def run_backward(self, P, dlogits, need_dx=False, param_grads=True, accumulate=False):
+        """dlogits: (B,1,Ho,Wo) gradient of the loss wrt the logits.  Fills kernel-layout weight gradients and the
+        bias / affine .grad (accumulating when `accumulate`); call finish() afterwards.  Returns d loss / d input."""
+        prec = ops.precision_id(self.precision)
+        book = P.book
+        book.reset()
+        B = P.B
+        last = P.layers[-1]
+        ops.copy_channels(Act(dlogits.contiguous().view(B, last['y'].H, last['y'].W, 1)), P.g_logits, mode=0)
+        book.twins[id(last['y'].t)] = P.g_logits.t
+        # the input view changes every call: its gradient always lives in P.dx
+        book.twins.pop(getattr(P, '_in_id', None), None)
+        P._in_id = id(P.x_in.t)
+        book.twins[P._in_id] = P.dx.view(B, P.H, P.W, 1)
+        for li in range(len(P.layers) - 1, -1, -1):
+            ent = P.layers[li]
+            L, node = ent['spec'], ent['node']
+            if li == 0:
+                x4 = None
+                if param_grads:
+                    ops.copy_channels(P.x_in, P.x4, mode=0)
+                node.need_dx = need_dx
+                E.conv_backward(node, book, prec, dbias_accumulate=accumulate, wgrad_accumulate=accumulate, wgrad=param_grads,
+                                x_wg=P.x4 if param_grads else None)
+                break
+            if not L['last']:
+                nm = self.model[L['norm']]
+                gy, gz = book.twin(ent['y']), book.twin(ent['z'])
+                bn = self.norm_kind == 'batch'
+                ops.norm_act_backward(gy, ent['y'], ent['z'], gz, self.norm_kind, P.training, ent['stats'],
+                                      gamma=nm.weight if bn else None, act='lrelu',
+                                      dgamma=nm.weight.grad if (bn and param_grads) else None,
+                                      dbeta=nm.bias.grad if (bn and param_grads) else None, param_accumulate=accumulate)
+            E.conv_backward(node, book, prec, dbias_accumulate=accumulate, wgrad_accumulate=accumulate, wgrad=param_grads)
+        if need_dx:
+            g = book.twin(P.x_in)
+            return g.t.view(B, 1, P.H, P.W)
+        return None
+
+    def finish(self):
+        self.paramset().finish_backward(accumulate=False)
+        self.paramset().attach_grads()
+
+    # ---------------------------------------------------------------- nn.Module API
+    def forward(self, input):
+        P = self.run_forward(input)
+        if torch.is_grad_enabled() and (input.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return _DiscFn.apply(input, self, P, P.logits)
+        return P.logits.clone()
+
+
+class _DiscFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, net, plan, logits):
+        ctx.net, ctx.plan, ctx.need_dx = net, plan, x.requires_grad
+        return logits.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        net = ctx.net
+        pg = any(p.requires_grad for p in net.parameters())
+        dx = net.run_backward(ctx.plan, g.contiguous(), need_dx=ctx.need_dx, param_grads=pg, accumulate=False)
+        if pg:
+            net.finish()
+        return (dx.clone() if dx is not None else None), None, None, None

@@ -1,0 +1,224 @@
+"""Pix2PixModel on the HIP path: the 2.5D coarse-to-fine generator + three PatchGAN discriminators train step.
+
+API mirror of the reference `models/pix2pix_model.py` (options :51-72, construction :74-135, set_input :137-175,
+forward :180-264, backward_D_1/2/3 :267-314, backward_G :317-354, optimize_parameters :356-382).  Same attribute,
+loss and visual names (train.py:56-99 reads them), but the step is an explicit sequence of libhvgan kernels:
+no autograd tape, no per-sample Python loops, no `.item()` host syncs (the SHRM row bounds are computed on the
+device), fused multi-tensor Adam.  Losses stay on the device until get_current_losses() converts them.
+"""
+import ctypes
+
+import torch
+
+from .. import ddp
+from .. import lib as _lib
+from .. import ops
+from ..lib import ptr, stream
+from ..optim import FusedAdam
+from . import networks
+from .base_model import BaseModel
+from .edge_operator import Sobel
+from .inpaint_networks import Generator
+
+
+def diceCoeff(pred, gt, eps=1e-5, activation='sigmoid'):
+    """Dice coefficient (reference :13-39); host-side helper kept for API parity (the train step uses the fused
+    hv_generator_losses kernel instead)."""
+    if activation not in (None, 'none', 'sigmoid', 'softmax2d'):
+        raise NotImplementedError("Activation implemented for sigmoid and softmax2d")
+    if activation == 'sigmoid':
+        pred = torch.sigmoid(pred)
+    elif activation == 'softmax2d':
+        pred = torch.softmax(pred, dim=1)
+    n = gt.shape[0]
+    p, g = pred.reshape(n, -1), gt.reshape(n, -1)
+    return ((2 * (g * p).sum(1) + eps) / (p.sum(1) + g.sum(1) + eps)).sum() / n
+
+
+class Pix2PixModel(BaseModel):
+    @staticmethod
+    def modify_commandline_options(parser, is_train=True):
+        parser.set_defaults(norm='batch', netG='unet_256', dataset_mode='aligned')
+        if is_train:
+            parser.set_defaults(pool_size=0, gan_mode='vanilla')
+            parser.add_argument('--lambda_L1', type=float, default=200.0, help='weight for L1 loss')
+        return parser
+
+    def __init__(self, opt):
+        BaseModel.__init__(self, opt)
+        if not self.gpu_ids:
+            raise RuntimeError("Pix2PixModel (healthivert-gan_amd) needs an MI355X: set --gpu_ids 0; there is no CPU path")
+        _lib.get()   # fail loudly if libhvgan.so is missing
+        self.loss_names = ['G_GAN', 'G_maskL1', 'G_Dice', 'coarse_Dice', 'edge', 'D_real_1', 'D_fake_1', 'D_real_2', 'D_fake_2',
+                           'D_real_3', 'D_fake_3', 'h']
+        self.visual_names = ['real_A', 'fake_B', 'fake_B_mask_raw', 'normal_vert', 'coarse_seg_binary', 'fake_B_coarse', 'real_B',
+                             'mask', 'fake_B_raw', 'real_B_mask', 'CAM', 'real_edges', 'fake_B_local']
+        self.model_names = ['G', 'D_1', 'D_2', 'D_3'] if self.isTrain else ['G']
+        self.netG = Generator({'input_dim': 1, 'ngf': 16}, True)
+        self.netG.to(self.device)
+        self.sobel_edge = Sobel(requires_grad=False).to(self.device)
+        self.half_band = 35
+        if self.isTrain:
+            for k in (1, 2, 3):
+                setattr(self, 'netD_%d' % k, networks.define_D(opt.input_nc, opt.ndf, opt.netD, opt.n_layers_D, opt.norm,
+                                                               opt.init_type, opt.init_gain, self.gpu_ids))
+            self.criterionGAN = networks.GANLoss(opt.gan_mode).to(self.device)
+            self.criterionL1 = torch.nn.L1Loss()
+            if opt.gan_mode not in ('vanilla', 'lsgan'):
+                raise NotImplementedError("Pix2PixModel HIP path: gan_mode in {vanilla, lsgan}")
+            self.optimizer_G = FusedAdam(self.netG.parameters(), lr=opt.lr, betas=(opt.beta1, 0.999))
+            self.optimizer_D_1 = FusedAdam(self.netD_1.parameters(), lr=opt.lr, betas=(opt.beta1, 0.999))
+            self.optimizer_D_2 = FusedAdam(self.netD_2.parameters(), lr=opt.lr, betas=(opt.beta1, 0.999))
+            self.optimizer_D_3 = FusedAdam(self.netD_3.parameters(), lr=opt.lr, betas=(opt.beta1, 0.999))
+            self.optimizers += [self.optimizer_G, self.optimizer_D_1, self.optimizer_D_2, self.optimizer_D_3]
+        self._loss_buf = torch.zeros(32, dtype=torch.float32, device=self.device)
+        self._bufs = {}
+        self.grad_sync = ddp.GradSync() if self.isTrain else None
+
+    # ---------------------------------------------------------------- inputs
+    def set_input(self, input):
+        AtoB = self.opt.direction == 'AtoB'
+        dev = self.device
+        f32 = lambda t: t.to(dev, non_blocking=True).float().contiguous()
+        self.real_B = f32(input['B' if AtoB else 'A'])
+        self.real_B_mask = f32(input['A_mask'])
+        self.real_A = f32(input['A' if AtoB else 'B'])
+        self.CAM = f32(input['CAM'])
+        self.normal_vert = f32(input['normal_vert'])
+        self.mask = f32(input['mask'])
+        self.height = input['height'].to(dev).long().contiguous()
+        self.slice_ratio = input['slice_ratio'].to(dev).double().contiguous()
+        self.x1 = input['x1'].to(dev).long().contiguous()
+        self.x2 = input['x2'].to(dev).long().contiguous()
+        self.maxheight = input['h2'].to(dev).long().contiguous()
+        self.image_paths = input['A_paths' if AtoB else 'B_paths']
+
+    def _buf(self, name, like=None, shape=None, dtype=torch.float32):
+        key = (name, tuple(like.shape) if like is not None else tuple(shape))
+        b = self._bufs.get(key)
+        if b is None:
+            b = torch.zeros(key[1], dtype=dtype, device=self.device)
+            self._bufs[key] = b
+        return b
+
+    # ---------------------------------------------------------------- forward
+    def forward(self):
+        L = _lib.get()
+        B, _, H, W = self.real_A.shape
+        cam_t = self._buf('cam_temp', self.CAM)
+        L.call('hv_affine', ptr(cam_t), ptr(self.CAM), ctypes.c_longlong(cam_t.numel()), ctypes.c_float(-1.0), ctypes.c_float(1.0), stream())
+        P = self.netG.run_forward(self.real_A, self.mask, cam_t, self.slice_ratio, training=self.netG.training)
+        self._gplan = P
+        self.coarse_seg_sigmoid, self.fake_B_mask_sigmoid = P.coarse_seg, P.fine_seg
+        self.x_stage1, self.fake_B_raw = P.x_stage1, P.x_stage2
+        self.offset_flow = None
+        d = L.hv_postg_desc()
+        outs = {}
+        for n in ('fake_B', 'fake_B_coarse', 'fake_B_local', 'real_B_local', 'fake_B_mask_raw', 'coarse_seg_binary'):
+            outs[n] = self._buf(n, self.real_B)
+            setattr(self, n, outs[n])
+        p1h, p2h = self._buf('pred1_h', shape=(1, B)), self._buf('pred2_h', shape=(1, B))
+        self._rows = self._buf('rows', shape=(B, 4), dtype=torch.int32)
+        for f, t in (('real_B', self.real_B), ('mask', self.mask), ('x_stage1', P.x_stage1), ('x_stage2', P.x_stage2),
+                     ('fine_seg', P.fine_seg), ('coarse_seg', P.coarse_seg), ('pred1', P.pred1), ('pred2', P.pred2),
+                     ('height', self.height), ('x1', self.x1), ('x2', self.x2), ('maxheight', self.maxheight),
+                     ('fake_B', outs['fake_B']), ('fake_B_coarse', outs['fake_B_coarse']), ('fake_B_local', outs['fake_B_local']),
+                     ('real_B_local', outs['real_B_local']), ('fine_bin', outs['fake_B_mask_raw']), ('coarse_bin', outs['coarse_seg_binary']),
+                     ('pred1_h', p1h), ('pred2_h', p2h), ('rows', self._rows)):
+            setattr(d, f, ptr(t).value)
+        d.B, d.H, d.W, d.half_band = B, H, W, self.half_band
+        L.call('hv_post_generator', ctypes.byref(d), stream())
+        self.pred1_h, self.pred2_h = p1h, p2h
+        self.real_edges = ops.sobel(self.real_B_mask, self._buf('real_edges', self.real_B))
+        self.fake_edges = ops.sobel(self.fake_B_mask_raw, self._buf('fake_edges', self.real_B))
+
+    # ---------------------------------------------------------------- discriminator updates
+    def _loss_slot(self, i):
+        return self._loss_buf[i:i + 1].view(())
+
+    def _backward_D(self, k, fake, real):
+        net = getattr(self, 'netD_%d' % k)
+        mode = self.opt.gan_mode
+        lf, lr = self._loss_slot(2 * k), self._loss_slot(2 * k + 1)
+        P = net.run_forward(fake, training=True, prep=True)
+        dz = self._buf('dz', P.logits)
+        ops.gan_loss(P.logits, False, mode, loss=lf, dz=dz, grad_weight=0.5)
+        net.run_backward(P, dz, need_dx=False, param_grads=True, accumulate=False)
+        P = net.run_forward(real, training=True, prep=False)
+        ops.gan_loss(P.logits, True, mode, loss=lr, dz=dz, grad_weight=0.5)
+        net.run_backward(P, dz, need_dx=False, param_grads=True, accumulate=True)
+        net.finish()
+        setattr(self, 'loss_D_fake_%d' % k, lf)
+        setattr(self, 'loss_D_real_%d' % k, lr)
+        self.grad_sync.reduce(net.paramset().flat_grad)
+
+    def backward_D_1(self):
+        self._backward_D(1, self.fake_B, self.real_B)
+
+    def backward_D_2(self):
+        self._backward_D(2, self.fake_B_mask_raw, self.real_B_mask)
+
+    def backward_D_3(self):
+        self._backward_D(3, self.fake_B_local, self.real_B_local)
+
+    # ---------------------------------------------------------------- generator update
+    def backward_G(self):
+        L = _lib.get()
+        mode = self.opt.gan_mode
+        B, _, H, W = self.real_B.shape
+        lg = self._loss_slot(0)
+        dxs = {}
+        fakes = {1: self.fake_B, 2: self.fake_B_mask_raw, 3: self.fake_B_local}
+        for k in (1, 2, 3):
+            net = getattr(self, 'netD_%d' % k)
+            P = net.run_forward(fakes[k], training=True, prep=True)
+            dz = self._buf('dz', P.logits)
+            ops.gan_loss(P.logits, True, mode, loss=lg, loss_weight=1.0 / 6.0, loss_accumulate=(k != 1), dz=dz, grad_weight=1.0 / 6.0)
+            if k != 2:   # D_2 sees a thresholded mask: no gradient path to G (reference :201,:324)
+                dxs[k] = net.run_backward(P, dz, need_dx=True, param_grads=False)
+        g = L.hv_gloss_desc()
+        seeds = {n: self._buf(n, self.real_B) for n in ('d_fake_B', 'd_fake_B_coarse', 'd_fine_seg', 'd_coarse_seg')}
+        dp1, dp2 = self._buf('d_pred1', shape=(B, 1)), self._buf('d_pred2', shape=(B, 1))
+        losses = self._loss_buf[8:14]
+        for f, t in (('fake_B', self.fake_B), ('fake_B_coarse', self.fake_B_coarse), ('real_B', self.real_B), ('mask', self.mask),
+                     ('fine_seg', self.fake_B_mask_sigmoid), ('coarse_seg', self.coarse_seg_sigmoid), ('real_B_mask', self.real_B_mask),
+                     ('normal_vert', self.normal_vert), ('fake_edges', self.fake_edges), ('real_edges', self.real_edges),
+                     ('pred1_h', self.pred1_h), ('pred2_h', self.pred2_h), ('height', self.height), ('maxheight', self.maxheight),
+                     ('losses', losses), ('d_fake_B', seeds['d_fake_B']), ('d_fake_B_coarse', seeds['d_fake_B_coarse']),
+                     ('d_fine_seg', seeds['d_fine_seg']), ('d_coarse_seg', seeds['d_coarse_seg']), ('d_pred1', dp1), ('d_pred2', dp2)):
+            setattr(g, f, ptr(t).value)
+        g.lambda_L1 = float(self.opt.lambda_L1)
+        g.B, g.H, g.W = B, H, W
+        need = L.size('hv_generator_losses_workspace_bytes', B)
+        ws, _ = ops._ws(need, self.device, slot=1)
+        g.workspace, g.workspace_bytes = ptr(ws).value, ws.numel()
+        L.call('hv_generator_losses', ctypes.byref(g), stream())
+        self.loss_G_GAN = lg
+        self.loss_G_maskL1, self.loss_G_Dice, self.loss_coarse_Dice = losses[0], losses[1], losses[2]
+        self.loss_edge, self.loss_h = losses[3], losses[4]
+        self.loss_G = self._loss_slot(14)
+        L.call('hv_affine', ptr(self.loss_G), ptr(losses[5:6]), ctypes.c_longlong(1), ctypes.c_float(1.0), ctypes.c_float(0.0), stream())
+        ops.axpy(self.loss_G, lg, 1.0)
+        # gradient wrt the composited images -> wrt the raw generator outputs (rows [xu, xb) only)
+        ops.axpy(seeds['d_fake_B'], dxs[1], 1.0)
+        d_x2, d_x1 = self._buf('d_x_stage2', self.real_B), self._buf('d_x_stage1', self.real_B)
+        L.call('hv_shrm_backward', ptr(seeds['d_fake_B']), ptr(dxs[3]), ptr(self.mask), ptr(self._rows), 0, ptr(d_x2), B, H, W,
+               self.half_band, 0, stream())
+        L.call('hv_shrm_backward', ptr(seeds['d_fake_B_coarse']), None, None, ptr(self._rows), 1, ptr(d_x1), B, H, W, self.half_band, 0, stream())
+        self.netG.run_backward(self._gplan, seeds['d_coarse_seg'], seeds['d_fine_seg'], d_x1, d_x2, dp1, dp2)
+        self.grad_sync.reduce(self.netG.paramset().flat_grad)
+
+    def optimize_parameters(self):
+        self.forward()
+        for k, bw in ((1, self.backward_D_1), (2, self.backward_D_2), (3, self.backward_D_3)):
+            self.set_requires_grad(getattr(self, 'netD_%d' % k), True)
+            opt = getattr(self, 'optimizer_D_%d' % k)
+            opt.zero_grad()
+            bw()
+            self.grad_sync.wait()
+            opt.step()
+        self.set_requires_grad([self.netD_1, self.netD_2, self.netD_3], False)
+        self.optimizer_G.zero_grad()
+        self.backward_G()
+        self.grad_sync.wait()
+        self.optimizer_G.step()

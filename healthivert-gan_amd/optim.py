@@ -1,0 +1,61 @@
+"""Multi-tensor Adam on the HIP path (one launch per optimiser), torch.optim.Adam semantics.
+
+Subclasses torch.optim.Optimizer only so that the reference's LR schedulers (LambdaLR etc.,
+reference models/networks.py:39-65, models/base_model.py:124-134) drive it unchanged; the update
+itself is hv_adam_step.  Reference: the four Adam optimisers of models/pix2pix_model.py:127-130.
+"""
+import torch
+
+from . import ops
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0):
+        if weight_decay != 0:
+            raise NotImplementedError("FusedAdam: weight_decay is not used by the reference and not implemented")
+        super().__init__(list(params), dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._table = ops.LayerTable('hv_adam_tensor')
+        self._m = self._v = self._step = self._lr = None
+        self._lr_host = None
+
+    def _ensure(self):
+        ps = [p for g in self.param_groups for p in g['params']]
+        if any(p.grad is None for p in ps):
+            raise RuntimeError("FusedAdam.step(): a parameter has no gradient")
+        key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in ps)
+        dev = ps[0].device
+        if self._m is None or self._m.device != dev:
+            n = sum(p.numel() for p in ps)
+            self._m = torch.zeros(n, dtype=torch.float32, device=dev)
+            self._v = torch.zeros(n, dtype=torch.float32, device=dev)
+            self._step = torch.zeros(1, dtype=torch.float32, device=dev)
+            self._lr = torch.zeros(1, dtype=torch.float32, device=dev)
+            self._lr_host = None
+        if key != self._table.key:
+            rows, off = [], 0
+            for p in ps:
+                n = p.numel()
+                rows.append(dict(p=p.data, g=p.grad, m=self._m[off:off + n], v=self._v[off:off + n], n=n))
+                off += n
+            self._table.update(rows, key, dev)
+            self._max = max(p.numel() for p in ps)
+        return ps
+
+    def sync_lr(self):
+        """Copy the scheduler's learning rate to the device scalar the kernel reads (outside any graph capture)."""
+        lr = float(self.param_groups[0]['lr'])
+        if lr != self._lr_host:
+            self._lr.fill_(lr)
+            self._lr_host = lr
+
+    @torch.no_grad()
+    def step(self, closure=None, sync_lr=True):
+        self._ensure()
+        if sync_lr:
+            self.sync_lr()
+        g = self.param_groups[0]
+        ops.adam_step(self._table, self._max, self._lr, g['betas'][0], g['betas'][1], g['eps'], self._step)
+
+    def zero_grad(self, set_to_none=False):
+        """Gradients are (re)assigned by the explicit backward; nothing to clear."""
+        return None

@@ -241,7 +241,7 @@ int hv_adam_step(const hv_adam_tensor* d_tensors, int n_tensors, long long max_n
 /* misc */
 int hv_fill(float* p, long long n, float value, void* stream);
 int hv_axpy(float* y, const float* x, long long n, float a, void* stream); /* y += a*x */
-int hv_scale_rows(float* y, const float* x, long long n, float a, void* stream); /* y = a*x */
+int hv_affine(float* y, const float* x, long long n, float a, float b, void* stream); /* y = a*x + b (e.g. 1 - CAM) */
 
 #ifdef __cplusplus
 }
