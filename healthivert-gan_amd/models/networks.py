@@ -76,10 +76,10 @@ def init_weights(net, init_type='normal', init_gain=0.02):
 def init_net(net, init_type='normal', init_gain=0.02, gpu_ids=[]):
     """The reference wraps multi-GPU nets in nn.DataParallel (:112-116); here every process drives ONE GPU and
     data parallelism is gradient all-reduce over RCCL (healthivert-gan_amd/ddp.py), so the net just moves to its device."""
+    init_weights(net, init_type, init_gain=init_gain)   # on the host RNG: the same seed gives the same weights as a CPU run
     if len(gpu_ids) > 0:
         assert torch.cuda.is_available()
         net.to(gpu_ids[0])
-    init_weights(net, init_type, init_gain=init_gain)
     return net
 
 

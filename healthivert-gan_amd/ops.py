@@ -15,6 +15,15 @@ from .lib import ACT, NORM, F16, F32, ptr, stream
 _PRECISION = {'fp32': F32, 'f32': F32, 'fp16': F16, 'f16': F16}
 
 
+_TIMER = None
+
+
+def set_timer(t):
+    """bench.py's live kernel timer (profiler.KernelTimer) or None."""
+    global _TIMER
+    _TIMER = t
+
+
 def default_precision():
     """HV_PRECISION=fp32 (exact fp32 MFMA, parity mode) | fp16 (fp16 MFMA operands, fp32 accumulate)."""
     return _PRECISION[os.environ.get('HV_PRECISION', 'fp32').lower()]
@@ -132,6 +141,12 @@ def conv2d(x, w, y, k, stride=1, pad=0, dil=1, bias=None, act='none', transposed
     d.y = ptr(y.t).value
     d.Ho, d.Wo, d.y_ld, d.y_coff = y.H, y.W, y.ld, y.coff
     d.precision = precision_id(precision)
+    if _TIMER is not None:
+        taps = kh * kw if not transposed else max(1, (kh * kw) // (stride * stride))
+        flops = 2.0 * y.B * y.H * y.W * d.Cout * taps * d.Cin
+        _TIMER.wrap(('conv', x.B, d.H, d.W, d.Cin, d.Cout, kh, stride, dil, int(transposed)), flops,
+                    lambda: L.call('hv_conv2d', ctypes.byref(d), stream()))
+        return y
     L.call('hv_conv2d', ctypes.byref(d), stream())
     return y
 
@@ -155,6 +170,11 @@ def conv2d_wgrad(x, g, dw, k, stride=1, pad=0, dil=1, in_shift=0, accumulate=Fal
     if need:
         b, _ = _ws(need, x.t.device)
         d.workspace, d.workspace_bytes = ptr(b).value, b.numel()
+    if _TIMER is not None:
+        flops = 2.0 * g.B * g.H * g.W * d.Cout * kh * kw * d.Cin
+        _TIMER.wrap(('wgrad', x.B, d.H, d.W, d.Cin, d.Cout, kh, stride, dil, 0), flops,
+                    lambda: L.call('hv_conv2d_wgrad', ctypes.byref(d), stream()))
+        return dw
     L.call('hv_conv2d_wgrad', ctypes.byref(d), stream())
     return dw
 

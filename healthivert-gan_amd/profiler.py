@@ -1,0 +1,68 @@
+"""Live per-kernel timing of the MFMA kernels with HIP events on the launch stream (bench.py's `roofline`).
+
+Two phases so that the timed region is not perturbed: `survey()` times every convolution launch of one
+untimed step and picks the dominant kernel class (largest total time); `enable()` then brackets only launches
+of that class with events during the timed steps.  FLOPs are algorithmic: 2*pixels*Cout*taps*Cin (valid taps only
+for the transposed/data-gradient form).
+"""
+import torch
+
+from . import ops
+
+
+class KernelTimer:
+    def __init__(self):
+        self.records = []
+        self.only = None
+        self.active = False
+
+    # ---- hook called by ops.conv2d / ops.conv2d_wgrad around each launch
+    def wrap(self, key, flops, launch):
+        if not self.active or (self.only is not None and key != self.only):
+            return launch()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        r = launch()
+        e.record()
+        self.records.append((key, flops, s, e))
+        return r
+
+    def enable(self, only=None):
+        self.records, self.only, self.active = [], only, True
+        ops.set_timer(self)
+
+    def disable(self):
+        self.active = False
+        ops.set_timer(None)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for key, flops, s, e in self.records:
+            a = agg.setdefault(key, [0.0, 0, flops])
+            a[0] += s.elapsed_time(e)
+            a[1] += 1
+        return agg   # key -> [total ms, launches, flops per launch]
+
+    def dominant(self):
+        agg = self.summary()
+        if not agg:
+            return None
+        return max(agg.items(), key=lambda kv: kv[1][0])
+
+    def roofline(self, precision, peak_tflops, total_ms=None):
+        d = self.dominant()
+        if d is None:
+            return None
+        key, (ms, n, flops) = d
+        avg_ms = ms / n
+        achieved = flops / (avg_ms * 1e-3) / 1e12
+        return {'bound': 'mfma', 'kernel': describe(key), 'achieved': round(achieved, 2), 'peak': peak_tflops, 'unit': 'TFLOP/s',
+                'frac': round(achieved / peak_tflops, 4), 'traffic': None, 'launches': n, 'avg_us': round(avg_ms * 1e3, 2),
+                'gflop_per_launch': round(flops / 1e9, 3)}
+
+
+def describe(key):
+    kind, B, H, W, cin, cout, k, s, d, tr = key
+    name = {'conv': 'conv_igemm_kernel', 'wgrad': 'wgrad_kernel'}[kind]
+    return '%s %s B%d %dx%d Cin%d->Cout%d k%d s%d d%d' % (name, 'transposed' if tr else 'forward', B, H, W, cin, cout, k, s, d)

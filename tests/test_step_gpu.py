@@ -1,0 +1,82 @@
+"""Full Pix2PixModel train step on the HIP path against (a) the golden vectors of the reference's own
+optimize_parameters (G5: B=2, 256^2, seed 1234, two steps) and (b) the CPU oracle run live on the same weights.
+fp32 mode; tolerance 1e-3 on continuous tensors, mismatch fraction on thresholded ones."""
+from argparse import Namespace
+
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def make_opt(**kw):
+    o = Namespace(gpu_ids=[0], isTrain=True, checkpoints_dir='/tmp/hv_ckpt', name='t', preprocess='none', input_nc=1, output_nc=1,
+                  ngf=64, ndf=64, netD='basic', netG='unet_256', n_layers_D=3, norm='batch', init_type='normal', init_gain=0.02,
+                  no_dropout=True, gan_mode='vanilla', lr=2e-4, beta1=0.5, lambda_L1=200.0, direction='BtoA', lr_policy='linear',
+                  epoch_count=1, n_epochs=100, n_epochs_decay=100, continue_train=False, load_iter=0, epoch='latest', verbose=False)
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def _sparse(t, step=8):
+    return t.detach()[..., ::step, ::step].cpu()
+
+
+def test_g5_two_train_steps_match_reference_golden():
+    import hvgan
+    from hvgan import synth
+    from hvgan.models.pix2pix_model import Pix2PixModel
+    g = load_golden('g5_full_step')
+    torch.manual_seed(1234)
+    model = Pix2PixModel(make_opt())
+    for n in ('G', 'D_1', 'D_2', 'D_3'):
+        sd = getattr(model, 'net' + n).state_dict()
+        chk = torch.tensor([float(v.double().sum()) for v in sd.values()] + [float(sum(v.double().abs().sum() for v in sd.values()))], dtype=torch.float64)
+        assert torch.allclose(chk, g['init'][n].double(), rtol=1e-6, atol=1e-5), "seeded initial weights differ from the reference for net" + n
+    report = {}
+    for step in range(2):
+        model.set_input(synth.make_batch(2, 256, seed=1234 + step))
+        model.optimize_parameters()
+        torch.cuda.synchronize()
+        losses = model.get_current_losses()
+        for k, v in g['losses%d' % step].items():
+            ref = float(v)
+            report['loss%d/%s' % (step, k)] = (losses[k], ref)
+            tol = 2e-3 * max(1.0, abs(ref))
+            assert abs(losses[k] - ref) <= tol, (step, k, losses[k], ref)
+        for k, ref in g['samples%d' % step].items():
+            got = _sparse(getattr(model, k))
+            if k in ('fake_edges',):
+                assert ((got - ref).abs() > 1e-3).float().mean().item() <= 2e-3, k
+            else:
+                frac = ((got - ref).abs() > 1e-3).float().mean().item()
+                assert frac <= 1e-3, (step, k, (got - ref).abs().max().item(), frac)
+        ph = torch.cat([model.pred1_h, model.pred2_h]).cpu()
+        assert (ph - g['pred_h%d' % step]).abs().max().item() <= 1e-2
+        for key, ref in g['norms%d' % step].items():
+            n, k = key.split('/', 1)
+            v = getattr(model, 'net' + n).state_dict()[k]
+            got = float(v.double().norm())
+            assert abs(got - float(ref)) <= 1e-3 * max(1.0, float(ref)), (step, key, got, float(ref))
+
+
+def test_g7_eval_forward_bs1_matches_reference_golden():
+    import hvgan
+    from hvgan import synth
+    from hvgan.models.inpaint_networks import Generator
+    g = load_golden('g7_inference')
+    torch.manual_seed(77)
+    net = Generator({'input_dim': 1, 'ngf': 16}, True).eval()
+    chk = torch.tensor([float(v.double().sum()) for v in net.state_dict().values()], dtype=torch.float64)
+    assert torch.allclose(chk, g['init'].double(), rtol=1e-6, atol=1e-5)
+    net.cuda()
+    b = synth.to_model_inputs(synth.make_batch(1, 256, seed=77))
+    dev = torch.device('cuda:0')
+    with torch.no_grad():
+        o = net(b['real_A'].to(dev), b['mask'].to(dev), (1 - b['CAM']).to(dev), b['slice_ratio'].to(dev))
+    for name, idx in (('coarse_seg', 0), ('fine_seg', 1), ('x_stage1', 2), ('x_stage2', 3)):
+        assert (_sparse(o[idx], 4) - g[name]).abs().max().item() <= 1e-3, name
+    assert (o[5].cpu() - g['pred1_h']).abs().max().item() <= 1e-3 and (o[6].cpu() - g['pred2_h']).abs().max().item() <= 1e-3
