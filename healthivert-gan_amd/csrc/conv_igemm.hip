@@ -308,7 +308,7 @@ static int dispatch_conv(ConvK& k, hipStream_t s) {
     else { BN = 128; BM = 128; }
     if (BN >= 64) {
         long long tiles = ((M + BM - 1) / BM) * ((k.Cout + BN - 1) / BN);
-        if (tiles < 512) { BM = 64; BN = 64; }
+        if (tiles < 160) { BM = 64; BN = 64; }
     }
     if (k.w_bs || k.scale_bs) {  // per-sample operands: a tile must stay inside one image
         for (int c = 0; c < k.ncls; ++c)
@@ -574,12 +574,28 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK p) {
         }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, long long n, int splits, int accumulate) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += slabs[(long long)k * n + i];
-    dw[i] = accumulate ? dw[i] + s : s;
+// 256 threads = 64 elements x 4 split groups; fixed summation order (deterministic)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, long long n, int splits, int accumulate) {
+    __shared__ float sh[4][64];
+    const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const long long i = (long long)blockIdx.x * 64 + e;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < n) {
+        int k = grp;
+        for (; k + 12 < splits; k += 16) {
+            s0 += slabs[(long long)k * n + i];
+            s1 += slabs[(long long)(k + 4) * n + i];
+            s2 += slabs[(long long)(k + 8) * n + i];
+            s3 += slabs[(long long)(k + 12) * n + i];
+        }
+        for (; k < splits; k += 4) s0 += slabs[(long long)k * n + i];
+    }
+    sh[grp][e] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (grp == 0 && i < n) {
+        const float s = (sh[0][e] + sh[1][e]) + (sh[2][e] + sh[3][e]);
+        dw[i] = accumulate ? dw[i] + s : s;
+    }
 }
 
 struct WgradPlan { int BN, BC, splits, chunk; };
@@ -592,7 +608,8 @@ static int wgrad_plan(const hv_wgrad_desc* d, WgradPlan* pl) {
     else if (d->Cout <= 64) { BN = 64; BC = 64; }
     else { BN = 128; BC = 64; }
     const long long tiles = (long long)hv_cdiv(d->Cout, BN) * hv_cdiv(J, BC);
-    long long want = (1536 + tiles - 1) / tiles;          // aim for ~6 workgroups per CU
+    long long want = (768 + tiles - 1) / tiles;           // aim for ~3 workgroups per CU
+    if (want > 256) want = 256;
     long long maxs = (M + 255) / 256;                     // at least 256 pixels per split
     long long splits = want < 1 ? 1 : want;
     if (splits > maxs) splits = maxs;
@@ -658,7 +675,7 @@ extern "C" int hv_conv2d_wgrad(const hv_wgrad_desc* d, void* stream) {
     rc = d->precision == HV_F32 ? launch_wgrad<float>(k, pl, s) : launch_wgrad<_Float16>(k, pl, s);
     if (rc != HV_OK) return rc;
     if (!direct) {
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(hv_cdiv(nW, 256)), dim3(256), 0, s, d->workspace, d->dw, nW, pl.splits, d->accumulate);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(hv_cdiv(nW, 64)), dim3(256), 0, s, d->workspace, d->dw, nW, pl.splits, d->accumulate);
         HV_LAUNCH_CHECK();
     }
     return HV_OK;

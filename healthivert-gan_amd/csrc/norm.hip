@@ -15,7 +15,7 @@ static NormPlan norm_plan(int B, int HW, int C, int norm) {
     p.rstep = n_vec_ok(C) ? 256 / (C / 4) : 256 / C;
     long long rpb = (long long)p.rstep * 32;
     long long nch = (p.R + rpb - 1) / rpb;
-    const long long cap = p.G > 1 ? 64 : 1024;
+    const long long cap = p.G > 1 ? 32 : 256;
     if (nch > cap) {
         rpb = (p.R + cap - 1) / cap;
         rpb = (rpb + p.rstep - 1) / p.rstep * p.rstep;
@@ -133,19 +133,25 @@ __global__ __launch_bounds__(256) void norm_reduce_kernel(const NormK k, double*
 __global__ void norm_fwd_finalize_kernel(const double* __restrict__ part, int G, int nchunk, int C, int R, float eps, float momentum,
                                          float* __restrict__ stats, float* running_mean, float* running_var, long long* nbt,
                                          int use_running, int update_running) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // one wave per (group, channel)
+    const int i = blockIdx.x;
     if (i >= G * C) return;
     const int g = i / C, c = i - g * C;
     if (use_running) {
-        stats[(long long)g * 2 * C + c] = running_mean[c];
-        stats[(long long)g * 2 * C + C + c] = 1.f / sqrtf(running_var[c] + eps);
+        if (threadIdx.x == 0) {
+            stats[(long long)g * 2 * C + c] = running_mean[c];
+            stats[(long long)g * 2 * C + C + c] = 1.f / sqrtf(running_var[c] + eps);
+        }
         return;
     }
     double s = 0, q = 0;
-    for (int k = 0; k < nchunk; ++k) {
+    for (int k = threadIdx.x; k < nchunk; k += 64) {
         s += part[((long long)g * nchunk + k) * 2 * C + c];
         q += part[((long long)g * nchunk + k) * 2 * C + C + c];
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+    if (threadIdx.x != 0) return;
     const double mean = s / R;
     double var = q / R - mean * mean;
     if (var < 0) var = 0;
@@ -224,7 +230,7 @@ extern "C" int hv_norm_act_forward(const hv_norm_desc* d, void* stream) {
         HV_LAUNCH_CHECK();
     }
     const int update = d->norm == HV_NORM_BATCH && d->training && d->running_mean && d->running_var;
-    hipLaunchKernelGGL(norm_fwd_finalize_kernel, dim3(hv_cdiv((long long)pl.G * d->C, 128)), dim3(128), 0, s, part, pl.G, pl.nchunk, d->C, pl.R,
+    hipLaunchKernelGGL(norm_fwd_finalize_kernel, dim3(pl.G * d->C), dim3(64), 0, s, part, pl.G, pl.nchunk, d->C, pl.R,
                        d->eps, d->momentum, d->stats, d->running_mean, d->running_var, d->num_batches_tracked, use_running ? 1 : 0, update);
     HV_LAUNCH_CHECK();
     const long long n = (long long)pl.G * pl.R * (vec ? d->C / 4 : d->C);
@@ -237,19 +243,24 @@ extern "C" int hv_norm_act_forward(const hv_norm_desc* d, void* stream) {
 // sums over chunks -> ab[g][2][C] (floats); dgamma/dbeta over groups
 __global__ void norm_bwd_finalize_kernel(const double* __restrict__ part, int G, int nchunk, int C, float* __restrict__ ab,
                                          float* dgamma, float* dbeta, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.x;   // one wave per channel
     if (c >= C) return;
     double ta = 0, tb = 0;
     for (int g = 0; g < G; ++g) {
         double a = 0, b = 0;
-        for (int k = 0; k < nchunk; ++k) {
+        for (int k = threadIdx.x; k < nchunk; k += 64) {
             a += part[((long long)g * nchunk + k) * 2 * C + c];
             b += part[((long long)g * nchunk + k) * 2 * C + C + c];
         }
-        ab[(long long)g * 2 * C + c] = (float)a;
-        ab[(long long)g * 2 * C + C + c] = (float)b;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+        if (threadIdx.x == 0) {
+            ab[(long long)g * 2 * C + c] = (float)a;
+            ab[(long long)g * 2 * C + C + c] = (float)b;
+        }
         ta += a; tb += b;
     }
+    if (threadIdx.x != 0) return;
     if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)tb : (float)tb;
     if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)ta : (float)ta;
 }
@@ -324,7 +335,7 @@ extern "C" int hv_norm_act_backward(const hv_norm_bwd_desc* d, void* stream) {
     if (vec) hipLaunchKernelGGL((norm_reduce_kernel<1, true>), grid, dim3(256), 0, s, k, part);
     else hipLaunchKernelGGL((norm_reduce_kernel<1, false>), grid, dim3(256), 0, s, k, part);
     HV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(hv_cdiv(d->C, 128)), dim3(128), 0, s, part, pl.G, pl.nchunk, d->C, ab, d->dgamma, d->dbeta,
+    hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(d->C), dim3(64), 0, s, part, pl.G, pl.nchunk, d->C, ab, d->dgamma, d->dbeta,
                        d->param_accumulate);
     HV_LAUNCH_CHECK();
     const int batch_stats = (d->norm == HV_NORM_INSTANCE || d->training) ? 1 : 0;

@@ -74,19 +74,29 @@ __global__ __launch_bounds__(PREP_THREADS) void weight_prep_kernel(const hv_wpre
         }
     }
     if (tid == 0 && L.sigma) L.sigma[0] = sigma;
-    // layouts (rows/channels beyond the real extent are written as zero)
+}
+
+// phase 2, grid-parallel over (chunk, layer): W/sigma written in the kernels' layouts
+// (rows/channels beyond the real extent are written as zero)
+__global__ __launch_bounds__(256) void weight_layout_kernel(const hv_wprep_layer* __restrict__ layers) {
+    const hv_wprep_layer L = layers[blockIdx.y];
     const long long nf = (long long)L.CoutF * L.taps * L.CinP;
-    for (long long i = tid; i < nf; i += PREP_THREADS) {
-        const int ci = (int)(i % L.CinP);
-        const long long r = i / L.CinP;
-        const int tap = (int)(r % L.taps), co = (int)(r / L.taps);
-        float val = 0.f;
-        if (co < L.Cout && ci < L.Cin) val = L.w_orig[wsrc_index(L, co, ci, tap)] / sigma;
-        L.w_fwd[i] = val;
-    }
-    if (L.w_bwd) {
-        const long long nb = (long long)L.CinB * L.taps * L.CoutP;
-        for (long long i = tid; i < nb; i += PREP_THREADS) {
+    const long long nb = L.w_bwd ? (long long)L.CinB * L.taps * L.CoutP : 0;
+    const long long base = (long long)blockIdx.x * 1024;
+    if (base >= nf + nb) return;
+    const float sigma = L.sigma[0];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        long long i = base + k * 256 + threadIdx.x;
+        if (i < nf) {
+            const int ci = (int)(i % L.CinP);
+            const long long r = i / L.CinP;
+            const int tap = (int)(r % L.taps), co = (int)(r / L.taps);
+            float val = 0.f;
+            if (co < L.Cout && ci < L.Cin) val = L.w_orig[wsrc_index(L, co, ci, tap)] / sigma;
+            L.w_fwd[i] = val;
+        } else if (i < nf + nb) {
+            i -= nf;
             const int co = (int)(i % L.CoutP);
             const long long r = i / L.CoutP;
             const int tap = (int)(r % L.taps), ci = (int)(r / L.taps);
@@ -97,28 +107,40 @@ __global__ __launch_bounds__(PREP_THREADS) void weight_prep_kernel(const hv_wpre
     }
 }
 
-extern "C" int hv_weight_prep(const hv_wprep_layer* d_layers, int n_layers, void* stream) {
-    if (!d_layers || n_layers <= 0) return HV_ERR_ARG;
+extern "C" int hv_weight_prep(const hv_wprep_layer* d_layers, int n_layers, long long max_numel, void* stream) {
+    if (!d_layers || n_layers <= 0 || max_numel <= 0) return HV_ERR_ARG;
     hipLaunchKernelGGL(weight_prep_kernel, dim3(n_layers), dim3(PREP_THREADS), 0, (hipStream_t)stream, d_layers);
+    HV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(weight_layout_kernel, dim3(hv_cdiv(max_numel, 1024), n_layers), dim3(256), 0, (hipStream_t)stream, d_layers);
     HV_LAUNCH_CHECK();
     return HV_OK;
 }
 
-__global__ __launch_bounds__(PREP_THREADS) void weight_prep_bwd_kernel(const hv_wprep_bwd_layer* __restrict__ layers) {
+// backward phase 1 (spectral-norm layers only): dot = <dWsn, Wsn> -> sigma[1]
+__global__ __launch_bounds__(PREP_THREADS) void weight_prep_bwd_dot_kernel(const hv_wprep_bwd_layer* __restrict__ layers) {
     const hv_wprep_bwd_layer L = layers[blockIdx.x];
+    if (!L.sn) return;
     __shared__ float red[20];
-    const int tid = threadIdx.x;
     const long long n = (long long)L.Cout * L.taps * L.CinP;
-    float dot = 0.f, sigma = 1.f;
-    if (L.sn) {
-        for (long long i = tid; i < n; i += PREP_THREADS) dot += L.dw_ohwi[i] * L.w_fwd[i];
-        dot = hv_block_sum(dot, red);
-        sigma = L.sigma[0];
-    }
+    float dot = 0.f;
+    for (long long i = threadIdx.x; i < n; i += PREP_THREADS) dot += L.dw_ohwi[i] * L.w_fwd[i];
+    dot = hv_block_sum(dot, red);
+    if (threadIdx.x == 0) const_cast<float*>(L.sigma)[1] = dot;
+}
+
+__global__ __launch_bounds__(256) void weight_prep_bwd_kernel(const hv_wprep_bwd_layer* __restrict__ layers) {
+    const hv_wprep_bwd_layer L = layers[blockIdx.y];
     const long long no = (long long)L.Cout * L.Cin * L.taps;
-    for (long long i = tid; i < no; i += PREP_THREADS) {
-        int co, ci, tap;
-        tap = (int)(i % L.taps);
+    const long long base = (long long)blockIdx.x * 1024;
+    if (base >= no) return;
+    float dot = 0.f, sigma = 1.f;
+    if (L.sn) { sigma = L.sigma[0]; dot = L.sigma[1]; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long long i = base + k * 256 + threadIdx.x;
+        if (i >= no) break;
+        int co, ci;
+        const int tap = (int)(i % L.taps);
         const long long r = i / L.taps;
         if (L.transposed_src) { co = (int)(r % L.Cout); ci = (int)(r / L.Cout); }
         else { ci = (int)(r % L.Cin); co = (int)(r / L.Cin); }
@@ -130,9 +152,13 @@ __global__ __launch_bounds__(PREP_THREADS) void weight_prep_bwd_kernel(const hv_
     }
 }
 
-extern "C" int hv_weight_prep_backward(const hv_wprep_bwd_layer* d_layers, int n_layers, void* stream) {
-    if (!d_layers || n_layers <= 0) return HV_ERR_ARG;
-    hipLaunchKernelGGL(weight_prep_bwd_kernel, dim3(n_layers), dim3(PREP_THREADS), 0, (hipStream_t)stream, d_layers);
+extern "C" int hv_weight_prep_backward(const hv_wprep_bwd_layer* d_layers, int n_layers, long long max_numel, int any_sn, void* stream) {
+    if (!d_layers || n_layers <= 0 || max_numel <= 0) return HV_ERR_ARG;
+    if (any_sn) {
+        hipLaunchKernelGGL(weight_prep_bwd_dot_kernel, dim3(n_layers), dim3(PREP_THREADS), 0, (hipStream_t)stream, d_layers);
+        HV_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(weight_prep_bwd_kernel, dim3(hv_cdiv(max_numel, 1024), n_layers), dim3(256), 0, (hipStream_t)stream, d_layers);
     HV_LAUNCH_CHECK();
     return HV_OK;
 }
@@ -190,12 +216,12 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(float* __restrict__ dy, co
     }
 }
 
-__global__ void colsum_finalize_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ out, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += (double)part[(long long)b * C + c];
-    out[c] = accumulate ? out[c] + (float)s : (float)s;
+__global__ __launch_bounds__(64) void colsum_finalize_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x;   // one wave per channel
+    float s = 0.f;
+    for (int b = threadIdx.x; b < nblk; b += 64) s += part[(long long)b * C + c];
+    s = hv_wave_sum(s);
+    if (threadIdx.x == 0) out[c] = accumulate ? out[c] + s : s;
 }
 
 static bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
@@ -206,8 +232,8 @@ static int act_bwd_blocks(long long npix, int C, int* rows_per_block) {
     const int rstep = act_vec_ok(C) ? 256 / (C / 4) : 256 / C;
     long long rpb = (long long)rstep * 16;
     long long nb = (npix + rpb - 1) / rpb;
-    if (nb > 2048) {
-        rpb = (npix + 2047) / 2048;
+    if (nb > 512) {
+        rpb = (npix + 511) / 512;
         rpb = (rpb + rstep - 1) / rstep * rstep;
         nb = (npix + rpb - 1) / rpb;
     }
@@ -241,7 +267,7 @@ extern "C" int hv_act_backward(float* dy, const float* y, long long npix, int C,
                            dbias ? workspace : nullptr, rpb);
     HV_LAUNCH_CHECK();
     if (dbias) {
-        hipLaunchKernelGGL(colsum_finalize_kernel, dim3(hv_cdiv(C, 64)), dim3(64), 0, s, workspace, nb, C, dbias, dbias_accumulate);
+        hipLaunchKernelGGL(colsum_finalize_kernel, dim3(C), dim3(64), 0, s, workspace, nb, C, dbias, dbias_accumulate);
         HV_LAUNCH_CHECK();
     }
     return HV_OK;

@@ -114,11 +114,11 @@ class ParamSet:
 
     def prep(self, device, power_iter):
         self._ensure(device)
-        ops.weight_prep(self.t_prep[bool(power_iter)])
+        ops.weight_prep(self.t_prep[bool(power_iter)], max(c.sizes()[0] + c.sizes()[1] for c in self.convs))
 
     def finish_backward(self, accumulate=False):
         """Kernel-layout weight gradients -> .grad of weight_orig / weight (spectral-norm backward included)."""
-        ops.weight_prep_backward(self.t_bwd[bool(accumulate)])
+        ops.weight_prep_backward(self.t_bwd[bool(accumulate)], max(c.cout * c.cin * c.taps for c in self.convs), any(c.sn for c in self.convs))
 
 
 class ConvNode:

@@ -211,12 +211,14 @@ class LayerTable:
         return ptr(self.dev)
 
 
-def weight_prep(table):
-    _lib.get().call('hv_weight_prep', ctypes.cast(table.ptr(), ctypes.POINTER(_lib.get().hv_wprep_layer)), table.n, stream())
+def weight_prep(table, max_numel):
+    _lib.get().call('hv_weight_prep', ctypes.cast(table.ptr(), ctypes.POINTER(_lib.get().hv_wprep_layer)), table.n,
+                    ctypes.c_longlong(max_numel), stream())
 
 
-def weight_prep_backward(table):
-    _lib.get().call('hv_weight_prep_backward', ctypes.cast(table.ptr(), ctypes.POINTER(_lib.get().hv_wprep_bwd_layer)), table.n, stream())
+def weight_prep_backward(table, max_numel, any_sn):
+    _lib.get().call('hv_weight_prep_backward', ctypes.cast(table.ptr(), ctypes.POINTER(_lib.get().hv_wprep_bwd_layer)), table.n,
+                    ctypes.c_longlong(max_numel), int(any_sn), stream())
 
 
 # ------------------------------------------------------------------------------------------------ pointwise

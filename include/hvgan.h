@@ -86,13 +86,13 @@ int hv_conv2d_wgrad(const hv_wgrad_desc* d, void* stream);
 typedef struct {
     const float* w_orig;  /* [Cout][Cin][KH][KW] (torch layout); for conv_transpose [Cin][Cout][KH][KW] with transposed_src=1 */
     float* u; float* v;   /* [Cout], [Cin*KH*KW]; NULL when sn=0 */
-    float* sigma;         /* [1] out (1.0 when sn=0) */
+    float* sigma;         /* [4] scratch: [0] = sigma out (1.0 when sn=0), [1] = <dWsn,Wsn> written by the backward */
     float* w_fwd;         /* [CoutF][taps][CinP]  rows >= Cout and channels >= Cin are zero */
     float* w_bwd;         /* [CinB][taps][CoutP]  or NULL */
     int Cout, Cin, taps, CinP, CoutF, CoutP, CinB;
     int sn, power_iter, transposed_src;
 } hv_wprep_layer;
-int hv_weight_prep(const hv_wprep_layer* d_layers, int n_layers, void* stream); /* d_layers: DEVICE array */
+int hv_weight_prep(const hv_wprep_layer* d_layers, int n_layers, long long max_numel, void* stream); /* d_layers: DEVICE array; max_numel = largest w_fwd+w_bwd element count of a layer */
 
 /* Backward of the above: dw_orig = (dWsn - <dWsn, Wsn> u v^T) / sigma  (sn=1) or a layout transform (sn=0).
  * dw_ohwi is the hv_conv2d_wgrad output [Cout][taps][CinP]. */
@@ -100,7 +100,7 @@ typedef struct {
     const float* dw_ohwi; const float* w_fwd; const float* u; const float* v; const float* sigma;
     float* dw_orig; int Cout, Cin, taps, CinP, sn, transposed_src, accumulate;
 } hv_wprep_bwd_layer;
-int hv_weight_prep_backward(const hv_wprep_bwd_layer* d_layers, int n_layers, void* stream);
+int hv_weight_prep_backward(const hv_wprep_bwd_layer* d_layers, int n_layers, long long max_numel, int any_sn, void* stream);
 
 /* ---------------------------------------------------------------- activation gradient + bias gradient
  * g[p,c] = dy[p,c] * act'(y[p,c]) in place over dy; dbias[c] (+)= sum_p g[p,c] when dbias != NULL.

@@ -116,3 +116,30 @@ def test_g3_discriminator(norm):
         assert _err(sd[k].double(), v) <= 1e-4, k
     net.eval()
     assert _err(net(x0), g['y_eval']) <= TOL
+
+
+def test_g6_unet_ct_mask_forward_backward():
+    from hvgan.models.UnetG_CT_mask import define_G
+    g = load_golden('g6_unet_mini')
+    dev = torch.device('cuda:0')
+    net = define_G(3, 1, 4, 'unet_256', 'batch', False, 'normal', 0.02, [])
+    net.load_state_dict(g['sd'])
+    net.cuda()
+    net.precision = 'fp32'
+    net.train()
+    x, tgt = g['x'].to(dev), g['tgt'].to(dev)
+    ct, mk = net(x)
+    assert _err(ct, g['ct']) <= TOL and _err(mk, g['mk']) <= TOL
+    loss = (ct - tgt).abs().mean() + (mk * tgt).mean()
+    assert abs(loss.item() - g['loss'].item()) <= 1e-3
+    loss.backward()
+    for k, p in net.named_parameters():
+        ref = g['grads'][k]
+        assert _err(p.grad, ref) <= TOL * max(1.0, ref.abs().max().item()), (k, _err(p.grad, ref))
+    sd = net.state_dict()
+    for k, v in g['sd_after'].items():
+        assert _err(sd[k].double(), v) <= 1e-4, k
+    net.eval()
+    with torch.no_grad():
+        cte, mke = net(x)
+    assert _err(cte, g['ct_eval']) <= TOL and _err(mke, g['mk_eval']) <= TOL
