@@ -451,3 +451,14 @@ extern "C" int hv_generator_losses(const hv_gloss_desc* d, void* stream) {
     }
     return HV_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ threshold (seg > 0.5 -> label id)
+__global__ void threshold_kernel(const float* __restrict__ x, float* __restrict__ y, long long n, float thr, float value) {
+    PW_LOOP(i, n) y[i] = x[i] > thr ? value : 0.f;
+}
+extern "C" int hv_threshold(const float* x, float* y, long long n, float thr, float value, void* stream) {
+    if (!x || !y || n <= 0) return HV_ERR_ARG;
+    hipLaunchKernelGGL(threshold_kernel, dim3(pw_grid(n)), dim3(256), 0, (hipStream_t)stream, x, y, n, thr, value);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}

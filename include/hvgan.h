@@ -239,6 +239,7 @@ int hv_adam_step(const hv_adam_tensor* d_tensors, int n_tensors, long long max_n
                  float beta2, float eps, float* d_step, void* stream);
 
 /* misc */
+int hv_threshold(const float* x, float* y, long long n, float thr, float value, void* stream); /* y = x > thr ? value : 0 (torch.where(seg > 0.5, ...)) */
 int hv_fill(float* p, long long n, float value, void* stream);
 int hv_axpy(float* y, const float* x, long long n, float a, void* stream); /* y += a*x */
 int hv_affine(float* y, const float* x, long long n, float a, float b, void* stream); /* y = a*x + b (e.g. 1 - CAM) */
