@@ -1,0 +1,338 @@
+// Halo-tiled implicit-GEMM convolution (fp16 MFMA operands, fp32 accumulate) for gfx950.
+//
+// The gather kernel in conv_igemm.hip re-reads the input from L2 once per filter tap, which pins it at
+// the per-CU L2->LDS load rate (~70 GB/s/CU) far below the MFMA rate.  This kernel stages the input
+// ONCE per (output tile, channel chunk): a TH x TW tile of output pixels needs a (TH-1)*s+span+1 square
+// patch of the input, kept in LDS as fp16 [patch pixel][CK channels]; every tap then reads its MFMA
+// B-fragments (8 contiguous channels of 16 consecutive pixels) straight from the patch at a shifted
+// address -- no im2col copy, 9-16x less L2 traffic.  Weights (pre-converted to fp16 by hv_weight_prep)
+// stream through a double-buffered LDS tile, TG taps per barrier.
+//
+// Used for: dilation 1, Cin % 16 == 0, shared (not per-sample) filters, HV_F16 precision; conv and
+// the gather form of conv_transpose / data gradient (per output-parity class).  Everything else stays on
+// conv_igemm_kernel.
+#include "hv_common.h"
+
+typedef _Float16 f16x4v __attribute__((ext_vector_type(4)));
+
+struct HaloCls {
+    int ph, pw, Hc, Wc, ntaps, tiles_x, tiles, t0;   // t0 = first tile index of the class in the grid
+    int dh_min, dw_min, PH, PW;
+    uint32_t taps[16];   // (dh-dh_min) | (dw-dw_min)<<8 | widx<<16
+};
+struct HaloK {
+    const float* x; const _Float16* w; const float* bias; float* y;
+    int B, Hl, Wl, in_shift, Wp, img_stride, x_ld, x_coff, Cin;
+    int Cout, w_row, y_ld, y_coff, Ho, Wo;
+    int bstep, boff, ostep;
+    float alpha; int act, accumulate, vec_store, ncls;
+    HaloCls cls[4];
+};
+
+template <int CK> struct HFrag;
+template <> struct HFrag<32> {
+    typedef f16x8 V;
+    static __device__ __forceinline__ V ld(const _Float16* p, int lane) { return *reinterpret_cast<const V*>(p + (lane >> 4) * 8); }
+    static __device__ __forceinline__ f32x4 mma(V a, V b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct HFrag<16> {
+    typedef f16x4v V;
+    static __device__ __forceinline__ V ld(const _Float16* p, int lane) { return *reinterpret_cast<const V*>(p + (lane >> 4) * 4); }
+    static __device__ __forceinline__ f32x4 mma(V a, V b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0); }
+};
+
+template <int TH, int TW, int BN, int WM, int WN, int TG, int CK>
+__global__ __launch_bounds__(256) void conv_halo_kernel(const HaloK p) {
+    constexpr int BM = TH * TW;
+    constexpr int LDP = CK + 8;                  // halfs per patch pixel / weight row (16 B pad: conflict-light b128 reads)
+    constexpr int MT = BM / WM / 16, NT = BN / WN / 16;
+    constexpr int GX = TW / 16;                  // 16-pixel groups per tile row
+    static_assert(WM * WN == 4 && MT >= 1 && NT >= 1 && TW % 16 == 0, "bad tile");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    _Float16* wbuf = reinterpret_cast<_Float16*>(smem);                  // [2][TG][BN][LDP]
+    _Float16* patch = wbuf + 2 * TG * BN * LDP;                         // [PH*PW][LDP]
+    __shared__ uint32_t taps_s[16];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int ci = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (i < p.ncls && (int)blockIdx.x >= p.cls[i].t0) ci = i;
+    const HaloCls& C = p.cls[ci];
+    const int ntaps = C.ntaps, PH = C.PH, PW = C.PW;
+    if (tid < ntaps) taps_s[tid] = C.taps[tid];
+    int t = (int)blockIdx.x - C.t0;
+    const int n_img = t / C.tiles;
+    t -= n_img * C.tiles;
+    const int tile_y = t / C.tiles_x, tile_x = t - tile_y * C.tiles_x;
+    const int i0 = tile_y * TH, j0 = tile_x * TW;           // class-pixel origin of the tile
+    const int n_base = blockIdx.y * BN;
+    // input coordinate of patch pixel (0,0)
+    const int h0 = i0 * p.bstep + p.boff + C.dh_min, w0 = j0 * p.bstep + p.boff + C.dw_min;
+    const float* ximg = p.x + (long long)n_img * p.img_stride + p.x_coff;
+    const int npatch = PH * PW;
+    const int wm = wave / WN, wn = wave % WN;
+
+    // per-lane patch offsets of the MT pixel groups this wave owns (without the tap shift)
+    int poff[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int g = wm * MT + m, ty = g / GX, tx = (g % GX) * 16 + (lane & 15);
+        poff[m] = (ty * p.bstep * PW + tx * p.bstep) * LDP;
+    }
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // weight tile loader: rows (tap-in-group, n) x CK halfs, 16 B (8 halfs) per thread-load.  Two register sets
+    // keep two tap groups in flight (prefetch distance 2) behind the MFMAs of the current group.
+    constexpr int WVEC = CK / 8;                             // 16-B vectors per row
+    constexpr int WLOADS = (TG * BN * WVEC + 255) / 256;
+    uint4 wra[WLOADS], wrb[WLOADS];
+    auto wload = [&](uint4 (&wr)[WLOADS], int grp, int c0) {
+#pragma unroll
+        for (int i = 0; i < WLOADS; ++i) {
+            const int e = tid + i * 256;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (e < TG * BN * WVEC) {
+                const int vec = e % WVEC, r = e / WVEC, n = r % BN, tg = r / BN;
+                const int tap = grp * TG + tg;
+                if (tap < ntaps && n_base + n < p.Cout) {
+                    const int widx = (int)(taps_s[tap] >> 16);
+                    v = *reinterpret_cast<const uint4*>(p.w + (long long)(n_base + n) * p.w_row + widx * p.Cin + c0 + vec * 8);
+                }
+            }
+            wr[i] = v;
+        }
+    };
+    auto wstore = [&](const uint4 (&wr)[WLOADS], int buf) {
+#pragma unroll
+        for (int i = 0; i < WLOADS; ++i) {
+            const int e = tid + i * 256;
+            if (e < TG * BN * WVEC) {
+                const int vec = e % WVEC, r = e / WVEC;
+                *reinterpret_cast<uint4*>(wbuf + (buf * TG * BN + r) * LDP + vec * 8) = wr[i];
+            }
+        }
+    };
+    // input patch: small patches are prefetched into registers one chunk ahead, large ones staged synchronously
+    constexpr int PV = CK / 4;
+    constexpr int PMAX = 8;
+    const bool patch_pf = npatch * PV <= PMAX * 256;
+    float4 preg[PMAX];
+    auto pload1 = [&](int e, int c0) -> float4 {
+        const int c4 = e % PV, pix = e / PV;
+        const int py = pix / PW, px = pix - py * PW;
+        const int hi = h0 + py, wi = w0 + px;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((unsigned)hi < (unsigned)p.Hl && (unsigned)wi < (unsigned)p.Wl)
+            v = *reinterpret_cast<const float4*>(ximg + (long long)((hi >> p.in_shift) * p.Wp + (wi >> p.in_shift)) * p.x_ld + c0 + c4 * 4);
+        return v;
+    };
+    auto pstore1 = [&](int e, float4 v) {
+        const int c4 = e % PV, pix = e / PV;
+        f16x4v h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+        *reinterpret_cast<f16x4v*>(patch + pix * LDP + c4 * 4) = h;
+    };
+    auto compute = [&](int g) {
+        const _Float16* wb = wbuf + (g & 1) * TG * BN * LDP;
+#pragma unroll
+        for (int tg = 0; tg < TG; ++tg) {
+            const int tap = g * TG + tg;
+            if (tap >= ntaps) break;
+            const uint32_t e = taps_s[tap];
+            const int toff = ((int)(e & 0xff) * PW + (int)((e >> 8) & 0xff)) * LDP;
+            typename HFrag<CK>::V wf[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) wf[n] = HFrag<CK>::ld(wb + (tg * BN + wn * (BN / WN) + n * 16 + (lane & 15)) * LDP, lane);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const typename HFrag<CK>::V xf = HFrag<CK>::ld(patch + poff[m] + toff, lane);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[n][m] = HFrag<CK>::mma(wf[n], xf, acc[n][m]);
+            }
+        }
+    };
+
+    __syncthreads();   // taps_s
+    const int ngroups = (ntaps + TG - 1) / TG;
+    if (patch_pf) {
+#pragma unroll
+        for (int i = 0; i < PMAX; ++i) { const int e = tid + i * 256; if (e < npatch * PV) preg[i] = pload1(e, 0); }
+    }
+    for (int c0 = 0; c0 < p.Cin; c0 += CK) {
+        // ---- patch of this chunk -> LDS (all MFMA reads of the previous chunk finished at its last barrier)
+        if (patch_pf) {
+#pragma unroll
+            for (int i = 0; i < PMAX; ++i) { const int e = tid + i * 256; if (e < npatch * PV) pstore1(e, preg[i]); }
+        } else {
+            for (int e = tid; e < npatch * PV; e += 256) pstore1(e, pload1(e, c0));
+        }
+        wload(wra, 0, c0);
+        wstore(wra, 0);
+        if (ngroups > 1) wload(wrb, 1, c0);
+        if (ngroups > 2) wload(wra, 2, c0);
+        if (patch_pf && c0 + CK < p.Cin) {   // next chunk's patch rides behind this chunk's MFMAs
+#pragma unroll
+            for (int i = 0; i < PMAX; ++i) { const int e = tid + i * 256; if (e < npatch * PV) preg[i] = pload1(e, c0 + CK); }
+        }
+        __syncthreads();
+        for (int g = 0; g < ngroups; g += 2) {
+            compute(g);
+            if (g + 1 < ngroups) { wstore(wrb, 1); if (g + 3 < ngroups) wload(wrb, g + 3, c0); }
+            __syncthreads();
+            if (g + 1 >= ngroups) break;
+            compute(g + 1);
+            if (g + 2 < ngroups) { wstore(wra, 0); if (g + 4 < ngroups) wload(wra, g + 4, c0); }
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue (same contract as conv_igemm_kernel)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int g = wm * MT + m, ty = g / GX, tx = (g % GX) * 16 + (lane & 15);
+        const int i = i0 + ty, j = j0 + tx;
+        if (i >= C.Hc || j >= C.Wc) continue;
+        const int ho = C.ph + i * p.ostep, wo = C.pw + j * p.ostep;
+        float* yp = p.y + ((long long)(n_img * p.Ho + ho) * p.Wo + wo) * p.y_ld + p.y_coff;
+#pragma unroll
+        for (int nn = 0; nn < NT; ++nn) {
+            const int ch0 = n_base + wn * (BN / WN) + nn * 16 + (lane >> 4) * 4;
+            if (ch0 >= p.Cout) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float tv = acc[nn][m][r] * p.alpha;
+                const int ch = ch0 + r;
+                if (ch < p.Cout) {
+                    if (p.bias) tv += p.bias[ch];
+                    if (p.accumulate == 2) tv += yp[ch];
+                }
+                v[r] = hv_act(tv, p.act);
+            }
+            if (p.vec_store && ch0 + 3 < p.Cout) {
+                float4 o = make_float4(v[0], v[1], v[2], v[3]);
+                if (p.accumulate == 1) {
+                    const float4 old = *reinterpret_cast<const float4*>(yp + ch0);
+                    o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+                }
+                *reinterpret_cast<float4*>(yp + ch0) = o;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (ch0 + r < p.Cout) yp[ch0 + r] = p.accumulate == 1 ? yp[ch0 + r] + v[r] : v[r];
+            }
+        }
+    }
+}
+
+template <int TH, int TW, int BN, int WM, int WN, int TG, int CK>
+static int launch_halo(const HaloK& k, int tiles, int maxpatch, hipStream_t s) {
+    constexpr int LDP = CK + 8;
+    const size_t lds = (size_t)(2 * TG * BN * LDP + maxpatch * LDP) * sizeof(_Float16);
+    if (lds > 150 * 1024) return HV_ERR_UNSUPPORTED;
+    auto kern = conv_halo_kernel<TH, TW, BN, WM, WN, TG, CK>;
+    static int lds_limit = 48 * 1024;   // per instantiation: raise the dynamic-LDS cap once (not a stream operation)
+    if ((int)lds > lds_limit) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e != hipSuccess) return -1000 - (int)e;
+        lds_limit = 150 * 1024;
+    }
+    dim3 grid(tiles, hv_cdiv(k.Cout, BN));
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, k);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+
+template <int TH, int TW, int CK>
+static int dispatch_halo_bn(HaloK& k, int maxpatch, hipStream_t s) {
+    int tiles = 0;
+    for (int c = 0; c < k.ncls; ++c) {
+        HaloCls& C = k.cls[c];
+        C.tiles_x = hv_cdiv(C.Wc, TW);
+        C.tiles = C.tiles_x * hv_cdiv(C.Hc, TH);
+        C.t0 = tiles;
+        tiles += C.tiles * k.B;
+    }
+    if (k.Cout <= 16) return launch_halo<TH, TW, 16, 4, 1, 16, CK>(k, tiles, maxpatch, s);
+    if (k.Cout <= 32) return launch_halo<TH, TW, 32, 4, 1, 8, CK>(k, tiles, maxpatch, s);
+    if (k.Cout <= 64) return launch_halo<TH, TW, 64, 2, 2, 4, CK>(k, tiles, maxpatch, s);
+    return launch_halo<TH, TW, 128, 2, 2, 2, CK>(k, tiles, maxpatch, s);
+}
+
+// Called by hv_conv2d when the fp16 weight copy is present and the shape qualifies; returns HV_ERR_UNSUPPORTED to
+// fall back to the gather kernel.
+int hv_conv2d_halo(const hv_conv_desc* d, const void* w_f16, hipStream_t s) {
+    if (d->dil != 1 || (d->Cin & 15) || d->w_bstride || d->ch_scale || d->KH * d->KW > 16 || d->stride > 2) return HV_ERR_UNSUPPORTED;
+    if ((d->x_ld & 3) || (d->x_coff & 3) || ((uintptr_t)d->x & 15) || ((uintptr_t)w_f16 & 15)) return HV_ERR_UNSUPPORTED;
+    HaloK k;
+    const int Hp = d->H >> d->in_shift, Wp = d->W >> d->in_shift;
+    k.x = d->x; k.w = (const _Float16*)w_f16; k.bias = d->bias; k.y = d->y;
+    k.B = d->B; k.Hl = d->H; k.Wl = d->W; k.in_shift = d->in_shift; k.Wp = Wp; k.img_stride = Hp * Wp * d->x_ld;
+    k.x_ld = d->x_ld; k.x_coff = d->x_coff; k.Cin = d->Cin;
+    k.Cout = d->Cout; k.w_row = d->KH * d->KW * d->Cin; k.y_ld = d->y_ld; k.y_coff = d->y_coff; k.Ho = d->Ho; k.Wo = d->Wo;
+    k.alpha = d->alpha; k.act = d->act; k.accumulate = d->accumulate;
+    k.vec_store = ((d->y_ld & 3) == 0 && (d->y_coff & 3) == 0 && ((uintptr_t)d->y & 15) == 0) ? 1 : 0;
+    int dhs[4][16], dws[4][16], wis[4][16];
+    if (!d->transposed) {
+        k.ncls = 1; k.bstep = d->stride; k.boff = -d->pad; k.ostep = 1;
+        HaloCls& c = k.cls[0];
+        c.ph = c.pw = 0; c.Hc = d->Ho; c.Wc = d->Wo; c.ntaps = d->KH * d->KW;
+        for (int r = 0; r < d->KH; ++r)
+            for (int q = 0; q < d->KW; ++q) { dhs[0][r * d->KW + q] = r; dws[0][r * d->KW + q] = q; wis[0][r * d->KW + q] = r * d->KW + q; }
+    } else {
+        k.bstep = 1; k.boff = 0; k.ostep = d->stride; k.ncls = 0;
+        for (int ph = 0; ph < d->stride; ++ph)
+            for (int pw = 0; pw < d->stride; ++pw) {
+                HaloCls& c = k.cls[k.ncls];
+                c.ph = ph; c.pw = pw;
+                c.Hc = (d->Ho - ph + d->stride - 1) / d->stride;
+                c.Wc = (d->Wo - pw + d->stride - 1) / d->stride;
+                if (c.Hc <= 0 || c.Wc <= 0) continue;
+                c.ntaps = 0;
+                for (int r = 0; r < d->KH; ++r) {
+                    const int vh = ph + d->pad - r;
+                    if (((vh % d->stride) + d->stride) % d->stride) continue;
+                    for (int q = 0; q < d->KW; ++q) {
+                        const int vw = pw + d->pad - q;
+                        if (((vw % d->stride) + d->stride) % d->stride) continue;
+                        dhs[k.ncls][c.ntaps] = vh / d->stride; dws[k.ncls][c.ntaps] = vw / d->stride; wis[k.ncls][c.ntaps] = r * d->KW + q;
+                        ++c.ntaps;
+                    }
+                }
+                if (c.ntaps == 0) return HV_ERR_UNSUPPORTED;   // rare (k < stride): let the gather kernel write the zeros
+                ++k.ncls;
+            }
+        if (k.ncls == 0) return HV_ERR_UNSUPPORTED;
+    }
+    // tile shape: 8x32 output pixels for unit input step, 8x16 when the patch grows with stride 2
+    bool small_tile = k.bstep == 2;
+    if (!small_tile) {   // 8x32 tiles would leave CUs idle on small feature maps: fall back to 8x16
+        long long wgs = 0;
+        const int bn = d->Cout <= 16 ? 16 : d->Cout <= 32 ? 32 : d->Cout <= 64 ? 64 : 128;
+        for (int c = 0; c < k.ncls; ++c) wgs += (long long)hv_cdiv(k.cls[c].Hc, 8) * hv_cdiv(k.cls[c].Wc, 32) * d->B * hv_cdiv(d->Cout, bn);
+        if (wgs < 400) small_tile = true;
+    }
+    const int TH = 8, TW = small_tile ? 16 : 32;
+    int maxpatch = 0;
+    for (int c = 0; c < k.ncls; ++c) {
+        HaloCls& C = k.cls[c];
+        int dh0 = 1 << 20, dh1 = -(1 << 20), dw0 = 1 << 20, dw1 = -(1 << 20);
+        for (int t = 0; t < C.ntaps; ++t) {
+            dh0 = dhs[c][t] < dh0 ? dhs[c][t] : dh0; dh1 = dhs[c][t] > dh1 ? dhs[c][t] : dh1;
+            dw0 = dws[c][t] < dw0 ? dws[c][t] : dw0; dw1 = dws[c][t] > dw1 ? dws[c][t] : dw1;
+        }
+        C.dh_min = dh0; C.dw_min = dw0;
+        C.PH = (TH - 1) * k.bstep + (dh1 - dh0) + 1;
+        C.PW = (TW - 1) * k.bstep + (dw1 - dw0) + 1;
+        for (int t = 0; t < C.ntaps; ++t)
+            C.taps[t] = (uint32_t)(dhs[c][t] - dh0) | ((uint32_t)(dws[c][t] - dw0) << 8) | ((uint32_t)wis[c][t] << 16);
+        if (C.PH * C.PW > maxpatch) maxpatch = C.PH * C.PW;
+    }
+    const bool ck32 = (d->Cin & 31) == 0;
+    if (small_tile) return ck32 ? dispatch_halo_bn<8, 16, 32>(k, maxpatch, s) : dispatch_halo_bn<8, 16, 16>(k, maxpatch, s);
+    return ck32 ? dispatch_halo_bn<8, 32, 32>(k, maxpatch, s) : dispatch_halo_bn<8, 32, 16>(k, maxpatch, s);
+}

@@ -18,6 +18,8 @@
 #define HV_MAX_TAPS 25
 #define HV_BK 32
 
+int hv_conv2d_halo(const hv_conv_desc* d, const void* w_f16, hipStream_t s);   // conv_halo.hip
+
 struct ConvCls {
     int ph, pw, Hc, Wc, ntaps, Ktot, m0, mcount;
     uint32_t taps[HV_MAX_TAPS];  // dh(int8) | dw(int8)<<8 | widx<<16
@@ -309,6 +311,8 @@ static int dispatch_conv(ConvK& k, hipStream_t s) {
     if (BN >= 64) {
         long long tiles = ((M + BM - 1) / BM) * ((k.Cout + BN - 1) / BN);
         if (tiles < 160) { BM = 64; BN = 64; }
+    } else if (BN == 16 && (M + 255) / 256 < 256) {
+        BM = 64;   // narrow outputs on small feature maps (PatchGAN logits): more, smaller workgroups
     }
     if (k.w_bs || k.scale_bs) {  // per-sample operands: a tile must stay inside one image
         for (int c = 0; c < k.ncls; ++c)
@@ -324,6 +328,7 @@ static int dispatch_conv(ConvK& k, hipStream_t s) {
     }
     if (mt <= 0) return HV_OK;
     if (BM == 256 && BN == 16) return launch_conv<T, 256, 16, 4, 1, ASC>(k, mt, s);
+    if (BM == 64 && BN == 16) return launch_conv<T, 64, 16, 4, 1, ASC>(k, mt, s);
     if (BM == 256 && BN == 32) return launch_conv<T, 256, 32, 4, 1, ASC>(k, mt, s);
     if (BM == 128 && BN == 64) return launch_conv<T, 128, 64, 2, 2, ASC>(k, mt, s);
     if (BM == 128 && BN == 128) return launch_conv<T, 128, 128, 2, 2, ASC>(k, mt, s);
@@ -345,6 +350,10 @@ extern "C" int hv_conv2d(const hv_conv_desc* d, void* stream) {
         return HV_ERR_UNSUPPORTED;
     if (d->H > 16000 || d->W > 16000 || (d->KH - 1) * d->dil > 120 || (d->KW - 1) * d->dil > 120) return HV_ERR_UNSUPPORTED;
 
+    if (d->precision == HV_F16 && d->w_f16) {   // halo-tiled fast path (conv_halo.hip) when the shape qualifies
+        const int rc = hv_conv2d_halo(d, d->w_f16, (hipStream_t)stream);
+        if (rc != HV_ERR_UNSUPPORTED) return rc;
+    }
     ConvK k;
     k.x = d->x; k.w = d->w; k.bias = d->bias; k.scale = d->ch_scale; k.y = d->y;
     k.w_bs = d->w_bstride; k.scale_bs = d->ch_scale ? d->ch_scale_bstride : 0;
@@ -608,7 +617,8 @@ static int wgrad_plan(const hv_wgrad_desc* d, WgradPlan* pl) {
     else if (d->Cout <= 64) { BN = 64; BC = 64; }
     else { BN = 128; BC = 64; }
     const long long tiles = (long long)hv_cdiv(d->Cout, BN) * hv_cdiv(J, BC);
-    long long want = (768 + tiles - 1) / tiles;           // aim for ~3 workgroups per CU
+    // ~3 workgroups per CU; layers whose dW already has many tiles get few splits (slab traffic grows with splits)
+    long long want = tiles >= 128 ? (512 + tiles - 1) / tiles : (768 + tiles - 1) / tiles;
     if (want > 256) want = 256;
     long long maxs = (M + 255) / 256;                     // at least 256 pixels per split
     long long splits = want < 1 ? 1 : want;

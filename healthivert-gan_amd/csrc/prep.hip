@@ -95,6 +95,7 @@ __global__ __launch_bounds__(256) void weight_layout_kernel(const hv_wprep_layer
             float val = 0.f;
             if (co < L.Cout && ci < L.Cin) val = L.w_orig[wsrc_index(L, co, ci, tap)] / sigma;
             L.w_fwd[i] = val;
+            if (L.w_fwd_h) reinterpret_cast<_Float16*>(L.w_fwd_h)[i] = (_Float16)val;
         } else if (i < nf + nb) {
             i -= nf;
             const int co = (int)(i % L.CoutP);
@@ -103,6 +104,7 @@ __global__ __launch_bounds__(256) void weight_layout_kernel(const hv_wprep_layer
             float val = 0.f;
             if (co < L.Cout && ci < L.Cin) val = L.w_orig[wsrc_index(L, co, ci, tap)] / sigma;
             L.w_bwd[i] = val;
+            if (L.w_bwd_h) reinterpret_cast<_Float16*>(L.w_bwd_h)[i] = (_Float16)val;
         }
     }
 }

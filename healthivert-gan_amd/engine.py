@@ -78,6 +78,14 @@ class ParamSet:
             c.dw = store[off:off + d]; off += d
             c.sigma = store[off:off + 4]; off += 4
         self._store = store
+        # fp16 copies of the prepared weights (halo-tiled conv kernel, HV_F16 precision)
+        hstore = torch.zeros(sum(c.sizes()[0] + c.sizes()[1] + 16 for c in self.convs), dtype=torch.float16, device=device)
+        off = 0
+        for c in self.convs:
+            a, b, _ = c.sizes()
+            c.w_fwd_h = hstore[off:off + a]; off += (a + 7) // 8 * 8
+            c.w_bwd_h = hstore[off:off + b]; off += (b + 7) // 8 * 8
+        self._hstore = hstore
         # flat gradients; .grad of every trainable tensor is a view into it
         ps = self.trainable()
         n = sum(p.numel() for p in ps)
@@ -90,7 +98,7 @@ class ParamSet:
             rows = []
             for c in self.convs:
                 rows.append(dict(w_orig=c.weight.data, u=c.u if c.sn else None, v=c.v if c.sn else None, sigma=c.sigma,
-                                 w_fwd=c.w_fwd, w_bwd=c.w_bwd, Cout=c.cout, Cin=c.cin, taps=c.taps, CinP=c.cin_fwd,
+                                 w_fwd=c.w_fwd, w_bwd=c.w_bwd, w_fwd_h=c.w_fwd_h, w_bwd_h=c.w_bwd_h, Cout=c.cout, Cin=c.cin, taps=c.taps, CinP=c.cin_fwd,
                                  CoutF=c.cout, CoutP=c.coutP, CinB=c.cin_fwd, sn=int(c.sn), power_iter=int(pi and c.sn),
                                  transposed_src=int(c.transposed_src)))
             self.t_prep[pi].update(rows, key, device)
@@ -132,7 +140,7 @@ class ConvNode:
     def forward(self, prec):
         p = self.p
         xin = Act(self.x.t, p.cin_fwd, self.x.coff)
-        ops.conv2d(xin, p.w_fwd, self.y, self.k, self.s, self.pad, self.d, bias=p.bias if self.use_bias else None, act=self.act,
+        ops.conv2d(xin, p.w_fwd, self.y, self.k, self.s, self.pad, self.d, bias=p.bias if self.use_bias else None, act=self.act, w_h=p.w_fwd_h,
                    in_shift=self.shift, transposed=self.transposed, precision=prec, cout=p.cout)
 
 
@@ -183,16 +191,16 @@ def conv_backward(node, book, prec, dbias_accumulate=False, wgrad_accumulate=Fal
     if node.need_dx and node.transposed:
         gx = book.twin(node.x)
         gx = Act(gx.t, p.cin_fwd, gx.coff)
-        ops.conv2d(gfull, p.w_bwd, gx, node.k, node.s, node.pad, node.d, transposed=False, accumulate=int(book.mark(gx)), precision=prec)
+        ops.conv2d(gfull, p.w_bwd, gx, node.k, node.s, node.pad, node.d, transposed=False, accumulate=int(book.mark(gx)), precision=prec, w_h=p.w_bwd_h)
     elif node.need_dx:
         gx = book.twin(node.x)
         gx = Act(gx.t, p.cin_fwd, gx.coff)
         if node.shift:
             full = tmp_full
-            ops.conv2d(gfull, p.w_bwd, full, node.k, node.s, node.pad, node.d, transposed=True, precision=prec)
+            ops.conv2d(gfull, p.w_bwd, full, node.k, node.s, node.pad, node.d, transposed=True, precision=prec, w_h=p.w_bwd_h)
             ops.copy_channels(full, gx, mode=3, accumulate=book.mark(gx))
         else:
-            ops.conv2d(gfull, p.w_bwd, gx, node.k, node.s, node.pad, node.d, transposed=True, accumulate=int(book.mark(gx)),
+            ops.conv2d(gfull, p.w_bwd, gx, node.k, node.s, node.pad, node.d, transposed=True, accumulate=int(book.mark(gx)), w_h=p.w_bwd_h,
                        precision=prec)
 
 

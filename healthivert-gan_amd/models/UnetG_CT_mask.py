@@ -10,10 +10,11 @@ import torch
 import torch.nn as nn
 from torch.nn import init
 
-from .. import engine as E
-from .. import lib as _lib
-from .. import ops
-from ..ops import Act, rup
+from ._backend import engine as E
+from ._backend import lib as _lib
+from ._backend import ops
+from ._backend import ops as _ops_
+Act, rup = _ops_.Act, _ops_.rup
 from .networks import init_weights  # same initialiser as the reference's private copy (:11-42)
 
 

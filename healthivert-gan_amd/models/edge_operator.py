@@ -3,8 +3,8 @@ Prewitt / Canny / edge_loss of the reference are never called by the hot path an
 import torch
 import torch.nn as nn
 
-from .. import lib as _lib
-from .. import ops
+from ._backend import lib as _lib
+from ._backend import ops
 
 
 class Sobel(nn.Module):

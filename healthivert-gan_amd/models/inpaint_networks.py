@@ -11,11 +11,13 @@ import torch
 import torch.nn as nn
 from torch.nn.utils import spectral_norm as _sn_register
 
-from .. import engine as E
-from .. import lib as _lib
-from .. import ops
-from ..lib import ptr, stream
-from ..ops import Act, rup
+from ._backend import engine as E
+from ._backend import lib as _lib
+from ._backend import ops
+from ._backend import lib as _lib_
+ptr, stream = _lib_.ptr, _lib_.stream
+from ._backend import ops as _ops_
+Act, rup = _ops_.Act, _ops_.rup
 
 _ACTS = ('relu', 'elu', 'lrelu', 'prelu', 'selu', 'tanh', 'sigmoid', 'none')
 

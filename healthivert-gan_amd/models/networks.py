@@ -14,10 +14,11 @@ import torch.nn as nn
 from torch.nn import init
 from torch.optim import lr_scheduler
 
-from .. import engine as E
-from .. import lib as _lib
-from .. import ops
-from ..ops import Act, rup
+from ._backend import engine as E
+from ._backend import lib as _lib
+from ._backend import ops
+from ._backend import ops as _ops_
+Act, rup = _ops_.Act, _ops_.rup
 
 
 class Identity(nn.Module):

@@ -10,11 +10,13 @@ import ctypes
 
 import torch
 
-from .. import ddp
-from .. import lib as _lib
-from .. import ops
-from ..lib import ptr, stream
-from ..optim import FusedAdam
+from ._backend import ddp
+from ._backend import lib as _lib
+from ._backend import ops
+from ._backend import lib as _lib_
+ptr, stream = _lib_.ptr, _lib_.stream
+from ._backend import optim as _optim_
+FusedAdam = _optim_.FusedAdam
 from . import networks
 from .base_model import BaseModel
 from .edge_operator import Sobel

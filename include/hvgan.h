@@ -61,6 +61,8 @@ typedef struct {
     float alpha; int act; int accumulate;   /* accumulate: 0 y = r; 1 y += r (after act); 2 y = act(r + y) */
     float* y; int Ho, Wo, y_ld, y_coff;
     int precision;
+    const void* w_f16;                /* optional fp16 copy of w (same layout, from hv_weight_prep): enables the
+                                         halo-tiled kernel for HV_F16, dilation 1, Cin % 16 == 0, shared filters */
 } hv_conv_desc;
 int hv_conv2d(const hv_conv_desc* d, void* stream);
 
@@ -89,6 +91,7 @@ typedef struct {
     float* sigma;         /* [4] scratch: [0] = sigma out (1.0 when sn=0), [1] = <dWsn,Wsn> written by the backward */
     float* w_fwd;         /* [CoutF][taps][CinP]  rows >= Cout and channels >= Cin are zero */
     float* w_bwd;         /* [CinB][taps][CoutP]  or NULL */
+    void* w_fwd_h; void* w_bwd_h;   /* optional fp16 copies of w_fwd / w_bwd (same layouts) or NULL */
     int Cout, Cin, taps, CinP, CoutF, CoutP, CinB;
     int sn, power_iter, transposed_src;
 } hv_wprep_layer;

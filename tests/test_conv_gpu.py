@@ -104,6 +104,52 @@ def test_conv_wgrad(case, prec, tol):
     assert err <= tol * max(1.0, w.grad.abs().max().item()), err
 
 
+HALO_CASES = [
+    # B, H, W, Cin, Cout, k, stride, pad, act, in_shift
+    (2, 32, 32, 16, 16, 3, 1, 1, 'elu', 0),
+    (2, 40, 24, 32, 64, 3, 1, 1, 'elu', 0),
+    (2, 32, 32, 64, 32, 3, 2, 1, 'elu', 0),
+    (3, 31, 31, 128, 256, 4, 1, 1, 'none', 0),
+    (2, 64, 64, 64, 128, 4, 2, 1, 'lrelu', 0),
+    (2, 16, 16, 64, 32, 3, 1, 1, 'elu', 1),
+    (16, 32, 32, 256, 512, 4, 1, 1, 'none', 0),
+    (2, 30, 30, 48, 8, 3, 1, 1, 'sigmoid', 0),
+]
+
+
+@pytest.mark.parametrize('case', HALO_CASES)
+def test_conv_halo_tiled_fp16_forward_and_dgrad(case):
+    """The halo-tiled fp16 kernel (taken when the fp16 weight copy is passed) against torch CPU fp32."""
+    from hvtest import to_act, from_act, ohwi, ohwi_T, dev, maxerr
+    from hvgan import ops
+    B, H, W, Cin, Cout, k, s, p, act, shift = case
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    xin = F.interpolate(x, scale_factor=2, mode='nearest') if shift else x
+    xin = xin.clone().requires_grad_(True)
+    y0 = F.conv2d(xin, w, b, stride=s, padding=p)
+    ref = _ref_act(y0, act)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    ya = ops.Act.empty(B, Ho, Wo, Cout, dev())
+    wf = ohwi(w)
+    ops.conv2d(to_act(x), wf, ya, k, s, p, 1, bias=b.to(dev()), act=act, in_shift=shift, precision='fp16', w_h=wf.half())
+    torch.cuda.synchronize()
+    err = maxerr(from_act(ya), ref.detach())
+    assert err <= 4e-3 * max(1.0, ref.abs().max().item()), err
+    if shift or Cout % 16:
+        return
+    gy = torch.randn(y0.shape, generator=g)
+    y0.backward(gy)
+    wb = ohwi_T(w)
+    dxa = ops.Act.empty(B, H, W, Cin, dev())
+    ops.conv2d(to_act(gy), wb, dxa, k, s, p, 1, transposed=True, precision='fp16', w_h=wb.half())
+    torch.cuda.synchronize()
+    err = maxerr(from_act(dxa), xin.grad)
+    assert err <= 4e-3 * max(1.0, xin.grad.abs().max().item()), err
+
+
 def test_conv_upsample_fused_and_transposed_conv_layer():
     """in_shift=1 == conv(F.interpolate(x, 2)); transposed=1 == F.conv_transpose2d (k4 s2 p1)."""
     from hvtest import to_act, from_act, ohwi, dev, maxerr

@@ -1,0 +1,23 @@
+"""Per-layer timing of one train step (HIP events around every conv / wgrad launch); prints the heaviest kernel classes."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+os.environ['HV_PRECISION'] = sys.argv[1] if len(sys.argv) > 1 else 'fp16'
+import hvgan
+from hvgan import synth, profiler
+from hvgan.models.pix2pix_model import Pix2PixModel
+torch.manual_seed(1234)
+opt = bench.make_opt(os.environ['HV_PRECISION'])
+model = Pix2PixModel(opt); model.setup(opt)
+model.set_input(synth.make_batch(16, 256, seed=1234))
+for _ in range(2):
+    model.optimize_parameters()
+torch.cuda.synchronize()
+prof = profiler.KernelTimer(); prof.enable()
+model.optimize_parameters()
+agg = prof.summary(); prof.disable()
+tot = sum(v[0] for v in agg.values())
+print('conv+wgrad total ms', round(tot, 3))
+for key, (ms, n, fl) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:28]:
+    print('%7.3f ms  n=%2d  avg %7.1f us  %6.1f TF  %s' % (ms, n, ms / n * 1e3, fl / (ms / n * 1e-3) / 1e12, profiler.describe(key)))
