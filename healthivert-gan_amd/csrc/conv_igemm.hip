@@ -615,7 +615,7 @@ static int wgrad_plan(const hv_wgrad_desc* d, WgradPlan* pl) {
     if (d->Cout <= 16) { BN = 16; BC = 128; }
     else if (d->Cout <= 32) { BN = 32; BC = 128; }
     else if (d->Cout <= 64) { BN = 64; BC = 64; }
-    else { BN = 128; BC = 64; }
+    else { BN = 128; BC = J >= 4096 ? 128 : 64; }
     const long long tiles = (long long)hv_cdiv(d->Cout, BN) * hv_cdiv(J, BC);
     // ~3 workgroups per CU; layers whose dW already has many tiles get few splits (slab traffic grows with splits)
     long long want = tiles >= 128 ? (512 + tiles - 1) / tiles : (768 + tiles - 1) / tiles;
@@ -659,6 +659,7 @@ static int launch_wgrad(const WgradK& k, const WgradPlan& pl, hipStream_t s) {
     if (pl.BN == 16) hipLaunchKernelGGL((wgrad_kernel<T, 16, 128, 1, 4>), grid, dim3(256), 0, s, k);
     else if (pl.BN == 32) hipLaunchKernelGGL((wgrad_kernel<T, 32, 128, 1, 4>), grid, dim3(256), 0, s, k);
     else if (pl.BN == 64) hipLaunchKernelGGL((wgrad_kernel<T, 64, 64, 2, 2>), grid, dim3(256), 0, s, k);
+    else if (pl.BC == 128) hipLaunchKernelGGL((wgrad_kernel<T, 128, 128, 2, 2>), grid, dim3(256), 0, s, k);
     else hipLaunchKernelGGL((wgrad_kernel<T, 128, 64, 2, 2>), grid, dim3(256), 0, s, k);
     HV_LAUNCH_CHECK();
     return HV_OK;

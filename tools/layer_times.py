@@ -21,3 +21,12 @@ tot = sum(v[0] for v in agg.values())
 print('conv+wgrad total ms', round(tot, 3))
 for key, (ms, n, fl) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:28]:
     print('%7.3f ms  n=%2d  avg %7.1f us  %6.1f TF  %s' % (ms, n, ms / n * 1e3, fl / (ms / n * 1e-3) / 1e12, profiler.describe(key)))
+kinds = {}
+for key, (ms, n, fl) in agg.items():
+    k = key[0] + ('_T' if key[-1] else '')
+    kinds[k] = kinds.get(k, 0.0) + ms
+print('by kind', {k: round(v, 2) for k, v in kinds.items()})
+print('--- all wgrad')
+for key, (ms, n, fl) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+    if key[0] == 'wgrad':
+        print('%7.3f ms  n=%2d  avg %7.1f us  %6.1f TF  %s' % (ms, n, ms / n * 1e3, fl / (ms / n * 1e-3) / 1e12, profiler.describe(key)))
