@@ -19,6 +19,8 @@
 #define HV_BK 32
 
 int hv_conv2d_halo(const hv_conv_desc* d, const void* w_f16, hipStream_t s);   // conv_halo.hip
+size_t hv_wgrad_halo_workspace_bytes(const hv_wgrad_desc* d);                  // wgrad_halo.hip
+int hv_wgrad_halo(const hv_wgrad_desc* d, int* nslabs, hipStream_t s);
 
 struct ConvCls {
     int ph, pw, Hc, Wc, ntaps, Ktot, m0, mcount;
@@ -647,6 +649,8 @@ static int wgrad_validate(const hv_wgrad_desc* d) {
 
 extern "C" size_t hv_conv2d_wgrad_workspace_bytes(const hv_wgrad_desc* d) {
     if (wgrad_validate(d) != HV_OK) return 0;
+    const size_t halo = hv_wgrad_halo_workspace_bytes(d);
+    if (halo) return halo;
     WgradPlan pl;
     wgrad_plan(d, &pl);
     if (pl.splits <= 1 && !d->accumulate) return 0;
@@ -668,9 +672,19 @@ static int launch_wgrad(const WgradK& k, const WgradPlan& pl, hipStream_t s) {
 extern "C" int hv_conv2d_wgrad(const hv_wgrad_desc* d, void* stream) {
     int rc = wgrad_validate(d);
     if (rc != HV_OK) return rc;
+    const long long nW = (long long)d->Cout * d->KH * d->KW * d->Cin;
+    {   // halo-tiled fast path (wgrad_halo.hip): 3x3 / 5x5, stride 1, fp16
+        int nslabs = 0;
+        rc = hv_wgrad_halo(d, &nslabs, (hipStream_t)stream);
+        if (rc == HV_OK) {
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(hv_cdiv(nW, 64)), dim3(256), 0, (hipStream_t)stream, d->workspace, d->dw, nW, nslabs, d->accumulate);
+            HV_LAUNCH_CHECK();
+            return HV_OK;
+        }
+        if (rc != HV_ERR_UNSUPPORTED) return rc;
+    }
     WgradPlan pl;
     wgrad_plan(d, &pl);
-    const long long nW = (long long)d->Cout * d->KH * d->KW * d->Cin;
     const bool direct = pl.splits <= 1 && !d->accumulate;
     if (!direct) {
         if (!d->workspace || d->workspace_bytes < (size_t)pl.splits * nW * sizeof(float)) return HV_ERR_WORKSPACE;

@@ -1,0 +1,222 @@
+// Halo-tiled weight gradient (fp16 MFMA operands, fp32 accumulate) for stride-1, dilation-1, 3x3 / 5x5 convolutions.
+//
+//   dW[co][(r,q)][ci] = sum_{n,oy,ox} g[n,oy,ox,co] * x[n, oy-pad+r, ox-pad+q, ci]
+//
+// The gather kernel (conv_igemm.hip: wgrad_kernel) re-reads x from L2 once per tap and g once per column tile.  Here a
+// workgroup walks output tiles of 8 rows x 32 pixels; per tile it stages g (8x32 pixels x BN channels) and the
+// (8+k-1) x (32+k-1) input patch (x BC channels) ONCE, transposed to [channel][row][pixel] fp16 in LDS so that the
+// contraction index (pixels along W) is contiguous for v_mfma_f32_16x16x32_f16.  A tap (r,q) is a shifted window of the
+// patch: row shift r is an address offset; column shift q is taken out of a 16-pixel aligned window in registers
+// (dword select for even q, v_alignbit for odd q) -- no misaligned LDS reads, no per-tap reloads.  Each wave owns two of
+// the eight rows and keeps all taps' accumulators; the four waves are summed in LDS and one slab per workgroup goes to
+// the deterministic slab reduction.
+#include "hv_common.h"
+
+struct WHaloK {
+    const float* x; const float* g; float* slabs;
+    int B, Hl, Wl, in_shift, Wp, img_stride, x_ld, x_coff, Cin;
+    int Ho, Wo, g_ld, g_coff, Cout, pad;
+    int tiles_x, tiles_per_img, ntiles;
+    long long slab;   // floats per slab = Cout * KS*KS * Cin
+};
+
+__device__ __forceinline__ uint32_t hv_pack2(float a, float b) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    h2 v = {(_Float16)a, (_Float16)b};
+    return *reinterpret_cast<uint32_t*>(&v);
+}
+
+template <int Q> __device__ __forceinline__ f16x8 window_frag(const uint32_t (&w)[8]) {
+    uint32_t o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (Q & 1) o[i] = __builtin_amdgcn_alignbit(w[(Q + 1) / 2 + i], w[(Q - 1) / 2 + i], 16);
+        else o[i] = w[Q / 2 + i];
+    }
+    uint4 u = make_uint4(o[0], o[1], o[2], o[3]);
+    return *reinterpret_cast<f16x8*>(&u);
+}
+
+template <int KS, int BN, int BC>
+__global__ __launch_bounds__(256) void wgrad_halo_kernel(const WHaloK p) {
+    constexpr int TH = 8, TW = 32, PH = TH + KS - 1, PWP = 40;   // 40 halfs per patch row: 32 + k - 1 <= 40, 16 B aligned
+    constexpr int NT = BN / 16, CT = BC / 16, TAPS = KS * KS;
+    constexpr int GROW = TW + 8;                                  // padded g row (halfs)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    _Float16* Gt = reinterpret_cast<_Float16*>(smem);             // [BN][TH][GROW]
+    _Float16* Xt = Gt + BN * TH * GROW;                          // [BC][PH][PWP]
+    float* red = reinterpret_cast<float*>(smem);                  // [TAPS][BN][BC] after the tile loop (aliases Gt/Xt)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int co0 = blockIdx.y * BN, ci0 = blockIdx.z * BC;
+    f32x4 acc[TAPS][NT][CT];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int c = 0; c < CT; ++c) acc[t][n][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        const int n_img = tile / p.tiles_per_img, tr = tile - n_img * p.tiles_per_img;
+        const int oy0 = (tr / p.tiles_x) * TH, ox0 = (tr % p.tiles_x) * TW;
+        __syncthreads();   // previous tile's MFMA reads are done
+        // ---- stage g: units = (BN/4 channel groups) x TH rows x 4 runs of 8 pixels
+        for (int u = tid; u < (BN / 4) * TH * 4; u += 256) {
+            const int cg = u % (BN / 4), rr = u / (BN / 4), run = rr & 3, ty = rr >> 2;
+            const int oy = oy0 + ty, co = co0 + cg * 4;
+            float4 v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int ox = ox0 + run * 8 + e;
+                v[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (oy < p.Ho && ox < p.Wo && co < p.Cout)
+                    v[e] = *reinterpret_cast<const float4*>(p.g + ((long long)(n_img * p.Ho + oy) * p.Wo + ox) * p.g_ld + p.g_coff + co);
+            }
+            const float* f = reinterpret_cast<const float*>(v);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                uint4 h = make_uint4(hv_pack2(f[c], f[4 + c]), hv_pack2(f[8 + c], f[12 + c]), hv_pack2(f[16 + c], f[20 + c]), hv_pack2(f[24 + c], f[28 + c]));
+                *reinterpret_cast<uint4*>(Gt + ((cg * 4 + c) * TH + ty) * GROW + run * 8) = h;
+            }
+        }
+        // ---- stage the x patch: units = (BC/4) x PH rows x 5 runs of 8 patch columns
+        const float* ximg = p.x + (long long)n_img * p.img_stride + p.x_coff;
+        for (int u = tid; u < (BC / 4) * PH * 5; u += 256) {
+            const int cg = u % (BC / 4), rr = u / (BC / 4), run = rr % 5, py = rr / 5;
+            const int hi = oy0 - p.pad + py, ci = ci0 + cg * 4;
+            float4 v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int wi = ox0 - p.pad + run * 8 + e;
+                v[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if ((unsigned)hi < (unsigned)p.Hl && (unsigned)wi < (unsigned)p.Wl && ci < p.Cin)
+                    v[e] = *reinterpret_cast<const float4*>(ximg + (long long)((hi >> p.in_shift) * p.Wp + (wi >> p.in_shift)) * p.x_ld + ci);
+            }
+            const float* f = reinterpret_cast<const float*>(v);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                uint4 h = make_uint4(hv_pack2(f[c], f[4 + c]), hv_pack2(f[8 + c], f[12 + c]), hv_pack2(f[16 + c], f[20 + c]), hv_pack2(f[24 + c], f[28 + c]));
+                *reinterpret_cast<uint4*>(Xt + ((cg * 4 + c) * PH + py) * PWP + run * 8) = h;
+            }
+        }
+        __syncthreads();
+        // ---- MFMA: this wave's rows ty = wave, wave + 4
+#pragma unroll
+        for (int rrow = 0; rrow < 2; ++rrow) {
+            const int ty = wave + rrow * 4;
+            f16x8 gf[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) gf[n] = *reinterpret_cast<const f16x8*>(Gt + ((n * 16 + (lane & 15)) * TH + ty) * GROW + (lane >> 4) * 8);
+#pragma unroll
+            for (int r = 0; r < KS; ++r) {
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    const _Float16* row = Xt + ((c * 16 + (lane & 15)) * PH + ty + r) * PWP + (lane >> 4) * 8;
+                    uint32_t w[8];
+                    *reinterpret_cast<uint4*>(&w[0]) = *reinterpret_cast<const uint4*>(row);
+                    *reinterpret_cast<uint4*>(&w[4]) = *reinterpret_cast<const uint4*>(row + 8);
+#pragma unroll
+                    for (int q = 0; q < KS; ++q) {
+                        f16x8 xf;
+                        if (q == 0) xf = window_frag<0>(w);
+                        else if (q == 1) xf = window_frag<1>(w);
+                        else if (q == 2) xf = window_frag<2>(w);
+                        else if (q == 3) xf = window_frag<3>(w);
+                        else xf = window_frag<4>(w);
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+                            acc[r * KS + q][n][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gf[n], xf, acc[r * KS + q][n][c], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // ---- sum the four waves in LDS (fixed order), write one slab per workgroup
+    __syncthreads();
+    for (int wv = 0; wv < 4; ++wv) {
+        if (wave == wv) {
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int c = 0; c < CT; ++c)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            // D layout: row (= co) = (lane>>4)*4 + r, col (= ci) = lane & 15
+                            float* d = red + (t * BN + n * 16 + (lane >> 4) * 4 + r) * BC + c * 16 + (lane & 15);
+                            *d = wv == 0 ? acc[t][n][c][r] : *d + acc[t][n][c][r];
+                        }
+        }
+        __syncthreads();
+    }
+    float* out = p.slabs + (long long)blockIdx.x * p.slab;
+    for (int e = tid; e < TAPS * BN * BC; e += 256) {
+        const int ci = e % BC, r2 = e / BC, co = r2 % BN, t = r2 / BN;
+        if (co0 + co < p.Cout && ci0 + ci < p.Cin) out[((long long)(co0 + co) * TAPS + t) * p.Cin + ci0 + ci] = red[e];
+    }
+}
+
+struct WHaloPlan { int BN, BC, gx; size_t lds; };
+static bool wgrad_halo_plan(const hv_wgrad_desc* d, WHaloPlan* pl) {
+    if (d->precision != HV_F16 || d->stride != 1 || d->dil != 1 || d->KH != d->KW || (d->KH != 3 && d->KH != 5)) return false;
+    if (d->Wo != d->W + 2 * d->pad - d->KW + 1 || d->Ho != d->H + 2 * d->pad - d->KH + 1) return false;
+    if (d->KH == 5 && (d->Cout > 16 || d->Cin > 16)) return false;      // 25 taps: 16x16 tiles only (register budget)
+    if (d->Cout > 16) return false;   // measured: with more than one 16-wide co tile the gather kernel's larger MFMA tiles win
+    pl->BN = (d->KH == 5 || d->Cout <= 16) ? 16 : 32;
+    pl->BC = (d->KH == 5 || d->Cin <= 16) ? 16 : 32;
+    const int PH = 8 + d->KH - 1;
+    size_t stage = (size_t)(pl->BN * 8 * 40 + pl->BC * PH * 40) * 2, red = (size_t)d->KH * d->KW * pl->BN * pl->BC * 4;
+    pl->lds = stage > red ? stage : red;
+    const long long ntiles = (long long)d->B * hv_cdiv(d->Ho, 8) * hv_cdiv(d->Wo, 32);
+    const long long pairs = (long long)hv_cdiv(d->Cout, pl->BN) * hv_cdiv(d->Cin, pl->BC);
+    long long gx = 1024 / pairs;
+    if (gx < 32) gx = 32;
+    if (gx > ntiles) gx = ntiles;
+    pl->gx = (int)gx;
+    return true;
+}
+
+size_t hv_wgrad_halo_workspace_bytes(const hv_wgrad_desc* d) {
+    WHaloPlan pl;
+    if (!wgrad_halo_plan(d, &pl)) return 0;
+    return (size_t)pl.gx * d->Cout * d->KH * d->KW * d->Cin * sizeof(float);
+}
+
+template <int KS, int BN, int BC>
+static int launch_wh(const WHaloK& k, const WHaloPlan& pl, const hv_wgrad_desc* d, hipStream_t s) {
+    auto kern = wgrad_halo_kernel<KS, BN, BC>;
+    static int lds_limit = 48 * 1024;
+    if ((int)pl.lds > lds_limit) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e != hipSuccess) return -1000 - (int)e;
+        lds_limit = 150 * 1024;
+    }
+    dim3 grid(pl.gx, hv_cdiv(d->Cout, BN), hv_cdiv(d->Cin, BC));
+    hipLaunchKernelGGL(kern, grid, dim3(256), pl.lds, s, k);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+
+// returns HV_ERR_UNSUPPORTED when the shape does not qualify (caller falls back to the gather kernel);
+// on success the slabs (pl.gx of them) are in d->workspace and *nslabs is set.
+int hv_wgrad_halo(const hv_wgrad_desc* d, int* nslabs, hipStream_t s) {
+    WHaloPlan pl;
+    if (!wgrad_halo_plan(d, &pl)) return HV_ERR_UNSUPPORTED;
+    const size_t need = hv_wgrad_halo_workspace_bytes(d);
+    if (!d->workspace || d->workspace_bytes < need) return HV_ERR_WORKSPACE;
+    WHaloK k;
+    k.x = d->x; k.g = d->g; k.slabs = d->workspace;
+    k.B = d->B; k.Hl = d->H; k.Wl = d->W; k.in_shift = d->in_shift; k.Wp = d->W >> d->in_shift;
+    k.img_stride = (d->H >> d->in_shift) * k.Wp * d->x_ld; k.x_ld = d->x_ld; k.x_coff = d->x_coff; k.Cin = d->Cin;
+    k.Ho = d->Ho; k.Wo = d->Wo; k.g_ld = d->g_ld; k.g_coff = d->g_coff; k.Cout = d->Cout; k.pad = d->pad;
+    k.tiles_x = hv_cdiv(d->Wo, 32); k.tiles_per_img = k.tiles_x * hv_cdiv(d->Ho, 8); k.ntiles = k.tiles_per_img * d->B;
+    k.slab = (long long)d->Cout * d->KH * d->KW * d->Cin;
+    *nslabs = pl.gx;
+    if (d->KH == 5) return launch_wh<5, 16, 16>(k, pl, d, s);
+    if (pl.BN == 16 && pl.BC == 16) return launch_wh<3, 16, 16>(k, pl, d, s);
+    if (pl.BN == 16) return launch_wh<3, 16, 32>(k, pl, d, s);
+    if (pl.BC == 16) return launch_wh<3, 32, 16>(k, pl, d, s);
+    return launch_wh<3, 32, 32>(k, pl, d, s);
+}
