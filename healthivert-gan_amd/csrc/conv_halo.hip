@@ -12,6 +12,7 @@
 // the gather form of conv_transpose / data gradient (per output-parity class).  Everything else stays on
 // conv_igemm_kernel.
 #include "hv_common.h"
+#include <stdlib.h>
 
 typedef _Float16 f16x4v __attribute__((ext_vector_type(4)));
 
@@ -41,7 +42,7 @@ template <> struct HFrag<16> {
     static __device__ __forceinline__ f32x4 mma(V a, V b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0); }
 };
 
-template <int TH, int TW, int BN, int WM, int WN, int TG, int CK>
+template <int TH, int TW, int BN, int WM, int WN, int TG, int CK, int PMAX>
 __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloK p) {
     constexpr int BM = TH * TW;
     constexpr int LDP = CK + 8;                  // halfs per patch pixel / weight row (16 B pad: conflict-light b128 reads)
@@ -119,7 +120,6 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloK p) {
     };
     // input patch: small patches are prefetched into registers one chunk ahead, large ones staged synchronously
     constexpr int PV = CK / 4;
-    constexpr int PMAX = 8;
     const bool patch_pf = npatch * PV <= PMAX * 256;
     float4 preg[PMAX];
     auto pload1 = [&](int e, int c0) -> float4 {
@@ -229,12 +229,12 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloK p) {
     }
 }
 
-template <int TH, int TW, int BN, int WM, int WN, int TG, int CK>
+template <int TH, int TW, int BN, int WM, int WN, int TG, int CK, int PMAX>
 static int launch_halo(const HaloK& k, int tiles, int maxpatch, hipStream_t s) {
     constexpr int LDP = CK + 8;
     const size_t lds = (size_t)(2 * TG * BN * LDP + maxpatch * LDP) * sizeof(_Float16);
     if (lds > 150 * 1024) return HV_ERR_UNSUPPORTED;
-    auto kern = conv_halo_kernel<TH, TW, BN, WM, WN, TG, CK>;
+    auto kern = conv_halo_kernel<TH, TW, BN, WM, WN, TG, CK, PMAX>;
     static int lds_limit = 48 * 1024;   // per instantiation: raise the dynamic-LDS cap once (not a stream operation)
     if ((int)lds > lds_limit) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
@@ -247,7 +247,7 @@ static int launch_halo(const HaloK& k, int tiles, int maxpatch, hipStream_t s) {
     return HV_OK;
 }
 
-template <int TH, int TW, int CK>
+template <int TH, int TW, int CK, bool S2>
 static int dispatch_halo_bn(HaloK& k, int maxpatch, hipStream_t s) {
     int tiles = 0;
     for (int c = 0; c < k.ncls; ++c) {
@@ -257,10 +257,18 @@ static int dispatch_halo_bn(HaloK& k, int maxpatch, hipStream_t s) {
         C.t0 = tiles;
         tiles += C.tiles * k.B;
     }
-    if (k.Cout <= 16) return launch_halo<TH, TW, 16, 4, 1, 16, CK>(k, tiles, maxpatch, s);
-    if (k.Cout <= 32) return launch_halo<TH, TW, 32, 4, 1, 8, CK>(k, tiles, maxpatch, s);
-    if (k.Cout <= 64) return launch_halo<TH, TW, 64, 2, 2, 4, CK>(k, tiles, maxpatch, s);
-    return launch_halo<TH, TW, 128, 2, 2, 2, CK>(k, tiles, maxpatch, s);
+    int bn = k.Cout <= 16 ? 16 : k.Cout <= 32 ? 32 : k.Cout <= 64 ? 64 : 128;
+    // one wave per SIMD cannot hide the staging latency: prefer >= 2 workgroups per CU over the widest tile
+    if (bn == 128 && (long long)tiles * hv_cdiv(k.Cout, 128) < 512) bn = 64;
+    static const char* force = getenv("HV_HALO_BN");   // tuning knob (tools/bench_conv.py)
+    if (force && k.Cout > 64) bn = atoi(force) == 64 ? 64 : 128;
+    // stride-2 patches are 4x larger: prefetch them with more registers and halve the weight tile so that two
+    // workgroups still fit in a CU's LDS
+    constexpr int PM = S2 ? 20 : 11, TD = S2 ? 2 : 1;
+    if (bn == 16) return launch_halo<TH, TW, 16, 4, 1, 16 / TD, CK, PM>(k, tiles, maxpatch, s);
+    if (bn == 32) return launch_halo<TH, TW, 32, 4, 1, 8 / TD, CK, PM>(k, tiles, maxpatch, s);
+    if (bn == 64) return launch_halo<TH, TW, 64, 2, 2, 4 / TD, CK, PM>(k, tiles, maxpatch, s);
+    return launch_halo<TH, TW, 128, 2, 2, 2 / TD, CK, PM>(k, tiles, maxpatch, s);
 }
 
 // Called by hv_conv2d when the fp16 weight copy is present and the shape qualifies; returns HV_ERR_UNSUPPORTED to
@@ -333,6 +341,7 @@ int hv_conv2d_halo(const hv_conv_desc* d, const void* w_f16, hipStream_t s) {
         if (C.PH * C.PW > maxpatch) maxpatch = C.PH * C.PW;
     }
     const bool ck32 = (d->Cin & 31) == 0;
-    if (small_tile) return ck32 ? dispatch_halo_bn<8, 16, 32>(k, maxpatch, s) : dispatch_halo_bn<8, 16, 16>(k, maxpatch, s);
-    return ck32 ? dispatch_halo_bn<8, 32, 32>(k, maxpatch, s) : dispatch_halo_bn<8, 32, 16>(k, maxpatch, s);
+    if (k.bstep == 2) return ck32 ? dispatch_halo_bn<8, 16, 32, true>(k, maxpatch, s) : dispatch_halo_bn<8, 16, 16, true>(k, maxpatch, s);
+    if (small_tile) return ck32 ? dispatch_halo_bn<8, 16, 32, false>(k, maxpatch, s) : dispatch_halo_bn<8, 16, 16, false>(k, maxpatch, s);
+    return ck32 ? dispatch_halo_bn<8, 32, 32, false>(k, maxpatch, s) : dispatch_halo_bn<8, 32, 16, false>(k, maxpatch, s);
 }

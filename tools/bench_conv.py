@@ -1,0 +1,49 @@
+"""Micro-benchmark of one convolution shape through the C ABI (for rocprofv3 --pmc runs and tile tuning).
+
+    python tools/bench_conv.py B H W Cin Cout k stride pad [transposed=0] [iters=20] [precision=fp16]
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import hvgan
+from hvgan import ops
+
+
+def main():
+    a = sys.argv[1:]
+    B, H, W, Cin, Cout, k, s, p = (int(v) for v in a[:8])
+    tr = int(a[8]) if len(a) > 8 else 0
+    iters = int(a[9]) if len(a) > 9 else 20
+    prec = a[10] if len(a) > 10 else 'fp16'
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device='cpu').manual_seed(0)
+    if tr:
+        Ho, Wo = (H - 1) * s - 2 * p + k, (W - 1) * s - 2 * p + k
+        if s == 2 and k == 4:
+            Ho, Wo = H * 2, W * 2
+    else:
+        Ho, Wo = ops.conv_out_size(H, k, s, p, 1), ops.conv_out_size(W, k, s, p, 1)
+    x = ops.Act(torch.randn(B, H, W, Cin, generator=g).to(dev))
+    w = (torch.randn(Cout, k * k, Cin, generator=g) / (Cin * k * k) ** 0.5).to(dev)
+    wh = w.half()
+    y = ops.Act.empty(B, Ho, Wo, Cout, dev)
+    for _ in range(3):
+        ops.conv2d(x, w, y, k, s, p, 1, transposed=bool(tr), precision=prec, w_h=wh)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        ops.conv2d(x, w, y, k, s, p, 1, transposed=bool(tr), precision=prec, w_h=wh)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / iters * 1e3
+    taps = k * k if not tr else max(1, k * k // (s * s))
+    fl = 2.0 * B * Ho * Wo * Cout * taps * Cin
+    print('%s B%d %dx%d Cin%d->Cout%d k%d s%d %s: %.1f us  %.1f TF' % ('T' if tr else 'F', B, H, W, Cin, Cout, k, s, prec, us, fl / us / 1e6))
+
+
+if __name__ == '__main__':
+    main()

@@ -30,3 +30,7 @@ print('--- all wgrad')
 for key, (ms, n, fl) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
     if key[0] == 'wgrad':
         print('%7.3f ms  n=%2d  avg %7.1f us  %6.1f TF  %s' % (ms, n, ms / n * 1e3, fl / (ms / n * 1e-3) / 1e12, profiler.describe(key)))
+print('--- all conv')
+for key, (ms, n, fl) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+    if key[0] == 'conv':
+        print('%7.3f ms  n=%2d  avg %7.1f us  %6.1f TF  %s' % (ms, n, ms / n * 1e3, fl / (ms / n * 1e-3) / 1e12, profiler.describe(key)))
