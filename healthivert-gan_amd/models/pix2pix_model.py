@@ -76,6 +76,8 @@ class Pix2PixModel(BaseModel):
         self._loss_buf = torch.zeros(32, dtype=torch.float32, device=self.device)
         self._bufs = {}
         self.grad_sync = ddp.GradSync() if self.isTrain else None
+        import os as _os
+        self.concurrent_d = _os.environ.get('HV_CONCURRENT_D', '1') != '0'
 
     # ---------------------------------------------------------------- inputs
     def set_input(self, input):
@@ -143,7 +145,7 @@ class Pix2PixModel(BaseModel):
         mode = self.opt.gan_mode
         lf, lr = self._loss_slot(2 * k), self._loss_slot(2 * k + 1)
         P = net.run_forward(fake, training=True, prep=True)
-        dz = self._buf('dz', P.logits)
+        dz = self._buf('dz%d' % k, P.logits)
         ops.gan_loss(P.logits, False, mode, loss=lf, dz=dz, grad_weight=0.5)
         net.run_backward(P, dz, need_dx=False, param_grads=True, accumulate=False)
         P = net.run_forward(real, training=True, prep=False)
@@ -164,20 +166,28 @@ class Pix2PixModel(BaseModel):
         self._backward_D(3, self.fake_B_local, self.real_B_local)
 
     # ---------------------------------------------------------------- generator update
-    def backward_G(self):
+    def _g_step_D(self, k):
+        """D_k(fake_k) with the freshly updated D_k, its share of loss_G_GAN and (k != 2) the gradient wrt fake_k."""
+        net = getattr(self, 'netD_%d' % k)
+        fake = {1: self.fake_B, 2: self.fake_B_mask_raw, 3: self.fake_B_local}[k]
+        P = net.run_forward(fake, training=True, prep=True)
+        dz = self._buf('dz%d' % k, P.logits)
+        ops.gan_loss(P.logits, True, self.opt.gan_mode, loss=self._loss_slot(15 + k), loss_weight=1.0 / 6.0, dz=dz, grad_weight=1.0 / 6.0)
+        if k != 2:   # D_2 sees a thresholded mask: no gradient path to G (reference :201,:324)
+            self._dxs[k] = net.run_backward(P, dz, need_dx=True, param_grads=False)
+
+    def backward_G(self, d_done=False):
         L = _lib.get()
-        mode = self.opt.gan_mode
         B, _, H, W = self.real_B.shape
         lg = self._loss_slot(0)
-        dxs = {}
-        fakes = {1: self.fake_B, 2: self.fake_B_mask_raw, 3: self.fake_B_local}
-        for k in (1, 2, 3):
-            net = getattr(self, 'netD_%d' % k)
-            P = net.run_forward(fakes[k], training=True, prep=True)
-            dz = self._buf('dz', P.logits)
-            ops.gan_loss(P.logits, True, mode, loss=lg, loss_weight=1.0 / 6.0, loss_accumulate=(k != 1), dz=dz, grad_weight=1.0 / 6.0)
-            if k != 2:   # D_2 sees a thresholded mask: no gradient path to G (reference :201,:324)
-                dxs[k] = net.run_backward(P, dz, need_dx=True, param_grads=False)
+        if not d_done:
+            self._dxs = {}
+            for k in (1, 2, 3):
+                self._g_step_D(k)
+        dxs = self._dxs
+        L.call('hv_affine', ptr(lg), ptr(self._loss_slot(16)), ctypes.c_longlong(1), ctypes.c_float(1.0), ctypes.c_float(0.0), stream())
+        ops.axpy(lg, self._loss_slot(17), 1.0)
+        ops.axpy(lg, self._loss_slot(18), 1.0)
         g = L.hv_gloss_desc()
         seeds = {n: self._buf(n, self.real_B) for n in ('d_fake_B', 'd_fake_B_coarse', 'd_fine_seg', 'd_coarse_seg')}
         dp1, dp2 = self._buf('d_pred1', shape=(B, 1)), self._buf('d_pred2', shape=(B, 1))
@@ -211,16 +221,33 @@ class Pix2PixModel(BaseModel):
         self.grad_sync.reduce(self.netG.paramset().flat_grad)
 
     def optimize_parameters(self):
+        """forward; D_1, D_2, D_3 updates; G update (reference :356-382).  The three discriminator updates are independent
+        of each other, so each runs on its own HIP stream (kernels of different discriminators overlap on the 256 CUs);
+        D_k's forward on the fakes for the generator loss follows its own update on the same stream."""
         self.forward()
+        main = torch.cuda.current_stream(self.device)
+        if getattr(self, '_d_streams', None) is None:
+            self._d_streams = [torch.cuda.Stream(device=self.device) for _ in range(3)]
+            self._fork = torch.cuda.Event()
+        self._fork.record(main)
+        self._dxs = {}
         for k, bw in ((1, self.backward_D_1), (2, self.backward_D_2), (3, self.backward_D_3)):
-            self.set_requires_grad(getattr(self, 'netD_%d' % k), True)
-            opt = getattr(self, 'optimizer_D_%d' % k)
-            opt.zero_grad()
-            bw()
-            self.grad_sync.wait()
-            opt.step()
+            side = self._d_streams[k - 1] if self.concurrent_d else main
+            if side is not main:
+                side.wait_event(self._fork)
+            with torch.cuda.stream(side):
+                self.set_requires_grad(getattr(self, 'netD_%d' % k), True)
+                opt = getattr(self, 'optimizer_D_%d' % k)
+                opt.zero_grad()
+                bw()
+                self.grad_sync.wait()
+                opt.step()
+                self._g_step_D(k)
+        for side in self._d_streams:
+            if self.concurrent_d:
+                main.wait_stream(side)
         self.set_requires_grad([self.netD_1, self.netD_2, self.netD_3], False)
         self.optimizer_G.zero_grad()
-        self.backward_G()
+        self.backward_G(d_done=True)
         self.grad_sync.wait()
         self.optimizer_G.step()

@@ -112,7 +112,8 @@ WS = _Workspace()
 
 
 def _ws(nbytes, device, slot=0):
-    b = WS.get(nbytes + 64, device, slot)
+    # one scratch buffer per (device, slot, stream): kernels on different streams may run concurrently
+    b = WS.get(nbytes + 64, device, (slot, torch.cuda.current_stream(device).cuda_stream))
     return b, ctypes.c_size_t(b.numel())
 
 
