@@ -21,6 +21,7 @@
 int hv_conv2d_halo(const hv_conv_desc* d, const void* w_f16, hipStream_t s);   // conv_halo.hip
 size_t hv_wgrad_halo_workspace_bytes(const hv_wgrad_desc* d);                  // wgrad_halo.hip
 int hv_wgrad_halo(const hv_wgrad_desc* d, int* nslabs, hipStream_t s);
+int hv_conv2d_narrow(const hv_conv_desc* d, hipStream_t s);                     // conv_narrow.hip
 
 struct ConvCls {
     int ph, pw, Hc, Wc, ntaps, Ktot, m0, mcount;
@@ -352,6 +353,10 @@ extern "C" int hv_conv2d(const hv_conv_desc* d, void* stream) {
         return HV_ERR_UNSUPPORTED;
     if (d->H > 16000 || d->W > 16000 || (d->KH - 1) * d->dil > 120 || (d->KW - 1) * d->dil > 120) return HV_ERR_UNSUPPORTED;
 
+    if (d->Cout == 1 && !d->transposed) {   // single-channel heads / logits: VALU kernels (conv_narrow.hip)
+        const int rc = hv_conv2d_narrow(d, (hipStream_t)stream);
+        if (rc != HV_ERR_UNSUPPORTED) return rc;
+    }
     if (d->precision == HV_F16 && d->w_f16) {   // halo-tiled fast path (conv_halo.hip) when the shape qualifies
         const int rc = hv_conv2d_halo(d, d->w_f16, (hipStream_t)stream);
         if (rc != HV_ERR_UNSUPPORTED) return rc;
@@ -673,9 +678,9 @@ extern "C" int hv_conv2d_wgrad(const hv_wgrad_desc* d, void* stream) {
     int rc = wgrad_validate(d);
     if (rc != HV_OK) return rc;
     const long long nW = (long long)d->Cout * d->KH * d->KW * d->Cin;
-    {   // halo-tiled fast path (wgrad_halo.hip): 3x3 / 5x5, stride 1, fp16
+    {   // single-output-channel VALU path (conv_narrow.hip), then the halo-tiled fast path (wgrad_halo.hip: 3x3 / 5x5, stride 1, fp16)
         int nslabs = 0;
-        rc = hv_wgrad_halo(d, &nslabs, (hipStream_t)stream);
+        rc = hv_wgrad_halo(d, &nslabs, (hipStream_t)stream);   // (measured: the VALU hv_wgrad_narrow is slower than the padded MFMA tiles)
         if (rc == HV_OK) {
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(hv_cdiv(nW, 64)), dim3(256), 0, (hipStream_t)stream, d->workspace, d->dw, nW, nslabs, d->accumulate);
             HV_LAUNCH_CHECK();
