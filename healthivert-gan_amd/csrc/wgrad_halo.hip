@@ -1,4 +1,5 @@
-// Halo-tiled weight gradient (fp16 MFMA operands, fp32 accumulate) for stride-1, dilation-1, 3x3 / 5x5 convolutions.
+// Halo-tiled weight gradient (fp16 MFMA operands, fp32 accumulate) for stride-1, dilation-1, 3x3 / 4x4 / 5x5 convolutions
+// with at most 16 output channels.
 //
 //   dW[co][(r,q)][ci] = sum_{n,oy,ox} g[n,oy,ox,co] * x[n, oy-pad+r, ox-pad+q, ci]
 //
@@ -160,12 +161,12 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const WHaloK p) {
 
 struct WHaloPlan { int BN, BC, gx; size_t lds; };
 static bool wgrad_halo_plan(const hv_wgrad_desc* d, WHaloPlan* pl) {
-    if (d->precision != HV_F16 || d->stride != 1 || d->dil != 1 || d->KH != d->KW || (d->KH != 3 && d->KH != 5)) return false;
+    if (d->precision != HV_F16 || d->stride != 1 || d->dil != 1 || d->KH != d->KW || d->KH < 3 || d->KH > 5) return false;
     if (d->Wo != d->W + 2 * d->pad - d->KW + 1 || d->Ho != d->H + 2 * d->pad - d->KH + 1) return false;
     if (d->KH == 5 && (d->Cout > 16 || d->Cin > 16)) return false;      // 25 taps: 16x16 tiles only (register budget)
     if (d->Cout > 16) return false;   // measured: with more than one 16-wide co tile the gather kernel's larger MFMA tiles win
     pl->BN = (d->KH == 5 || d->Cout <= 16) ? 16 : 32;
-    pl->BC = (d->KH == 5 || d->Cin <= 16) ? 16 : 32;
+    pl->BC = (d->KH == 5 || d->Cin <= 16) ? 16 : 32;   // k4: 16 taps x (16 x 32) = 128 accumulator registers
     const int PH = 8 + d->KH - 1;
     size_t stage = (size_t)(pl->BN * 8 * 40 + pl->BC * PH * 40) * 2, red = (size_t)d->KH * d->KW * pl->BN * pl->BC * 4;
     pl->lds = stage > red ? stage : red;
@@ -215,6 +216,7 @@ int hv_wgrad_halo(const hv_wgrad_desc* d, int* nslabs, hipStream_t s) {
     k.slab = (long long)d->Cout * d->KH * d->KW * d->Cin;
     *nslabs = pl.gx;
     if (d->KH == 5) return launch_wh<5, 16, 16>(k, pl, d, s);
+    if (d->KH == 4) return pl.BC == 16 ? launch_wh<4, 16, 16>(k, pl, d, s) : launch_wh<4, 16, 32>(k, pl, d, s);
     if (pl.BN == 16 && pl.BC == 16) return launch_wh<3, 16, 16>(k, pl, d, s);
     if (pl.BN == 16) return launch_wh<3, 16, 32>(k, pl, d, s);
     if (pl.BC == 16) return launch_wh<3, 32, 16>(k, pl, d, s);
