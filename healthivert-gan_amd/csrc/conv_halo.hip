@@ -45,7 +45,9 @@ template <> struct HFrag<16> {
 template <int TH, int TW, int BN, int WM, int WN, int TG, int CK, int PMAX>
 __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloK p) {
     constexpr int BM = TH * TW;
-    constexpr int LDP = CK + 8;                  // halfs per patch pixel / weight row (16 B pad: conflict-light b128 reads)
+    // halfs per patch pixel / weight row.  With 16-B fragments, a 96-B row stride (CK 32 + 16 pad) maps the 16 lanes of every
+    // ds_read_b128 lane group onto all 64 banks exactly once for unit-step pixel reads; stride-2 reads prefer 80 B.
+    constexpr int LDP = CK + ((CK == 32 && PMAX < 16) ? 16 : 8);
     constexpr int MT = BM / WM / 16, NT = BN / WN / 16;
     constexpr int GX = TW / 16;                  // 16-pixel groups per tile row
     static_assert(WM * WN == 4 && MT >= 1 && NT >= 1 && TW % 16 == 0, "bad tile");
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloK p) {
 
 template <int TH, int TW, int BN, int WM, int WN, int TG, int CK, int PMAX>
 static int launch_halo(const HaloK& k, int tiles, int maxpatch, hipStream_t s) {
-    constexpr int LDP = CK + 8;
+    constexpr int LDP = CK + ((CK == 32 && PMAX < 16) ? 16 : 8);
     const size_t lds = (size_t)(2 * TG * BN * LDP + maxpatch * LDP) * sizeof(_Float16);
     if (lds > 150 * 1024) return HV_ERR_UNSUPPORTED;
     auto kern = conv_halo_kernel<TH, TW, BN, WM, WN, TG, CK, PMAX>;

@@ -8,10 +8,10 @@ static bool n_vec_ok(int C) { return (C % 4 == 0) && n_pow2(C / 4) && C / 4 <= 2
 static bool n_shape_ok(int C) { return n_vec_ok(C) || (n_pow2(C) && C <= 256); }
 
 struct NormPlan { int G, R, nchunk, rpb, rstep; };
-static NormPlan norm_plan(int B, int HW, int C, int norm) {
+static NormPlan norm_plan(int B, int HW, int C, int norm, int groups = 1) {
     NormPlan p;
-    p.G = norm == HV_NORM_INSTANCE ? B : 1;
-    p.R = norm == HV_NORM_INSTANCE ? HW : B * HW;
+    p.G = norm == HV_NORM_INSTANCE ? B : (groups > 0 ? groups : 1);
+    p.R = norm == HV_NORM_INSTANCE ? HW : (B / p.G) * HW;
     p.rstep = n_vec_ok(C) ? 256 / (C / 4) : 256 / C;
     long long rpb = (long long)p.rstep * 32;
     long long nch = (p.R + rpb - 1) / rpb;
@@ -130,38 +130,41 @@ __global__ __launch_bounds__(256) void norm_reduce_kernel(const NormK k, double*
     }
 }
 
+// one wave per channel; groups are visited in order so that several batch-norm groups in one launch (fake | real halves of a
+// discriminator batch) update the running statistics exactly like consecutive forward calls
 __global__ void norm_fwd_finalize_kernel(const double* __restrict__ part, int G, int nchunk, int C, int R, float eps, float momentum,
                                          float* __restrict__ stats, float* running_mean, float* running_var, long long* nbt,
                                          int use_running, int update_running) {
-    // one wave per (group, channel)
-    const int i = blockIdx.x;
-    if (i >= G * C) return;
-    const int g = i / C, c = i - g * C;
-    if (use_running) {
-        if (threadIdx.x == 0) {
-            stats[(long long)g * 2 * C + c] = running_mean[c];
-            stats[(long long)g * 2 * C + C + c] = 1.f / sqrtf(running_var[c] + eps);
+    const int c = blockIdx.x;
+    if (c >= C) return;
+    for (int g = 0; g < G; ++g) {
+        if (use_running) {
+            if (threadIdx.x == 0) {
+                stats[(long long)g * 2 * C + c] = running_mean[c];
+                stats[(long long)g * 2 * C + C + c] = 1.f / sqrtf(running_var[c] + eps);
+            }
+            continue;
         }
-        return;
-    }
-    double s = 0, q = 0;
-    for (int k = threadIdx.x; k < nchunk; k += 64) {
-        s += part[((long long)g * nchunk + k) * 2 * C + c];
-        q += part[((long long)g * nchunk + k) * 2 * C + C + c];
-    }
+        double s = 0, q = 0;
+        for (int k = threadIdx.x; k < nchunk; k += 64) {
+            s += part[((long long)g * nchunk + k) * 2 * C + c];
+            q += part[((long long)g * nchunk + k) * 2 * C + C + c];
+        }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
-    if (threadIdx.x != 0) return;
-    const double mean = s / R;
-    double var = q / R - mean * mean;
-    if (var < 0) var = 0;
-    stats[(long long)g * 2 * C + c] = (float)mean;
-    stats[(long long)g * 2 * C + C + c] = 1.f / sqrtf((float)var + eps);
-    if (update_running) {
-        const double unb = R > 1 ? var * R / (R - 1) : var;
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
-        if (i == 0 && nbt) nbt[0] += 1;
+        for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+        if (threadIdx.x == 0) {
+            const double mean = s / R;
+            double var = q / R - mean * mean;
+            if (var < 0) var = 0;
+            stats[(long long)g * 2 * C + c] = (float)mean;
+            stats[(long long)g * 2 * C + C + c] = 1.f / sqrtf((float)var + eps);
+            if (update_running) {
+                const double unb = R > 1 ? var * R / (R - 1) : var;
+                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+                if (c == 0 && nbt) nbt[0] += 1;
+            }
+        }
     }
 }
 
@@ -211,7 +214,8 @@ extern "C" int hv_norm_act_forward(const hv_norm_desc* d, void* stream) {
     const bool vec = n_vec_ok(d->C) && aligned;
     if (!vec && !(n_pow2(d->C) && d->C <= 256)) return HV_ERR_UNSUPPORTED;
     if (d->norm == HV_NORM_BATCH && (!d->gamma || !d->beta)) return HV_ERR_ARG;
-    NormPlan pl = norm_plan(d->B, d->HW, d->C, d->norm);
+    if (d->norm == HV_NORM_BATCH && d->groups > 1 && d->B % d->groups) return HV_ERR_ARG;
+    NormPlan pl = norm_plan(d->B, d->HW, d->C, d->norm, d->groups);
     if (!vec) { pl.rstep = 256 / d->C; pl.rpb = (pl.rpb + pl.rstep - 1) / pl.rstep * pl.rstep; pl.nchunk = hv_cdiv(pl.R, pl.rpb); }
     const bool use_running = d->norm == HV_NORM_BATCH && !d->training;
     if (use_running && (!d->running_mean || !d->running_var)) return HV_ERR_ARG;
@@ -230,7 +234,7 @@ extern "C" int hv_norm_act_forward(const hv_norm_desc* d, void* stream) {
         HV_LAUNCH_CHECK();
     }
     const int update = d->norm == HV_NORM_BATCH && d->training && d->running_mean && d->running_var;
-    hipLaunchKernelGGL(norm_fwd_finalize_kernel, dim3(pl.G * d->C), dim3(64), 0, s, part, pl.G, pl.nchunk, d->C, pl.R,
+    hipLaunchKernelGGL(norm_fwd_finalize_kernel, dim3(d->C), dim3(64), 0, s, part, pl.G, pl.nchunk, d->C, pl.R,
                        d->eps, d->momentum, d->stats, d->running_mean, d->running_var, d->num_batches_tracked, use_running ? 1 : 0, update);
     HV_LAUNCH_CHECK();
     const long long n = (long long)pl.G * pl.R * (vec ? d->C / 4 : d->C);
@@ -317,7 +321,7 @@ extern "C" int hv_norm_act_backward(const hv_norm_bwd_desc* d, void* stream) {
                          !(((uintptr_t)d->x | (uintptr_t)d->y | (uintptr_t)d->dy | (uintptr_t)d->dx) & 15);
     const bool vec = n_vec_ok(d->C) && aligned;
     if (!vec && !(n_pow2(d->C) && d->C <= 256)) return HV_ERR_UNSUPPORTED;
-    NormPlan pl = norm_plan(d->B, d->HW, d->C, d->norm);
+    NormPlan pl = norm_plan(d->B, d->HW, d->C, d->norm, d->groups);
     if (!vec) { pl.rstep = 256 / d->C; pl.rpb = (pl.rpb + pl.rstep - 1) / pl.rstep * pl.rstep; pl.nchunk = hv_cdiv(pl.R, pl.rpb); }
     const size_t need_part = (size_t)pl.G * pl.nchunk * 2 * d->C * sizeof(double);
     const size_t need = need_part + (size_t)pl.G * 2 * d->C * sizeof(float);

@@ -238,9 +238,11 @@ class NLayerDiscriminator(nn.Module):
         return self._plans[key]
 
     # ---------------------------------------------------------------- explicit forward / backward
-    def run_forward(self, x, training=None, prep=True):
+    def run_forward(self, x, training=None, prep=True, groups=1):
         """x: (B,1,H,W) device tensor -> plan; logits in plan.logits (B,1,Ho,Wo).  BatchNorm running statistics are
-        updated when training (every call, like the reference's three calls per step)."""
+        updated when training (every call, like the reference's three calls per step).  groups=2 treats the two halves of
+        the batch as two consecutive calls (separate batch statistics, running stats updated half by half): the fake and
+        the real pass of one discriminator update in a single launch sequence."""
         _lib.require_gpu(x)
         training = self.training if training is None else training
         prec = ops.precision_id(self.precision)
@@ -263,10 +265,10 @@ class NLayerDiscriminator(nn.Module):
             nm = self.model[L['norm']]
             if self.norm_kind == 'batch':
                 ops.norm_act_forward(ent['z'], ent['y'], 'batch', training, ent['stats'], nm.weight, nm.bias, nm.running_mean,
-                                     nm.running_var, nm.num_batches_tracked, act='lrelu', eps=nm.eps, momentum=nm.momentum)
+                                     nm.running_var, nm.num_batches_tracked, act='lrelu', eps=nm.eps, momentum=nm.momentum, groups=groups)
             else:
                 ops.norm_act_forward(ent['z'], ent['y'], 'instance', training, ent['stats'], act='lrelu', eps=nm.eps)
-        P.training = training
+        P.training, P.groups = training, groups
         return P
 
     def run_backward(self, P, dlogits, need_dx=False, param_grads=True, accumulate=False):
@@ -301,7 +303,8 @@ class NLayerDiscriminator(nn.Module):
                 ops.norm_act_backward(gy, ent['y'], ent['z'], gz, self.norm_kind, P.training, ent['stats'],
                                       gamma=nm.weight if bn else None, act='lrelu',
                                       dgamma=nm.weight.grad if (bn and param_grads) else None,
-                                      dbeta=nm.bias.grad if (bn and param_grads) else None, param_accumulate=accumulate)
+                                      dbeta=nm.bias.grad if (bn and param_grads) else None, param_accumulate=accumulate,
+                                      groups=P.groups)
             E.conv_backward(node, book, prec, dbias_accumulate=accumulate, wgrad_accumulate=accumulate, wgrad=param_grads)
         if need_dx:
             g = book.twin(P.x_in)

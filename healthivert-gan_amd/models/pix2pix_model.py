@@ -78,6 +78,7 @@ class Pix2PixModel(BaseModel):
         self.grad_sync = ddp.GradSync() if self.isTrain else None
         import os as _os
         self.concurrent_d = _os.environ.get('HV_CONCURRENT_D', '1') != '0'
+        self.batch_d = _os.environ.get('HV_BATCH_D', '0') != '0'   # measured: no gain once the three D streams overlap
 
     # ---------------------------------------------------------------- inputs
     def set_input(self, input):
@@ -141,16 +142,33 @@ class Pix2PixModel(BaseModel):
         return self._loss_buf[i:i + 1].view(())
 
     def _backward_D(self, k, fake, real):
+        """loss_D_k = 0.5 * (BCE(D_k(fake), 0) + BCE(D_k(real), 1)); backward (reference :267-314).  With batch_d the fake and
+        the real pass run as ONE 2B-sample launch sequence whose BatchNorm layers keep separate statistics per half and update
+        their running statistics half by half -- arithmetically the reference's two consecutive calls, with twice the work per
+        kernel launch."""
         net = getattr(self, 'netD_%d' % k)
         mode = self.opt.gan_mode
+        L = _lib.get()
         lf, lr = self._loss_slot(2 * k), self._loss_slot(2 * k + 1)
-        P = net.run_forward(fake, training=True, prep=True)
-        dz = self._buf('dz%d' % k, P.logits)
-        ops.gan_loss(P.logits, False, mode, loss=lf, dz=dz, grad_weight=0.5)
-        net.run_backward(P, dz, need_dx=False, param_grads=True, accumulate=False)
-        P = net.run_forward(real, training=True, prep=False)
-        ops.gan_loss(P.logits, True, mode, loss=lr, dz=dz, grad_weight=0.5)
-        net.run_backward(P, dz, need_dx=False, param_grads=True, accumulate=True)
+        if self.batch_d:
+            B = fake.shape[0]
+            x2 = self._buf('dcat%d' % k, shape=(2 * B,) + tuple(fake.shape[1:]))
+            n = ctypes.c_longlong(fake.numel())
+            L.call('hv_affine', ptr(x2[:B]), ptr(fake), n, ctypes.c_float(1.0), ctypes.c_float(0.0), stream())
+            L.call('hv_affine', ptr(x2[B:]), ptr(real), n, ctypes.c_float(1.0), ctypes.c_float(0.0), stream())
+            P = net.run_forward(x2, training=True, prep=True, groups=2)
+            dz = self._buf('dzz%d' % k, P.logits)
+            ops.gan_loss(P.logits[:B], False, mode, loss=lf, dz=dz[:B], grad_weight=0.5)
+            ops.gan_loss(P.logits[B:], True, mode, loss=lr, dz=dz[B:], grad_weight=0.5)
+            net.run_backward(P, dz, need_dx=False, param_grads=True, accumulate=False)
+        else:
+            P = net.run_forward(fake, training=True, prep=True)
+            dz = self._buf('dz%d' % k, P.logits)
+            ops.gan_loss(P.logits, False, mode, loss=lf, dz=dz, grad_weight=0.5)
+            net.run_backward(P, dz, need_dx=False, param_grads=True, accumulate=False)
+            P = net.run_forward(real, training=True, prep=False)
+            ops.gan_loss(P.logits, True, mode, loss=lr, dz=dz, grad_weight=0.5)
+            net.run_backward(P, dz, need_dx=False, param_grads=True, accumulate=True)
         net.finish()
         setattr(self, 'loss_D_fake_%d' % k, lf)
         setattr(self, 'loss_D_real_%d' % k, lr)

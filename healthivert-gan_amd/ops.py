@@ -287,7 +287,7 @@ def adam_step(table, max_numel, lr_dev, beta1, beta2, eps, step_dev):
 
 # ------------------------------------------------------------------------------------------------ norm + activation
 def norm_act_forward(x, y, norm, training, stats, gamma=None, beta=None, running_mean=None, running_var=None, nbt=None,
-                     act='lrelu', post_sigmoid=False, eps=1e-5, momentum=0.1):
+                     act='lrelu', post_sigmoid=False, eps=1e-5, momentum=0.1, groups=1):
     L = _lib.get()
     d = L.hv_norm_desc()
     d.x, d.y = ptr(x.t).value, ptr(y.t).value
@@ -297,7 +297,7 @@ def norm_act_forward(x, y, norm, training, stats, gamma=None, beta=None, running
     for f, v in (('gamma', gamma), ('beta', beta), ('running_mean', running_mean), ('running_var', running_var),
                  ('num_batches_tracked', nbt), ('stats', stats)):
         setattr(d, f, None if v is None else ptr(v).value)
-    d.act, d.post_sigmoid = ACT[act], int(post_sigmoid)
+    d.act, d.post_sigmoid, d.groups = ACT[act], int(post_sigmoid), int(groups)
     need = L.size('hv_norm_workspace_bytes', x.B, x.H * x.W, x.C)
     b, _ = _ws(need, x.t.device)
     d.workspace, d.workspace_bytes = ptr(b).value, b.numel()
@@ -305,7 +305,7 @@ def norm_act_forward(x, y, norm, training, stats, gamma=None, beta=None, running
 
 
 def norm_act_backward(dy, y, x, dx, norm, training, stats, gamma=None, act='lrelu', post_sigmoid=False, dgamma=None, dbeta=None,
-                      param_accumulate=False):
+                      param_accumulate=False, groups=1):
     L = _lib.get()
     d = L.hv_norm_bwd_desc()
     d.dy, d.y, d.x, d.dx = ptr(dy.t).value, ptr(y.t).value, ptr(x.t).value, ptr(dx.t).value
@@ -319,6 +319,7 @@ def norm_act_backward(dy, y, x, dx, norm, training, stats, gamma=None, act='lrel
     d.dgamma = None if dgamma is None else ptr(dgamma).value
     d.dbeta = None if dbeta is None else ptr(dbeta).value
     d.param_accumulate = int(param_accumulate)
+    d.groups = int(groups)
     need = L.size('hv_norm_workspace_bytes', x.B, x.H * x.W, x.C)
     b, _ = _ws(need, x.t.device)
     d.workspace, d.workspace_bytes = ptr(b).value, b.numel()

@@ -123,6 +123,8 @@ typedef struct {
     const float* gamma; const float* beta; float* running_mean; float* running_var; long long* num_batches_tracked;
     float* stats; int act; int post_sigmoid;
     float* workspace; size_t workspace_bytes;
+    int groups;   /* batch norm: the batch is split into `groups` equal parts with separate statistics, running stats updated
+                     part by part (fake | real halves of one discriminator launch == two consecutive calls); 0/1 = one group */
 } hv_norm_desc;
 size_t hv_norm_workspace_bytes(int B, int HW, int C);
 int hv_norm_act_forward(const hv_norm_desc* d, void* stream);
@@ -134,6 +136,7 @@ typedef struct {
     int act; int post_sigmoid;
     float* dgamma; float* dbeta; int param_accumulate;
     float* workspace; size_t workspace_bytes;
+    int groups;
 } hv_norm_bwd_desc;
 int hv_norm_act_backward(const hv_norm_bwd_desc* d, void* stream);
 
