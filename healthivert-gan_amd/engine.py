@@ -4,7 +4,9 @@ the first call for a given shape (so a whole train step can be captured in a hip
 
 The nn.Modules of `models/` hold the parameters (reference state-dict keys) and delegate here.
 """
+import contextlib
 import ctypes
+import os
 
 import torch
 
@@ -150,6 +152,21 @@ class GradBook:
     def __init__(self):
         self.twins = {}
         self.written = set()
+        self.side = None          # side HIP stream for weight gradients (they overlap the data-gradient chain)
+        self.overlap = os.environ.get('HV_OVERLAP_WGRAD', '1') != '0'
+
+    def fork(self):
+        """Side stream, ordered after everything queued so far on the current stream."""
+        cur = torch.cuda.current_stream()
+        if self.side is None:
+            self.side = torch.cuda.Stream(device=cur.device)
+        self.side.wait_stream(cur)
+        return self.side
+
+    def join(self):
+        """The current stream waits for the side stream's weight gradients."""
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
 
     def twin(self, a):
         t = self.twins.get(id(a.t))
@@ -169,6 +186,15 @@ class GradBook:
         return acc
 
 
+def _wgrad(node, p, xin, gfull, accumulate, prec):
+    if node.transposed:
+        # y = conv_transpose(x): the weight gradient is that of a strided conv with the roles of x and g swapped;
+        # the result is laid out [cin][taps][coutP] (hv_weight_prep_backward knows, transposed_src)
+        ops.conv2d_wgrad(gfull, xin, p.dw, node.k, node.s, node.pad, node.d, accumulate=accumulate, precision=prec)
+    else:
+        ops.conv2d_wgrad(xin, gfull, p.dw, node.k, node.s, node.pad, node.d, in_shift=node.shift, accumulate=accumulate, precision=prec)
+
+
 def conv_backward(node, book, prec, dbias_accumulate=False, wgrad_accumulate=False, tmp_full=None, wgrad=True, x_wg=None):
     """Backward of one ConvNode: activation gradient (+bias gradient), weight gradient, data gradient.
     x_wg: channel-padded copy of the input for the weight-gradient kernel (1-channel image inputs)."""
@@ -181,13 +207,11 @@ def conv_backward(node, book, prec, dbias_accumulate=False, wgrad_accumulate=Fal
     if wgrad:
         xs = node.x if x_wg is None else x_wg
         xin = Act(xs.t, p.cin_wg, xs.coff)
-        if node.transposed:
-            # y = conv_transpose(x): the weight gradient is that of a strided conv with the roles of x and g swapped;
-            # the result is laid out [cin][taps][coutP] (hv_weight_prep_backward knows, transposed_src)
-            ops.conv2d_wgrad(gfull, xin, p.dw, node.k, node.s, node.pad, node.d, accumulate=wgrad_accumulate, precision=prec)
-        else:
-            ops.conv2d_wgrad(xin, gfull, p.dw, node.k, node.s, node.pad, node.d, in_shift=node.shift, accumulate=wgrad_accumulate,
-                             precision=prec)
+        # the weight gradient only feeds the optimiser: queue it on the side stream so that it overlaps the data-gradient
+        # chain (joined by GradBook.join() before the gradients are finalised / the activations are overwritten)
+        ctx = torch.cuda.stream(book.fork()) if book.overlap else contextlib.nullcontext()
+        with ctx:
+            _wgrad(node, p, xin, gfull, wgrad_accumulate, prec)
     if node.need_dx and node.transposed:
         gx = book.twin(node.x)
         gx = Act(gx.t, p.cin_fwd, gx.coff)

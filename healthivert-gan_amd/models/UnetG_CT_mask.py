@@ -222,6 +222,7 @@ class UnetGenerator(nn.Module):
                 ops.norm_act_backward(book.twin(ent['y']), ent['y'], ent['zbuf'], book.twin(ent['zbuf']), 'batch', P.training, ent['stats'],
                                       gamma=bn.weight, act='lrelu', dgamma=bn.weight.grad, dbeta=bn.bias.grad)
             E.conv_backward(ent['node'], book, prec)
+        book.join()     # side-stream weight gradients
         self.paramset().finish_backward(accumulate=False)
         self.paramset().attach_grads()
 

@@ -466,6 +466,7 @@ class Generator(nn.Module):
                                     cg.fc_height.weight.grad, cg.fc_height.bias.grad)
         for n in reversed(C[:10]):
             E.conv_backward(n, book, prec)
+        book.join()     # side-stream weight gradients
         self.paramset().finish_backward(accumulate=False)
         self.paramset().attach_grads()
 

@@ -249,6 +249,7 @@ class NLayerDiscriminator(nn.Module):
         x = x.contiguous().float()
         B, _, H, W = x.shape
         P = self._plan(B, H, W, x.device)
+        P.book.join()   # weight gradients of the previous backward still read this plan's activations on the side stream
         if prep:
             self.paramset().prep(x.device, power_iter=False)
         xin = Act(x.view(B, H, W, 1))
@@ -312,6 +313,8 @@ class NLayerDiscriminator(nn.Module):
         return None
 
     def finish(self):
+        for P in self._plans.values():
+            P.book.join()
         self.paramset().finish_backward(accumulate=False)
         self.paramset().attach_grads()
 
