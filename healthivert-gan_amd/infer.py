@@ -53,3 +53,107 @@ def synthesize(model, ct_masked, mask, cam, index_ratio, ori_ct, label, x1, x2, 
     lab = torch.empty(B, H, W, device=dev)
     L.call('hv_shrm_composite', ptr(seg), ptr(label.contiguous()), ptr(pred), ptr(height), ptr(x1), ptr(x2), ptr(lab), None, B, H, W, stream())
     return lab, ct, P.pred2.view(B).clone()
+
+
+# ------------------------------------------------------------------------------------------------ stage-batched volume driver
+def _clean_components(mask, min_size):
+    """remove_small_connected_components of the reference (eval_3d_sagittal_twostage.py:15-30): 8-connectivity."""
+    import numpy as np
+    from scipy.ndimage import label as cc_label
+    lab, n = cc_label(mask, np.ones((3, 3), dtype=np.int32))
+    for i in range(1, n + 1):
+        if np.sum(lab == i) < min_size:
+            mask[lab == i] = 0
+    return mask
+
+
+def prepare_slice(cam2d, label2d, ct2d, vert_id, maxheight=40):
+    """CPU part of run_model (reference :46-98): bbox of the vertebra, 41-row mask band (note `max_x+1`, :75), masked CT and
+    CAM re-stacked around the band, uint8 quantisation, ToTensor/Normalize.  Returns None when the vertebra is absent."""
+    import numpy as np
+    vl = np.zeros_like(label2d)
+    vl[label2d == vert_id] = 1
+    vl = _clean_components(vl, 50)
+    coords = np.argwhere(vl)
+    if coords.size == 0:
+        return None
+    x1, x2 = int(coords[:, 0].min()), int(coords[:, 0].max())
+    width = vl.shape[0]
+    height = x2 - x1
+    if height > maxheight:
+        x_mean = int(np.mean(coords[:, 0]))
+        x1 = x_mean - 20
+        x2 = x1 + 40
+    mask_x, h2 = (x1 + x2) // 2, maxheight
+    if mask_x <= h2 // 2:
+        min_x = 0
+    elif width - mask_x <= h2 / 2:
+        min_x = width - h2
+    else:
+        min_x = mask_x - h2 // 2
+    max_x = min_x + h2
+    mask = np.zeros(vl.shape, np.uint8)
+    mask[min_x:max_x + 1] = 255
+    ct_u8 = ct2d.astype(np.uint8)
+    ct_masked = np.zeros_like(mask)
+    ct_masked[:min_x] = ct_u8[(x1 - min_x):x1]
+    ct_masked[max_x:] = ct_u8[x2:x2 + (width - max_x)]
+    cam = np.zeros_like(mask)
+    cam_u8 = cam2d.astype(np.uint8)
+    cam[:min_x] = cam_u8[(x1 - min_x):x1]
+    cam[max_x:] = cam_u8[x2:x2 + (width - max_x)]
+    f = lambda a, norm: ((a.astype(np.float32) / 255.0 - 0.5) / 0.5) if norm else a.astype(np.float32) / 255.0
+    return dict(ct_masked=f(ct_masked, True), ori_ct=f(ct_u8, True), mask=f(mask, False), cam=f(cam, False), x1=x1, x2=x2, height=height)
+
+
+def _stage(model, cam_vol, labels, cts, zs, ratios, vert_id, device, maxheight):
+    """One synthesis stage for all z-slices at once: labels/cts are lists of 2-D arrays (per z).  Returns new lists
+    (slices where the vertebra is absent pass through unchanged, like the reference's `output == None`)."""
+    import numpy as np
+    preps = [prepare_slice(cam_vol[:, :, z], labels[i], cts[i], vert_id, maxheight) for i, z in enumerate(zs)]
+    idx = [i for i, p in enumerate(preps) if p is not None]
+    out_l, out_c = list(labels), list(cts)
+    if not idx:
+        return out_l, out_c, idx
+    t = lambda key: torch.from_numpy(np.stack([preps[i][key] for i in idx])).unsqueeze(1).to(device)
+    iv = lambda key: torch.tensor([preps[i][key] for i in idx], dtype=torch.int64, device=device)
+    lab_t = torch.from_numpy(np.stack([labels[i] for i in idx]).astype(np.float32)).unsqueeze(1).to(device)
+    ratio = torch.tensor([ratios[i] for i in idx], dtype=torch.float64, device=device)
+    lab, ct, _ = synthesize(model, t('ct_masked'), t('mask'), t('cam'), ratio, t('ori_ct'), lab_t, iv('x1'), iv('x2'), iv('height'),
+                            vert_id, maxheight)
+    lab, ct = lab.cpu().numpy().astype(np.float64), ct.cpu().numpy().astype(np.float64)
+    for j, i in enumerate(idx):
+        out_l[i], out_c[i] = lab[j], ct[j]
+    return out_l, out_c, idx
+
+
+def process_volume(model, ct_data, label_data, cam_data, vert_id, device, maxheight=40):
+    """process_nii_files' per-volume loop (reference :186-234) with the three chained syntheses (upper neighbour, lower
+    neighbour, target) each batched over ALL z-slices: 3 generator launches per volume instead of ~130 bs=1 calls.
+    ct_data in 0..255, label_data = vertebra ids, cam_data already scaled by 255 (reference :181).  Returns
+    (output_ct [H,W,Z], output_seg [H,W,Z]) as float64 numpy arrays (zeros outside the processed z range)."""
+    import numpy as np
+    vl = label_data == vert_id
+    loc = np.where(vl)
+    z0, z1 = int(loc[2].min()), int(loc[2].max())
+    rng_len = z1 - z0 + 1
+    new_len = int(rng_len * 4 / 5)
+    nz0 = z0 + (rng_len - new_len) // 2
+    nz1 = nz0 + new_len - 1
+    centre = (nz0 + nz1) // 2
+    zs = list(range(nz0, nz1 + 1))
+    ratios = [abs(z - centre) / rng_len * 2 for z in zs]
+    labels = [label_data[:, :, z].copy() for z in zs]
+    cts = [ct_data[:, :, z].copy() for z in zs]
+    out_ct, out_seg = np.zeros_like(ct_data, dtype=np.float64), np.zeros_like(ct_data, dtype=np.float64)
+    for nb, cond in ((vert_id - 1, vert_id > 8), (vert_id + 1, vert_id < 24)):
+        sel = [i for i, z in enumerate(zs) if cond and np.sum(label_data[:, :, z] == nb) > 200]
+        if sel:
+            l2, c2, _ = _stage(model, cam_data, [labels[i] for i in sel], [cts[i] for i in sel], [zs[i] for i in sel],
+                               [ratios[i] for i in sel], nb, device, maxheight)
+            for j, i in enumerate(sel):
+                labels[i], cts[i] = l2[j], c2[j]
+    l3, c3, done = _stage(model, cam_data, labels, cts, zs, ratios, vert_id, device, maxheight)
+    for i in done:
+        out_seg[:, :, zs[i]], out_ct[:, :, zs[i]] = l3[i], c3[i]
+    return out_ct, out_seg

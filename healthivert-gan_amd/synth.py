@@ -107,3 +107,32 @@ def to_model_inputs(batch, direction='BtoA'):
                 real_B_mask=batch['A_mask'], mask=batch['mask'], CAM=batch['CAM'], normal_vert=batch['normal_vert'],
                 height=batch['height'], x1=batch['x1'], x2=batch['x2'], maxheight=batch['h2'],
                 slice_ratio=batch['slice_ratio'])
+
+
+def make_volume(nz=16, size=256, seed=7, target_id=20):
+    """Synthetic straightened volume like the reference's datasets/straightened/{CT,label} + heat-map:
+    returns (ct [size,size,nz] float in 0..255, label [size,size,nz] float vertebra ids target_id-2..target_id+2,
+    cam [size,size,nz] float in 0..1).  The target vertebra spans the central z range, neighbours are present."""
+    rng = np.random.default_rng(seed)
+    base = make_slice(rng, size)
+    field = gaussian_filter(rng.standard_normal((size, size, nz)), sigma=(4, 4, 1))
+    field = field / (np.abs(field).max() + 1e-8) * 20
+    ct = np.zeros((size, size, nz)); label = np.zeros((size, size, nz)); cam = np.zeros((size, size, nz))
+    s = size / 256.0
+    pitch, centre, ccol = int(round(28 * s)), size // 2, size // 2
+    dims = [(int(round(rng.integers(22, 30) * s)), int(round(rng.integers(38, 46) * s))) for _ in range(5)]
+    for z in range(nz):
+        shrink = 1.0 - 0.25 * abs(z - (nz - 1) / 2) / (nz / 2)     # vertebra cross-section narrows towards the ends
+        img = base['A'].astype(np.float64) * 0.6 + field[:, :, z] + 20
+        lab = np.zeros((size, size))
+        for k, (hgt, wid) in zip(range(-2, 3), dims):
+            w2 = max(8, int(wid * shrink))
+            r0, c0 = centre + k * pitch - hgt // 2, ccol - w2 // 2
+            m = _rounded_rect((size, size), r0, r0 + hgt, c0, c0 + w2, rad=max(2, int(4 * s)))
+            img[m] += 60
+            lab[m] = target_id + k
+        ct[:, :, z] = np.clip(img, 0, 255)
+        label[:, :, z] = lab
+        rr, cc = np.mgrid[0:size, 0:size]
+        cam[:, :, z] = np.exp(-((rr - (centre - pitch)) ** 2 + (cc - ccol) ** 2) / (2 * (12 * s) ** 2))
+    return ct, label, cam

@@ -37,3 +37,56 @@ def test_stage_batched_synthesis_matches_oracle():
     seg = (fs > 0.5).float() * 20
     ref_lab = R.shrm_composite(seg, label, ph, b['height'], b['x1'], b['x2'])
     assert ((lab.cpu() - ref_lab[:, 0]).abs() > 0).float().mean().item() <= 1e-4
+
+
+def test_stage_batched_volume_matches_sequential_oracle():
+    """process_volume (3 batched launches per volume) == the reference's per-slice chain restated with the CPU oracle."""
+    import numpy as np
+    import hvgan
+    from hvgan import synth, infer
+    from hvgan.models.inpaint_networks import Generator
+    from oracle import restate as R
+    torch.manual_seed(5)
+    net = Generator({'input_dim': 1, 'ngf': 16}, True)
+    net.fine_generator.fc_height.bias.data.fill_(0.41)
+    net.fine_generator.fc_height.weight.data.mul_(1e-2)
+    net.cuda().train()
+    dev = torch.device('cuda:0')
+    b = synth.to_model_inputs(synth.make_batch(2, 256, seed=3))
+    for _ in range(3):
+        net.run_forward(b['real_A'].to(dev), b['mask'].to(dev), (1 - b['CAM']).to(dev), b['slice_ratio'].to(dev), training=True)
+    net.eval()
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    ct, label, cam = synth.make_volume(nz=6, size=256, seed=2)
+    cam255 = cam * 255
+    out_ct, out_seg = infer.process_volume(net, ct, label, cam255, 20, dev)
+
+    def oracle_run(cam2d, lab2d, ct2d, vid, ratio):
+        p = infer.prepare_slice(cam2d, lab2d, ct2d, vid)
+        if p is None:
+            return None
+        t = lambda a: torch.from_numpy(a)[None, None]
+        with torch.no_grad():
+            (cs, fs, s1, s2, p1, p2), _ = R.generator_forward(sd, t(p['ct_masked']), t(p['mask']), 1 - t(p['cam']),
+                                                              torch.tensor([ratio], dtype=torch.float64), training=False)
+        ph = p2.view(-1) * 40
+        h, x1, x2 = (torch.tensor([p[k]]) for k in ('height', 'x1', 'x2'))
+        fb = (R.shrm_composite(s2, t(p['ori_ct']), ph, h, x1, x2) + 1) * 127.5
+        seg = R.shrm_composite((fs > 0.5).float() * vid, t(lab2d.astype(np.float32)), ph, h, x1, x2)
+        return seg[0, 0].numpy().astype(np.float64), fb[0, 0].numpy().astype(np.float64)
+
+    zs = [z for z in range(ct.shape[2]) if out_seg[:, :, z].any()]
+    assert len(zs) >= 3
+    rng_len = 6
+    centre = (zs[0] + zs[-1]) // 2
+    bad = 0
+    for z in zs[:3]:
+        ratio = abs(z - centre) / rng_len * 2
+        l, c = label[:, :, z], ct[:, :, z]
+        for vid in (19, 21, 20):
+            r = oracle_run(cam255[:, :, z], l, c, vid, ratio)
+            if r is not None:
+                l, c = r
+        assert np.abs(out_ct[:, :, z] - c).max() <= 0.6, np.abs(out_ct[:, :, z] - c).max()    # uint8 re-quantisation between stages
+        bad += (out_seg[:, :, z] != l).mean()
+    assert bad / 3 <= 1e-3
