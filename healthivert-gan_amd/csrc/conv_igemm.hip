@@ -430,7 +430,8 @@ struct WgradK {
 };
 
 template <typename T, int BN, int BC, int WN, int WC>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradK p) {
+__global__ __launch_bounds__(WN * WC * 64) void wgrad_kernel(const WgradK p) {
+    constexpr int NTHR = WN * WC * 64;          // 4 waves (256 threads) or 8 waves (512 threads, the 256 x 128 tile)
     constexpr int KT = 32;                      // pixels per step
     constexpr bool F16 = sizeof(T) == 2;
     // fp32: [pixel][ch] (ch contiguous, +4 pad); fp16: [ch][pixel] (pixel contiguous, +8 pad) so that a lane
@@ -442,11 +443,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK p) {
     __shared__ __attribute__((aligned(16))) T Gs[F16 ? BN * LDG : KT * LDG];
     __shared__ __attribute__((aligned(16))) T Xs[F16 ? BC * LDX : KT * LDX];
     constexpr int TNW = BN / WN, TCW = BC / WC, NT = TNW / 16, CT = TCW / 16;
-    static_assert(WN * WC == 4 && NT >= 1 && CT >= 1, "bad tile");
+    static_assert((WN * WC == 4 || WN * WC == 8) && NT >= 1 && CT >= 1, "bad tile");
     constexpr int GTHREADS = BN;                // (BN/4 channel groups) x 4 pixel runs
     constexpr int XTHREADS = BC;
-    static_assert(GTHREADS + XTHREADS <= 256 || (GTHREADS <= 256 && XTHREADS <= 256), "tile too wide");
-    constexpr bool TWO_PASS = GTHREADS + XTHREADS > 256;
+    static_assert(GTHREADS + XTHREADS <= NTHR || (GTHREADS <= NTHR && XTHREADS <= NTHR), "tile too wide");
+    constexpr bool TWO_PASS = GTHREADS + XTHREADS > NTHR;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_base = blockIdx.y * BN, j_base = blockIdx.z * BC;
