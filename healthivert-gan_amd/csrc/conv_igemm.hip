@@ -420,21 +420,29 @@ extern "C" int hv_conv2d(const hv_conv_desc* d, void* stream) {
 
 // ------------------------------------------------------------------------------------------------ weight gradient
 // D[co][j] = sum_pix G[pix][co] * X[pix(tap_j)][c_j],  j = (tap, ci) flattened.  A workgroup owns a BN x BC tile
-// of dW and one chunk of pixels; every thread stages 8 consecutive pixels x 4 channels per step.
+// of dW and one chunk of pixels.  Staging is the issue-bound part of this kernel (the 16x16x32 MFMA leaves 8 of its
+// 16 cycles to other vector instructions), so it is kept branch-free: one item = 8 consecutive pixels x 4 channels
+// fetched with 8 buffer_load_dwordx4 whose out-of-image / out-of-chunk lanes get an out-of-range offset (the
+// descriptor's range check returns zeros), addresses advance by a constant per pixel when the output width is a
+// power of two (FAST), and the next tile's loads are issued before this tile's MFMAs.
 struct WgradK {
     const float* x; const float* g; float* out;
     int B, Hl, Wl, in_shift, Wp, img_stride, x_ld, x_coff, Cin;
     int Ho, Wo, g_ld, g_coff, Cout;
     int KW, stride, pad, dil, J /* taps*Cin */, M /* B*Ho*Wo */, chunk;
-    long long slab;  // Cout*J floats per split
+    int lw, lhw;                 // FAST: log2(Wo), log2(Ho*Wo)
+    unsigned x_bytes, g_bytes;   // buffer descriptor ranges
+    long long slab;              // Cout*J floats per split
 };
 
-template <typename T, int BN, int BC, int WN, int WC>
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define HV_OOB 0x80000000u       // beyond every descriptor range (tensors are < 2 GiB): the load returns zeros
+
+template <typename T, int BN, int BC, int WN, int WC, int KT, bool FAST>
 __global__ __launch_bounds__(WN * WC * 64) void wgrad_kernel(const WgradK p) {
-    constexpr int NTHR = WN * WC * 64;          // 4 waves (256 threads) or 8 waves (512 threads, the 256 x 128 tile)
-    constexpr int KT = 32;                      // pixels per step
+    constexpr int NTHR = WN * WC * 64;
     constexpr bool F16 = sizeof(T) == 2;
-    // fp32: [pixel][ch] (ch contiguous, +4 pad); fp16: [ch][pixel] (pixel contiguous, +8 pad) so that a lane
+    // fp32: [pixel][ch] (ch contiguous, padded); fp16: [ch][pixel] (pixel contiguous, +8 pad) so that a lane
     // reads 8 contiguous k (= pixels) for the 16x16x32 MFMA.
     // fp32 rows are padded so that row stride = 16 (mod 32) banks: the two 16-lane halves of a ds_read_b32
     // (pixels k and k+1) then hit disjoint banks.
@@ -443,11 +451,10 @@ __global__ __launch_bounds__(WN * WC * 64) void wgrad_kernel(const WgradK p) {
     __shared__ __attribute__((aligned(16))) T Gs[F16 ? BN * LDG : KT * LDG];
     __shared__ __attribute__((aligned(16))) T Xs[F16 ? BC * LDX : KT * LDX];
     constexpr int TNW = BN / WN, TCW = BC / WC, NT = TNW / 16, CT = TCW / 16;
-    static_assert((WN * WC == 4 || WN * WC == 8) && NT >= 1 && CT >= 1, "bad tile");
-    constexpr int GTHREADS = BN;                // (BN/4 channel groups) x 4 pixel runs
-    constexpr int XTHREADS = BC;
-    static_assert(GTHREADS + XTHREADS <= NTHR || (GTHREADS <= NTHR && XTHREADS <= NTHR), "tile too wide");
-    constexpr bool TWO_PASS = GTHREADS + XTHREADS > NTHR;
+    static_assert(WN * WC == 4 && NT >= 1 && CT >= 1 && KT % 32 == 0, "bad tile");
+    constexpr int GI = (BN / 4) * (KT / 8);     // staging items: (channel groups of 4) x (pixel runs of 8)
+    constexpr int XI = (BC / 4) * (KT / 8);
+    static_assert(GI <= NTHR && XI <= NTHR, "at most one G item and one X item per thread");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_base = blockIdx.y * BN, j_base = blockIdx.z * BC;
@@ -455,15 +462,15 @@ __global__ __launch_bounds__(WN * WC * 64) void wgrad_kernel(const WgradK p) {
     const int pix_end = min(p.M, pix_begin + p.chunk);
     const int HWo = p.Ho * p.Wo;
 
-    // role of this thread in staging
-    const bool is_g = TWO_PASS ? true : tid < GTHREADS;
-    const int t2 = TWO_PASS ? tid : (is_g ? tid : tid - GTHREADS);
-    // G role
-    const int g_cg = t2 % (BN / 4), g_run = t2 / (BN / 4);
-    // X role
-    const int x_cg = t2 % (BC / 4), x_run = t2 / (BC / 4);
+    // G items sit on the first threads, X items on the last: when a tile has fewer items than threads the two
+    // roles land on different waves (different SIMDs) and stage in parallel.
+    const bool has_g = tid < GI;
+    const int xt = tid - (NTHR - XI);
+    const bool has_x = xt >= 0;
+    const int g_cg = tid % (BN / 4), g_run = tid / (BN / 4);
+    const int x_cg = (has_x ? xt : 0) % (BC / 4), x_run = (has_x ? xt : 0) / (BC / 4);
     const int jx = j_base + x_cg * 4;
-    const bool jok = jx < p.J;
+    const bool jok = has_x && jx < p.J;
     int dh = 0, dw = 0, cx = 0;
     if (jok) {
         const int tap = jx / p.Cin;
@@ -473,51 +480,71 @@ __global__ __launch_bounds__(WN * WC * 64) void wgrad_kernel(const WgradK p) {
         dw = s * p.dil - p.pad;
     }
     const int gch = n_base + g_cg * 4;
-    const bool gok = gch < p.Cout;  // Cout % 4 == 0 is guaranteed by the host
+    const bool gok = has_g && gch < p.Cout;  // Cout % 4 == 0 is guaranteed by the host
 
-    float4 rg[8], rx[8];
-    auto decode = [&](int m, int& n, int& ho, int& wo) {
-        n = m / HWo;
-        const int rem = m - n * HWo;
-        ho = rem / p.Wo;
-        wo = rem - ho * p.Wo;
-    };
-    auto load_g = [&](int pix0, int run) {
-        int m = pix0 + run * 8;
+    const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t gsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.g), 0, p.g_bytes, 0x00020000);
+
+    u32x4 rg[8], rx[8];
+    auto load_g = [&](int pix0) __attribute__((always_inline)) {
+        const int m0 = pix0 + g_run * 8;
+        if (FAST) {   // M % 8 == 0 and chunk % KT == 0: a run is wholly inside or outside the chunk
+            unsigned off = (gok && m0 < pix_end) ? (unsigned)(m0 * p.g_ld + p.g_coff + gch) * 4u : HV_OOB;
+            const unsigned step = (unsigned)p.g_ld * 4u;
 #pragma unroll
-        for (int e = 0; e < 8; ++e, ++m) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gok && m < pix_end) v = *reinterpret_cast<const float4*>(p.g + (long long)m * p.g_ld + p.g_coff + gch);
-            rg[e] = v;
-        }
-    };
-    auto load_x = [&](int pix0, int run) {
-        int m = pix0 + run * 8, n, ho, wo;
-        decode(m, n, ho, wo);
-#pragma unroll
-        for (int e = 0; e < 8; ++e, ++m) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int hi = ho * p.stride + dh, wi = wo * p.stride + dw;
-            if (jok && m < pix_end && (unsigned)hi < (unsigned)p.Hl && (unsigned)wi < (unsigned)p.Wl)
-                v = *reinterpret_cast<const float4*>(p.x + n * p.img_stride + ((hi >> p.in_shift) * p.Wp + (wi >> p.in_shift)) * p.x_ld + p.x_coff + cx);
-            rx[e] = v;
-            if (++wo == p.Wo) { wo = 0; if (++ho == p.Ho) { ho = 0; ++n; } }
-        }
-    };
-    auto store = [&](T* dst, int ld, const float4* r, int cg, int run) {
-        if (F16) {
-            // transpose 8 pixels x 4 channels -> 4 rows of 8 halfs
-            const float* f = reinterpret_cast<const float*>(r);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                f16x8 h;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) h[e] = (_Float16)f[e * 4 + c];
-                *reinterpret_cast<f16x8*>(reinterpret_cast<_Float16*>(dst) + (cg * 4 + c) * ld + run * 8) = h;
-            }
+            for (int e = 0; e < 8; ++e, off += step) rg[e] = __builtin_amdgcn_raw_buffer_load_b128(gsrc, off, 0, 0);
         } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) *reinterpret_cast<float4*>(reinterpret_cast<float*>(dst) + (run * 8 + e) * ld + cg * 4) = r[e];
+            for (int e = 0; e < 8; ++e) {
+                const unsigned off = (gok && m0 + e < pix_end) ? (unsigned)((m0 + e) * p.g_ld + p.g_coff + gch) * 4u : HV_OOB;
+                rg[e] = __builtin_amdgcn_raw_buffer_load_b128(gsrc, off, 0, 0);
+            }
+        }
+    };
+    auto load_x = [&](int pix0) __attribute__((always_inline)) {
+        const int m0 = pix0 + x_run * 8;
+        if (FAST) {   // Wo is a power of two >= 8: the 8 pixels of a run share one output row
+            const int n = m0 >> p.lhw, ho = (m0 >> p.lw) & (p.Ho - 1), wo0 = m0 & (p.Wo - 1);
+            const int hi = ho * p.stride + dh;
+            const bool rok = jok && m0 < pix_end && (unsigned)hi < (unsigned)p.Hl;
+            const int base = n * p.img_stride + (hi >> p.in_shift) * p.Wp * p.x_ld + p.x_coff + cx;
+            int wi = wo0 * p.stride + dw;
+#pragma unroll
+            for (int e = 0; e < 8; ++e, wi += p.stride) {
+                const unsigned off = (rok && (unsigned)wi < (unsigned)p.Wl) ? (unsigned)(base + (wi >> p.in_shift) * p.x_ld) * 4u : HV_OOB;
+                rx[e] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, off, 0, 0);
+            }
+        } else {
+            int n = m0 / HWo;
+            const int rem = m0 - n * HWo;
+            int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int hi = ho * p.stride + dh, wi = wo * p.stride + dw;
+                const bool ok = jok && m0 + e < pix_end && (unsigned)hi < (unsigned)p.Hl && (unsigned)wi < (unsigned)p.Wl;
+                const unsigned off = ok ? (unsigned)(n * p.img_stride + ((hi >> p.in_shift) * p.Wp + (wi >> p.in_shift)) * p.x_ld + p.x_coff + cx) * 4u : HV_OOB;
+                rx[e] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, off, 0, 0);
+                if (++wo == p.Wo) { wo = 0; if (++ho == p.Ho) { ho = 0; ++n; } }
+            }
+        }
+    };
+    auto store = [&](T* dst, int ld, const u32x4 (&r)[8], int cg, int run) __attribute__((always_inline)) {
+        if (F16) {
+            // transpose 8 pixels x 4 channels -> 4 rows of 8 halfs
+            f16x8 h0, h1, h2, h3;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                h0[e] = (_Float16)__uint_as_float(r[e].x); h1[e] = (_Float16)__uint_as_float(r[e].y);
+                h2[e] = (_Float16)__uint_as_float(r[e].z); h3[e] = (_Float16)__uint_as_float(r[e].w);
+            }
+            _Float16* base = reinterpret_cast<_Float16*>(dst) + (cg * 4) * ld + run * 8;
+            *reinterpret_cast<f16x8*>(base) = h0;
+            *reinterpret_cast<f16x8*>(base + ld) = h1;
+            *reinterpret_cast<f16x8*>(base + 2 * ld) = h2;
+            *reinterpret_cast<f16x8*>(base + 3 * ld) = h3;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) *reinterpret_cast<u32x4*>(reinterpret_cast<float*>(dst) + (run * 8 + e) * ld + cg * 4) = r[e];
         }
     };
 
@@ -528,35 +555,34 @@ __global__ __launch_bounds__(WN * WC * 64) void wgrad_kernel(const WgradK p) {
         for (int c = 0; c < CT; ++c) acc[n][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int wn = wave / WC, wc = wave % WC;
 
+    if (pix_begin < pix_end) {
+        if (has_g) load_g(pix_begin);
+        if (has_x) load_x(pix_begin);
+    }
     for (int pix0 = pix_begin; pix0 < pix_end; pix0 += KT) {
-        if (TWO_PASS) {
-            if (tid < GTHREADS) load_g(pix0, g_run);
-            if (tid < XTHREADS) load_x(pix0, x_run);
-        } else {
-            if (is_g) load_g(pix0, g_run);
-            else if (t2 < XTHREADS) load_x(pix0, x_run);
-        }
         __syncthreads();  // previous step's MFMA reads done
-        if (TWO_PASS) {
-            if (tid < GTHREADS) store(Gs, LDG, rg, g_cg, g_run);
-            if (tid < XTHREADS) store(Xs, LDX, rx, x_cg, x_run);
-        } else {
-            if (is_g) store(Gs, LDG, rg, g_cg, g_run);
-            else if (t2 < XTHREADS) store(Xs, LDX, rx, x_cg, x_run);
-        }
+        if (has_g) store(Gs, LDG, rg, g_cg, g_run);
+        if (has_x) store(Xs, LDX, rx, x_cg, x_run);
         __syncthreads();
+        if (pix0 + KT < pix_end) {   // next tile's loads fly behind this tile's MFMAs
+            if (has_g) load_g(pix0 + KT);
+            if (has_x) load_x(pix0 + KT);
+        }
         if (F16) {
             const _Float16* G16 = reinterpret_cast<const _Float16*>(Gs);
             const _Float16* X16 = reinterpret_cast<const _Float16*>(Xs);
-            f16x8 a[NT], b[CT];
 #pragma unroll
-            for (int n = 0; n < NT; ++n) a[n] = *reinterpret_cast<const f16x8*>(G16 + (wn * TNW + n * 16 + (lane & 15)) * LDG + (lane >> 4) * 8);
+            for (int ks = 0; ks < KT / 32; ++ks) {
+                f16x8 a[NT], b[CT];
 #pragma unroll
-            for (int c = 0; c < CT; ++c) b[c] = *reinterpret_cast<const f16x8*>(X16 + (wc * TCW + c * 16 + (lane & 15)) * LDX + (lane >> 4) * 8);
+                for (int n = 0; n < NT; ++n) a[n] = *reinterpret_cast<const f16x8*>(G16 + (wn * TNW + n * 16 + (lane & 15)) * LDG + ks * 32 + (lane >> 4) * 8);
 #pragma unroll
-            for (int n = 0; n < NT; ++n)
+                for (int c = 0; c < CT; ++c) b[c] = *reinterpret_cast<const f16x8*>(X16 + (wc * TCW + c * 16 + (lane & 15)) * LDX + ks * 32 + (lane >> 4) * 8);
 #pragma unroll
-                for (int c = 0; c < CT; ++c) acc[n][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[n], b[c], acc[n][c], 0, 0, 0);
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) acc[n][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[n], b[c], acc[n][c], 0, 0, 0);
+            }
         } else {
             const float* G32 = reinterpret_cast<const float*>(Gs);
             const float* X32 = reinterpret_cast<const float*>(Xs);
@@ -615,7 +641,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
-struct WgradPlan { int BN, BC, splits, chunk; };
+struct WgradPlan { int BN, BC, KT, splits, chunk; };
 static int wgrad_plan(const hv_wgrad_desc* d, WgradPlan* pl) {
     const int J = d->KH * d->KW * d->Cin;
     const long long M = (long long)d->B * d->Ho * d->Wo;
@@ -632,10 +658,12 @@ static int wgrad_plan(const hv_wgrad_desc* d, WgradPlan* pl) {
     long long splits = want < 1 ? 1 : want;
     if (splits > maxs) splits = maxs;
     if (splits < 1) splits = 1;
+    // pixels per staging step: fp16 tiles take 64 (128 for the 64x64 tile) so that every thread stages an X item
+    const int KT = d->precision == HV_F32 ? 32 : (BN == 64 ? 128 : 64);
     long long chunk = (M + splits - 1) / splits;
-    chunk = (chunk + 31) / 32 * 32;
+    chunk = (chunk + KT - 1) / KT * KT;
     splits = (M + chunk - 1) / chunk;
-    pl->BN = BN; pl->BC = BC; pl->splits = (int)splits; pl->chunk = (int)chunk;
+    pl->BN = BN; pl->BC = BC; pl->KT = KT; pl->splits = (int)splits; pl->chunk = (int)chunk;
     return HV_OK;
 }
 
@@ -649,7 +677,8 @@ static int wgrad_validate(const hv_wgrad_desc* d) {
     if (d->in_shift < 0 || d->in_shift > 1) return HV_ERR_UNSUPPORTED;
     if (d->precision != HV_F32 && d->precision != HV_F16) return HV_ERR_ARG;
     const int Hp = d->H >> d->in_shift, Wp = d->W >> d->in_shift;
-    if ((long long)d->B * Hp * Wp * d->x_ld >= (1ll << 31) || (long long)d->B * d->Ho * d->Wo * d->g_ld >= (1ll << 31)) return HV_ERR_UNSUPPORTED;
+    // byte offsets are 32-bit buffer offsets with 0x80000000 as the out-of-range marker: tensors stay below 2 GiB
+    if ((long long)d->B * Hp * Wp * d->x_ld >= (1ll << 29) || (long long)d->B * d->Ho * d->Wo * d->g_ld >= (1ll << 29)) return HV_ERR_UNSUPPORTED;
     return HV_OK;
 }
 
@@ -663,14 +692,17 @@ extern "C" size_t hv_conv2d_wgrad_workspace_bytes(const hv_wgrad_desc* d) {
     return (size_t)pl.splits * d->Cout * d->KH * d->KW * d->Cin * sizeof(float);
 }
 
-template <typename T>
+template <typename T, bool FAST>
 static int launch_wgrad(const WgradK& k, const WgradPlan& pl, hipStream_t s) {
+    constexpr bool F16 = sizeof(T) == 2;
+    constexpr int KT = F16 ? 64 : 32, KT64 = F16 ? 128 : 32;
     dim3 grid(pl.splits, hv_cdiv(k.Cout, pl.BN), hv_cdiv(k.J, pl.BC));
-    if (pl.BN == 16) hipLaunchKernelGGL((wgrad_kernel<T, 16, 128, 1, 4>), grid, dim3(256), 0, s, k);
-    else if (pl.BN == 32) hipLaunchKernelGGL((wgrad_kernel<T, 32, 128, 1, 4>), grid, dim3(256), 0, s, k);
-    else if (pl.BN == 64) hipLaunchKernelGGL((wgrad_kernel<T, 64, 64, 2, 2>), grid, dim3(256), 0, s, k);
-    else if (pl.BC == 128) hipLaunchKernelGGL((wgrad_kernel<T, 128, 128, 2, 2>), grid, dim3(256), 0, s, k);
-    else hipLaunchKernelGGL((wgrad_kernel<T, 128, 64, 2, 2>), grid, dim3(256), 0, s, k);
+    if (pl.KT != (pl.BN == 64 ? KT64 : KT)) return HV_ERR_ARG;
+    if (pl.BN == 16) hipLaunchKernelGGL((wgrad_kernel<T, 16, 128, 1, 4, KT, FAST>), grid, dim3(256), 0, s, k);
+    else if (pl.BN == 32) hipLaunchKernelGGL((wgrad_kernel<T, 32, 128, 1, 4, KT, FAST>), grid, dim3(256), 0, s, k);
+    else if (pl.BN == 64) hipLaunchKernelGGL((wgrad_kernel<T, 64, 64, 2, 2, KT64, FAST>), grid, dim3(256), 0, s, k);
+    else if (pl.BC == 128) hipLaunchKernelGGL((wgrad_kernel<T, 128, 128, 2, 2, KT, FAST>), grid, dim3(256), 0, s, k);
+    else hipLaunchKernelGGL((wgrad_kernel<T, 128, 64, 2, 2, KT, FAST>), grid, dim3(256), 0, s, k);
     HV_LAUNCH_CHECK();
     return HV_OK;
 }
@@ -702,8 +734,15 @@ extern "C" int hv_conv2d_wgrad(const hv_wgrad_desc* d, void* stream) {
     k.Ho = d->Ho; k.Wo = d->Wo; k.g_ld = d->g_ld; k.g_coff = d->g_coff; k.Cout = d->Cout;
     k.KW = d->KW; k.stride = d->stride; k.pad = d->pad; k.dil = d->dil; k.J = d->KH * d->KW * d->Cin;
     k.M = d->B * d->Ho * d->Wo; k.chunk = pl.chunk; k.slab = nW;
+    k.x_bytes = (unsigned)((size_t)d->B * (d->H >> d->in_shift) * k.Wp * d->x_ld * sizeof(float));
+    k.g_bytes = (unsigned)((size_t)k.M * d->g_ld * sizeof(float));
+    auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+    const bool fast = pow2(d->Wo) && pow2(d->Ho) && d->Wo >= 8;
+    k.lw = k.lhw = 0;
+    if (fast) { k.lw = __builtin_ctz(d->Wo); k.lhw = k.lw + __builtin_ctz(d->Ho); }
     hipStream_t s = (hipStream_t)stream;
-    rc = d->precision == HV_F32 ? launch_wgrad<float>(k, pl, s) : launch_wgrad<_Float16>(k, pl, s);
+    if (d->precision == HV_F32) rc = fast ? launch_wgrad<float, true>(k, pl, s) : launch_wgrad<float, false>(k, pl, s);
+    else rc = fast ? launch_wgrad<_Float16, true>(k, pl, s) : launch_wgrad<_Float16, false>(k, pl, s);
     if (rc != HV_OK) return rc;
     if (!direct) {
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(hv_cdiv(nW, 64)), dim3(256), 0, s, d->workspace, d->dw, nW, pl.splits, d->accumulate);

@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'hvgan.h')
-LIB_PATH = os.path.join(_HERE, 'libhvgan.so')
+LIB_PATH = os.environ.get('HVGAN_LIB') or os.path.join(_HERE, 'libhvgan.so')   # HVGAN_LIB: A/B a kernel variant build
 
 F32, F16 = 0, 1
 ACT = {'none': 0, 'elu': 1, 'relu': 2, 'lrelu': 3, 'sigmoid': 4, 'clamp': 5}
