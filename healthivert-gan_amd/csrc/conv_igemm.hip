@@ -431,6 +431,7 @@ struct WgradK {
     int Ho, Wo, g_ld, g_coff, Cout;
     int KW, stride, pad, dil, J /* taps*Cin */, M /* B*Ho*Wo */, chunk;
     int lw, lhw;                 // FAST: log2(Wo), log2(Ho*Wo)
+    int kt_q, kt_r;              // !FAST: KT / Wo, KT % Wo
     unsigned x_bytes, g_bytes;   // buffer descriptor ranges
     long long slab;              // Cout*J floats per split
 };
@@ -446,12 +447,15 @@ __global__ __launch_bounds__(WN * WC * 64) void wgrad_kernel(const WgradK p) {
     // reads 8 contiguous k (= pixels) for the 16x16x32 MFMA.
     // fp32 rows are padded so that row stride = 16 (mod 32) banks: the two 16-lane halves of a ds_read_b32
     // (pixels k and k+1) then hit disjoint banks.
-    constexpr int LDG = F16 ? (KT + 8) : (BN + ((BN % 32 == 16) ? 0 : 16));
-    constexpr int LDX = F16 ? (KT + 8) : (BC + ((BC % 32 == 16) ? 0 : 16));
+    // fp16 rows are KT + 16 halfs (row stride = 8 mod 16 dwords, odd multiple of 8) and the 16-B column of a row is
+    // XOR-swizzled with (row >> 2) & 7: the four 16-lane groups of a ds_read_b128 (16 rows x two k-groups) then cover
+    // all 64 banks once, and so do the 8 lanes of a staging ds_write_b128 group (8 channel groups, same pixel run).
+    constexpr int LDG = F16 ? (KT + 16) : (BN + ((BN % 32 == 16) ? 0 : 16));
+    constexpr int LDX = F16 ? (KT + 16) : (BC + ((BC % 32 == 16) ? 0 : 16));
     __shared__ __attribute__((aligned(16))) T Gs[F16 ? BN * LDG : KT * LDG];
     __shared__ __attribute__((aligned(16))) T Xs[F16 ? BC * LDX : KT * LDX];
     constexpr int TNW = BN / WN, TCW = BC / WC, NT = TNW / 16, CT = TCW / 16;
-    static_assert(WN * WC == 4 && NT >= 1 && CT >= 1 && KT % 32 == 0, "bad tile");
+    static_assert(WN * WC == 4 && NT >= 1 && CT >= 1 && KT % 32 == 0 && (!F16 || KT % 64 == 0), "bad tile");
     constexpr int GI = (BN / 4) * (KT / 8);     // staging items: (channel groups of 4) x (pixel runs of 8)
     constexpr int XI = (BC / 4) * (KT / 8);
     static_assert(GI <= NTHR && XI <= NTHR, "at most one G item and one X item per thread");
@@ -467,8 +471,9 @@ __global__ __launch_bounds__(WN * WC * 64) void wgrad_kernel(const WgradK p) {
     const bool has_g = tid < GI;
     const int xt = tid - (NTHR - XI);
     const bool has_x = xt >= 0;
+    const int xi = has_x ? xt : 0;
     const int g_cg = tid % (BN / 4), g_run = tid / (BN / 4);
-    const int x_cg = (has_x ? xt : 0) % (BC / 4), x_run = (has_x ? xt : 0) / (BC / 4);
+    const int x_cg = xi % (BC / 4), x_run = xi / (BC / 4);
     const int jx = j_base + x_cg * 4;
     const bool jok = has_x && jx < p.J;
     int dh = 0, dw = 0, cx = 0;
@@ -485,6 +490,16 @@ __global__ __launch_bounds__(WN * WC * 64) void wgrad_kernel(const WgradK p) {
     const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t gsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.g), 0, p.g_bytes, 0x00020000);
 
+    // decode state of this thread's X item (first pixel of its run) for the non-power-of-two path; load_x is called
+    // with pix_begin, pix_begin + KT, ... in order and advances it
+    int xs_n = 0, xs_ho = 0, xs_wo = 0;
+    if (!FAST) {
+        const int m0 = pix_begin + x_run * 8;
+        xs_n = m0 / HWo;
+        const int rem = m0 - xs_n * HWo;
+        xs_ho = rem / p.Wo;
+        xs_wo = rem - xs_ho * p.Wo;
+    }
     u32x4 rg[8], rx[8];
     auto load_g = [&](int pix0) __attribute__((always_inline)) {
         const int m0 = pix0 + g_run * 8;
@@ -514,10 +529,24 @@ __global__ __launch_bounds__(WN * WC * 64) void wgrad_kernel(const WgradK p) {
                 const unsigned off = (rok && (unsigned)wi < (unsigned)p.Wl) ? (unsigned)(base + (wi >> p.in_shift) * p.x_ld) * 4u : HV_OOB;
                 rx[e] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, off, 0, 0);
             }
-        } else {
-            int n = m0 / HWo;
-            const int rem = m0 - n * HWo;
-            int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+        } else if (p.Wo >= 8) {   // any output size: the run crosses an output row at most once -- two row bases, one select per pixel
+            const int cross = p.Wo - xs_wo;                       // pixels e >= cross sit on the next output row
+            int ho1 = xs_ho + 1, n1 = xs_n;
+            if (ho1 == p.Ho) { ho1 = 0; ++n1; }
+            const int hiA = xs_ho * p.stride + dh, hiB = ho1 * p.stride + dh;
+            const bool rokA = jok && (unsigned)hiA < (unsigned)p.Hl, rokB = jok && (unsigned)hiB < (unsigned)p.Hl;
+            const int baseA = xs_n * p.img_stride + (hiA >> p.in_shift) * p.Wp * p.x_ld + p.x_coff + cx;
+            const int baseB = n1 * p.img_stride + (hiB >> p.in_shift) * p.Wp * p.x_ld + p.x_coff + cx;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bool nb = e >= cross;
+                const int wi = (xs_wo + e - (nb ? p.Wo : 0)) * p.stride + dw;
+                const bool ok = (nb ? rokB : rokA) && m0 + e < pix_end && (unsigned)wi < (unsigned)p.Wl;
+                const unsigned off = ok ? (unsigned)((nb ? baseB : baseA) + (wi >> p.in_shift) * p.x_ld) * 4u : HV_OOB;
+                rx[e] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, off, 0, 0);
+            }
+        } else {                  // tiny maps: step pixel by pixel
+            int n = xs_n, ho = xs_ho, wo = xs_wo;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int hi = ho * p.stride + dh, wi = wo * p.stride + dw;
@@ -526,6 +555,12 @@ __global__ __launch_bounds__(WN * WC * 64) void wgrad_kernel(const WgradK p) {
                 rx[e] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, off, 0, 0);
                 if (++wo == p.Wo) { wo = 0; if (++ho == p.Ho) { ho = 0; ++n; } }
             }
+        }
+        if (!FAST) {
+            // advance the decode state by one step (KT pixels) without dividing
+            xs_wo += p.kt_r; xs_ho += p.kt_q;
+            if (xs_wo >= p.Wo) { xs_wo -= p.Wo; ++xs_ho; }
+            while (xs_ho >= p.Ho) { xs_ho -= p.Ho; ++xs_n; }
         }
     };
     auto store = [&](T* dst, int ld, const u32x4 (&r)[8], int cg, int run) __attribute__((always_inline)) {
@@ -537,7 +572,7 @@ __global__ __launch_bounds__(WN * WC * 64) void wgrad_kernel(const WgradK p) {
                 h0[e] = (_Float16)__uint_as_float(r[e].x); h1[e] = (_Float16)__uint_as_float(r[e].y);
                 h2[e] = (_Float16)__uint_as_float(r[e].z); h3[e] = (_Float16)__uint_as_float(r[e].w);
             }
-            _Float16* base = reinterpret_cast<_Float16*>(dst) + (cg * 4) * ld + run * 8;
+            _Float16* base = reinterpret_cast<_Float16*>(dst) + (cg * 4) * ld + (run ^ (cg & 7)) * 8;
             *reinterpret_cast<f16x8*>(base) = h0;
             *reinterpret_cast<f16x8*>(base + ld) = h1;
             *reinterpret_cast<f16x8*>(base + 2 * ld) = h2;
@@ -575,9 +610,15 @@ __global__ __launch_bounds__(WN * WC * 64) void wgrad_kernel(const WgradK p) {
             for (int ks = 0; ks < KT / 32; ++ks) {
                 f16x8 a[NT], b[CT];
 #pragma unroll
-                for (int n = 0; n < NT; ++n) a[n] = *reinterpret_cast<const f16x8*>(G16 + (wn * TNW + n * 16 + (lane & 15)) * LDG + ks * 32 + (lane >> 4) * 8);
+                for (int n = 0; n < NT; ++n) {
+                    const int row = wn * TNW + n * 16 + (lane & 15);
+                    a[n] = *reinterpret_cast<const f16x8*>(G16 + row * LDG + ((ks * 4 + (lane >> 4)) ^ ((row >> 2) & 7)) * 8);
+                }
 #pragma unroll
-                for (int c = 0; c < CT; ++c) b[c] = *reinterpret_cast<const f16x8*>(X16 + (wc * TCW + c * 16 + (lane & 15)) * LDX + ks * 32 + (lane >> 4) * 8);
+                for (int c = 0; c < CT; ++c) {
+                    const int row = wc * TCW + c * 16 + (lane & 15);
+                    b[c] = *reinterpret_cast<const f16x8*>(X16 + row * LDX + ((ks * 4 + (lane >> 4)) ^ ((row >> 2) & 7)) * 8);
+                }
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
 #pragma unroll
@@ -739,6 +780,7 @@ extern "C" int hv_conv2d_wgrad(const hv_wgrad_desc* d, void* stream) {
     auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
     const bool fast = pow2(d->Wo) && pow2(d->Ho) && d->Wo >= 8;
     k.lw = k.lhw = 0;
+    k.kt_q = pl.KT / d->Wo; k.kt_r = pl.KT % d->Wo;
     if (fast) { k.lw = __builtin_ctz(d->Wo); k.lhw = k.lw + __builtin_ctz(d->Ho); }
     hipStream_t s = (hipStream_t)stream;
     if (d->precision == HV_F32) rc = fast ? launch_wgrad<float, true>(k, pl, s) : launch_wgrad<float, false>(k, pl, s);
