@@ -15,6 +15,8 @@
 #include <stdlib.h>
 
 typedef _Float16 f16x4v __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define HV_OOB 0x80000000u       // beyond every descriptor range (tensors are < 2 GiB): the load returns zeros
 
 struct HaloCls {
     int ph, pw, Hc, Wc, ntaps, tiles_x, tiles, t0;   // t0 = first tile index of the class in the grid
@@ -27,6 +29,7 @@ struct HaloK {
     int Cout, w_row, y_ld, y_coff, Ho, Wo;
     int bstep, boff, ostep;
     float alpha; int act, accumulate, vec_store, ncls;
+    unsigned x_bytes, w_bytes;   // buffer descriptor ranges
     HaloCls cls[4];
 };
 
@@ -93,37 +96,84 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloK p) {
     // keep two tap groups in flight (prefetch distance 2) behind the MFMAs of the current group.
     constexpr int WVEC = CK / 8;                             // 16-B vectors per row
     constexpr int WLOADS = (TG * BN * WVEC + 255) / 256;
+    constexpr bool WTAP_UNIFORM = (BN * WVEC) % 256 == 0;    // every load instruction of the workgroup stays inside one tap
+    // Staging is kept off the vector ALU (an MFMA leaves only half its cycles to other vector instructions): row
+    // offsets are computed once, the tap/chunk part of the address is a scalar buffer offset, rows beyond Cout get an
+    // out-of-range offset (the descriptor's range check returns zeros) instead of a branch.
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.w), 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+    unsigned wvo[WLOADS];                                    // byte offset of (row n, vector) inside w, without tap / chunk
+    int wlo[WLOADS];                                         // LDS offset (halfs) inside one weight buffer, -1 = no element
+    int wtg[WLOADS];                                         // tap-in-group of the element
+#pragma unroll
+    for (int i = 0; i < WLOADS; ++i) {
+        const int e = tid + i * 256;
+        const int vec = e % WVEC, r = e / WVEC, n = r % BN;
+        const bool in = e < TG * BN * WVEC;
+        wtg[i] = r / BN;
+        wlo[i] = in ? r * LDP + vec * 8 : -1;
+        wvo[i] = (in && n_base + n < p.Cout) ? (unsigned)(((n_base + n) * p.w_row + vec * 8) * 2) : HV_OOB;
+    }
     uint4 wra[WLOADS], wrb[WLOADS];
-    auto wload = [&](uint4 (&wr)[WLOADS], int grp, int c0) {
+    auto wload = [&](uint4 (&wr)[WLOADS], int grp, int c0) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < WLOADS; ++i) {
-            const int e = tid + i * 256;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (e < TG * BN * WVEC) {
-                const int vec = e % WVEC, r = e / WVEC, n = r % BN, tg = r / BN;
-                const int tap = grp * TG + tg;
-                if (tap < ntaps && n_base + n < p.Cout) {
-                    const int widx = (int)(taps_s[tap] >> 16);
-                    v = *reinterpret_cast<const uint4*>(p.w + (long long)(n_base + n) * p.w_row + widx * p.Cin + c0 + vec * 8);
+            if (WTAP_UNIFORM) {
+                const int tap = grp * TG + (i * 256) / (BN * WVEC);
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (tap < ntaps) {   // scalar condition
+                    const int widx = (int)(__builtin_amdgcn_readfirstlane(taps_s[tap]) >> 16);
+                    v = __builtin_amdgcn_raw_buffer_load_b128(wsrc, wvo[i], (widx * p.Cin + c0) * 2, 0);
                 }
+                wr[i] = make_uint4(v.x, v.y, v.z, v.w);
+            } else {
+                const int tap = grp * TG + wtg[i];
+                const int widx = (int)(taps_s[tap < ntaps ? tap : 0] >> 16);
+                const unsigned off = tap < ntaps ? wvo[i] + (unsigned)((widx * p.Cin + c0) * 2) : HV_OOB;
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wsrc, off, 0, 0);
+                wr[i] = make_uint4(v.x, v.y, v.z, v.w);
             }
-            wr[i] = v;
         }
     };
-    auto wstore = [&](const uint4 (&wr)[WLOADS], int buf) {
+    auto wstore = [&](const uint4 (&wr)[WLOADS], int buf) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < WLOADS; ++i) {
-            const int e = tid + i * 256;
-            if (e < TG * BN * WVEC) {
-                const int vec = e % WVEC, r = e / WVEC;
-                *reinterpret_cast<uint4*>(wbuf + (buf * TG * BN + r) * LDP + vec * 8) = wr[i];
-            }
-        }
+        for (int i = 0; i < WLOADS; ++i)
+            if (wlo[i] >= 0) *reinterpret_cast<uint4*>(wbuf + buf * TG * BN * LDP + wlo[i]) = wr[i];
     };
-    // input patch: small patches are prefetched into registers one chunk ahead, large ones staged synchronously
+    // input patch: small patches are prefetched into registers one chunk ahead (offsets computed once, buffer loads
+    // with the chunk as scalar offset), large ones staged synchronously
     constexpr int PV = CK / 4;
     const bool patch_pf = npatch * PV <= PMAX * 256;
-    float4 preg[PMAX];
+    u32x4 preg[PMAX];
+    unsigned pvo[PMAX];          // byte offset of (patch pixel, channel quad) in x, HV_OOB outside the image / patch
+    int plo[PMAX];               // LDS offset (halfs), -1 = no element
+    const unsigned xbase = (unsigned)(n_img * p.img_stride + p.x_coff) * 4u;
+    if (patch_pf) {
+#pragma unroll
+        for (int i = 0; i < PMAX; ++i) {
+            const int e = tid + i * 256;
+            const int c4 = e % PV, pix = e / PV;
+            const int py = pix / PW, px = pix - py * PW;
+            const int hi = h0 + py, wi = w0 + px;
+            const bool in = e < npatch * PV;
+            plo[i] = in ? pix * LDP + c4 * 4 : -1;
+            pvo[i] = (in && (unsigned)hi < (unsigned)p.Hl && (unsigned)wi < (unsigned)p.Wl)
+                         ? xbase + (unsigned)(((hi >> p.in_shift) * p.Wp + (wi >> p.in_shift)) * p.x_ld + c4 * 4) * 4u : HV_OOB;
+        }
+    }
+    auto ppref = [&](int c0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < PMAX; ++i) preg[i] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, pvo[i], c0 * 4, 0);
+    };
+    auto pflush = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < PMAX; ++i) {
+            if (plo[i] < 0) continue;
+            f16x4v h = {(_Float16)__uint_as_float(preg[i].x), (_Float16)__uint_as_float(preg[i].y),
+                        (_Float16)__uint_as_float(preg[i].z), (_Float16)__uint_as_float(preg[i].w)};
+            *reinterpret_cast<f16x4v*>(patch + plo[i]) = h;
+        }
+    };
     auto pload1 = [&](int e, int c0) -> float4 {
         const int c4 = e % PV, pix = e / PV;
         const int py = pix / PW, px = pix - py * PW;
@@ -144,7 +194,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloK p) {
         for (int tg = 0; tg < TG; ++tg) {
             const int tap = g * TG + tg;
             if (tap >= ntaps) break;
-            const uint32_t e = taps_s[tap];
+            const uint32_t e = __builtin_amdgcn_readfirstlane(taps_s[tap]);
             const int toff = ((int)(e & 0xff) * PW + (int)((e >> 8) & 0xff)) * LDP;
             typename HFrag<CK>::V wf[NT];
 #pragma unroll
@@ -160,15 +210,11 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloK p) {
 
     __syncthreads();   // taps_s
     const int ngroups = (ntaps + TG - 1) / TG;
-    if (patch_pf) {
-#pragma unroll
-        for (int i = 0; i < PMAX; ++i) { const int e = tid + i * 256; if (e < npatch * PV) preg[i] = pload1(e, 0); }
-    }
+    if (patch_pf) ppref(0);
     for (int c0 = 0; c0 < p.Cin; c0 += CK) {
         // ---- patch of this chunk -> LDS (all MFMA reads of the previous chunk finished at its last barrier)
         if (patch_pf) {
-#pragma unroll
-            for (int i = 0; i < PMAX; ++i) { const int e = tid + i * 256; if (e < npatch * PV) pstore1(e, preg[i]); }
+            pflush();
         } else {
             for (int e = tid; e < npatch * PV; e += 256) pstore1(e, pload1(e, c0));
         }
@@ -176,10 +222,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloK p) {
         wstore(wra, 0);
         if (ngroups > 1) wload(wrb, 1, c0);
         if (ngroups > 2) wload(wra, 2, c0);
-        if (patch_pf && c0 + CK < p.Cin) {   // next chunk's patch rides behind this chunk's MFMAs
-#pragma unroll
-            for (int i = 0; i < PMAX; ++i) { const int e = tid + i * 256; if (e < npatch * PV) preg[i] = pload1(e, c0 + CK); }
-        }
+        if (patch_pf && c0 + CK < p.Cin) ppref(c0 + CK);   // next chunk's patch rides behind this chunk's MFMAs
         __syncthreads();
         for (int g = 0; g < ngroups; g += 2) {
             compute(g);
@@ -283,6 +326,9 @@ int hv_conv2d_halo(const hv_conv_desc* d, const void* w_f16, hipStream_t s) {
     k.x = d->x; k.w = (const _Float16*)w_f16; k.bias = d->bias; k.y = d->y;
     k.B = d->B; k.Hl = d->H; k.Wl = d->W; k.in_shift = d->in_shift; k.Wp = Wp; k.img_stride = Hp * Wp * d->x_ld;
     k.x_ld = d->x_ld; k.x_coff = d->x_coff; k.Cin = d->Cin;
+    if ((long long)d->B * k.img_stride >= (1ll << 29) || (long long)d->Cout * d->KH * d->KW * d->Cin >= (1ll << 30)) return HV_ERR_UNSUPPORTED;
+    k.x_bytes = (unsigned)((size_t)d->B * k.img_stride * sizeof(float));
+    k.w_bytes = (unsigned)((size_t)d->Cout * d->KH * d->KW * d->Cin * sizeof(_Float16));
     k.Cout = d->Cout; k.w_row = d->KH * d->KW * d->Cin; k.y_ld = d->y_ld; k.y_coff = d->y_coff; k.Ho = d->Ho; k.Wo = d->Wo;
     k.alpha = d->alpha; k.act = d->act; k.accumulate = d->accumulate;
     k.vec_store = ((d->y_ld & 3) == 0 && (d->y_coff & 3) == 0 && ((uintptr_t)d->y & 15) == 0) ? 1 : 0;
