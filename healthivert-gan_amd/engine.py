@@ -146,6 +146,12 @@ class ConvNode:
                    in_shift=self.shift, transposed=self.transposed, precision=prec, cout=p.cout)
 
 
+# streams on which weight gradients stay in line instead of forking to a side stream: the per-discriminator streams of
+# the train step (three chains already run concurrently there, and a fork nested inside a forked stream crashes
+# hipStreamEndCapture on ROCm 7.2 when the step is captured as a graph)
+NO_FORK_STREAMS = set()
+
+
 class GradBook:
     """Gradient twins of activation buffers; first write assigns, later writes accumulate."""
 
@@ -154,6 +160,9 @@ class GradBook:
         self.written = set()
         self.side = None          # side HIP stream for weight gradients (they overlap the data-gradient chain)
         self.overlap = os.environ.get('HV_OVERLAP_WGRAD', '1') != '0'
+
+    def can_fork(self):
+        return self.overlap and torch.cuda.current_stream().cuda_stream not in NO_FORK_STREAMS
 
     def fork(self):
         """Side stream, ordered after everything queued so far on the current stream."""
@@ -209,7 +218,7 @@ def conv_backward(node, book, prec, dbias_accumulate=False, wgrad_accumulate=Fal
         xin = Act(xs.t, p.cin_wg, xs.coff)
         # the weight gradient only feeds the optimiser: queue it on the side stream so that it overlaps the data-gradient
         # chain (joined by GradBook.join() before the gradients are finalised / the activations are overwritten)
-        ctx = torch.cuda.stream(book.fork()) if book.overlap else contextlib.nullcontext()
+        ctx = torch.cuda.stream(book.fork()) if book.can_fork() else contextlib.nullcontext()
         with ctx:
             _wgrad(node, p, xin, gfull, wgrad_accumulate, prec)
     if node.need_dx and node.transposed:

@@ -11,6 +11,7 @@ import ctypes
 import torch
 
 from ._backend import ddp
+from ._backend import engine
 from ._backend import lib as _lib
 from ._backend import ops
 from ._backend import lib as _lib_
@@ -21,6 +22,11 @@ from . import networks
 from .base_model import BaseModel
 from .edge_operator import Sobel
 from .inpaint_networks import Generator
+
+
+def _os_environ_graph():
+    import os
+    return os.environ.get('HV_GRAPH', '1') != '0'
 
 
 def diceCoeff(pred, gt, eps=1e-5, activation='sigmoid'):
@@ -75,6 +81,10 @@ class Pix2PixModel(BaseModel):
             self.optimizers += [self.optimizer_G, self.optimizer_D_1, self.optimizer_D_2, self.optimizer_D_3]
         self._loss_buf = torch.zeros(32, dtype=torch.float32, device=self.device)
         self._bufs = {}
+        self._in = {}
+        self._graphs = None
+        self._eager_steps = 0
+        self.use_graph = _os_environ_graph()
         self.grad_sync = ddp.GradSync() if self.isTrain else None
         import os as _os
         self.concurrent_d = _os.environ.get('HV_CONCURRENT_D', '1') != '0'
@@ -82,20 +92,29 @@ class Pix2PixModel(BaseModel):
 
     # ---------------------------------------------------------------- inputs
     def set_input(self, input):
+        """Unpack a batch dict (reference models/pix2pix_model.py:137-175).  The tensors land in persistent device buffers
+        (one set per batch shape): the captured step graph reads its inputs from fixed addresses."""
         AtoB = self.opt.direction == 'AtoB'
-        dev = self.device
-        f32 = lambda t: t.to(dev, non_blocking=True).float().contiguous()
-        self.real_B = f32(input['B' if AtoB else 'A'])
-        self.real_B_mask = f32(input['A_mask'])
-        self.real_A = f32(input['A' if AtoB else 'B'])
-        self.CAM = f32(input['CAM'])
-        self.normal_vert = f32(input['normal_vert'])
-        self.mask = f32(input['mask'])
-        self.height = input['height'].to(dev).long().contiguous()
-        self.slice_ratio = input['slice_ratio'].to(dev).double().contiguous()
-        self.x1 = input['x1'].to(dev).long().contiguous()
-        self.x2 = input['x2'].to(dev).long().contiguous()
-        self.maxheight = input['h2'].to(dev).long().contiguous()
+
+        def put(name, t, dtype):
+            b = self._in.get(name)
+            if b is None or b.shape != t.shape or b.dtype != dtype:
+                b = torch.empty(t.shape, dtype=dtype, device=self.device)
+                self._in[name] = b
+                self._graphs = None        # input addresses changed: captured graphs are stale
+            b.copy_(t, non_blocking=True)
+            return b
+        self.real_B = put('real_B', input['B' if AtoB else 'A'], torch.float32)
+        self.real_B_mask = put('real_B_mask', input['A_mask'], torch.float32)
+        self.real_A = put('real_A', input['A' if AtoB else 'B'], torch.float32)
+        self.CAM = put('CAM', input['CAM'], torch.float32)
+        self.normal_vert = put('normal_vert', input['normal_vert'], torch.float32)
+        self.mask = put('mask', input['mask'], torch.float32)
+        self.height = put('height', input['height'], torch.int64)
+        self.slice_ratio = put('slice_ratio', input['slice_ratio'], torch.float64)
+        self.x1 = put('x1', input['x1'], torch.int64)
+        self.x2 = put('x2', input['x2'], torch.int64)
+        self.maxheight = put('maxheight', input['h2'], torch.int64)
         self.image_paths = input['A_paths' if AtoB else 'B_paths']
 
     def _buf(self, name, like=None, shape=None, dtype=torch.float32):
@@ -172,7 +191,6 @@ class Pix2PixModel(BaseModel):
         net.finish()
         setattr(self, 'loss_D_fake_%d' % k, lf)
         setattr(self, 'loss_D_real_%d' % k, lr)
-        self.grad_sync.reduce(net.paramset().flat_grad)
 
     def backward_D_1(self):
         self._backward_D(1, self.fake_B, self.real_B)
@@ -236,36 +254,97 @@ class Pix2PixModel(BaseModel):
                self.half_band, 0, stream())
         L.call('hv_shrm_backward', ptr(seeds['d_fake_B_coarse']), None, None, ptr(self._rows), 1, ptr(d_x1), B, H, W, self.half_band, 0, stream())
         self.netG.run_backward(self._gplan, seeds['d_coarse_seg'], seeds['d_fine_seg'], d_x1, d_x2, dp1, dp2)
-        self.grad_sync.reduce(self.netG.paramset().flat_grad)
 
-    def optimize_parameters(self):
-        """forward; D_1, D_2, D_3 updates; G update (reference :356-382).  The three discriminator updates are independent
-        of each other, so each runs on its own HIP stream (kernels of different discriminators overlap on the 256 CUs);
-        D_k's forward on the fakes for the generator loss follows its own update on the same stream."""
+    # ---------------------------------------------------------------- the step, in three device-only phases
+    def _phase_a(self):
+        """forward; D_1, D_2, D_3 forward/backward (reference :356-370 up to the optimiser steps).  The three discriminator
+        updates are independent of each other, so each runs on its own HIP stream (kernels of different discriminators
+        overlap on the 256 CUs)."""
         self.forward()
         main = torch.cuda.current_stream(self.device)
         if getattr(self, '_d_streams', None) is None:
             self._d_streams = [torch.cuda.Stream(device=self.device) for _ in range(3)]
-            self._fork = torch.cuda.Event()
-        self._fork.record(main)
+            engine.NO_FORK_STREAMS.update(st.cuda_stream for st in self._d_streams)
         self._dxs = {}
         for k, bw in ((1, self.backward_D_1), (2, self.backward_D_2), (3, self.backward_D_3)):
             side = self._d_streams[k - 1] if self.concurrent_d else main
             if side is not main:
-                side.wait_event(self._fork)
+                side.wait_stream(main)
             with torch.cuda.stream(side):
                 self.set_requires_grad(getattr(self, 'netD_%d' % k), True)
-                opt = getattr(self, 'optimizer_D_%d' % k)
-                opt.zero_grad()
+                getattr(self, 'optimizer_D_%d' % k).zero_grad()
                 bw()
-                self.grad_sync.wait()
-                opt.step()
+        self._join_d(main)
+
+    def _phase_b(self):
+        """D_k optimiser step, D_k forward on the fakes with the updated weights (its own stream), generator losses and
+        backward (reference :370-382 up to optimizer_G.step)."""
+        main = torch.cuda.current_stream(self.device)
+        for k in (1, 2, 3):
+            side = self._d_streams[k - 1] if self.concurrent_d else main
+            if side is not main:
+                side.wait_stream(main)
+            with torch.cuda.stream(side):
+                getattr(self, 'optimizer_D_%d' % k).step(sync_lr=False)
                 self._g_step_D(k)
-        for side in self._d_streams:
-            if self.concurrent_d:
-                main.wait_stream(side)
+        self._join_d(main)
         self.set_requires_grad([self.netD_1, self.netD_2, self.netD_3], False)
         self.optimizer_G.zero_grad()
         self.backward_G(d_done=True)
+
+    def _phase_c(self):
+        self.optimizer_G.step(sync_lr=False)
+
+    def _join_d(self, main):
+        if self.concurrent_d:
+            for side in self._d_streams:
+                main.wait_stream(side)
+
+    def _reduce(self, nets):
+        """Average the gradients of `nets` across ranks (RCCL, eager -- never inside a captured graph)."""
+        for n in nets:
+            self.grad_sync.reduce(n.paramset().flat_grad)
         self.grad_sync.wait()
-        self.optimizer_G.step()
+
+    GRAPH_WARMUP = 2     # eager steps before capture (lazy allocations, stream creation, weight tables)
+
+    def optimize_parameters(self):
+        """forward; D_1, D_2, D_3 updates; G update (reference :356-382).
+
+        The step is device-only (no host reads, learning rate and Adam step count live on the device), so after
+        GRAPH_WARMUP eager steps its three phases are captured once as hipGraphs and replayed: ~650 kernel launches per
+        step become three graph launches, which removes the host launch latency that otherwise leaves the GPU idle
+        between the short kernels of the backward passes.  The gradient all-reduces of a multi-GPU job run between
+        the graphs.  HV_GRAPH=0 or an active kernel timer keeps the eager path."""
+        for o in self.optimizers:
+            o.sync_lr()
+        graphable = self.use_graph and ops.timer() is None
+        if graphable and self._graphs is None and self._eager_steps >= self.GRAPH_WARMUP:
+            self._capture()
+        if graphable and self._graphs is not None:
+            ga, gb, gc = self._graphs
+            ga.replay()
+            self._reduce([self.netD_1, self.netD_2, self.netD_3])
+            gb.replay()
+            self._reduce([self.netG])
+            gc.replay()
+            return
+        self._phase_a()
+        self._reduce([self.netD_1, self.netD_2, self.netD_3])
+        self._phase_b()
+        self._reduce([self.netG])
+        self._phase_c()
+        self._eager_steps += 1
+
+    def _capture(self):
+        if getattr(self, '_capture_stream', None) is None:
+            self._capture_stream = torch.cuda.Stream(device=self.device)
+        torch.cuda.synchronize(self.device)
+        graphs, pool = [], None
+        for phase in (self._phase_a, self._phase_b, self._phase_c):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool, stream=self._capture_stream):
+                phase()
+            pool = g.pool()
+            graphs.append(g)
+        self._graphs = tuple(graphs)

@@ -18,6 +18,11 @@ _PRECISION = {'fp32': F32, 'f32': F32, 'fp16': F16, 'f16': F16}
 _TIMER = None
 
 
+def timer():
+    """The active per-launch kernel timer (profiler.KernelTimer) or None."""
+    return _TIMER
+
+
 def set_timer(t):
     """bench.py's live kernel timer (profiler.KernelTimer) or None."""
     global _TIMER

@@ -28,9 +28,9 @@ class FusedAdam(torch.optim.Optimizer):
             n = sum(p.numel() for p in ps)
             self._m = torch.zeros(n, dtype=torch.float32, device=dev)
             self._v = torch.zeros(n, dtype=torch.float32, device=dev)
-            self._step = torch.zeros(1, dtype=torch.float32, device=dev)
-            self._lr = torch.zeros(1, dtype=torch.float32, device=dev)
-            self._lr_host = None
+            if self._lr is None or self._lr.device != dev:
+                self._lr = None
+                self.sync_lr()
         if key != self._table.key:
             rows, off = [], 0
             for p in ps:
@@ -44,6 +44,11 @@ class FusedAdam(torch.optim.Optimizer):
     def sync_lr(self):
         """Copy the scheduler's learning rate to the device scalar the kernel reads (outside any graph capture)."""
         lr = float(self.param_groups[0]['lr'])
+        if self._lr is None:
+            dev = self.param_groups[0]['params'][0].device
+            self._step = torch.zeros(1, dtype=torch.float32, device=dev)
+            self._lr = torch.zeros(1, dtype=torch.float32, device=dev)
+            self._lr_host = None
         if lr != self._lr_host:
             self._lr.fill_(lr)
             self._lr_host = lr
