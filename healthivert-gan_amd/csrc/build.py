@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 ROOT = os.path.dirname(PKG)
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-SOURCES = ['conv_igemm.hip', 'conv_halo.hip', 'wgrad_halo.hip', 'conv_narrow.hip','prep.hip', 'norm.hip', 'pointwise.hip', 'attention.hip']
+SOURCES = ['conv_igemm.hip', 'conv_halo.hip', 'conv_halo2.hip', 'wgrad_halo.hip', 'conv_narrow.hip', 'prep.hip', 'norm.hip', 'pointwise.hip', 'attention.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wno-unused-result']
 OUT = os.path.join(PKG, 'libhvgan.so')
 
@@ -29,7 +29,7 @@ def _newer(src, dst, deps):
 def build(force=False, verbose=True):
     objdir = os.path.join(HERE, 'build')
     os.makedirs(objdir, exist_ok=True)
-    deps = [os.path.join(HERE, 'hv_common.h'), os.path.join(ROOT, 'include', 'hvgan.h')]
+    deps = [os.path.join(HERE, 'hv_common.h'), os.path.join(HERE, 'conv_halo.h'), os.path.join(ROOT, 'include', 'hvgan.h')]
     jobs = []
     for s in SOURCES:
         src, obj = os.path.join(HERE, s), os.path.join(objdir, s.replace('.hip', '.o'))

@@ -11,39 +11,9 @@
 // Used for: dilation 1, Cin % 16 == 0, shared (not per-sample) filters, HV_F16 precision; conv and
 // the gather form of conv_transpose / data gradient (per output-parity class).  Everything else stays on
 // conv_igemm_kernel.
-#include "hv_common.h"
 #include <stdlib.h>
 
-typedef _Float16 f16x4v __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-#define HV_OOB 0x80000000u       // beyond every descriptor range (tensors are < 2 GiB): the load returns zeros
-
-struct HaloCls {
-    int ph, pw, Hc, Wc, ntaps, tiles_x, tiles, t0;   // t0 = first tile index of the class in the grid
-    int dh_min, dw_min, PH, PW;
-    uint32_t taps[16];   // (dh-dh_min) | (dw-dw_min)<<8 | widx<<16
-};
-struct HaloK {
-    const float* x; const _Float16* w; const float* bias; float* y;
-    int B, Hl, Wl, in_shift, Wp, img_stride, x_ld, x_coff, Cin;
-    int Cout, w_row, y_ld, y_coff, Ho, Wo;
-    int bstep, boff, ostep;
-    float alpha; int act, accumulate, vec_store, ncls;
-    unsigned x_bytes, w_bytes;   // buffer descriptor ranges
-    HaloCls cls[4];
-};
-
-template <int CK> struct HFrag;
-template <> struct HFrag<32> {
-    typedef f16x8 V;
-    static __device__ __forceinline__ V ld(const _Float16* p, int lane) { return *reinterpret_cast<const V*>(p + (lane >> 4) * 8); }
-    static __device__ __forceinline__ f32x4 mma(V a, V b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
-};
-template <> struct HFrag<16> {
-    typedef f16x4v V;
-    static __device__ __forceinline__ V ld(const _Float16* p, int lane) { return *reinterpret_cast<const V*>(p + (lane >> 4) * 4); }
-    static __device__ __forceinline__ f32x4 mma(V a, V b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0); }
-};
+#include "conv_halo.h"
 
 template <int TH, int TW, int BN, int WM, int WN, int TG, int CK, int PMAX>
 __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloK p) {
@@ -389,6 +359,11 @@ int hv_conv2d_halo(const hv_conv_desc* d, const void* w_f16, hipStream_t s) {
         if (C.PH * C.PW > maxpatch) maxpatch = C.PH * C.PW;
     }
     const bool ck32 = (d->Cin & 31) == 0;
+    static const bool halo2 = !(getenv("HV_HALO2") && atoi(getenv("HV_HALO2")) == 0);   // A/B knob
+    if (halo2) {   // weights-in-registers form where an instantiation exists
+        const int rc = hv_halo2_launch(k, TW, d->KH, d->KW, maxpatch, s);
+        if (rc != HV_ERR_UNSUPPORTED) return rc;
+    }
     if (k.bstep == 2) return ck32 ? dispatch_halo_bn<8, 16, 32, true>(k, maxpatch, s) : dispatch_halo_bn<8, 16, 16, true>(k, maxpatch, s);
     if (small_tile) return ck32 ? dispatch_halo_bn<8, 16, 32, false>(k, maxpatch, s) : dispatch_halo_bn<8, 16, 16, false>(k, maxpatch, s);
     return ck32 ? dispatch_halo_bn<8, 32, 32, false>(k, maxpatch, s) : dispatch_halo_bn<8, 32, 16, false>(k, maxpatch, s);

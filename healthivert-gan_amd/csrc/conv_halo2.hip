@@ -1,0 +1,269 @@
+// Halo-tiled implicit-GEMM convolution, second form: weights go straight from L2 into MFMA operand registers.
+//
+// conv_halo_kernel (conv_halo.hip) streams the filter taps through a double-buffered LDS tile: one barrier and one
+// LDS round trip per TG taps, ~50 KB of LDS that caps a CU at two workgroups.  The layers of this model are short
+// (tens of microseconds), so those barriers and the low occupancy cost more than the MFMAs.  Here
+//   * the input patch is the only thing in LDS (fp16 [patch pixel][CK channels], double-buffered over channel chunks):
+//     ONE barrier per 32-channel chunk;
+//   * every wave owns BN/WN output channels and fetches their filter rows itself: lane (row = lane & 15, k-group =
+//     lane >> 4) loads the 16 B of  w[cout0 + row][tap][c0 + 8*kgroup ..]  it needs as MFMA A-operand, a ring of D
+//     taps ahead of the MFMAs (weights are L2-resident; the ring index is static because the tap count is a template
+//     parameter and D divides it);
+//   * staging is branch-free: offsets are computed once, taps / chunks enter as scalar buffer offsets, out-of-image
+//     and out-of-range lanes carry an offset beyond the descriptor's range (the load returns zeros).
+// Shapes: the same as conv_halo_kernel with a uniform tap count of 4 (4x4 stride-2 data gradient classes), 9 (3x3) or
+// 16 (4x4); everything else stays on conv_halo_kernel.
+#include <stdlib.h>
+
+#include "conv_halo.h"
+
+template <int CK> struct WLoad;
+template <> struct WLoad<32> {
+    static __device__ __forceinline__ f16x8 ld(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+        return __builtin_bit_cast(f16x8, v);
+    }
+};
+template <> struct WLoad<16> {
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ f16x4v ld(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+        return __builtin_bit_cast(f16x4v, v);
+    }
+};
+
+// SPAN = filter extent in input pixels of one class (2: stride-2 data-gradient class of a 4x4 filter, 3, 4)
+// CK = channels per staged chunk: 16 (one 16x16x16 MFMA step), 32 (one 16x16x32 step) or 64 (two steps: a lane's two
+// 16-B weight loads then consume a whole 128-B line of its filter row, and barriers halve)
+template <int TH, int TW, int BN, int WM, int WN, int CK, int BSTEP, int SPAN, int D>
+__global__ __launch_bounds__(256) void conv_halo2_kernel(const HaloK p) {
+    constexpr int NTAPS = SPAN * SPAN;
+    constexpr int BM = TH * TW;
+    constexpr int FK = CK == 16 ? 16 : 32;                          // channels per MFMA step
+    constexpr int KS = CK / FK;                                     // MFMA steps per chunk
+    // patch row stride (halfs): 96 B (CK 32) and 160 B (CK 64) rows are conflict-free for unit-step b128 reads; 80 B for stride 2
+    constexpr int LDP = CK + ((CK >= 32 && BSTEP == 1) ? 16 : 8);
+    constexpr int MT = BM / WM / 16, NT = BN / WN / 16, GX = TW / 16;
+    constexpr int PHM = (TH - 1) * BSTEP + SPAN, PWM = (TW - 1) * BSTEP + SPAN;   // patch extent
+    constexpr int PV = CK / 4;                                                    // float4 loads per patch pixel and chunk
+    constexpr int PMAX = (PHM * PWM * PV + 255) / 256;
+    static_assert(WM * WN == 4 && MT >= 1 && NT >= 1 && TW % 16 == 0 && NTAPS % D == 0, "bad tile");
+    typedef typename HFrag<FK>::V V;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    _Float16* patch = reinterpret_cast<_Float16*>(smem);                          // [2][PHM*PWM][LDP]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int ci = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (i < p.ncls && (int)blockIdx.x >= p.cls[i].t0) ci = i;
+    const HaloCls& C = p.cls[ci];
+    const int PW = C.PW, npatch = C.PH * C.PW;
+    int t = (int)blockIdx.x - C.t0;
+    const int n_img = t / C.tiles;
+    t -= n_img * C.tiles;
+    const int tile_y = t / C.tiles_x, tile_x = t - tile_y * C.tiles_x;
+    const int i0 = tile_y * TH, j0 = tile_x * TW;
+    const int n_base = blockIdx.y * BN;
+    const int h0 = i0 * p.bstep + p.boff + C.dh_min, w0 = j0 * p.bstep + p.boff + C.dw_min;
+    const int wm = wave / WN, wn = wave % WN;
+
+    // scalar tap table: LDS offset of the tap inside the patch, filter index
+    int toff[NTAPS], widx[NTAPS];
+#pragma unroll
+    for (int q = 0; q < NTAPS; ++q) {
+        const uint32_t e = C.taps[q];
+        toff[q] = ((int)(e & 0xff) * PW + (int)((e >> 8) & 0xff)) * LDP;
+        widx[q] = (int)(e >> 16);
+    }
+    int poff[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int g = wm * MT + m, ty = g / GX, tx = (g % GX) * 16 + (lane & 15);
+        poff[m] = (ty * BSTEP * PW + tx * BSTEP) * LDP;
+    }
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.w), 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+    unsigned wvo[NT];            // byte offset of this lane's filter row / k-group, without tap and chunk
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int row = n_base + wn * (BN / WN) + n * 16 + (lane & 15);
+        wvo[n] = row < p.Cout ? (unsigned)((row * p.w_row + (lane >> 4) * (FK / 4)) * 2) : HV_OOB;
+    }
+    u32x4 preg[PMAX];
+    unsigned pvo[PMAX];          // byte offset of (patch pixel, channel quad) in x, HV_OOB outside the image / patch
+    int plo[PMAX];               // LDS offset (halfs), -1 = no element
+    const unsigned xbase = (unsigned)(n_img * p.img_stride + p.x_coff) * 4u;
+#pragma unroll
+    for (int i = 0; i < PMAX; ++i) {
+        const int e = tid + i * 256;
+        const int c4 = e % PV, pix = e / PV;
+        const int py = pix / PW, px = pix - py * PW;
+        const int hi = h0 + py, wi = w0 + px;
+        const bool in = e < npatch * PV;
+        plo[i] = in ? pix * LDP + c4 * 4 : -1;
+        pvo[i] = (in && (unsigned)hi < (unsigned)p.Hl && (unsigned)wi < (unsigned)p.Wl)
+                     ? xbase + (unsigned)(((hi >> p.in_shift) * p.Wp + (wi >> p.in_shift)) * p.x_ld + c4 * 4) * 4u : HV_OOB;
+    }
+    auto ppref = [&](int c0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < PMAX; ++i) preg[i] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, pvo[i], c0 * 4, 0);
+    };
+    auto pflush = [&](_Float16* dst) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < PMAX; ++i) {
+            if (plo[i] < 0) continue;
+            f16x4v h = {(_Float16)__uint_as_float(preg[i].x), (_Float16)__uint_as_float(preg[i].y),
+                        (_Float16)__uint_as_float(preg[i].z), (_Float16)__uint_as_float(preg[i].w)};
+            *reinterpret_cast<f16x4v*>(dst + plo[i]) = h;
+        }
+    };
+
+    const int nchunks = p.Cin / CK;
+    V wf[D][NT][KS];
+    ppref(0);
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) wf[j][n][ks] = WLoad<FK>::ld(wsrc, wvo[n], (widx[j] * p.Cin + ks * FK) * 2);
+    pflush(patch);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const _Float16* pb = patch + (c & 1) * (PHM * PWM * LDP);
+        if (c + 1 < nchunks) ppref((c + 1) * CK);     // next chunk's patch rides behind this chunk's MFMAs
+#pragma unroll
+        for (int q = 0; q < NTAPS; ++q) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                V xf[MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) xf[m] = HFrag<FK>::ld(pb + poff[m] + toff[q] + ks * FK, lane);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) acc[n][m] = HFrag<FK>::mma(wf[q % D][n][ks], xf[m], acc[n][m]);
+            }
+            // refill the ring slot with the tap D ahead (possibly the next chunk's)
+            const int qn = (q + D) % NTAPS;
+            const int cn = (q + D >= NTAPS) ? c + 1 : c;
+            if (cn < nchunks) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) wf[q % D][n][ks] = WLoad<FK>::ld(wsrc, wvo[n], (widx[qn] * p.Cin + cn * CK + ks * FK) * 2);
+            }
+        }
+        if (c + 1 < nchunks) pflush(patch + ((c + 1) & 1) * (PHM * PWM * LDP));
+        __syncthreads();
+    }
+
+    // ---- epilogue (same contract as conv_halo_kernel)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int g = wm * MT + m, ty = g / GX, tx = (g % GX) * 16 + (lane & 15);
+        const int i = i0 + ty, j = j0 + tx;
+        if (i >= C.Hc || j >= C.Wc) continue;
+        const int ho = C.ph + i * p.ostep, wo = C.pw + j * p.ostep;
+        float* yp = p.y + ((long long)(n_img * p.Ho + ho) * p.Wo + wo) * p.y_ld + p.y_coff;
+#pragma unroll
+        for (int nn = 0; nn < NT; ++nn) {
+            const int ch0 = n_base + wn * (BN / WN) + nn * 16 + (lane >> 4) * 4;
+            if (ch0 >= p.Cout) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float tv = acc[nn][m][r] * p.alpha;
+                const int ch = ch0 + r;
+                if (ch < p.Cout) {
+                    if (p.bias) tv += p.bias[ch];
+                    if (p.accumulate == 2) tv += yp[ch];
+                }
+                v[r] = hv_act(tv, p.act);
+            }
+            if (p.vec_store && ch0 + 3 < p.Cout) {
+                float4 o = make_float4(v[0], v[1], v[2], v[3]);
+                if (p.accumulate == 1) {
+                    const float4 old = *reinterpret_cast<const float4*>(yp + ch0);
+                    o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+                }
+                *reinterpret_cast<float4*>(yp + ch0) = o;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (ch0 + r < p.Cout) yp[ch0 + r] = p.accumulate == 1 ? yp[ch0 + r] + v[r] : v[r];
+            }
+        }
+    }
+}
+
+template <int TH, int TW, int BN, int WM, int WN, int CK, int BSTEP, int SPAN, int D>
+static int launch2(HaloK& k, hipStream_t s) {
+    constexpr int LDP = CK + ((CK >= 32 && BSTEP == 1) ? 16 : 8);
+    constexpr int PHM = (TH - 1) * BSTEP + SPAN, PWM = (TW - 1) * BSTEP + SPAN;
+    int tiles = 0;
+    for (int c = 0; c < k.ncls; ++c) {
+        HaloCls& C = k.cls[c];
+        if (C.PH > PHM || C.PW > PWM || C.ntaps != SPAN * SPAN) return HV_ERR_UNSUPPORTED;
+        C.tiles_x = hv_cdiv(C.Wc, TW);
+        C.tiles = C.tiles_x * hv_cdiv(C.Hc, TH);
+        C.t0 = tiles;
+        tiles += C.tiles * k.B;
+    }
+    const size_t lds = (size_t)2 * PHM * PWM * LDP * sizeof(_Float16);
+    auto kern = conv_halo2_kernel<TH, TW, BN, WM, WN, CK, BSTEP, SPAN, D>;
+    static bool raised = false;   // per instantiation: raise the dynamic-LDS cap once (not a stream operation)
+    if (lds > 48 * 1024 && !raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e != hipSuccess) return -1000 - (int)e;
+        raised = true;
+    }
+    dim3 grid(tiles, hv_cdiv(k.Cout, BN));
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, k);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+
+int hv_halo2_launch(HaloK& k, int TW, int KH, int KW, int maxpatch, hipStream_t s) {
+    (void)maxpatch;
+    if (k.Cin % 16) return HV_ERR_UNSUPPORTED;
+    int ntaps = k.cls[0].ntaps;
+    for (int c = 1; c < k.ncls; ++c)
+        if (k.cls[c].ntaps != ntaps) return HV_ERR_UNSUPPORTED;
+    // PatchGAN layers: 4x4 filters, Cout >= 128
+    if (ntaps == 16 && KH == 4 && KW == 4 && TW == 16 && k.Cout > 64 && k.bstep == 1 && k.Cin % 32 == 0) return launch2<8, 16, 128, 1, 4, 32, 1, 4, 4>(k, s);
+    // data gradient of the 4x4 stride-2 layers: four output-parity classes of 2x2 taps each
+    static const int m4 = getenv("HV_HALO2_S2T") ? atoi(getenv("HV_HALO2_S2T")) : 1;
+    if (m4 && ntaps == 4 && KH == 4 && KW == 4 && k.bstep == 1 && k.Cin % 32 == 0 && k.Cout > 32) {
+        if (TW == 32) return k.Cout <= 64 ? launch2<8, 32, 64, 1, 4, 32, 1, 2, 4>(k, s) : launch2<8, 32, 128, 1, 4, 32, 1, 2, 4>(k, s);
+        return k.Cout <= 64 ? launch2<8, 16, 64, 1, 4, 32, 1, 2, 4>(k, s) : launch2<8, 16, 128, 1, 4, 32, 1, 2, 4>(k, s);
+    }
+    // 3x3 layers of the generator.  Waves split the output channels (WN = 4) wherever a wave still gets 16 of them, so
+    // no two waves fetch the same filter rows.  HV_HALO2_MASK (bit per Cout class 16/32/64/128) is an A/B knob.
+    static const int mask = getenv("HV_HALO2_MASK") ? atoi(getenv("HV_HALO2_MASK")) : 15;
+    if (ntaps == 9 && KH == 3 && KW == 3 && k.bstep == 1) {
+        const bool ck32 = k.Cin % 32 == 0;
+        const int cls = k.Cout <= 16 ? 1 : k.Cout <= 32 ? 2 : k.Cout <= 64 ? 4 : 8;
+        if (!(mask & cls)) return HV_ERR_UNSUPPORTED;
+        if (TW == 32) {
+            if (cls == 1) return ck32 ? launch2<8, 32, 16, 4, 1, 32, 1, 3, 3>(k, s) : launch2<8, 32, 16, 4, 1, 16, 1, 3, 3>(k, s);
+            if (cls == 2) return ck32 ? launch2<8, 32, 32, 2, 2, 32, 1, 3, 3>(k, s) : launch2<8, 32, 32, 2, 2, 16, 1, 3, 3>(k, s);
+            if (!ck32) return HV_ERR_UNSUPPORTED;
+            if (cls == 4) return launch2<8, 32, 64, 1, 4, 32, 1, 3, 3>(k, s);
+            return launch2<8, 32, 128, 1, 4, 32, 1, 3, 3>(k, s);
+        }
+        if (!ck32) return HV_ERR_UNSUPPORTED;
+        if (cls == 1) return launch2<8, 16, 16, 4, 1, 32, 1, 3, 3>(k, s);
+        if (cls == 2) return launch2<8, 16, 32, 2, 2, 32, 1, 3, 3>(k, s);
+        if (cls == 4) return launch2<8, 16, 64, 1, 4, 32, 1, 3, 3>(k, s);
+        return launch2<8, 16, 128, 1, 4, 32, 1, 3, 3>(k, s);
+    }
+    return HV_ERR_UNSUPPORTED;
+}

@@ -114,6 +114,18 @@ HALO_CASES = [
     (2, 16, 16, 64, 32, 3, 1, 1, 'elu', 1),
     (16, 32, 32, 256, 512, 4, 1, 1, 'none', 0),
     (2, 30, 30, 48, 8, 3, 1, 1, 'sigmoid', 0),
+    # weights-in-registers form (conv_halo2.hip): every instantiation, forward and data gradient
+    (2, 32, 32, 32, 16, 3, 1, 1, 'elu', 0),
+    (2, 32, 32, 32, 32, 3, 1, 1, 'elu', 0),
+    (2, 32, 32, 64, 128, 3, 1, 1, 'none', 0),
+    (16, 128, 128, 16, 16, 3, 1, 1, 'elu', 0),
+    (16, 128, 128, 16, 32, 3, 1, 1, 'elu', 0),
+    (16, 128, 128, 32, 16, 3, 1, 1, 'elu', 0),
+    (16, 128, 128, 32, 32, 3, 1, 1, 'none', 0),
+    (16, 128, 128, 32, 64, 3, 1, 1, 'elu', 0),
+    (16, 128, 128, 32, 128, 3, 1, 1, 'none', 0),
+    (4, 64, 64, 128, 256, 4, 2, 1, 'lrelu', 0),
+    (16, 128, 128, 64, 128, 4, 2, 1, 'lrelu', 0),
 ]
 
 
