@@ -58,6 +58,7 @@ def main():
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--precision', default=os.environ.get('HV_PRECISION', 'fp16'), choices=['fp16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--serial', action='store_true', help='one HIP stream for the whole run (profiling: per-kernel durations without stream-level overlap)')
     ap.add_argument('--no-graph', action='store_true', help='launch kernels eagerly instead of replaying a captured hipGraph')
     args = ap.parse_args()
 
@@ -94,6 +95,9 @@ def main():
         torch.cuda.synchronize()
 
     step = model.optimize_parameters
+    from hvgan import engine
+    if args.serial:
+        engine.SERIAL = True
     if args.no_graph:
         model.use_graph = False
     # W untimed warm-up steps; the step graph is captured after the model's first eager steps, so a warm-up shorter than
@@ -102,23 +106,29 @@ def main():
         step()
     barrier()
     prof = profiler.KernelTimer()
+    serial0 = engine.SERIAL
+    engine.SERIAL = True              # per-kernel HIP-event timing: one stream, the kernel has the GPU to itself
     prof.enable()                     # untimed eager survey step: time every conv launch, pick the dominant kernel class
     step()
     dom = prof.dominant()
     prof.disable()
+    engine.SERIAL = serial0
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):       # the timed region: K steps (graph replays unless --no-graph)
         step()
     barrier()
     dt = time.perf_counter() - t0
-    # roofline leg: the same K steps once more, launched eagerly with HIP events around the dominant kernel's launches
-    # (a captured graph cannot carry timing events); rocprofv3 sees the kernels of both legs (profiles/)
+    # roofline leg: the same K steps once more, launched eagerly on ONE stream with HIP events around the dominant
+    # kernel's launches (a captured graph cannot carry timing events, and with other streams busy an event pair would
+    # also time the wait for free CUs); `bench.py --serial` under rocprofv3 gives the matching per-kernel averages
+    engine.SERIAL = True
     prof.enable(only=dom[0] if dom else None)
     for _ in range(args.steps):
         step()
     barrier()
     prof.disable()
+    engine.SERIAL = serial0
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -139,8 +149,16 @@ def main():
     }
     if rank == 0:
         out['roofline'] = prof.roofline(args.precision, MFMA_PEAK_TFLOPS[args.precision])
-        out['roofline']['timed_in'] = 'eager re-run of the K steps after the timed region (HIP events on the launch stream)'
-        out['config']['launch'] = 'hipGraph replay (3 graphs/step)' if model.use_graph else 'eager'
+        try:      # HBM bytes per launch from the committed PMC passes (profiles/r01_traffic.json), when this kernel was measured
+            tr = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_traffic.json')))['kernels']
+            ent = tr.get(out['roofline']['kernel'])
+            if ent:
+                out['roofline']['traffic'] = ent['traffic_bytes']
+                out['roofline']['traffic_source'] = 'profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)'
+        except (OSError, ValueError, KeyError):
+            pass
+        out['roofline']['timed_in'] = 'eager single-stream re-run of the K steps after the timed region (HIP events on the launch stream)'
+        out['config']['launch'] = ('hipGraph replay (3 graphs/step)' if model.use_graph else 'eager') + (', one stream' if args.serial else ', 4 streams')
         out['losses'] = {k: round(v, 4) for k, v in model.get_current_losses().items()}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(model, args.batch, args.size, 1234)

@@ -257,6 +257,7 @@ static int launch_halo(const HaloK& k, int tiles, int maxpatch, hipStream_t s) {
         lds_limit = 150 * 1024;
     }
     dim3 grid(tiles, hv_cdiv(k.Cout, BN));
+    hv_path_note = 2;
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, k);
     HV_LAUNCH_CHECK();
     return HV_OK;

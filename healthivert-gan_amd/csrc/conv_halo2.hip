@@ -226,6 +226,7 @@ static int launch2(HaloK& k, hipStream_t s) {
         raised = true;
     }
     dim3 grid(tiles, hv_cdiv(k.Cout, BN));
+    hv_path_note = 3;
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, k);
     HV_LAUNCH_CHECK();
     return HV_OK;

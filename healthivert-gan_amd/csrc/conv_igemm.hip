@@ -18,6 +18,9 @@
 #define HV_MAX_TAPS 25
 #define HV_BK 32
 
+thread_local int hv_path_note = 0;
+extern "C" int hv_last_kernel_path(void) { return hv_path_note; }
+
 int hv_conv2d_halo(const hv_conv_desc* d, const void* w_f16, hipStream_t s);   // conv_halo.hip
 size_t hv_wgrad_halo_workspace_bytes(const hv_wgrad_desc* d);                  // wgrad_halo.hip
 int hv_wgrad_halo(const hv_wgrad_desc* d, int* nslabs, hipStream_t s);
@@ -414,6 +417,7 @@ extern "C" int hv_conv2d(const hv_conv_desc* d, void* stream) {
     const bool vec_in = (d->Cin & 3) == 0 && (d->x_ld & 3) == 0 && (d->x_coff & 3) == 0 && ((uintptr_t)d->x & 15) == 0 &&
                         ((uintptr_t)d->w & 15) == 0 && (d->w_bstride & 3) == 0;
     hipStream_t s = (hipStream_t)stream;
+    hv_path_note = 0;
     if (d->precision == HV_F32) return vec_in ? dispatch_conv<float, false>(k, s) : dispatch_conv<float, true>(k, s);
     return vec_in ? dispatch_conv<_Float16, false>(k, s) : dispatch_conv<_Float16, true>(k, s);
 }
@@ -768,6 +772,7 @@ extern "C" int hv_conv2d_wgrad(const hv_wgrad_desc* d, void* stream) {
     if (!direct) {
         if (!d->workspace || d->workspace_bytes < (size_t)pl.splits * nW * sizeof(float)) return HV_ERR_WORKSPACE;
     }
+    hv_path_note = 10;
     WgradK k;
     k.x = d->x; k.g = d->g; k.out = direct ? d->dw : d->workspace;
     k.B = d->B; k.Hl = d->H; k.Wl = d->W; k.in_shift = d->in_shift; k.Wp = d->W >> d->in_shift;

@@ -84,6 +84,7 @@ int hv_conv2d_narrow(const hv_conv_desc* d, hipStream_t s) {
         const int lpp = c4 >= 64 ? 64 : c4 >= 16 ? 16 : c4 >= 4 ? 4 : 1;
         long long nb = (npix + 256 / lpp - 1) / (256 / lpp);
         if (nb > 65536) nb = 65536;
+        hv_path_note = 1;
         if (lpp == 64) hipLaunchKernelGGL((narrow_fwd_kernel<64>), dim3((int)nb), dim3(256), 0, s, k);
         else if (lpp == 16) hipLaunchKernelGGL((narrow_fwd_kernel<16>), dim3((int)nb), dim3(256), 0, s, k);
         else if (lpp == 4) hipLaunchKernelGGL((narrow_fwd_kernel<4>), dim3((int)nb), dim3(256), 0, s, k);

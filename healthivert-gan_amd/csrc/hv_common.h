@@ -14,6 +14,8 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
         if (e__ != hipSuccess) return -1000 - (int)e__;     \
     } while (0)
 
+extern thread_local int hv_path_note;   // set by the launcher that actually launched (hv_last_kernel_path)
+
 static inline int hv_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 __device__ __forceinline__ float hv_act(float v, int act) {

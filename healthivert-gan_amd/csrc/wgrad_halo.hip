@@ -195,6 +195,7 @@ static int launch_wh(const WHaloK& k, const WHaloPlan& pl, const hv_wgrad_desc* 
         lds_limit = 150 * 1024;
     }
     dim3 grid(pl.gx, hv_cdiv(d->Cout, BN), hv_cdiv(d->Cin, BC));
+    hv_path_note = 11;
     hipLaunchKernelGGL(kern, grid, dim3(256), pl.lds, s, k);
     HV_LAUNCH_CHECK();
     return HV_OK;

@@ -150,6 +150,7 @@ class ConvNode:
 # the train step (three chains already run concurrently there, and a fork nested inside a forked stream crashes
 # hipStreamEndCapture on ROCm 7.2 when the step is captured as a graph)
 NO_FORK_STREAMS = set()
+SERIAL = False            # True: no side streams at all (per-kernel timing with HIP events needs the GPU to itself)
 
 
 class GradBook:
@@ -162,7 +163,7 @@ class GradBook:
         self.overlap = os.environ.get('HV_OVERLAP_WGRAD', '1') != '0'
 
     def can_fork(self):
-        return self.overlap and torch.cuda.current_stream().cuda_stream not in NO_FORK_STREAMS
+        return self.overlap and not SERIAL and torch.cuda.current_stream().cuda_stream not in NO_FORK_STREAMS
 
     def fork(self):
         """Side stream, ordered after everything queued so far on the current stream."""

@@ -267,7 +267,7 @@ class Pix2PixModel(BaseModel):
             engine.NO_FORK_STREAMS.update(st.cuda_stream for st in self._d_streams)
         self._dxs = {}
         for k, bw in ((1, self.backward_D_1), (2, self.backward_D_2), (3, self.backward_D_3)):
-            side = self._d_streams[k - 1] if self.concurrent_d else main
+            side = self._d_streams[k - 1] if (self.concurrent_d and not engine.SERIAL) else main
             if side is not main:
                 side.wait_stream(main)
             with torch.cuda.stream(side):
@@ -281,7 +281,7 @@ class Pix2PixModel(BaseModel):
         backward (reference :370-382 up to optimizer_G.step)."""
         main = torch.cuda.current_stream(self.device)
         for k in (1, 2, 3):
-            side = self._d_streams[k - 1] if self.concurrent_d else main
+            side = self._d_streams[k - 1] if (self.concurrent_d and not engine.SERIAL) else main
             if side is not main:
                 side.wait_stream(main)
             with torch.cuda.stream(side):
@@ -296,7 +296,7 @@ class Pix2PixModel(BaseModel):
         self.optimizer_G.step(sync_lr=False)
 
     def _join_d(self, main):
-        if self.concurrent_d:
+        if self.concurrent_d and not engine.SERIAL:
             for side in self._d_streams:
                 main.wait_stream(side)
 

@@ -7,12 +7,14 @@ for the transposed/data-gradient form).
 """
 import torch
 
+from . import lib as _lib
 from . import ops
 
 
 class KernelTimer:
     def __init__(self):
         self.records = []
+        self.paths = {}
         self.only = None
         self.active = False
 
@@ -24,6 +26,7 @@ class KernelTimer:
         s.record()
         r = launch()
         e.record()
+        self.paths[key] = _lib.get().cdll.hv_last_kernel_path()   # which kernel family the C side dispatched to
         self.records.append((key, flops, s, e))
         return r
 
@@ -57,12 +60,16 @@ class KernelTimer:
         key, (ms, n, flops) = d
         avg_ms = ms / n
         achieved = flops / (avg_ms * 1e-3) / 1e12
-        return {'bound': 'mfma', 'kernel': describe(key), 'achieved': round(achieved, 2), 'peak': peak_tflops, 'unit': 'TFLOP/s',
+        return {'bound': 'mfma', 'kernel': describe(key, self.paths.get(key)), 'achieved': round(achieved, 2), 'peak': peak_tflops, 'unit': 'TFLOP/s',
                 'frac': round(achieved / peak_tflops, 4), 'traffic': None, 'launches': n, 'avg_us': round(avg_ms * 1e3, 2),
                 'gflop_per_launch': round(flops / 1e9, 3)}
 
 
-def describe(key):
+KERNEL_NAMES = {0: 'conv_igemm_kernel', 1: 'narrow_fwd_kernel', 2: 'conv_halo_kernel', 3: 'conv_halo2_kernel', 10: 'wgrad_kernel',
+                11: 'wgrad_halo_kernel'}
+
+
+def describe(key, path=None):
     kind, B, H, W, cin, cout, k, s, d, tr = key
-    name = {'conv': 'conv_igemm_kernel', 'wgrad': 'wgrad_kernel'}[kind]
+    name = KERNEL_NAMES.get(path, {'conv': 'conv_igemm_kernel', 'wgrad': 'wgrad_kernel'}[kind])
     return '%s %s B%d %dx%d Cin%d->Cout%d k%d s%d d%d' % (name, 'transposed' if tr else 'forward', B, H, W, cin, cout, k, s, d)

@@ -5,11 +5,13 @@ import torch
 import bench
 os.environ['HV_PRECISION'] = sys.argv[1] if len(sys.argv) > 1 else 'fp16'
 import hvgan
-from hvgan import synth, profiler
+from hvgan import synth, profiler, engine
+engine.SERIAL = True      # one stream: HIP events then time the kernel, not the wait for free CUs
 from hvgan.models.pix2pix_model import Pix2PixModel
 torch.manual_seed(1234)
 opt = bench.make_opt(os.environ['HV_PRECISION'])
 model = Pix2PixModel(opt); model.setup(opt)
+model.use_graph = False
 model.set_input(synth.make_batch(16, 256, seed=1234))
 for _ in range(2):
     model.optimize_parameters()
@@ -20,7 +22,7 @@ agg = prof.summary(); prof.disable()
 tot = sum(v[0] for v in agg.values())
 print('conv+wgrad total ms', round(tot, 3))
 for key, (ms, n, fl) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:28]:
-    print('%7.3f ms  n=%2d  avg %7.1f us  %6.1f TF  %s' % (ms, n, ms / n * 1e3, fl / (ms / n * 1e-3) / 1e12, profiler.describe(key)))
+    print('%7.3f ms  n=%2d  avg %7.1f us  %6.1f TF  %s' % (ms, n, ms / n * 1e3, fl / (ms / n * 1e-3) / 1e12, profiler.describe(key, prof.paths.get(key))))
 kinds = {}
 for key, (ms, n, fl) in agg.items():
     k = key[0] + ('_T' if key[-1] else '')
@@ -29,8 +31,8 @@ print('by kind', {k: round(v, 2) for k, v in kinds.items()})
 print('--- all wgrad')
 for key, (ms, n, fl) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
     if key[0] == 'wgrad':
-        print('%7.3f ms  n=%2d  avg %7.1f us  %6.1f TF  %s' % (ms, n, ms / n * 1e3, fl / (ms / n * 1e-3) / 1e12, profiler.describe(key)))
+        print('%7.3f ms  n=%2d  avg %7.1f us  %6.1f TF  %s' % (ms, n, ms / n * 1e3, fl / (ms / n * 1e-3) / 1e12, profiler.describe(key, prof.paths.get(key))))
 print('--- all conv')
 for key, (ms, n, fl) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
     if key[0] == 'conv':
-        print('%7.3f ms  n=%2d  avg %7.1f us  %6.1f TF  %s' % (ms, n, ms / n * 1e3, fl / (ms / n * 1e-3) / 1e12, profiler.describe(key)))
+        print('%7.3f ms  n=%2d  avg %7.1f us  %6.1f TF  %s' % (ms, n, ms / n * 1e3, fl / (ms / n * 1e-3) / 1e12, profiler.describe(key, prof.paths.get(key))))
