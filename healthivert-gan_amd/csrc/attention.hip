@@ -144,8 +144,58 @@ __global__ void ca_fuse_kernel(const float* __restrict__ S, float* __restrict__ 
         out[i] = acc;
     }
 }
+// the same for h, w powers of two (the 32 x 32 attention map): all index arithmetic is shifts and masks, 32-bit inside a sample
+template <bool ADJ>
+__global__ __launch_bounds__(256) void ca_fuse_p2_kernel(const float* __restrict__ S, float* __restrict__ out, int lh, int lw) {
+    const int h = 1 << lh, w = 1 << lw, L = h * w, lL = lh + lw;
+    const float* Sb = S + (long long)blockIdx.y * L * L;
+    float* ob = out + (long long)blockIdx.y * L * L;
+    auto tr = [&](int l) { return ((l & (w - 1)) << lh) + (l >> lw); };      // (lh,lw) -> lw*h+lh
+    auto itr = [&](int a) { return ((a & (h - 1)) << lw) + (a >> lh); };     // inverse
+    const int n = L * L;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int l = i & (L - 1), p = i >> lL;
+        float acc = 0.f;
+        if (!ADJ) {
+            const int tp = tr(p), tl = tr(l);
+#pragma unroll
+            for (int d = -1; d <= 1; ++d) {
+                const int a = tp + d, b = tl + d;
+                if ((unsigned)a >= (unsigned)L || (unsigned)b >= (unsigned)L) continue;
+                const int pa = itr(a), lb = itr(b);
+#pragma unroll
+                for (int e = -1; e <= 1; ++e) {
+                    const int pp = pa + e, ll = lb + e;
+                    if ((unsigned)pp < (unsigned)L && (unsigned)ll < (unsigned)L) acc += Sb[(pp << lL) + ll];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int e = -1; e <= 1; ++e) {
+                const int pe = p + e, le = l + e;
+                if ((unsigned)pe >= (unsigned)L || (unsigned)le >= (unsigned)L) continue;
+                const int tp = tr(pe), tl = tr(le);
+#pragma unroll
+                for (int d = -1; d <= 1; ++d) {
+                    const int a = tp + d, b = tl + d;
+                    if ((unsigned)a < (unsigned)L && (unsigned)b < (unsigned)L) acc += Sb[(itr(a) << lL) + itr(b)];
+                }
+            }
+        }
+        ob[i] = acc;
+    }
+}
+static bool at_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 extern "C" int hv_ca_fuse(const float* S, float* out, int B, int h, int w, int adjoint, void* stream) {
     if (!S || !out || S == out || B <= 0 || h <= 0 || w <= 0) return HV_ERR_ARG;
+    if (at_pow2(h) && at_pow2(w) && (long long)h * w <= 32768) {
+        const int lh = __builtin_ctz(h), lw = __builtin_ctz(w);
+        const dim3 grid(at_grid((long long)h * w * h * w, 4096), B);
+        if (adjoint) hipLaunchKernelGGL((ca_fuse_p2_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, S, out, lh, lw);
+        else hipLaunchKernelGGL((ca_fuse_p2_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, S, out, lh, lw);
+        HV_LAUNCH_CHECK();
+        return HV_OK;
+    }
     const long long L = (long long)h * w, n = (long long)B * L * L;
     hipLaunchKernelGGL(ca_fuse_kernel, dim3(at_grid(n, 65536)), dim3(256), 0, (hipStream_t)stream, S, out, h, w, adjoint, n);
     HV_LAUNCH_CHECK();
@@ -256,14 +306,37 @@ __global__ __launch_bounds__(256) void ca_gs_kernel(const float* __restrict__ dS
     }
 }
 // coef[b][l] = -(sum_p dS[p][l]*S0[p][l]) / norm[l]^2   (0 where the norm was clamped)
-__global__ void ca_coef_kernel(const float* __restrict__ dS, const float* __restrict__ S0, const float* __restrict__ norm, float* __restrict__ coef, int L) {
+// grid (L/64, B, CA_PCH): 64 columns x 4 row lanes per block, the rows split into CA_PCH chunks -> part[b][chunk][l];
+// a second tiny kernel folds the chunks in fixed order
+#define CA_PCH 16
+__global__ __launch_bounds__(256) void ca_coef_part_kernel(const float* __restrict__ dS, const float* __restrict__ S0, float* __restrict__ part, int L) {
+    __shared__ float sh[4][64];
+    const long long b = blockIdx.y;
+    const int lx = threadIdx.x & 63, pr = threadIdx.x >> 6;
+    const int l = blockIdx.x * 64 + lx;
+    const int rows = (L + CA_PCH - 1) / CA_PCH, p0 = blockIdx.z * rows, p1 = min(L, p0 + rows);
+    const float* D = dS + b * (long long)L * L;
+    const float* S = S0 + b * (long long)L * L;
+    float s0 = 0.f, s1 = 0.f;
+    if (l < L) {
+        int p = p0 + pr;
+        for (; p + 4 < p1; p += 8) {
+            s0 += D[(long long)p * L + l] * S[(long long)p * L + l];
+            s1 += D[(long long)(p + 4) * L + l] * S[(long long)(p + 4) * L + l];
+        }
+        for (; p < p1; p += 4) s0 += D[(long long)p * L + l] * S[(long long)p * L + l];
+    }
+    sh[pr][lx] = s0 + s1;
+    __syncthreads();
+    if (pr == 0 && l < L) part[(b * CA_PCH + blockIdx.z) * L + l] = (sh[0][lx] + sh[1][lx]) + (sh[2][lx] + sh[3][lx]);
+}
+__global__ void ca_coef_final_kernel(const float* __restrict__ part, const float* __restrict__ norm, float* __restrict__ coef, int L) {
     const long long b = blockIdx.y;
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= L) return;
-    const float* D = dS + b * (long long)L * L;
-    const float* S = S0 + b * (long long)L * L;
     float s = 0.f;
-    for (int p = 0; p < L; ++p) s += D[(long long)p * L + l] * S[(long long)p * L + l];
+#pragma unroll
+    for (int c = 0; c < CA_PCH; ++c) s += part[(b * CA_PCH + c) * L + l];
     const float nv = norm[b * L + l];
     coef[b * L + l] = nv > 1e-4f ? -s / (nv * nv) : 0.f;
 }
@@ -273,7 +346,11 @@ extern "C" int hv_ca_score_backward_prep(const float* dS, const float* S0, const
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(ca_gs_kernel, dim3(L / 32, L / 32, B), dim3(256), 0, s, dS, rnorm, Gs, L);
     HV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ca_coef_kernel, dim3(hv_cdiv(L, 128), B), dim3(128), 0, s, dS, S0, norm, coef, L);
+    // row-chunk partials live behind the result: coef holds B*L*(1 + 16) floats (include/hvgan.h)
+    float* part = coef + (long long)B * L;
+    hipLaunchKernelGGL(ca_coef_part_kernel, dim3(hv_cdiv(L, 64), B, CA_PCH), dim3(256), 0, s, dS, S0, part, L);
+    HV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ca_coef_final_kernel, dim3(hv_cdiv(L, 128), B), dim3(128), 0, s, part, norm, coef, L);
     HV_LAUNCH_CHECK();
     return HV_OK;
 }

@@ -7,15 +7,23 @@ static bool n_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 static bool n_vec_ok(int C) { return (C % 4 == 0) && n_pow2(C / 4) && C / 4 <= 256; }
 static bool n_shape_ok(int C) { return n_vec_ok(C) || (n_pow2(C) && C <= 256); }
 
-struct NormPlan { int G, R, nchunk, rpb, rstep; };
-static NormPlan norm_plan(int B, int HW, int C, int norm, int groups = 1) {
+struct NormPlan { int G, R, nchunk, rpb, rstep, CB, slices; };
+// Reduction grid: (row chunks) x (groups) x (channel slices).  A block covers CB = min(C/4, 32) channel quads (512 B of a
+// row) and 256/CB rows per iteration; chunks are sized for ~2048 blocks so that every CU has enough loads in flight to
+// stream from HBM, while the fp64 partials ([G][nchunk][2][C]) stay small against the activation.
+static NormPlan norm_plan(int B, int HW, int C, int norm, int groups = 1, bool vec = true) {
     NormPlan p;
     p.G = norm == HV_NORM_INSTANCE ? B : (groups > 0 ? groups : 1);
     p.R = norm == HV_NORM_INSTANCE ? HW : (B / p.G) * HW;
-    p.rstep = n_vec_ok(C) ? 256 / (C / 4) : 256 / C;
-    long long rpb = (long long)p.rstep * 32;
+    const int CV = vec ? C / 4 : C;                       // lanes per row
+    p.CB = vec ? (CV < 32 ? CV : 32) : CV;
+    p.slices = CV / p.CB;
+    p.rstep = 256 / p.CB;
+    long long cap = 2048 / ((long long)p.G * p.slices);
+    if (cap < 16) cap = 16;
+    if (cap > 512) cap = 512;
+    long long rpb = (long long)p.rstep * 8;              // at least 8 iterations per block
     long long nch = (p.R + rpb - 1) / rpb;
-    const long long cap = p.G > 1 ? 32 : 256;
     if (nch > cap) {
         rpb = (p.R + cap - 1) / cap;
         rpb = (rpb + p.rstep - 1) / p.rstep * p.rstep;
@@ -28,15 +36,20 @@ static NormPlan norm_plan(int B, int HW, int C, int norm, int groups = 1) {
 
 extern "C" size_t hv_norm_workspace_bytes(int B, int HW, int C) {
     if (B <= 0 || HW <= 0 || C <= 0 || !n_shape_ok(C)) return 0;
-    const NormPlan a = norm_plan(B, HW, C, HV_NORM_BATCH), b = norm_plan(B, HW, C, HV_NORM_INSTANCE);
-    const size_t pa = (size_t)a.G * a.nchunk, pb = (size_t)b.G * b.nchunk;
+    size_t pa = 0, pb = 0;
+    for (int vec = 0; vec < 2; ++vec) {
+        if (vec ? !n_vec_ok(C) : !(n_pow2(C) && C <= 256)) continue;
+        const NormPlan a = norm_plan(B, HW, C, HV_NORM_BATCH, 1, vec), b = norm_plan(B, HW, C, HV_NORM_INSTANCE, 1, vec);
+        if ((size_t)a.G * a.nchunk > pa) pa = (size_t)a.G * a.nchunk;
+        if ((size_t)b.G * b.nchunk > pb) pb = (size_t)b.G * b.nchunk;
+    }
     return (pa > pb ? pa : pb) * 2 * C * sizeof(double) + (size_t)B * 2 * C * sizeof(float) + 64;
 }
 
 struct NormK {
     const float* x; const float* y; const float* dy; float* out;
     int x_ld, x_coff, y_ld, y_coff, dy_ld, dy_coff, o_ld, o_coff;
-    int C, R, rpb, nchunk, act, post_sigmoid;
+    int C, R, rpb, nchunk, act, post_sigmoid, CB, lc;   // CB: lanes per row in the reduction; lc: log2(lanes per row) in the apply pass
     const float* stats; const float* gamma; const float* beta;
 };
 
@@ -59,73 +72,68 @@ __device__ __forceinline__ float norm_act_bwd(float y, int act, int post_sigmoid
 }
 
 // MODE 0: (sum x, sum x^2);  MODE 1: (sum g, sum g*xhat) with g = dy*act'(y), xhat = (x-mean)*rstd
+// grid (chunk, group, channel slice); V floats per lane; rows of the chunk strided by 256/CB, two rows in flight per lane
 template <int MODE, bool VEC>
 __global__ __launch_bounds__(256) void norm_reduce_kernel(const NormK k, double* __restrict__ part) {
-    __shared__ double sh[256 * 2 * (VEC ? 4 : 1)];
-    const int tid = threadIdx.x, g = blockIdx.y;
+    constexpr int V = VEC ? 4 : 1;
+    __shared__ double sh[256 * 2 * V];
+    const int tid = threadIdx.x, g = blockIdx.y, CB = k.CB;
     const long long r0 = (long long)g * k.R + (long long)blockIdx.x * k.rpb;
     const long long r1 = min((long long)(g + 1) * k.R, r0 + k.rpb);
     const int C = k.C;
     double* dst = part + ((long long)g * k.nchunk + blockIdx.x) * 2 * C;
-    if (VEC) {
-        const int C4 = C >> 2, cg = tid % C4, rp = tid / C4, rstep = 256 / C4;
-        double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
-        float mean[4], rstd[4];
-        if (MODE == 1) {
+    const int lane = tid % CB, rp = tid / CB, rstep = 256 / CB;
+    const int c0 = (blockIdx.z * CB + lane) * V;           // first channel of this lane
+    double a[V], b[V];
+    float mean[V], rstd[V];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { mean[e] = k.stats[(long long)g * 2 * C + cg * 4 + e]; rstd[e] = k.stats[(long long)g * 2 * C + C + cg * 4 + e]; }
-        }
-        for (long long r = r0 + rp; r < r1; r += rstep) {
-            const float4 xv = *reinterpret_cast<const float4*>(k.x + r * k.x_ld + k.x_coff + cg * 4);
-            const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
-            if (MODE == 0) {
+    for (int e = 0; e < V; ++e) {
+        a[e] = 0; b[e] = 0; mean[e] = 0.f; rstd[e] = 1.f;
+        if (MODE == 1) { mean[e] = k.stats[(long long)g * 2 * C + c0 + e]; rstd[e] = k.stats[(long long)g * 2 * C + C + c0 + e]; }
+    }
+    auto ldv = [&](const float* p, long long r, int ld, int coff, float (&o)[V]) __attribute__((always_inline)) {
+        if (VEC) { const float4 v = *reinterpret_cast<const float4*>(p + r * ld + coff + c0); o[0] = v.x; o[V > 1 ? 1 : 0] = v.y; o[V > 2 ? 2 : 0] = v.z; o[V > 3 ? 3 : 0] = v.w; }
+        else o[0] = p[r * ld + coff + c0];
+    };
+    auto acc1 = [&](const float (&xs)[V], const float (&ds)[V], const float (&ys)[V]) __attribute__((always_inline)) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { a[e] += xs[e]; b[e] += (double)xs[e] * xs[e]; }
-            } else {
-                const float4 dv = *reinterpret_cast<const float4*>(k.dy + r * k.dy_ld + k.dy_coff + cg * 4);
-                const float4 yv = *reinterpret_cast<const float4*>(k.y + r * k.y_ld + k.y_coff + cg * 4);
-                const float ds[4] = {dv.x, dv.y, dv.z, dv.w}, ys[4] = {yv.x, yv.y, yv.z, yv.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float gq = ds[e] * norm_act_bwd(ys[e], k.act, k.post_sigmoid);
-                    a[e] += gq;
-                    b[e] += (double)gq * ((xs[e] - mean[e]) * rstd[e]);
-                }
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { sh[(tid * 4 + e) * 2] = a[e]; sh[(tid * 4 + e) * 2 + 1] = b[e]; }
-        __syncthreads();
-        if (tid < C4) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                double sa = 0, sb = 0;
-                for (int t = tid; t < 256; t += C4) { sa += sh[(t * 4 + e) * 2]; sb += sh[(t * 4 + e) * 2 + 1]; }
-                dst[tid * 4 + e] = sa;
-                dst[C + tid * 4 + e] = sb;
-            }
-        }
-    } else {
-        const int c = tid % C, rp = tid / C, rstep = 256 / C;
-        double a = 0, b = 0;
-        float mean = 0.f, rstd = 1.f;
-        if (MODE == 1) { mean = k.stats[(long long)g * 2 * C + c]; rstd = k.stats[(long long)g * 2 * C + C + c]; }
-        for (long long r = r0 + rp; r < r1; r += rstep) {
-            const float xv = k.x[r * k.x_ld + k.x_coff + c];
-            if (MODE == 0) { a += xv; b += (double)xv * xv; }
+        for (int e = 0; e < V; ++e) {
+            if (MODE == 0) { a[e] += xs[e]; b[e] += (double)xs[e] * xs[e]; }
             else {
-                const float gq = k.dy[r * k.dy_ld + k.dy_coff + c] * norm_act_bwd(k.y[r * k.y_ld + k.y_coff + c], k.act, k.post_sigmoid);
-                a += gq;
-                b += (double)gq * ((xv - mean) * rstd);
+                const float gq = ds[e] * norm_act_bwd(ys[e], k.act, k.post_sigmoid);
+                a[e] += gq;
+                b[e] += (double)gq * ((xs[e] - mean[e]) * rstd[e]);
             }
         }
-        sh[tid * 2] = a; sh[tid * 2 + 1] = b;
-        __syncthreads();
-        if (tid < C) {
+    };
+    long long r = r0 + rp;
+    for (; r + rstep < r1; r += 2 * rstep) {     // two independent rows per iteration
+        float x0[V], x1[V], d0[V], d1[V], y0[V], y1[V];
+        ldv(k.x, r, k.x_ld, k.x_coff, x0);
+        ldv(k.x, r + rstep, k.x_ld, k.x_coff, x1);
+        if (MODE == 1) {
+            ldv(k.dy, r, k.dy_ld, k.dy_coff, d0); ldv(k.dy, r + rstep, k.dy_ld, k.dy_coff, d1);
+            ldv(k.y, r, k.y_ld, k.y_coff, y0); ldv(k.y, r + rstep, k.y_ld, k.y_coff, y1);
+        }
+        acc1(x0, d0, y0);
+        acc1(x1, d1, y1);
+    }
+    if (r < r1) {
+        float x0[V], d0[V], y0[V];
+        ldv(k.x, r, k.x_ld, k.x_coff, x0);
+        if (MODE == 1) { ldv(k.dy, r, k.dy_ld, k.dy_coff, d0); ldv(k.y, r, k.y_ld, k.y_coff, y0); }
+        acc1(x0, d0, y0);
+    }
+#pragma unroll
+    for (int e = 0; e < V; ++e) { sh[(tid * V + e) * 2] = a[e]; sh[(tid * V + e) * 2 + 1] = b[e]; }
+    __syncthreads();
+    if (tid < CB) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
             double sa = 0, sb = 0;
-            for (int t = tid; t < 256; t += C) { sa += sh[t * 2]; sb += sh[t * 2 + 1]; }
-            dst[tid] = sa;
-            dst[C + tid] = sb;
+            for (int t = tid; t < 256; t += CB) { sa += sh[(t * V + e) * 2]; sb += sh[(t * V + e) * 2 + 1]; }
+            dst[c0 + e] = sa;
+            dst[C + c0 + e] = sb;
         }
     }
 }
@@ -168,43 +176,40 @@ __global__ void norm_fwd_finalize_kernel(const double* __restrict__ part, int G,
     }
 }
 
+// grid (blocks, group): lanes per row CV = C/V is a power of two <= 256, so a thread keeps its channels over the grid-stride
+// loop: per-channel constants live in registers and the row index is a shift
 template <bool VEC>
-__global__ __launch_bounds__(256) void norm_apply_kernel(const NormK k, int G) {
-    const int C = k.C;
-    const long long total = (long long)G * k.R;
-    if (VEC) {
-        const int C4 = C >> 2;
-        long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-        const long long n = total * C4, st = (long long)gridDim.x * 256;
-        for (; i < n; i += st) {
-            const long long r = i / C4;
-            const int cg = (int)(i - r * C4), g = (int)(r / k.R);
-            const float4 xv = *reinterpret_cast<const float4*>(k.x + r * k.x_ld + k.x_coff + cg * 4);
-            const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
-            float o[4];
+__global__ __launch_bounds__(256) void norm_apply_kernel(const NormK k) {
+    constexpr int V = VEC ? 4 : 1;
+    const int C = k.C, g = blockIdx.y, lc = k.lc;
+    const int cg = threadIdx.x & ((1 << lc) - 1), c0 = cg * V;
+    float mean[V], rstd[V], gam[V], bet[V];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int c = cg * 4 + e;
-                float v = (xs[e] - k.stats[(long long)g * 2 * C + c]) * k.stats[(long long)g * 2 * C + C + c];
-                if (k.gamma) v = v * k.gamma[c] + k.beta[c];
-                o[e] = norm_act_fwd(v, k.act, k.post_sigmoid);
-            }
-            *reinterpret_cast<float4*>(k.out + r * k.o_ld + k.o_coff + cg * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    for (int e = 0; e < V; ++e) {
+        mean[e] = k.stats[(long long)g * 2 * C + c0 + e];
+        rstd[e] = k.stats[(long long)g * 2 * C + C + c0 + e];
+        gam[e] = k.gamma ? k.gamma[c0 + e] : 1.f;
+        bet[e] = k.gamma ? k.beta[c0 + e] : 0.f;
+    }
+    const long long base = (long long)g * k.R, n = (long long)k.R << lc, st = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += st) {
+        const long long r = base + (i >> lc);
+        float xs[V], o[V];
+        if (VEC) { const float4 xv = *reinterpret_cast<const float4*>(k.x + r * k.x_ld + k.x_coff + c0); xs[0] = xv.x; xs[V > 1 ? 1 : 0] = xv.y; xs[V > 2 ? 2 : 0] = xv.z; xs[V > 3 ? 3 : 0] = xv.w; }
+        else xs[0] = k.x[r * k.x_ld + k.x_coff + c0];
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            float v = (xs[e] - mean[e]) * rstd[e];
+            if (k.gamma) v = v * gam[e] + bet[e];
+            o[e] = norm_act_fwd(v, k.act, k.post_sigmoid);
         }
-    } else {
-        long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-        const long long n = total * C, st = (long long)gridDim.x * 256;
-        for (; i < n; i += st) {
-            const long long r = i / C;
-            const int c = (int)(i - r * C), g = (int)(r / k.R);
-            float v = (k.x[r * k.x_ld + k.x_coff + c] - k.stats[(long long)g * 2 * C + c]) * k.stats[(long long)g * 2 * C + C + c];
-            if (k.gamma) v = v * k.gamma[c] + k.beta[c];
-            k.out[r * k.o_ld + k.o_coff + c] = norm_act_fwd(v, k.act, k.post_sigmoid);
-        }
+        if (VEC) *reinterpret_cast<float4*>(k.out + r * k.o_ld + k.o_coff + c0) = make_float4(o[0], o[V > 1 ? 1 : 0], o[V > 2 ? 2 : 0], o[V > 3 ? 3 : 0]);
+        else k.out[r * k.o_ld + k.o_coff + c0] = o[0];
     }
 }
 
-static int apply_grid(long long n) { long long b = (n + 255) / 256; return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
+static int apply_grid(long long n, int G) { long long b = (n + 255) / 256, cap = 4096 / (G > 0 ? G : 1); if (cap < 8) cap = 8; return (int)(b > cap ? cap : (b < 1 ? 1 : b)); }
+static int n_log2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
 extern "C" int hv_norm_act_forward(const hv_norm_desc* d, void* stream) {
     if (!d || !d->x || !d->y || !d->stats || d->B <= 0 || d->HW <= 0 || d->C <= 0) return HV_ERR_ARG;
@@ -215,8 +220,7 @@ extern "C" int hv_norm_act_forward(const hv_norm_desc* d, void* stream) {
     if (!vec && !(n_pow2(d->C) && d->C <= 256)) return HV_ERR_UNSUPPORTED;
     if (d->norm == HV_NORM_BATCH && (!d->gamma || !d->beta)) return HV_ERR_ARG;
     if (d->norm == HV_NORM_BATCH && d->groups > 1 && d->B % d->groups) return HV_ERR_ARG;
-    NormPlan pl = norm_plan(d->B, d->HW, d->C, d->norm, d->groups);
-    if (!vec) { pl.rstep = 256 / d->C; pl.rpb = (pl.rpb + pl.rstep - 1) / pl.rstep * pl.rstep; pl.nchunk = hv_cdiv(pl.R, pl.rpb); }
+    NormPlan pl = norm_plan(d->B, d->HW, d->C, d->norm, d->groups, vec);
     const bool use_running = d->norm == HV_NORM_BATCH && !d->training;
     if (use_running && (!d->running_mean || !d->running_var)) return HV_ERR_ARG;
     const size_t need = (size_t)pl.G * pl.nchunk * 2 * d->C * sizeof(double);
@@ -225,10 +229,11 @@ extern "C" int hv_norm_act_forward(const hv_norm_desc* d, void* stream) {
     NormK k = {};
     k.x = d->x; k.out = d->y; k.x_ld = d->x_ld; k.x_coff = d->x_coff; k.o_ld = d->y_ld; k.o_coff = d->y_coff;
     k.C = d->C; k.R = pl.R; k.rpb = pl.rpb; k.nchunk = pl.nchunk; k.act = d->act; k.post_sigmoid = d->post_sigmoid;
+    k.CB = pl.CB; k.lc = n_log2(vec ? d->C / 4 : d->C);
     k.stats = d->stats; k.gamma = d->norm == HV_NORM_BATCH ? d->gamma : nullptr; k.beta = d->beta;
     double* part = (double*)d->workspace;
     if (!use_running) {
-        dim3 grid(pl.nchunk, pl.G);
+        dim3 grid(pl.nchunk, pl.G, pl.slices);
         if (vec) hipLaunchKernelGGL((norm_reduce_kernel<0, true>), grid, dim3(256), 0, s, k, part);
         else hipLaunchKernelGGL((norm_reduce_kernel<0, false>), grid, dim3(256), 0, s, k, part);
         HV_LAUNCH_CHECK();
@@ -237,9 +242,10 @@ extern "C" int hv_norm_act_forward(const hv_norm_desc* d, void* stream) {
     hipLaunchKernelGGL(norm_fwd_finalize_kernel, dim3(d->C), dim3(64), 0, s, part, pl.G, pl.nchunk, d->C, pl.R,
                        d->eps, d->momentum, d->stats, d->running_mean, d->running_var, d->num_batches_tracked, use_running ? 1 : 0, update);
     HV_LAUNCH_CHECK();
-    const long long n = (long long)pl.G * pl.R * (vec ? d->C / 4 : d->C);
-    if (vec) hipLaunchKernelGGL((norm_apply_kernel<true>), dim3(apply_grid(n)), dim3(256), 0, s, k, pl.G);
-    else hipLaunchKernelGGL((norm_apply_kernel<false>), dim3(apply_grid(n)), dim3(256), 0, s, k, pl.G);
+    const long long n = (long long)pl.R * (vec ? d->C / 4 : d->C);
+    const dim3 agrid(apply_grid(n, pl.G), pl.G);
+    if (vec) hipLaunchKernelGGL((norm_apply_kernel<true>), agrid, dim3(256), 0, s, k);
+    else hipLaunchKernelGGL((norm_apply_kernel<false>), agrid, dim3(256), 0, s, k);
     HV_LAUNCH_CHECK();
     return HV_OK;
 }
@@ -270,46 +276,50 @@ __global__ void norm_bwd_finalize_kernel(const double* __restrict__ part, int G,
 }
 
 template <bool VEC>
-__global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const NormK k, int G, const float* __restrict__ ab, int batch_stats) {
-    const int C = k.C;
-    const long long total = (long long)G * k.R;
+__global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const NormK k, const float* __restrict__ ab, int batch_stats) {
+    constexpr int V = VEC ? 4 : 1;
+    const int C = k.C, g = blockIdx.y, lc = k.lc;
     const float invR = 1.f / (float)k.R;
-    const int V = VEC ? 4 : 1, CV = C / V;
-    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long n = total * CV, st = (long long)gridDim.x * 256;
-    for (; i < n; i += st) {
-        const long long r = i / CV;
-        const int cg = (int)(i - r * CV), g = (int)(r / k.R);
-        float xs[4], ds[4], ys[4], o[4];
+    const int cg = threadIdx.x & ((1 << lc) - 1), c0 = cg * V;
+    float mean[V], rstd[V], gam[V], sa[V], sb[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+        mean[e] = k.stats[(long long)g * 2 * C + c0 + e];
+        rstd[e] = k.stats[(long long)g * 2 * C + C + c0 + e];
+        gam[e] = k.gamma ? k.gamma[c0 + e] : 1.f;
+        sa[e] = ab[(long long)g * 2 * C + c0 + e];
+        sb[e] = ab[(long long)g * 2 * C + C + c0 + e];
+    }
+    const long long base = (long long)g * k.R, n = (long long)k.R << lc, st = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += st) {
+        const long long r = base + (i >> lc);
+        float xs[V], ds[V], ys[V], o[V];
         if (VEC) {
-            const float4 xv = *reinterpret_cast<const float4*>(k.x + r * k.x_ld + k.x_coff + cg * 4);
-            const float4 dv = *reinterpret_cast<const float4*>(k.dy + r * k.dy_ld + k.dy_coff + cg * 4);
-            const float4 yv = *reinterpret_cast<const float4*>(k.y + r * k.y_ld + k.y_coff + cg * 4);
-            xs[0] = xv.x; xs[1] = xv.y; xs[2] = xv.z; xs[3] = xv.w;
-            ds[0] = dv.x; ds[1] = dv.y; ds[2] = dv.z; ds[3] = dv.w;
-            ys[0] = yv.x; ys[1] = yv.y; ys[2] = yv.z; ys[3] = yv.w;
+            const float4 xv = *reinterpret_cast<const float4*>(k.x + r * k.x_ld + k.x_coff + c0);
+            const float4 dv = *reinterpret_cast<const float4*>(k.dy + r * k.dy_ld + k.dy_coff + c0);
+            const float4 yv = *reinterpret_cast<const float4*>(k.y + r * k.y_ld + k.y_coff + c0);
+            xs[0] = xv.x; xs[V > 1 ? 1 : 0] = xv.y; xs[V > 2 ? 2 : 0] = xv.z; xs[V > 3 ? 3 : 0] = xv.w;
+            ds[0] = dv.x; ds[V > 1 ? 1 : 0] = dv.y; ds[V > 2 ? 2 : 0] = dv.z; ds[V > 3 ? 3 : 0] = dv.w;
+            ys[0] = yv.x; ys[V > 1 ? 1 : 0] = yv.y; ys[V > 2 ? 2 : 0] = yv.z; ys[V > 3 ? 3 : 0] = yv.w;
         } else {
-            xs[0] = k.x[r * k.x_ld + k.x_coff + cg];
-            ds[0] = k.dy[r * k.dy_ld + k.dy_coff + cg];
-            ys[0] = k.y[r * k.y_ld + k.y_coff + cg];
+            xs[0] = k.x[r * k.x_ld + k.x_coff + c0];
+            ds[0] = k.dy[r * k.dy_ld + k.dy_coff + c0];
+            ys[0] = k.y[r * k.y_ld + k.y_coff + c0];
         }
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-            const int c = cg * V + e;
-            const float mean = k.stats[(long long)g * 2 * C + c], rstd = k.stats[(long long)g * 2 * C + C + c];
             const float gq = ds[e] * norm_act_bwd(ys[e], k.act, k.post_sigmoid);
-            const float gam = k.gamma ? k.gamma[c] : 1.f;
             float v;
             if (batch_stats) {
-                const float xhat = (xs[e] - mean) * rstd;
-                v = gam * rstd * (gq - ab[(long long)g * 2 * C + c] * invR - xhat * ab[(long long)g * 2 * C + C + c] * invR);
+                const float xhat = (xs[e] - mean[e]) * rstd[e];
+                v = gam[e] * rstd[e] * (gq - sa[e] * invR - xhat * sb[e] * invR);
             } else {
-                v = gam * rstd * gq;
+                v = gam[e] * rstd[e] * gq;
             }
             o[e] = v;
         }
-        if (VEC) *reinterpret_cast<float4*>(k.out + r * k.o_ld + k.o_coff + cg * 4) = make_float4(o[0], o[1], o[2], o[3]);
-        else k.out[r * k.o_ld + k.o_coff + cg] = o[0];
+        if (VEC) *reinterpret_cast<float4*>(k.out + r * k.o_ld + k.o_coff + c0) = make_float4(o[0], o[V > 1 ? 1 : 0], o[V > 2 ? 2 : 0], o[V > 3 ? 3 : 0]);
+        else k.out[r * k.o_ld + k.o_coff + c0] = o[0];
     }
 }
 
@@ -321,8 +331,7 @@ extern "C" int hv_norm_act_backward(const hv_norm_bwd_desc* d, void* stream) {
                          !(((uintptr_t)d->x | (uintptr_t)d->y | (uintptr_t)d->dy | (uintptr_t)d->dx) & 15);
     const bool vec = n_vec_ok(d->C) && aligned;
     if (!vec && !(n_pow2(d->C) && d->C <= 256)) return HV_ERR_UNSUPPORTED;
-    NormPlan pl = norm_plan(d->B, d->HW, d->C, d->norm, d->groups);
-    if (!vec) { pl.rstep = 256 / d->C; pl.rpb = (pl.rpb + pl.rstep - 1) / pl.rstep * pl.rstep; pl.nchunk = hv_cdiv(pl.R, pl.rpb); }
+    NormPlan pl = norm_plan(d->B, d->HW, d->C, d->norm, d->groups, vec);
     const size_t need_part = (size_t)pl.G * pl.nchunk * 2 * d->C * sizeof(double);
     const size_t need = need_part + (size_t)pl.G * 2 * d->C * sizeof(float);
     if (!d->workspace || d->workspace_bytes < need || ((uintptr_t)d->workspace & 7)) return HV_ERR_WORKSPACE;
@@ -332,10 +341,11 @@ extern "C" int hv_norm_act_backward(const hv_norm_bwd_desc* d, void* stream) {
     k.x_ld = d->x_ld; k.x_coff = d->x_coff; k.y_ld = d->y_ld; k.y_coff = d->y_coff; k.dy_ld = d->dy_ld; k.dy_coff = d->dy_coff;
     k.o_ld = d->dx_ld; k.o_coff = d->dx_coff;
     k.C = d->C; k.R = pl.R; k.rpb = pl.rpb; k.nchunk = pl.nchunk; k.act = d->act; k.post_sigmoid = d->post_sigmoid;
+    k.CB = pl.CB; k.lc = n_log2(vec ? d->C / 4 : d->C);
     k.stats = d->stats; k.gamma = d->norm == HV_NORM_BATCH ? d->gamma : nullptr;
     double* part = (double*)d->workspace;
     float* ab = (float*)((char*)d->workspace + need_part);
-    dim3 grid(pl.nchunk, pl.G);
+    dim3 grid(pl.nchunk, pl.G, pl.slices);
     if (vec) hipLaunchKernelGGL((norm_reduce_kernel<1, true>), grid, dim3(256), 0, s, k, part);
     else hipLaunchKernelGGL((norm_reduce_kernel<1, false>), grid, dim3(256), 0, s, k, part);
     HV_LAUNCH_CHECK();
@@ -343,9 +353,10 @@ extern "C" int hv_norm_act_backward(const hv_norm_bwd_desc* d, void* stream) {
                        d->param_accumulate);
     HV_LAUNCH_CHECK();
     const int batch_stats = (d->norm == HV_NORM_INSTANCE || d->training) ? 1 : 0;
-    const long long n = (long long)pl.G * pl.R * (vec ? d->C / 4 : d->C);
-    if (vec) hipLaunchKernelGGL((norm_bwd_apply_kernel<true>), dim3(apply_grid(n)), dim3(256), 0, s, k, pl.G, ab, batch_stats);
-    else hipLaunchKernelGGL((norm_bwd_apply_kernel<false>), dim3(apply_grid(n)), dim3(256), 0, s, k, pl.G, ab, batch_stats);
+    const long long n = (long long)pl.R * (vec ? d->C / 4 : d->C);
+    const dim3 agrid(apply_grid(n, pl.G), pl.G);
+    if (vec) hipLaunchKernelGGL((norm_bwd_apply_kernel<true>), agrid, dim3(256), 0, s, k, ab, batch_stats);
+    else hipLaunchKernelGGL((norm_bwd_apply_kernel<false>), agrid, dim3(256), 0, s, k, ab, batch_stats);
     HV_LAUNCH_CHECK();
     return HV_OK;
 }

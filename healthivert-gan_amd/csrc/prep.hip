@@ -178,7 +178,23 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(float* __restrict__ dy, co
     if (VEC) {
         const int C4 = C >> 2, cg = tid % C4, rp = tid / C4, rstep = 256 / C4;
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (long long r = r0 + rp; r < r1; r += rstep) {
+        long long r = r0 + rp;
+        for (; r + rstep < r1; r += 2 * rstep) {   // two rows in flight per lane (HBM streaming needs the loads, not the math)
+            float* p0 = dy + r * dy_ld + dy_coff + cg * 4;
+            float* p1 = p0 + (long long)rstep * dy_ld;
+            float4 g0 = *reinterpret_cast<float4*>(p0), g1 = *reinterpret_cast<float4*>(p1);
+            const float4 o0 = *reinterpret_cast<const float4*>(y + r * y_ld + y_coff + cg * 4);
+            const float4 o1 = *reinterpret_cast<const float4*>(y + (r + rstep) * y_ld + y_coff + cg * 4);
+            g0.x *= hv_act_grad_from_out(o0.x, act); g0.y *= hv_act_grad_from_out(o0.y, act);
+            g0.z *= hv_act_grad_from_out(o0.z, act); g0.w *= hv_act_grad_from_out(o0.w, act);
+            g1.x *= hv_act_grad_from_out(o1.x, act); g1.y *= hv_act_grad_from_out(o1.y, act);
+            g1.z *= hv_act_grad_from_out(o1.z, act); g1.w *= hv_act_grad_from_out(o1.w, act);
+            *reinterpret_cast<float4*>(p0) = g0;
+            *reinterpret_cast<float4*>(p1) = g1;
+            s.x += g0.x; s.y += g0.y; s.z += g0.z; s.w += g0.w;
+            s.x += g1.x; s.y += g1.y; s.z += g1.z; s.w += g1.w;
+        }
+        for (; r < r1; r += rstep) {
             float4 g = *reinterpret_cast<float4*>(dy + r * dy_ld + dy_coff + cg * 4);
             const float4 o = *reinterpret_cast<const float4*>(y + r * y_ld + y_coff + cg * 4);
             g.x *= hv_act_grad_from_out(o.x, act); g.y *= hv_act_grad_from_out(o.y, act);
@@ -234,8 +250,8 @@ static int act_bwd_blocks(long long npix, int C, int* rows_per_block) {
     const int rstep = act_vec_ok(C) ? 256 / (C / 4) : 256 / C;
     long long rpb = (long long)rstep * 16;
     long long nb = (npix + rpb - 1) / rpb;
-    if (nb > 512) {
-        rpb = (npix + 511) / 512;
+    if (nb > 2048) {   // ~8 workgroups per CU keep enough loads in flight to stream from HBM
+        rpb = (npix + 2047) / 2048;
         rpb = (rpb + rstep - 1) / rstep * rstep;
         nb = (npix + rpb - 1) / rpb;
     }

@@ -284,7 +284,7 @@ class AttentionPlan:
             z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dout.t.device)
             self.bw = dict(dA=Act(z(B, self.h, self.w, L)), AT=Act(z(B, self.h, self.w, L)), dOrawT=z(B, C, 16 * L),
                            dS1=Act(z(B, self.h, self.w, L)), dS0=Act(z(B, self.h, self.w, L)), Gs=Act(z(B, self.h, self.w, L)),
-                           coef=z(B, L), dwp=Act(z(B, self.h, self.w, 9 * C)))
+                           coef=z(17 * B, L), dwp=Act(z(B, self.h, self.w, 9 * C)))
         bw = self.bw
         # through the paste: dA and d(raw patches)
         ops.conv2d(dout, self.raw, bw['dA'], 4, 2, 1, 1, alpha=0.25, w_bstride=L * 16 * C, precision=prec)

@@ -187,7 +187,8 @@ int hv_ca_fuse(const float* S, float* out, int B, int h, int w, int adjoint, voi
 int hv_ca_softmax(const float* S, const float* mm, float* A, int B, int L, float scale, int* argmax, void* stream);
 int hv_ca_softmax_backward(const float* dA, const float* A, const float* mm, float* dS, int B, int L, float scale, void* stream);
 int hv_transpose_batched(const float* src, float* dst, int B, int R, int C, void* stream); /* dst[b][c][r] = src[b][r][c] */
-/* Gs[b][i][j] = dS[b][j][i]*rnorm[b][i] + dS[b][i][j]*rnorm[b][j];  coef[b][l] = -(sum_p dS[p][l]*S0[p][l])/norm[l]^2 */
+/* Gs[b][i][j] = dS[b][j][i]*rnorm[b][i] + dS[b][i][j]*rnorm[b][j];  coef[b][l] = -(sum_p dS[p][l]*S0[p][l])/norm[l]^2.
+ * coef must hold 17*B*L floats: the first B*L are the result, the rest is scratch for the row-chunk partial sums. */
 int hv_ca_score_backward_prep(const float* dS, const float* S0, const float* norm, const float* rnorm, float* Gs, float* coef,
                               int B, int L, void* stream);
 /* col2im of (dwp + coef*wp) back to the even positions of the full-resolution map (adjoint of hv_ca_patches). */
