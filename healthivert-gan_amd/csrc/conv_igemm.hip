@@ -14,6 +14,7 @@
 // Precision: float -> v_mfma_f32_16x16x4_f32 (exact fp32, the parity mode);
 //            _Float16 -> v_mfma_f32_16x16x32_f16 with fp32 accumulation.
 #include "hv_common.h"
+#include <stdlib.h>
 
 #define HV_MAX_TAPS 25
 #define HV_BK 32
@@ -462,7 +463,8 @@ __global__ __launch_bounds__(WN * WC * 64) void wgrad_kernel(const WgradK p) {
     static_assert(WN * WC == 4 && NT >= 1 && CT >= 1 && KT % 32 == 0 && (!F16 || KT % 64 == 0), "bad tile");
     constexpr int GI = (BN / 4) * (KT / 8);     // staging items: (channel groups of 4) x (pixel runs of 8)
     constexpr int XI = (BC / 4) * (KT / 8);
-    static_assert(GI <= NTHR && XI <= NTHR, "at most one G item and one X item per thread");
+    constexpr int XPT = (XI + NTHR - 1) / NTHR; // X items per thread (wide J tiles re-read G fewer times)
+    static_assert(GI <= NTHR && (XI <= NTHR || XI % NTHR == 0), "one G item per thread; X items fill whole thread passes");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_base = blockIdx.y * BN, j_base = blockIdx.z * BC;
@@ -473,20 +475,26 @@ __global__ __launch_bounds__(WN * WC * 64) void wgrad_kernel(const WgradK p) {
     // G items sit on the first threads, X items on the last: when a tile has fewer items than threads the two
     // roles land on different waves (different SIMDs) and stage in parallel.
     const bool has_g = tid < GI;
-    const int xt = tid - (NTHR - XI);
+    const int xt = XI < NTHR ? tid - (NTHR - XI) : tid;
     const bool has_x = xt >= 0;
-    const int xi = has_x ? xt : 0;
     const int g_cg = tid % (BN / 4), g_run = tid / (BN / 4);
-    const int x_cg = xi % (BC / 4), x_run = xi / (BC / 4);
-    const int jx = j_base + x_cg * 4;
-    const bool jok = has_x && jx < p.J;
-    int dh = 0, dw = 0, cx = 0;
-    if (jok) {
-        const int tap = jx / p.Cin;
-        cx = jx - tap * p.Cin;
-        const int r = tap / p.KW, s = tap - r * p.KW;
-        dh = r * p.dil - p.pad;
-        dw = s * p.dil - p.pad;
+    int x_cg[XPT], x_run[XPT], dh[XPT], dw[XPT], cx[XPT];
+    bool jok[XPT];
+#pragma unroll
+    for (int it = 0; it < XPT; ++it) {
+        const int xi = (has_x ? xt : 0) + it * NTHR;
+        x_cg[it] = xi % (BC / 4);
+        x_run[it] = xi / (BC / 4);
+        const int jx = j_base + x_cg[it] * 4;
+        jok[it] = has_x && jx < p.J;
+        dh[it] = dw[it] = cx[it] = 0;
+        if (jok[it]) {
+            const int tap = jx / p.Cin;
+            cx[it] = jx - tap * p.Cin;
+            const int r = tap / p.KW, q = tap - r * p.KW;
+            dh[it] = r * p.dil - p.pad;
+            dw[it] = q * p.dil - p.pad;
+        }
     }
     const int gch = n_base + g_cg * 4;
     const bool gok = has_g && gch < p.Cout;  // Cout % 4 == 0 is guaranteed by the host
@@ -494,17 +502,21 @@ __global__ __launch_bounds__(WN * WC * 64) void wgrad_kernel(const WgradK p) {
     const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t gsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.g), 0, p.g_bytes, 0x00020000);
 
-    // decode state of this thread's X item (first pixel of its run) for the non-power-of-two path; load_x is called
+    // decode state of this thread's X items (first pixel of the run) for the non-power-of-two path; load_x is called
     // with pix_begin, pix_begin + KT, ... in order and advances it
-    int xs_n = 0, xs_ho = 0, xs_wo = 0;
-    if (!FAST) {
-        const int m0 = pix_begin + x_run * 8;
-        xs_n = m0 / HWo;
-        const int rem = m0 - xs_n * HWo;
-        xs_ho = rem / p.Wo;
-        xs_wo = rem - xs_ho * p.Wo;
+    int xs_n[XPT], xs_ho[XPT], xs_wo[XPT];
+#pragma unroll
+    for (int it = 0; it < XPT; ++it) {
+        xs_n[it] = xs_ho[it] = xs_wo[it] = 0;
+        if (!FAST) {
+            const int m0 = pix_begin + x_run[it] * 8;
+            xs_n[it] = m0 / HWo;
+            const int rem = m0 - xs_n[it] * HWo;
+            xs_ho[it] = rem / p.Wo;
+            xs_wo[it] = rem - xs_ho[it] * p.Wo;
+        }
     }
-    u32x4 rg[8], rx[8];
+    u32x4 rg[8], rx[XPT][8];
     auto load_g = [&](int pix0) __attribute__((always_inline)) {
         const int m0 = pix0 + g_run * 8;
         if (FAST) {   // M % 8 == 0 and chunk % KT == 0: a run is wholly inside or outside the chunk
@@ -520,52 +532,56 @@ __global__ __launch_bounds__(WN * WC * 64) void wgrad_kernel(const WgradK p) {
             }
         }
     };
-    auto load_x = [&](int pix0) __attribute__((always_inline)) {
-        const int m0 = pix0 + x_run * 8;
+    auto load_x1 = [&](int pix0, int it, u32x4 (&r)[8]) __attribute__((always_inline)) {
+        const int m0 = pix0 + x_run[it] * 8;
         if (FAST) {   // Wo is a power of two >= 8: the 8 pixels of a run share one output row
             const int n = m0 >> p.lhw, ho = (m0 >> p.lw) & (p.Ho - 1), wo0 = m0 & (p.Wo - 1);
-            const int hi = ho * p.stride + dh;
-            const bool rok = jok && m0 < pix_end && (unsigned)hi < (unsigned)p.Hl;
-            const int base = n * p.img_stride + (hi >> p.in_shift) * p.Wp * p.x_ld + p.x_coff + cx;
-            int wi = wo0 * p.stride + dw;
+            const int hi = ho * p.stride + dh[it];
+            const bool rok = jok[it] && m0 < pix_end && (unsigned)hi < (unsigned)p.Hl;
+            const int base = n * p.img_stride + (hi >> p.in_shift) * p.Wp * p.x_ld + p.x_coff + cx[it];
+            int wi = wo0 * p.stride + dw[it];
 #pragma unroll
             for (int e = 0; e < 8; ++e, wi += p.stride) {
                 const unsigned off = (rok && (unsigned)wi < (unsigned)p.Wl) ? (unsigned)(base + (wi >> p.in_shift) * p.x_ld) * 4u : HV_OOB;
-                rx[e] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, off, 0, 0);
+                r[e] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, off, 0, 0);
             }
         } else if (p.Wo >= 8) {   // any output size: the run crosses an output row at most once -- two row bases, one select per pixel
-            const int cross = p.Wo - xs_wo;                       // pixels e >= cross sit on the next output row
-            int ho1 = xs_ho + 1, n1 = xs_n;
+            const int cross = p.Wo - xs_wo[it];                   // pixels e >= cross sit on the next output row
+            int ho1 = xs_ho[it] + 1, n1 = xs_n[it];
             if (ho1 == p.Ho) { ho1 = 0; ++n1; }
-            const int hiA = xs_ho * p.stride + dh, hiB = ho1 * p.stride + dh;
-            const bool rokA = jok && (unsigned)hiA < (unsigned)p.Hl, rokB = jok && (unsigned)hiB < (unsigned)p.Hl;
-            const int baseA = xs_n * p.img_stride + (hiA >> p.in_shift) * p.Wp * p.x_ld + p.x_coff + cx;
-            const int baseB = n1 * p.img_stride + (hiB >> p.in_shift) * p.Wp * p.x_ld + p.x_coff + cx;
+            const int hiA = xs_ho[it] * p.stride + dh[it], hiB = ho1 * p.stride + dh[it];
+            const bool rokA = jok[it] && (unsigned)hiA < (unsigned)p.Hl, rokB = jok[it] && (unsigned)hiB < (unsigned)p.Hl;
+            const int baseA = xs_n[it] * p.img_stride + (hiA >> p.in_shift) * p.Wp * p.x_ld + p.x_coff + cx[it];
+            const int baseB = n1 * p.img_stride + (hiB >> p.in_shift) * p.Wp * p.x_ld + p.x_coff + cx[it];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const bool nb = e >= cross;
-                const int wi = (xs_wo + e - (nb ? p.Wo : 0)) * p.stride + dw;
+                const int wi = (xs_wo[it] + e - (nb ? p.Wo : 0)) * p.stride + dw[it];
                 const bool ok = (nb ? rokB : rokA) && m0 + e < pix_end && (unsigned)wi < (unsigned)p.Wl;
                 const unsigned off = ok ? (unsigned)((nb ? baseB : baseA) + (wi >> p.in_shift) * p.x_ld) * 4u : HV_OOB;
-                rx[e] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, off, 0, 0);
+                r[e] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, off, 0, 0);
             }
         } else {                  // tiny maps: step pixel by pixel
-            int n = xs_n, ho = xs_ho, wo = xs_wo;
+            int n = xs_n[it], ho = xs_ho[it], wo = xs_wo[it];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const int hi = ho * p.stride + dh, wi = wo * p.stride + dw;
-                const bool ok = jok && m0 + e < pix_end && (unsigned)hi < (unsigned)p.Hl && (unsigned)wi < (unsigned)p.Wl;
-                const unsigned off = ok ? (unsigned)(n * p.img_stride + ((hi >> p.in_shift) * p.Wp + (wi >> p.in_shift)) * p.x_ld + p.x_coff + cx) * 4u : HV_OOB;
-                rx[e] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, off, 0, 0);
+                const int hi = ho * p.stride + dh[it], wi = wo * p.stride + dw[it];
+                const bool ok = jok[it] && m0 + e < pix_end && (unsigned)hi < (unsigned)p.Hl && (unsigned)wi < (unsigned)p.Wl;
+                const unsigned off = ok ? (unsigned)(n * p.img_stride + ((hi >> p.in_shift) * p.Wp + (wi >> p.in_shift)) * p.x_ld + p.x_coff + cx[it]) * 4u : HV_OOB;
+                r[e] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, off, 0, 0);
                 if (++wo == p.Wo) { wo = 0; if (++ho == p.Ho) { ho = 0; ++n; } }
             }
         }
         if (!FAST) {
             // advance the decode state by one step (KT pixels) without dividing
-            xs_wo += p.kt_r; xs_ho += p.kt_q;
-            if (xs_wo >= p.Wo) { xs_wo -= p.Wo; ++xs_ho; }
-            while (xs_ho >= p.Ho) { xs_ho -= p.Ho; ++xs_n; }
+            xs_wo[it] += p.kt_r; xs_ho[it] += p.kt_q;
+            if (xs_wo[it] >= p.Wo) { xs_wo[it] -= p.Wo; ++xs_ho[it]; }
+            while (xs_ho[it] >= p.Ho) { xs_ho[it] -= p.Ho; ++xs_n[it]; }
         }
+    };
+    auto load_x = [&](int pix0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < XPT; ++it) load_x1(pix0, it, rx[it]);
     };
     auto store = [&](T* dst, int ld, const u32x4 (&r)[8], int cg, int run) __attribute__((always_inline)) {
         if (F16) {
@@ -601,7 +617,10 @@ __global__ __launch_bounds__(WN * WC * 64) void wgrad_kernel(const WgradK p) {
     for (int pix0 = pix_begin; pix0 < pix_end; pix0 += KT) {
         __syncthreads();  // previous step's MFMA reads done
         if (has_g) store(Gs, LDG, rg, g_cg, g_run);
-        if (has_x) store(Xs, LDX, rx, x_cg, x_run);
+        if (has_x) {
+#pragma unroll
+            for (int it = 0; it < XPT; ++it) store(Xs, LDX, rx[it], x_cg[it], x_run[it]);
+        }
         __syncthreads();
         if (pix0 + KT < pix_end) {   // next tile's loads fly behind this tile's MFMAs
             if (has_g) load_g(pix0 + KT);
@@ -690,21 +709,23 @@ struct WgradPlan { int BN, BC, KT, splits, chunk; };
 static int wgrad_plan(const hv_wgrad_desc* d, WgradPlan* pl) {
     const int J = d->KH * d->KW * d->Cin;
     const long long M = (long long)d->B * d->Ho * d->Wo;
+    static const bool wide64 = !(getenv("HV_WGRAD_WIDE") && atoi(getenv("HV_WGRAD_WIDE")) == 0);   // A/B knob
     int BN, BC;
     if (d->Cout <= 16) { BN = 16; BC = 128; }
     else if (d->Cout <= 32) { BN = 32; BC = 128; }
-    else if (d->Cout <= 64) { BN = 64; BC = 64; }
+    else if (d->Cout <= 64) { BN = 64; BC = (J >= 512 && wide64) ? 256 : 64; }   // wide J tile: G is re-read J/256 instead of J/64 times
     else { BN = 128; BC = J >= 4096 ? 128 : 64; }
     const long long tiles = (long long)hv_cdiv(d->Cout, BN) * hv_cdiv(J, BC);
     // ~3 workgroups per CU; layers whose dW already has many tiles get few splits (slab traffic grows with splits)
-    long long want = tiles >= 128 ? (512 + tiles - 1) / tiles : (768 + tiles - 1) / tiles;
+    static const int want_wg = getenv("HV_WGRAD_WANT") ? atoi(getenv("HV_WGRAD_WANT")) : 768;   // tuning knob
+    long long want = tiles >= 128 ? (512 + tiles - 1) / tiles : (want_wg + tiles - 1) / tiles;
     if (want > 256) want = 256;
     long long maxs = (M + 255) / 256;                     // at least 256 pixels per split
     long long splits = want < 1 ? 1 : want;
     if (splits > maxs) splits = maxs;
     if (splits < 1) splits = 1;
     // pixels per staging step: fp16 tiles take 64 (128 for the 64x64 tile) so that every thread stages an X item
-    const int KT = d->precision == HV_F32 ? 32 : (BN == 64 ? 128 : 64);
+    const int KT = d->precision == HV_F32 ? 32 : ((BN == 64 && BC == 64) ? 128 : 64);
     long long chunk = (M + splits - 1) / splits;
     chunk = (chunk + KT - 1) / KT * KT;
     splits = (M + chunk - 1) / chunk;
@@ -742,9 +763,10 @@ static int launch_wgrad(const WgradK& k, const WgradPlan& pl, hipStream_t s) {
     constexpr bool F16 = sizeof(T) == 2;
     constexpr int KT = F16 ? 64 : 32, KT64 = F16 ? 128 : 32;
     dim3 grid(pl.splits, hv_cdiv(k.Cout, pl.BN), hv_cdiv(k.J, pl.BC));
-    if (pl.KT != (pl.BN == 64 ? KT64 : KT)) return HV_ERR_ARG;
+    if (pl.KT != ((pl.BN == 64 && pl.BC == 64) ? KT64 : KT)) return HV_ERR_ARG;
     if (pl.BN == 16) hipLaunchKernelGGL((wgrad_kernel<T, 16, 128, 1, 4, KT, FAST>), grid, dim3(256), 0, s, k);
     else if (pl.BN == 32) hipLaunchKernelGGL((wgrad_kernel<T, 32, 128, 1, 4, KT, FAST>), grid, dim3(256), 0, s, k);
+    else if (pl.BN == 64 && pl.BC == 256) hipLaunchKernelGGL((wgrad_kernel<T, 64, 256, 1, 4, KT, FAST>), grid, dim3(256), 0, s, k);
     else if (pl.BN == 64) hipLaunchKernelGGL((wgrad_kernel<T, 64, 64, 2, 2, KT64, FAST>), grid, dim3(256), 0, s, k);
     else if (pl.BC == 128) hipLaunchKernelGGL((wgrad_kernel<T, 128, 128, 2, 2, KT, FAST>), grid, dim3(256), 0, s, k);
     else hipLaunchKernelGGL((wgrad_kernel<T, 128, 64, 2, 2, KT, FAST>), grid, dim3(256), 0, s, k);

@@ -123,7 +123,7 @@ HALO_CASES = [
     (16, 128, 128, 32, 16, 3, 1, 1, 'elu', 0),
     (16, 128, 128, 32, 32, 3, 1, 1, 'none', 0),
     (16, 128, 128, 32, 64, 3, 1, 1, 'elu', 0),
-    (16, 128, 128, 32, 128, 3, 1, 1, 'none', 0),
+    (16, 128, 128, 64, 68, 3, 1, 1, 'none', 0),
     (4, 64, 64, 128, 256, 4, 2, 1, 'lrelu', 0),
     (16, 128, 128, 64, 128, 4, 2, 1, 'lrelu', 0),
 ]
