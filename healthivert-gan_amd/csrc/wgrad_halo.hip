@@ -8,9 +8,8 @@
 // (8+k-1) x (32+k-1) input patch (x BC channels) ONCE, transposed to [channel][row][pixel] fp16 in LDS so that the
 // contraction index (pixels along W) is contiguous for v_mfma_f32_16x16x32_f16.  A tap (r,q) is a shifted window of the
 // patch: row shift r is an address offset; column shift q is taken out of a 16-pixel aligned window in registers
-// (dword select for even q, v_alignbit for odd q) -- no misaligned LDS reads, no per-tap reloads.  Each wave owns two of
-// the eight rows and keeps all taps' accumulators; the four waves are summed in LDS and one slab per workgroup goes to
-// the deterministic slab reduction.
+// (dword select for even q, v_alignbit for odd q) -- no misaligned LDS reads, no per-tap reloads.  The taps are dealt
+// round-robin to the four waves; one slab per workgroup goes to the deterministic slab reduction.
 #include "hv_common.h"
 
 struct WHaloK {
@@ -19,6 +18,7 @@ struct WHaloK {
     int Ho, Wo, g_ld, g_coff, Cout, pad;
     int tiles_x, tiles_per_img, ntiles;
     long long slab;   // floats per slab = Cout * KS*KS * Cin
+    unsigned x_bytes, g_bytes;   // buffer descriptor ranges
 };
 
 __device__ __forceinline__ uint32_t hv_pack2(float a, float b) {
@@ -38,7 +38,10 @@ template <int Q> __device__ __forceinline__ f16x8 window_frag(const uint32_t (&w
     return *reinterpret_cast<f16x8*>(&u);
 }
 
-template <int KS, int BN, int BC>
+// TS (tap split): the taps are dealt round-robin to the four waves, each wave walks all eight rows -- few accumulator registers
+// (3-4 workgroups per CU) for 4x more LDS reads: wins where the tile count is small (PatchGAN logits layer); otherwise every
+// wave owns two of the eight rows, keeps all taps' accumulators and the four waves are summed in LDS at the end.
+template <int KS, int BN, int BC, bool TS>
 __global__ __launch_bounds__(256) void wgrad_halo_kernel(const WHaloK p) {
     constexpr int TH = 8, TW = 32, PH = TH + KS - 1, PWP = 40;   // 40 halfs per patch row: 32 + k - 1 <= 40, 16 B aligned
     constexpr int NT = BN / 16, CT = BC / 16, TAPS = KS * KS;
@@ -46,116 +49,198 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const WHaloK p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     _Float16* Gt = reinterpret_cast<_Float16*>(smem);             // [BN][TH][GROW]
     _Float16* Xt = Gt + BN * TH * GROW;                          // [BC][PH][PWP]
-    float* red = reinterpret_cast<float*>(smem);                  // [TAPS][BN][BC] after the tile loop (aliases Gt/Xt)
+    float* red = reinterpret_cast<float*>(smem);                  // [TAPS][BN][BC] after the tile loop (aliases Gt/Xt), !TS
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the wave index steers MFMA-only branches: it must be a scalar (MFMA ignores EXEC, so an exec-masked "skipped" block
+    // whose skip branch the compiler elides would still accumulate)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int co0 = blockIdx.y * BN, ci0 = blockIdx.z * BC;
-    f32x4 acc[TAPS][NT][CT];
+    // taps are dealt round-robin to the four waves (tap t belongs to wave t & 3, accumulator slot t >> 2): a wave keeps
+    // only TAPS/4 accumulator tiles (two or three workgroups fit a CU instead of one) and owns its taps' results outright
+    constexpr int SLOTS = TS ? (TAPS + 3) / 4 : TAPS;
+    f32x4 acc[SLOTS][NT][CT];
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t)
+    for (int t = 0; t < SLOTS; ++t)
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int c = 0; c < CT; ++c) acc[t][n][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    // Staging is software-pipelined through registers: the loads of tile i+1 are issued (branch-free buffer loads, lanes
+    // outside the image / channel range carry an out-of-range offset and read zeros) before the MFMAs of tile i, so the
+    // one workgroup a CU can hold (100-130 accumulator registers per lane) does not sit idle for an HBM round trip per tile.
+    constexpr int GU = (BN / 4) * TH * 4, XU = (BC / 4) * PH * 5;     // staging units of 8 pixels x 4 channels
+    constexpr int GPT = (GU + 255) / 256, XPT = (XU + 255) / 256;
+    const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t gsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.g), 0, p.g_bytes, 0x00020000);
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 rg[GPT][8], rx[XPT][8];
+    auto prefetch = [&](int tile) __attribute__((always_inline)) {
         const int n_img = tile / p.tiles_per_img, tr = tile - n_img * p.tiles_per_img;
         const int oy0 = (tr / p.tiles_x) * TH, ox0 = (tr % p.tiles_x) * TW;
-        __syncthreads();   // previous tile's MFMA reads are done
-        // ---- stage g: units = (BN/4 channel groups) x TH rows x 4 runs of 8 pixels
-        for (int u = tid; u < (BN / 4) * TH * 4; u += 256) {
+#pragma unroll
+        for (int i = 0; i < GPT; ++i) {
+            const int u = tid + i * 256;
             const int cg = u % (BN / 4), rr = u / (BN / 4), run = rr & 3, ty = rr >> 2;
-            const int oy = oy0 + ty, co = co0 + cg * 4;
-            float4 v[8];
+            const int oy = oy0 + ty, co = co0 + cg * 4, ox = ox0 + run * 8;
+            const bool rok = u < GU && oy < p.Ho && co < p.Cout;
+            const unsigned base = (unsigned)(((n_img * p.Ho + oy) * p.Wo + ox) * p.g_ld + p.g_coff + co) * 4u;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int ox = ox0 + run * 8 + e;
-                v[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (oy < p.Ho && ox < p.Wo && co < p.Cout)
-                    v[e] = *reinterpret_cast<const float4*>(p.g + ((long long)(n_img * p.Ho + oy) * p.Wo + ox) * p.g_ld + p.g_coff + co);
-            }
-            const float* f = reinterpret_cast<const float*>(v);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                uint4 h = make_uint4(hv_pack2(f[c], f[4 + c]), hv_pack2(f[8 + c], f[12 + c]), hv_pack2(f[16 + c], f[20 + c]), hv_pack2(f[24 + c], f[28 + c]));
-                *reinterpret_cast<uint4*>(Gt + ((cg * 4 + c) * TH + ty) * GROW + run * 8) = h;
-            }
+            for (int e = 0; e < 8; ++e)
+                rg[i][e] = __builtin_amdgcn_raw_buffer_load_b128(gsrc, (rok && ox + e < p.Wo) ? base + (unsigned)(e * p.g_ld) * 4u : 0x80000000u, 0, 0);
         }
-        // ---- stage the x patch: units = (BC/4) x PH rows x 5 runs of 8 patch columns
-        const float* ximg = p.x + (long long)n_img * p.img_stride + p.x_coff;
-        for (int u = tid; u < (BC / 4) * PH * 5; u += 256) {
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            const int u = tid + i * 256;
             const int cg = u % (BC / 4), rr = u / (BC / 4), run = rr % 5, py = rr / 5;
-            const int hi = oy0 - p.pad + py, ci = ci0 + cg * 4;
-            float4 v[8];
+            const int hi = oy0 - p.pad + py, ci = ci0 + cg * 4, wi0 = ox0 - p.pad + run * 8;
+            const bool rok = u < XU && (unsigned)hi < (unsigned)p.Hl && ci < p.Cin;
+            const unsigned base = (unsigned)(n_img * p.img_stride + p.x_coff + (hi >> p.in_shift) * p.Wp * p.x_ld + ci) * 4u;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const int wi = ox0 - p.pad + run * 8 + e;
-                v[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if ((unsigned)hi < (unsigned)p.Hl && (unsigned)wi < (unsigned)p.Wl && ci < p.Cin)
-                    v[e] = *reinterpret_cast<const float4*>(ximg + (long long)((hi >> p.in_shift) * p.Wp + (wi >> p.in_shift)) * p.x_ld + ci);
-            }
-            const float* f = reinterpret_cast<const float*>(v);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                uint4 h = make_uint4(hv_pack2(f[c], f[4 + c]), hv_pack2(f[8 + c], f[12 + c]), hv_pack2(f[16 + c], f[20 + c]), hv_pack2(f[24 + c], f[28 + c]));
-                *reinterpret_cast<uint4*>(Xt + ((cg * 4 + c) * PH + py) * PWP + run * 8) = h;
+                const int wi = wi0 + e;
+                rx[i][e] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, (rok && (unsigned)wi < (unsigned)p.Wl) ? base + (unsigned)((wi >> p.in_shift) * p.x_ld) * 4u : 0x80000000u, 0, 0);
             }
         }
+    };
+    auto pack4 = [&](const u32x4 (&v)[8], int c) __attribute__((always_inline)) {
+        auto f = [&](int e) { return __uint_as_float(c == 0 ? v[e].x : c == 1 ? v[e].y : c == 2 ? v[e].z : v[e].w); };
+        return make_uint4(hv_pack2(f(0), f(1)), hv_pack2(f(2), f(3)), hv_pack2(f(4), f(5)), hv_pack2(f(6), f(7)));
+    };
+    auto flush = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < GPT; ++i) {
+            const int u = tid + i * 256;
+            if (u >= GU) continue;
+            const int cg = u % (BN / 4), rr = u / (BN / 4), run = rr & 3, ty = rr >> 2;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) *reinterpret_cast<uint4*>(Gt + ((cg * 4 + c) * TH + ty) * GROW + run * 8) = pack4(rg[i], c);
+        }
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            const int u = tid + i * 256;
+            if (u >= XU) continue;
+            const int cg = u % (BC / 4), rr = u / (BC / 4), run = rr % 5, py = rr / 5;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) *reinterpret_cast<uint4*>(Xt + ((cg * 4 + c) * PH + py) * PWP + run * 8) = pack4(rx[i], c);
+        }
+    };
+
+    if ((int)blockIdx.x < p.ntiles) prefetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        __syncthreads();   // previous tile's MFMA reads are done
+        flush();
         __syncthreads();
-        // ---- MFMA: this wave's rows ty = wave, wave + 4
-#pragma unroll
-        for (int rrow = 0; rrow < 2; ++rrow) {
-            const int ty = wave + rrow * 4;
-            f16x8 gf[NT];
-#pragma unroll
-            for (int n = 0; n < NT; ++n) gf[n] = *reinterpret_cast<const f16x8*>(Gt + ((n * 16 + (lane & 15)) * TH + ty) * GROW + (lane >> 4) * 8);
-#pragma unroll
-            for (int r = 0; r < KS; ++r) {
-#pragma unroll
-                for (int c = 0; c < CT; ++c) {
-                    const _Float16* row = Xt + ((c * 16 + (lane & 15)) * PH + ty + r) * PWP + (lane >> 4) * 8;
-                    uint32_t w[8];
-                    *reinterpret_cast<uint4*>(&w[0]) = *reinterpret_cast<const uint4*>(row);
-                    *reinterpret_cast<uint4*>(&w[4]) = *reinterpret_cast<const uint4*>(row + 8);
-#pragma unroll
-                    for (int q = 0; q < KS; ++q) {
-                        f16x8 xf;
-                        if (q == 0) xf = window_frag<0>(w);
-                        else if (q == 1) xf = window_frag<1>(w);
-                        else if (q == 2) xf = window_frag<2>(w);
-                        else if (q == 3) xf = window_frag<3>(w);
-                        else xf = window_frag<4>(w);
-#pragma unroll
-                        for (int n = 0; n < NT; ++n)
-                            acc[r * KS + q][n][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gf[n], xf, acc[r * KS + q][n][c], 0, 0, 0);
+        if (tile + (int)gridDim.x < p.ntiles) prefetch(tile + gridDim.x);   // next tile's loads fly behind this tile's MFMAs
+        if (TS) {
+            // ---- MFMA: every wave walks all rows for its own taps
+    #pragma unroll 1
+            for (int ty = 0; ty < TH; ++ty) {
+                f16x8 gf[NT];
+    #pragma unroll
+                for (int n = 0; n < NT; ++n) gf[n] = *reinterpret_cast<const f16x8*>(Gt + ((n * 16 + (lane & 15)) * TH + ty) * GROW + (lane >> 4) * 8);
+    #pragma unroll
+                for (int r = 0; r < KS; ++r) {
+    #pragma unroll
+                    for (int c = 0; c < CT; ++c) {
+                        const _Float16* row = Xt + ((c * 16 + (lane & 15)) * PH + ty + r) * PWP + (lane >> 4) * 8;
+                        uint32_t w[8];
+                        *reinterpret_cast<uint4*>(&w[0]) = *reinterpret_cast<const uint4*>(row);
+                        *reinterpret_cast<uint4*>(&w[4]) = *reinterpret_cast<const uint4*>(row + 8);
+    #pragma unroll
+                        for (int q = 0; q < KS; ++q) {
+                            const int t = r * KS + q;
+                            if ((t & 3) != wave) continue;     // wave-uniform
+                            f16x8 xf;
+                            if (q == 0) xf = window_frag<0>(w);
+                            else if (q == 1) xf = window_frag<1>(w);
+                            else if (q == 2) xf = window_frag<2>(w);
+                            else if (q == 3) xf = window_frag<3>(w);
+                            else xf = window_frag<4>(w);
+    #pragma unroll
+                            for (int n = 0; n < NT; ++n)
+                                acc[t >> 2][n][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gf[n], xf, acc[t >> 2][n][c], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        } else {
+            // ---- MFMA: this wave's rows ty = wave, wave + 4
+    #pragma unroll
+            for (int rrow = 0; rrow < 2; ++rrow) {
+                const int ty = wave + rrow * 4;
+                f16x8 gf[NT];
+    #pragma unroll
+                for (int n = 0; n < NT; ++n) gf[n] = *reinterpret_cast<const f16x8*>(Gt + ((n * 16 + (lane & 15)) * TH + ty) * GROW + (lane >> 4) * 8);
+    #pragma unroll
+                for (int r = 0; r < KS; ++r) {
+    #pragma unroll
+                    for (int c = 0; c < CT; ++c) {
+                        const _Float16* row = Xt + ((c * 16 + (lane & 15)) * PH + ty + r) * PWP + (lane >> 4) * 8;
+                        uint32_t w[8];
+                        *reinterpret_cast<uint4*>(&w[0]) = *reinterpret_cast<const uint4*>(row);
+                        *reinterpret_cast<uint4*>(&w[4]) = *reinterpret_cast<const uint4*>(row + 8);
+    #pragma unroll
+                        for (int q = 0; q < KS; ++q) {
+                            f16x8 xf;
+                            if (q == 0) xf = window_frag<0>(w);
+                            else if (q == 1) xf = window_frag<1>(w);
+                            else if (q == 2) xf = window_frag<2>(w);
+                            else if (q == 3) xf = window_frag<3>(w);
+                            else xf = window_frag<4>(w);
+    #pragma unroll
+                            for (int n = 0; n < NT; ++n)
+                                acc[r * KS + q][n][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gf[n], xf, acc[r * KS + q][n][c], 0, 0, 0);
+                        }
                     }
                 }
             }
         }
     }
-    // ---- sum the four waves in LDS (fixed order), write one slab per workgroup
-    __syncthreads();
-    for (int wv = 0; wv < 4; ++wv) {
-        if (wave == wv) {
-#pragma unroll
-            for (int t = 0; t < TAPS; ++t)
-#pragma unroll
-                for (int n = 0; n < NT; ++n)
-#pragma unroll
-                    for (int c = 0; c < CT; ++c)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            // D layout: row (= co) = (lane>>4)*4 + r, col (= ci) = lane & 15
-                            float* d = red + (t * BN + n * 16 + (lane >> 4) * 4 + r) * BC + c * 16 + (lane & 15);
-                            *d = wv == 0 ? acc[t][n][c][r] : *d + acc[t][n][c][r];
-                        }
+    if (TS) {
+        // ---- one slab per workgroup: every wave writes its own taps (D layout: row (= co) = (lane>>4)*4 + r, col (= ci) = lane & 15)
+        float* out = p.slabs + (long long)blockIdx.x * p.slab;
+    #pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl) {
+            const int t = sl * 4 + wave;
+            if (t >= TAPS) continue;
+    #pragma unroll
+            for (int n = 0; n < NT; ++n)
+    #pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    const int ci = ci0 + c * 16 + (lane & 15);
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int co = co0 + n * 16 + (lane >> 4) * 4 + r;
+                        if (co < p.Cout && ci < p.Cin) out[((long long)co * TAPS + t) * p.Cin + ci] = acc[sl][n][c][r];
+                    }
+                }
         }
+    } else {
+        // ---- sum the four waves in LDS (fixed order), write one slab per workgroup
         __syncthreads();
-    }
-    float* out = p.slabs + (long long)blockIdx.x * p.slab;
-    for (int e = tid; e < TAPS * BN * BC; e += 256) {
-        const int ci = e % BC, r2 = e / BC, co = r2 % BN, t = r2 / BN;
-        if (co0 + co < p.Cout && ci0 + ci < p.Cin) out[((long long)(co0 + co) * TAPS + t) * p.Cin + ci0 + ci] = red[e];
+        for (int wv = 0; wv < 4; ++wv) {
+            if (wave == wv) {
+    #pragma unroll
+                for (int t = 0; t < TAPS; ++t)
+    #pragma unroll
+                    for (int n = 0; n < NT; ++n)
+    #pragma unroll
+                        for (int c = 0; c < CT; ++c)
+    #pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                // D layout: row (= co) = (lane>>4)*4 + r, col (= ci) = lane & 15
+                                float* d = red + (t * BN + n * 16 + (lane >> 4) * 4 + r) * BC + c * 16 + (lane & 15);
+                                *d = wv == 0 ? acc[t][n][c][r] : *d + acc[t][n][c][r];
+                            }
+            }
+            __syncthreads();
+        }
+        float* out = p.slabs + (long long)blockIdx.x * p.slab;
+        for (int e = tid; e < TAPS * BN * BC; e += 256) {
+            const int ci = e % BC, r2 = e / BC, co = r2 % BN, t = r2 / BN;
+            if (co0 + co < p.Cout && ci0 + ci < p.Cin) out[((long long)(co0 + co) * TAPS + t) * p.Cin + ci0 + ci] = red[e];
+        }
     }
 }
 
@@ -185,9 +270,9 @@ size_t hv_wgrad_halo_workspace_bytes(const hv_wgrad_desc* d) {
     return (size_t)pl.gx * d->Cout * d->KH * d->KW * d->Cin * sizeof(float);
 }
 
-template <int KS, int BN, int BC>
+template <int KS, int BN, int BC, bool TS = false>
 static int launch_wh(const WHaloK& k, const WHaloPlan& pl, const hv_wgrad_desc* d, hipStream_t s) {
-    auto kern = wgrad_halo_kernel<KS, BN, BC>;
+    auto kern = wgrad_halo_kernel<KS, BN, BC, TS>;
     static int lds_limit = 48 * 1024;
     if ((int)pl.lds > lds_limit) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
@@ -215,9 +300,11 @@ int hv_wgrad_halo(const hv_wgrad_desc* d, int* nslabs, hipStream_t s) {
     k.Ho = d->Ho; k.Wo = d->Wo; k.g_ld = d->g_ld; k.g_coff = d->g_coff; k.Cout = d->Cout; k.pad = d->pad;
     k.tiles_x = hv_cdiv(d->Wo, 32); k.tiles_per_img = k.tiles_x * hv_cdiv(d->Ho, 8); k.ntiles = k.tiles_per_img * d->B;
     k.slab = (long long)d->Cout * d->KH * d->KW * d->Cin;
+    k.x_bytes = (unsigned)((size_t)d->B * k.img_stride * sizeof(float));
+    k.g_bytes = (unsigned)((size_t)d->B * d->Ho * d->Wo * d->g_ld * sizeof(float));
     *nslabs = pl.gx;
     if (d->KH == 5) return launch_wh<5, 16, 16>(k, pl, d, s);
-    if (d->KH == 4) return pl.BC == 16 ? launch_wh<4, 16, 16>(k, pl, d, s) : launch_wh<4, 16, 32>(k, pl, d, s);
+    if (d->KH == 4) return pl.BC == 16 ? launch_wh<4, 16, 16, true>(k, pl, d, s) : launch_wh<4, 16, 32, true>(k, pl, d, s);
     if (pl.BN == 16 && pl.BC == 16) return launch_wh<3, 16, 16>(k, pl, d, s);
     if (pl.BN == 16) return launch_wh<3, 16, 32>(k, pl, d, s);
     if (pl.BC == 16) return launch_wh<3, 32, 16>(k, pl, d, s);
