@@ -205,17 +205,23 @@ __global__ __launch_bounds__(256) void conv_halo2_kernel(const HaloK p) {
 }
 
 template <int TH, int TW, int BN, int WM, int WN, int CK, int BSTEP, int SPAN, int D>
-static int launch2(HaloK& k, hipStream_t s) {
+static int launch2(HaloK& k, hipStream_t s, int th0 = 8, int tw0 = TW) {
     constexpr int LDP = CK + ((CK >= 32 && BSTEP == 1) ? 16 : 8);
     constexpr int PHM = (TH - 1) * BSTEP + SPAN, PWM = (TW - 1) * BSTEP + SPAN;
     int tiles = 0;
     for (int c = 0; c < k.ncls; ++c) {
         HaloCls& C = k.cls[c];
-        if (C.PH > PHM || C.PW > PWM || C.ntaps != SPAN * SPAN) return HV_ERR_UNSUPPORTED;
+        // the caller sized the patch for its th0 x tw0 tile: re-size it for this instantiation's tile
+        const int ph = C.PH - (th0 - TH) * k.bstep, pw = C.PW - (tw0 - TW) * k.bstep;
+        if (ph > PHM || pw > PWM || C.ntaps != SPAN * SPAN) return HV_ERR_UNSUPPORTED;
         C.tiles_x = hv_cdiv(C.Wc, TW);
         C.tiles = C.tiles_x * hv_cdiv(C.Hc, TH);
         C.t0 = tiles;
         tiles += C.tiles * k.B;
+    }
+    for (int c = 0; c < k.ncls; ++c) {
+        k.cls[c].PH -= (th0 - TH) * k.bstep;
+        k.cls[c].PW -= (tw0 - TW) * k.bstep;
     }
     const size_t lds = (size_t)2 * PHM * PWM * LDP * sizeof(_Float16);
     auto kern = conv_halo2_kernel<TH, TW, BN, WM, WN, CK, BSTEP, SPAN, D>;
@@ -240,6 +246,12 @@ int hv_halo2_launch(HaloK& k, int TW, int KH, int KW, int maxpatch, hipStream_t 
         if (k.cls[c].ntaps != ntaps) return HV_ERR_UNSUPPORTED;
     // PatchGAN layers: 4x4 filters, Cout >= 128
     if (ntaps == 16 && KH == 4 && KW == 4 && TW == 16 && k.Cout > 64 && k.bstep == 1 && k.Cin % 32 == 0) return launch2<8, 16, 128, 1, 4, 32, 1, 4, 4>(k, s);
+    // PatchGAN logits layer (512 -> 1): the single output channel rides in a 16-channel MFMA tile, the input is staged once
+    if (ntaps == 16 && KH == 4 && KW == 4 && TW == 16 && k.Cout <= 16 && k.bstep == 1 && k.Cin % 32 == 0) {
+        // small maps: 4-row tiles double the workgroup count (31 x 31 logits: 128 -> 256 workgroups)
+        if ((long long)k.B * hv_cdiv(k.cls[0].Hc, 8) * hv_cdiv(k.cls[0].Wc, 16) < 256) return launch2<4, 16, 16, 4, 1, 32, 1, 4, 4>(k, s, 8, 16);
+        return launch2<8, 16, 16, 4, 1, 32, 1, 4, 4>(k, s);
+    }
     // data gradient of the 4x4 stride-2 layers: four output-parity classes of 2x2 taps each
     static const int m4 = getenv("HV_HALO2_S2T") ? atoi(getenv("HV_HALO2_S2T")) : 1;
     if (m4 && ntaps == 4 && KH == 4 && KW == 4 && k.bstep == 1 && k.Cin % 32 == 0 && k.Cout > 32) {

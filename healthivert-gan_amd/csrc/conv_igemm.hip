@@ -26,6 +26,7 @@ int hv_conv2d_halo(const hv_conv_desc* d, const void* w_f16, hipStream_t s);   /
 size_t hv_wgrad_halo_workspace_bytes(const hv_wgrad_desc* d);                  // wgrad_halo.hip
 int hv_wgrad_halo(const hv_wgrad_desc* d, int* nslabs, hipStream_t s);
 int hv_conv2d_narrow(const hv_conv_desc* d, hipStream_t s);                     // conv_narrow.hip
+int hv_conv2d_thin_in(const hv_conv_desc* d, hipStream_t s);
 
 struct ConvCls {
     int ph, pw, Hc, Wc, ntaps, Ktot, m0, mcount;
@@ -357,8 +358,16 @@ extern "C" int hv_conv2d(const hv_conv_desc* d, void* stream) {
         return HV_ERR_UNSUPPORTED;
     if (d->H > 16000 || d->W > 16000 || (d->KH - 1) * d->dil > 120 || (d->KW - 1) * d->dil > 120) return HV_ERR_UNSUPPORTED;
 
-    if (d->Cout == 1 && !d->transposed) {   // single-channel heads / logits: VALU kernels (conv_narrow.hip)
+    // single-channel heads / logits: VALU kernels (conv_narrow.hip), except where the halo-tiled MFMA kernel stages the input
+    // once instead of once per tap (many input channels, fp16 mode)
+    static const int narrow_max_cin = getenv("HV_NARROW_MAX_CIN") ? atoi(getenv("HV_NARROW_MAX_CIN")) : 15;   // A/B knob
+    const bool halo_ok = d->precision == HV_F16 && d->w_f16 && d->dil == 1 && (d->Cin & 15) == 0 && !d->w_bstride && !d->ch_scale;
+    if (d->Cout == 1 && !d->transposed && !(halo_ok && d->Cin > narrow_max_cin)) {
         const int rc = hv_conv2d_narrow(d, (hipStream_t)stream);
+        if (rc != HV_ERR_UNSUPPORTED) return rc;
+    }
+    if (d->Cin <= 4 && !d->transposed) {   // image-like inputs: direct fp32 VALU kernel, output-write bound (conv_narrow.hip)
+        const int rc = hv_conv2d_thin_in(d, (hipStream_t)stream);
         if (rc != HV_ERR_UNSUPPORTED) return rc;
     }
     if (d->precision == HV_F16 && d->w_f16) {   // halo-tiled fast path (conv_halo.hip) when the shape qualifies

@@ -37,34 +37,86 @@ __device__ __forceinline__ void narrow_store(const NarrowK& p, long long pix, fl
 }
 
 // LPP lanes cooperate on one output pixel: lanes split the channels (16 B each), taps are looped.
+// grid (pixel blocks of one output row, B*Ho rows): no per-pixel index divisions.
 template <int LPP>
 __global__ __launch_bounds__(256) void narrow_fwd_kernel(const NarrowK p) {
-    const long long n = (long long)p.B * p.Ho * p.Wo;
     const int sub = threadIdx.x % LPP;
-    constexpr int PPB = 256 / LPP;   // pixels per block pass
-    for (long long i0 = (long long)blockIdx.x * PPB; i0 < n; i0 += (long long)gridDim.x * PPB) {
-        const long long i = i0 + threadIdx.x / LPP;
-        float acc = 0.f;
-        if (i < n) {
-            const int ox = (int)(i % p.Wo);
-            const long long r2 = i / p.Wo;
-            const int oy = (int)(r2 % p.Ho), b = (int)(r2 / p.Ho);
-            const float* ximg = p.x + (long long)b * p.img_stride + p.x_coff;
-            for (int r = 0; r < p.KH; ++r)
-                for (int s = 0; s < p.KW; ++s) {
-                    int hi, wi;
-                    if (!narrow_tap(p, oy, ox, r, s, hi, wi)) continue;
-                    const float* xp = ximg + (long long)((hi >> p.in_shift) * p.Wp + (wi >> p.in_shift)) * p.x_ld;
-                    const float* wp = p.w + (r * p.KW + s) * p.Cin;
-                    for (int c = sub * 4; c < p.Cin; c += LPP * 4) {
-                        const float4 xv = *reinterpret_cast<const float4*>(xp + c), wv = *reinterpret_cast<const float4*>(wp + c);
-                        acc += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
-                    }
+    constexpr int PPB = 256 / LPP;   // pixels per block
+    const int row = blockIdx.y, b = row / p.Ho, oy = row - b * p.Ho;
+    const int ox = blockIdx.x * PPB + threadIdx.x / LPP;
+    float acc = 0.f;
+    if (ox < p.Wo) {
+        const float* ximg = p.x + (long long)b * p.img_stride + p.x_coff;
+        for (int r = 0; r < p.KH; ++r)
+            for (int s = 0; s < p.KW; ++s) {
+                int hi, wi;
+                if (!narrow_tap(p, oy, ox, r, s, hi, wi)) continue;
+                const float* xp = ximg + (long long)((hi >> p.in_shift) * p.Wp + (wi >> p.in_shift)) * p.x_ld;
+                const float* wp = p.w + (r * p.KW + s) * p.Cin;
+                for (int c = sub * 4; c < p.Cin; c += LPP * 4) {
+                    const float4 xv = *reinterpret_cast<const float4*>(xp + c), wv = *reinterpret_cast<const float4*>(wp + c);
+                    acc += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
                 }
-        }
+            }
+    }
 #pragma unroll
-        for (int o = LPP / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-        if (sub == 0 && i < n) narrow_store(p, i, acc);
+    for (int o = LPP / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (sub == 0 && ox < p.Wo) narrow_store(p, (long long)row * p.Wo + ox, acc);
+}
+
+// Forward convolution of a 1-channel image into 4..64 channels with a KS x KS filter (the PatchGAN stem: 1 -> 64, 4x4, stride 2).
+// K = taps is 16, the layer is bound by writing its output (67 MB at B=16): fp32 VALU, exact in both precision modes.
+// One lane = one pixel x 4 output channels (16 lanes write a pixel's 256 B); the lane's filter taps live in registers (staged
+// once per block through LDS), a block walks PXB pixel groups of one output row.  grid (row segments, B*Ho rows).
+template <int KS, int PXB>
+__global__ __launch_bounds__(256) void thin1_fwd_kernel(const NarrowK p) {
+    constexpr int TAPS = KS * KS;
+    __shared__ __attribute__((aligned(16))) float wl[TAPS * 64];        // [tap][Cout]
+    const int CG = p.Cout >> 2;                                         // Cout a power of two <= 64
+    for (int e = threadIdx.x; e < TAPS * p.Cout; e += 256) {
+        const int co = e % p.Cout, t = e / p.Cout;
+        wl[e] = p.w[(long long)co * TAPS + t];
+    }
+    __syncthreads();
+    const int cg = threadIdx.x % CG, pl = threadIdx.x / CG, PPB = 256 / CG;
+    float4 wr[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) wr[t] = *reinterpret_cast<const float4*>(wl + t * p.Cout + cg * 4);
+    float bias[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bias[e] = p.bias[cg * 4 + e];
+    }
+    const int row = blockIdx.y, b = row / p.Ho, oy = row - b * p.Ho;
+    const float* ximg = p.x + (long long)b * p.img_stride + p.x_coff;
+#pragma unroll 2
+    for (int it = 0; it < PXB; ++it) {
+        const int ox = (blockIdx.x * PXB + it) * PPB + pl;
+        if (ox >= p.Wo) break;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < KS; ++r) {
+            const int hi = oy * p.stride - p.pad + r;
+            const bool rok = (unsigned)hi < (unsigned)p.H;
+#pragma unroll
+            for (int q = 0; q < KS; ++q) {
+                const int wi = ox * p.stride - p.pad + q;
+                float xv = 0.f;
+                if (rok && (unsigned)wi < (unsigned)p.W) xv = ximg[(long long)((hi >> p.in_shift) * p.Wp + (wi >> p.in_shift)) * p.x_ld];
+                const float4 wv = wr[r * KS + q];
+                acc.x += xv * wv.x; acc.y += xv * wv.y; acc.z += xv * wv.z; acc.w += xv * wv.w;
+            }
+        }
+        float* yp = p.y + ((long long)row * p.Wo + ox) * p.y_ld + p.y_coff + cg * 4;
+        float o[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float t = o[e] * p.alpha + bias[e];
+            if (p.accumulate == 2) t += yp[e];
+            t = hv_act(t, p.act);
+            o[e] = p.accumulate == 1 ? yp[e] + t : t;
+        }
+        *reinterpret_cast<float4*>(yp) = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
 
@@ -78,19 +130,41 @@ int hv_conv2d_narrow(const hv_conv_desc* d, hipStream_t s) {
     k.KH = d->KH; k.KW = d->KW; k.stride = d->stride; k.pad = d->pad; k.transposed = d->transposed;
     k.Ho = d->Ho; k.Wo = d->Wo; k.y_ld = d->y_ld; k.y_coff = d->y_coff; k.Cout = d->Cout;
     k.alpha = d->alpha; k.act = d->act; k.accumulate = d->accumulate;
-    const long long npix = (long long)d->B * d->Ho * d->Wo;
     if (d->Cout == 1 && (d->Cin & 3) == 0 && !(d->x_ld & 3) && !(d->x_coff & 3) && !((uintptr_t)d->x & 15) && !((uintptr_t)d->w & 15)) {
         const int c4 = d->Cin / 4;
         const int lpp = c4 >= 64 ? 64 : c4 >= 16 ? 16 : c4 >= 4 ? 4 : 1;
-        long long nb = (npix + 256 / lpp - 1) / (256 / lpp);
-        if (nb > 65536) nb = 65536;
+        if ((long long)d->B * d->Ho > 65535) return HV_ERR_UNSUPPORTED;
+        const dim3 grid(hv_cdiv(d->Wo, 256 / lpp), d->B * d->Ho);
         hv_path_note = 1;
-        if (lpp == 64) hipLaunchKernelGGL((narrow_fwd_kernel<64>), dim3((int)nb), dim3(256), 0, s, k);
-        else if (lpp == 16) hipLaunchKernelGGL((narrow_fwd_kernel<16>), dim3((int)nb), dim3(256), 0, s, k);
-        else if (lpp == 4) hipLaunchKernelGGL((narrow_fwd_kernel<4>), dim3((int)nb), dim3(256), 0, s, k);
-        else hipLaunchKernelGGL((narrow_fwd_kernel<1>), dim3((int)nb), dim3(256), 0, s, k);
+        if (lpp == 64) hipLaunchKernelGGL((narrow_fwd_kernel<64>), grid, dim3(256), 0, s, k);
+        else if (lpp == 16) hipLaunchKernelGGL((narrow_fwd_kernel<16>), grid, dim3(256), 0, s, k);
+        else if (lpp == 4) hipLaunchKernelGGL((narrow_fwd_kernel<4>), grid, dim3(256), 0, s, k);
+        else hipLaunchKernelGGL((narrow_fwd_kernel<1>), grid, dim3(256), 0, s, k);
         HV_LAUNCH_CHECK();
         return HV_OK;
     }
     return HV_ERR_UNSUPPORTED;
+}
+
+// 1-channel image into 4..64 channels, 4x4 filter, forward only; w is the fp32 filter [Cout][taps][1]
+int hv_conv2d_thin_in(const hv_conv_desc* d, hipStream_t s) {
+    if (d->transposed || d->w_bstride || d->ch_scale || d->dil != 1 || d->Cin != 1 || d->KH != 4 || d->KW != 4 || d->Cout < 4 || d->Cout > 64 ||
+        (d->Cout & (d->Cout - 1)))
+        return HV_ERR_UNSUPPORTED;   // Cout a power of two: 256 threads = whole pixels
+    if ((d->y_ld & 3) || (d->y_coff & 3) || ((uintptr_t)d->y & 15) || (long long)d->B * d->Ho > 65535) return HV_ERR_UNSUPPORTED;
+    NarrowK k;
+    const int Hp = d->H >> d->in_shift, Wp = d->W >> d->in_shift;
+    k.x = d->x; k.w = d->w; k.bias = d->bias; k.y = d->y;
+    k.B = d->B; k.H = d->H; k.W = d->W; k.in_shift = d->in_shift; k.Wp = Wp; k.img_stride = Hp * Wp * d->x_ld;
+    k.x_ld = d->x_ld; k.x_coff = d->x_coff; k.Cin = d->Cin;
+    k.KH = d->KH; k.KW = d->KW; k.stride = d->stride; k.pad = d->pad; k.transposed = 0;
+    k.Ho = d->Ho; k.Wo = d->Wo; k.y_ld = d->y_ld; k.y_coff = d->y_coff; k.Cout = d->Cout;
+    k.alpha = d->alpha; k.act = d->act; k.accumulate = d->accumulate;
+    constexpr int PXB = 8;
+    const int ppb = 256 / (d->Cout / 4);
+    const dim3 grid(hv_cdiv(d->Wo, ppb * PXB), d->B * d->Ho);
+    hv_path_note = 4;
+    hipLaunchKernelGGL((thin1_fwd_kernel<4, PXB>), grid, dim3(256), 0, s, k);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
 }

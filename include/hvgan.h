@@ -38,7 +38,8 @@ enum { HV_NORM_NONE = 0, HV_NORM_BATCH = 1, HV_NORM_INSTANCE = 2 };
 int hv_version(void);
 const char* hv_arch(void); /* "gfx950" */
 /* which kernel family the calling thread's most recent hv_conv2d / hv_conv2d_wgrad launched (profiling labels):
- * 0 conv_igemm_kernel, 1 narrow_fwd_kernel, 2 conv_halo_kernel, 3 conv_halo2_kernel, 10 wgrad_kernel, 11 wgrad_halo_kernel */
+ * 0 conv_igemm_kernel, 1 narrow_fwd_kernel, 2 conv_halo_kernel, 3 conv_halo2_kernel, 4 thin1_fwd_kernel, 10 wgrad_kernel,
+ * 11 wgrad_halo_kernel */
 int hv_last_kernel_path(void);
 
 /* ---------------------------------------------------------------- convolution (implicit GEMM on MFMA)
