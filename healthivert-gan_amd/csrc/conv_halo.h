@@ -10,7 +10,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 struct HaloCls {
     int ph, pw, Hc, Wc, ntaps, tiles_x, tiles, t0;   // t0 = first tile index of the class in the grid
     int dh_min, dw_min, PH, PW;
-    uint32_t taps[16];   // (dh-dh_min) | (dw-dw_min)<<8 | widx<<16
+    uint32_t taps[25];   // (dh-dh_min) | (dw-dw_min)<<8 | widx<<16   (conv_halo_kernel: at most 16, conv_halo2_kernel: up to 5x5)
 };
 struct HaloK {
     const float* x; const _Float16* w; const float* bias; float* y;

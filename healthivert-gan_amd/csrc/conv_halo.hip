@@ -290,7 +290,7 @@ static int dispatch_halo_bn(HaloK& k, int maxpatch, hipStream_t s) {
 // Called by hv_conv2d when the fp16 weight copy is present and the shape qualifies; returns HV_ERR_UNSUPPORTED to
 // fall back to the gather kernel.
 int hv_conv2d_halo(const hv_conv_desc* d, const void* w_f16, hipStream_t s) {
-    if (d->dil != 1 || (d->Cin & 15) || d->w_bstride || d->ch_scale || d->KH * d->KW > 16 || d->stride > 2) return HV_ERR_UNSUPPORTED;
+    if (d->dil != 1 || (d->Cin & 3) || d->w_bstride || d->ch_scale || d->KH * d->KW > 25 || d->stride > 2) return HV_ERR_UNSUPPORTED;
     if ((d->x_ld & 3) || (d->x_coff & 3) || ((uintptr_t)d->x & 15) || ((uintptr_t)w_f16 & 15)) return HV_ERR_UNSUPPORTED;
     HaloK k;
     const int Hp = d->H >> d->in_shift, Wp = d->W >> d->in_shift;
@@ -303,7 +303,7 @@ int hv_conv2d_halo(const hv_conv_desc* d, const void* w_f16, hipStream_t s) {
     k.Cout = d->Cout; k.w_row = d->KH * d->KW * d->Cin; k.y_ld = d->y_ld; k.y_coff = d->y_coff; k.Ho = d->Ho; k.Wo = d->Wo;
     k.alpha = d->alpha; k.act = d->act; k.accumulate = d->accumulate;
     k.vec_store = ((d->y_ld & 3) == 0 && (d->y_coff & 3) == 0 && ((uintptr_t)d->y & 15) == 0) ? 1 : 0;
-    int dhs[4][16], dws[4][16], wis[4][16];
+    int dhs[4][25], dws[4][25], wis[4][25];
     if (!d->transposed) {
         k.ncls = 1; k.bstep = d->stride; k.boff = -d->pad; k.ostep = 1;
         HaloCls& c = k.cls[0];
@@ -365,6 +365,7 @@ int hv_conv2d_halo(const hv_conv_desc* d, const void* w_f16, hipStream_t s) {
         const int rc = hv_halo2_launch(k, TW, d->KH, d->KW, maxpatch, s);
         if (rc != HV_ERR_UNSUPPORTED) return rc;
     }
+    if ((d->Cin & 15) || d->KH * d->KW > 16) return HV_ERR_UNSUPPORTED;   // conv_halo_kernel: whole 16-channel chunks, 16-entry tap table
     if (k.bstep == 2) return ck32 ? dispatch_halo_bn<8, 16, 32, true>(k, maxpatch, s) : dispatch_halo_bn<8, 16, 16, true>(k, maxpatch, s);
     if (small_tile) return ck32 ? dispatch_halo_bn<8, 16, 32, false>(k, maxpatch, s) : dispatch_halo_bn<8, 16, 16, false>(k, maxpatch, s);
     return ck32 ? dispatch_halo_bn<8, 32, 32, false>(k, maxpatch, s) : dispatch_halo_bn<8, 32, 16, false>(k, maxpatch, s);

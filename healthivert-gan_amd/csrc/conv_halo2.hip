@@ -111,9 +111,25 @@ __global__ __launch_bounds__(256) void conv_halo2_kernel(const HaloK p) {
         pvo[i] = (in && (unsigned)hi < (unsigned)p.Hl && (unsigned)wi < (unsigned)p.Wl)
                      ? xbase + (unsigned)(((hi >> p.in_shift) * p.Wp + (wi >> p.in_shift)) * p.x_ld + c4 * 4) * 4u : HV_OOB;
     }
+    // ragged channel counts (Cin % CK != 0, CK == 16 only: a lane's 4 channels are all inside or all outside): lanes beyond Cin
+    // read zeros through the range check, for the patch and for the filter rows alike
+    const bool ragged = (p.Cin % CK) != 0;
     auto ppref = [&](int c0) __attribute__((always_inline)) {
+        if (ragged) {
 #pragma unroll
-        for (int i = 0; i < PMAX; ++i) preg[i] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, pvo[i], c0 * 4, 0);
+            for (int i = 0; i < PMAX; ++i) {
+                const int c4 = (tid + i * 256) % PV;
+                preg[i] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, c0 + c4 * 4 < p.Cin ? pvo[i] : HV_OOB, c0 * 4, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < PMAX; ++i) preg[i] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, pvo[i], c0 * 4, 0);
+        }
+    };
+    const int kgc = (lane >> 4) * (FK / 4);          // first channel of this lane's k-group inside an MFMA step
+    auto wld = [&](int n, int widx_, int c0, int ks) __attribute__((always_inline)) {
+        const unsigned vo = (ragged && c0 + ks * FK + kgc >= p.Cin) ? HV_OOB : wvo[n];
+        return WLoad<FK>::ld(wsrc, vo, (widx_ * p.Cin + c0 + ks * FK) * 2);
     };
     auto pflush = [&](_Float16* dst) __attribute__((always_inline)) {
 #pragma unroll
@@ -125,7 +141,7 @@ __global__ __launch_bounds__(256) void conv_halo2_kernel(const HaloK p) {
         }
     };
 
-    const int nchunks = p.Cin / CK;
+    const int nchunks = (p.Cin + CK - 1) / CK;
     V wf[D][NT][KS];
     ppref(0);
 #pragma unroll
@@ -133,7 +149,7 @@ __global__ __launch_bounds__(256) void conv_halo2_kernel(const HaloK p) {
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) wf[j][n][ks] = WLoad<FK>::ld(wsrc, wvo[n], (widx[j] * p.Cin + ks * FK) * 2);
+            for (int ks = 0; ks < KS; ++ks) wf[j][n][ks] = wld(n, widx[j], 0, ks);
     pflush(patch);
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
@@ -158,7 +174,7 @@ __global__ __launch_bounds__(256) void conv_halo2_kernel(const HaloK p) {
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
 #pragma unroll
-                    for (int ks = 0; ks < KS; ++ks) wf[q % D][n][ks] = WLoad<FK>::ld(wsrc, wvo[n], (widx[qn] * p.Cin + cn * CK + ks * FK) * 2);
+                    for (int ks = 0; ks < KS; ++ks) wf[q % D][n][ks] = wld(n, widx[qn], cn * CK, ks);
             }
         }
         if (c + 1 < nchunks) pflush(patch + ((c + 1) & 1) * (PHM * PWM * LDP));
@@ -240,11 +256,14 @@ static int launch2(HaloK& k, hipStream_t s, int th0 = 8, int tw0 = TW) {
 
 int hv_halo2_launch(HaloK& k, int TW, int KH, int KW, int maxpatch, hipStream_t s) {
     (void)maxpatch;
-    if (k.Cin % 16) return HV_ERR_UNSUPPORTED;
+    if (k.Cin % 4) return HV_ERR_UNSUPPORTED;
+    const bool whole16 = k.Cin % 16 == 0;
     int ntaps = k.cls[0].ntaps;
     for (int c = 1; c < k.ncls; ++c)
         if (k.cls[c].ntaps != ntaps) return HV_ERR_UNSUPPORTED;
     // PatchGAN layers: 4x4 filters, Cout >= 128
+    // 5x5 stems of the generators (4 input channels) and their data gradient (4 output channels): Cout <= 16, 256x256 maps
+    if (ntaps == 25 && KH == 5 && KW == 5 && k.bstep == 1 && TW == 32 && k.Cout <= 16) return launch2<8, 32, 16, 4, 1, 16, 1, 5, 5>(k, s);
     if (ntaps == 16 && KH == 4 && KW == 4 && TW == 16 && k.Cout > 64 && k.bstep == 1 && k.Cin % 32 == 0) return launch2<8, 16, 128, 1, 4, 32, 1, 4, 4>(k, s);
     // PatchGAN logits layer (512 -> 1): the single output channel rides in a 16-channel MFMA tile, the input is staged once
     if (ntaps == 16 && KH == 4 && KW == 4 && TW == 16 && k.Cout <= 16 && k.bstep == 1 && k.Cin % 32 == 0) {
@@ -264,12 +283,12 @@ int hv_halo2_launch(HaloK& k, int TW, int KH, int KW, int maxpatch, hipStream_t 
     if (ntaps == 9 && KH == 3 && KW == 3 && k.bstep == 1) {
         const bool ck32 = k.Cin % 32 == 0;
         const int cls = k.Cout <= 16 ? 1 : k.Cout <= 32 ? 2 : k.Cout <= 64 ? 4 : 8;
+        if (!whole16 && TW != 32) return HV_ERR_UNSUPPORTED;   // ragged channel counts: 16-channel chunks, 8x32 tiles only
         if (!(mask & cls)) return HV_ERR_UNSUPPORTED;
         if (TW == 32) {
             if (cls == 1) return ck32 ? launch2<8, 32, 16, 4, 1, 32, 1, 3, 3>(k, s) : launch2<8, 32, 16, 4, 1, 16, 1, 3, 3>(k, s);
             if (cls == 2) return ck32 ? launch2<8, 32, 32, 2, 2, 32, 1, 3, 3>(k, s) : launch2<8, 32, 32, 2, 2, 16, 1, 3, 3>(k, s);
-            if (!ck32) return HV_ERR_UNSUPPORTED;
-            if (cls == 4) return launch2<8, 32, 64, 1, 4, 32, 1, 3, 3>(k, s);
+            if (cls == 4) return ck32 ? launch2<8, 32, 64, 1, 4, 32, 1, 3, 3>(k, s) : launch2<8, 32, 64, 1, 4, 16, 1, 3, 3>(k, s);
             // 128 channels x 256 pixels per workgroup needs 128 accumulator registers per lane and wastes half of them on the
             // 68-channel layer of this model (measured 2.5x slower than conv_halo_kernel): not taken
             return HV_ERR_UNSUPPORTED;

@@ -320,7 +320,13 @@ class Pix2PixModel(BaseModel):
             o.sync_lr()
         graphable = self.use_graph and ops.timer() is None
         if graphable and self._graphs is None and self._eager_steps >= self.GRAPH_WARMUP:
-            self._capture()
+            try:
+                self._capture()
+            except RuntimeError as e:     # capture refused by the runtime: keep launching eagerly, say so once
+                import warnings
+                warnings.warn('hipGraph capture of the train step failed (%s); continuing with eager launches' % str(e).splitlines()[0])
+                self.use_graph, self._graphs, graphable = False, None, False
+                torch.cuda.synchronize(self.device)
         if graphable and self._graphs is not None:
             ga, gb, gc = self._graphs
             ga.replay()
@@ -343,7 +349,8 @@ class Pix2PixModel(BaseModel):
         graphs, pool = [], None
         for phase in (self._phase_a, self._phase_b, self._phase_c):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool, stream=self._capture_stream):
+            # thread_local: a process-group watchdog thread polling its events must not invalidate the capture
+            with torch.cuda.graph(g, pool=pool, stream=self._capture_stream, capture_error_mode='thread_local'):
                 phase()
             pool = g.pool()
             graphs.append(g)

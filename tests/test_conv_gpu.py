@@ -125,6 +125,11 @@ HALO_CASES = [
     (16, 128, 128, 32, 64, 3, 1, 1, 'elu', 0),
     (16, 128, 128, 64, 68, 3, 1, 1, 'none', 0),
     (4, 64, 64, 128, 256, 4, 2, 1, 'lrelu', 0),
+    # ragged channel counts (16-channel chunks with range-checked lanes) and the 5x5 stems
+    (16, 128, 128, 4, 16, 5, 1, 2, 'elu', 0),
+    (16, 128, 128, 36, 32, 3, 1, 1, 'elu', 0),
+    (16, 128, 128, 68, 64, 3, 1, 1, 'elu', 0),
+    (16, 128, 128, 12, 16, 3, 1, 1, 'none', 0),
     (16, 128, 128, 64, 128, 4, 2, 1, 'lrelu', 0),
 ]
 

@@ -25,9 +25,11 @@ from test_step_gpu import make_opt
 torch.manual_seed(11)
 model = Pix2PixModel(make_opt(ndf=16))
 ddp.broadcast_parameters([model.netG, model.netD_1, model.netD_2, model.netD_3])
-model.set_input(synth.make_batch(2, 256, seed=100 + rank))
-model.optimize_parameters()
+for step in range(4):      # steps 3 and 4 replay the captured hipGraphs with the reductions in between
+    model.set_input(synth.make_batch(2, 256, seed=100 + rank + 10 * step))
+    model.optimize_parameters()
 torch.cuda.synchronize()
+assert model._graphs is not None
 sd = {n: {k: v.detach().cpu() for k, v in getattr(model, 'net' + n).state_dict().items() if 'running' not in k and 'tracked' not in k}
       for n in ('G', 'D_1', 'D_2', 'D_3')}
 torch.save(sd, sys.argv[3] + '/rank%%d.pt' %% rank)
@@ -56,7 +58,8 @@ def test_two_ranks_keep_identical_weights(tmp_path):
     os.environ['HV_PRECISION'] = 'fp32'
     torch.manual_seed(11)
     model = Pix2PixModel(make_opt(ndf=16))
-    model.set_input(synth.make_batch(2, 256, seed=100))
-    model.optimize_parameters()
+    for step in range(4):
+        model.set_input(synth.make_batch(2, 256, seed=100 + 10 * step))
+        model.optimize_parameters()
     w = model.netG.state_dict()['fine_generator.allconv17.conv.weight_orig'].cpu()
     assert not torch.equal(w, a['G']['fine_generator.allconv17.conv.weight_orig'])
