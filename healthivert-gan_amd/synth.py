@@ -136,3 +136,29 @@ def make_volume(nz=16, size=256, seed=7, target_id=20):
         rr, cc = np.mgrid[0:size, 0:size]
         cam[:, :, z] = np.exp(-((rr - (centre - pitch)) ** 2 + (cc - ccol) ** 2) / (2 * (12 * s) ** 2))
     return ct, label, cam
+
+
+def make_rhlv_pair(seed=0, H=64, W=64, Z=16, label_index=20, collapse=0.35, empty_ends=2, fake_shorter=False):
+    """A (generated, original) pair of straightened label volumes [H, W, Z] like the inputs of the reference's
+    evaluation/RHLV_quantification.py: the original vertebra (`label`) is wedge-compressed by `collapse` towards one side,
+    the generated one (`fake`) has its restored height; voxels carry `label_index`, a neighbour vertebra carries
+    label_index + 1, the first/last `empty_ends` slices are empty.  fake_shorter exercises the rescaling branch."""
+    rng = np.random.default_rng(seed)
+    fake = np.zeros((H, W, Z)); label = np.zeros((H, W, Z))
+    c0, c1 = W // 4 + int(rng.integers(-3, 4)), 3 * W // 4 + int(rng.integers(-3, 4))
+    r_mid = H // 2 + int(rng.integers(-2, 3))
+    full_h = H // 3 + int(rng.integers(-2, 3))
+    for z in range(empty_ends, Z - empty_ends):
+        shrink = 1.0 - 0.3 * abs(z - (Z - 1) / 2) / (Z / 2)
+        a, b = int(c0 + (1 - shrink) * 4), int(c1 - (1 - shrink) * 4)
+        for w in range(a, b):
+            t = (w - a) / max(1, b - a - 1)
+            hf = int(round(full_h * shrink * (0.9 + 0.1 * np.sin(3 * t))))
+            hl = int(round(hf * (1.0 - collapse * (1 - t)) + rng.integers(-1, 2)))
+            if fake_shorter:
+                hf, hl = max(1, hl - 2), hf
+            fake[max(0, r_mid - hf // 2):r_mid + (hf + 1) // 2, w, z] = label_index
+            label[max(0, r_mid - hl // 2):r_mid + (hl + 1) // 2, w, z] = label_index
+        fake[2:6, a:b, z] = label_index + 1          # a neighbour: must be ignored by the == label_index test
+        label[2:6, a:b, z] = label_index + 1
+    return fake, label

@@ -255,6 +255,18 @@ int hv_fill(float* p, long long n, float value, void* stream);
 int hv_axpy(float* y, const float* x, long long n, float a, void* stream); /* y += a*x */
 int hv_affine(float* y, const float* x, long long n, float a, float b, void* stream); /* y = a*x + b (e.g. 1 - CAM) */
 
+/* ---- RHLV quantification (reference evaluation/RHLV_quantification.py:41-147,160-178) ----
+ * fake / label: straightened label volumes of the generated and the original vertebra, element (h, w, z) at
+ * base[h*stride_h + w*stride_w + z*stride_z] (strides in elements); dtype 0 = float32, 1 = uint8.  A voxel belongs to the vertebra if it
+ * equals label_index (label_index < 0: if it is non-zero).  z_lo == INT_MIN: the slice range is derived from the original vertebra's
+ * z-extent like the reference (centre = int(mean z), half-length = (max_z - min_z) // length_divisor, numpy slice rules), else [z_lo, z_hi).
+ * out (14 doubles, device): all / pre / mid / post RHLV, relative height of the original, the eight mean heights
+ * (all_f, all_l, pre_f, pre_l, mid_f, mid_l, post_f, post_l), and 1.0 / 0.0 = the original vertebra exists. */
+size_t hv_rhlv_workspace_bytes(int W, int Z);
+int hv_rhlv(const void* fake, const void* label, int dtype, long long stride_h, long long stride_w, long long stride_z, int H, int W, int Z,
+            float label_index, int length_divisor, int z_lo, int z_hi, double height_threshold, double* out, void* workspace,
+            size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -114,3 +114,21 @@ def test_g6_unet():
         (cte, mke), _ = R.unet_forward(sd, g['x'], 5, False)
         close(cte, g['ct_eval'])
         close(mke, g['mk_eval'])
+
+
+def test_g8_rhlv_oracle_matches_reference_outputs():
+    """RHLV restatement (oracle.restate.rhlv / rhlv_volume) against the reference's calculate_rhlv / calculate_heights outputs (G8)."""
+    import numpy as np
+    from oracle import restate as R
+    g = load_golden('g8_rhlv')
+    names = sorted({k.split('/')[0] for k in g.keys()})
+    assert len(names) >= 6
+    for n in names:
+        idx, div, thr, cz, length = (float(v) for v in g[n + '/params'])
+        fake, label = np.asarray(g[n + '/fake'], dtype=np.float64), np.asarray(g[n + '/label'], dtype=np.float64)
+        res, means = R.rhlv_volume(fake, label, idx, int(div), thr)
+        assert np.array_equal(np.array(res), np.asarray(g[n + '/out'])), (n, res)          # same numpy operations: bit-identical
+        assert np.array_equal(np.array(means), np.asarray(g[n + '/means'])), n
+        sf, sl = (fake == idx).astype(np.float64), (label == idx).astype(np.float64)
+        res2, _ = R.rhlv(sf, sl, int(cz), int(length), thr)
+        assert np.array_equal(np.array(res2), np.asarray(g[n + '/out']))
