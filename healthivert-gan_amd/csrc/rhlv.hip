@@ -2,7 +2,8 @@
 // (reference evaluation/RHLV_quantification.py:41-147 and the per-vertebra body of process_datasets_to_excel :160-178).
 //
 // Integer / HBM-byte work: both volumes are read once (column counts per z-slice), everything after that is a few KB.
-//   rhlv_counts_kernel   grid (Z, 2): cnt[v][z][w] = #{h : vol_v[h][w][z] == label_index}, tot[v][z]
+//   rhlv_counts_kernel   grid (Z, 2): cnt[v][z][w] = #{h : vol_v[h][w][z] == label_index}, tot[v][z]   (lanes along w; a z-fastest
+//                        variant with lanes along z serves the reference's [H][W][Z] arrays)
 //   rhlv_range_kernel    <<<1,256>>>: z-extent of the original vertebra -> centre, half-length -> [lo, hi) (numpy slice rules)
 //   rhlv_slice_kernel    grid (Z): thirds of the generated vertebra's column extent, centre columns, rescale ratios,
 //                        thresholded integer sums per (all | pre | mid | post) x (generated | original)
@@ -31,6 +32,36 @@ __global__ __launch_bounds__(256) void rhlv_counts_kernel(const T* __restrict__ 
         cnt[((long long)v * Z + z) * W + w] = c;
         mine += c;
     }
+    red[threadIdx.x] = mine;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tot[v * Z + z] = red[0];
+}
+
+// the same for volumes whose z index is the fastest-varying one in memory (the reference's [H][W][Z] arrays): a lane owns one (w, z)
+// column and walks h, 64 consecutive lanes read 64 consecutive z -- coalesced.  grid (ceil(W*Z/256), 2); tot by rhlv_tot_kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void rhlv_counts_zfast_kernel(const T* __restrict__ fake, const T* __restrict__ label, long long sh, long long sw,
+                                                                long long sz, int H, int W, int Z, float label_index, int* __restrict__ cnt) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)W * Z) return;
+    const int v = blockIdx.y, w = (int)(i / Z), z = (int)(i - (long long)w * Z);
+    const T* p = (v == 0 ? fake : label) + (long long)w * sw + (long long)z * sz;
+    int c = 0;
+    for (int h = 0; h < H; ++h) {
+        const float val = (float)p[(long long)h * sh];
+        c += label_index < 0.f ? (val != 0.f) : (val == label_index);
+    }
+    cnt[((long long)v * Z + z) * W + w] = c;
+}
+__global__ __launch_bounds__(256) void rhlv_tot_kernel(const int* __restrict__ cnt, int W, int* __restrict__ tot) {
+    __shared__ int red[256];
+    const int z = blockIdx.x, v = blockIdx.y, Z = gridDim.x;
+    int mine = 0;
+    for (int w = threadIdx.x; w < W; w += 256) mine += cnt[((long long)v * Z + z) * W + w];
     red[threadIdx.x] = mine;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
@@ -182,12 +213,23 @@ extern "C" int hv_rhlv(const void* fake, const void* label, int dtype, long long
     int* cnt = (int*)ws; ws += (size_t)2 * Z * W * sizeof(int);
     int* tot = (int*)ws; ws += (size_t)2 * Z * sizeof(int);
     int* params = (int*)ws;
-    if (dtype == 0)
+    if (stride_z == 1 && stride_w != 1) {   // z fastest in memory: lanes along z
+        const dim3 grid(hv_cdiv((long long)W * Z, 256), 2);
+        if (dtype == 0)
+            hipLaunchKernelGGL((rhlv_counts_zfast_kernel<float>), grid, dim3(256), 0, s, (const float*)fake, (const float*)label, stride_h, stride_w,
+                               stride_z, H, W, Z, label_index, cnt);
+        else
+            hipLaunchKernelGGL((rhlv_counts_zfast_kernel<unsigned char>), grid, dim3(256), 0, s, (const unsigned char*)fake, (const unsigned char*)label,
+                               stride_h, stride_w, stride_z, H, W, Z, label_index, cnt);
+        HV_LAUNCH_CHECK();
+        hipLaunchKernelGGL(rhlv_tot_kernel, dim3(Z, 2), dim3(256), 0, s, cnt, W, tot);
+    } else if (dtype == 0) {
         hipLaunchKernelGGL((rhlv_counts_kernel<float>), dim3(Z, 2), dim3(256), 0, s, (const float*)fake, (const float*)label, stride_h, stride_w, stride_z,
                            H, W, label_index, cnt, tot);
-    else
+    } else {
         hipLaunchKernelGGL((rhlv_counts_kernel<unsigned char>), dim3(Z, 2), dim3(256), 0, s, (const unsigned char*)fake, (const unsigned char*)label,
                            stride_h, stride_w, stride_z, H, W, label_index, cnt, tot);
+    }
     HV_LAUNCH_CHECK();
     hipLaunchKernelGGL(rhlv_range_kernel, dim3(1), dim3(64), 0, s, tot, Z, length_divisor, z_lo, z_hi, params);
     HV_LAUNCH_CHECK();
