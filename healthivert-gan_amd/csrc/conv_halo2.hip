@@ -36,7 +36,7 @@ template <> struct WLoad<16> {
 // CK = channels per staged chunk: 16 (one 16x16x16 MFMA step), 32 (one 16x16x32 step) or 64 (two steps: a lane's two
 // 16-B weight loads then consume a whole 128-B line of its filter row, and barriers halve)
 template <int TH, int TW, int BN, int WM, int WN, int CK, int BSTEP, int SPAN, int D>
-__global__ __launch_bounds__(256) void conv_halo2_kernel(const HaloK p) {
+__global__ __launch_bounds__(256, 2) void conv_halo2_kernel(const HaloK p) {   // two workgroups per CU: at most 256 registers per lane
     constexpr int NTAPS = SPAN * SPAN;
     constexpr int BM = TH * TW;
     constexpr int FK = CK == 16 ? 16 : 32;                          // channels per MFMA step
@@ -155,17 +155,40 @@ __global__ __launch_bounds__(256) void conv_halo2_kernel(const HaloK p) {
     for (int c = 0; c < nchunks; ++c) {
         const _Float16* pb = patch + (c & 1) * (PHM * PWM * LDP);
         if (c + 1 < nchunks) ppref((c + 1) * CK);     // next chunk's patch rides behind this chunk's MFMAs
+        // The B-fragments of tap q+1 are read from LDS while the MFMAs of tap q run (two register sets): with the reads issued
+        // right before their use a wave waited ~100 cycles per pair of MFMAs (PMC: 64 % of the wave cycles in s_waitcnt).
+        // (only where the second register set is affordable: up to 8 fragments per tap)
+        constexpr bool DB = KS * MT <= 8;
+        V xf[DB ? 2 : 1][KS][MT];
+        if (DB) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) xf[0][ks][m] = HFrag<FK>::ld(pb + poff[m] + toff[0] + ks * FK, lane);
+        }
 #pragma unroll
         for (int q = 0; q < NTAPS; ++q) {
+            const int cur = DB ? (q & 1) : 0;
+            if (DB ? (q + 1 < NTAPS) : true) {
+                const int qq = DB ? q + 1 : q;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                V xf[MT];
+                for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                for (int m = 0; m < MT; ++m) xf[m] = HFrag<FK>::ld(pb + poff[m] + toff[q] + ks * FK, lane);
+                    for (int m = 0; m < MT; ++m) xf[DB ? ((q + 1) & 1) : 0][ks][m] = HFrag<FK>::ld(pb + poff[m] + toff[qq] + ks * FK, lane);
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
-                    for (int n = 0; n < NT; ++n) acc[n][m] = HFrag<FK>::mma(wf[q % D][n][ks], xf[m], acc[n][m]);
+                    for (int n = 0; n < NT; ++n) acc[n][m] = HFrag<FK>::mma(wf[q % D][n][ks], xf[cur][ks][m], acc[n][m]);
+            // keep the next tap's LDS reads ahead of this tap's MFMAs in the instruction stream (the scheduler would sink them)
+            if (DB && q + 1 < NTAPS) {
+#pragma unroll
+                for (int i = 0; i < KS * MT; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // one ds_read
+                    __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);      // NT MFMAs
+                }
             }
             // refill the ring slot with the tap D ahead (possibly the next chunk's)
             const int qn = (q + D) % NTAPS;
