@@ -320,6 +320,9 @@ class Generator(nn.Module):
         self.precision = None          # None -> HV_PRECISION env (fp32 parity mode by default)
         self._plans = {}
         self._pset = None
+        self._eval_graphs = {}
+        import os as _os
+        self.use_graph = _os.environ.get('HV_GRAPH', '1') != '0'
         self._pset_convs = None
 
     # ---------------------------------------------------------------- parameters
@@ -476,7 +479,10 @@ class Generator(nn.Module):
         (coarse_seg, fine_seg, x_stage1, x_stage2, offset_flow, pred1_h, pred2_h)."""
         if not torch.is_tensor(slice_ratio):
             slice_ratio = torch.as_tensor(slice_ratio, dtype=torch.float64).reshape(-1)
-        P = self.run_forward(x, mask, CAM, slice_ratio)
+        if self.use_graph and not self.training and not torch.is_grad_enabled() and ops.timer() is None and x.is_cuda:
+            P = self._eval_replay(x, mask, CAM, slice_ratio)
+        else:
+            P = self.run_forward(x, mask, CAM, slice_ratio)
         outs = (P.coarse_seg, P.fine_seg, P.x_stage1, P.x_stage2, P.pred1, P.pred2)
         flow = offsets_to_flow(P.attn.argmax, P.B, P.attn.h, P.attn.w, 2)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
@@ -485,6 +491,39 @@ class Generator(nn.Module):
         else:
             o = tuple(t.clone() for t in outs)
         return o[0], o[1], o[2], o[3], flow, o[4], o[5]
+
+
+def _generator_eval_replay(self, x, mask, CAM, slice_ratio):
+    """Eval-mode forward as a captured hipGraph per input shape: the ~250 launches of a bs=1 inference call (launch-bound when
+    issued eagerly: the reference's eval loop runs ~130 of them per volume) become one graph launch.  Inputs are copied into
+    the graph's fixed buffers; the weights are re-prepared from the current parameters inside the graph on every replay."""
+    key = (tuple(x.shape), x.device.index, next(self.parameters()).data_ptr())
+    ent = self._eval_graphs.get(key)
+    if ent is None:
+        dev = x.device
+        static = [x.detach().to(dev, torch.float32).contiguous().clone(), mask.detach().to(dev, torch.float32).contiguous().clone(),
+                  CAM.detach().to(dev, torch.float32).contiguous().clone(), slice_ratio.detach().to(dev, torch.float64).contiguous().clone()]
+        self.run_forward(*static)                       # eager warm-up: plan buffers, weight tables, kernel attributes
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(g, stream=torch.cuda.Stream(device=dev), capture_error_mode='thread_local'):
+                P = self.run_forward(*static)
+        except RuntimeError:
+            self.use_graph = False
+            torch.cuda.synchronize(dev)
+            return self.run_forward(x, mask, CAM, slice_ratio)
+        if len(self._eval_graphs) >= 8:                 # a handful of shapes at most (bs=1 loop, batched stages)
+            self._eval_graphs.clear()
+        ent = self._eval_graphs[key] = (g, static, P)
+    g, static, P = ent
+    for dst, src in zip(static, (x, mask, CAM, slice_ratio)):
+        dst.copy_(src, non_blocking=True)
+    g.replay()
+    return P
+
+
+Generator._eval_replay = _generator_eval_replay
 
 
 class _GeneratorFn(torch.autograd.Function):

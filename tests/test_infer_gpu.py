@@ -90,3 +90,36 @@ def test_stage_batched_volume_matches_sequential_oracle():
         assert np.abs(out_ct[:, :, z] - c).max() <= 0.6, np.abs(out_ct[:, :, z] - c).max()    # uint8 re-quantisation between stages
         bad += (out_seg[:, :, z] != l).mean()
     assert bad / 3 <= 1e-3
+
+
+def test_eval_forward_graph_replay_matches_eager():
+    """Generator.forward in eval mode under no_grad replays a captured hipGraph per input shape: same 7-tuple as eager launches,
+    for changing inputs and after a weight update in place."""
+    import hvgan
+    from hvgan import synth
+    from hvgan.models.inpaint_networks import Generator
+    torch.manual_seed(21)
+    net = Generator({'input_dim': 1, 'ngf': 16}, True).cuda().eval()
+    dev = torch.device('cuda:0')
+
+    def args(seed, B):
+        b = synth.to_model_inputs(synth.make_batch(B, 256, seed=seed))
+        return [b['real_A'].to(dev), b['mask'].to(dev), (1 - b['CAM']).to(dev), b['slice_ratio'].to(dev)]
+
+    def both(a):
+        with torch.no_grad():
+            net.use_graph = False
+            e = net(*a)
+            net.use_graph = True
+            g = net(*a)
+        return e, g
+
+    for seed, B in ((1, 1), (2, 1), (3, 2), (4, 1)):
+        e, g = both(args(seed, B))
+        for i in (0, 1, 2, 3, 5, 6):
+            assert torch.equal(e[i], g[i]), (seed, i)
+    with torch.no_grad():
+        net.coarse_generator.conv5.conv.weight_orig.mul_(1.05)          # in-place update: the graph re-prepares the weights
+    e, g = both(args(5, 1))
+    assert torch.equal(e[3], g[3]) and torch.equal(e[0], g[0])
+    assert len(net._eval_graphs) == 2

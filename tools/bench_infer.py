@@ -49,3 +49,18 @@ for B in (1, 16, 64):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
     print('eval forward bs=%d: %.2f ms -> %.0f slices/s (%.1f TFLOP/s at 17.56 GFLOP/slice)' % (B, ms, B / ms * 1e3, 17.56 * B / ms))
+
+for B in (1, 16):     # the nn.Module call of the eval scripts: hipGraph replay per input shape (+ copies of the 6 outputs)
+    bb = synth.to_model_inputs(synth.make_batch(B, 256, seed=3))
+    args = [bb['real_A'].to(dev), bb['mask'].to(dev), (1 - bb['CAM']).to(dev), bb['slice_ratio'].to(dev)]
+    with torch.no_grad():
+        for _ in range(3):
+            net(*args)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 50
+        for _ in range(n):
+            net(*args)
+        torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / n * 1e3
+    print('netG(...) eval, no_grad, bs=%d (graph replay): %.2f ms per call -> %.0f slices/s' % (B, ms, B / ms * 1e3))
