@@ -448,6 +448,7 @@ struct WgradK {
     int kt_q, kt_r;              // !FAST: KT / Wo, KT % Wo
     unsigned x_bytes, g_bytes;   // buffer descriptor ranges
     long long slab;              // Cout*J floats per split
+    float* bias_out;             // per-split column sums of g (bias gradient), [splits][Cout], or NULL
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -618,6 +619,9 @@ __global__ __launch_bounds__(WN * WC * 64) void wgrad_kernel(const WgradK p) {
 #pragma unroll
         for (int c = 0; c < CT; ++c) acc[n][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int wn = wave / WC, wc = wave % WC;
+    // bias gradient: the first column tile also sums the g values it stages (fp32, before the fp16 conversion)
+    const bool do_bias = p.bias_out != nullptr && blockIdx.z == 0;
+    float bs0 = 0.f, bs1 = 0.f, bs2 = 0.f, bs3 = 0.f;
 
     if (pix_begin < pix_end) {
         if (has_g) load_g(pix_begin);
@@ -626,6 +630,13 @@ __global__ __launch_bounds__(WN * WC * 64) void wgrad_kernel(const WgradK p) {
     for (int pix0 = pix_begin; pix0 < pix_end; pix0 += KT) {
         __syncthreads();  // previous step's MFMA reads done
         if (has_g) store(Gs, LDG, rg, g_cg, g_run);
+        if (do_bias && has_g) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                bs0 += __uint_as_float(rg[e].x); bs1 += __uint_as_float(rg[e].y);
+                bs2 += __uint_as_float(rg[e].z); bs3 += __uint_as_float(rg[e].w);
+            }
+        }
         if (has_x) {
 #pragma unroll
             for (int it = 0; it < XPT; ++it) store(Xs, LDX, rx[it], x_cg[it], x_run[it]);
@@ -674,6 +685,18 @@ __global__ __launch_bounds__(WN * WC * 64) void wgrad_kernel(const WgradK p) {
             }
         }
     }
+    if (do_bias) {   // fold the pixel runs of a channel group in LDS (fixed order), one row per split
+        __syncthreads();
+        float* bsh = reinterpret_cast<float*>(Xs);          // GI x 4 floats <= the X tile
+        if (has_g) { bsh[tid * 4 + 0] = bs0; bsh[tid * 4 + 1] = bs1; bsh[tid * 4 + 2] = bs2; bsh[tid * 4 + 3] = bs3; }
+        __syncthreads();
+        if (tid < BN && n_base + tid < p.Cout) {
+            const int cg = tid >> 2, c = tid & 3;
+            float t = 0.f;
+            for (int run = 0; run < KT / 8; ++run) t += bsh[(run * (BN / 4) + cg) * 4 + c];
+            p.bias_out[(long long)blockIdx.x * p.Cout + n_base + tid] = t;
+        }
+    }
     // D layout: row (= co) = (lane>>4)*4 + r, col (= j) = lane & 15
     float* out = p.out + (long long)blockIdx.x * p.slab;
 #pragma unroll
@@ -690,27 +713,34 @@ __global__ __launch_bounds__(WN * WC * 64) void wgrad_kernel(const WgradK p) {
         }
 }
 
-// 256 threads = 64 elements x 4 split groups; fixed summation order (deterministic)
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, long long n, int splits, int accumulate) {
+// 256 threads = 64 elements x 4 split groups; fixed summation order (deterministic).  Blocks beyond the dW range fold the
+// per-split bias rows (bslabs [splits][nb]) into dbias.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, long long n, int splits, int accumulate,
+                                                           const float* __restrict__ bslabs, float* __restrict__ dbias, int nb, int bias_accumulate) {
     __shared__ float sh[4][64];
     const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const long long i = (long long)blockIdx.x * 64 + e;
+    const long long wblocks = (n + 63) / 64;
+    const bool bias = (long long)blockIdx.x >= wblocks;
+    const float* src = bias ? bslabs : slabs;
+    const long long nn = bias ? nb : n;
+    const long long i = ((long long)blockIdx.x - (bias ? wblocks : 0)) * 64 + e;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    if (i < n) {
+    if (i < nn) {
         int k = grp;
         for (; k + 12 < splits; k += 16) {
-            s0 += slabs[(long long)k * n + i];
-            s1 += slabs[(long long)(k + 4) * n + i];
-            s2 += slabs[(long long)(k + 8) * n + i];
-            s3 += slabs[(long long)(k + 12) * n + i];
+            s0 += src[(long long)k * nn + i];
+            s1 += src[(long long)(k + 4) * nn + i];
+            s2 += src[(long long)(k + 8) * nn + i];
+            s3 += src[(long long)(k + 12) * nn + i];
         }
-        for (; k < splits; k += 4) s0 += slabs[(long long)k * n + i];
+        for (; k < splits; k += 4) s0 += src[(long long)k * nn + i];
     }
     sh[grp][e] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (grp == 0 && i < n) {
+    if (grp == 0 && i < nn) {
         const float s = (sh[0][e] + sh[1][e]) + (sh[2][e] + sh[3][e]);
-        dw[i] = accumulate ? dw[i] + s : s;
+        if (bias) dbias[i] = bias_accumulate ? dbias[i] + s : s;
+        else dw[i] = accumulate ? dw[i] + s : s;
     }
 }
 
@@ -763,8 +793,8 @@ extern "C" size_t hv_conv2d_wgrad_workspace_bytes(const hv_wgrad_desc* d) {
     if (halo) return halo;
     WgradPlan pl;
     wgrad_plan(d, &pl);
-    if (pl.splits <= 1 && !d->accumulate) return 0;
-    return (size_t)pl.splits * d->Cout * d->KH * d->KW * d->Cin * sizeof(float);
+    if (pl.splits <= 1 && !d->accumulate && !d->dbias) return 0;
+    return (size_t)pl.splits * ((size_t)d->Cout * d->KH * d->KW * d->Cin + (d->dbias ? d->Cout : 0)) * sizeof(float);
 }
 
 template <typename T, bool FAST>
@@ -791,7 +821,9 @@ extern "C" int hv_conv2d_wgrad(const hv_wgrad_desc* d, void* stream) {
         int nslabs = 0;
         rc = hv_wgrad_halo(d, &nslabs, (hipStream_t)stream);   // (measured: the VALU hv_wgrad_narrow is slower than the padded MFMA tiles)
         if (rc == HV_OK) {
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(hv_cdiv(nW, 64)), dim3(256), 0, (hipStream_t)stream, d->workspace, d->dw, nW, nslabs, d->accumulate);
+            const float* bsl = d->dbias ? d->workspace + (long long)nslabs * nW : nullptr;
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(hv_cdiv(nW, 64) + (d->dbias ? hv_cdiv(d->Cout, 64) : 0)), dim3(256), 0, (hipStream_t)stream,
+                               d->workspace, d->dw, nW, nslabs, d->accumulate, bsl, d->dbias, d->Cout, d->dbias_accumulate);
             HV_LAUNCH_CHECK();
             return HV_OK;
         }
@@ -799,9 +831,9 @@ extern "C" int hv_conv2d_wgrad(const hv_wgrad_desc* d, void* stream) {
     }
     WgradPlan pl;
     wgrad_plan(d, &pl);
-    const bool direct = pl.splits <= 1 && !d->accumulate;
+    const bool direct = pl.splits <= 1 && !d->accumulate && !d->dbias;
     if (!direct) {
-        if (!d->workspace || d->workspace_bytes < (size_t)pl.splits * nW * sizeof(float)) return HV_ERR_WORKSPACE;
+        if (!d->workspace || d->workspace_bytes < (size_t)pl.splits * (nW + (d->dbias ? d->Cout : 0)) * sizeof(float)) return HV_ERR_WORKSPACE;
     }
     hv_path_note = 10;
     WgradK k;
@@ -811,6 +843,7 @@ extern "C" int hv_conv2d_wgrad(const hv_wgrad_desc* d, void* stream) {
     k.Ho = d->Ho; k.Wo = d->Wo; k.g_ld = d->g_ld; k.g_coff = d->g_coff; k.Cout = d->Cout;
     k.KW = d->KW; k.stride = d->stride; k.pad = d->pad; k.dil = d->dil; k.J = d->KH * d->KW * d->Cin;
     k.M = d->B * d->Ho * d->Wo; k.chunk = pl.chunk; k.slab = nW;
+    k.bias_out = d->dbias ? d->workspace + (long long)pl.splits * nW : nullptr;
     k.x_bytes = (unsigned)((size_t)d->B * (d->H >> d->in_shift) * k.Wp * d->x_ld * sizeof(float));
     k.g_bytes = (unsigned)((size_t)k.M * d->g_ld * sizeof(float));
     auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
@@ -823,7 +856,8 @@ extern "C" int hv_conv2d_wgrad(const hv_wgrad_desc* d, void* stream) {
     else rc = fast ? launch_wgrad<_Float16, true>(k, pl, s) : launch_wgrad<_Float16, false>(k, pl, s);
     if (rc != HV_OK) return rc;
     if (!direct) {
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(hv_cdiv(nW, 64)), dim3(256), 0, s, d->workspace, d->dw, nW, pl.splits, d->accumulate);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(hv_cdiv(nW, 64) + (d->dbias ? hv_cdiv(d->Cout, 64) : 0)), dim3(256), 0, s, d->workspace, d->dw, nW,
+                           pl.splits, d->accumulate, k.bias_out, d->dbias, d->Cout, d->dbias_accumulate);
         HV_LAUNCH_CHECK();
     }
     return HV_OK;

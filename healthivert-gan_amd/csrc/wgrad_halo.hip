@@ -19,6 +19,7 @@ struct WHaloK {
     int tiles_x, tiles_per_img, ntiles;
     long long slab;   // floats per slab = Cout * KS*KS * Cin
     unsigned x_bytes, g_bytes;   // buffer descriptor ranges
+    float* bias_out;             // per-workgroup column sums of g (bias gradient), [gridDim.x][Cout], or NULL
 };
 
 __device__ __forceinline__ uint32_t hv_pack2(float a, float b) {
@@ -107,11 +108,22 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const WHaloK p) {
         auto f = [&](int e) { return __uint_as_float(c == 0 ? v[e].x : c == 1 ? v[e].y : c == 2 ? v[e].z : v[e].w); };
         return make_uint4(hv_pack2(f(0), f(1)), hv_pack2(f(2), f(3)), hv_pack2(f(4), f(5)), hv_pack2(f(6), f(7)));
     };
+    const bool do_bias = p.bias_out != nullptr && blockIdx.z == 0;
+    float bsum[GPT][4];
+#pragma unroll
+    for (int i = 0; i < GPT; ++i) bsum[i][0] = bsum[i][1] = bsum[i][2] = bsum[i][3] = 0.f;
     auto flush = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < GPT; ++i) {
             const int u = tid + i * 256;
             if (u >= GU) continue;
+            if (do_bias) {   // bias gradient: fp32 sums of the staged g values (zeros outside the image)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    bsum[i][0] += __uint_as_float(rg[i][e].x); bsum[i][1] += __uint_as_float(rg[i][e].y);
+                    bsum[i][2] += __uint_as_float(rg[i][e].z); bsum[i][3] += __uint_as_float(rg[i][e].w);
+                }
+            }
             const int cg = u % (BN / 4), rr = u / (BN / 4), run = rr & 3, ty = rr >> 2;
 #pragma unroll
             for (int c = 0; c < 4; ++c) *reinterpret_cast<uint4*>(Gt + ((cg * 4 + c) * TH + ty) * GROW + run * 8) = pack4(rg[i], c);
@@ -197,6 +209,23 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const WHaloK p) {
             }
         }
     }
+    if (do_bias) {   // fold the units of a channel group (fixed order) -> one row per workgroup
+        __syncthreads();
+        float* bsh = reinterpret_cast<float*>(smem);          // GU x 4 floats (the staging tiles are dead)
+#pragma unroll
+        for (int i = 0; i < GPT; ++i) {
+            const int u = tid + i * 256;
+            if (u < GU) { bsh[u * 4 + 0] = bsum[i][0]; bsh[u * 4 + 1] = bsum[i][1]; bsh[u * 4 + 2] = bsum[i][2]; bsh[u * 4 + 3] = bsum[i][3]; }
+        }
+        __syncthreads();
+        if (tid < BN && co0 + tid < p.Cout) {
+            const int cg = tid >> 2, c = tid & 3;
+            float t = 0.f;
+            for (int k = 0; k < TH * 4; ++k) t += bsh[(cg + k * (BN / 4)) * 4 + c];
+            p.bias_out[(long long)blockIdx.x * p.Cout + co0 + tid] = t;
+        }
+        __syncthreads();
+    }
     if (TS) {
         // ---- one slab per workgroup: every wave writes its own taps (D layout: row (= co) = (lane>>4)*4 + r, col (= ci) = lane & 15)
         float* out = p.slabs + (long long)blockIdx.x * p.slab;
@@ -267,7 +296,7 @@ static bool wgrad_halo_plan(const hv_wgrad_desc* d, WHaloPlan* pl) {
 size_t hv_wgrad_halo_workspace_bytes(const hv_wgrad_desc* d) {
     WHaloPlan pl;
     if (!wgrad_halo_plan(d, &pl)) return 0;
-    return (size_t)pl.gx * d->Cout * d->KH * d->KW * d->Cin * sizeof(float);
+    return (size_t)pl.gx * ((size_t)d->Cout * d->KH * d->KW * d->Cin + (d->dbias ? d->Cout : 0)) * sizeof(float);
 }
 
 template <int KS, int BN, int BC, bool TS = false>
@@ -300,6 +329,7 @@ int hv_wgrad_halo(const hv_wgrad_desc* d, int* nslabs, hipStream_t s) {
     k.Ho = d->Ho; k.Wo = d->Wo; k.g_ld = d->g_ld; k.g_coff = d->g_coff; k.Cout = d->Cout; k.pad = d->pad;
     k.tiles_x = hv_cdiv(d->Wo, 32); k.tiles_per_img = k.tiles_x * hv_cdiv(d->Ho, 8); k.ntiles = k.tiles_per_img * d->B;
     k.slab = (long long)d->Cout * d->KH * d->KW * d->Cin;
+    k.bias_out = d->dbias ? d->workspace + (long long)pl.gx * k.slab : nullptr;
     k.x_bytes = (unsigned)((size_t)d->B * k.img_stride * sizeof(float));
     k.g_bytes = (unsigned)((size_t)d->B * d->Ho * d->Wo * d->g_ld * sizeof(float));
     *nslabs = pl.gx;

@@ -150,6 +150,7 @@ class ConvNode:
 # the train step (three chains already run concurrently there, and a fork nested inside a forked stream crashes
 # hipStreamEndCapture on ROCm 7.2 when the step is captured as a graph)
 NO_FORK_STREAMS = set()
+FUSE_DBIAS = os.environ.get('HV_FUSE_DBIAS', '1') != '0'   # bias gradients computed inside the weight-gradient kernels
 SERIAL = False            # True: no side streams at all (per-kernel timing with HIP events needs the GPU to itself)
 
 
@@ -196,13 +197,14 @@ class GradBook:
         return acc
 
 
-def _wgrad(node, p, xin, gfull, accumulate, prec):
+def _wgrad(node, p, xin, gfull, accumulate, prec, dbias=None, dbias_accumulate=False):
     if node.transposed:
         # y = conv_transpose(x): the weight gradient is that of a strided conv with the roles of x and g swapped;
         # the result is laid out [cin][taps][coutP] (hv_weight_prep_backward knows, transposed_src)
         ops.conv2d_wgrad(gfull, xin, p.dw, node.k, node.s, node.pad, node.d, accumulate=accumulate, precision=prec)
     else:
-        ops.conv2d_wgrad(xin, gfull, p.dw, node.k, node.s, node.pad, node.d, in_shift=node.shift, accumulate=accumulate, precision=prec)
+        ops.conv2d_wgrad(xin, gfull, p.dw, node.k, node.s, node.pad, node.d, in_shift=node.shift, accumulate=accumulate, precision=prec,
+                         dbias=dbias, dbias_accumulate=dbias_accumulate)
 
 
 def conv_backward(node, book, prec, dbias_accumulate=False, wgrad_accumulate=False, tmp_full=None, wgrad=True, x_wg=None):
@@ -210,9 +212,12 @@ def conv_backward(node, book, prec, dbias_accumulate=False, wgrad_accumulate=Fal
     x_wg: channel-padded copy of the input for the weight-gradient kernel (1-channel image inputs)."""
     p = node.p
     gy = book.twin(node.y)
-    if node.act != 'none' or (p.bias is not None and node.use_bias):
-        ops.act_backward(gy, node.y, node.act, dbias=p.bias.grad if (p.bias is not None and node.use_bias and wgrad) else None,
-                         dbias_accumulate=dbias_accumulate)
+    want_dbias = p.bias is not None and node.use_bias and wgrad
+    # the bias gradient (column sums of the activation gradient) rides in the weight-gradient kernels, which stream g anyway;
+    # conv_transpose nodes (roles of x and g swapped there) and unpadded channel counts keep the stand-alone reduction
+    fuse_dbias = want_dbias and not node.transposed and FUSE_DBIAS and p.coutP == p.cout
+    if node.act != 'none' or (want_dbias and not fuse_dbias):
+        ops.act_backward(gy, node.y, node.act, dbias=p.bias.grad if (want_dbias and not fuse_dbias) else None, dbias_accumulate=dbias_accumulate)
     gfull = Act(gy.t, p.coutP, gy.coff)
     if wgrad:
         xs = node.x if x_wg is None else x_wg
@@ -221,7 +226,7 @@ def conv_backward(node, book, prec, dbias_accumulate=False, wgrad_accumulate=Fal
         # chain (joined by GradBook.join() before the gradients are finalised / the activations are overwritten)
         ctx = torch.cuda.stream(book.fork()) if book.can_fork() else contextlib.nullcontext()
         with ctx:
-            _wgrad(node, p, xin, gfull, wgrad_accumulate, prec)
+            _wgrad(node, p, xin, gfull, wgrad_accumulate, prec, dbias=p.bias.grad if fuse_dbias else None, dbias_accumulate=dbias_accumulate)
     if node.need_dx and node.transposed:
         gx = book.twin(node.x)
         gx = Act(gx.t, p.cin_fwd, gx.coff)

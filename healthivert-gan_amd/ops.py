@@ -158,8 +158,10 @@ def conv2d(x, w, y, k, stride=1, pad=0, dil=1, bias=None, act='none', transposed
     return y
 
 
-def conv2d_wgrad(x, g, dw, k, stride=1, pad=0, dil=1, in_shift=0, accumulate=False, precision=None, cin=None, cout=None):
-    """dw[Cout][k*k][Cin] = sum_pixels g (x) x.  x: conv input view, g: gradient wrt the conv output."""
+def conv2d_wgrad(x, g, dw, k, stride=1, pad=0, dil=1, in_shift=0, accumulate=False, precision=None, cin=None, cout=None, dbias=None,
+                 dbias_accumulate=False):
+    """dw[Cout][k*k][Cin] = sum_pixels g (x) x.  x: conv input view, g: gradient wrt the conv output.
+    dbias: optional [Cout] tensor that receives sum_pixels g (the bias gradient), computed by the same kernels."""
     L = _lib.get()
     d = L.hv_wgrad_desc()
     kh, kw = (k, k) if isinstance(k, int) else k
@@ -172,6 +174,8 @@ def conv2d_wgrad(x, g, dw, k, stride=1, pad=0, dil=1, in_shift=0, accumulate=Fal
     d.dw = ptr(dw).value
     d.accumulate = int(accumulate)
     d.precision = precision_id(precision)
+    d.dbias = None if dbias is None else ptr(dbias).value
+    d.dbias_accumulate = int(dbias_accumulate)
     d.workspace, d.workspace_bytes = None, 0
     need = L.size('hv_conv2d_wgrad_workspace_bytes', ctypes.byref(d))
     if need:

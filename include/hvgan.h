@@ -80,6 +80,8 @@ typedef struct {
     float* dw; int accumulate;
     float* workspace; size_t workspace_bytes;
     int precision;
+    float* dbias; int dbias_accumulate;   /* optional: dbias[co] (+)= sum over pixels of g[.., co] (bias gradient of the same conv), folded
+                                             into the kernel that already streams g; NULL = not computed */
 } hv_wgrad_desc;
 size_t hv_conv2d_wgrad_workspace_bytes(const hv_wgrad_desc* d);
 int hv_conv2d_wgrad(const hv_wgrad_desc* d, void* stream);

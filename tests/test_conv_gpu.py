@@ -97,11 +97,18 @@ def test_conv_wgrad(case, prec, tol):
     ga = to_act(g, CoutP)
     ga = ops.Act(ga.t, CoutP, 0)
     dw = torch.empty(CoutP, k * k, CinP4, device=dev())
-    ops.conv2d_wgrad(xa, ga, dw, k, s, p, d, precision=prec)
+    db = torch.full((CoutP,), 7.0, device=dev())
+    ops.conv2d_wgrad(xa, ga, dw, k, s, p, d, precision=prec, dbias=db)          # bias gradient rides in the same kernels
     torch.cuda.synchronize()
     got = dw[:Cout, :, :Cin].cpu().reshape(Cout, k, k, Cin).permute(0, 3, 1, 2)
     err = maxerr(got, w.grad)
     assert err <= tol * max(1.0, w.grad.abs().max().item()), err
+    gsum = g.sum(dim=(0, 2, 3))
+    assert maxerr(db[:Cout].cpu(), gsum) <= 1e-4 * max(1.0, g.abs().sum(dim=(0, 2, 3)).max().item()), (db[:Cout].cpu() - gsum).abs().max()
+    ops.conv2d_wgrad(xa, ga, dw, k, s, p, d, precision=prec, accumulate=True, dbias=db, dbias_accumulate=True)
+    torch.cuda.synchronize()
+    assert maxerr(db[:Cout].cpu(), 2 * gsum) <= 2e-4 * max(1.0, g.abs().sum(dim=(0, 2, 3)).max().item())
+    assert maxerr(dw[:Cout, :, :Cin].cpu().reshape(Cout, k, k, Cin).permute(0, 3, 1, 2), 2 * w.grad) <= 2 * tol * max(1.0, w.grad.abs().max().item())
 
 
 HALO_CASES = [
