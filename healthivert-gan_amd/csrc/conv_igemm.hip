@@ -21,6 +21,11 @@
 
 thread_local int hv_path_note = 0;
 extern "C" int hv_last_kernel_path(void) { return hv_path_note; }
+thread_local hipEvent_t hv_ev_start = nullptr, hv_ev_stop = nullptr;
+extern "C" int hv_set_kernel_timing(void* ev_start, void* ev_stop) {
+    hv_ev_start = (hipEvent_t)ev_start; hv_ev_stop = (hipEvent_t)ev_stop;
+    return HV_OK;
+}
 
 int hv_conv2d_halo(const hv_conv_desc* d, const void* w_f16, hipStream_t s);   // conv_halo.hip
 size_t hv_wgrad_halo_workspace_bytes(const hv_wgrad_desc* d);                  // wgrad_halo.hip
@@ -852,8 +857,10 @@ extern "C" int hv_conv2d_wgrad(const hv_wgrad_desc* d, void* stream) {
     k.kt_q = pl.KT / d->Wo; k.kt_r = pl.KT % d->Wo;
     if (fast) { k.lw = __builtin_ctz(d->Wo); k.lhw = k.lw + __builtin_ctz(d->Ho); }
     hipStream_t s = (hipStream_t)stream;
+    HV_TIMING_BEGIN(s);
     if (d->precision == HV_F32) rc = fast ? launch_wgrad<float, true>(k, pl, s) : launch_wgrad<float, false>(k, pl, s);
     else rc = fast ? launch_wgrad<_Float16, true>(k, pl, s) : launch_wgrad<_Float16, false>(k, pl, s);
+    HV_TIMING_END(s);
     if (rc != HV_OK) return rc;
     if (!direct) {
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(hv_cdiv(nW, 64) + (d->dbias ? hv_cdiv(d->Cout, 64) : 0)), dim3(256), 0, s, d->workspace, d->dw, nW,

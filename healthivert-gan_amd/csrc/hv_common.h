@@ -15,6 +15,10 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
     } while (0)
 
 extern thread_local int hv_path_note;   // set by the launcher that actually launched (hv_last_kernel_path)
+// hv_set_kernel_timing: events recorded right around the MAIN kernel of the next weight-gradient call (not its slab reduction)
+extern thread_local hipEvent_t hv_ev_start, hv_ev_stop;
+#define HV_TIMING_BEGIN(s) do { if (hv_ev_start) (void)hipEventRecord(hv_ev_start, (s)); } while (0)
+#define HV_TIMING_END(s) do { if (hv_ev_stop) (void)hipEventRecord(hv_ev_stop, (s)); hv_ev_start = hv_ev_stop = nullptr; } while (0)
 
 static inline int hv_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 

@@ -310,7 +310,9 @@ static int launch_wh(const WHaloK& k, const WHaloPlan& pl, const hv_wgrad_desc* 
     }
     dim3 grid(pl.gx, hv_cdiv(d->Cout, BN), hv_cdiv(d->Cin, BC));
     hv_path_note = 11;
+    HV_TIMING_BEGIN(s);
     hipLaunchKernelGGL(kern, grid, dim3(256), pl.lds, s, k);
+    HV_TIMING_END(s);
     HV_LAUNCH_CHECK();
     return HV_OK;
 }
