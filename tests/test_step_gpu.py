@@ -147,13 +147,18 @@ def test_benchmark_configuration_bs16_matches_live_oracle(precision, loss_tol, a
         a, b = getattr(model, name).detach().cpu(), outs[name].detach()
         frac = ((a - b).abs() > act_tol).float().mean().item()
         assert frac <= 1e-3, (name, (a - b).abs().max().item(), frac)
-    # parameters after the Adam step: |dp| <= lr-scale tolerance (Adam's first step moves every weight by ~lr)
+    # parameter gradients (relative L2 error per tensor) and, in the exact-fp32 mode, the parameters after the Adam step (Adam's first
+    # step moves every weight by ~lr*sign(g): a sign flip of a round-off-level gradient shows as 2*lr, so only a small fraction may differ)
+    gtol = 2e-3 if precision == 'fp32' else 1e-1      # fp16 operands: the layers behind the attention soft-max see 5 % (observed), the rest < 1 %
     for n, sd in (('G', st.g), ('D_1', st.d[0]), ('D_2', st.d[1]), ('D_3', st.d[2])):
-        msd = getattr(model, 'net' + n).state_dict()
+        net = getattr(model, 'net' + n)
+        msd, params = net.state_dict(), dict(net.named_parameters())
         for k, v in sd.items():
-            if not (k.endswith('weight_orig') or k.endswith('.weight') or k.endswith('.bias')) or v.dtype != torch.float32:
+            if not (k.endswith('weight_orig') or k.endswith('.weight') or k.endswith('.bias')) or v.dtype != torch.float32 or v.grad is None:
                 continue
-            d = (msd[k].detach().cpu() - v.detach()).abs()
-            # a sign flip of a near-zero gradient moves a weight by 2*lr under Adam: allow a small fraction of such elements
-            # (fp16 operands: layers behind the attention soft-max have many gradients at round-off level -> up to a few percent)
-            assert (d > 1e-4).float().mean().item() <= (2e-3 if precision == 'fp32' else 5e-2), (n, k, d.max().item())
+            g_ref, g = v.grad.detach(), params[k].grad.detach().cpu()
+            rel = (g - g_ref).norm().item() / max(g_ref.norm().item(), 1e-12)
+            assert rel <= gtol, (n, k, rel)
+            if precision == 'fp32':
+                d = (msd[k].detach().cpu() - v.detach()).abs()
+                assert (d > 1e-4).float().mean().item() <= 2e-3, (n, k, d.max().item())
