@@ -18,6 +18,7 @@ struct HaloK {
     int Cout, w_row, y_ld, y_coff, Ho, Wo;
     int bstep, boff, ostep;
     float alpha; int act, accumulate, vec_store, ncls;
+    const float* mul_src; int mul_ld, mul_coff, mul_act, mul_vec;   // epilogue factor act'(mul_src[..]) or NULL; mul_vec: 16-B loads are aligned
     unsigned x_bytes, w_bytes;   // buffer descriptor ranges
     HaloCls cls[4];
 };

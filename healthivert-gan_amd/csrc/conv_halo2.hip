@@ -211,7 +211,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo2_kernel(const HaloK p) {   /
         const int i = i0 + ty, j = j0 + tx;
         if (i >= C.Hc || j >= C.Wc) continue;
         const int ho = C.ph + i * p.ostep, wo = C.pw + j * p.ostep;
-        float* yp = p.y + ((long long)(n_img * p.Ho + ho) * p.Wo + wo) * p.y_ld + p.y_coff;
+        const long long opix = (long long)(n_img * p.Ho + ho) * p.Wo + wo;
+        float* yp = p.y + opix * p.y_ld + p.y_coff;
 #pragma unroll
         for (int nn = 0; nn < NT; ++nn) {
             const int ch0 = n_base + wn * (BN / WN) + nn * 16 + (lane >> 4) * 4;
@@ -226,6 +227,18 @@ __global__ __launch_bounds__(256, 2) void conv_halo2_kernel(const HaloK p) {   /
                     if (p.accumulate == 2) tv += yp[ch];
                 }
                 v[r] = hv_act(tv, p.act);
+            }
+            if (p.mul_src) {   // hand the producer its pre-activation gradient: multiply by act'(its output)
+                const float* mp = p.mul_src + opix * p.mul_ld + p.mul_coff;
+                if (p.mul_vec && ch0 + 3 < p.Cout) {
+                    const float4 m4 = *reinterpret_cast<const float4*>(mp + ch0);
+                    v[0] *= hv_act_grad_from_out(m4.x, p.mul_act); v[1] *= hv_act_grad_from_out(m4.y, p.mul_act);
+                    v[2] *= hv_act_grad_from_out(m4.z, p.mul_act); v[3] *= hv_act_grad_from_out(m4.w, p.mul_act);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (ch0 + r < p.Cout) v[r] *= hv_act_grad_from_out(mp[ch0 + r], p.mul_act);
+                }
             }
             if (p.vec_store && ch0 + 3 < p.Cout) {
                 float4 o = make_float4(v[0], v[1], v[2], v[3]);

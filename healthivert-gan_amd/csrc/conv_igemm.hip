@@ -44,6 +44,7 @@ struct ConvK {
     int Cout, w_row, y_ld, y_coff, Ho, Wo;
     int bstep, boff, ostep;
     float alpha; int act, accumulate, vec_store, ncls;
+    const float* mul_src; int mul_ld, mul_coff, mul_act, mul_vec;   // epilogue factor act'(mul_src[..]) or NULL; mul_vec: 16-B loads are aligned
     ConvCls cls[4];
 };
 
@@ -269,7 +270,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
         const int n = mm / HWc, rem = mm - n * HWc;
         const int ii = rem / Wc, jj = rem - ii * Wc;
         const int ho = ph + ii * p.ostep, wo = pw + jj * p.ostep;
-        float* yp = p.y + ((long long)(n * p.Ho + ho) * p.Wo + wo) * p.y_ld + p.y_coff;
+        const long long opix = (long long)(n * p.Ho + ho) * p.Wo + wo;
+        float* yp = p.y + opix * p.y_ld + p.y_coff;
 #pragma unroll
         for (int nn = 0; nn < NT; ++nn) {
             const int ch0 = n_base + wn * TNW + nn * 16 + (lane >> 4) * 4;
@@ -285,6 +287,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
                     if (p.accumulate == 2) t += yp[ch];   // pre-activation accumulate (split-K over concatenated inputs)
                 }
                 v[r] = hv_act(t, p.act);
+            }
+            if (p.mul_src) {   // hand the producer its pre-activation gradient: multiply by act'(its output)
+                const float* mp = p.mul_src + opix * p.mul_ld + p.mul_coff;
+                if (p.mul_vec && ch0 + 3 < p.Cout) {
+                    const float4 m4 = *reinterpret_cast<const float4*>(mp + ch0);
+                    v[0] *= hv_act_grad_from_out(m4.x, p.mul_act); v[1] *= hv_act_grad_from_out(m4.y, p.mul_act);
+                    v[2] *= hv_act_grad_from_out(m4.z, p.mul_act); v[3] *= hv_act_grad_from_out(m4.w, p.mul_act);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (ch0 + r < p.Cout) v[r] *= hv_act_grad_from_out(mp[ch0 + r], p.mul_act);
+                }
             }
             if (p.vec_store && ch0 + 3 < p.Cout) {
                 float4 o = make_float4(v[0], v[1], v[2], v[3]);
@@ -367,11 +381,11 @@ extern "C" int hv_conv2d(const hv_conv_desc* d, void* stream) {
     // once instead of once per tap (many input channels, fp16 mode)
     static const int narrow_max_cin = getenv("HV_NARROW_MAX_CIN") ? atoi(getenv("HV_NARROW_MAX_CIN")) : 15;   // A/B knob
     const bool halo_ok = d->precision == HV_F16 && d->w_f16 && d->dil == 1 && (d->Cin & 15) == 0 && !d->w_bstride && !d->ch_scale;
-    if (d->Cout == 1 && !d->transposed && !(halo_ok && d->Cin > narrow_max_cin)) {
+    if (d->Cout == 1 && !d->transposed && !d->mul_src && !(halo_ok && d->Cin > narrow_max_cin)) {
         const int rc = hv_conv2d_narrow(d, (hipStream_t)stream);
         if (rc != HV_ERR_UNSUPPORTED) return rc;
     }
-    if (d->Cin <= 4 && !d->transposed) {   // image-like inputs: direct fp32 VALU kernel, output-write bound (conv_narrow.hip)
+    if (d->Cin <= 4 && !d->transposed && !d->mul_src) {   // image-like inputs: direct fp32 VALU kernel, output-write bound (conv_narrow.hip)
         const int rc = hv_conv2d_thin_in(d, (hipStream_t)stream);
         if (rc != HV_ERR_UNSUPPORTED) return rc;
     }
@@ -382,6 +396,8 @@ extern "C" int hv_conv2d(const hv_conv_desc* d, void* stream) {
     ConvK k;
     k.x = d->x; k.w = d->w; k.bias = d->bias; k.scale = d->ch_scale; k.y = d->y;
     k.w_bs = d->w_bstride; k.scale_bs = d->ch_scale ? d->ch_scale_bstride : 0;
+    k.mul_src = d->mul_src; k.mul_ld = d->mul_ld; k.mul_coff = d->mul_coff; k.mul_act = d->mul_act;
+    k.mul_vec = (d->mul_src && !(d->mul_ld & 3) && !(d->mul_coff & 3) && !((uintptr_t)d->mul_src & 15)) ? 1 : 0;
     k.B = d->B; k.Hl = d->H; k.Wl = d->W; k.in_shift = d->in_shift; k.Wp = Wp; k.img_stride = Hp * Wp * d->x_ld;
     k.x_ld = d->x_ld; k.x_coff = d->x_coff; k.Cin = d->Cin;
     k.Cout = d->Cout; k.w_row = d->KH * d->KW * d->Cin; k.y_ld = d->y_ld; k.y_coff = d->y_coff; k.Ho = d->Ho; k.Wo = d->Wo;

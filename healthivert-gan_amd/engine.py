@@ -207,17 +207,21 @@ def _wgrad(node, p, xin, gfull, accumulate, prec, dbias=None, dbias_accumulate=F
                          dbias=dbias, dbias_accumulate=dbias_accumulate)
 
 
-def conv_backward(node, book, prec, dbias_accumulate=False, wgrad_accumulate=False, tmp_full=None, wgrad=True, x_wg=None):
+def conv_backward(node, book, prec, dbias_accumulate=False, wgrad_accumulate=False, tmp_full=None, wgrad=True, x_wg=None, premultiplied=False,
+                  mul_x=None):
     """Backward of one ConvNode: activation gradient (+bias gradient), weight gradient, data gradient.
-    x_wg: channel-padded copy of the input for the weight-gradient kernel (1-channel image inputs)."""
+    x_wg: channel-padded copy of the input for the weight-gradient kernel (1-channel image inputs).
+    premultiplied: the gradient buffer of node.y already holds the PRE-activation gradient (its only writer applied act').
+    mul_x: activation name of the layer that produced node.x -- the data gradient is multiplied by act'(node.x) in the conv
+    epilogue, so that layer's backward starts `premultiplied` (conv_backward_chain)."""
     p = node.p
     gy = book.twin(node.y)
     want_dbias = p.bias is not None and node.use_bias and wgrad
     # the bias gradient (column sums of the activation gradient) rides in the weight-gradient kernels, which stream g anyway;
     # conv_transpose nodes (roles of x and g swapped there) and unpadded channel counts keep the stand-alone reduction
     fuse_dbias = want_dbias and not node.transposed and FUSE_DBIAS and p.coutP == p.cout
-    if node.act != 'none' or (want_dbias and not fuse_dbias):
-        ops.act_backward(gy, node.y, node.act, dbias=p.bias.grad if (want_dbias and not fuse_dbias) else None, dbias_accumulate=dbias_accumulate)
+    if (node.act != 'none' and not premultiplied) or (want_dbias and not fuse_dbias):
+        ops.act_backward(gy, node.y, 'none' if premultiplied else node.act, dbias=p.bias.grad if (want_dbias and not fuse_dbias) else None, dbias_accumulate=dbias_accumulate)
     gfull = Act(gy.t, p.coutP, gy.coff)
     if wgrad:
         xs = node.x if x_wg is None else x_wg
@@ -240,10 +244,25 @@ def conv_backward(node, book, prec, dbias_accumulate=False, wgrad_accumulate=Fal
             ops.copy_channels(full, gx, mode=3, accumulate=book.mark(gx))
         else:
             ops.conv2d(gfull, p.w_bwd, gx, node.k, node.s, node.pad, node.d, transposed=True, accumulate=int(book.mark(gx)), w_h=p.w_bwd_h,
-                       precision=prec)
+                       precision=prec, mul=(Act(node.x.t, p.cin_fwd, node.x.coff), mul_x) if mul_x else None)
 
 
-# ================================================================================================ contextual attention
+FUSE_ACT = os.environ.get('HV_FUSE_ACT', '1') != '0'   # act' of the producer layer applied in the consumer's data-gradient epilogue
+
+
+def conv_backward_chain(nodes, book, prec, tmp_full=None):
+    """Backward of a PURE chain of ConvNodes given in backward order: nodes[i].x is exactly the output buffer of nodes[i+1] and
+    nothing else reads or writes that buffer's gradient.  Inside the chain the data gradient of nodes[i] is multiplied by
+    act'(output of nodes[i+1]) in its conv epilogue, so nodes[i+1] starts from its pre-activation gradient: the in-place
+    act-gradient pass (read g, read y, write g) between two convs disappears."""
+    pre = False
+    for i, n in enumerate(nodes):
+        nxt = nodes[i + 1] if i + 1 < len(nodes) else None
+        link = (FUSE_ACT and nxt is not None and n.need_dx and not n.transposed and not n.shift and nxt.act != 'none'
+                and n.x.t is nxt.y.t and n.x.coff == nxt.y.coff and n.p.cin_fwd <= nxt.y.t.shape[-1] - nxt.y.coff)
+        conv_backward(n, book, prec, premultiplied=pre, mul_x=nxt.act if link else None, tmp_full=(tmp_full or {}).get(id(n)))
+        pre = link
+
 class AttentionPlan:
     """ContextualAttention(ksize=3, stride=1, rate=2, fuse_k=3, softmax_scale=10, fuse=True) on an NHWC feature map
     (reference models/inpaint_networks.py:235-410)."""

@@ -433,23 +433,18 @@ class Generator(nn.Module):
         d_xs1_total = P.__dict__.setdefault('d_xs1_total', torch.zeros_like(P.x_stage1))
         ops.copy_channels(Act(d_x_stage1.view(B, H, W, 1)), Act(d_xs1_total.view(B, H, W, 1)), mode=0)
         ops.copy_channels(gcat17.slice(c // 2, 1), Act(d_xs1_total.view(B, H, W, 1)), mode=0, accumulate=True)
-        E.conv_backward(M[6], book, prec)
-        E.conv_backward(M[5], book, prec, tmp_full=self._tmp_up(P, M[5]))
-        E.conv_backward(M[4], book, prec)
-        E.conv_backward(M[3], book, prec, tmp_full=self._tmp_up(P, M[3]))
-        E.conv_backward(M[2], book, prec)
-        E.conv_backward(M[1], book, prec)
+        # pure links (single producer, single consumer): the consumer's data gradient applies the producer's act'
+        E.conv_backward_chain([M[6], M[5]], book, prec, tmp_full={id(M[5]): self._tmp_up(P, M[5])})
+        E.conv_backward_chain([M[4], M[3]], book, prec, tmp_full={id(M[3]): self._tmp_up(P, M[3])})
+        E.conv_backward_chain([M[2], M[1]], book, prec)        # a11 (input of M[1]) also feeds the height head: not fused
         ops.gap_fc_sigmoid_backward(d_pred2, P.pred2, P.f_pool, fg.fc_height.weight, book.twin(a['a11']),
                                     fg.fc_height.weight.grad, fg.fc_height.bias.grad)
         E.conv_backward(M[0], book, prec)
-        for n in reversed(P.f_nodes_pm2):
-            E.conv_backward(n, book, prec)
+        E.conv_backward_chain(list(reversed(P.f_nodes_pm2)), book, prec)
         gp6 = book.twin(a['p6'])
         P.attn.backward(book.twin(a['ca']), gp6, book.mark(gp6), prec)
-        for n in reversed(P.f_nodes_pm):
-            E.conv_backward(n, book, prec)
-        for n in reversed(P.f_nodes_conv):
-            E.conv_backward(n, book, prec)
+        E.conv_backward_chain(list(reversed(P.f_nodes_pm)), book, prec)
+        E.conv_backward_chain(list(reversed(P.f_nodes_conv)), book, prec)
         # coarse_seg enters the fine generator as channel 1 of its input
         d_cs_total = P.__dict__.setdefault('d_cs_total', torch.zeros_like(P.coarse_seg))
         ops.copy_channels(Act(d_coarse_seg.view(B, H, W, 1)), Act(d_cs_total.view(B, H, W, 1)), mode=0)
@@ -458,17 +453,16 @@ class Generator(nn.Module):
         C = P.c_nodes
         self._head_backward(P, C[18], d_xs1_total, 'c17', prec, book)
         self._head_backward(P, C[19], d_cs_total, 'c18', prec, book)
-        E.conv_backward(C[17], book, prec); E.conv_backward(C[16], book, prec); E.conv_backward(C[15], book, prec)
+        E.conv_backward_chain([C[17], C[16], C[15]], book, prec)
         g14 = book.twin(a['c14'])
         ops.copy_channels(book.twin(a['cat19']).slice(0, 2 * c), g14, mode=3, accumulate=book.mark(g14))
-        E.conv_backward(C[14], book, prec); E.conv_backward(C[13], book, prec); E.conv_backward(C[12], book, prec)
+        E.conv_backward_chain([C[14], C[13], C[12]], book, prec)
         g12 = book.twin(a['c12'])
         ops.copy_channels(book.twin(a['cat20']).slice(0, 4 * c), g12, mode=3, accumulate=book.mark(g12))
-        E.conv_backward(C[11], book, prec); E.conv_backward(C[10], book, prec)
+        E.conv_backward_chain([C[11], C[10]], book, prec)
         ops.gap_fc_sigmoid_backward(d_pred1, P.pred1, P.c_pool, cg.fc_height.weight, book.twin(a['c10']),
                                     cg.fc_height.weight.grad, cg.fc_height.bias.grad)
-        for n in reversed(C[:10]):
-            E.conv_backward(n, book, prec)
+        E.conv_backward_chain(list(reversed(C[:10])), book, prec)
         book.join()     # side-stream weight gradients
         self.paramset().finish_backward(accumulate=False)
         self.paramset().attach_grads()

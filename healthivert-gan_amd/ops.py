@@ -128,8 +128,8 @@ def conv_out_size(n, k, stride, pad, dil):
 
 
 def conv2d(x, w, y, k, stride=1, pad=0, dil=1, bias=None, act='none', transposed=False, in_shift=0, alpha=1.0,
-           accumulate=0, ch_scale=None, w_bstride=0, ch_scale_bstride=0, precision=None, cin=None, cout=None, w_h=None):
-    """y = act(alpha*ch_scale*conv(x, w) + bias).  x,y: Act; w: prepared [CoutF][k*k][CinP] tensor (or [B][...] with
+           accumulate=0, ch_scale=None, w_bstride=0, ch_scale_bstride=0, precision=None, cin=None, cout=None, w_h=None, mul=None):
+    """y = act(alpha*ch_scale*conv(x, w) + bias)  [* act'(m) with mul = (Act m, activation name): see hv_conv_desc.mul_src].  x,y: Act; w: prepared [CoutF][k*k][CinP] tensor (or [B][...] with
     w_bstride).  cin/cout default to the view widths (x.C consumed, y.C produced)."""
     L = _lib.get()
     d = L.hv_conv_desc()
@@ -148,6 +148,9 @@ def conv2d(x, w, y, k, stride=1, pad=0, dil=1, bias=None, act='none', transposed
     d.Ho, d.Wo, d.y_ld, d.y_coff = y.H, y.W, y.ld, y.coff
     d.precision = precision_id(precision)
     d.w_f16 = None if w_h is None else ptr(w_h).value
+    if mul is not None:
+        m, mact = mul
+        d.mul_src, d.mul_ld, d.mul_coff, d.mul_act = ptr(m.t).value, m.ld, m.coff, ACT[mact]
     if _TIMER is not None:
         taps = kh * kw if not transposed else max(1, (kh * kw) // (stride * stride))
         flops = 2.0 * y.B * y.H * y.W * d.Cout * taps * d.Cin

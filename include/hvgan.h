@@ -70,6 +70,11 @@ typedef struct {
     int precision;
     const void* w_f16;                /* optional fp16 copy of w (same layout, from hv_weight_prep): enables the
                                          halo-tiled kernel for HV_F16, dilation 1, Cin % 16 == 0, shared filters */
+    const float* mul_src; int mul_ld, mul_coff, mul_act;
+                                      /* optional epilogue factor: r *= act'(m) with m = mul_src[pixel*mul_ld + mul_coff + channel] the OUTPUT
+                                         of activation mul_act at the same pixel/channel, applied after act and before accumulate == 1.
+                                         Used by data gradients to hand the producer layer its pre-activation gradient directly
+                                         (the separate in-place multiply pass over the gradient disappears).  NULL = none */
 } hv_conv_desc;
 int hv_conv2d(const hv_conv_desc* d, void* stream);
 
