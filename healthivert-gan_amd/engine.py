@@ -250,12 +250,12 @@ def conv_backward(node, book, prec, dbias_accumulate=False, wgrad_accumulate=Fal
 FUSE_ACT = os.environ.get('HV_FUSE_ACT', '1') != '0'   # act' of the producer layer applied in the consumer's data-gradient epilogue
 
 
-def conv_backward_chain(nodes, book, prec, tmp_full=None):
+def conv_backward_chain(nodes, book, prec, tmp_full=None, premultiplied_first=False):
     """Backward of a PURE chain of ConvNodes given in backward order: nodes[i].x is exactly the output buffer of nodes[i+1] and
     nothing else reads or writes that buffer's gradient.  Inside the chain the data gradient of nodes[i] is multiplied by
     act'(output of nodes[i+1]) in its conv epilogue, so nodes[i+1] starts from its pre-activation gradient: the in-place
     act-gradient pass (read g, read y, write g) between two convs disappears."""
-    pre = False
+    pre = premultiplied_first and FUSE_ACT     # every writer of nodes[0]'s output gradient already applied its act'
     for i, n in enumerate(nodes):
         nxt = nodes[i + 1] if i + 1 < len(nodes) else None
         link = (FUSE_ACT and nxt is not None and n.need_dx and not n.transposed and not n.shift and nxt.act != 'none'

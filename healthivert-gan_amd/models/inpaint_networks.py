@@ -404,12 +404,12 @@ class Generator(nn.Module):
             P.tmp_up[key] = Act(torch.zeros(x.B, x.H * 2, x.W * 2, x.ld, dtype=torch.float32, device=x.t.device), node.p.cin_fwd, 0)
         return P.tmp_up[key]
 
-    def _head_backward(self, P, node, seed, gname, prec, book):
+    def _head_backward(self, P, node, seed, gname, prec, book, mul_x=None):
         """1-channel head: seed (B,1,H,W) -> padded carrier -> activation/bias gradient -> wgrad + dgrad."""
         carrier = P.g_head[gname]                       # [B,H,W,4], channel 0 live
         ops.copy_channels(Act(seed.view(P.B, P.H, P.W, 1)), carrier, mode=0)
         book.twins[id(node.y.t)] = carrier.t            # the head's output gradient lives in the carrier
-        E.conv_backward(node, book, prec)
+        E.conv_backward(node, book, prec, mul_x=mul_x if E.FUSE_ACT else None)
 
     def run_backward(self, P, d_coarse_seg, d_fine_seg, d_x_stage1, d_x_stage2, d_pred1, d_pred2):
         """Gradients of a scalar loss wrt the six differentiable outputs -> .grad of every parameter.
@@ -439,21 +439,23 @@ class Generator(nn.Module):
         E.conv_backward_chain([M[2], M[1]], book, prec)        # a11 (input of M[1]) also feeds the height head: not fused
         ops.gap_fc_sigmoid_backward(d_pred2, P.pred2, P.f_pool, fg.fc_height.weight, book.twin(a['a11']),
                                     fg.fc_height.weight.grad, fg.fc_height.bias.grad)
-        E.conv_backward(M[0], book, prec)
-        E.conv_backward_chain(list(reversed(P.f_nodes_pm2)), book, prec)
+        # cat11 = [conv10_atrous | pmconv10], both ELU: allconv11's data gradient applies elu' for both producers
+        E.conv_backward(M[0], book, prec, mul_x='elu' if E.FUSE_ACT else None)
+        E.conv_backward_chain(list(reversed(P.f_nodes_pm2)), book, prec, premultiplied_first=True)
         gp6 = book.twin(a['p6'])
         P.attn.backward(book.twin(a['ca']), gp6, book.mark(gp6), prec)
         E.conv_backward_chain(list(reversed(P.f_nodes_pm)), book, prec)
-        E.conv_backward_chain(list(reversed(P.f_nodes_conv)), book, prec)
+        E.conv_backward_chain(list(reversed(P.f_nodes_conv)), book, prec, premultiplied_first=True)
         # coarse_seg enters the fine generator as channel 1 of its input
         d_cs_total = P.__dict__.setdefault('d_cs_total', torch.zeros_like(P.coarse_seg))
         ops.copy_channels(Act(d_coarse_seg.view(B, H, W, 1)), Act(d_cs_total.view(B, H, W, 1)), mode=0)
         ops.copy_channels(book.twin(P.f_in).slice(1, 1), Act(d_cs_total.view(B, H, W, 1)), mode=0, accumulate=True)
         # ---- coarse
         C = P.c_nodes
-        self._head_backward(P, C[18], d_xs1_total, 'c17', prec, book)
-        self._head_backward(P, C[19], d_cs_total, 'c18', prec, book)
-        E.conv_backward_chain([C[17], C[16], C[15]], book, prec)
+        # both heads read c16 (output of conv16, ELU): each applies elu'(c16) to its share of the gradient
+        self._head_backward(P, C[18], d_xs1_total, 'c17', prec, book, mul_x='elu')
+        self._head_backward(P, C[19], d_cs_total, 'c18', prec, book, mul_x='elu')
+        E.conv_backward_chain([C[17], C[16], C[15]], book, prec, premultiplied_first=True)
         g14 = book.twin(a['c14'])
         ops.copy_channels(book.twin(a['cat19']).slice(0, 2 * c), g14, mode=3, accumulate=book.mark(g14))
         E.conv_backward_chain([C[14], C[13], C[12]], book, prec)
