@@ -286,6 +286,7 @@ class NLayerDiscriminator(nn.Module):
         book.twins.pop(getattr(P, '_in_id', None), None)
         P._in_id = id(P.x_in.t)
         book.twins[P._in_id] = P.dx.view(B, P.H, P.W, 1)
+        fuse0 = E.FUSE_ACT and len(P.layers) > 1 and P.layers[0]['node'].act != 'none' and not P.layers[1]['node'].shift
         for li in range(len(P.layers) - 1, -1, -1):
             ent = P.layers[li]
             L, node = ent['spec'], ent['node']
@@ -295,7 +296,7 @@ class NLayerDiscriminator(nn.Module):
                     ops.copy_channels(P.x_in, P.x4, mode=0)
                 node.need_dx = need_dx
                 E.conv_backward(node, book, prec, dbias_accumulate=accumulate, wgrad_accumulate=accumulate, wgrad=param_grads,
-                                x_wg=P.x4 if param_grads else None)
+                                x_wg=P.x4 if param_grads else None, premultiplied=fuse0)
                 break
             if not L['last']:
                 nm = self.model[L['norm']]
@@ -306,7 +307,9 @@ class NLayerDiscriminator(nn.Module):
                                       dgamma=nm.weight.grad if (bn and param_grads) else None,
                                       dbeta=nm.bias.grad if (bn and param_grads) else None, param_accumulate=accumulate,
                                       groups=P.groups)
-            E.conv_backward(node, book, prec, dbias_accumulate=accumulate, wgrad_accumulate=accumulate, wgrad=param_grads)
+            # the stem's output has one consumer (layer 1): its LeakyReLU' rides in layer 1's data-gradient epilogue
+            E.conv_backward(node, book, prec, dbias_accumulate=accumulate, wgrad_accumulate=accumulate, wgrad=param_grads,
+                            mul_x=P.layers[0]['node'].act if (li == 1 and fuse0) else None)
         if need_dx:
             g = book.twin(P.x_in)
             return g.t.view(B, 1, P.H, P.W)
