@@ -247,22 +247,52 @@ def conv_backward(node, book, prec, dbias_accumulate=False, wgrad_accumulate=Fal
                        precision=prec, mul=(Act(node.x.t, p.cin_fwd, node.x.coff), mul_x) if mul_x else None)
 
 
+BRANCHES = os.environ.get('HV_G_BRANCHES', '0') != '0'   # independent generator branches on two HIP streams / graph branches
+#   (measured under graph replay: 16.3 / 16.5 ms on vs 16.5 ms off -- within noise, so off by default)
+_branch_streams = {}
+
+
+def branch_stream():
+    """Side stream for an independent branch of the generator (None when everything must stay on one stream).  Weight gradients
+    issued on it stay in line (no nested fork: see NO_FORK_STREAMS)."""
+    if not BRANCHES or SERIAL:
+        return None
+    cur = torch.cuda.current_stream()
+    if cur.cuda_stream in NO_FORK_STREAMS:
+        return None
+    key = cur.device.index
+    st = _branch_streams.get(key)
+    if st is None:
+        st = _branch_streams[key] = torch.cuda.Stream(device=cur.device)
+        NO_FORK_STREAMS.add(st.cuda_stream)
+    return st
+
+
 FUSE_ACT = os.environ.get('HV_FUSE_ACT', '1') != '0'   # act' of the producer layer applied in the consumer's data-gradient epilogue
 
 
-def conv_backward_chain(nodes, book, prec, tmp_full=None, premultiplied_first=False):
+def chain_link(n, nxt):
+    """True when n's data gradient can carry act' of nxt (the producer of n.x): see conv_backward_chain."""
+    return bool(FUSE_ACT and nxt is not None and n.need_dx and not n.transposed and not n.shift and nxt.act != 'none'
+                and n.x.t is nxt.y.t and n.x.coff == nxt.y.coff and n.p.cin_fwd <= nxt.y.t.shape[-1] - nxt.y.coff)
+
+
+def conv_backward_chain(nodes, book, prec, tmp_full=None, premultiplied_first=False, stop_before=None):
     """Backward of a PURE chain of ConvNodes given in backward order: nodes[i].x is exactly the output buffer of nodes[i+1] and
     nothing else reads or writes that buffer's gradient.  Inside the chain the data gradient of nodes[i] is multiplied by
     act'(output of nodes[i+1]) in its conv epilogue, so nodes[i+1] starts from its pre-activation gradient: the in-place
-    act-gradient pass (read g, read y, write g) between two convs disappears."""
+    act-gradient pass (read g, read y, write g) between two convs disappears.
+    stop_before: the node that follows nodes[-1] in the chain but is run by the caller later (with
+    premultiplied=chain_link(nodes[-1], stop_before))."""
     pre = premultiplied_first and FUSE_ACT     # every writer of nodes[0]'s output gradient already applied its act'
     for i, n in enumerate(nodes):
-        nxt = nodes[i + 1] if i + 1 < len(nodes) else None
-        link = (FUSE_ACT and nxt is not None and n.need_dx and not n.transposed and not n.shift and nxt.act != 'none'
-                and n.x.t is nxt.y.t and n.x.coff == nxt.y.coff and n.p.cin_fwd <= nxt.y.t.shape[-1] - nxt.y.coff)
+        nxt = nodes[i + 1] if i + 1 < len(nodes) else stop_before
+        link = chain_link(n, nxt)
         conv_backward(n, book, prec, premultiplied=pre, mul_x=nxt.act if link else None, tmp_full=(tmp_full or {}).get(id(n)))
         pre = link
 
+
+# ================================================================================================ contextual attention
 class AttentionPlan:
     """ContextualAttention(ksize=3, stride=1, rate=2, fuse_k=3, softmax_scale=10, fuse=True) on an NHWC feature map
     (reference models/inpaint_networks.py:235-410)."""

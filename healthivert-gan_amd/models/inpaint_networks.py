@@ -5,6 +5,7 @@ state-dict keys and 7-tuple return: reference :16-32, :36-117, :120-232, :235-41
 the forward/backward are explicit kernel sequences from `engine.py` over NHWC buffers; the torch
 modules created here are parameter containers only (their own forward is never run).
 """
+import contextlib
 import ctypes
 
 import torch
@@ -382,13 +383,21 @@ class Generator(nn.Module):
             n.forward(prec)
         # ---- fine
         ops.gen_input(x, P.coarse_seg, mask, ratio, P.f_in, 1)
+        # the dilated-conv branch and the attention branch only share their input: two streams (two branches of the step graph)
+        side = E.branch_stream()
+        main = torch.cuda.current_stream()
+        if side is not None:
+            side.wait_stream(main)
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            for n in P.f_nodes_pm:
+                n.forward(prec)
+            P.attn.forward(a['p6'], mask, a['ca'], prec)
+            for n in P.f_nodes_pm2:
+                n.forward(prec)
         for n in P.f_nodes_conv:
             n.forward(prec)
-        for n in P.f_nodes_pm:
-            n.forward(prec)
-        P.attn.forward(a['p6'], mask, a['ca'], prec)
-        for n in P.f_nodes_pm2:
-            n.forward(prec)
+        if side is not None:
+            main.wait_stream(side)
         P.f_nodes_merge[0].forward(prec)
         ops.gap_fc_sigmoid(a['a11'], fg.fc_height.weight, fg.fc_height.bias, P.f_pool, P.pred2)
         for n in P.f_nodes_merge[1:7]:
@@ -441,11 +450,22 @@ class Generator(nn.Module):
                                     fg.fc_height.weight.grad, fg.fc_height.bias.grad)
         # cat11 = [conv10_atrous | pmconv10], both ELU: allconv11's data gradient applies elu' for both producers
         E.conv_backward(M[0], book, prec, mul_x='elu' if E.FUSE_ACT else None)
-        E.conv_backward_chain(list(reversed(P.f_nodes_pm2)), book, prec, premultiplied_first=True)
-        gp6 = book.twin(a['p6'])
-        P.attn.backward(book.twin(a['ca']), gp6, book.mark(gp6), prec)
-        E.conv_backward_chain(list(reversed(P.f_nodes_pm)), book, prec)
+        # the two branches run concurrently; both end in the gradient of f_in: the attention branch stops before its first conv,
+        # which is run after the join (assign / accumulate order of the shared buffer stays that of the single-stream schedule)
+        side = E.branch_stream()
+        main = torch.cuda.current_stream()
+        pm_rev = list(reversed(P.f_nodes_pm))
+        if side is not None:
+            side.wait_stream(main)
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            E.conv_backward_chain(list(reversed(P.f_nodes_pm2)), book, prec, premultiplied_first=True)
+            gp6 = book.twin(a['p6'])
+            P.attn.backward(book.twin(a['ca']), gp6, book.mark(gp6), prec)
+            E.conv_backward_chain(pm_rev if side is None else pm_rev[:-1], book, prec, stop_before=None if side is None else pm_rev[-1])
         E.conv_backward_chain(list(reversed(P.f_nodes_conv)), book, prec, premultiplied_first=True)
+        if side is not None:
+            main.wait_stream(side)
+            E.conv_backward(pm_rev[-1], book, prec, premultiplied=E.chain_link(pm_rev[-2], pm_rev[-1]))
         # coarse_seg enters the fine generator as channel 1 of its input
         d_cs_total = P.__dict__.setdefault('d_cs_total', torch.zeros_like(P.coarse_seg))
         ops.copy_channels(Act(d_coarse_seg.view(B, H, W, 1)), Act(d_cs_total.view(B, H, W, 1)), mode=0)
