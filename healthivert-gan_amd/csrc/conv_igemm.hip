@@ -770,11 +770,12 @@ static int wgrad_plan(const hv_wgrad_desc* d, WgradPlan* pl) {
     const int J = d->KH * d->KW * d->Cin;
     const long long M = (long long)d->B * d->Ho * d->Wo;
     static const bool wide64 = !(getenv("HV_WGRAD_WIDE") && atoi(getenv("HV_WGRAD_WIDE")) == 0);   // A/B knob
+    static const int bc128_minj = getenv("HV_WGRAD_BC128_MINJ") ? atoi(getenv("HV_WGRAD_BC128_MINJ")) : 4096;   // tuning knob
     int BN, BC;
     if (d->Cout <= 16) { BN = 16; BC = 128; }
     else if (d->Cout <= 32) { BN = 32; BC = 128; }
     else if (d->Cout <= 64) { BN = 64; BC = (J >= 512 && wide64) ? 256 : 64; }   // wide J tile: G is re-read J/256 instead of J/64 times
-    else { BN = 128; BC = J >= 4096 ? 128 : 64; }
+    else { BN = 128; BC = J >= bc128_minj ? 128 : 64; }
     const long long tiles = (long long)hv_cdiv(d->Cout, BN) * hv_cdiv(J, BC);
     // ~3 workgroups per CU; layers whose dW already has many tiles get few splits (slab traffic grows with splits)
     static const int want_wg = getenv("HV_WGRAD_WANT") ? atoi(getenv("HV_WGRAD_WANT")) : 768;   // tuning knob
