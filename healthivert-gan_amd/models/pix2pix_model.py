@@ -101,7 +101,8 @@ class Pix2PixModel(BaseModel):
             if b is None or b.shape != t.shape or b.dtype != dtype:
                 b = torch.empty(t.shape, dtype=dtype, device=self.device)
                 self._in[name] = b
-                self._graphs = None        # input addresses changed: captured graphs are stale
+                self._graphs = None        # input addresses changed: captured graphs are stale,
+                self._eager_steps = 0      # and the new shape needs its own eager warm-up (plans, tables) before a capture
             b.copy_(t, non_blocking=True)
             return b
         self.real_B = put('real_B', input['B' if AtoB else 'A'], torch.float32)

@@ -166,3 +166,31 @@ def test_benchmark_configuration_bs16_matches_live_oracle(precision, loss_tol, a
             if precision == 'fp32':
                 d = (msd[k].detach().cpu() - v.detach()).abs()
                 assert (d > 1e-4).float().mean().item() <= 2e-3, (n, k, d.max().item())
+
+
+def test_graph_recapture_when_the_batch_shape_changes(monkeypatch):
+    """A last, smaller batch of an epoch: the captured graphs are dropped, the new shape warms up eagerly and is captured again;
+    results stay those of eager launches."""
+    monkeypatch.setenv('HV_PRECISION', 'fp16')
+    import hvgan
+    from hvgan import synth
+    from hvgan.models.pix2pix_model import Pix2PixModel
+
+    def run(use_graph):
+        torch.manual_seed(7)
+        model = Pix2PixModel(make_opt())
+        model.use_graph = use_graph
+        seen = []
+        for step, B in enumerate((2, 2, 2, 2, 1, 1, 1, 2, 2, 2)):
+            model.set_input(synth.make_batch(B, 256, seed=900 + step))
+            model.optimize_parameters()
+            seen.append(model._graphs is not None)
+        torch.cuda.synchronize()
+        return seen, {k: v.detach().clone() for k, v in model.netG.state_dict().items()}, model.get_current_losses()
+
+    se, we, le = run(False)
+    sg, wg, lg = run(True)
+    assert sg == [False, False, True, True, False, False, True, False, False, True] and not any(se)
+    for k in we:
+        assert torch.equal(we[k], wg[k]), k
+    assert le == lg
