@@ -206,6 +206,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloK p) {
     }
 
     // ---- epilogue (same contract as conv_igemm_kernel)
+    const HvEpi epi = {p.alpha, p.act, p.accumulate, p.vec_store, p.Cout, p.bias, nullptr, p.mul_act, p.mul_vec};
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int g = wm * MT + m, ty = g / GX, tx = (g % GX) * 16 + (lane & 15);
@@ -217,42 +218,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloK p) {
 #pragma unroll
         for (int nn = 0; nn < NT; ++nn) {
             const int ch0 = n_base + wn * (BN / WN) + nn * 16 + (lane >> 4) * 4;
-            if (ch0 >= p.Cout) continue;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float tv = acc[nn][m][r] * p.alpha;
-                const int ch = ch0 + r;
-                if (ch < p.Cout) {
-                    if (p.bias) tv += p.bias[ch];
-                    if (p.accumulate == 2) tv += yp[ch];
-                }
-                v[r] = hv_act(tv, p.act);
-            }
-            if (p.mul_src) {   // hand the producer its pre-activation gradient: multiply by act'(its output)
-                const float* mp = p.mul_src + opix * p.mul_ld + p.mul_coff;
-                if (p.mul_vec && ch0 + 3 < p.Cout) {
-                    const float4 m4 = *reinterpret_cast<const float4*>(mp + ch0);
-                    v[0] *= hv_act_grad_from_out(m4.x, p.mul_act); v[1] *= hv_act_grad_from_out(m4.y, p.mul_act);
-                    v[2] *= hv_act_grad_from_out(m4.z, p.mul_act); v[3] *= hv_act_grad_from_out(m4.w, p.mul_act);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (ch0 + r < p.Cout) v[r] *= hv_act_grad_from_out(mp[ch0 + r], p.mul_act);
-                }
-            }
-            if (p.vec_store && ch0 + 3 < p.Cout) {
-                float4 o = make_float4(v[0], v[1], v[2], v[3]);
-                if (p.accumulate == 1) {
-                    const float4 old = *reinterpret_cast<const float4*>(yp + ch0);
-                    o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
-                }
-                *reinterpret_cast<float4*>(yp + ch0) = o;
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (ch0 + r < p.Cout) yp[ch0 + r] = p.accumulate == 1 ? yp[ch0 + r] + v[r] : v[r];
-            }
+            hv_conv_epilogue4(epi, acc[nn][m], ch0, yp, p.mul_src ? p.mul_src + opix * p.mul_ld + p.mul_coff : nullptr);
         }
     }
 }

@@ -67,3 +67,50 @@ __device__ __forceinline__ float hv_block_sum(float v, float* red /* >= 17 float
     for (int i = 0; i < nw; ++i) s += red[i];
     return s;
 }
+
+// Shared conv epilogue for one lane's 4 consecutive output channels (ch0 .. ch0+3) of one output pixel:
+//   t = acc*alpha [*scale] [+bias] [+y if accumulate == 2];  v = act(t) [* act'(mul)];  y = v  or  y += v (accumulate == 1)
+// yp / mp point at the pixel's channel 0 (mp = NULL: no multiplier); scale / bias are per-channel arrays or NULL.
+struct HvEpi {
+    float alpha; int act, accumulate, vec_store, Cout;
+    const float* bias; const float* scale;
+    int mul_act, mul_vec;
+};
+__device__ __forceinline__ void hv_conv_epilogue4(const HvEpi& e, const f32x4& a, int ch0, float* __restrict__ yp, const float* __restrict__ mp) {
+    if (ch0 >= e.Cout) return;
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float t = a[r] * e.alpha;
+        const int ch = ch0 + r;
+        if (ch < e.Cout) {
+            if (e.scale) t *= e.scale[ch];
+            if (e.bias) t += e.bias[ch];
+            if (e.accumulate == 2) t += yp[ch];   // pre-activation accumulate (split-K over concatenated inputs)
+        }
+        v[r] = hv_act(t, e.act);
+    }
+    if (mp) {   // hand the producer layer its pre-activation gradient: multiply by act'(its output)
+        if (e.mul_vec && ch0 + 3 < e.Cout) {
+            const float4 m4 = *reinterpret_cast<const float4*>(mp + ch0);
+            v[0] *= hv_act_grad_from_out(m4.x, e.mul_act); v[1] *= hv_act_grad_from_out(m4.y, e.mul_act);
+            v[2] *= hv_act_grad_from_out(m4.z, e.mul_act); v[3] *= hv_act_grad_from_out(m4.w, e.mul_act);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (ch0 + r < e.Cout) v[r] *= hv_act_grad_from_out(mp[ch0 + r], e.mul_act);
+        }
+    }
+    if (e.vec_store && ch0 + 3 < e.Cout) {
+        float4 o = make_float4(v[0], v[1], v[2], v[3]);
+        if (e.accumulate == 1) {
+            const float4 old = *reinterpret_cast<const float4*>(yp + ch0);
+            o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+        }
+        *reinterpret_cast<float4*>(yp + ch0) = o;
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (ch0 + r < e.Cout) yp[ch0 + r] = e.accumulate == 1 ? yp[ch0 + r] + v[r] : v[r];
+    }
+}
