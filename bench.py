@@ -123,7 +123,7 @@ def main():
     # kernel's launches (a captured graph cannot carry timing events, and with other streams busy an event pair would
     # also time the wait for free CUs); `bench.py --serial` under rocprofv3 gives the matching per-kernel averages
     engine.SERIAL = True
-    prof.enable(only=dom[0] if dom else None)
+    prof.enable(only=dom[1] if dom else None)
     for _ in range(args.steps):
         step()
     barrier()
@@ -151,9 +151,9 @@ def main():
         out['roofline'] = prof.roofline(args.precision, MFMA_PEAK_TFLOPS[args.precision])
         try:      # HBM bytes per launch from the committed PMC passes (profiles/r01_traffic.json), when this kernel was measured
             tr = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_traffic.json')))['kernels']
-            ent = tr.get(out['roofline']['kernel'])
-            if ent:
-                out['roofline']['traffic'] = ent['traffic_bytes']
+            ents = [(tr.get(sh['shape']), sh['launches']) for sh in out['roofline']['shapes']]
+            if ents and all(e for e, _ in ents):      # launch-weighted mean over the layer shapes this instantiation serves
+                out['roofline']['traffic'] = int(sum(e['traffic_bytes'] * n for e, n in ents) / sum(n for _, n in ents))
                 out['roofline']['traffic_source'] = 'profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)'
         except (OSError, ValueError, KeyError):
             pass

@@ -237,6 +237,7 @@ static int launch_halo(const HaloK& k, int tiles, int maxpatch, hipStream_t s) {
     }
     dim3 grid(tiles, hv_cdiv(k.Cout, BN));
     hv_path_note = 2;
+    HV_KNAME("conv_halo_kernel<%d, %d, %d, %d, %d, %d, %d, %d>", TH, TW, BN, WM, WN, TG, CK, PMAX);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, k);
     HV_LAUNCH_CHECK();
     return HV_OK;

@@ -251,6 +251,7 @@ static int launch2(HaloK& k, hipStream_t s, int th0 = 8, int tw0 = TW) {
     }
     dim3 grid(tiles, hv_cdiv(k.Cout, BN));
     hv_path_note = 3;
+    HV_KNAME("conv_halo2_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %d>", TH, TW, BN, WM, WN, CK, BSTEP, SPAN, D);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, k);
     HV_LAUNCH_CHECK();
     return HV_OK;

@@ -20,6 +20,8 @@
 #define HV_BK 32
 
 thread_local int hv_path_note = 0;
+thread_local char hv_kname[192] = "";
+extern "C" const char* hv_last_kernel_name(void) { return hv_kname; }
 extern "C" int hv_last_kernel_path(void) { return hv_path_note; }
 thread_local hipEvent_t hv_ev_start = nullptr, hv_ev_stop = nullptr;
 extern "C" int hv_set_kernel_timing(void* ev_start, void* ev_stop) {
@@ -284,6 +286,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
 template <typename T, int BM, int BN, int WM, int WN, bool ASC>
 static int launch_conv(const ConvK& k, int mtiles, hipStream_t s) {
     dim3 grid(mtiles, hv_cdiv(k.Cout, BN));
+    HV_KNAME("conv_igemm_kernel<%s, %d, %d, %d, %d, %s>", sizeof(T) == 2 ? "_Float16" : "float", BM, BN, WM, WN, ASC ? "true" : "false");
     hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN, ASC>), grid, dim3(256), 0, s, k);
     HV_LAUNCH_CHECK();
     return HV_OK;
@@ -790,6 +793,10 @@ static int launch_wgrad(const WgradK& k, const WgradPlan& pl, hipStream_t s) {
     constexpr int KT = F16 ? 64 : 32, KT64 = F16 ? 128 : 32;
     dim3 grid(pl.splits, hv_cdiv(k.Cout, pl.BN), hv_cdiv(k.J, pl.BC));
     if (pl.KT != ((pl.BN == 64 && pl.BC == 64) ? KT64 : KT)) return HV_ERR_ARG;
+    {
+        const int bn = pl.BN, bc = pl.BN == 16 || pl.BN == 32 ? 128 : pl.BC, wn = (pl.BN <= 32 || (pl.BN == 64 && pl.BC == 256)) ? 1 : 2;
+        HV_KNAME("wgrad_kernel<%s, %d, %d, %d, %d, %d, %s>", F16 ? "_Float16" : "float", bn, bc, wn, 4 / wn, pl.KT, FAST ? "true" : "false");
+    }
     if (pl.BN == 16) hipLaunchKernelGGL((wgrad_kernel<T, 16, 128, 1, 4, KT, FAST>), grid, dim3(256), 0, s, k);
     else if (pl.BN == 32) hipLaunchKernelGGL((wgrad_kernel<T, 32, 128, 1, 4, KT, FAST>), grid, dim3(256), 0, s, k);
     else if (pl.BN == 64 && pl.BC == 256) hipLaunchKernelGGL((wgrad_kernel<T, 64, 256, 1, 4, KT, FAST>), grid, dim3(256), 0, s, k);

@@ -136,6 +136,7 @@ int hv_conv2d_narrow(const hv_conv_desc* d, hipStream_t s) {
         if ((long long)d->B * d->Ho > 65535) return HV_ERR_UNSUPPORTED;
         const dim3 grid(hv_cdiv(d->Wo, 256 / lpp), d->B * d->Ho);
         hv_path_note = 1;
+        HV_KNAME("narrow_fwd_kernel<%d>", lpp);
         if (lpp == 64) hipLaunchKernelGGL((narrow_fwd_kernel<64>), grid, dim3(256), 0, s, k);
         else if (lpp == 16) hipLaunchKernelGGL((narrow_fwd_kernel<16>), grid, dim3(256), 0, s, k);
         else if (lpp == 4) hipLaunchKernelGGL((narrow_fwd_kernel<4>), grid, dim3(256), 0, s, k);
@@ -164,6 +165,7 @@ int hv_conv2d_thin_in(const hv_conv_desc* d, hipStream_t s) {
     const int ppb = 256 / (d->Cout / 4);
     const dim3 grid(hv_cdiv(d->Wo, ppb * PXB), d->B * d->Ho);
     hv_path_note = 4;
+    HV_KNAME("thin1_fwd_kernel<4, %d>", PXB);
     hipLaunchKernelGGL((thin1_fwd_kernel<4, PXB>), grid, dim3(256), 0, s, k);
     HV_LAUNCH_CHECK();
     return HV_OK;

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include "../../include/hvgan.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -15,6 +16,9 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
     } while (0)
 
 extern thread_local int hv_path_note;   // set by the launcher that actually launched (hv_last_kernel_path)
+// name of the kernel instantiation the last launcher launched, as rocprofv3 lists it (hv_last_kernel_name)
+extern thread_local char hv_kname[192];
+#define HV_KNAME(...) snprintf(hv_kname, sizeof(hv_kname), __VA_ARGS__)
 // hv_set_kernel_timing: events recorded right around the MAIN kernel of the next weight-gradient call (not its slab reduction)
 extern thread_local hipEvent_t hv_ev_start, hv_ev_stop;
 #define HV_TIMING_BEGIN(s) do { if (hv_ev_start) (void)hipEventRecord(hv_ev_start, (s)); } while (0)

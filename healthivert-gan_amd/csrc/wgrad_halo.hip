@@ -314,6 +314,7 @@ static int launch_wh(const WHaloK& k, const WHaloPlan& pl, const hv_wgrad_desc* 
     }
     dim3 grid(pl.gx, hv_cdiv(d->Cout, BN), hv_cdiv(d->Cin, BC));
     hv_path_note = 11;
+    HV_KNAME("wgrad_halo_kernel<%d, %d, %d, %s>", KS, BN, BC, TS ? "true" : "false");
     HV_TIMING_BEGIN(s);
     hipLaunchKernelGGL(kern, grid, dim3(256), pl.lds, s, k);
     HV_TIMING_END(s);

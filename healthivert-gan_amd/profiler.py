@@ -1,8 +1,8 @@
 """Live per-kernel timing of the MFMA kernels with HIP events on the launch stream (bench.py's `roofline`).
 
 Two phases so that the timed region is not perturbed: `survey()` times every convolution launch of one
-untimed step and picks the dominant kernel class (largest total time); `enable()` then brackets only launches
-of that class with events during the timed steps.  FLOPs are algorithmic: 2*pixels*Cout*taps*Cin (valid taps only
+untimed step and picks the dominant kernel instantiation (largest total time over all the layer shapes it serves -- the
+granularity of a rocprofv3 stats row); `enable(only=...)` then brackets only its launches with events.  FLOPs are algorithmic: 2*pixels*Cout*taps*Cin (valid taps only
 for the transposed/data-gradient form).
 """
 import ctypes
@@ -17,30 +17,33 @@ class KernelTimer:
     def __init__(self):
         self.records = []
         self.paths = {}
-        self.only = None
+        self.names = {}       # shape key -> kernel instantiation name as rocprofv3 prints it (hv_last_kernel_name)
+        self.only = None      # set of shape keys to time, or None = all
         self.active = False
 
     # ---- hook called by ops.conv2d / ops.conv2d_wgrad around each launch
     def wrap(self, key, flops, launch):
-        if not self.active or (self.only is not None and key != self.only):
+        if not self.active or (self.only is not None and key not in self.only):
             return launch()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        L = _lib.get().cdll
         if key[0] == 'wgrad':
             # two kernels per call (main kernel + slab reduction): the C side records the events around the main kernel only, so the
             # duration is that of the kernel rocprofv3 lists under the same name
             s.record(); e.record()          # create the underlying hipEvents
-            _lib.get().cdll.hv_set_kernel_timing(ctypes.c_void_p(s.cuda_event), ctypes.c_void_p(e.cuda_event))
+            L.hv_set_kernel_timing(ctypes.c_void_p(s.cuda_event), ctypes.c_void_p(e.cuda_event))
             r = launch()
         else:
             s.record()
             r = launch()
             e.record()
-        self.paths[key] = _lib.get().cdll.hv_last_kernel_path()   # which kernel family the C side dispatched to
+        self.paths[key] = L.hv_last_kernel_path()          # which kernel family the C side dispatched to
+        self.names[key] = (L.hv_last_kernel_name() or b'').decode()
         self.records.append((key, flops, s, e))
         return r
 
     def enable(self, only=None):
-        self.records, self.only, self.active = [], only, True
+        self.records, self.only, self.active = [], (set(only) if only else None), True
         ops.set_timer(self)
 
     def disable(self):
@@ -54,24 +57,36 @@ class KernelTimer:
             a = agg.setdefault(key, [0.0, 0, flops])
             a[0] += s.elapsed_time(e)
             a[1] += 1
-        return agg   # key -> [total ms, launches, flops per launch]
+        return agg   # shape key -> [total ms, launches, flops per launch]
+
+    def by_kernel(self):
+        """kernel instantiation name -> [total ms, launches, total flops, [shape keys]] (the granularity of a rocprofv3 stats row)."""
+        out = {}
+        for key, (ms, n, flops) in self.summary().items():
+            a = out.setdefault(self.names.get(key) or describe(key, self.paths.get(key)), [0.0, 0, 0.0, []])
+            a[0] += ms; a[1] += n; a[2] += flops * n; a[3].append(key)
+        return out
 
     def dominant(self):
-        agg = self.summary()
-        if not agg:
+        """(kernel name, [shape keys]) of the instantiation with the largest total time."""
+        bk = self.by_kernel()
+        if not bk:
             return None
-        return max(agg.items(), key=lambda kv: kv[1][0])
+        name, a = max(bk.items(), key=lambda kv: kv[1][0])
+        return name, a[3]
 
     def roofline(self, precision, peak_tflops, total_ms=None):
-        d = self.dominant()
-        if d is None:
+        bk = self.by_kernel()
+        if not bk:
             return None
-        key, (ms, n, flops) = d
-        avg_ms = ms / n
-        achieved = flops / (avg_ms * 1e-3) / 1e12
-        return {'bound': 'mfma', 'kernel': describe(key, self.paths.get(key)), 'achieved': round(achieved, 2), 'peak': peak_tflops, 'unit': 'TFLOP/s',
-                'frac': round(achieved / peak_tflops, 4), 'traffic': None, 'launches': n, 'avg_us': round(avg_ms * 1e3, 2),
-                'gflop_per_launch': round(flops / 1e9, 3)}
+        name, (ms, n, flops, keys) = max(bk.items(), key=lambda kv: kv[1][0])
+        agg = self.summary()
+        achieved = flops / (ms * 1e-3) / 1e12
+        shapes = [{'shape': describe(k, self.paths.get(k)), 'launches': agg[k][1], 'avg_us': round(agg[k][0] / agg[k][1] * 1e3, 2),
+                   'tflops': round(agg[k][2] / (agg[k][0] / agg[k][1] * 1e-3) / 1e12, 1)} for k in sorted(keys, key=lambda k: -agg[k][0])]
+        return {'bound': 'mfma', 'kernel': name, 'achieved': round(achieved, 2), 'peak': peak_tflops, 'unit': 'TFLOP/s',
+                'frac': round(achieved / peak_tflops, 4), 'traffic': None, 'launches': n, 'avg_us': round(ms / n * 1e3, 2),
+                'gflop_per_launch': round(flops / n / 1e9, 3), 'shapes': shapes}
 
 
 KERNEL_NAMES = {0: 'conv_igemm_kernel', 1: 'narrow_fwd_kernel', 2: 'conv_halo_kernel', 3: 'conv_halo2_kernel', 4: 'thin1_fwd_kernel', 10: 'wgrad_kernel',
