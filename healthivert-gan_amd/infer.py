@@ -56,14 +56,27 @@ def synthesize(model, ct_masked, mask, cam, index_ratio, ori_ct, label, x1, x2, 
 
 
 # ------------------------------------------------------------------------------------------------ stage-batched volume driver
+_POOL = None
+
+
+def _pool():
+    global _POOL
+    if _POOL is None:
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL = ThreadPoolExecutor(max_workers=max(1, min(8, (os.cpu_count() or 2) // 2)))
+    return _POOL
+
+
 def _clean_components(mask, min_size):
     """remove_small_connected_components of the reference (eval_3d_sagittal_twostage.py:15-30): 8-connectivity."""
     import numpy as np
     from scipy.ndimage import label as cc_label
     lab, n = cc_label(mask, np.ones((3, 3), dtype=np.int32))
-    for i in range(1, n + 1):
-        if np.sum(lab == i) < min_size:
-            mask[lab == i] = 0
+    if n:
+        small = np.bincount(lab.ravel(), minlength=n + 1) < min_size     # component sizes in one pass
+        small[0] = False
+        mask[small[lab]] = 0
     return mask
 
 
@@ -107,10 +120,16 @@ def prepare_slice(cam2d, label2d, ct2d, vert_id, maxheight=40):
 
 
 def _stage(model, cam_vol, labels, cts, zs, ratios, vert_id, device, maxheight):
-    """One synthesis stage for all z-slices at once: labels/cts are lists of 2-D arrays (per z).  Returns new lists
+    """One synthesis stage for all z-slices at once: labels/cts are lists of 2-D arrays (per z), cam_vol is [Z, H, W].  Returns new lists
     (slices where the vertebra is absent pass through unchanged, like the reference's `output == None`)."""
     import numpy as np
-    preps = [prepare_slice(cam_vol[:, :, z], labels[i], cts[i], vert_id, maxheight) for i, z in enumerate(zs)]
+    # host-side slice preparation (connected components, bounding box, band re-stacking) is independent per slice: a small thread
+    # pool keeps it off the critical path of the three batched generator launches (numpy / scipy release the GIL in their loops)
+    prep1 = lambda iz: prepare_slice(cam_vol[iz[1]], labels[iz[0]], cts[iz[0]], vert_id, maxheight)       # cam_vol is z-major
+    if len(zs) >= 8:
+        preps = list(_pool().map(prep1, list(enumerate(zs))))
+    else:
+        preps = [prep1(iz) for iz in enumerate(zs)]
     idx = [i for i, p in enumerate(preps) if p is not None]
     out_l, out_c = list(labels), list(cts)
     if not idx:
@@ -133,9 +152,12 @@ def process_volume(model, ct_data, label_data, cam_data, vert_id, device, maxhei
     ct_data in 0..255, label_data = vertebra ids, cam_data already scaled by 255 (reference :181).  Returns
     (output_ct [H,W,Z], output_seg [H,W,Z]) as float64 numpy arrays (zeros outside the processed z range)."""
     import numpy as np
-    vl = label_data == vert_id
-    loc = np.where(vl)
-    z0, z1 = int(loc[2].min()), int(loc[2].max())
+    # z-major contiguous copies: every per-slice access below is then a contiguous 2-D array (the [H, W, Z] inputs have z fastest)
+    lab_z = np.ascontiguousarray(np.moveaxis(label_data, 2, 0))
+    ct_z = np.ascontiguousarray(np.moveaxis(ct_data, 2, 0))
+    cam_z = np.ascontiguousarray(np.moveaxis(cam_data, 2, 0))
+    zhas = np.flatnonzero((lab_z == vert_id).reshape(lab_z.shape[0], -1).any(axis=1))
+    z0, z1 = int(zhas.min()), int(zhas.max())
     rng_len = z1 - z0 + 1
     new_len = int(rng_len * 4 / 5)
     nz0 = z0 + (rng_len - new_len) // 2
@@ -143,17 +165,18 @@ def process_volume(model, ct_data, label_data, cam_data, vert_id, device, maxhei
     centre = (nz0 + nz1) // 2
     zs = list(range(nz0, nz1 + 1))
     ratios = [abs(z - centre) / rng_len * 2 for z in zs]
-    labels = [label_data[:, :, z].copy() for z in zs]
-    cts = [ct_data[:, :, z].copy() for z in zs]
-    out_ct, out_seg = np.zeros_like(ct_data, dtype=np.float64), np.zeros_like(ct_data, dtype=np.float64)
+    labels = [lab_z[z].copy() for z in zs]
+    cts = [ct_z[z].copy() for z in zs]
+    out_ct, out_seg = np.zeros(ct_z.shape, dtype=np.float64), np.zeros(ct_z.shape, dtype=np.float64)      # z-major, returned as [H, W, Z] views
     for nb, cond in ((vert_id - 1, vert_id > 8), (vert_id + 1, vert_id < 24)):
-        sel = [i for i, z in enumerate(zs) if cond and np.sum(label_data[:, :, z] == nb) > 200]
+        cnt = (lab_z[nz0:nz1 + 1] == nb).reshape(len(zs), -1).sum(axis=1) if cond else None
+        sel = [i for i in range(len(zs)) if cond and cnt[i] > 200]
         if sel:
-            l2, c2, _ = _stage(model, cam_data, [labels[i] for i in sel], [cts[i] for i in sel], [zs[i] for i in sel],
+            l2, c2, _ = _stage(model, cam_z, [labels[i] for i in sel], [cts[i] for i in sel], [zs[i] for i in sel],
                                [ratios[i] for i in sel], nb, device, maxheight)
             for j, i in enumerate(sel):
                 labels[i], cts[i] = l2[j], c2[j]
-    l3, c3, done = _stage(model, cam_data, labels, cts, zs, ratios, vert_id, device, maxheight)
+    l3, c3, done = _stage(model, cam_z, labels, cts, zs, ratios, vert_id, device, maxheight)
     for i in done:
-        out_seg[:, :, zs[i]], out_ct[:, :, zs[i]] = l3[i], c3[i]
-    return out_ct, out_seg
+        out_seg[zs[i]], out_ct[zs[i]] = l3[i], c3[i]
+    return np.moveaxis(out_ct, 0, 2), np.moveaxis(out_seg, 0, 2)
