@@ -325,6 +325,10 @@ int hv_conv2d_halo(const hv_conv_desc* d, const void* w_f16, hipStream_t s) {
         for (int c = 0; c < k.ncls; ++c) wgs += (long long)hv_cdiv(k.cls[c].Hc, 8) * hv_cdiv(k.cls[c].Wc, 32) * d->B * hv_cdiv(d->Cout, bn);
         if (wgs < 400) small_tile = true;
     }
+    // 3x3 layers with whole 32-channel chunks: the 8x16-pixel conv_halo2 instantiations (twice the workgroups, half the accumulators)
+    // measured faster than 8x32 on the 128x128 and 256x256 maps as well (53 vs 65, 22 vs 29, 36 vs 51 us); HV_HALO_TW16=0 restores 8x32
+    static const int tw16 = getenv("HV_HALO_TW16") ? atoi(getenv("HV_HALO_TW16")) : 1;
+    if (tw16 && k.bstep == 1 && d->KH == 3 && d->KW == 3 && (d->Cin & 31) == 0) small_tile = true;
     const int TH = 8, TW = small_tile ? 16 : 32;
     int maxpatch = 0;
     for (int c = 0; c < k.ncls; ++c) {
