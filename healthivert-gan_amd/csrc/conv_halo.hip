@@ -328,7 +328,8 @@ int hv_conv2d_halo(const hv_conv_desc* d, const void* w_f16, hipStream_t s) {
     // 3x3 layers with whole 32-channel chunks: the 8x16-pixel conv_halo2 instantiations (twice the workgroups, half the accumulators)
     // measured faster than 8x32 on the 128x128 and 256x256 maps as well (53 vs 65, 22 vs 29, 36 vs 51 us); HV_HALO_TW16=0 restores 8x32
     static const int tw16 = getenv("HV_HALO_TW16") ? atoi(getenv("HV_HALO_TW16")) : 1;
-    if (tw16 && k.bstep == 1 && d->KH == 3 && d->KW == 3 && (d->Cin & 31) == 0) small_tile = true;
+    static const int tw16r = getenv("HV_HALO_TW16R") ? atoi(getenv("HV_HALO_TW16R")) : 1;   // also for 16-channel chunks (measured: 49 vs 54, 31 vs 42, 65 vs 81, 115 vs 105 us)
+    if (tw16 && k.bstep == 1 && d->KH == 3 && d->KW == 3 && ((d->Cin & 31) == 0 || (tw16r && d->Cout <= 64))) small_tile = true;
     const int TH = 8, TW = small_tile ? 16 : 32;
     int maxpatch = 0;
     for (int c = 0; c < k.ncls; ++c) {

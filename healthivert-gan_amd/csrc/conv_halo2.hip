@@ -286,7 +286,6 @@ int hv_halo2_launch(HaloK& k, int TW, int KH, int KW, int maxpatch, hipStream_t 
     if (ntaps == 9 && KH == 3 && KW == 3 && k.bstep == 1) {
         const bool ck32 = k.Cin % 32 == 0;
         const int cls = k.Cout <= 16 ? 1 : k.Cout <= 32 ? 2 : k.Cout <= 64 ? 4 : 8;
-        if (!whole16 && TW != 32) return HV_ERR_UNSUPPORTED;   // ragged channel counts: 16-channel chunks, 8x32 tiles only
         if (!(mask & cls)) return HV_ERR_UNSUPPORTED;
         if (TW == 32) {
             if (cls == 1) return ck32 ? launch2<8, 32, 16, 4, 1, 32, 1, 3, 3>(k, s) : launch2<8, 32, 16, 4, 1, 16, 1, 3, 3>(k, s);
@@ -296,7 +295,12 @@ int hv_halo2_launch(HaloK& k, int TW, int KH, int KW, int maxpatch, hipStream_t 
             // 68-channel layer of this model (measured 2.5x slower than conv_halo_kernel): not taken
             return HV_ERR_UNSUPPORTED;
         }
-        if (!ck32) return HV_ERR_UNSUPPORTED;
+        if (!ck32) {   // 16-channel chunks (whole or ragged) on 8x16 tiles
+            if (cls == 1) return launch2<8, 16, 16, 4, 1, 16, 1, 3, 3>(k, s);
+            if (cls == 2) return launch2<8, 16, 32, 2, 2, 16, 1, 3, 3>(k, s);
+            if (cls == 4) return launch2<8, 16, 64, 1, 4, 16, 1, 3, 3>(k, s);
+            return HV_ERR_UNSUPPORTED;
+        }
         if (cls == 1) return launch2<8, 16, 16, 4, 1, 32, 1, 3, 3>(k, s);
         if (cls == 2) return launch2<8, 16, 32, 2, 2, 32, 1, 3, 3>(k, s);
         if (cls == 4) return launch2<8, 16, 64, 1, 4, 32, 1, 3, 3>(k, s);

@@ -137,6 +137,8 @@ HALO_CASES = [
     (16, 128, 128, 36, 32, 3, 1, 1, 'elu', 0),
     (16, 128, 128, 68, 64, 3, 1, 1, 'elu', 0),
     (16, 128, 128, 12, 16, 3, 1, 1, 'none', 0),
+    (4, 64, 64, 16, 32, 3, 1, 1, 'elu', 0),
+    (4, 64, 64, 20, 64, 3, 1, 1, 'elu', 0),
     (16, 128, 128, 64, 128, 4, 2, 1, 'lrelu', 0),
 ]
 
