@@ -330,6 +330,9 @@ int hv_conv2d_halo(const hv_conv_desc* d, const void* w_f16, hipStream_t s) {
     static const int tw16 = getenv("HV_HALO_TW16") ? atoi(getenv("HV_HALO_TW16")) : 1;
     static const int tw16r = getenv("HV_HALO_TW16R") ? atoi(getenv("HV_HALO_TW16R")) : 1;   // also for 16-channel chunks (measured: 49 vs 54, 31 vs 42, 65 vs 81, 115 vs 105 us)
     if (tw16 && k.bstep == 1 && d->KH == 3 && d->KW == 3 && ((d->Cin & 31) == 0 || (tw16r && d->Cout <= 64))) small_tile = true;
+    static const int tw16x = getenv("HV_HALO_TW16X") ? atoi(getenv("HV_HALO_TW16X")) : 1;   // bit 1 = stride-2 data gradient classes (54 vs 61 us), bit 2 = 5x5 (no gain)
+    if ((tw16x & 1) && d->transposed && d->stride == 2 && d->KH == 4) small_tile = true;
+    if ((tw16x & 2) && d->KH == 5 && k.bstep == 1) small_tile = true;
     const int TH = 8, TW = small_tile ? 16 : 32;
     int maxpatch = 0;
     for (int c = 0; c < k.ncls; ++c) {

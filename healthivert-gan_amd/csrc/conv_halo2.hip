@@ -267,6 +267,7 @@ int hv_halo2_launch(HaloK& k, int TW, int KH, int KW, int maxpatch, hipStream_t 
     // PatchGAN layers: 4x4 filters, Cout >= 128
     // 5x5 stems of the generators (4 input channels) and their data gradient (4 output channels): Cout <= 16, 256x256 maps
     if (ntaps == 25 && KH == 5 && KW == 5 && k.bstep == 1 && TW == 32 && k.Cout <= 16) return launch2<8, 32, 16, 4, 1, 16, 1, 5, 5>(k, s);
+    if (ntaps == 25 && KH == 5 && KW == 5 && k.bstep == 1 && TW == 16 && k.Cout <= 16) return launch2<8, 16, 16, 4, 1, 16, 1, 5, 5>(k, s);
     if (ntaps == 16 && KH == 4 && KW == 4 && TW == 16 && k.Cout > 64 && k.bstep == 1 && k.Cin % 32 == 0) return launch2<8, 16, 128, 1, 4, 32, 1, 4, 4>(k, s);
     // PatchGAN logits layer (512 -> 1): the single output channel rides in a 16-channel MFMA tile, the input is staged once
     if (ntaps == 16 && KH == 4 && KW == 4 && TW == 16 && k.Cout <= 16 && k.bstep == 1 && k.Cin % 32 == 0) {
