@@ -1,6 +1,8 @@
 // Weight preparation (spectral norm + layout), its backward, activation/bias gradient, Adam, fills.
 // All HBM-bound or latency-bound; the spectral-norm kernels are batched over layers (one workgroup per
 // layer) so a whole generator needs one launch instead of 47.
+#include <stdlib.h>
+
 #include "hv_common.h"
 
 #define SN_EPS 1e-12f
@@ -250,8 +252,9 @@ static int act_bwd_blocks(long long npix, int C, int* rows_per_block) {
     const int rstep = act_vec_ok(C) ? 256 / (C / 4) : 256 / C;
     long long rpb = (long long)rstep * 16;
     long long nb = (npix + rpb - 1) / rpb;
-    if (nb > 2048) {   // ~8 workgroups per CU keep enough loads in flight to stream from HBM
-        rpb = (npix + 2047) / 2048;
+    static const int ab = getenv("HV_ACT_BLOCKS") ? atoi(getenv("HV_ACT_BLOCKS")) : 2048;   // tuning knob
+    if (nb > ab) {   // ~8 workgroups per CU keep enough loads in flight to stream from HBM
+        rpb = (npix + ab - 1) / ab;
         rpb = (rpb + rstep - 1) / rstep * rstep;
         nb = (npix + rpb - 1) / rpb;
     }
