@@ -747,7 +747,8 @@ static int wgrad_plan(const hv_wgrad_desc* d, WgradPlan* pl) {
     const long long tiles = (long long)hv_cdiv(d->Cout, BN) * hv_cdiv(J, BC);
     // ~2 workgroups per CU; layers whose dW already has many tiles get few splits (slab traffic grows with splits)
     static const int want_wg = getenv("HV_WGRAD_WANT") ? atoi(getenv("HV_WGRAD_WANT")) : 512;   // tuning knob (step time 15.13 ms at 512 vs 15.33 at 384, 15.46 at 640, 15.56 at 768+)
-    long long want = tiles >= 128 ? (512 + tiles - 1) / tiles : (want_wg + tiles - 1) / tiles;
+    static const int want_big = getenv("HV_WGRAD_WANT_BIG") ? atoi(getenv("HV_WGRAD_WANT_BIG")) : 512;   // tuning knob (layers with >= 128 tiles)
+    long long want = tiles >= 128 ? (want_big + tiles - 1) / tiles : (want_wg + tiles - 1) / tiles;
     if (want > 256) want = 256;
     long long maxs = (M + 255) / 256;                     // at least 256 pixels per split
     long long splits = want < 1 ? 1 : want;
