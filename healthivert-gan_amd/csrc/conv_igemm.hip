@@ -305,7 +305,8 @@ static int dispatch_conv(ConvK& k, hipStream_t s) {
     else { BN = 128; BM = 128; }
     if (BN >= 64) {
         long long tiles = ((M + BM - 1) / BM) * ((k.Cout + BN - 1) / BN);
-        if (tiles < 160) { BM = 64; BN = 64; }
+        static const int small_thr = getenv("HV_IGEMM_SMALL") ? atoi(getenv("HV_IGEMM_SMALL")) : 600;   // tuning knob (step-level A/B: 15.05 ms at 600 vs 15.16 at 160)
+        if (tiles < small_thr) { BM = 64; BN = 64; }
     } else if (BN == 16 && (M + 255) / 256 < 256) {
         BM = 64;   // narrow outputs on small feature maps (PatchGAN logits): more, smaller workgroups
     }
