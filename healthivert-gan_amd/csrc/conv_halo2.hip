@@ -268,7 +268,11 @@ int hv_halo2_launch(HaloK& k, int TW, int KH, int KW, int maxpatch, hipStream_t 
     // 5x5 stems of the generators (4 input channels) and their data gradient (4 output channels): Cout <= 16, 256x256 maps
     if (ntaps == 25 && KH == 5 && KW == 5 && k.bstep == 1 && TW == 32 && k.Cout <= 16) return launch2<8, 32, 16, 4, 1, 16, 1, 5, 5>(k, s);
     if (ntaps == 25 && KH == 5 && KW == 5 && k.bstep == 1 && TW == 16 && k.Cout <= 16) return launch2<8, 16, 16, 4, 1, 16, 1, 5, 5>(k, s);
-    if (ntaps == 16 && KH == 4 && KW == 4 && TW == 16 && k.Cout > 64 && k.bstep == 1 && k.Cin % 32 == 0) return launch2<8, 16, 128, 1, 4, 32, 1, 4, 4>(k, s);
+    if (ntaps == 16 && KH == 4 && KW == 4 && TW == 16 && k.Cout > 64 && k.bstep == 1 && k.Cin % 32 == 0) {
+        // 64-channel blocks when 128-channel blocks would leave a CU with a single workgroup (512 -> 256 data gradient: 102 vs 112 us)
+        const long long wgs128 = (long long)k.B * hv_cdiv(k.cls[0].Hc, 8) * hv_cdiv(k.cls[0].Wc, 16) * hv_cdiv(k.Cout, 128);
+        return wgs128 < 512 ? launch2<8, 16, 64, 1, 4, 32, 1, 4, 4>(k, s) : launch2<8, 16, 128, 1, 4, 32, 1, 4, 4>(k, s);
+    }
     // PatchGAN logits layer (512 -> 1): the single output channel rides in a 16-channel MFMA tile, the input is staged once
     if (ntaps == 16 && KH == 4 && KW == 4 && TW == 16 && k.Cout <= 16 && k.bstep == 1 && k.Cin % 32 == 0) {
         // small maps: 4-row tiles double the workgroup count (31 x 31 logits: 128 -> 256 workgroups)
