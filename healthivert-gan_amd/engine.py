@@ -247,8 +247,8 @@ def conv_backward(node, book, prec, dbias_accumulate=False, wgrad_accumulate=Fal
                        precision=prec, mul=(Act(node.x.t, p.cin_fwd, node.x.coff), mul_x) if mul_x else None)
 
 
-BRANCHES = os.environ.get('HV_G_BRANCHES', '0') != '0'   # independent generator branches on two HIP streams / graph branches
-#   (measured under graph replay: 16.3 / 16.5 ms on vs 16.5 ms off -- within noise, so off by default)
+BRANCHES = os.environ.get('HV_G_BRANCHES', '1') != '0'   # independent generator branches on two HIP streams / graph branches
+#   (step-level A/B under graph replay, three pairs in one call: 14.80 / 14.81 / 14.85 ms on vs 15.01 / 14.96 / 15.05 ms off)
 _branch_streams = {}
 
 
