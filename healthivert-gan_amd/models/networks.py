@@ -174,6 +174,14 @@ class _DiscPlan:
         self.dx = torch.zeros(B, 1, H, W, dtype=torch.float32, device=device)
 
 
+def _stat_momentum(m, order):
+    if order == 'swapped_first':
+        return m / (1.0 - m * (1.0 - m))
+    if order == 'swapped_second':
+        return m * (1.0 - m)
+    return m
+
+
 class NLayerDiscriminator(nn.Module):
     """PatchGAN: Conv(k4,s2)+LReLU, (n_layers-1)x[Conv(k4,s2)+Norm+LReLU], Conv(k4,s1)+Norm+LReLU, Conv(k4,s1)->1."""
 
@@ -238,11 +246,15 @@ class NLayerDiscriminator(nn.Module):
         return self._plans[key]
 
     # ---------------------------------------------------------------- explicit forward / backward
-    def run_forward(self, x, training=None, prep=True, groups=1):
+    def run_forward(self, x, training=None, prep=True, groups=1, stat_order=None):
         """x: (B,1,H,W) device tensor -> plan; logits in plan.logits (B,1,Ho,Wo).  BatchNorm running statistics are
         updated when training (every call, like the reference's three calls per step).  groups=2 treats the two halves of
         the batch as two consecutive calls (separate batch statistics, running stats updated half by half): the fake and
-        the real pass of one discriminator update in a single launch sequence."""
+        the real pass of one discriminator update in a single launch sequence.
+        stat_order: the train step runs the REAL pass before the FAKE pass (so that it overlaps the generator forward) while the
+        reference updates the running statistics fake-then-real; 'swapped_first' / 'swapped_second' use momenta m/(1-m(1-m)) and
+        m(1-m), which leave exactly the reference's running statistics after the pair:
+        (1-m)^2 r + m(1-m) fake + m real."""
         _lib.require_gpu(x)
         training = self.training if training is None else training
         prec = ops.precision_id(self.precision)
@@ -266,7 +278,8 @@ class NLayerDiscriminator(nn.Module):
             nm = self.model[L['norm']]
             if self.norm_kind == 'batch':
                 ops.norm_act_forward(ent['z'], ent['y'], 'batch', training, ent['stats'], nm.weight, nm.bias, nm.running_mean,
-                                     nm.running_var, nm.num_batches_tracked, act='lrelu', eps=nm.eps, momentum=nm.momentum, groups=groups)
+                                     nm.running_var, nm.num_batches_tracked, act='lrelu', eps=nm.eps, momentum=_stat_momentum(nm.momentum, stat_order),
+                                     groups=groups)
             else:
                 ops.norm_act_forward(ent['z'], ent['y'], 'instance', training, ent['stats'], act='lrelu', eps=nm.eps)
         P.training, P.groups = training, groups

@@ -89,6 +89,7 @@ class Pix2PixModel(BaseModel):
         import os as _os
         self.concurrent_d = _os.environ.get('HV_CONCURRENT_D', '1') != '0'
         self.batch_d = _os.environ.get('HV_BATCH_D', '0') != '0'   # measured: no gain once the three D streams overlap
+        self.real_first = _os.environ.get('HV_REAL_FIRST', '1') != '0'   # D real passes overlap the generator forward
 
     # ---------------------------------------------------------------- inputs
     def set_input(self, input):
@@ -193,6 +194,42 @@ class Pix2PixModel(BaseModel):
         setattr(self, 'loss_D_fake_%d' % k, lf)
         setattr(self, 'loss_D_real_%d' % k, lr)
 
+    def _d_real_first(self, k, real):
+        """Real-image half of loss_D_k (reference :285-296), run FIRST: it needs nothing from the generator, so its stream overlaps
+        the generator forward.  Gradients are assigned; BatchNorm running statistics use the swapped-order momentum."""
+        net = getattr(self, 'netD_%d' % k)
+        lr = self._loss_slot(2 * k + 1)
+        P = net.run_forward(real, training=True, prep=True, stat_order='swapped_first')
+        dz = self._buf('dz%d' % k, P.logits)
+        ops.gan_loss(P.logits, True, self.opt.gan_mode, loss=lr, dz=dz, grad_weight=0.5)
+        net.run_backward(P, dz, need_dx=False, param_grads=True, accumulate=False)
+        setattr(self, 'loss_D_real_%d' % k, lr)
+
+    def _d_fake_second(self, k, fake):
+        """Fake half of loss_D_k, accumulated onto the real half's gradients (a + b == b + a in IEEE arithmetic: same bits as the
+        reference's fake-then-real order)."""
+        net = getattr(self, 'netD_%d' % k)
+        lf = self._loss_slot(2 * k)
+        P = net.run_forward(fake, training=True, prep=False, stat_order='swapped_second')
+        dz = self._buf('dz%d' % k, P.logits)
+        ops.gan_loss(P.logits, False, self.opt.gan_mode, loss=lf, dz=dz, grad_weight=0.5)
+        net.run_backward(P, dz, need_dx=False, param_grads=True, accumulate=True)
+        net.finish()
+        setattr(self, 'loss_D_fake_%d' % k, lf)
+
+    def _real_local_early(self):
+        """real_B_local = mask * real_B * centre band (reference :254-258,:263) without waiting for the generator."""
+        B, _, H, W = self.real_B.shape
+        mc = self._bufs.get(('mc', (B, 1, H, W)))
+        if mc is None:
+            mc = torch.zeros(B, 1, H, W, dtype=torch.float32, device=self.device)
+            mc[:, :, :, W // 2 - self.half_band:W // 2 + self.half_band] = 1
+            self._bufs[('mc', (B, 1, H, W))] = mc
+        out = self._buf('real_B_local_early', self.real_B)
+        torch.mul(self.mask, self.real_B, out=out)
+        out.mul_(mc)
+        return out
+
     def backward_D_1(self):
         self._backward_D(1, self.fake_B, self.real_B)
 
@@ -261,20 +298,34 @@ class Pix2PixModel(BaseModel):
         """forward; D_1, D_2, D_3 forward/backward (reference :356-370 up to the optimiser steps).  The three discriminator
         updates are independent of each other, so each runs on its own HIP stream (kernels of different discriminators
         overlap on the 256 CUs)."""
-        self.forward()
         main = torch.cuda.current_stream(self.device)
         if getattr(self, '_d_streams', None) is None:
             self._d_streams = [torch.cuda.Stream(device=self.device) for _ in range(3)]
             engine.NO_FORK_STREAMS.update(st.cuda_stream for st in self._d_streams)
         self._dxs = {}
-        for k, bw in ((1, self.backward_D_1), (2, self.backward_D_2), (3, self.backward_D_3)):
+        split = self.real_first and not self.batch_d
+        def on(k):
             side = self._d_streams[k - 1] if (self.concurrent_d and not engine.SERIAL) else main
             if side is not main:
                 side.wait_stream(main)
-            with torch.cuda.stream(side):
-                self.set_requires_grad(getattr(self, 'netD_%d' % k), True)
-                getattr(self, 'optimizer_D_%d' % k).zero_grad()
-                bw()
+            return side
+        if split:      # the discriminators' real-image passes do not depend on the generator: they start now, on their streams
+            reals = {1: self.real_B, 2: self.real_B_mask, 3: self._real_local_early()}
+            for k in (1, 2, 3):
+                with torch.cuda.stream(on(k)):
+                    self.set_requires_grad(getattr(self, 'netD_%d' % k), True)
+                    getattr(self, 'optimizer_D_%d' % k).zero_grad()
+                    self._d_real_first(k, reals[k])
+        self.forward()
+        fakes = {1: self.fake_B, 2: self.fake_B_mask_raw, 3: self.fake_B_local}
+        for k, bw in ((1, self.backward_D_1), (2, self.backward_D_2), (3, self.backward_D_3)):
+            with torch.cuda.stream(on(k)):
+                if split:
+                    self._d_fake_second(k, fakes[k])
+                else:
+                    self.set_requires_grad(getattr(self, 'netD_%d' % k), True)
+                    getattr(self, 'optimizer_D_%d' % k).zero_grad()
+                    bw()
         self._join_d(main)
 
     def _phase_b(self):
