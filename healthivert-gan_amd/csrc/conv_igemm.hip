@@ -34,6 +34,7 @@ size_t hv_wgrad_halo_workspace_bytes(const hv_wgrad_desc* d);                  /
 int hv_wgrad_halo(const hv_wgrad_desc* d, int* nslabs, hipStream_t s);
 int hv_conv2d_narrow(const hv_conv_desc* d, hipStream_t s);                     // conv_narrow.hip
 int hv_conv2d_thin_in(const hv_conv_desc* d, hipStream_t s);
+int hv_conv2d_head(const hv_conv_desc* d, hipStream_t s);                       // conv_head.hip
 
 struct ConvCls {
     int ph, pw, Hc, Wc, ntaps, Ktot, m0, mcount;
@@ -350,6 +351,10 @@ extern "C" int hv_conv2d(const hv_conv_desc* d, void* stream) {
     // once instead of once per tap (many input channels, fp16 mode)
     static const int narrow_max_cin = getenv("HV_NARROW_MAX_CIN") ? atoi(getenv("HV_NARROW_MAX_CIN")) : 15;   // A/B knob
     const bool halo_ok = d->precision == HV_F16 && d->w_f16 && d->dil == 1 && (d->Cin & 15) == 0 && !d->w_bstride && !d->ch_scale;
+    if (d->Cout == 1 && d->workspace) {   // many input channels: taps as the GEMM's second dimension (conv_head.hip)
+        const int rc = hv_conv2d_head(d, (hipStream_t)stream);
+        if (rc != HV_ERR_UNSUPPORTED) return rc;
+    }
     if (d->Cout == 1 && !d->transposed && !d->mul_src && !(halo_ok && d->Cin > narrow_max_cin)) {
         const int rc = hv_conv2d_narrow(d, (hipStream_t)stream);
         if (rc != HV_ERR_UNSUPPORTED) return rc;

@@ -151,6 +151,11 @@ def conv2d(x, w, y, k, stride=1, pad=0, dil=1, bias=None, act='none', transposed
     if mul is not None:
         m, mact = mul
         d.mul_src, d.mul_ld, d.mul_coff, d.mul_act = ptr(m.t).value, m.ld, m.coff, ACT[mact]
+    if d.Cout == 1:      # single-channel heads / logits: the [pixel][tap] table of conv_head.hip lives in the per-stream scratch
+        need = L.size('hv_conv2d_workspace_bytes', ctypes.byref(d))
+        if need:
+            b, _ = _ws(need, x.t.device, slot=1)
+            d.workspace, d.workspace_bytes = ptr(b).value, b.numel()
     if _TIMER is not None:
         taps = kh * kw if not transposed else max(1, (kh * kw) // (stride * stride))
         flops = 2.0 * y.B * y.H * y.W * d.Cout * taps * d.Cin

@@ -89,7 +89,7 @@ class KernelTimer:
                 'gflop_per_launch': round(flops / n / 1e9, 3), 'shapes': shapes}
 
 
-KERNEL_NAMES = {0: 'conv_igemm_kernel', 1: 'narrow_fwd_kernel', 2: 'conv_halo_kernel', 3: 'conv_halo2_kernel', 4: 'thin1_fwd_kernel', 10: 'wgrad_kernel',
+KERNEL_NAMES = {0: 'conv_igemm_kernel', 1: 'narrow_fwd_kernel', 2: 'conv_halo_kernel', 3: 'conv_halo2_kernel', 4: 'thin1_fwd_kernel', 5: 'head_gemm_kernel', 10: 'wgrad_kernel',
                 11: 'wgrad_halo_kernel'}
 
 

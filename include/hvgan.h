@@ -38,7 +38,7 @@ enum { HV_NORM_NONE = 0, HV_NORM_BATCH = 1, HV_NORM_INSTANCE = 2 };
 int hv_version(void);
 const char* hv_arch(void); /* "gfx950" */
 /* which kernel family the calling thread's most recent hv_conv2d / hv_conv2d_wgrad launched (profiling labels):
- * 0 conv_igemm_kernel, 1 narrow_fwd_kernel, 2 conv_halo_kernel, 3 conv_halo2_kernel, 4 thin1_fwd_kernel, 10 wgrad_kernel,
+ * 0 conv_igemm_kernel, 1 narrow_fwd_kernel, 2 conv_halo_kernel, 3 conv_halo2_kernel, 4 thin1_fwd_kernel, 5 head_gemm_kernel, 10 wgrad_kernel,
  * 11 wgrad_halo_kernel */
 int hv_last_kernel_path(void);
 /* name of that kernel instantiation as rocprofv3 prints it, e.g. "conv_halo2_kernel<8, 16, 128, 1, 4, 32, 1, 4, 4>" (the gather and weight-
@@ -78,8 +78,13 @@ typedef struct {
                                          of activation mul_act at the same pixel/channel, applied after act and before accumulate == 1.
                                          Used by data gradients to hand the producer layer its pre-activation gradient directly
                                          (the separate in-place multiply pass over the gradient disappears).  NULL = none */
+    void* workspace; size_t workspace_bytes;
+                                      /* optional scratch (16-byte aligned) of hv_conv2d_workspace_bytes(d) bytes: enables the two-kernel path for
+                                         Cout == 1 with many input channels (PatchGAN logits, data gradient of the 1-channel stem), which
+                                         streams x once into a [pixel][tap] table and sums the taps afterwards.  NULL = other kernels */
 } hv_conv_desc;
 int hv_conv2d(const hv_conv_desc* d, void* stream);
+size_t hv_conv2d_workspace_bytes(const hv_conv_desc* d);   /* 0 when no kernel for this shape wants scratch */
 
 /* Weight gradient: dw[co][(r,s)][ci] = sum_{n,ho,wo} g[n,ho,wo,co] * x[n, ho*stride-pad+r*dil, ..., ci].
  * (autograd of the convs above; for a transposed conv swap the roles of x and g on the caller side).

@@ -176,6 +176,60 @@ def test_conv_halo_tiled_fp16_forward_and_dgrad(case):
     assert err <= 4e-3 * max(1.0, xin.grad.abs().max().item()), err
 
 
+HEAD_CASES = [   # B, H, W, Cin, k, stride, pad, transposed, act
+    (16, 31, 31, 512, 4, 1, 1, 0, 'none'),     # PatchGAN logits
+    (3, 17, 23, 96, 3, 1, 1, 0, 'sigmoid'),    # 9 taps, one 32-channel step per item, ragged pixel count
+    (2, 20, 20, 192, 4, 2, 1, 0, 'lrelu'),     # strided forward, two steps per item
+    (4, 64, 64, 64, 4, 2, 1, 1, 'none'),       # data gradient of the 1-channel stem (conv_transpose form)
+    (2, 15, 15, 128, 3, 1, 1, 1, 'none'),
+]
+
+
+@pytest.mark.parametrize('case', HEAD_CASES)
+def test_conv_single_output_channel_tap_gemm(case):
+    """Cout == 1 with many input channels (conv_head.hip: [pixel][tap] table + tap sum) against torch CPU fp32, incl. the epilogue
+    options (bias, activation, accumulate, act' multiplier) and the kernel actually taken."""
+    from hvtest import to_act, from_act, ohwi, ohwi_T, dev, maxerr
+    from hvgan import ops, lib
+    B, H, W, Cin, k, s, p, tr, act = case
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    if not tr:
+        w = torch.randn(1, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+        b = torch.randn(1, generator=g) * 0.1
+        ref = _ref_act(F.conv2d(x, w, b, stride=s, padding=p), act)
+        wf = ohwi(w)
+        ya = ops.Act.empty(B, ref.shape[2], ref.shape[3], 1, dev())
+        ops.conv2d(to_act(x), wf, ya, k, s, p, 1, bias=b.to(dev()), act=act, precision='fp16', w_h=wf.half())
+        assert lib.get().size('hv_last_kernel_path') == 5
+        torch.cuda.synchronize()
+        assert maxerr(from_act(ya), ref) <= 4e-3 * max(1.0, ref.abs().max().item())
+        # y += r (accumulate 1) on top of the first result, and y = act(r + y) (accumulate 2)
+        ops.conv2d(to_act(x), wf, ya, k, s, p, 1, bias=b.to(dev()), act=act, accumulate=1, precision='fp16', w_h=wf.half())
+        torch.cuda.synchronize()
+        assert maxerr(from_act(ya), 2 * ref) <= 8e-3 * max(1.0, ref.abs().max().item())
+        y0 = torch.randn(ref.shape, generator=g)
+        yb = to_act(y0)
+        ops.conv2d(to_act(x), wf, yb, k, s, p, 1, act=act, accumulate=2, precision='fp16', w_h=wf.half())
+        torch.cuda.synchronize()
+        ref2 = _ref_act(F.conv2d(x, w, None, stride=s, padding=p) + y0, act)
+        assert maxerr(from_act(yb), ref2) <= 4e-3 * max(1.0, ref2.abs().max().item())
+        return
+    # x is the gradient of a conv 1 -> Cin (stride s): the data gradient is conv_transpose2d(x, w) with w [Cin][1][k][k]
+    w = torch.randn(Cin, 1, k, k, generator=g) / (Cin * k * k) ** 0.5
+    ref = F.conv_transpose2d(x, w, stride=s, padding=p)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    wb = ohwi_T(w)                          # [1][taps][Cin]
+    assert tuple(wb.shape) == (1, k * k, Cin)
+    m = torch.randn(B, 1, Ho, Wo, generator=g)        # output of a LeakyReLU producer: factor 1 or 0.2
+    ya = ops.Act.empty(B, Ho, Wo, 1, dev())
+    ops.conv2d(to_act(x), wb, ya, k, s, p, 1, transposed=True, precision='fp16', w_h=wb.half(), mul=(to_act(m), 'lrelu'))
+    assert lib.get().size('hv_last_kernel_path') == 5
+    torch.cuda.synchronize()
+    ref = ref * torch.where(m > 0, torch.ones_like(m), torch.full_like(m, 0.2))
+    assert maxerr(from_act(ya), ref) <= 4e-3 * max(1.0, ref.abs().max().item())
+
+
 def test_conv_upsample_fused_and_transposed_conv_layer():
     """in_shift=1 == conv(F.interpolate(x, 2)); transposed=1 == F.conv_transpose2d (k4 s2 p1)."""
     from hvtest import to_act, from_act, ohwi, dev, maxerr
