@@ -64,6 +64,42 @@ __global__ __launch_bounds__(256) void narrow_fwd_kernel(const NarrowK p) {
     if (sub == 0 && ox < p.Wo) narrow_store(p, (long long)row * p.Wo + ox, acc);
 }
 
+// Few input channels (C4 float4 groups, the generator's 1-channel heads: 8 -> 1, 12 -> 1 at full resolution), 3x3 forward: one lane = one
+// output pixel, its 9 * C4 sixteen-byte loads are all issued before the first is used (clamped address + mask, no branches) -- the
+// loop form above serialises a load round trip per tap here.
+template <int C4>
+__global__ __launch_bounds__(256) void narrow3_fwd_kernel(const NarrowK p) {
+    const int row = blockIdx.y, b = row / p.Ho, oy = row - b * p.Ho;
+    const int ox = blockIdx.x * 256 + threadIdx.x;
+    if (ox >= p.Wo) return;
+    const float* ximg = p.x + (long long)b * p.img_stride + p.x_coff;
+    float4 xv[9][C4];
+    bool ok[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int hi = oy * p.stride - p.pad + r, wi = ox * p.stride - p.pad + s;
+            ok[r * 3 + s] = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            const int hc = min(max(hi, 0), p.H - 1), wc = min(max(wi, 0), p.W - 1);
+            const float* xp = ximg + (long long)((hc >> p.in_shift) * p.Wp + (wc >> p.in_shift)) * p.x_ld;
+#pragma unroll
+            for (int c = 0; c < C4; ++c) xv[r * 3 + s][c] = *reinterpret_cast<const float4*>(xp + c * 4);
+        }
+    float acc = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        float a = 0.f;
+#pragma unroll
+        for (int c = 0; c < C4; ++c) {
+            const float4 wv = *reinterpret_cast<const float4*>(p.w + t * p.Cin + c * 4), v = xv[t][c];
+            a += v.x * wv.x + v.y * wv.y + v.z * wv.z + v.w * wv.w;
+        }
+        acc += ok[t] ? a : 0.f;
+    }
+    narrow_store(p, (long long)row * p.Wo + ox, acc);
+}
+
 // Forward convolution of a 1-channel image into 4..64 channels with a KS x KS filter (the PatchGAN stem: 1 -> 64, 4x4, stride 2).
 // K = taps is 16, the layer is bound by writing its output (67 MB at B=16): fp32 VALU, exact in both precision modes.
 // One lane = one pixel x 4 output channels (16 lanes write a pixel's 256 B); the lane's filter taps live in registers (staged
@@ -136,6 +172,14 @@ int hv_conv2d_narrow(const hv_conv_desc* d, hipStream_t s) {
         if ((long long)d->B * d->Ho > 65535) return HV_ERR_UNSUPPORTED;
         const dim3 grid(hv_cdiv(d->Wo, 256 / lpp), d->B * d->Ho);
         hv_path_note = 1;
+        if (lpp == 1 && !d->transposed && d->KH == 3 && d->KW == 3 && (c4 == 2 || c4 == 3)) {
+            const dim3 g3(hv_cdiv(d->Wo, 256), d->B * d->Ho);
+            HV_KNAME("narrow3_fwd_kernel<%d>", c4);
+            if (c4 == 2) hipLaunchKernelGGL((narrow3_fwd_kernel<2>), g3, dim3(256), 0, s, k);
+            else hipLaunchKernelGGL((narrow3_fwd_kernel<3>), g3, dim3(256), 0, s, k);
+            HV_LAUNCH_CHECK();
+            return HV_OK;
+        }
         HV_KNAME("narrow_fwd_kernel<%d>", lpp);
         if (lpp == 64) hipLaunchKernelGGL((narrow_fwd_kernel<64>), grid, dim3(256), 0, s, k);
         else if (lpp == 16) hipLaunchKernelGGL((narrow_fwd_kernel<16>), grid, dim3(256), 0, s, k);

@@ -230,6 +230,35 @@ def test_conv_single_output_channel_tap_gemm(case):
     assert maxerr(from_act(ya), ref) <= 4e-3 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize('prec,tol', [('fp32', 1e-4), ('fp16', 4e-3)])
+@pytest.mark.parametrize('case', [(16, 31, 31, 512, 4, 1), (2, 9, 14, 96, 3, 1), (3, 20, 20, 320, 4, 2)])
+def test_conv_single_output_channel_data_gradient(case, prec, tol):
+    """Data gradient of a Cout == 1 conv: gradient stored channel-padded to 4, act' multiplier of the producer layer and
+    accumulate == 1 included."""
+    from hvtest import to_act, from_act, ohwi_T, dev, maxerr
+    from hvgan import ops, lib
+    B, H, W, C, k, p = case
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, C, H, W, generator=g, requires_grad=True)
+    w = torch.randn(1, C, k, k, generator=g) / (C * k * k) ** 0.5
+    y = F.conv2d(x, w, None, stride=1, padding=p)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    wb = ohwi_T(w, CoutP=4)                                    # [C][taps][4]
+    ga = to_act(gy, 4)
+    ga = ops.Act(ga.t, 4, 0)
+    m = torch.randn(B, C, H, W, generator=g)
+    fac = torch.where(m > 0, torch.ones_like(m), torch.full_like(m, 0.2))
+    dxa = ops.Act.empty(B, H, W, C, dev())
+    ops.conv2d(ga, wb, dxa, k, 1, p, 1, transposed=True, precision=prec, w_h=wb.half(), mul=(to_act(m), 'lrelu'))
+    torch.cuda.synchronize()
+    ref = x.grad * fac
+    assert maxerr(from_act(dxa), ref) <= tol * max(1.0, ref.abs().max().item())
+    ops.conv2d(ga, wb, dxa, k, 1, p, 1, transposed=True, precision=prec, w_h=wb.half(), accumulate=1)
+    torch.cuda.synchronize()
+    assert maxerr(from_act(dxa), ref + x.grad) <= 2 * tol * max(1.0, ref.abs().max().item())
+
+
 def test_conv_upsample_fused_and_transposed_conv_layer():
     """in_shift=1 == conv(F.interpolate(x, 2)); transposed=1 == F.conv_transpose2d (k4 s2 p1)."""
     from hvtest import to_act, from_act, ohwi, dev, maxerr
