@@ -149,12 +149,21 @@ def main():
     }
     if rank == 0:
         out['roofline'] = prof.roofline(args.precision, MFMA_PEAK_TFLOPS[args.precision])
-        try:      # HBM bytes per launch from the committed PMC passes (profiles/r01_traffic.json), when this kernel was measured
-            tr = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_traffic.json')))['kernels']
+        # HBM bytes per launch from the committed PMC passes: per layer shape where that kernel was profiled alone
+        # (profiles/r01_traffic.json), else the per-instantiation mean over the whole step (profiles/r01_traffic_step.json)
+        pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles')
+        try:
+            tr = json.load(open(os.path.join(pdir, 'r01_traffic.json')))['kernels']
             ents = [(tr.get(sh['shape']), sh['launches']) for sh in out['roofline']['shapes']]
             if ents and all(e for e, _ in ents):      # launch-weighted mean over the layer shapes this instantiation serves
                 out['roofline']['traffic'] = int(sum(e['traffic_bytes'] * n for e, n in ents) / sum(n for _, n in ents))
                 out['roofline']['traffic_source'] = 'profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)'
+            else:
+                e = json.load(open(os.path.join(pdir, 'r01_traffic_step.json')))['kernels'].get(out['roofline']['kernel'])
+                if e:
+                    out['roofline']['traffic'] = int(e['traffic_bytes'])
+                    out['roofline']['traffic_source'] = ('profiles/r01_traffic_step.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate '
+                                                         'passes over a serial bench run; mean per launch of this instantiation)')
         except (OSError, ValueError, KeyError):
             pass
         out['roofline']['timed_in'] = 'eager single-stream re-run of the K steps after the timed region (HIP events on the launch stream)'

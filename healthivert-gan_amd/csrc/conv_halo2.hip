@@ -279,6 +279,8 @@ int hv_halo2_launch(HaloK& k, int TW, int KH, int KW, int maxpatch, hipStream_t 
         if ((long long)k.B * hv_cdiv(k.cls[0].Hc, 8) * hv_cdiv(k.cls[0].Wc, 16) < 256) return launch2<4, 16, 16, 4, 1, 32, 1, 4, 4>(k, s, 8, 16);
         return launch2<8, 16, 16, 4, 1, 32, 1, 4, 4>(k, s);
     }
+    // (4x4 stride-2 FORWARD stays on conv_halo_kernel: its 18 x 34-pixel patch leaves this kernel either 16-channel chunks or 4-row tiles
+    // to keep two workgroups per CU -- measured 60-76 us against 48 us on 64 -> 128 @128^2 and 48-66 us against 43 us on 128 -> 256 @64^2)
     // data gradient of the 4x4 stride-2 layers: four output-parity classes of 2x2 taps each
     static const int m4 = getenv("HV_HALO2_S2T") ? atoi(getenv("HV_HALO2_S2T")) : 1;
     if (m4 && ntaps == 4 && KH == 4 && KW == 4 && k.bstep == 1 && k.Cin % 32 == 0 && k.Cout > 32) {
