@@ -162,3 +162,24 @@ def make_rhlv_pair(seed=0, H=64, W=64, Z=16, label_index=20, collapse=0.35, empt
         fake[2:6, a:b, z] = label_index + 1          # a neighbour: must be ignored by the == label_index test
         label[2:6, a:b, z] = label_index + 1
     return fake, label
+
+
+def make_spine_volume(seed, H=96, W=56, Z=10, first_id=10, n_vert=5, pitch=18):
+    """Synthetic straightened-spine volume for the batch-assembly path: ct in [0, 255) with fractional parts,
+    label = vertebra ids stacked along the rows (extent varying with z, plus a few specks below the 50-pixel component filter),
+    cam in [0, 1].  Returns float32 ct, uint8 label, float32 cam, all [H, W, Z] like the reference's NIfTI arrays."""
+    import numpy as np
+    rng = np.random.RandomState(seed)
+    ct = (rng.rand(H, W, Z) * 255).astype(np.float32)
+    cam = rng.rand(H, W, Z).astype(np.float32)
+    label = np.zeros((H, W, Z), dtype=np.uint8)
+    for v in range(n_vert):
+        top = 3 + v * pitch
+        for z in range(1, Z - 1):
+            h = int(rng.randint(10, 15))
+            w0 = int(rng.randint(4, 10))
+            label[top + int(rng.randint(0, 3)):top + h, w0:W - w0, z] = first_id + v
+        for _ in range(3):      # specks: fewer than 50 pixels, away from the body
+            z, r, c = int(rng.randint(1, Z - 1)), top + 15, int(rng.randint(0, W - 4))
+            label[r:r + 2, c:c + 3, z] = first_id + v
+    return ct, label, cam

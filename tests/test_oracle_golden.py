@@ -1,5 +1,7 @@
 """The CPU oracle (oracle/restate.py) against the golden vectors the reference produced
 (oracle/make_golden.py).  CPU only; this is what pins the oracle."""
+import os
+
 import torch
 
 from oracle import restate as R
@@ -132,3 +134,38 @@ def test_g8_rhlv_oracle_matches_reference_outputs():
         sf, sl = (fake == idx).astype(np.float64), (label == idx).astype(np.float64)
         res2, _ = R.rhlv(sf, sl, int(cz), int(length), thr)
         assert np.array_equal(np.array(res2), np.asarray(g[n + '/out']))
+
+
+G9_VOLUME_KW = {1: dict(), 2: dict(), 3: dict(H=112, W=72, Z=14)}
+
+
+def g9_cases():
+    """(name, float64 volumes, vertebra id, normal list, numpy seed, expected dict) for every G9 case."""
+    import numpy as np
+    import hvgan  # noqa: F401
+    from hvgan import synth
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'g9_assemble.npz'))
+    for name in z['cases']:
+        name = str(name)
+        vseed, vert_id, nseed, sl, height, x1, x2, h2 = (int(v) for v in z[name + '/meta'])
+        ct, label, cam = synth.make_spine_volume(vseed, **G9_VOLUME_KW[vseed])
+        exp = {k: z[name + '/' + k] for k in ('A', 'B', 'A_mask', 'mask', 'normal_vert', 'CAM')}
+        exp.update(slice=sl, height=height, x1=x1, x2=x2, h2=h2, slice_ratio=float(z[name + '/slice_ratio'][0]))
+        yield name, ct, label, cam, vert_id, [str(v) for v in z[name + '/normals']], nseed, exp
+
+
+def test_g9_batch_assembly_oracle_matches_reference_getitem():
+    """oracle.restate.dataset_item_u8 (slice draw, component filter, row re-stacking, uint8 quantisation) against the outputs of the
+    reference's AlignedDataset.__getitem__ (G9): bit-identical images and metadata."""
+    import numpy as np
+    n = 0
+    for name, ct, label, cam, vert_id, normals, nseed, exp in g9_cases():
+        np.random.seed(nseed)
+        got = R.dataset_item_u8(ct.astype(np.float64), label.astype(np.float64), cam.astype(np.float64) * 255, vert_id, normals)
+        for k in ('slice', 'height', 'x1', 'x2', 'h2'):
+            assert got[k] == exp[k], (name, k, got[k], exp[k])
+        assert got['slice_ratio'] == exp['slice_ratio']
+        for k in ('A', 'B', 'A_mask', 'mask', 'normal_vert', 'CAM'):
+            assert np.array_equal(got[k], exp[k]), (name, k)
+        n += 1
+    assert n >= 6
