@@ -285,6 +285,23 @@ int hv_rhlv(const void* fake, const void* label, int dtype, long long stride_h, 
             float label_index, int length_divisor, int z_lo, int z_hi, double height_threshold, double* out, void* workspace,
             size_t workspace_bytes, void* stream);
 
+/* ---- batch assembly on the device (reference data/aligned_dataset.py:204-280, AlignedDataset.__getitem__) ----
+ * One item = one sagittal slice of a vertebra volume whose four uint8 planes [H][W] are resident on the device: ct = ct_data.astype(uint8)
+ * (:245), vert = component-filtered vertebra mask * 255 (:247-248), normal = the patient's normal vertebrae as 0/255 (:190-196), cam =
+ * (CAM * 255).astype(uint8) (:167,250) -- the reference quantises per item, a resident volume is quantised once.  [min_x, max_x) is the
+ * masked band (:214-226), x1 / x2 the vertebra's first / last row (:205).  Outputs are the six float32 planes [B][H][W] the loader
+ * collates: A = norm(ct), B = norm(restack(ct)), A_mask = vert / 255, mask = band, normal_vert = restack(normal) / 255,
+ * CAM = restack(cam) / 255, with restack(v)[r] = v[r + x1 - min_x] above the band, v[x2 + r - max_x] below it, 0 inside (:232-243),
+ * norm(u) = (u / 255 - 0.5) / 0.5 (torchvision ToTensor + Normalize((0.5,), (0.5,)), float32 arithmetic, bit-identical).
+ * Every source row an item addresses must lie in [0, H) (the reference raises a broadcasting error otherwise): HV_ERR_ARG is NOT
+ * detected for device-side descriptors -- the host mirror validates before upload. */
+typedef struct {
+    const uint8_t* ct; const uint8_t* vert; const uint8_t* normal; const uint8_t* cam;
+    int x1, x2, min_x, max_x;
+} hv_assemble_item;
+int hv_assemble_batch(const hv_assemble_item* d_items, int B, int H, int W, float* A, float* Bimg, float* A_mask, float* mask,
+                      float* normal_vert, float* CAM, void* stream);   /* d_items: DEVICE array of B descriptors */
+
 #ifdef __cplusplus
 }
 #endif
