@@ -87,9 +87,11 @@ extern "C" int hv_ca_raw_patches(const float* f, int B, int H, int W, int C, int
 }
 
 // ---- mask of valid background patches (sample 0 only) ------------------------------------------------
-__global__ void ca_mask_kernel(const float* __restrict__ mask, int Himg, int Wimg, int h, int w, float* __restrict__ mm) {
+__global__ void ca_mask_kernel(const float* __restrict__ mask, int Himg, int Wimg, int h, int w, float* __restrict__ mm, long long mask_bs) {
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= h * w) return;
+    mask += blockIdx.y * mask_bs;      // blockIdx.y = sample (hv_ca_mask_batched); the one-sample form launches a single row
+    mm += (long long)blockIdx.y * h * w;
     const int sy = Himg / h, sx = Wimg / w;
     float s = 0.f;
     for (int t = 0; t < 9; ++t) {
@@ -100,7 +102,14 @@ __global__ void ca_mask_kernel(const float* __restrict__ mask, int Himg, int Wim
 }
 extern "C" int hv_ca_mask(const float* mask, int Himg, int Wimg, int h, int w, float* mm, void* stream) {
     if (!mask || !mm || h <= 0 || w <= 0 || Himg % h || Wimg % w) return HV_ERR_ARG;
-    hipLaunchKernelGGL(ca_mask_kernel, dim3(hv_cdiv(h * w, 256)), dim3(256), 0, (hipStream_t)stream, mask, Himg, Wimg, h, w, mm);
+    hipLaunchKernelGGL(ca_mask_kernel, dim3(hv_cdiv(h * w, 256)), dim3(256), 0, (hipStream_t)stream, mask, Himg, Wimg, h, w, mm, 0ll);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+// every sample's own mask: mm[B][h*w] (a batch that stands for B independent single-sample calls, e.g. the z-slices of one inference stage)
+extern "C" int hv_ca_mask_batched(const float* mask, int B, long long mask_bstride, int Himg, int Wimg, int h, int w, float* mm, void* stream) {
+    if (!mask || !mm || B <= 0 || B > 65535 || h <= 0 || w <= 0 || Himg % h || Wimg % w) return HV_ERR_ARG;
+    hipLaunchKernelGGL(ca_mask_kernel, dim3(hv_cdiv(h * w, 256), B), dim3(256), 0, (hipStream_t)stream, mask, Himg, Wimg, h, w, mm, mask_bstride);
     HV_LAUNCH_CHECK();
     return HV_OK;
 }
@@ -204,10 +213,11 @@ extern "C" int hv_ca_fuse(const float* S, float* out, int B, int h, int w, int a
 
 // ---- masked scaled softmax over l (one 256-thread block per row) -------------------------------------
 __global__ __launch_bounds__(256) void ca_softmax_kernel(const float* __restrict__ S, const float* __restrict__ mm, float* __restrict__ A, int L,
-                                                         float scale, int* __restrict__ argmax) {
+                                                         float scale, int* __restrict__ argmax, long long mm_bs) {
     __shared__ float red[8];
     __shared__ int redi[8];
     const long long row = blockIdx.x;
+    mm += (row / L) * mm_bs;           // per-sample masks (hv_ca_softmax_batched) or one shared mask (stride 0)
     const float* s = S + row * L;
     float* a = A + row * L;
     const int tid = threadIdx.x;
@@ -250,7 +260,14 @@ __global__ __launch_bounds__(256) void ca_softmax_kernel(const float* __restrict
 }
 extern "C" int hv_ca_softmax(const float* S, const float* mm, float* A, int B, int L, float scale, int* argmax, void* stream) {
     if (!S || !mm || !A || B <= 0 || L <= 0) return HV_ERR_ARG;
-    hipLaunchKernelGGL(ca_softmax_kernel, dim3(B * L), dim3(256), 0, (hipStream_t)stream, S, mm, A, L, scale, argmax);
+    hipLaunchKernelGGL(ca_softmax_kernel, dim3(B * L), dim3(256), 0, (hipStream_t)stream, S, mm, A, L, scale, argmax, 0ll);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+extern "C" int hv_ca_softmax_batched(const float* S, const float* mm, long long mm_bstride, float* A, int B, int L, float scale, int* argmax,
+                                     void* stream) {
+    if (!S || !mm || !A || B <= 0 || L <= 0 || mm_bstride < 0) return HV_ERR_ARG;
+    hipLaunchKernelGGL(ca_softmax_kernel, dim3(B * L), dim3(256), 0, (hipStream_t)stream, S, mm, A, L, scale, argmax, mm_bstride);
     HV_LAUNCH_CHECK();
     return HV_OK;
 }

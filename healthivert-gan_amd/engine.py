@@ -309,25 +309,38 @@ class AttentionPlan:
         self.norm, self.rnorm = z(B, L), z(B, L)
         self.raw, self.rawT = z(B, L, 16 * C), z(B, C, 16 * L)
         self.mm = z(L)
+        self.mm_b = None      # [B][L], allocated on the first per-sample-mask forward
         self.S0, self.S1, self.A = Act(z(B, self.h, self.w, L)), Act(z(B, self.h, self.w, L)), Act(z(B, self.h, self.w, L))
         self.argmax = torch.zeros(B * L, dtype=torch.int32, device=device)
         self.bw = None
 
-    def forward(self, f, mask_img, out, prec, want_argmax=False):
-        """f: Act [B,H,W,C] (foreground == background), mask_img: (B,1,Himg,Wimg) tensor, out: Act [B,H,W,C]."""
+    def forward(self, f, mask_img, out, prec, want_argmax=False, per_sample_mask=False):
+        """f: Act [B,H,W,C] (foreground == background), mask_img: (B,1,Himg,Wimg) tensor, out: Act [B,H,W,C].
+        per_sample_mask: every sample's own mask decides its valid patches -- the batch stands for B independent batch-1 calls (the
+        reference's inference loop); False = the reference's batched behaviour (sample 0's mask for all, inpaint_networks.py:314)."""
         L_ = _lib.get()
         B, H, W, C, L = self.B, self.H, self.W, self.C, self.L
         L_.call('hv_ca_patches', ptr(f.t), B, H, W, C, f.ld, ptr(self.fd.t), ptr(self.wp), ptr(self.wpT), ptr(self.norm), ptr(self.rnorm), stream())
         L_.call('hv_ca_raw_patches', ptr(f.t), B, H, W, C, f.ld, ptr(self.raw), ptr(self.rawT), stream())
-        L_.call('hv_ca_mask', ptr(mask_img), self.img_hw[0], self.img_hw[1], self.h, self.w, ptr(self.mm), stream())
+        if per_sample_mask:
+            if self.mm_b is None:
+                self.mm_b = torch.zeros(B, L, dtype=torch.float32, device=self.mm.device)
+            L_.call('hv_ca_mask_batched', ptr(mask_img), B, ctypes.c_longlong(self.img_hw[0] * self.img_hw[1]), self.img_hw[0], self.img_hw[1],
+                    self.h, self.w, ptr(self.mm_b), stream())
+        else:
+            L_.call('hv_ca_mask', ptr(mask_img), self.img_hw[0], self.img_hw[1], self.h, self.w, ptr(self.mm), stream())
         ops.conv2d(self.fd, self.wp, self.S0, 3, 1, 1, 1, w_bstride=L * 9 * C, ch_scale=self.rnorm, ch_scale_bstride=L, precision=prec)
         if self.fuse:
             L_.call('hv_ca_fuse', ptr(self.S0.t), ptr(self.S1.t), B, self.h, self.w, 0, stream())
             s = self.S1
         else:
             s = self.S0
-        L_.call('hv_ca_softmax', ptr(s.t), ptr(self.mm), ptr(self.A.t), B, L, ctypes.c_float(self.scale),
-                ptr(self.argmax) if want_argmax else None, stream())
+        if per_sample_mask:
+            L_.call('hv_ca_softmax_batched', ptr(s.t), ptr(self.mm_b), ctypes.c_longlong(L), ptr(self.A.t), B, L, ctypes.c_float(self.scale),
+                    ptr(self.argmax) if want_argmax else None, stream())
+        else:
+            L_.call('hv_ca_softmax', ptr(s.t), ptr(self.mm), ptr(self.A.t), B, L, ctypes.c_float(self.scale),
+                    ptr(self.argmax) if want_argmax else None, stream())
         ops.conv2d(self.A, self.rawT, out, 4, 2, 1, 1, transposed=True, alpha=0.25, w_bstride=C * 16 * L, precision=prec)
 
     def backward(self, dout, df, accumulate, prec):

@@ -41,7 +41,8 @@ def synthesize(model, ct_masked, mask, cam, index_ratio, ori_ct, label, x1, x2, 
     n = ctypes.c_longlong(B * H * W)
     cam_t = torch.empty_like(cam)
     L.call('hv_affine', ptr(cam_t), ptr(cam.contiguous()), n, ctypes.c_float(-1.0), ctypes.c_float(1.0), stream())
-    P = model.run_forward(ct_masked, mask, cam_t, index_ratio, training=False)
+    # the reference synthesises slice by slice at batch 1: each slice's own mask band selects its valid attention patches
+    P = model.run_forward(ct_masked, mask, cam_t, index_ratio, training=False, per_sample_mask=True)
     pred = torch.empty(B, device=dev)
     L.call('hv_affine', ptr(pred), ptr(P.pred2), ctypes.c_longlong(B), ctypes.c_float(float(maxheight)), ctypes.c_float(0.0), stream())
     x1, x2, height = (t.to(dev).long().contiguous() for t in (x1, x2, height))

@@ -350,9 +350,10 @@ class Generator(nn.Module):
         return self._plans[key]
 
     # ---------------------------------------------------------------- explicit forward / backward
-    def run_forward(self, x, mask, CAM, slice_ratio, training=None):
+    def run_forward(self, x, mask, CAM, slice_ratio, training=None, per_sample_mask=False):
         """x, mask, CAM: (B,1,H,W) fp32 device tensors; slice_ratio: (B,) fp64.  Returns the plan (all activations
-        stay in its buffers); outputs are plan.coarse_seg/fine_seg/x_stage1/x_stage2 (B,1,H,W) and plan.pred1/pred2 (B,1)."""
+        stay in its buffers); outputs are plan.coarse_seg/fine_seg/x_stage1/x_stage2 (B,1,H,W) and plan.pred1/pred2 (B,1).
+        per_sample_mask: the batch stands for B independent batch-1 calls (attention masks per sample, see AttentionPlan.forward)."""
         _lib.require_gpu(x, mask, CAM)
         training = self.training if training is None else training
         prec = ops.precision_id(self.precision)
@@ -391,7 +392,7 @@ class Generator(nn.Module):
         with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
             for n in P.f_nodes_pm:
                 n.forward(prec)
-            P.attn.forward(a['p6'], mask, a['ca'], prec)
+            P.attn.forward(a['p6'], mask, a['ca'], prec, per_sample_mask=per_sample_mask)
             for n in P.f_nodes_pm2:
                 n.forward(prec)
         for n in P.f_nodes_conv:

@@ -199,11 +199,16 @@ int hv_ca_patches(const float* f, int B, int H, int W, int C, int f_ld, float* f
 int hv_ca_raw_patches(const float* f, int B, int H, int W, int C, int f_ld, float* raw, float* rawT, void* stream);
 /* mm[l] = 1 iff the 3x3 patch of the x1/8-downsampled mask of SAMPLE 0 is all zero (:304-317). */
 int hv_ca_mask(const float* mask, int Himg, int Wimg, int h, int w, float* mm, void* stream);
+/* the same for every sample's own mask: mm[B][h*w] -- a batch that stands for B independent single-sample calls (the reference's inference
+ * loop runs the generator at batch 1, eval_3d_sagittal_twostage.py:101), not for one training batch (which shares sample 0's mask) */
+int hv_ca_mask_batched(const float* mask, int B, long long mask_bstride, int Himg, int Wimg, int h, int w, float* mm, void* stream);
 /* score fusion (two diagonal 3-tap sums with the (h,w)<->(w,h) transposes, :352-361); adjoint=1 applies the
  * transposed operator (backward).  h == w required. */
 int hv_ca_fuse(const float* S, float* out, int B, int h, int w, int adjoint, void* stream);
 /* A[b][p][l] = softmax_l(S*mm*scale)*mm (:364-366); optional argmax over l -> argmax[b*L+p] (:368). */
 int hv_ca_softmax(const float* S, const float* mm, float* A, int B, int L, float scale, int* argmax, void* stream);
+int hv_ca_softmax_batched(const float* S, const float* mm, long long mm_bstride, float* A, int B, int L, float scale, int* argmax,
+                          void* stream);   /* mm_bstride = L: per-sample masks from hv_ca_mask_batched; 0: shared */
 int hv_ca_softmax_backward(const float* dA, const float* A, const float* mm, float* dS, int B, int L, float scale, void* stream);
 int hv_transpose_batched(const float* src, float* dst, int B, int R, int C, void* stream); /* dst[b][c][r] = src[b][r][c] */
 /* Gs[b][i][j] = dS[b][j][i]*rnorm[b][i] + dS[b][i][j]*rnorm[b][j];  coef[b][l] = -(sum_p dS[p][l]*S0[p][l])/norm[l]^2.

@@ -26,8 +26,12 @@ def test_stage_batched_synthesis_matches_oracle():
     label = b['real_B_mask'] * 20.0
     lab, ct, pred = infer.synthesize(net, b['real_A'].to(dev), b['mask'].to(dev), b['CAM'].to(dev), b['slice_ratio'].to(dev),
                                      b['real_B'].to(dev), label.to(dev), b['x1'].to(dev), b['x2'].to(dev), b['height'].to(dev), 20)
+    # the reference synthesises slice by slice at batch 1 (every slice's own mask selects its attention patches): oracle per sample
+    assert not torch.equal(b['mask'][0], b['mask'][1]) or not torch.equal(b['mask'][0], b['mask'][2])
     with torch.no_grad():
-        (cs, fs, x1s, x2s, p1, p2), _ = R.generator_forward(sd, b['real_A'], b['mask'], 1 - b['CAM'], b['slice_ratio'], training=False)
+        per = [R.generator_forward(sd, b['real_A'][i:i + 1], b['mask'][i:i + 1], 1 - b['CAM'][i:i + 1], b['slice_ratio'][i:i + 1],
+                                   training=False)[0] for i in range(3)]
+    cs, fs, x1s, x2s, p1, p2 = (torch.cat([o[k] for o in per]) for k in range(6))
     assert (pred.cpu() - p2.view(-1)).abs().max().item() <= 1e-3
     ph = p2.view(-1) * 40
     # keep the comparison away from the ceil() discontinuity
