@@ -43,17 +43,31 @@ def synthesize(model, ct_masked, mask, cam, index_ratio, ori_ct, label, x1, x2, 
     L.call('hv_affine', ptr(cam_t), ptr(cam.contiguous()), n, ctypes.c_float(-1.0), ctypes.c_float(1.0), stream())
     # the reference synthesises slice by slice at batch 1: each slice's own mask band selects its valid attention patches
     P = model.run_forward(ct_masked, mask, cam_t, index_ratio, training=False, per_sample_mask=True)
+    lab, ct = recomposite(P.x_stage2, P.fine_seg, P.pred2, ori_ct, label, x1, x2, height, vert_id, maxheight)
+    return lab, ct, P.pred2.view(B).clone()
+
+
+@torch.no_grad()
+def recomposite(x_stage2, fine_seg, pred2, ori_ct, label, x1, x2, height, vert_id, maxheight=40):
+    """Post-processing of run_model (reference :103-130) for a batch: pred_h = max(ceil(pred2 * maxheight), height), generated rows
+    [x_upper, x_bottom) between the re-stacked original rows, CT back to [0, 255], label = (fine_seg > 0.5) * vert_id in the same rows.
+    x_stage2, fine_seg, ori_ct, label: (B,1,H,W) fp32 device tensors; pred2: (B,1) or (B,).  Returns (label_fake, ct_fake) (B,H,W)."""
+    L = _lib.get()
+    _lib.require_gpu(x_stage2, fine_seg, ori_ct, label)
+    B, _, H, W = x_stage2.shape
+    dev = x_stage2.device
+    n = ctypes.c_longlong(B * H * W)
     pred = torch.empty(B, device=dev)
-    L.call('hv_affine', ptr(pred), ptr(P.pred2), ctypes.c_longlong(B), ctypes.c_float(float(maxheight)), ctypes.c_float(0.0), stream())
+    L.call('hv_affine', ptr(pred), ptr(pred2.contiguous()), ctypes.c_longlong(B), ctypes.c_float(float(maxheight)), ctypes.c_float(0.0), stream())
     x1, x2, height = (t.to(dev).long().contiguous() for t in (x1, x2, height))
     ct = torch.empty(B, H, W, device=dev)
-    L.call('hv_shrm_composite', ptr(P.x_stage2), ptr(ori_ct.contiguous()), ptr(pred), ptr(height), ptr(x1), ptr(x2), ptr(ct), None, B, H, W, stream())
+    L.call('hv_shrm_composite', ptr(x_stage2.contiguous()), ptr(ori_ct.contiguous()), ptr(pred), ptr(height), ptr(x1), ptr(x2), ptr(ct), None, B, H, W, stream())
     L.call('hv_affine', ptr(ct), ptr(ct), n, ctypes.c_float(127.5), ctypes.c_float(127.5), stream())
     seg = torch.empty(B, 1, H, W, device=dev)
-    L.call('hv_threshold', ptr(P.fine_seg), ptr(seg), n, ctypes.c_float(0.5), ctypes.c_float(float(vert_id)), stream())
+    L.call('hv_threshold', ptr(fine_seg.contiguous()), ptr(seg), n, ctypes.c_float(0.5), ctypes.c_float(float(vert_id)), stream())
     lab = torch.empty(B, H, W, device=dev)
     L.call('hv_shrm_composite', ptr(seg), ptr(label.contiguous()), ptr(pred), ptr(height), ptr(x1), ptr(x2), ptr(lab), None, B, H, W, stream())
-    return lab, ct, P.pred2.view(B).clone()
+    return lab, ct
 
 
 # ------------------------------------------------------------------------------------------------ stage-batched volume driver

@@ -133,3 +133,25 @@ def test_gradient_averaging_two_ranks_gloo():
     for p in procs:
         out, _ = p.communicate(timeout=300)
         assert p.returncode == 0 and b'ok' in out, out.decode()[-2000:]
+
+
+def test_infer_prepare_slice_matches_reference_network_inputs():
+    """infer.prepare_slice (the host-side slice preparation of the stage-batched inference driver) produces exactly the tensors the
+    reference's run_model hands to the network (fixture G10, recorded by a stand-in network) and the same rows / height."""
+    import numpy as np
+    import torch
+    import hvgan  # noqa: F401
+    from hvgan import infer
+    from oracle import restate as R
+    from test_oracle_golden import g10_cases
+    for name, ct, label, cam, vert_id, ratio, model, exp in g10_cases():
+        p = infer.prepare_slice(cam, label, ct, vert_id)
+        if exp is None:
+            assert p is None, name
+            continue
+        q = R.infer_prepare(cam, label, ct, vert_id)
+        assert (p['x1'], p['x2'], p['height']) == (q['x1'], q['x2'], q['height']) and p['height'] == int(exp['height'][0]), name
+        assert torch.equal(torch.from_numpy(p['ct_masked'])[None], R.to_tensor_u8(exp['in_ct'], True)), name
+        assert torch.equal(torch.from_numpy(p['mask'])[None], R.to_tensor_u8(exp['in_mask'], False)), name
+        assert torch.equal(torch.from_numpy(p['cam'])[None], R.to_tensor_u8(exp['in_cam'], False)), name
+        assert torch.equal(torch.from_numpy(p['ori_ct'])[None], q['ori_ct']), name

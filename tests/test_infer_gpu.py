@@ -127,3 +127,29 @@ def test_eval_forward_graph_replay_matches_eager():
     e, g = both(args(5, 1))
     assert torch.equal(e[3], g[3]) and torch.equal(e[0], g[0])
     assert len(net._eval_graphs) == 2
+
+
+def test_recomposite_matches_reference_run_model_outputs():
+    """infer.recomposite (device re-compositing of run_model :103-130) on the stand-in network outputs of fixture G10: label slice exact,
+    CT slice within float32 rounding of the reference's (x + 1) * 127.5."""
+    import numpy as np
+    import hvgan  # noqa: F401
+    from hvgan import infer
+    from oracle import restate as R
+    from oracle.make_golden_infer import fake_outputs
+    from test_oracle_golden import g10_cases
+    dev = torch.device('cuda:0')
+    n = 0
+    for i, (name, ct, label, cam, vert_id, ratio, model, exp) in enumerate(g10_cases()):
+        if exp is None:
+            continue
+        p = R.infer_prepare(cam, label, ct, vert_id)
+        seg, raw = fake_outputs(500 + i)
+        t = lambda a: a.to(dev)
+        iv = lambda v: torch.tensor([v], dtype=torch.int64, device=dev)
+        lab, ctf = infer.recomposite(t(raw), t(seg), torch.tensor([[model.frac]], device=dev), t(p['ori_ct'][None]),
+                                     t(torch.from_numpy(label.astype(np.float32))[None, None]), iv(p['x1']), iv(p['x2']), iv(p['height']), vert_id)
+        assert np.array_equal(lab[0].cpu().numpy().astype(np.float64), exp['label_fake']), name
+        assert np.abs(ctf[0].cpu().numpy().astype(np.float64) - exp['ct_fake']).max() <= 5e-5, name
+        n += 1
+    assert n >= 6

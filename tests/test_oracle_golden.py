@@ -169,3 +169,35 @@ def test_g9_batch_assembly_oracle_matches_reference_getitem():
             assert np.array_equal(got[k], exp[k]), (name, k)
         n += 1
     assert n >= 6
+
+
+def g10_cases():
+    """(name, ct, label, cam slices, vertebra id, ratio tensor, recording model, expected arrays or None) for every G10 case."""
+    import numpy as np
+    from oracle.make_golden_infer import CASES, make_slice, RecordingModel
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'g10_infer.npz'))
+    for i, (name, rows, vert_id, frac, specks) in enumerate(CASES):
+        ct, label, cam = make_slice(i, rows, vert_id, specks)
+        exp = None if (name + '/none') in z.files else {k: z[name + '/' + k] for k in ('in_ct', 'in_mask', 'in_cam', 'label_fake', 'ct_fake', 'height')}
+        yield name, ct, label, cam, vert_id, torch.tensor([0.125 * i]), RecordingModel(500 + i, frac), exp
+
+
+def test_g10_inference_slice_oracle_matches_reference_run_model():
+    """oracle.restate.infer_run_model (component filter, bbox / too-tall window, 41-row mask band, re-stacking, uint8 quantisation, then the
+    re-compositing around the network's outputs) against the reference's run_model driven by the same recording stand-in network (G10)."""
+    import numpy as np
+    n = 0
+    for name, ct, label, cam, vert_id, ratio, model, exp in g10_cases():
+        res = R.infer_run_model(model, cam.copy(), label.copy(), ct.copy(), vert_id, ratio)
+        if exp is None:
+            assert res is None, name
+            continue
+        lab, ctf, height = res
+        ctb, mb, cinv, r = model.inputs
+        assert torch.equal(ctb[0], R.to_tensor_u8(exp['in_ct'], True)) and torch.equal(mb[0], R.to_tensor_u8(exp['in_mask'], False)), name
+        assert torch.equal(cinv[0], 1 - R.to_tensor_u8(exp['in_cam'], False)) and torch.equal(r, ratio), name
+        assert height == int(exp['height'][0])
+        assert np.array_equal(np.asarray(lab, dtype=np.float64), exp['label_fake']), name
+        assert np.array_equal(np.asarray(ctf, dtype=np.float64), exp['ct_fake']), name
+        n += 1
+    assert n >= 6
