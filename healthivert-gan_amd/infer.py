@@ -4,7 +4,7 @@ on the HIP path: eval-mode generator forward, pred_h = ceil(pred2_h*maxheight), 
 
 The reference runs ~130 sequential bs=1 forwards per volume, each with a PIL->tensor->H2D hop and a D2H copy
 (SURVEY.md section 3.2); z-slices of one stage are independent, so `synthesize` takes a whole batch of slices.
-File I/O, connected-component cleaning and the uint8 mask-band construction stay on the caller's side.
+`process_volume` keeps the slices on the device across the three chained stages, connected-component cleaning and band construction included.
 """
 import ctypes
 
@@ -71,18 +71,6 @@ def recomposite(x_stage2, fine_seg, pred2, ori_ct, label, x1, x2, height, vert_i
 
 
 # ------------------------------------------------------------------------------------------------ stage-batched volume driver
-_POOL = None
-
-
-def _pool():
-    global _POOL
-    if _POOL is None:
-        import os
-        from concurrent.futures import ThreadPoolExecutor
-        _POOL = ThreadPoolExecutor(max_workers=max(1, min(8, (os.cpu_count() or 2) // 2)))
-    return _POOL
-
-
 def _clean_components(mask, min_size):
     """remove_small_connected_components of the reference (eval_3d_sagittal_twostage.py:15-30): 8-connectivity."""
     import numpy as np
@@ -96,7 +84,8 @@ def _clean_components(mask, min_size):
 
 
 def prepare_slice(cam2d, label2d, ct2d, vert_id, maxheight=40):
-    """CPU part of run_model (reference :46-98): bbox of the vertebra, 41-row mask band (note `max_x+1`, :75), masked CT and
+    """Host mirror of the slice preparation in run_model (reference :46-98; the device path is hv_slice_components + hv_infer_prepare,
+    pinned against this function and fixture G10): bbox of the vertebra, 41-row mask band (note `max_x+1`, :75), masked CT and
     CAM re-stacked around the band, uint8 quantisation, ToTensor/Normalize.  Returns None when the vertebra is absent."""
     import numpy as np
     vl = np.zeros_like(label2d)
@@ -134,44 +123,44 @@ def prepare_slice(cam2d, label2d, ct2d, vert_id, maxheight=40):
     return dict(ct_masked=f(ct_masked, True), ori_ct=f(ct_u8, True), mask=f(mask, False), cam=f(cam, False), x1=x1, x2=x2, height=height)
 
 
-def _stage(model, cam_vol, labels, cts, zs, ratios, vert_id, device, maxheight):
-    """One synthesis stage for all z-slices at once: labels/cts are lists of 2-D arrays (per z), cam_vol is [Z, H, W].  Returns new lists
-    (slices where the vertebra is absent pass through unchanged, like the reference's `output == None`)."""
-    import numpy as np
-    # host-side slice preparation (connected components, bounding box, band re-stacking) is independent per slice: a small thread
-    # pool keeps it off the critical path of the three batched generator launches (numpy / scipy release the GIL in their loops)
-    prep1 = lambda iz: prepare_slice(cam_vol[iz[1]], labels[iz[0]], cts[iz[0]], vert_id, maxheight)       # cam_vol is z-major
-    if len(zs) >= 8:
-        preps = list(_pool().map(prep1, list(enumerate(zs))))
-    else:
-        preps = [prep1(iz) for iz in enumerate(zs)]
-    idx = [i for i, p in enumerate(preps) if p is not None]
-    out_l, out_c = list(labels), list(cts)
-    if not idx:
-        return out_l, out_c, idx
-    t = lambda key: torch.from_numpy(np.stack([preps[i][key] for i in idx])).unsqueeze(1).to(device)
-    iv = lambda key: torch.tensor([preps[i][key] for i in idx], dtype=torch.int64, device=device)
-    lab_t = torch.from_numpy(np.stack([labels[i] for i in idx]).astype(np.float32)).unsqueeze(1).to(device)
-    ratio = torch.tensor([ratios[i] for i in idx], dtype=torch.float64, device=device)
-    lab, ct, _ = synthesize(model, t('ct_masked'), t('mask'), t('cam'), ratio, t('ori_ct'), lab_t, iv('x1'), iv('x2'), iv('height'),
-                            vert_id, maxheight)
-    lab, ct = lab.cpu().numpy().astype(np.float64), ct.cpu().numpy().astype(np.float64)
-    for j, i in enumerate(idx):
-        out_l[i], out_c[i] = lab[j], ct[j]
-    return out_l, out_c, idx
+def _stage_device(model, st, vert_id, selected, maxheight):
+    """One synthesis stage with the slices resident on the device (st: lab / ct / cam [S,H,W] fp32, ratio [S] fp64): component filter and
+    row statistics (hv_slice_components), the generator's input planes (hv_infer_prepare), the batched generator + re-compositing, and
+    the write-back of the slices that contained the vertebra (hv_select_slices).  Returns the valid flags ([S] int32, device); no host sync."""
+    L = _lib.get()
+    lab, ct, cam = st['lab'], st['ct'], st['cam']
+    S, H, W = lab.shape
+    dev = lab.device
+    need = L.size('hv_slice_components_workspace_bytes', S, H, W)
+    ws = st.get('ws')
+    if ws is None or ws.numel() < need:
+        ws = st['ws'] = torch.empty(need, dtype=torch.uint8, device=dev)
+    stats = torch.empty(S, 4, dtype=torch.int32, device=dev)
+    L.call('hv_slice_components', ptr(lab), S, H, W, ctypes.c_float(float(vert_id)), 50, ptr(stats), ptr(ws), ctypes.c_size_t(ws.numel()), stream())
+    planes = torch.empty(4, S, 1, H, W, dtype=torch.float32, device=dev)
+    x1, x2, height = (torch.empty(S, dtype=torch.int64, device=dev) for _ in range(3))
+    valid = torch.empty(S, dtype=torch.int32, device=dev)
+    L.call('hv_infer_prepare', ptr(ct), ptr(cam), ptr(stats), ptr(selected), S, H, W, int(maxheight), ptr(planes[0]), ptr(planes[1]), ptr(planes[2]),
+           ptr(planes[3]), ptr(x1), ptr(x2), ptr(height), ptr(valid), stream())
+    lab_o, ct_o, _ = synthesize(model, planes[0], planes[2], planes[3], st['ratio'], planes[1], lab.view(S, 1, H, W), x1, x2, height, vert_id, maxheight)
+    per = ctypes.c_longlong(H * W)
+    L.call('hv_select_slices', ptr(valid), ptr(lab_o), ptr(lab), S, per, 1, stream())
+    L.call('hv_select_slices', ptr(valid), ptr(ct_o), ptr(ct), S, per, 1, stream())
+    return valid
 
 
 def process_volume(model, ct_data, label_data, cam_data, vert_id, device, maxheight=40):
     """process_nii_files' per-volume loop (reference :186-234) with the three chained syntheses (upper neighbour, lower
-    neighbour, target) each batched over ALL z-slices: 3 generator launches per volume instead of ~130 bs=1 calls.
-    ct_data in 0..255, label_data = vertebra ids, cam_data already scaled by 255 (reference :181).  Returns
-    (output_ct [H,W,Z], output_seg [H,W,Z]) as float64 numpy arrays (zeros outside the processed z range)."""
+    neighbour, target) each batched over ALL z-slices: 3 generator launches per volume instead of ~130 bs=1 calls, and the slices
+    stay on the device between the stages -- component filter, bounding rows, band re-stacking and quantisation (run_model :46-98) run there
+    too (`_stage_device`).  ct_data in 0..255, label_data = vertebra ids, cam_data already scaled by 255 (reference :181).  Returns
+    (output_ct [H,W,Z], output_seg [H,W,Z]) as float64 numpy arrays (zeros outside the processed z range).
+    (Where the reference would raise -- a neighbour stage returning None, :212,:221 -- the slice passes through unchanged.)"""
     import numpy as np
-    # z-major contiguous copies: every per-slice access below is then a contiguous 2-D array (the [H, W, Z] inputs have z fastest)
-    lab_z = np.ascontiguousarray(np.moveaxis(label_data, 2, 0))
-    ct_z = np.ascontiguousarray(np.moveaxis(ct_data, 2, 0))
-    cam_z = np.ascontiguousarray(np.moveaxis(cam_data, 2, 0))
-    zhas = np.flatnonzero((lab_z == vert_id).reshape(lab_z.shape[0], -1).any(axis=1))
+    L = _lib.get()
+    dev = torch.device(device)
+    H, W, Z = label_data.shape
+    zhas = np.flatnonzero((label_data == vert_id).any(axis=(0, 1)))
     z0, z1 = int(zhas.min()), int(zhas.max())
     rng_len = z1 - z0 + 1
     new_len = int(rng_len * 4 / 5)
@@ -179,19 +168,31 @@ def process_volume(model, ct_data, label_data, cam_data, vert_id, device, maxhei
     nz1 = nz0 + new_len - 1
     centre = (nz0 + nz1) // 2
     zs = list(range(nz0, nz1 + 1))
-    ratios = [abs(z - centre) / rng_len * 2 for z in zs]
-    labels = [lab_z[z].copy() for z in zs]
-    cts = [ct_z[z].copy() for z in zs]
-    out_ct, out_seg = np.zeros(ct_z.shape, dtype=np.float64), np.zeros(ct_z.shape, dtype=np.float64)      # z-major, returned as [H, W, Z] views
+    S = len(zs)
+    out_ct, out_seg = np.zeros((H, W, Z), dtype=np.float64), np.zeros((H, W, Z), dtype=np.float64)
+    if S == 0:
+        return out_ct, out_seg
+    # the [H, W, Z] inputs have z fastest: the z-range is cut out as it lies (float32, [H*W][S]) and transposed to slices on the device
+    slab = lambda vol: np.ascontiguousarray(vol[:, :, nz0:nz1 + 1], dtype=np.float32)
+    lab_hws = slab(label_data)
+    hws = torch.from_numpy(np.stack([lab_hws, slab(ct_data), slab(cam_data)])).to(dev)
+    vols = torch.empty(3, S, H, W, dtype=torch.float32, device=dev)
+    L.call('hv_transpose_batched', ptr(hws), ptr(vols), 3, H * W, S, stream())
+    st = {'lab': vols[0], 'ct': vols[1], 'cam': vols[2],
+          'ratio': torch.tensor([abs(z - centre) / rng_len * 2 for z in zs], dtype=torch.float64, device=dev)}
     for nb, cond in ((vert_id - 1, vert_id > 8), (vert_id + 1, vert_id < 24)):
-        cnt = (lab_z[nz0:nz1 + 1] == nb).reshape(len(zs), -1).sum(axis=1) if cond else None
-        sel = [i for i in range(len(zs)) if cond and cnt[i] > 200]
-        if sel:
-            l2, c2, _ = _stage(model, cam_z, [labels[i] for i in sel], [cts[i] for i in sel], [zs[i] for i in sel],
-                               [ratios[i] for i in sel], nb, device, maxheight)
-            for j, i in enumerate(sel):
-                labels[i], cts[i] = l2[j], c2[j]
-    l3, c3, done = _stage(model, cam_z, labels, cts, zs, ratios, vert_id, device, maxheight)
-    for i in done:
-        out_seg[zs[i]], out_ct[zs[i]] = l3[i], c3[i]
-    return np.moveaxis(out_ct, 0, 2), np.moveaxis(out_seg, 0, 2)
+        if not cond:
+            continue
+        sel = (lab_hws == nb).sum(axis=(0, 1)) > 200          # on the ORIGINAL labels, like the reference (:208,:217)
+        if sel.any():
+            _stage_device(model, st, nb, torch.from_numpy(sel.astype(np.int32)).to(dev), maxheight)
+    valid = _stage_device(model, st, vert_id, None, maxheight)
+    res = torch.zeros(2, S, H * W, dtype=torch.float32, device=dev)
+    per = ctypes.c_longlong(H * W)
+    L.call('hv_select_slices', ptr(valid), ptr(st['ct']), ptr(res[0]), S, per, 0, stream())
+    L.call('hv_select_slices', ptr(valid), ptr(st['lab']), ptr(res[1]), S, per, 0, stream())
+    res_hws = torch.empty(2, H * W, S, dtype=torch.float32, device=dev)
+    L.call('hv_transpose_batched', ptr(res), ptr(res_hws), 2, S, H * W, stream())
+    res_hws = res_hws.cpu().numpy().reshape(2, H, W, S)
+    out_ct[:, :, nz0:nz1 + 1], out_seg[:, :, nz0:nz1 + 1] = res_hws[0], res_hws[1]
+    return out_ct, out_seg

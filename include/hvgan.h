@@ -307,6 +307,24 @@ typedef struct {
 int hv_assemble_batch(const hv_assemble_item* d_items, int B, int H, int W, float* A, float* Bimg, float* A_mask, float* mask,
                       float* normal_vert, float* CAM, void* stream);   /* d_items: DEVICE array of B descriptors */
 
+/* ---- slice preparation of the inference driver on the device (reference eval_3d_sagittal_twostage.py:15-30,46-98; 8f rows f1 / f2) ----
+ * hv_slice_components: per slice s of label [S][H][W]: 8-connected components of (label == value), components with fewer than min_size
+ * pixels dropped (remove_small_connected_components); stats[s] = {pixel count, first row, last row, sum of row indices} of what remains
+ * (count 0: first row -1).  workspace: hv_slice_components_workspace_bytes(S, H, W) bytes.
+ * hv_infer_prepare: from those stats the rows run_model works with (x1, x2, height; the 40-row window around the mean row when the vertebra
+ * is taller than maxheight) and the generator's four input planes [S][1][H][W]: ct_masked / cam = uint8-quantised slice re-stacked around the
+ * band [min_x, max_x), ori_ct = the quantised slice, mask = rows [min_x, max_x] -- ToTensor / Normalize applied.  ct / cam: [S][H][W] float32 in
+ * [0, 256).  selected (or NULL = all): slices this stage runs on.  valid[s] = vertebra present and selected; slices that are not valid get
+ * rows that keep the re-compositing in bounds (x1 = x2 = 0, height = H) and zero planes.
+ * hv_select_slices: dst[s] = flag[s] ? src[s] : (keep_unflagged ? dst[s] : 0)  -- slices without the vertebra pass a stage unchanged. */
+size_t hv_slice_components_workspace_bytes(int S, int H, int W);
+int hv_slice_components(const float* label, int S, int H, int W, float value, int min_size, int* stats, void* workspace,
+                        size_t workspace_bytes, void* stream);
+int hv_infer_prepare(const float* ct, const float* cam, const int* stats, const int* selected, int S, int H, int W, int maxheight,
+                     float* ct_masked, float* ori_ct, float* mask, float* cam_out, long long* x1, long long* x2, long long* height,
+                     int* valid, void* stream);
+int hv_select_slices(const int* flag, const float* src, float* dst, int S, long long per_slice, int keep_unflagged, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

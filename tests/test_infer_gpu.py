@@ -91,7 +91,11 @@ def test_stage_batched_volume_matches_sequential_oracle():
             r = oracle_run(cam255[:, :, z], l, c, vid, ratio)
             if r is not None:
                 l, c = r
-        assert np.abs(out_ct[:, :, z] - c).max() <= 0.6, np.abs(out_ct[:, :, z] - c).max()    # uint8 re-quantisation between stages
+        # a stage's float output is truncated to uint8 by the next stage: where the device and the CPU generator differ by 1e-3 across an
+        # integer the re-stacked pixel differs by exactly 1 -- a handful of pixels per slice, everything else within float rounding
+        dct = np.abs(out_ct[:, :, z] - c)
+        assert dct.max() <= 1.0 + 1e-3 and (dct > 0.6).mean() <= 1e-3, (dct.max(), (dct > 0.6).mean())
+        assert np.median(dct) <= 1e-3
         bad += (out_seg[:, :, z] != l).mean()
     assert bad / 3 <= 1e-3
 
@@ -153,3 +157,102 @@ def test_recomposite_matches_reference_run_model_outputs():
         assert np.abs(ctf[0].cpu().numpy().astype(np.float64) - exp['ct_fake']).max() <= 5e-5, name
         n += 1
     assert n >= 6
+
+
+def _blob_slices(seed, S, H, W, value):
+    """Label slices with assorted shapes: rectangles, diagonal chains (8- but not 4-connected), a spiral (long label chains), specks."""
+    import numpy as np
+    rng = np.random.RandomState(seed)
+    lab = np.zeros((S, H, W), dtype=np.float32)
+    for s in range(S):
+        for _ in range(rng.randint(1, 5)):
+            r, c, h, w = rng.randint(0, H - 30), rng.randint(0, W - 30), rng.randint(2, 30), rng.randint(2, 30)
+            lab[s, r:r + h, c:c + w] = value if rng.rand() < 0.7 else value + 1
+        for _ in range(6):
+            r, c = rng.randint(0, H - 2), rng.randint(0, W - 3)
+            lab[s, r:r + rng.randint(1, 3), c:c + rng.randint(1, 4)] = value          # specks
+        r, c = rng.randint(0, H - 70), rng.randint(0, W - 70)
+        for i in range(60):                                                           # diagonal chain, 60 pixels
+            lab[s, r + i, c + i] = value
+    # one spiral: a single component whose label has to travel ~1500 pixels
+    sp = np.zeros((H, W), dtype=np.float32)
+    r0, r1, c0, c1 = 10, H - 10, 10, W - 10
+    while r1 - r0 > 8 and c1 - c0 > 8:
+        sp[r0, c0:c1] = value; sp[r0:r1, c1 - 1] = value; sp[r1 - 1, c0 + 4:c1] = value; sp[r0 + 4:r1, c0 + 4] = value
+        sp[r0 + 4, c0 + 4:c0 + 9] = value
+        r0 += 8; c0 += 8; r1 -= 8; c1 -= 8
+    lab[0] = sp
+    lab[1] = 0                                                                        # empty slice
+    return lab
+
+
+def test_slice_components_match_scipy():
+    """hv_slice_components (device connected components + small-component filter + row statistics) against scipy.ndimage.label."""
+    import ctypes
+    import numpy as np
+    from scipy.ndimage import label as cc_label
+    import hvgan  # noqa: F401
+    from hvgan import lib
+    from hvgan.lib import ptr, stream
+    L = lib.get()
+    dev = torch.device('cuda:0')
+    for (S, H, W, seed) in ((6, 128, 96, 1), (5, 256, 256, 2)):
+        lab = _blob_slices(seed, S, H, W, 20.0)
+        d = torch.from_numpy(lab).to(dev)
+        need = L.size('hv_slice_components_workspace_bytes', S, H, W)
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        stats = torch.full((S, 4), -7, dtype=torch.int32, device=dev)
+        L.call('hv_slice_components', ptr(d), S, H, W, ctypes.c_float(20.0), 50, ptr(stats), ptr(ws), ctypes.c_size_t(need), stream())
+        got = stats.cpu().numpy()
+        for s in range(S):
+            m = (lab[s] == 20.0).astype(np.int32)
+            cl, n = cc_label(m, np.ones((3, 3), dtype=np.int32))
+            for i in range(1, n + 1):
+                if np.sum(cl == i) < 50:
+                    m[cl == i] = 0
+            rows = np.argwhere(m)[:, 0]
+            exp = [len(rows), rows.min() if len(rows) else -1, rows.max() if len(rows) else -1, rows.sum() if len(rows) else 0]
+            assert list(got[s]) == [int(v) for v in exp], (S, s, got[s], exp)
+
+
+def test_infer_prepare_matches_reference_network_inputs():
+    """hv_slice_components + hv_infer_prepare on the G10 slices as one batch: the generator's input planes equal what the reference's
+    run_model fed its network, bit for bit; rows / height / presence flags too."""
+    import ctypes
+    import numpy as np
+    import hvgan  # noqa: F401
+    from hvgan import lib
+    from hvgan.lib import ptr, stream
+    from oracle import restate as R
+    from test_oracle_golden import g10_cases
+    L = lib.get()
+    dev = torch.device('cuda:0')
+    cases = list(g10_cases())
+    S = len(cases)
+    H, W = cases[0][1].shape
+    vids = sorted({c[4] for c in cases})
+    for vid in vids:          # one stage = one vertebra id for all slices of the batch
+        f32 = lambda k: torch.from_numpy(np.stack([c[k] for c in cases]).astype(np.float32)).to(dev)
+        ct, lab, cam = f32(1), f32(2), f32(3)
+        need = L.size('hv_slice_components_workspace_bytes', S, H, W)
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        stats = torch.empty(S, 4, dtype=torch.int32, device=dev)
+        L.call('hv_slice_components', ptr(lab), S, H, W, ctypes.c_float(float(vid)), 50, ptr(stats), ptr(ws), ctypes.c_size_t(need), stream())
+        planes = torch.empty(4, S, 1, H, W, device=dev)
+        x1, x2, height = (torch.empty(S, dtype=torch.int64, device=dev) for _ in range(3))
+        valid = torch.empty(S, dtype=torch.int32, device=dev)
+        L.call('hv_infer_prepare', ptr(ct), ptr(cam), ptr(stats), None, S, H, W, 40, ptr(planes[0]), ptr(planes[1]), ptr(planes[2]), ptr(planes[3]),
+               ptr(x1), ptr(x2), ptr(height), ptr(valid), stream())
+        pl = planes.cpu()
+        for s, (name, c_ct, c_lab, c_cam, c_vid, ratio, model, exp) in enumerate(cases):
+            q = R.infer_prepare(c_cam, c_lab, c_ct, vid)           # oracle for THIS stage's vertebra id (the fixture pins the case's own id)
+            assert int(valid[s]) == (q is not None), (name, vid)
+            if q is None:
+                assert (int(x1[s]), int(x2[s]), int(height[s])) == (0, 0, H)
+                continue
+            assert (int(x1[s]), int(x2[s]), int(height[s])) == (q['x1'], q['x2'], q['height']), (name, vid)
+            assert torch.equal(pl[0, s], q['ct_batch']) and torch.equal(pl[1, s], q['ori_ct']), (name, vid)
+            assert torch.equal(pl[2, s], q['mask_batch']) and torch.equal(pl[3, s], q['cam']), (name, vid)
+            if c_vid == vid and exp is not None:
+                assert torch.equal(pl[0, s], R.to_tensor_u8(exp['in_ct'], True)) and torch.equal(pl[2, s], R.to_tensor_u8(exp['in_mask'], False))
+                assert torch.equal(pl[3, s], R.to_tensor_u8(exp['in_cam'], False)) and int(height[s]) == int(exp['height'][0])
