@@ -47,6 +47,7 @@ struct ConvK {
     int Cout, w_row, y_ld, y_coff, Ho, Wo;
     int bstep, boff, ostep;
     float alpha; int act, accumulate, vec_store, ncls;
+    int xcd_swizzle;   // remap blockIdx.x so that each of the 8 XCDs (round-robin over the linear workgroup id) owns a CONTIGUOUS range of pixel tiles
     const float* mul_src; int mul_ld, mul_coff, mul_act, mul_vec;   // epilogue factor act'(mul_src[..]) or NULL; mul_vec: 16-B loads are aligned
     ConvCls cls[4];
 };
@@ -131,14 +132,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
     __shared__ uint32_t taps_s[32];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bx = blockIdx.x;
+    if (p.xcd_swizzle) {   // every tap re-reads a tile's input rows through L2: neighbouring tiles (the same images) belong on the same XCD's L2
+        const int q = gridDim.x >> 3, r = gridDim.x & 7, xcd = bx & 7, loc = bx >> 3;
+        bx = xcd < r ? xcd * (q + 1) + loc : r * (q + 1) + (xcd - r) * q + loc;
+    }
     int ci = 0;
 #pragma unroll
     for (int i = 1; i < 4; ++i)
-        if (i < p.ncls && (int)blockIdx.x >= p.cls[i].m0) ci = i;
+        if (i < p.ncls && bx >= p.cls[i].m0) ci = i;
     const ConvCls& C = p.cls[ci];
     const int ntaps = C.ntaps, Ktot = C.Ktot, Hc = C.Hc, Wc = C.Wc, Mc = C.mcount, ph = C.ph, pw = C.pw;
     if (tid < ntaps) taps_s[tid] = C.taps[tid];
-    const int m_base = ((int)blockIdx.x - C.m0) * BM;
+    const int m_base = (bx - C.m0) * BM;
     const int n_base = blockIdx.y * BN;
     const int HWc = Hc * Wc;
 
@@ -324,6 +330,11 @@ static int dispatch_conv(ConvK& k, hipStream_t s) {
         mt += hv_cdiv(k.cls[c].mcount, BM);
     }
     if (mt <= 0) return HV_OK;
+    {   // XCD-contiguous tile ranges when the linear workgroup id modulo 8 is blockIdx.x modulo 8 (HV_XCD=0: A/B knob)
+        static const int xcd = getenv("HV_XCD") ? atoi(getenv("HV_XCD")) : 1;
+        const int gy = (k.Cout + BN - 1) / BN;
+        k.xcd_swizzle = (xcd && mt >= 64 && (gy == 1 || (mt & 7) == 0)) ? 1 : 0;
+    }
     if (BM == 256 && BN == 16) return launch_conv<T, 256, 16, 4, 1, ASC>(k, mt, s);
     if (BM == 64 && BN == 16) return launch_conv<T, 64, 16, 4, 1, ASC>(k, mt, s);
     if (BM == 256 && BN == 32) return launch_conv<T, 256, 32, 4, 1, ASC>(k, mt, s);

@@ -159,8 +159,10 @@ def conv2d(x, w, y, k, stride=1, pad=0, dil=1, bias=None, act='none', transposed
     if _TIMER is not None:
         taps = kh * kw if not transposed else max(1, (kh * kw) // (stride * stride))
         flops = 2.0 * y.B * y.H * y.W * d.Cout * taps * d.Cin
+        wbytes = (2 if (w_h is not None and d.precision == F16 and not w_bstride) else 4) * d.Cout * kh * kw * d.Cin * (x.B if w_bstride else 1)
+        nbytes = 4 * (x.B * x.H * x.W * d.Cin + y.B * y.H * y.W * d.Cout * (2 if accumulate else 1)) + wbytes + (4 * y.B * y.H * y.W * d.Cout if mul is not None else 0)
         _TIMER.wrap(('conv', x.B, d.H, d.W, d.Cin, d.Cout, kh, stride, dil, int(transposed)), flops,
-                    lambda: L.call('hv_conv2d', ctypes.byref(d), stream()))
+                    lambda: L.call('hv_conv2d', ctypes.byref(d), stream()), nbytes)
         return y
     L.call('hv_conv2d', ctypes.byref(d), stream())
     return y
@@ -191,8 +193,9 @@ def conv2d_wgrad(x, g, dw, k, stride=1, pad=0, dil=1, in_shift=0, accumulate=Fal
         d.workspace, d.workspace_bytes = ptr(b).value, b.numel()
     if _TIMER is not None:
         flops = 2.0 * g.B * g.H * g.W * d.Cout * kh * kw * d.Cin
+        nbytes = 4 * (x.B * x.H * x.W * d.Cin + g.B * g.H * g.W * d.Cout + d.Cout * kh * kw * d.Cin)     # x and g read once, dW written once
         _TIMER.wrap(('wgrad', x.B, d.H, d.W, d.Cin, d.Cout, kh, stride, dil, 0), flops,
-                    lambda: L.call('hv_conv2d_wgrad', ctypes.byref(d), stream()))
+                    lambda: L.call('hv_conv2d_wgrad', ctypes.byref(d), stream()), nbytes)
         return dw
     L.call('hv_conv2d_wgrad', ctypes.byref(d), stream())
     return dw

@@ -17,12 +17,14 @@ class KernelTimer:
     def __init__(self):
         self.records = []
         self.paths = {}
+        self.bytes = {}       # shape key -> algorithmic bytes per launch
         self.names = {}       # shape key -> kernel instantiation name as rocprofv3 prints it (hv_last_kernel_name)
         self.only = None      # set of shape keys to time, or None = all
         self.active = False
 
     # ---- hook called by ops.conv2d / ops.conv2d_wgrad around each launch
-    def wrap(self, key, flops, launch):
+    def wrap(self, key, flops, launch, nbytes=0):
+        self.bytes[key] = nbytes                            # algorithmic HBM bytes of one launch (each operand once)
         if not self.active or (self.only is not None and key not in self.only):
             return launch()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -84,10 +86,22 @@ class KernelTimer:
         achieved = flops / (ms * 1e-3) / 1e12
         shapes = [{'shape': describe(k, self.paths.get(k)), 'launches': agg[k][1], 'avg_us': round(agg[k][0] / agg[k][1] * 1e3, 2),
                    'tflops': round(agg[k][2] / (agg[k][0] / agg[k][1] * 1e-3) / 1e12, 1)} for k in sorted(keys, key=lambda k: -agg[k][0])]
-        return {'bound': 'mfma', 'kernel': name, 'achieved': round(achieved, 2), 'peak': peak_tflops, 'unit': 'TFLOP/s',
-                'frac': round(achieved / peak_tflops, 4), 'traffic': None, 'launches': n, 'avg_us': round(ms / n * 1e3, 2),
-                'gflop_per_launch': round(flops / n / 1e9, 3), 'shapes': shapes}
+        nbytes = sum(self.bytes.get(k, 0) * agg[k][1] for k in keys)          # algorithmic bytes over all launches of the instantiation
+        out = {'kernel': name, 'launches': n, 'avg_us': round(ms / n * 1e3, 2), 'gflop_per_launch': round(flops / n / 1e9, 3),
+               'algorithmic_mb_per_launch': round(nbytes / n / 1e6, 2), 'shapes': shapes, 'traffic': None}
+        # which roofline bounds it: arithmetic intensity against the ridge of the two peaks
+        ridge = peak_tflops * 1e12 / (HBM_PEAK_GBS * 1e9)
+        if nbytes and flops / nbytes < ridge:
+            gbs = nbytes / (ms * 1e-3) / 1e9
+            out.update(bound='hbm', achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(gbs / HBM_PEAK_GBS, 4),
+                       achieved_tflops=round(achieved, 2), flop_per_byte=round(flops / nbytes, 1), ridge_flop_per_byte=round(ridge, 1))
+        else:
+            out.update(bound='mfma', achieved=round(achieved, 2), peak=peak_tflops, unit='TFLOP/s', frac=round(achieved / peak_tflops, 4),
+                       flop_per_byte=round(flops / nbytes, 1) if nbytes else None, ridge_flop_per_byte=round(ridge, 1))
+        return out
 
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 KERNEL_NAMES = {0: 'conv_igemm_kernel', 1: 'narrow_fwd_kernel', 2: 'conv_halo_kernel', 3: 'conv_halo2_kernel', 4: 'thin1_fwd_kernel', 5: 'head_gemm_kernel', 10: 'wgrad_kernel',
                 11: 'wgrad_halo_kernel'}
