@@ -301,6 +301,25 @@ def test_conv_per_sample_filters_and_accumulate_modes():
     assert maxerr(from_act(ya), F.elu(base + F.conv2d(x, ws[0], None, padding=1))) <= 1e-4
 
 
+@pytest.mark.parametrize('prec,tol', [('fp32', 2e-4), ('fp16', 6e-3)])
+def test_conv_per_sample_paste_long_contraction(prec, tol):
+    """The attention paste shape class: conv_transpose2d(k4, s2, p1) with per-sample filters and a 4 x 1024-long contraction per parity class
+    against torch."""
+    from hvtest import to_act, from_act, dev, maxerr
+    from hvgan import ops
+    g = torch.Generator().manual_seed(8)
+    B, L, C = 2, 1024, 64
+    a = torch.rand(B, L, 32, 32, generator=g) / 8                       # attention scores [B, L, h, w]
+    raw = torch.randn(B, L, C, 4, 4, generator=g) / 4                   # raw 4x4 patches per sample (conv_transpose weights [L, C, 4, 4])
+    ref = torch.cat([F.conv_transpose2d(a[i:i + 1], raw[i], stride=2, padding=1) / 4. for i in range(B)])
+    # gather form: y[co] = sum_{tap, l} x[l] * w[co][tap][l]  ->  per-sample filters [C][16][L]
+    wt = raw.permute(0, 2, 3, 4, 1).reshape(B, C, 16, L).contiguous().to(dev())
+    ya = ops.Act.empty(B, 64, 64, C, dev())
+    ops.conv2d(to_act(a), wt, ya, 4, 2, 1, 1, transposed=True, alpha=0.25, w_bstride=C * 16 * L, precision=prec)
+    torch.cuda.synchronize()
+    assert maxerr(from_act(ya), ref) <= tol * max(1.0, ref.abs().max().item())
+
+
 def test_conv_rejects_bad_arguments():
     from hvtest import to_act, ohwi, dev
     from hvgan import ops
