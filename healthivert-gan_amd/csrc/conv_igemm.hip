@@ -319,7 +319,8 @@ static int dispatch_conv(ConvK& k, hipStream_t s) {
     }
     // (Attention paste -- per-sample filters, K = 4 taps x 1024 patches: every 64-pixel tile of a sample re-reads 1 MB of filters, 1.06 GB of
     // HBM fetches per launch = 8x the operands.  256-pixel tiles quarter the re-reads but leave one workgroup per CU: measured 212 us
-    // against 168 us, step +0.1 ms.  Not kept; a blocked attention kernel is the real fix.)
+    // against 168 us, step +0.1 ms; 128-pixel tiles: 174 us.  The fetches are served fast enough (MALL): the launch is bound by the gather's
+    // issue / latency structure, not by HBM.  Not kept; a blocked attention kernel is the real fix.)
     if (k.w_bs || k.scale_bs) {  // per-sample operands: a tile must stay inside one image
         for (int c = 0; c < k.ncls; ++c)
             if ((k.cls[c].Hc * k.cls[c].Wc) % BM) {
