@@ -6,6 +6,8 @@ reference's per-batch quirks stay per-rank) and the four networks' gradients are
 all-reduce each, issued on a side HIP stream so that D_k's reduction overlaps D_{k+1}'s forward/backward
 (SURVEY.md section 8e).  With no process group initialised every call is a no-op.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -18,7 +20,8 @@ class GradSync:
 
     @staticmethod
     def active():
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        # HV_DDP_FORCE=1: run the exchange even in a one-rank group (RCCL smoke test of the exact call sequence on a single GPU)
+        return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get('HV_DDP_FORCE') == '1')
 
     def reduce(self, flat):
         """Start averaging `flat` (a network's flat gradient buffer) across ranks."""
