@@ -259,6 +259,29 @@ def test_conv_single_output_channel_data_gradient(case, prec, tol):
     assert maxerr(from_act(dxa), ref + x.grad) <= 2 * tol * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize('case', [(16, 256, 256, 64, 2, 'lrelu'), (2, 37, 41, 32, 2, 'none'), (3, 20, 22, 16, 1, 'elu'), (2, 70, 50, 64, 2, 'lrelu')])
+def test_conv_one_channel_stem_mfma(case):
+    """1-channel image into 16..64 channels, 4x4 filter (PatchGAN stem), fp16 mode with the fp16 filter copy: the 16 taps are the contraction
+    of one 16x16x16 MFMA (stem1_mfma_kernel); against torch CPU fp32, incl. ragged row ends, bias, activation and accumulate."""
+    from hvtest import to_act, from_act, ohwi, dev, maxerr
+    from hvgan import ops, lib
+    B, H, W, Cout, s, act = case
+    g = torch.Generator().manual_seed(21)
+    x = torch.rand(B, 1, H, W, generator=g) * 2 - 1
+    w = torch.randn(Cout, 1, 4, 4, generator=g) / 4
+    b = torch.randn(Cout, generator=g) * 0.1
+    ref = _ref_act(F.conv2d(x, w, b, stride=s, padding=1), act)
+    wf = ohwi(w)
+    ya = ops.Act.empty(B, ref.shape[2], ref.shape[3], Cout, dev())
+    ops.conv2d(to_act(x), wf, ya, 4, s, 1, 1, bias=b.to(dev()), act=act, precision='fp16', w_h=wf.half())
+    assert (lib.get().cdll.hv_last_kernel_name() or b'').decode() == 'stem1_mfma_kernel'
+    torch.cuda.synchronize()
+    assert maxerr(from_act(ya), ref) <= 4e-3 * max(1.0, ref.abs().max().item())
+    ops.conv2d(to_act(x), wf, ya, 4, s, 1, 1, bias=b.to(dev()), act=act, accumulate=1, precision='fp16', w_h=wf.half())
+    torch.cuda.synchronize()
+    assert maxerr(from_act(ya), 2 * ref) <= 8e-3 * max(1.0, ref.abs().max().item())
+
+
 def test_conv_upsample_fused_and_transposed_conv_layer():
     """in_shift=1 == conv(F.interpolate(x, 2)); transposed=1 == F.conv_transpose2d (k4 s2 p1)."""
     from hvtest import to_act, from_act, ohwi, dev, maxerr
