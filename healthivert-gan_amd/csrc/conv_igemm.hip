@@ -34,6 +34,7 @@ size_t hv_wgrad_halo_workspace_bytes(const hv_wgrad_desc* d);                  /
 int hv_wgrad_halo(const hv_wgrad_desc* d, int* nslabs, hipStream_t s);
 int hv_conv2d_narrow(const hv_conv_desc* d, hipStream_t s);                     // conv_narrow.hip
 int hv_conv2d_thin_in(const hv_conv_desc* d, hipStream_t s);
+int hv_conv2d_stem5(const hv_conv_desc* d, hipStream_t s);
 int hv_conv2d_head(const hv_conv_desc* d, hipStream_t s);                       // conv_head.hip
 
 struct ConvCls {
@@ -376,6 +377,10 @@ extern "C" int hv_conv2d(const hv_conv_desc* d, void* stream) {
     }
     if (d->Cin <= 4 && !d->transposed && !d->mul_src) {   // image-like inputs: direct fp32 VALU kernel, output-write bound (conv_narrow.hip)
         const int rc = hv_conv2d_thin_in(d, (hipStream_t)stream);
+        if (rc != HV_ERR_UNSUPPORTED) return rc;
+    }
+    if (d->Cin == 4 && d->KH == 5 && d->precision == HV_F16 && d->w_f16) {   // 5x5 stems of the generators: (tap, channel) as one MFMA contraction
+        const int rc = hv_conv2d_stem5(d, (hipStream_t)stream);
         if (rc != HV_ERR_UNSUPPORTED) return rc;
     }
     if (d->precision == HV_F16 && d->w_f16) {   // halo-tiled fast path (conv_halo.hip) when the shape qualifies

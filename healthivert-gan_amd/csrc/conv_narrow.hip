@@ -208,6 +208,76 @@ __global__ __launch_bounds__(256) void stem1_mfma_kernel(const NarrowK p, const 
     }
 }
 
+// The generators' 5x5 stems (4 -> 16 channels at full resolution), fp16 mode: K = 25 taps x 4 channels = 100, flattened (tap, channel) and
+// padded to 128 = four v_mfma_f32_16x16x32_f16 per 16 pixels x 16 channels -- the halo-tiled kernel spends one quarter-filled 16-deep MFMA
+// per tap.  No LDS: lane (pixel, k-group) loads its two taps' 4-channel pixels (16 B each) straight from global memory, L1 serves the
+// 25-fold reuse; the lane's accumulators are four consecutive output channels of its pixel.  One workgroup = one output row.
+struct Stem5K {
+    const float* x; const _Float16* w; float* y;
+    int H, W, x_ld, x_coff, img_stride, y_ld, y_coff;
+    HvEpi epi;
+};
+__global__ __launch_bounds__(256) void stem5_mfma_kernel(const Stem5K p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
+    f16x8 wa[4];                                       // filters of channel n: k = 32j + 8g .. +7 of the (tap, ci) axis, zero past 100
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k0 = 32 * j + 8 * g;
+        f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (k0 + 8 <= 100) v = *reinterpret_cast<const f16x8*>(p.w + n * 100 + k0);
+        else if (k0 < 100) {
+            const f16x4 h = *reinterpret_cast<const f16x4*>(p.w + n * 100 + k0);
+            v = f16x8{h[0], h[1], h[2], h[3], 0, 0, 0, 0};
+        }
+        wa[j] = v;
+    }
+    const int row = blockIdx.x, b = row / p.H, oy = row - b * p.H;
+    const float* ximg = p.x + (long long)b * p.img_stride + p.x_coff;
+    for (int ox0 = wave * 16; ox0 < p.W; ox0 += 64) {
+        const int ox = ox0 + n;
+        float4 xv[4][2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int t = 8 * j + 2 * g + h;                     // tap index (25..31: padding)
+                const int r = t / 5, q = t - r * 5;
+                const int iy = oy - 2 + r, ix = ox - 2 + q;
+                const bool ok = t < 25 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                const float4 v = *reinterpret_cast<const float4*>(ximg + ((long long)(ok ? iy : 0) * p.W + (ok ? ix : 0)) * p.x_ld);
+                xv[j][h] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f16x8 xb = {(_Float16)xv[j][0].x, (_Float16)xv[j][0].y, (_Float16)xv[j][0].z, (_Float16)xv[j][0].w,
+                              (_Float16)xv[j][1].x, (_Float16)xv[j][1].y, (_Float16)xv[j][1].z, (_Float16)xv[j][1].w};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[j], xb, acc, 0, 0, 0);
+        }
+        if (ox < p.W) hv_conv_epilogue4(p.epi, acc, g * 4, p.y + ((long long)row * p.W + ox) * p.y_ld + p.y_coff, nullptr);
+    }
+}
+
+// 4 -> 16 channels, 5x5, stride 1, 'same' padding, fp16 filter copy [16][25][4]
+int hv_conv2d_stem5(const hv_conv_desc* d, hipStream_t s) {
+    static const int enabled = getenv("HV_STEM5") ? atoi(getenv("HV_STEM5")) : 1;   // A/B knob
+    if (!enabled || d->precision != HV_F16 || !d->w_f16 || d->transposed || d->in_shift || d->w_bstride || d->ch_scale || d->mul_src || d->dil != 1 ||
+        d->Cin != 4 || d->Cout != 16 || d->KH != 5 || d->KW != 5 || d->stride != 1 || d->pad != 2 || d->Ho != d->H || d->Wo != d->W)
+        return HV_ERR_UNSUPPORTED;
+    if ((d->x_ld & 3) || (d->x_coff & 3) || ((uintptr_t)d->x & 15) || ((uintptr_t)d->w_f16 & 7) || (long long)d->B * d->H >= (1ll << 31)) return HV_ERR_UNSUPPORTED;
+    Stem5K k;
+    k.x = d->x; k.w = reinterpret_cast<const _Float16*>(d->w_f16); k.y = d->y;
+    k.H = d->H; k.W = d->W; k.x_ld = d->x_ld; k.x_coff = d->x_coff; k.img_stride = d->H * d->W * d->x_ld; k.y_ld = d->y_ld; k.y_coff = d->y_coff;
+    k.epi.alpha = d->alpha; k.epi.act = d->act; k.epi.accumulate = d->accumulate; k.epi.Cout = 16; k.epi.bias = d->bias; k.epi.scale = nullptr;
+    k.epi.mul_act = 0; k.epi.mul_vec = 0;
+    k.epi.vec_store = ((d->y_ld & 3) == 0 && (d->y_coff & 3) == 0 && ((uintptr_t)d->y & 15) == 0) ? 1 : 0;
+    hv_path_note = 4;
+    HV_KNAME("stem5_mfma_kernel");
+    hipLaunchKernelGGL(stem5_mfma_kernel, dim3(d->B * d->H), dim3(256), 0, s, k);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+
 int hv_conv2d_narrow(const hv_conv_desc* d, hipStream_t s) {
     if (d->w_bstride || d->ch_scale || d->dil != 1 || d->stride > 2) return HV_ERR_UNSUPPORTED;
     NarrowK k;
