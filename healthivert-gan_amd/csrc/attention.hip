@@ -63,6 +63,45 @@ __global__ void ca_raw_kernel(const float* __restrict__ f, float* __restrict__ r
     }
 }
 
+extern "C" int hv_transpose_batched(const float* src, float* dst, int B, int R, int C, void* stream);
+
+// Both patch layouts from one LDS-staged tile (the element-wise kernels above pay 64-bit divisions per element and write one of the two
+// layouts 4 bytes at a 4-KB stride: 81 / 93 us for 38 / 134 MB).  One workgroup = 64 patch positions x 64 channels of one tap:
+// rows are read (and the [l][tap][c] copy written) 16 bytes per lane along the channels, the [c][tap][l] copy is written along l from
+// the transposed tile.  KS x KS taps, stride ST, pad 1 (3x3 / 1 on the down-sampled map, 4x4 / 2 on the full map).
+template <int KS, int ST>
+__global__ __launch_bounds__(256) void ca_patch_tile_kernel(const float* __restrict__ src, float* __restrict__ lt, float* __restrict__ tl,
+                                                            int Hs, int Ws, int w, int L, int C, int s_ld) {
+    __shared__ float tile[64][65];
+    constexpr int T = KS * KS;
+    const int t = threadIdx.x, l0 = blockIdx.x * 64, tap = blockIdx.y % T, c0 = (blockIdx.y / T) * 64;
+    const long long b = blockIdx.z;
+    const int dy = tap / KS - 1, dx = tap % KS - 1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int ll = (t >> 4) + 16 * k, l = l0 + ll, c = c0 + (t & 15) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (l < L && c < C) {
+            const int y = ST * (l / w) + dy, x = ST * (l % w) + dx;
+            if ((unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws) v = *reinterpret_cast<const float4*>(src + ((b * Hs + y) * Ws + x) * s_ld + c);
+            if (lt) *reinterpret_cast<float4*>(lt + ((b * L + l) * T + tap) * C + c) = v;
+        }
+        tile[ll][(t & 15) * 4 + 0] = v.x; tile[ll][(t & 15) * 4 + 1] = v.y; tile[ll][(t & 15) * 4 + 2] = v.z; tile[ll][(t & 15) * 4 + 3] = v.w;
+    }
+    __syncthreads();
+    if (!tl) return;
+    const int ll = t & 63;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int cc = (t >> 6) + 4 * k;
+        if (l0 + ll < L && c0 + cc < C) tl[((b * C + c0 + cc) * T + tap) * L + l0 + ll] = tile[ll][cc];
+    }
+}
+static bool ca_tile_ok(const float* src, int C, int s_ld, const float* lt) {
+    static const int enabled = getenv("HV_CA_TILE") ? atoi(getenv("HV_CA_TILE")) : 1;   // A/B knob
+    return enabled && (C & 3) == 0 && (s_ld & 3) == 0 && !((uintptr_t)src & 15) && !((uintptr_t)lt & 15);
+}
+
 extern "C" int hv_ca_patches(const float* f, int B, int H, int W, int C, int f_ld, float* fd, float* wp, float* wpT, float* norm,
                              float* rnorm, void* stream) {
     if (!f || !fd || !wp || !norm || !rnorm || B <= 0 || H <= 0 || W <= 0 || C <= 0 || ((H | W) & 1) || f_ld < C) return HV_ERR_ARG;
@@ -72,8 +111,15 @@ extern "C" int hv_ca_patches(const float* f, int B, int H, int W, int C, int f_l
     hipLaunchKernelGGL(ca_down_kernel, dim3(at_grid(n)), dim3(256), 0, s, f, fd, H, W, C, f_ld, n);
     HV_LAUNCH_CHECK();
     n *= 9;
-    hipLaunchKernelGGL(ca_wp_kernel, dim3(at_grid(n)), dim3(256), 0, s, fd, wp, wpT, h, w, C, n);
+    if (ca_tile_ok(fd, C, C, wp) && B <= 65535)    // wpT layout: [b][(tap, c)][l] -- as [c][tap][l] it would need c outermost: only wp here, wpT below
+        hipLaunchKernelGGL((ca_patch_tile_kernel<3, 1>), dim3(hv_cdiv(h * w, 64), 9 * hv_cdiv(C, 64), B), dim3(256), 0, s, fd, wp, (float*)nullptr, h, w, w, h * w, C, C);
+    else
+        hipLaunchKernelGGL(ca_wp_kernel, dim3(at_grid(n)), dim3(256), 0, s, fd, wp, (float*)nullptr, h, w, C, n);
     HV_LAUNCH_CHECK();
+    if (wpT) {   // [b][tap*C + c][l] = transpose of wp[b][l][tap*C + c]
+        const int rc = hv_transpose_batched(wp, wpT, B, h * w, 9 * C, stream);
+        if (rc != HV_OK) return rc;
+    }
     hipLaunchKernelGGL(ca_norm_kernel, dim3(B * h * w), dim3(64), 0, s, wp, norm, rnorm, 9 * C);
     HV_LAUNCH_CHECK();
     return HV_OK;
@@ -81,7 +127,11 @@ extern "C" int hv_ca_patches(const float* f, int B, int H, int W, int C, int f_l
 extern "C" int hv_ca_raw_patches(const float* f, int B, int H, int W, int C, int f_ld, float* raw, float* rawT, void* stream) {
     if (!f || (!raw && !rawT) || B <= 0 || H <= 0 || W <= 0 || C <= 0 || ((H | W) & 1) || f_ld < C) return HV_ERR_ARG;
     const long long n = (long long)B * C * 16 * (H / 2) * (W / 2);
-    hipLaunchKernelGGL(ca_raw_kernel, dim3(at_grid(n)), dim3(256), 0, (hipStream_t)stream, f, raw, rawT, H, W, C, f_ld, n);
+    if (ca_tile_ok(f, C, f_ld, raw) && B <= 65535)
+        hipLaunchKernelGGL((ca_patch_tile_kernel<4, 2>), dim3(hv_cdiv((H / 2) * (W / 2), 64), 16 * hv_cdiv(C, 64), B), dim3(256), 0, (hipStream_t)stream,
+                           f, raw, rawT, H, W, W / 2, (H / 2) * (W / 2), C, f_ld);
+    else
+        hipLaunchKernelGGL(ca_raw_kernel, dim3(at_grid(n)), dim3(256), 0, (hipStream_t)stream, f, raw, rawT, H, W, C, f_ld, n);
     HV_LAUNCH_CHECK();
     return HV_OK;
 }
@@ -194,6 +244,8 @@ __global__ __launch_bounds__(256) void ca_fuse_p2_kernel(const float* __restrict
         ob[i] = acc;
     }
 }
+// (A variant with the nine index maps tabulated in LDS -- nine table reads instead of ~150 integer instructions per element -- measured
+// 204 / 220 us against 109 / 117 us: the dependent LDS read in front of every global load costs more than the arithmetic.  Not kept.)
 static bool at_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 extern "C" int hv_ca_fuse(const float* S, float* out, int B, int h, int w, int adjoint, void* stream) {
     if (!S || !out || S == out || B <= 0 || h <= 0 || w <= 0) return HV_ERR_ARG;

@@ -320,18 +320,37 @@ __global__ __launch_bounds__(1024) void gan_loss_kernel(const float* __restrict_
                                                         float gw, float* __restrict__ dz) {
     __shared__ float red[20];
     float s = 0.f;
-    for (long long i = threadIdx.x; i < n; i += 1024) {
-        const float v = z[i];
-        float l, g;
-        if (mode == 0) {
-            l = fmaxf(v, 0.f) - v * t + log1pf(expf(-fabsf(v)));
-            g = 1.f / (1.f + expf(-v)) - t;
-        } else {
-            l = (v - t) * (v - t);
-            g = 2.f * (v - t);
+    auto term = [&](float v, float& g) {
+        if (mode == 0) {   // one exponential serves both: e = exp(-|v|); sigmoid(v) = 1/(1+e) or e/(1+e); softplus tail = log1p(e)
+            const float e = expf(-fabsf(v)), r = 1.f / (1.f + e);
+            g = (v >= 0.f ? r : e * r) - t;
+            return fmaxf(v, 0.f) - v * t + log1pf(e);
         }
-        s += l;
-        if (dz) dz[i] = gw * g / (float)n;
+        g = 2.f * (v - t);
+        return (v - t) * (v - t);
+    };
+    if (n <= 16 * 1024) {   // PatchGAN logits (B x 30 x 30): all of a lane's loads in flight at once -- the rolled loop below pays one
+        float v[16];        // memory round trip per 1024 elements (19 us for 14 400 logits); the summation order is the same
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const long long i = threadIdx.x + k * 1024;
+            v[k] = i < n ? z[i] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const long long i = threadIdx.x + k * 1024;
+            if (i < n) {
+                float g;
+                s += term(v[k], g);
+                if (dz) dz[i] = gw * g / (float)n;
+            }
+        }
+    } else {
+        for (long long i = threadIdx.x; i < n; i += 1024) {
+            float g;
+            s += term(z[i], g);
+            if (dz) dz[i] = gw * g / (float)n;
+        }
     }
     s = hv_block_sum(s, red);
     if (threadIdx.x == 0 && loss) {
@@ -345,6 +364,55 @@ extern "C" int hv_gan_loss(const float* z, long long n, int target_is_real, int 
     hipLaunchKernelGGL(gan_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, z, n, target_is_real ? 1.f : 0.f, mode, loss_weight, loss,
                        loss_accumulate, grad_weight, dz);
     HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+
+// The same over many workgroups (one CU evaluates the 14 400 logits' exp / log1p in ~19 us): 256 elements per workgroup, per-workgroup sums
+// to the caller's scratch, the last stage adds them in index order (deterministic).
+__global__ __launch_bounds__(256) void gan_loss_part_kernel(const float* __restrict__ z, long long n, float t, int mode, float gw, float* __restrict__ dz,
+                                                            float* __restrict__ part) {
+    __shared__ float red[20];
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    float l = 0.f;
+    if (i < n) {
+        const float v = z[i];
+        float g;
+        if (mode == 0) {
+            const float e = expf(-fabsf(v)), r = 1.f / (1.f + e);
+            g = (v >= 0.f ? r : e * r) - t;
+            l = fmaxf(v, 0.f) - v * t + log1pf(e);
+        } else {
+            g = 2.f * (v - t);
+            l = (v - t) * (v - t);
+        }
+        if (dz) dz[i] = gw * g / (float)n;
+    }
+    l = hv_block_sum(l, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = l;
+}
+__global__ __launch_bounds__(256) void gan_loss_final_kernel(const float* __restrict__ part, int nparts, long long n, float lw, float* loss, int lacc) {
+    __shared__ float red[20];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 256) s += part[i];
+    s = hv_block_sum(s, red);
+    if (threadIdx.x == 0) {
+        const float v = lw * s / (float)n;
+        loss[0] = lacc ? loss[0] + v : v;
+    }
+}
+extern "C" size_t hv_gan_loss_workspace_bytes(long long n) { return (size_t)((n + 255) / 256) * sizeof(float); }
+extern "C" int hv_gan_loss_ws(const float* z, long long n, int target_is_real, int mode, float loss_weight, float* loss, int loss_accumulate,
+                              float grad_weight, float* dz, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!z || n <= 0 || mode < 0 || mode > 1) return HV_ERR_ARG;
+    if (!workspace || workspace_bytes < hv_gan_loss_workspace_bytes(n) || ((uintptr_t)workspace & 3)) return HV_ERR_WORKSPACE;
+    const int nparts = (int)((n + 255) / 256);
+    float* part = reinterpret_cast<float*>(workspace);
+    hipLaunchKernelGGL(gan_loss_part_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, z, n, target_is_real ? 1.f : 0.f, mode, grad_weight, dz, part);
+    HV_LAUNCH_CHECK();
+    if (loss) {
+        hipLaunchKernelGGL(gan_loss_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, part, nparts, n, loss_weight, loss, loss_accumulate);
+        HV_LAUNCH_CHECK();
+    }
     return HV_OK;
 }
 
@@ -380,16 +448,32 @@ __global__ __launch_bounds__(256) void gloss_partial_kernel(const hv_gloss_desc 
     if (tid < GL_NQ) part[((long long)b * GL_CHUNKS + blockIdx.x) * GL_NQ + tid] = sh[0][tid] + sh[1][tid] + sh[2][tid] + sh[3][tid];
 }
 // coef layout (floats): [0] coefL1; [1+4b..] per sample {fine: A=(sp+sg+eps), T=(2tp+eps); coarse: A, T}
-__global__ void gloss_finalize_kernel(const hv_gloss_desc d, const double* __restrict__ part, float* __restrict__ coef) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// one workgroup: thread (b, k) sums quantity k of sample b over its GL_CHUNKS partials in a fixed order (was: one thread walking all
+// B*GL_CHUNKS*GL_NQ values from global memory, 72 us at B = 16); thread 0 then combines the samples in order as before -- same result.
+#define GL_MAXB 64
+__global__ __launch_bounds__(256) void gloss_finalize_kernel(const hv_gloss_desc d, const double* __restrict__ part, float* __restrict__ coef) {
+    __shared__ double qs[GL_MAXB][GL_NQ];
     const int B = d.B;
+    for (int b0 = 0; b0 < B; b0 += GL_MAXB) {       // (B <= GL_MAXB in practice: one pass)
+        __syncthreads();
+        for (int e = threadIdx.x; e < min(B - b0, GL_MAXB) * GL_NQ; e += 256) {
+            const int b = e / GL_NQ, k = e - b * GL_NQ;
+            double q = 0;
+            for (int c = 0; c < GL_CHUNKS; ++c) q += part[((long long)(b0 + b) * GL_CHUNKS + c) * GL_NQ + k];
+            qs[b][k] = q;
+        }
+        __syncthreads();
+        if (b0 + GL_MAXB < B && threadIdx.x == 0)     // spill the finished rows back (only for B > GL_MAXB)
+            for (int b = 0; b < GL_MAXB; ++b)
+                for (int k = 0; k < GL_NQ; ++k) const_cast<double*>(part)[((long long)(b0 + b) * GL_CHUNKS) * GL_NQ + k] = qs[b][k];
+    }
+    if (threadIdx.x != 0) return;
     const double N = (double)B * d.H * d.W, eps = 1e-5;
     double S1 = 0, S2 = 0, cnt = 0, E = 0, dice_f = 0, dice_c = 0;
+    const int last0 = ((B - 1) / GL_MAXB) * GL_MAXB;
     for (int b = 0; b < B; ++b) {
         double q[GL_NQ];
-        for (int k = 0; k < GL_NQ; ++k) q[k] = 0;
-        for (int c = 0; c < GL_CHUNKS; ++c)
-            for (int k = 0; k < GL_NQ; ++k) q[k] += part[((long long)b * GL_CHUNKS + c) * GL_NQ + k];
+        for (int k = 0; k < GL_NQ; ++k) q[k] = b >= last0 ? qs[b - last0][k] : part[((long long)b * GL_CHUNKS) * GL_NQ + k];
         S1 += q[0]; S2 += q[1]; cnt += q[2]; E += q[9];
         const double Af = q[4] + q[5] + eps, Tf = 2 * q[3] + eps, Ac = q[7] + q[8] + eps, Tc = 2 * q[6] + eps;
         dice_f += Tf / Af;
@@ -442,7 +526,7 @@ extern "C" int hv_generator_losses(const hv_gloss_desc* d, void* stream) {
     float* coef = (float*)((char*)d->workspace + (size_t)d->B * GL_CHUNKS * GL_NQ * sizeof(double));
     hipLaunchKernelGGL(gloss_partial_kernel, dim3(GL_CHUNKS, d->B), dim3(256), 0, s, *d, part);
     HV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gloss_finalize_kernel, dim3(1), dim3(64), 0, s, *d, part, coef);
+    hipLaunchKernelGGL(gloss_finalize_kernel, dim3(1), dim3(256), 0, s, *d, part, coef);
     HV_LAUNCH_CHECK();
     if (d->d_fake_B && d->d_fake_B_coarse && d->d_fine_seg && d->d_coarse_seg) {
         const long long n = (long long)d->B * d->H * d->W;

@@ -293,10 +293,20 @@ def sobel(img, out=None):
     return out
 
 
+GAN_LOSS_WS = os.environ.get('HV_GAN_LOSS_WS', '1') != '0'   # A/B knob
+
+
 def gan_loss(z, target_is_real, mode='vanilla', loss=None, loss_weight=1.0, loss_accumulate=False, dz=None, grad_weight=1.0):
     m = {'vanilla': 0, 'lsgan': 1}[mode]
-    _lib.get().call('hv_gan_loss', ptr(z), ctypes.c_longlong(z.numel()), int(bool(target_is_real)), m, ctypes.c_float(loss_weight),
-                    ptr(loss), int(loss_accumulate), ctypes.c_float(grad_weight), ptr(dz), stream())
+    L = _lib.get()
+    n = z.numel()
+    if n >= 4096 and GAN_LOSS_WS:      # many workgroups + per-stream scratch for their partial sums
+        b, nb = _ws(L.size('hv_gan_loss_workspace_bytes', ctypes.c_longlong(n)), z.device, slot=2)
+        L.call('hv_gan_loss_ws', ptr(z), ctypes.c_longlong(n), int(bool(target_is_real)), m, ctypes.c_float(loss_weight), ptr(loss),
+               int(loss_accumulate), ctypes.c_float(grad_weight), ptr(dz), ptr(b), nb, stream())
+        return
+    L.call('hv_gan_loss', ptr(z), ctypes.c_longlong(n), int(bool(target_is_real)), m, ctypes.c_float(loss_weight),
+           ptr(loss), int(loss_accumulate), ctypes.c_float(grad_weight), ptr(dz), stream())
 
 
 def adam_step(table, max_numel, lr_dev, beta1, beta2, eps, step_dev):
