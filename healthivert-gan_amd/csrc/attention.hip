@@ -273,6 +273,53 @@ __global__ __launch_bounds__(256) void ca_softmax_kernel(const float* __restrict
     const float* s = S + row * L;
     float* a = A + row * L;
     const int tid = threadIdx.x;
+    if (L <= 2048 && (L & 255) == 0) {   // the row fits the workgroup's registers: S is read once instead of three times
+        const int ept = L >> 8;
+        float v[8], m[8];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (k < ept) { m[k] = mm[tid + k * 256]; v[k] = s[tid + k * 256] * m[k] * scale; mx = fmaxf(mx, v[k]); }
+        mx = hv_wave_max(mx);
+        if ((tid & 63) == 0) red[tid >> 6] = mx;
+        __syncthreads();
+        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (k < ept) { v[k] = expf(v[k] - mx); sum += v[k]; }
+        sum = hv_wave_sum(sum);
+        __syncthreads();
+        if ((tid & 63) == 0) red[4 + (tid >> 6)] = sum;
+        __syncthreads();
+        sum = red[4] + red[5] + red[6] + red[7];
+        float best = -1.f;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (k < ept) {
+                const float o = v[k] / sum * m[k];
+                a[tid + k * 256] = o;
+                if (o > best) { best = o; bi = tid + k * 256; }
+            }
+        if (argmax) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ob = __shfl_xor(best, o, 64);
+                const int oi = __shfl_xor(bi, o, 64);
+                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            }
+            __syncthreads();
+            if ((tid & 63) == 0) { red[tid >> 6] = best; redi[tid >> 6] = bi; }
+            __syncthreads();
+            if (tid == 0) {
+                for (int k = 1; k < 4; ++k)
+                    if (red[k] > best || (red[k] == best && redi[k] < bi)) { best = red[k]; bi = redi[k]; }
+                argmax[row] = bi;
+            }
+        }
+        return;
+    }
     float mx = -3.0e38f;
     for (int l = tid; l < L; l += 256) mx = fmaxf(mx, s[l] * mm[l] * scale);
     mx = hv_wave_max(mx);
