@@ -194,3 +194,31 @@ def test_graph_recapture_when_the_batch_shape_changes(monkeypatch):
     for k in we:
         assert torch.equal(we[k], wg[k]), k
     assert le == lg
+
+
+def test_step_at_512_matches_live_oracle(monkeypatch):
+    """BASELINE config #5's slice size: one full train step at 512 x 512 (attention over 128 x 128 patches, L = 4096; 62 x 62 PatchGAN logits)
+    from seeded weights against the CPU oracle on the same weights and batch -- nothing in the kernels or the host mirror is tied to 256."""
+    monkeypatch.setenv('HV_PRECISION', 'fp32')
+    import hvgan
+    from hvgan import synth
+    from hvgan.models.pix2pix_model import Pix2PixModel
+    from oracle import restate as R
+    torch.manual_seed(99)
+    model = Pix2PixModel(make_opt())
+    sd_g = {k: v.detach().cpu().clone() for k, v in model.netG.state_dict().items()}
+    sd_d = [{k: v.detach().cpu().clone() for k, v in getattr(model, 'netD_%d' % k).state_dict().items()} for k in (1, 2, 3)]
+    raw = synth.make_batch(2, 512, seed=31)
+    model.set_input(raw)
+    model.optimize_parameters()
+    torch.cuda.synchronize()
+    st = R.StepState(sd_g, sd_d, lr=2e-4, beta1=0.5, norm='batch', gan_mode='vanilla', lambda_l1=200.0)
+    losses, outs = R.pix2pix_step(st, synth.to_model_inputs(raw))
+    got = model.get_current_losses()
+    for k, ref in losses.items():
+        assert abs(got[k] - ref) <= 2e-3 * max(1.0, abs(ref)), (k, got[k], ref)
+    for name in ('fake_B', 'fake_B_coarse', 'x_stage1'):
+        a, b = getattr(model, name).detach().cpu(), outs[name].detach()
+        assert a.shape == b.shape == (2, 1, 512, 512)
+        frac = ((a - b).abs() > 1e-3).float().mean().item()
+        assert frac <= 1e-3, (name, (a - b).abs().max().item(), frac)
