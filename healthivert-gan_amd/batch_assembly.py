@@ -82,9 +82,15 @@ class VertebraVolume:
             self._info[z] = info
         return info
 
-    def weighted_random_slice(self):
-        """aligned_dataset.py:100-124 (one np.random.choice per call)."""
-        if self._choice is None:      # the weights depend on (z0, z1) only; the draw itself stays one np.random.choice call per attempt
+    def prefilter(self):
+        """Run the component filter on every slice the weighted draw can return (the central 4/5 of the z-extent)."""
+        self.weighted_random_slice_range()
+        for z in self._choice[0]:
+            self.slice_info(z)
+
+    def weighted_random_slice_range(self):
+        """(candidate slices, their probabilities, centre, z-extent) of aligned_dataset.py:100-121; depends on (z0, z1) only."""
+        if self._choice is None:
             z0, z1 = self.z0, self.z1
             range_length = z1 - z0 + 1
             new_range_length = int(range_length * 4 / 5)
@@ -94,7 +100,11 @@ class VertebraVolume:
             weights = [1 - abs(i - center) / (new_z1 - new_z0) for i in range(new_z0, new_z1 + 1)]
             total = sum(weights)
             self._choice = (range(new_z0, new_z1 + 1), [w / total for w in weights], center, range_length)
-        rng, p, center, range_length = self._choice
+        return self._choice
+
+    def weighted_random_slice(self):
+        """aligned_dataset.py:100-124 (one np.random.choice per call)."""
+        rng, p, center, range_length = self.weighted_random_slice_range()
         idx = int(np.random.choice(rng, p=p))
         return idx, abs(idx - center) / range_length * 2
 
@@ -125,6 +135,7 @@ class DeviceBatchAssembler:
         (self.H, self.W), = shapes
         self._planes = []         # per volume: uint8 tensor [4][Z][H][W] = ct, vert, normal, cam
         for v in self.volumes:
+            v.prefilter()         # component-filter every slice a draw can reach BEFORE the upload: no blocking plane refresh in the training loop
             host = torch.from_numpy(np.stack([v.ct, v.vert, v.normal, v.cam]))
             self._planes.append(host.to(self.device))
             v.dirty.clear()
@@ -132,6 +143,14 @@ class DeviceBatchAssembler:
 
     def __len__(self):
         return len(self.volumes)
+
+    def _pinned(self, nbytes):
+        """Next buffer of a small ring of pinned staging buffers (a buffer is reused only four batches later, long after its copy ran)."""
+        self._ring_i = (getattr(self, '_ring_i', -1) + 1) % 4
+        ring = self.__dict__.setdefault('_ring', [None] * 4)
+        if ring[self._ring_i] is None or ring[self._ring_i].numel() < nbytes:
+            ring[self._ring_i] = torch.empty(max(nbytes, 4096), dtype=torch.uint8).pin_memory()
+        return ring[self._ring_i]
 
     def _sync_filtered(self, i):
         v = self.volumes[i]
@@ -159,16 +178,27 @@ class DeviceBatchAssembler:
             it.x1, it.x2, it.min_x, it.max_x = x1, x2, min_x, max_x
             for k, val in (('height', x2 - x1), ('x1', x1), ('x2', x2), ('h2', v.maxheight), ('slice_ratio', ratio), ('slice', z)):
                 meta[k].append(val)
-        d_items = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(self.device)
+        # one packed, pinned upload per batch (descriptor table + integer / float64 metadata): a pageable H2D copy would block the host until the
+        # previous step's kernels have drained, and the host-side slice draws of this batch would no longer overlap them
+        isz = ctypes.sizeof(L.hv_assemble_item) * B
+        total = isz + 5 * 8 * B
+        pin = self._pinned(total)
+        pin[:isz] = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8)
+        pin[isz:isz + 32 * B].view(torch.int64).copy_(torch.tensor([meta[k] for k in ('height', 'x1', 'x2', 'h2')], dtype=torch.int64).reshape(-1))
+        pin[isz + 32 * B:total].view(torch.float64).copy_(torch.tensor(meta['slice_ratio'], dtype=torch.float64))
+        dev = torch.empty(total, dtype=torch.uint8, device=self.device)
+        dev.copy_(pin[:total], non_blocking=True)
+        d_items = dev[:isz]
         out = torch.empty(6, B, 1, H, W, dtype=torch.float32, device=self.device)
         L.call('hv_assemble_batch', ctypes.cast(ptr(d_items), ctypes.POINTER(L.hv_assemble_item)), B, H, W,
                *(ptr(out[k]) for k in range(6)), stream())
         batch = {k: out[n] for n, k in enumerate(self.IMAGE_KEYS)}
-        for k in ('height', 'x1', 'x2', 'h2'):
-            batch[k] = torch.tensor(meta[k], dtype=torch.int64)
-        batch['slice_ratio'] = torch.tensor(meta['slice_ratio'], dtype=torch.float64)
+        ints = dev[isz:isz + 32 * B].view(torch.int64).view(4, B)
+        for n, k in enumerate(('height', 'x1', 'x2', 'h2')):
+            batch[k] = ints[n]
+        batch['slice_ratio'] = dev[isz + 32 * B:total].view(torch.float64)
         batch['slice'] = meta['slice']
         batch['A_paths'] = [self.volumes[i].path for i in indices]
         batch['B_paths'] = list(batch['A_paths'])
-        self._keep = d_items     # the descriptor table must outlive the asynchronous launch
+        self._keep = dev         # the descriptor table must outlive the asynchronous launch
         return batch
