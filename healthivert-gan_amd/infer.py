@@ -123,6 +123,16 @@ def prepare_slice(cam2d, label2d, ct2d, vert_id, maxheight=40):
     return dict(ct_masked=f(ct_masked, True), ori_ct=f(ct_u8, True), mask=f(mask, False), cam=f(cam, False), x1=x1, x2=x2, height=height)
 
 
+_PIN = {}
+
+
+def _pinned_f32(n):
+    b = _PIN.get('buf')
+    if b is None or b.numel() < n:
+        b = _PIN['buf'] = torch.empty(n, dtype=torch.float32).pin_memory()
+    return b[:n]
+
+
 def _stage_device(model, st, vert_id, selected, maxheight):
     """One synthesis stage with the slices resident on the device (st: lab / ct / cam [S,H,W] fp32, ratio [S] fp64): component filter and
     row statistics (hv_slice_components), the generator's input planes (hv_infer_prepare), the batched generator + re-compositing, and
@@ -173,9 +183,12 @@ def process_volume(model, ct_data, label_data, cam_data, vert_id, device, maxhei
     if S == 0:
         return out_ct, out_seg
     # the [H, W, Z] inputs have z fastest: the z-range is cut out as it lies (float32, [H*W][S]) and transposed to slices on the device
-    slab = lambda vol: np.ascontiguousarray(vol[:, :, nz0:nz1 + 1], dtype=np.float32)
-    lab_hws = slab(label_data)
-    hws = torch.from_numpy(np.stack([lab_hws, slab(ct_data), slab(cam_data)])).to(dev)
+    stage = _pinned_f32(3 * H * W * S).view(3, H, W, S)          # one pinned staging buffer: no intermediate copies, asynchronous upload
+    stage_np = stage.numpy()
+    for i, vol in enumerate((label_data, ct_data, cam_data)):
+        np.copyto(stage_np[i], vol[:, :, nz0:nz1 + 1], casting='unsafe')
+    lab_hws = stage_np[0]
+    hws = stage.to(dev, non_blocking=True)
     vols = torch.empty(3, S, H, W, dtype=torch.float32, device=dev)
     L.call('hv_transpose_batched', ptr(hws), ptr(vols), 3, H * W, S, stream())
     st = {'lab': vols[0], 'ct': vols[1], 'cam': vols[2],
