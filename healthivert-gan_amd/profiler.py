@@ -29,16 +29,11 @@ class KernelTimer:
             return launch()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         L = _lib.get().cdll
-        if key[0] == 'wgrad':
-            # two kernels per call (main kernel + slab reduction): the C side records the events around the main kernel only, so the
-            # duration is that of the kernel rocprofv3 lists under the same name
-            s.record(); e.record()          # create the underlying hipEvents
-            L.hv_set_kernel_timing(ctypes.c_void_p(s.cuda_event), ctypes.c_void_p(e.cuda_event))
-            r = launch()
-        else:
-            s.record()
-            r = launch()
-            e.record()
+        # the C side records the two events right around the kernel launch (for a weight gradient: around the main kernel only, not its slab
+        # reduction), so the duration is that of the kernel rocprofv3 lists under the same name and no host latency sits between the records
+        s.record(); e.record()          # create the underlying hipEvents
+        L.hv_set_kernel_timing(ctypes.c_void_p(s.cuda_event), ctypes.c_void_p(e.cuda_event))
+        r = launch()
         self.paths[key] = L.hv_last_kernel_path()          # which kernel family the C side dispatched to
         self.names[key] = (L.hv_last_kernel_name() or b'').decode()
         self.records.append((key, flops, s, e))

@@ -44,8 +44,8 @@ int hv_last_kernel_path(void);
 /* name of that kernel instantiation as rocprofv3 prints it, e.g. "conv_halo2_kernel<8, 16, 128, 1, 4, 32, 1, 4, 4>" (the gather and weight-
  * gradient kernels are templated on _Float16, which rocprofv3 leaves mangled: _Z12wgrad_kernelIDF16_Li128E... = wgrad_kernel<_Float16, 128, ...>) */
 const char* hv_last_kernel_name(void);
-/* profiling: the calling thread's NEXT hv_conv2d_wgrad records these two hipEvent_t right around its main kernel (the slab reduction that
- * follows is a separate kernel); the pair is consumed by that call.  NULL, NULL cancels. */
+/* profiling: the calling thread's NEXT hv_conv2d or hv_conv2d_wgrad records these two hipEvent_t right around its kernel launch (for a weight
+ * gradient: around the main kernel; the slab reduction that follows is a separate kernel); the pair is consumed by that call.  NULL, NULL cancels. */
 int hv_set_kernel_timing(void* ev_start, void* ev_stop);
 
 /* ---------------------------------------------------------------- convolution (implicit GEMM on MFMA)
