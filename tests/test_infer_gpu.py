@@ -256,3 +256,31 @@ def test_infer_prepare_matches_reference_network_inputs():
             if c_vid == vid and exp is not None:
                 assert torch.equal(pl[0, s], R.to_tensor_u8(exp['in_ct'], True)) and torch.equal(pl[2, s], R.to_tensor_u8(exp['in_mask'], False))
                 assert torch.equal(pl[3, s], R.to_tensor_u8(exp['in_cam'], False)) and int(height[s]) == int(exp['height'][0])
+
+
+def test_slice_kernels_reject_bad_arguments_and_select_semantics():
+    """Error convention of the slice-preparation entry points (no exception across the ABI, negative status) and hv_select_slices' two modes."""
+    import ctypes
+    import hvgan  # noqa: F401
+    from hvgan import lib
+    from hvgan.lib import ptr, stream
+    L = lib.get()
+    dev = torch.device('cuda:0')
+    lab = torch.zeros(2, 16, 16, device=dev)
+    stats = torch.zeros(2, 4, dtype=torch.int32, device=dev)
+    ws = torch.empty(64, dtype=torch.uint8, device=dev)                     # far too small
+    rc = L.cdll.hv_slice_components(ptr(lab), 2, 16, 16, ctypes.c_float(1.0), 50, ptr(stats), ptr(ws), ctypes.c_size_t(64), stream())
+    assert rc == -3                                                         # HV_ERR_WORKSPACE
+    assert L.cdll.hv_slice_components(None, 2, 16, 16, ctypes.c_float(1.0), 50, ptr(stats), ptr(ws), ctypes.c_size_t(64), stream()) == -1
+    with pytest.raises(RuntimeError, match='HV_ERR_WORKSPACE'):
+        L.call('hv_slice_components', ptr(lab), 2, 16, 16, ctypes.c_float(1.0), 50, ptr(stats), ptr(ws), ctypes.c_size_t(64), stream())
+    src = torch.arange(3 * 8, dtype=torch.float32, device=dev).view(3, 8)
+    flag = torch.tensor([1, 0, 1], dtype=torch.int32, device=dev)
+    keep = torch.full((3, 8), -1.0, device=dev)
+    L.call('hv_select_slices', ptr(flag), ptr(src), ptr(keep), 3, ctypes.c_longlong(8), 1, stream())
+    zero = torch.full((3, 8), -1.0, device=dev)
+    L.call('hv_select_slices', ptr(flag), ptr(src), ptr(zero), 3, ctypes.c_longlong(8), 0, stream())
+    torch.cuda.synchronize()
+    assert torch.equal(keep[0], src[0]) and torch.equal(keep[2], src[2]) and bool((keep[1] == -1).all())
+    assert torch.equal(zero[0], src[0]) and bool((zero[1] == 0).all())
+    assert L.cdll.hv_select_slices(ptr(flag), ptr(src), ptr(zero), 0, ctypes.c_longlong(8), 0, stream()) == -1
