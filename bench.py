@@ -1,26 +1,36 @@
 #!/usr/bin/env python
 """bench.py -- sagittal slices/sec of one full HealthiVert-GAN train step (G + 3xD) at 256x256, per-GPU bs=16.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU over RCCL.  Launched by `python -m torch.distributed.run` (the driver's form) the ranks are
+already there; from a plain shell this script starts them itself -- as CHILD processes, before anything in the parent
+has touched the GPU -- and exits with their status.  A run whose rank count differs from --gpus exits non-zero.
 
 One "step" = Pix2PixModel.optimize_parameters on one synthetic batch already resident in HBM: generator forward,
 three discriminator updates (fake + real pass each, Adam), generator backward through D_1/D_3 + losses, Adam.
 Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel, measured live with HIP
-events on the launch stream) and `cpu_baseline` (the CPU oracle timed on this box's host cores, rank 0, N=1 only).
+events on the launch stream), `fine_generator_forward` (the north-star's secondary gate), `inference` (BASELINE
+config #4) and `cpu_baseline` (the CPU oracle timed on this box's host cores, rank 0, N=1 only).
+
+    python bench.py --gpus 2 --dry-run      # CPU-only rehearsal of the multi-rank plumbing (gloo): launcher, rendezvous,
+                                            # flat-gradient exchange of the real networks' sizes, MAX-over-ranks clock
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from argparse import Namespace
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 GFLOP_PER_SLICE = 195.9          # SURVEY.md section 8d / BASELINE.md section 2: whole train step, per slice
+GFLOP_FINE_FWD = 10.23           # FineGenerator forward per slice, the north-star's MFMA gate
+GFLOP_G_FWD = 17.56              # whole Generator forward per slice
 MFMA_PEAK_TFLOPS = {'fp16': 2500.0, 'fp32': 157.3}   # MI355X dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -32,24 +42,7 @@ def make_opt(precision):
                      epoch='latest', verbose=False, hv_precision=precision)
 
 
-def cpu_baseline(model, batch_size, size, seed):
-    """The CPU oracle (oracle/restate.py, kind 'port') on the same weights and the same synthetic batch: ONE full
-    train step at the bench batch size (bounded sample: ~20-30 s of CPU work)."""
-    from hvgan import synth
-    from oracle import restate as R
-    sd_g = {k: v.detach().cpu() for k, v in model.netG.state_dict().items()}
-    sd_d = [{k: v.detach().cpu() for k, v in getattr(model, 'netD_%d' % k).state_dict().items()} for k in (1, 2, 3)]
-    st = R.StepState(sd_g, sd_d, lr=2e-4, beta1=0.5, norm='batch', gan_mode='vanilla', lambda_l1=200.0)
-    batch = synth.to_model_inputs(synth.make_batch(batch_size, size, seed=seed))
-    t0 = time.time()
-    R.pix2pix_step(st, batch)
-    dt = time.time() - t0
-    return dict(value=batch_size / dt, unit='slices/s', cores=torch.get_num_threads(), kind='port',
-                sample='1 full train step (G + 3xD) at bs=%d, %dx%d, fp32, CPU oracle oracle/restate.py' % (batch_size, size, size),
-                seconds=round(dt, 2))
-
-
-def main():
+def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
@@ -58,33 +51,167 @@ def main():
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--precision', default=os.environ.get('HV_PRECISION', 'fp16'), choices=['fp16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-inference', action='store_true', help='skip the config-#4 inference sub-record')
     ap.add_argument('--serial', action='store_true', help='one HIP stream for the whole run (profiling: per-kernel durations without stream-level overlap)')
-    ap.add_argument('--no-graph', action='store_true', help='launch kernels eagerly instead of replaying a captured hipGraph')
-    args = ap.parse_args()
+    ap.add_argument('--no-graph', action='store_true', help='launch kernels eagerly instead of replaying captured hipGraphs')
+    ap.add_argument('--dry-run', action='store_true', help='CPU-only rehearsal of the multi-rank path over gloo (no GPU, no kernels)')
+    return ap.parse_args()
 
+
+def launch_ranks(args):
+    """Plain `python bench.py --gpus N`: start the N ranks as children through torch.distributed.run and hand back their
+    exit status.  Nothing in this (parent) process has initialised the GPU, and it never does."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(args, rank, world):
+    """The multi-rank path without a GPU: gloo process group, the four networks built on the host (so the flat gradient buffers
+    have the real sizes: G 3.95 MB, each D 11.05 MB), K exchange rounds through ddp.GradSync with a check of the mean, and the
+    same barrier / MAX-over-ranks clock as the real run.  Prints a JSON line marked dry_run (not a performance number)."""
+    import torch
+    import torch.distributed as dist
+    import hvgan  # noqa: F401
+    from hvgan import ddp
+    from hvgan.models import networks
+    from hvgan.models.inpaint_networks import Generator
+    if world > 1:
+        os.environ['HV_DDP_BACKEND'] = 'gloo'
+        ddp.init_from_env()
+    torch.manual_seed(1234)
+    nets = [Generator({'input_dim': 1, 'ngf': 16}, True)] + [networks.define_D(1, 64, 'basic', 3, 'batch', 'normal', 0.02, []) for _ in range(3)]
+    flats = [torch.zeros(sum(p.numel() for p in n.parameters() if p.requires_grad)) for n in nets]
+    gs = ddp.GradSync()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+    for it in range(args.warmup + args.steps):
+        if it == args.warmup:
+            barrier()
+            t0 = time.perf_counter()
+        for i, f in enumerate(flats):
+            f.fill_(float(rank + 1) * (i + 1))
+            gs.reduce(f)
+            want = (i + 1) * (world + 1) / 2.0          # mean over ranks of (rank+1)*(i+1)
+            assert abs(float(f[0]) - want) < 1e-6 and abs(float(f[-1]) - want) < 1e-6, (float(f[0]), want)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        print(json.dumps({'metric': 'dry-run gradient exchange rounds/sec (gloo, CPU; plumbing rehearsal, not a benchmark)',
+                          'value': round(args.steps / dt, 2), 'unit': 'rounds/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                          'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+                          'dtype': 'f32', 'data': 'synthetic', 'dry_run': True,
+                          'config': {'workload': 'flat-gradient mean of G + 3xD over %d gloo ranks' % world,
+                                     'bytes_per_round': int(sum(f.numel() for f in flats) * 4)}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(model, size, seed, batch_size=4, warm=1, timed=3):
+    """The CPU oracle (oracle/restate.py, kind 'port') on the same weights: `warm` untimed + `timed` timed full train steps at a
+    bounded batch size (about 10-30 s of CPU work in all; slices/s of the CPU step depends little on the batch size: BASELINE.md
+    section 3 measured 0.71 at bs=2 and 0.82 at bs=16 on 8 cores)."""
+    import torch
+    from hvgan import synth
+    from oracle import restate as R
+    sd_g = {k: v.detach().cpu() for k, v in model.netG.state_dict().items()}
+    sd_d = [{k: v.detach().cpu() for k, v in getattr(model, 'netD_%d' % k).state_dict().items()} for k in (1, 2, 3)]
+    st = R.StepState(sd_g, sd_d, lr=2e-4, beta1=0.5, norm='batch', gan_mode='vanilla', lambda_l1=200.0)
+    times = []
+    for i in range(warm + timed):
+        batch = synth.to_model_inputs(synth.make_batch(batch_size, size, seed=seed + i))
+        t0 = time.time()
+        R.pix2pix_step(st, batch)
+        if i >= warm:
+            times.append(time.time() - t0)
+    dt = sum(times) / len(times)
+    return dict(value=round(batch_size / dt, 3), unit='slices/s', cores=torch.get_num_threads(), kind='port',
+                sample='%d warm-up + %d timed full train steps (G + 3xD) at bs=%d, %dx%d, fp32, CPU oracle oracle/restate.py'
+                       % (warm, timed, batch_size, size, size),
+                seconds_per_step=[round(t, 2) for t in times], gflops=round(GFLOP_PER_SLICE * batch_size / dt, 1))
+
+
+def inference_record(dev, precision):
+    """BASELINE config #4: the three chained synthesis stages of one straightened 256x256x64 volume (infer.process_volume, host
+    pre/post-processing and PCIe copies included), eval-mode generator with random-init weights, synthetic volume."""
+    import torch
+    from hvgan import synth, infer
+    from hvgan.models.inpaint_networks import Generator
+    torch.manual_seed(0)
+    net = Generator({'input_dim': 1, 'ngf': 16}, True)
+    net.fine_generator.fc_height.bias.data.fill_(0.4)        # plausible heights from untrained weights
+    net.fine_generator.fc_height.weight.data.mul_(1e-2)
+    net.to(dev).eval()
+    net.precision = precision
+    ct, label, cam = synth.make_volume(nz=64, size=256, seed=2)
+    for _ in range(2):
+        infer.process_volume(net, ct, label, cam * 255, 20, dev)
+    torch.cuda.synchronize()
+    n, t0 = 5, time.perf_counter()
+    for _ in range(n):
+        out_ct, out_seg = infer.process_volume(net, ct, label, cam * 255, 20, dev)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    nz = int((out_seg.reshape(-1, out_seg.shape[2]) != 0).any(axis=0).sum())
+    # the bare stage batch: eval forward of the generator on one batch of that many slices (HIP events, inputs resident)
+    bb = synth.to_model_inputs(synth.make_batch(max(nz, 1), 256, seed=3))
+    a = [bb['real_A'].to(dev), bb['mask'].to(dev), (1 - bb['CAM']).to(dev), bb['slice_ratio'].to(dev)]
+    for _ in range(2):
+        net.run_forward(*a, training=False, per_sample_mask=True)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        net.run_forward(*a, training=False, per_sample_mask=True)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    return {'workload': 'eval_3d_sagittal_twostage: 256x256x64 synthetic volume, upper -> lower -> target synthesis, each stage one batched launch',
+            'ms_per_volume': round(dt * 1e3, 2), 'volumes_per_s': round(1.0 / dt, 2), 'slices_with_output': nz,
+            'slice_stages_per_s': round(3 * nz / dt, 1), 'stage_batch_forward_ms': round(ms, 3),
+            'stage_batch_slices_per_s': round(max(nz, 1) / ms * 1e3, 1),
+            'stage_batch_tflops': round(GFLOP_G_FWD * max(nz, 1) / ms, 1), 'includes': 'host slicing, PCIe in/out, device preparation, 3 generator stages'}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))           # parent: spawn the ranks, never touch the GPU
+    if args.gpus != world:
+        raise SystemExit('bench.py: --gpus %d but %d rank(s) are running (WORLD_SIZE)' % (args.gpus, world))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    if args.gpus != world and world > 1:
-        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    if args.dry_run:
+        return dry_run(args, rank, world)
+
+    import torch
+    import torch.distributed as dist
     os.environ['HV_PRECISION'] = args.precision
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
-    import hvgan
-    from hvgan import synth, ddp, profiler
+    import hvgan  # noqa: F401
+    from hvgan import synth, ddp, profiler, engine
     from hvgan.models.pix2pix_model import Pix2PixModel
 
-    torch.manual_seed(1234)                       # same initial weights on every rank
+    torch.manual_seed(1234)                       # same initial weights on every rank (and rank 0's are broadcast)
     opt = make_opt(args.precision)
     opt.gpu_ids = [local_rank]
-    model = Pix2PixModel(opt)
+    model = Pix2PixModel(opt)                     # joins the RCCL job described by the environment (ddp.init_from_env)
     model.setup(opt)
-    ddp.broadcast_parameters([model.netG, model.netD_1, model.netD_2, model.netD_3])
+    model.strict_graph = True                     # a failed hipGraph capture is an error here, never a silent eager fallback
+    if world > 1 and not (dist.is_initialized() and dist.get_world_size() == world):
+        raise SystemExit('bench.py: process group not initialised for %d ranks' % world)
     batch = synth.make_batch(args.batch, args.size, seed=1234 + rank)     # weak scaling: each rank its own 16 slices
     model.set_input(batch)                        # inputs resident in HBM before the timed region
 
@@ -95,16 +222,17 @@ def main():
         torch.cuda.synchronize()
 
     step = model.optimize_parameters
-    from hvgan import engine
     if args.serial:
         engine.SERIAL = True
     if args.no_graph:
         model.use_graph = False
-    # W untimed warm-up steps; the step graph is captured after the model's first eager steps, so a warm-up shorter than
+    # W untimed warm-up steps; the step graphs are captured after the model's first eager steps, so a warm-up shorter than
     # that is topped up (untimed) to keep the capture out of the timed region
     for _ in range(max(args.warmup, model.GRAPH_WARMUP + 1 if model.use_graph else 1)):
         step()
     barrier()
+    if model.use_graph and not (model._graphs or model._dp_graphs):
+        raise SystemExit('bench.py: the step was not captured as hipGraphs')
     prof = profiler.KernelTimer()
     serial0 = engine.SERIAL
     engine.SERIAL = True              # per-kernel HIP-event timing: one stream, the kernel has the GPU to itself
@@ -121,13 +249,17 @@ def main():
     dt = time.perf_counter() - t0
     # roofline leg: the same K steps once more, launched eagerly on ONE stream with HIP events around the dominant
     # kernel's launches (a captured graph cannot carry timing events, and with other streams busy an event pair would
-    # also time the wait for free CUs); `bench.py --serial` under rocprofv3 gives the matching per-kernel averages
+    # also time the wait for free CUs); `bench.py --serial` under rocprofv3 gives the matching per-kernel averages.
+    # The same eager single-stream steps carry the event pair around the refinement generator's forward.
     engine.SERIAL = True
     prof.enable(only=dom[1] if dom else None)
+    model.netG.time_fine = []
     for _ in range(args.steps):
         step()
     barrier()
     prof.disable()
+    fine = model.netG.time_fine
+    model.netG.time_fine = None
     engine.SERIAL = serial0
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -143,36 +275,43 @@ def main():
         'dtype': 'f16' if args.precision == 'fp16' else 'f32', 'data': 'synthetic',
         'config': {'workload': 'two-stage coarse+refine generator + 3x PatchGAN D train step, %dx%d, per-GPU bs=%d, norm=batch, vanilla GAN'
                                % (args.size, args.size, args.batch),
-                   'global_batch': world * args.batch, 'precision': 'fp16 MFMA operands / fp32 accumulate, fp32 storage'
-                   if args.precision == 'fp16' else 'fp32 MFMA', 'parallelism': 'dp%d' % world},
+                   'global_batch': world * args.batch, 'precision': engine.precision_note(args.precision), 'parallelism': 'dp%d' % world},
         'achieved_tflops': round(GFLOP_PER_SLICE * value / 1e3, 2),
     }
     if rank == 0:
         out['roofline'] = prof.roofline(args.precision, MFMA_PEAK_TFLOPS[args.precision])
-        # HBM bytes per launch from the committed PMC passes: per layer shape where that kernel was profiled alone
-        # (profiles/r01_traffic.json), else the per-instantiation mean over the whole step (profiles/r01_traffic_step.json)
-        pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles')
-        try:
-            tr = json.load(open(os.path.join(pdir, 'r01_traffic.json')))['kernels']
-            ents = [(tr.get(sh['shape']), sh['launches']) for sh in out['roofline']['shapes']]
-            if ents and all(e for e, _ in ents):      # launch-weighted mean over the layer shapes this instantiation serves
-                out['roofline']['traffic'] = int(sum(e['traffic_bytes'] * n for e, n in ents) / sum(n for _, n in ents))
-                out['roofline']['traffic_source'] = 'profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)'
-            else:
-                e = json.load(open(os.path.join(pdir, 'r01_traffic_step.json')))['kernels'].get(out['roofline']['kernel'])
-                if e:
-                    out['roofline']['traffic'] = int(e['traffic_bytes'])
-                    out['roofline']['traffic_source'] = ('profiles/r01_traffic_step.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate '
-                                                         'passes over a serial bench run; mean per launch of this instantiation)')
-        except (OSError, ValueError, KeyError):
-            pass
+        # HBM bytes per launch from the committed PMC passes of this round (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate
+        # passes over a serial bench run; mean per launch of this instantiation)
+        pdir = os.path.join(ROOT, 'profiles')
+        for fn in ('r02_traffic_step.json', 'r01_traffic_step.json'):
+            try:
+                e = json.load(open(os.path.join(pdir, fn)))['kernels'].get(out['roofline']['kernel'])
+            except (OSError, ValueError, KeyError):
+                e = None
+            if e:
+                out['roofline']['traffic'] = int(e['traffic_bytes'])
+                out['roofline']['traffic_source'] = 'profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, serial bench run)' % fn
+                break
         out['roofline']['timed_in'] = 'eager single-stream re-run of the K steps after the timed region (HIP events on the launch stream)'
-        out['config']['launch'] = ('hipGraph replay (3 graphs/step)' if model.use_graph else 'eager') + (', one stream' if args.serial else ', 4 streams')
+        if fine:
+            torch.cuda.synchronize()
+            fms = sum(s.elapsed_time(e) for s, e in fine) / len(fine)
+            tf = GFLOP_FINE_FWD * args.batch * (args.size / 256.0) ** 2 / fms
+            out['fine_generator_forward'] = {'ms': round(fms, 3), 'gflop': round(GFLOP_FINE_FWD * args.batch * (args.size / 256.0) ** 2, 1),
+                                             'tflops': round(tf, 1), 'frac_of_mfma_peak': round(tf / MFMA_PEAK_TFLOPS[args.precision], 4),
+                                             'timed_in': 'the same eager single-stream steps: HIP events around FineGenerator (training forward, '
+                                                         'both branches + contextual attention in line), mean of %d' % len(fine)}
+        ngraphs = len(model._dp_graphs or ()) or len(model._graphs or ())
+        out['config']['launch'] = ('hipGraph replay (%d graphs/step)' % ngraphs if model.use_graph else 'eager') + \
+                                  (', one stream' if args.serial else ', %d streams' % (5 if world > 1 else 4))
         out['losses'] = {k: round(v, 4) for k, v in model.get_current_losses().items()}
+        if world == 1 and not args.no_inference and args.size == 256:
+            out['inference'] = inference_record(dev, args.precision)
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(model, args.batch, args.size, 1234)
+            out['cpu_baseline'] = cpu_baseline(model, args.size, 1234)
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -506,3 +506,60 @@ extern "C" int hv_ca_patches_backward(const float* dwp, const float* wp, const f
     HV_LAUNCH_CHECK();
     return HV_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ offset_flow (visualisation slot)
+// The reference colours the arg-max offsets with the Middlebury wheel on the host (inpaint_networks.py:368,389-410; inpaint_tools.py:73-100,
+// 181-211,245-280), one device->host->device round trip per forward.  Same arithmetic here in double precision, in the reference's
+// operation order: offsets (row, col) = (arg // w - y, arg % w - x); the radius is normalised by the RUNNING maximum over samples 0..b
+// (flow_to_image keeps maxrad across the batch loop); colour = wheel interpolation, floor(255*col) as uint8, /255, nearest x`up`.
+__device__ __forceinline__ double flow_wheel(int k, int ch) {   // make_color_wheel(): 55 rows (RY 15, YG 6, GC 4, CB 11, BM 13, MR 6)
+    const int seg_n[6] = {15, 6, 4, 11, 13, 6}, full[6] = {0, 1, 1, 2, 2, 0}, ramp[6] = {1, 0, 2, 1, 0, 2}, up[6] = {1, 0, 1, 0, 1, 0};
+    int s = 0, base = 0;
+    while (k >= base + seg_n[s]) { base += seg_n[s]; ++s; }
+    if (ch == full[s]) return 255.0;
+    if (ch != ramp[s]) return 0.0;
+    const double t = floor(255.0 * (double)(k - base) / (double)seg_n[s]);
+    return up[s] ? t : 255.0 - t;
+}
+
+__global__ void __launch_bounds__(256) ca_flow_kernel(const int* __restrict__ argmax, int B, int h, int w, int up, float* __restrict__ flow) {
+    __shared__ double red[4];
+    const int b = blockIdx.x, L = h * w;
+    // running maximum radius over samples 0..b (initial value -1, like the reference)
+    double mx = -1.0;
+    for (long long i = threadIdx.x; i < (long long)(b + 1) * L; i += blockDim.x) {
+        const int p = (int)(i % L), a = argmax[i];
+        const double u = (double)(a / w - p / w), v = (double)(a % w - p % w);
+        mx = fmax(mx, sqrt(u * u + v * v));
+    }
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    const double den = mx + 2.220446049250313e-16;   // np.finfo(float).eps
+    const int Ho = h * up, Wo = w * up;
+    for (int p = threadIdx.x; p < L; p += blockDim.x) {
+        const int a = argmax[(long long)b * L + p];
+        const double u = (double)(a / w - p / w) / den, v = (double)(a % w - p % w) / den;
+        const double rad = sqrt(u * u + v * v);
+        const double ang = atan2(-v, -u) / 3.141592653589793;
+        const double fk = (ang + 1.0) / 2.0 * 54.0 + 1.0;
+        const int k0 = (int)floor(fk);
+        const int k1 = (k0 + 1 == 56) ? 1 : k0 + 1;
+        const double f = fk - (double)k0;
+        for (int ch = 0; ch < 3; ++ch) {
+            double col = (1.0 - f) * (flow_wheel(k0 - 1, ch) / 255.0) + f * (flow_wheel(k1 - 1, ch) / 255.0);
+            col = (rad <= 1.0) ? 1.0 - rad * (1.0 - col) : col * 0.75;
+            const float val = (float)(unsigned char)floor(255.0 * col) / 255.f;
+            float* dst = flow + (((long long)b * 3 + ch) * Ho + (long long)(p / w) * up) * Wo + (long long)(p % w) * up;
+            for (int yy = 0; yy < up; ++yy)
+                for (int xx = 0; xx < up; ++xx) dst[(long long)yy * Wo + xx] = val;
+        }
+    }
+}
+extern "C" int hv_ca_flow(const int* argmax, int B, int h, int w, int up, float* flow, void* stream) {
+    if (!argmax || !flow || B <= 0 || h <= 0 || w <= 0 || up <= 0) return HV_ERR_ARG;
+    hipLaunchKernelGGL(ca_flow_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, argmax, B, h, w, up, flow);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}

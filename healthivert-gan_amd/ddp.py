@@ -3,50 +3,85 @@
 The reference has no distributed code (only nn.DataParallel on the discriminators, reference
 models/networks.py:112-116).  Here every rank runs the whole step on its own 16-slice batch (all of the
 reference's per-batch quirks stay per-rank) and the four networks' gradients are averaged with one flat
-all-reduce each, issued on a side HIP stream so that D_k's reduction overlaps D_{k+1}'s forward/backward
-(SURVEY.md section 8e).  With no process group initialised every call is a no-op.
+all-reduce each on a dedicated high-priority HIP stream:
+
+* D_k's reduction is issued the moment D_k's backward has been queued on D_k's stream and only D_k's optimiser step
+  waits for it, so it overlaps the other discriminators' passes and their generator-step forwards;
+* the generator's reduction and its Adam step run on the exchange stream BESIDE the next step's real-image
+  discriminator passes (which need neither the generator's weights nor its gradients).
+
+`init_from_env()` joins the process group that `python -m torch.distributed.run` describes in the environment, so
+a reference `train.py` needs no edit.  With no process group initialised every call is a no-op.
 """
+import ctypes
 import os
 
 import torch
 import torch.distributed as dist
 
 
+def init_from_env():
+    """Join the job described by RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (set by torch.distributed.run) if there is one and
+    nobody has joined it yet.  Returns the local device index this rank must drive, or None when the process is not part
+    of a multi-process job.  Backend: RCCL ('nccl' IS RCCL on ROCm); HV_DDP_BACKEND=gloo for dry runs / tests."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world <= 1 or not dist.is_available():
+        return None
+    local = int(os.environ.get('LOCAL_RANK', os.environ.get('RANK', '0')))
+    if not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        backend = os.environ.get('HV_DDP_BACKEND', 'nccl')
+        kw = {}
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+            kw['device_id'] = torch.device('cuda', local)
+        dist.init_process_group(backend, rank=int(os.environ['RANK']), world_size=world, **kw)
+    return local
+
+
+def rank():
+    return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+
+
 class GradSync:
     def __init__(self, group=None):
         self.group = group
         self.stream = None
-        self.pending = []
 
     @staticmethod
     def active():
         # HV_DDP_FORCE=1: run the exchange even in a one-rank group (RCCL smoke test of the exact call sequence on a single GPU)
         return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get('HV_DDP_FORCE') == '1')
 
-    def reduce(self, flat):
-        """Start averaging `flat` (a network's flat gradient buffer) across ranks."""
+    def exchange_stream(self, device):
+        if self.stream is None:
+            self.stream = torch.cuda.Stream(device=device, priority=-1)
+        return self.stream
+
+    def reduce(self, flat, after=None):
+        """Average `flat` (a network's flat gradient buffer) across ranks on the exchange stream, ordered after everything queued
+        on stream `after` (default: the current stream).  Returns an event that is complete when `flat` holds the mean (None
+        for CPU tensors, which are reduced synchronously); the consumer's stream waits for it -- nothing blocks the host."""
         if not self.active():
-            return
+            return None
         ws = dist.get_world_size(self.group)
-        if flat.is_cuda:
-            if self.stream is None:
-                self.stream = torch.cuda.Stream(device=flat.device)
-            self.stream.wait_stream(torch.cuda.current_stream(flat.device))
-            with torch.cuda.stream(self.stream):
-                flat.mul_(1.0 / ws)
-                work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            self.pending.append((work, flat))
-        else:   # gloo on CPU tensors (tests)
+        if not flat.is_cuda:   # gloo on CPU tensors (tests, dry runs)
             flat.mul_(1.0 / ws)
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-
-    def wait(self):
-        """Make the current stream wait for every outstanding reduction (before the optimiser reads the gradients)."""
-        for work, flat in self.pending:
-            work.wait()
-            if flat.is_cuda:
-                torch.cuda.current_stream(flat.device).wait_stream(self.stream)
-        self.pending = []
+            return None
+        from . import lib as _lib
+        st = self.exchange_stream(flat.device)
+        st.wait_stream(after if after is not None else torch.cuda.current_stream(flat.device))
+        with torch.cuda.stream(st):
+            # pre-scale (1/ws) with the library's own pointwise kernel, then SUM: the mean of the ranks' gradients
+            _lib.get().call('hv_affine', _lib.ptr(flat), _lib.ptr(flat), ctypes.c_longlong(flat.numel()), ctypes.c_float(1.0 / ws),
+                            ctypes.c_float(0.0), _lib.stream())
+            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            work.wait()        # RCCL: the exchange stream waits for the collective's stream (no host block); gloo: host wait
+            ev = torch.cuda.Event()
+            ev.record(st)
+        return ev
 
 
 def broadcast_parameters(modules, src=0, group=None):

@@ -16,6 +16,13 @@ from .lib import ptr, stream
 from .ops import Act, rup
 
 
+def precision_note(precision):
+    """What the precision mode means, for bench.py's config record."""
+    if precision in ('fp16', 'f16'):
+        return 'fp16 MFMA operands / fp32 accumulate, fp32 storage'
+    return 'fp32 MFMA (v_mfma_f32_16x16x4_f32), fp32 storage'
+
+
 # ================================================================================================ parameters
 class ConvParams:
     """One convolution's parameters and their kernel-layout copies.

@@ -239,10 +239,12 @@ class _UnetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, net, plan, ct, mk):
         ctx.net, ctx.plan = net, plan
+        plan.generation = ctx.generation = getattr(plan, 'generation', 0) + 1
         return ct.clone(), mk.clone()
 
     @staticmethod
     def backward(ctx, g_ct, g_mk):
-        z = lambda g, ref: torch.zeros(ref) if g is None else g
+        if ctx.plan.generation != ctx.generation:
+            raise RuntimeError("UnetGenerator: a later forward pass of the same shape overwrote this pass's activations before its backward ran")
         ctx.net.run_backward(ctx.plan, g_ct, g_mk)
         return (None,) * 5

@@ -8,6 +8,7 @@ from collections import OrderedDict
 import torch
 
 from . import networks
+from ._backend import ddp
 
 
 class BaseModel(ABC):
@@ -46,7 +47,11 @@ class BaseModel(ABC):
             self.load_networks('iter_%d' % opt.load_iter if opt.load_iter > 0 else opt.epoch)
         self.print_networks(opt.verbose)
 
+    def sync_tail(self):
+        """Order the current stream after work a subclass leaves pending on other streams (Pix2PixModel's data-parallel step)."""
+
     def eval(self):
+        self.sync_tail()
         for _, net in self._nets():
             net.eval()
 
@@ -75,12 +80,16 @@ class BaseModel(ABC):
         print('learning rate %.7f -> %.7f' % (old_lr, self.optimizers[0].param_groups[0]['lr']))
 
     def get_current_visuals(self):
+        self.sync_tail()
         return OrderedDict((n, getattr(self, n)) for n in self.visual_names if isinstance(n, str))
 
     def get_current_losses(self):
         return OrderedDict((n, float(getattr(self, 'loss_' + n))) for n in self.loss_names if isinstance(n, str))
 
     def save_networks(self, epoch):
+        if ddp.rank() != 0:        # one process per GPU, identical weights on every rank: rank 0 writes the checkpoint
+            return
+        self.sync_tail()
         os.makedirs(self.save_dir, exist_ok=True)
         for name, net in self._nets():
             sd = OrderedDict((k, v.detach().cpu()) for k, v in net.state_dict().items())

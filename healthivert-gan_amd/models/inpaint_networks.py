@@ -192,11 +192,12 @@ class _AttentionFn(torch.autograd.Function):
 
 
 def offsets_to_flow(argmax, B, h, w, rate):
-    """offset_flow slot of the 7-tuple: the reference colours the arg-max offsets with a NumPy colour wheel on the
-    host (inpaint_tools.py:73-100), forcing a device sync every forward, and nothing downstream consumes it
-    (pix2pix_model.py:82-87).  The arg-max indices are produced on the device; the colour-wheel image is visualisation
-    only and is returned as zeros of the right shape."""
-    return torch.zeros(B, 3, h * rate * 4, w * rate * 4, device=argmax.device)
+    """offset_flow slot of the 7-tuple (reference :368,:389-410): the arg-max offsets coloured with the Middlebury wheel and nearest-
+    upsampled by rate*4.  The reference does this with NumPy on the host (inpaint_tools.py:73-100), one device sync per forward; here
+    it is one small kernel on the arg-max indices the soft-max already produced (hv_ca_flow)."""
+    flow = torch.empty(B, 3, h * rate * 4, w * rate * 4, dtype=torch.float32, device=argmax.device)
+    _lib.get().call('hv_ca_flow', ptr(argmax), B, h, w, rate * 4, ptr(flow), stream())
+    return flow
 
 
 # ================================================================================================ generator plan
@@ -325,6 +326,11 @@ class Generator(nn.Module):
         import os as _os
         self.use_graph = _os.environ.get('HV_GRAPH', '1') != '0'
         self._pset_convs = None
+        self._tail_stream = None       # a stream still updating the weights (the data-parallel step's exchange stream)
+
+    def _wait_tail(self):
+        if self._tail_stream is not None and not torch.cuda.is_current_stream_capturing():
+            torch.cuda.current_stream().wait_stream(self._tail_stream)
 
     # ---------------------------------------------------------------- parameters
     def paramset(self):
@@ -383,6 +389,12 @@ class Generator(nn.Module):
         for n in P.c_nodes[15:]:
             n.forward(prec)
         # ---- fine
+        tf = getattr(self, 'time_fine', None)
+        if tf is not None and not torch.cuda.is_current_stream_capturing():     # bench.py: HIP events around the refinement generator
+            tf.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
+            tf[-1][0].record()
+        else:
+            tf = None
         ops.gen_input(x, P.coarse_seg, mask, ratio, P.f_in, 1)
         # the dilated-conv branch and the attention branch only share their input: two streams (two branches of the step graph)
         side = E.branch_stream()
@@ -392,7 +404,7 @@ class Generator(nn.Module):
         with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
             for n in P.f_nodes_pm:
                 n.forward(prec)
-            P.attn.forward(a['p6'], mask, a['ca'], prec, per_sample_mask=per_sample_mask)
+            P.attn.forward(a['p6'], mask, a['ca'], prec, want_argmax=True, per_sample_mask=per_sample_mask)
             for n in P.f_nodes_pm2:
                 n.forward(prec)
         for n in P.f_nodes_conv:
@@ -405,6 +417,8 @@ class Generator(nn.Module):
             n.forward(prec)
         ops.copy_channels(Act(P.x_stage1.view(B, H, W, 1)), a['cat17'].slice(c // 2, 1), mode=0)
         P.f_nodes_merge[7].forward(prec); P.f_nodes_merge[8].forward(prec)
+        if tf is not None:
+            tf[-1][1].record()
         return P
 
     def _tmp_up(self, P, node):
@@ -496,6 +510,7 @@ class Generator(nn.Module):
         (coarse_seg, fine_seg, x_stage1, x_stage2, offset_flow, pred1_h, pred2_h)."""
         if not torch.is_tensor(slice_ratio):
             slice_ratio = torch.as_tensor(slice_ratio, dtype=torch.float64).reshape(-1)
+        self._wait_tail()
         if self.use_graph and not self.training and not torch.is_grad_enabled() and ops.timer() is None and x.is_cuda:
             P = self._eval_replay(x, mask, CAM, slice_ratio)
         else:
@@ -550,10 +565,14 @@ class _GeneratorFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, gen, plan, *outs):
         ctx.gen, ctx.plan = gen, plan
+        plan.generation = ctx.generation = getattr(plan, 'generation', 0) + 1
         return tuple(t.clone() for t in outs)
 
     @staticmethod
     def backward(ctx, g_cs, g_fs, g_x1, g_x2, g_p1, g_p2):
         # gradients are ASSIGNED into .grad (the reference always zero_grad()s before backward)
+        if ctx.plan.generation != ctx.generation:
+            raise RuntimeError("Generator: a later forward pass of the same shape overwrote this pass's activations before its backward ran "
+                               "(one activation plan per input shape); run backward before the next forward")
         ctx.gen.run_backward(ctx.plan, g_cs, g_fs, g_x1, g_x2, g_p1, g_p2)
         return (None,) * 9

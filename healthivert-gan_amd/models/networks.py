@@ -172,6 +172,7 @@ class _DiscPlan:
             h, w = ho, wo
             self.layers.append(ent)
         self.dx = torch.zeros(B, 1, H, W, dtype=torch.float32, device=device)
+        self.pending = None        # weakref to the autograd token of the nn.Module-API forward that owns these activations
 
 
 def _stat_momentum(m, order):
@@ -238,15 +239,26 @@ class NLayerDiscriminator(nn.Module):
             self._pset = E.ParamSet(convs, extra)
         return self._pset
 
-    def _plan(self, B, H, W, device):
-        key = (B, H, W, str(device))
+    def _plan(self, B, H, W, device, slot=0):
+        """slot 0 is the explicit executor's plan (Pix2PixModel's fused step); the nn.Module API takes one plan per forward whose
+        autograd graph is still alive (slot 1, 2, ...): `pred_fake = D(fake); pred_real = D(real); loss.backward()` -- the
+        reference's own backward_D (pix2pix_model.py:267-283) -- keeps both passes' activations until their backward ran."""
+        key = (B, H, W, str(device), slot)
         if key not in self._plans:
             self.paramset()
             self._plans[key] = _DiscPlan(self, B, H, W, device)
         return self._plans[key]
 
+    def _free_plan_slot(self, B, H, W, device):
+        slot = 1
+        while True:
+            P = self._plans.get((B, H, W, str(device), slot))
+            if P is None or P.pending is None or P.pending() is None:
+                return slot
+            slot += 1
+
     # ---------------------------------------------------------------- explicit forward / backward
-    def run_forward(self, x, training=None, prep=True, groups=1, stat_order=None):
+    def run_forward(self, x, training=None, prep=True, groups=1, stat_order=None, slot=0):
         """x: (B,1,H,W) device tensor -> plan; logits in plan.logits (B,1,Ho,Wo).  BatchNorm running statistics are
         updated when training (every call, like the reference's three calls per step).  groups=2 treats the two halves of
         the batch as two consecutive calls (separate batch statistics, running stats updated half by half): the fake and
@@ -260,7 +272,7 @@ class NLayerDiscriminator(nn.Module):
         prec = ops.precision_id(self.precision)
         x = x.contiguous().float()
         B, _, H, W = x.shape
-        P = self._plan(B, H, W, x.device)
+        P = self._plan(B, H, W, x.device, slot)
         P.book.join()   # weight gradients of the previous backward still read this plan's activations on the side stream
         if prep:
             self.paramset().prep(x.device, power_iter=False)
@@ -336,23 +348,47 @@ class NLayerDiscriminator(nn.Module):
 
     # ---------------------------------------------------------------- nn.Module API
     def forward(self, input):
-        P = self.run_forward(input)
         if torch.is_grad_enabled() and (input.requires_grad or any(p.requires_grad for p in self.parameters())):
+            B, _, H, W = input.shape
+            P = self.run_forward(input, slot=self._free_plan_slot(B, H, W, input.device))
             return _DiscFn.apply(input, self, P, P.logits)
-        return P.logits.clone()
+        return self.run_forward(input).logits.clone()
+
+
+class _PlanToken:
+    """Alive as long as the autograd node that owns a plan's activations is."""
+
+
+def grads_are_fresh(net):
+    """True when nothing has been written into the net's gradients since the last zero_grad(): the next backward ASSIGNS, later
+    ones accumulate -- torch.autograd's .grad semantics for the nn.Module API of the explicit-backward networks.  FusedAdam.zero_grad
+    flags the first parameter; torch optimisers either drop .grad (set_to_none) or zero it (then accumulating is right anyway)."""
+    p0 = next(net.parameters())
+    fresh = getattr(p0, '_hv_fresh', False) or p0.grad is None
+    p0._hv_fresh = False
+    return fresh
 
 
 class _DiscFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, net, plan, logits):
+        import weakref
         ctx.net, ctx.plan, ctx.need_dx = net, plan, x.requires_grad
+        ctx.token = _PlanToken()
+        plan.pending = weakref.ref(ctx.token)
         return logits.clone()
 
     @staticmethod
     def backward(ctx, g):
-        net = ctx.net
+        net, plan = ctx.net, ctx.plan
+        if plan.pending is None or plan.pending() is not ctx.token:
+            raise RuntimeError("NLayerDiscriminator: the activations of this forward pass were overwritten before its backward ran")
         pg = any(p.requires_grad for p in net.parameters())
-        dx = net.run_backward(ctx.plan, g.contiguous(), need_dx=ctx.need_dx, param_grads=pg, accumulate=False)
+        acc = pg and not grads_are_fresh(net)
+        if pg:
+            net.paramset().attach_grads()
+        dx = net.run_backward(plan, g.contiguous(), need_dx=ctx.need_dx, param_grads=pg, accumulate=acc)
         if pg:
             net.finish()
+        plan.pending = None
         return (dx.clone() if dx is not None else None), None, None, None

@@ -53,6 +53,12 @@ class Pix2PixModel(BaseModel):
         return parser
 
     def __init__(self, opt):
+        # launched by `python -m torch.distributed.run --nproc-per-node N train.py ...`: join the job and drive THIS rank's GPU
+        # (train.py itself stays unedited; it passes --gpu_ids 0 to every rank)
+        local = ddp.init_from_env()
+        if local is not None and opt.gpu_ids:
+            opt.gpu_ids = [local]
+            torch.cuda.set_device(local)
         BaseModel.__init__(self, opt)
         if not self.gpu_ids:
             raise RuntimeError("Pix2PixModel (healthivert-gan_amd) needs an MI355X: set --gpu_ids 0; there is no CPU path")
@@ -82,27 +88,50 @@ class Pix2PixModel(BaseModel):
         self._loss_buf = torch.zeros(32, dtype=torch.float32, device=self.device)
         self._bufs = {}
         self._in = {}
+        self._shapes, self._cur = {}, None      # per batch shape: input buffers, warm-up count, captured graphs
         self._graphs = None
+        self._dp_graphs = None
         self._eager_steps = 0
         self.use_graph = _os_environ_graph()
         self.grad_sync = ddp.GradSync() if self.isTrain else None
+        if self.isTrain:       # every rank starts from rank 0's initial weights (a no-op without a process group)
+            ddp.broadcast_parameters([self.netG, self.netD_1, self.netD_2, self.netD_3])
         import os as _os
         self.concurrent_d = _os.environ.get('HV_CONCURRENT_D', '1') != '0'
         self.batch_d = _os.environ.get('HV_BATCH_D', '0') != '0'   # measured: no gain once the three D streams overlap
         self.real_first = _os.environ.get('HV_REAL_FIRST', '1') != '0'   # D real passes overlap the generator forward
 
+    # tensors forward()/backward bind as attributes; they live in per-shape buffers, so the names follow the active batch shape
+    _STEP_OUTPUTS = ('fake_B', 'fake_B_coarse', 'fake_B_local', 'real_B_local', 'fake_B_mask_raw', 'coarse_seg_binary', 'coarse_seg_sigmoid',
+                     'fake_B_mask_sigmoid', 'x_stage1', 'fake_B_raw', 'pred1_h', 'pred2_h', 'real_edges', 'fake_edges', '_gplan', '_rows', '_dxs')
+
     # ---------------------------------------------------------------- inputs
     def set_input(self, input):
-        """Unpack a batch dict (reference models/pix2pix_model.py:137-175).  The tensors land in persistent device buffers
-        (one set per batch shape): the captured step graph reads its inputs from fixed addresses."""
+        """Unpack a batch dict (reference models/pix2pix_model.py:137-175).  The tensors land in persistent device buffers, one set
+        per batch shape: the captured step graphs read their inputs from fixed addresses, and a shape that comes back (the partial
+        last batch of every epoch, then full batches again) finds its buffers, its warm-up count and its captured graphs again
+        instead of re-capturing.  The attributes (and get_current_visuals()) are views of these buffers: the next set_input of the
+        same shape overwrites them -- clone what must outlive a step."""
         AtoB = self.opt.direction == 'AtoB'
+        key = tuple(input['A_mask'].shape)
+        st = self._shapes.get(key)
+        if st is None:
+            st = self._shapes[key] = {'in': {}, 'graphs': None, 'dp_graphs': None, 'eager': 0}
+        if st is not self._cur:
+            if self._cur is not None:
+                self._cur.update(graphs=self._graphs, dp_graphs=self._dp_graphs, eager=self._eager_steps,
+                                 outs={n: getattr(self, n) for n in self._STEP_OUTPUTS if hasattr(self, n)})
+            self._cur, self._in = st, st['in']
+            self._graphs, self._dp_graphs, self._eager_steps = st['graphs'], st['dp_graphs'], st['eager']
+            for n, v in st.get('outs', {}).items():     # a graph replay does not re-run the Python that binds these names
+                setattr(self, n, v)
 
         def put(name, t, dtype):
             b = self._in.get(name)
             if b is None or b.shape != t.shape or b.dtype != dtype:
                 b = torch.empty(t.shape, dtype=dtype, device=self.device)
                 self._in[name] = b
-                self._graphs = None        # input addresses changed: captured graphs are stale,
+                self._graphs = self._dp_graphs = None        # input addresses changed: captured graphs are stale,
                 self._eager_steps = 0      # and the new shape needs its own eager warm-up (plans, tables) before a capture
             b.copy_(t, non_blocking=True)
             return b
@@ -127,6 +156,14 @@ class Pix2PixModel(BaseModel):
             self._bufs[key] = b
         return b
 
+    @property
+    def offset_flow(self):
+        """The 5th output of netG (reference :187): coloured arg-max offsets of the contextual attention, built on demand from the
+        indices the last forward left on the device (nothing in the train step consumes it)."""
+        from .inpaint_networks import offsets_to_flow
+        P = getattr(self, '_gplan', None)
+        return None if P is None else offsets_to_flow(P.attn.argmax, P.B, P.attn.h, P.attn.w, 2)
+
     # ---------------------------------------------------------------- forward
     def forward(self):
         L = _lib.get()
@@ -137,7 +174,6 @@ class Pix2PixModel(BaseModel):
         self._gplan = P
         self.coarse_seg_sigmoid, self.fake_B_mask_sigmoid = P.coarse_seg, P.fine_seg
         self.x_stage1, self.fake_B_raw = P.x_stage1, P.x_stage2
-        self.offset_flow = None
         d = L.hv_postg_desc()
         outs = {}
         for n in ('fake_B', 'fake_B_coarse', 'fake_B_local', 'real_B_local', 'fake_B_mask_raw', 'coarse_seg_binary'):
@@ -352,47 +388,159 @@ class Pix2PixModel(BaseModel):
             for side in self._d_streams:
                 main.wait_stream(side)
 
-    def _reduce(self, nets):
-        """Average the gradients of `nets` across ranks (RCCL, eager -- never inside a captured graph)."""
-        for n in nets:
-            self.grad_sync.reduce(n.paramset().flat_grad)
-        self.grad_sync.wait()
-
     GRAPH_WARMUP = 2     # eager steps before capture (lazy allocations, stream creation, weight tables)
+
+    def _graph_failed(self, e):
+        """hipGraph capture refused by the runtime: keep launching eagerly and say so once -- unless the caller asked for a
+        hard failure (bench.py: a number labelled 'hipGraph replay' must never come from eager launches)."""
+        if getattr(self, 'strict_graph', False):
+            raise RuntimeError('hipGraph capture of the train step failed: %s' % str(e).splitlines()[0]) from e
+        import warnings
+        warnings.warn('hipGraph capture of the train step failed (%s); continuing with eager launches' % str(e).splitlines()[0])
+        self.use_graph, self._graphs, self._dp_graphs = False, None, None
+        torch.cuda.synchronize(self.device)
 
     def optimize_parameters(self):
         """forward; D_1, D_2, D_3 updates; G update (reference :356-382).
 
         The step is device-only (no host reads, learning rate and Adam step count live on the device), so after
-        GRAPH_WARMUP eager steps its three phases are captured once as hipGraphs and replayed: ~650 kernel launches per
-        step become three graph launches, which removes the host launch latency that otherwise leaves the GPU idle
-        between the short kernels of the backward passes.  The gradient all-reduces of a multi-GPU job run between
-        the graphs.  HV_GRAPH=0 or an active kernel timer keeps the eager path."""
+        GRAPH_WARMUP eager steps its phases are captured once as hipGraphs and replayed: ~650 kernel launches per
+        step become a few graph launches, which removes the host launch latency that otherwise leaves the GPU idle
+        between the short kernels of the backward passes.  A multi-GPU job runs the data-parallel schedule
+        (_step_data_parallel); HV_GRAPH=0 or an active kernel timer keeps the eager path."""
         for o in self.optimizers:
             o.sync_lr()
         graphable = self.use_graph and ops.timer() is None
+        if self.grad_sync.active():
+            return self._step_data_parallel(graphable)
         if graphable and self._graphs is None and self._eager_steps >= self.GRAPH_WARMUP:
             try:
                 self._capture()
-            except RuntimeError as e:     # capture refused by the runtime: keep launching eagerly, say so once
-                import warnings
-                warnings.warn('hipGraph capture of the train step failed (%s); continuing with eager launches' % str(e).splitlines()[0])
-                self.use_graph, self._graphs, graphable = False, None, False
-                torch.cuda.synchronize(self.device)
+            except RuntimeError as e:
+                self._graph_failed(e)
+                graphable = False
         if graphable and self._graphs is not None:
-            ga, gb, gc = self._graphs
-            ga.replay()
-            self._reduce([self.netD_1, self.netD_2, self.netD_3])
-            gb.replay()
-            self._reduce([self.netG])
-            gc.replay()
+            for g in self._graphs:
+                g.replay()
             return
         self._phase_a()
-        self._reduce([self.netD_1, self.netD_2, self.netD_3])
         self._phase_b()
-        self._reduce([self.netG])
         self._phase_c()
         self._eager_steps += 1
+
+    # ---------------------------------------------------------------- the data-parallel step (one process per GPU)
+    # Phases, the stream each runs on, and what it waits for:
+    #   real_k  (S_k)   D_k on the real images, gradients assigned        <- the batch (main)
+    #   gfwd    (main)  generator forward + compositing + Sobel           <- previous step's G Adam (exchange stream)
+    #   fake_k  (S_k)   D_k on the fakes, gradients accumulated, finish   <- gfwd
+    #   [exchange stream: mean of D_k's flat gradient over the ranks      <- fake_k]
+    #   dstep_k (S_k)   Adam D_k, D_k(fake) with the new weights, d/dfake <- D_k's reduction only
+    #   gbwd    (main)  generator losses + backward                       <- dstep_1..3
+    #   [exchange stream: mean of G's flat gradient, then gadam = Adam G  <- gbwd]
+    # so D_k's reduction runs beside the other discriminators' passes / generator-step forwards, and the generator's
+    # reduction + Adam beside the NEXT step's real_k.  Each phase is one hipGraph after the warm-up steps; the RCCL calls are
+    # issued eagerly between the graph launches (never captured), and nothing blocks the host.
+    def _dp_phases(self):
+        def real(k):
+            def f():
+                reals = {1: lambda: self.real_B, 2: lambda: self.real_B_mask, 3: self._real_local_early}
+                self.set_requires_grad(getattr(self, 'netD_%d' % k), True)
+                getattr(self, 'optimizer_D_%d' % k).zero_grad()
+                self._d_real_first(k, reals[k]())
+            return f
+
+        def fake(k):
+            return lambda: self._d_fake_second(k, {1: self.fake_B, 2: self.fake_B_mask_raw, 3: self.fake_B_local}[k])
+
+        def dstep(k):
+            def f():
+                getattr(self, 'optimizer_D_%d' % k).step(sync_lr=False)
+                self._g_step_D(k)
+            return f
+
+        def gbwd():
+            self.set_requires_grad([self.netD_1, self.netD_2, self.netD_3], False)
+            self.optimizer_G.zero_grad()
+            self.backward_G(d_done=True)
+        ph = {'gfwd': self.forward, 'gbwd': gbwd, 'gadam': self._phase_c}
+        for k in (1, 2, 3):
+            ph['real%d' % k], ph['fake%d' % k], ph['dstep%d' % k] = real(k), fake(k), dstep(k)
+        return ph
+
+    def _dp_setup(self):
+        if getattr(self, '_d_streams', None) is None:
+            self._d_streams = [torch.cuda.Stream(device=self.device) for _ in range(3)]
+            engine.NO_FORK_STREAMS.update(st.cuda_stream for st in self._d_streams)
+        if getattr(self, '_dp_ph', None) is None:
+            self._dp_ph = self._dp_phases()
+            self._dp_graphs = None
+        self._dxs = getattr(self, '_dxs', None) or {}
+        comm = self.grad_sync.exchange_stream(self.device)
+        self.netG._tail_stream = comm          # direct users of netG (train.py's evaluate_model) wait for the pending Adam step
+        return comm
+
+    def _dp_run(self, name, st):
+        with torch.cuda.stream(st):
+            g = self._dp_graphs.get(name) if self._dp_graphs else None
+            if g is not None:
+                g.replay()
+            else:
+                self._dp_ph[name]()
+
+    def sync_tail(self):
+        """Order the current stream after the generator's pending all-reduce + Adam step (they run on the exchange stream)."""
+        if self.grad_sync is not None and self.grad_sync.stream is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self.grad_sync.stream)
+
+    def _step_data_parallel(self, graphable):
+        comm = self._dp_setup()
+        main = torch.cuda.current_stream(self.device)
+        S = self._d_streams
+        serial = engine.SERIAL
+        on = (lambda k: main) if serial else (lambda k: S[k - 1])
+        if graphable and self._dp_graphs is None and self._eager_steps >= self.GRAPH_WARMUP:
+            try:
+                self._capture_data_parallel()
+            except RuntimeError as e:
+                self._graph_failed(e)
+        for k in (1, 2, 3):
+            on(k).wait_stream(main)                 # the batch (set_input copies) and last step's readers of D_k's outputs
+            self._dp_run('real%d' % k, on(k))
+        main.wait_stream(comm)                      # last step's generator Adam
+        self._dp_run('gfwd', main)
+        events = {}
+        for k in (1, 2, 3):
+            on(k).wait_stream(main)
+            self._dp_run('fake%d' % k, on(k))
+            events[k] = self.grad_sync.reduce(getattr(self, 'netD_%d' % k).paramset().flat_grad, after=on(k))
+        for k in (1, 2, 3):
+            if events[k] is not None:
+                on(k).wait_event(events[k])
+            self._dp_run('dstep%d' % k, on(k))
+        for k in (1, 2, 3):
+            main.wait_stream(on(k))
+        self._dp_run('gbwd', main)
+        self.grad_sync.reduce(self.netG.paramset().flat_grad, after=main)
+        self._dp_run('gadam', comm)
+        if serial:
+            main.wait_stream(comm)
+        if not (self._dp_graphs and graphable):
+            self._eager_steps += 1
+
+    def _capture_data_parallel(self):
+        if getattr(self, '_capture_stream', None) is None:
+            self._capture_stream = torch.cuda.Stream(device=self.device)
+        torch.cuda.synchronize(self.device)
+        graphs = {}
+        for name, fn in self._dp_ph.items():
+            # the discriminator phases are captured on the stream they replay on: per-stream scratch buffers stay disjoint
+            # between phases that run concurrently
+            st = self._d_streams[int(name[-1]) - 1] if name[-1] in '123' else self._capture_stream
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=st, capture_error_mode='thread_local'):
+                fn()
+            graphs[name] = g
+        self._dp_graphs = graphs
 
     def _capture(self):
         if getattr(self, '_capture_stream', None) is None:

@@ -103,11 +103,14 @@ def from_nchw(x, CP=None):
 class _Workspace:
     def __init__(self):
         self.buf = {}
+        self.retired = []     # outgrown buffers stay alive: a hipGraph captured earlier still launches kernels that point at them
 
     def get(self, nbytes, device, slot=0):
         key = (device, slot)
         b = self.buf.get(key)
         if b is None or b.numel() < nbytes:
+            if b is not None:
+                self.retired.append(b)
             b = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
             self.buf[key] = b
         return b

@@ -62,5 +62,7 @@ class FusedAdam(torch.optim.Optimizer):
         ops.adam_step(self._table, self._max, self._lr, g['betas'][0], g['betas'][1], g['eps'], self._step)
 
     def zero_grad(self, set_to_none=False):
-        """Gradients are (re)assigned by the explicit backward; nothing to clear."""
+        """Gradients are (re)assigned by the explicit backward; nothing to clear.  The first parameter is flagged so that the
+        nn.Module-API autograd bridges know the next backward assigns and later ones accumulate (networks.grads_are_fresh)."""
+        self.param_groups[0]['params'][0]._hv_fresh = True
         return None

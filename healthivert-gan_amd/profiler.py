@@ -79,13 +79,20 @@ class KernelTimer:
         name, (ms, n, flops, keys) = max(bk.items(), key=lambda kv: kv[1][0])
         agg = self.summary()
         achieved = flops / (ms * 1e-3) / 1e12
-        shapes = [{'shape': describe(k, self.paths.get(k)), 'launches': agg[k][1], 'avg_us': round(agg[k][0] / agg[k][1] * 1e3, 2),
-                   'tflops': round(agg[k][2] / (agg[k][0] / agg[k][1] * 1e-3) / 1e12, 1)} for k in sorted(keys, key=lambda k: -agg[k][0])]
+        ridge = peak_tflops * 1e12 / (HBM_PEAK_GBS * 1e9)
+
+        def shape_row(k):
+            avg_s = agg[k][0] / agg[k][1] * 1e-3
+            tf, gbs = agg[k][2] / avg_s / 1e12, self.bytes.get(k, 0) / avg_s / 1e9
+            hbm = bool(self.bytes.get(k)) and agg[k][2] / self.bytes[k] < ridge        # this shape's own bound
+            return {'shape': describe(k, self.paths.get(k)), 'launches': agg[k][1], 'avg_us': round(avg_s * 1e6, 2), 'tflops': round(tf, 1),
+                    'algorithmic_gbs': round(gbs, 1), 'bound': 'hbm' if hbm else 'mfma',
+                    'frac': round(gbs / HBM_PEAK_GBS if hbm else tf / peak_tflops, 4)}
+        shapes = [shape_row(k) for k in sorted(keys, key=lambda k: -agg[k][0])]
         nbytes = sum(self.bytes.get(k, 0) * agg[k][1] for k in keys)          # algorithmic bytes over all launches of the instantiation
         out = {'kernel': name, 'launches': n, 'avg_us': round(ms / n * 1e3, 2), 'gflop_per_launch': round(flops / n / 1e9, 3),
                'algorithmic_mb_per_launch': round(nbytes / n / 1e6, 2), 'shapes': shapes, 'traffic': None}
         # which roofline bounds it: arithmetic intensity against the ridge of the two peaks
-        ridge = peak_tflops * 1e12 / (HBM_PEAK_GBS * 1e9)
         if nbytes and flops / nbytes < ridge:
             gbs = nbytes / (ms * 1e-3) / 1e9
             out.update(bound='hbm', achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(gbs / HBM_PEAK_GBS, 4),

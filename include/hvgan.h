@@ -209,6 +209,10 @@ int hv_ca_fuse(const float* S, float* out, int B, int h, int w, int adjoint, voi
 int hv_ca_softmax(const float* S, const float* mm, float* A, int B, int L, float scale, int* argmax, void* stream);
 int hv_ca_softmax_batched(const float* S, const float* mm, long long mm_bstride, float* A, int B, int L, float scale, int* argmax,
                           void* stream);   /* mm_bstride = L: per-sample masks from hv_ca_mask_batched; 0: shared */
+/* offset_flow of the reference's 7-tuple (:368,:389-410 + inpaint_tools.flow_to_image/compute_color :73-100,181-211): the arg-max offsets
+ * coloured with the Middlebury wheel (double precision, running maximum radius over samples 0..b like the reference's batch loop), as
+ * uint8/255 and nearest-upsampled x`up` (rate*4): flow[B][3][h*up][w*up] (NCHW like the reference's tensor). */
+int hv_ca_flow(const int* argmax, int B, int h, int w, int up, float* flow, void* stream);
 int hv_ca_softmax_backward(const float* dA, const float* A, const float* mm, float* dS, int B, int L, float scale, void* stream);
 int hv_transpose_batched(const float* src, float* dst, int B, int R, int C, void* stream); /* dst[b][c][r] = src[b][r][c] */
 /* Gs[b][i][j] = dS[b][j][i]*rnorm[b][i] + dS[b][i][j]*rnorm[b][j];  coef[b][l] = -(sum_p dS[p][l]*S0[p][l])/norm[l]^2.

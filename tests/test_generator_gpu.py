@@ -13,6 +13,16 @@ def _err(a, b):
     return (a.detach().cpu().double() - b.double()).abs().max().item()
 
 
+def _flow_close(got, ref, name):
+    """offset_flow: uint8 colour codes / 255.  The arg-max of near-tied scores may pick a different patch on the device than the CPU
+    reference did (a different colour for that pixel's 8x8 block), and floor(255*col) can fall either side of an integer: allow a
+    handful of pixels; everything else must agree to half a colour step."""
+    d = (got.detach().cpu() - ref).abs()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    frac = (d > 0.5 / 255).float().mean().item()
+    assert frac <= 5e-3, (name, frac, d.max().item())
+
+
 def _gen(g, ngf=4):
     import hvgan
     from hvgan.models.inpaint_networks import Generator
@@ -52,6 +62,13 @@ def test_g1_generator_forward_buffers_and_grads():
     outs = dict(coarse_seg=P.coarse_seg, fine_seg=P.fine_seg, x_stage1=P.x_stage1, x_stage2=P.x_stage2, pred1_h=P.pred1, pred2_h=P.pred2)
     for n, t in outs.items():
         assert _err(t, g['eval'][n]) <= TOL, (n, _err(t, g['eval'][n]))
+    # offset_flow slot (reference :368,:389-410): train- and eval-mode values against the reference's own tensors
+    from hvgan.models.inpaint_networks import offsets_to_flow
+    _flow_close(offsets_to_flow(P.attn.argmax, P.B, P.attn.h, P.attn.w, 2), g['flow_eval'], 'flow_eval')
+    net.load_state_dict(g['sd'])
+    net.train()
+    P = net.run_forward(x, mask, cam, ratio, training=True)
+    _flow_close(offsets_to_flow(P.attn.argmax, P.B, P.attn.h, P.attn.w, 2), g['flow_train'], 'flow_train')
 
 
 def test_g1_generator_module_call_and_autograd_bridge():
@@ -62,6 +79,8 @@ def test_g1_generator_module_call_and_autograd_bridge():
     x, mask, cam, ratio = (g[k].to(dev) for k in ('x', 'mask', 'cam', 'ratio'))
     o = net(x, mask, cam, ratio)
     assert len(o) == 7 and o[4].shape == (2, 3, 64, 64)
+    _flow_close(o[4], g['flow_train'], 'flow_train (module call)')
+    assert float(o[4].abs().max()) > 0
     outs = [o[0], o[1], o[2], o[3], o[5], o[6]]
     loss = sum((a * g['coef'][str(i)].to(dev)).sum() for i, a in enumerate(outs))
     assert abs(loss.item() - g['loss'].item()) <= 1e-2 * max(1.0, abs(g['loss'].item()))
@@ -79,6 +98,7 @@ def test_g2_contextual_attention_batch0_mask_quirk():
     f = g['f'].to(dev).requires_grad_(True)
     y, flow = ca(f, f, g['mask'].to(dev))
     assert _err(y, g['y']) <= TOL
+    _flow_close(flow, g['flow'], 'g2 flow')
     (y * g['coef'].to(dev)).sum().backward()
     assert _err(f.grad, g['grad_f']) <= TOL * max(1.0, g['grad_f'].abs().max().item())
 
@@ -143,3 +163,63 @@ def test_g6_unet_ct_mask_forward_backward():
     with torch.no_grad():
         cte, mke = net(x)
     assert _err(cte, g['ct_eval']) <= TOL and _err(mke, g['mk_eval']) <= TOL
+
+
+@pytest.mark.parametrize('norm', ['batch', 'instance'])
+def test_discriminator_module_api_two_forwards_then_one_backward(norm):
+    """The reference's own discriminator update through the nn.Module API (pix2pix_model.py:267-283): pred_fake = D(fake.detach());
+    pred_real = D(real); loss_D = 0.5 * (GAN(pred_fake, False) + GAN(pred_real, True)); loss_D.backward().  Both passes' activations must
+    survive until the single backward and their gradients must ADD: compared with autograd through the CPU oracle.  A second
+    zero_grad + backward round must assign again (not keep accumulating)."""
+    import hvgan  # noqa: F401
+    from hvgan.models import networks
+    from hvgan.optim import FusedAdam
+    from oracle import restate as R
+    g = load_golden('g3_disc_%s' % norm)
+    dev = torch.device('cuda:0')
+    net = networks.define_D(1, 8, 'basic', 3, norm, 'normal', 0.02, [])
+    net.load_state_dict(g['sd'])
+    net.cuda().train()
+    net.precision = 'fp32'
+    crit = networks.GANLoss('vanilla').to(dev)
+    opt = FusedAdam(net.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    sd = {k: v.clone() for k, v in g['sd'].items()}
+    params = [k for k in sd if k.endswith('.weight') or k.endswith('.bias')]
+    for k in params:
+        sd[k].requires_grad_(True)
+    for rnd in range(2):
+        fake, real = g['x'][str(rnd)], g['x'][str(rnd + 1)]
+        opt.zero_grad()
+        pf = net(fake.to(dev).detach())
+        pr = net(real.to(dev))
+        loss = (crit(pf, False) + crit(pr, True)) * 0.5
+        loss.backward()
+        torch.cuda.synchronize()
+        for k in params:
+            sd[k].grad = None
+        rf, u1 = R.disc_forward(sd, fake, norm, True)
+        with torch.no_grad():
+            for k, v in u1.items():
+                sd[k].copy_(v)
+        rr, u2 = R.disc_forward(sd, real, norm, True)
+        with torch.no_grad():
+            for k, v in u2.items():
+                sd[k].copy_(v)
+        rloss = (R.gan_loss(rf, False, 'vanilla') + R.gan_loss(rr, True, 'vanilla')) * 0.5
+        rloss.backward()
+        assert abs(loss.item() - rloss.item()) <= 1e-4
+        got = dict(net.named_parameters())
+        for k in params:
+            ref = sd[k].grad
+            assert _err(got[k].grad, ref) <= TOL * max(1.0, ref.abs().max().item()), (rnd, k, _err(got[k].grad, ref))
+    # a forward whose plan is reused before its backward must fail loudly, never return another pass's gradients
+    from hvgan.models.inpaint_networks import Generator
+    gg = load_golden('g1_generator_mini')
+    gen = _gen(gg)
+    gen.train()
+    x, mask, cam, ratio = (gg[k].to(dev) for k in ('x', 'mask', 'cam', 'ratio'))
+    o1 = gen(x, mask, cam, ratio)
+    o2 = gen(x, mask, cam, ratio)
+    with pytest.raises(RuntimeError, match='overwrote'):
+        o1[0].sum().backward()
+    o2[0].sum().backward()

@@ -114,7 +114,7 @@ os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=sys.argv[2])
 dist.init_process_group('gloo', rank=rank, world_size=world)
 flat = torch.full((1000,), float(rank + 1))
 gs = ddp.GradSync()
-gs.reduce(flat); gs.wait()
+assert gs.reduce(flat) is None      # CPU tensors: reduced synchronously, no event
 assert torch.allclose(flat, torch.full((1000,), 1.5)), flat[:3]
 lin = torch.nn.Linear(4, 4)
 ddp.broadcast_parameters([lin])
@@ -133,6 +133,60 @@ def test_gradient_averaging_two_ranks_gloo():
     for p in procs:
         out, _ = p.communicate(timeout=300)
         assert p.returncode == 0 and b'ok' in out, out.decode()[-2000:]
+
+
+def test_bench_starts_its_own_ranks_dry_run():
+    """`python bench.py --gpus 2` from a plain shell (WORLD_SIZE unset) must start two ranks itself and report n_gpus == 2; the
+    --dry-run form rehearses exactly that plumbing over gloo on the CPU: launcher, rendezvous on 127.0.0.1, the flat-gradient mean of
+    the real networks' sizes through ddp.GradSync, barrier and MAX-over-ranks clock, one JSON line from rank 0."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run', '--steps', '2', '--warmup', '1'],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1, p.stdout.decode()[-2000:]
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['dry_run'] is True and rec['config']['bytes_per_round'] > 30e6
+    # a rank count that differs from --gpus is an error, not a silently smaller run
+    env2 = dict(env, WORLD_SIZE='1', RANK='0')
+    q = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run'], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=300, env=env2)
+    assert q.returncode != 0 and b'--gpus 2' in q.stderr
+
+
+def test_oracle_data_parallel_step_is_the_mean_of_rank_gradients():
+    """oracle.restate.pix2pix_step_data_parallel (the spec the GPU ranks are compared with): with the SAME batch on
+    both ranks it must reproduce the single-process step bit for bit (the mean of two equal gradients); with different batches both
+    ranks end with identical weights that differ from either single-rank result."""
+    import torch
+    import hvgan  # noqa: F401
+    from hvgan import synth
+    from hvgan.models.inpaint_networks import Generator
+    from hvgan.models import networks
+    from oracle import restate as R
+    torch.manual_seed(5)
+    G = Generator({'input_dim': 1, 'ngf': 4}, True)
+    Ds = [networks.define_D(1, 8, 'basic', 3, 'batch', 'normal', 0.02, []) for _ in range(3)]
+    mk = lambda: R.StepState(G.state_dict(), [d.state_dict() for d in Ds])
+    b0 = synth.to_model_inputs(synth.make_batch(2, 64, seed=1))
+    b1 = synth.to_model_inputs(synth.make_batch(2, 64, seed=2))
+    single = mk()
+    R.pix2pix_step(single, b0)
+    a, b = mk(), mk()
+    R.pix2pix_step_data_parallel([a, b], [b0, b0])
+    for k in single.g_params:
+        assert torch.equal(single.g[k], a.g[k]) and torch.equal(a.g[k], b.g[k]), k
+    a, b = mk(), mk()
+    R.pix2pix_step_data_parallel([a, b], [b0, b1])
+    diff = 0
+    for k in single.g_params:
+        assert torch.equal(a.g[k], b.g[k]) and torch.equal(a.g[k].grad, b.g[k].grad), k
+        diff += int(not torch.equal(a.g[k], single.g[k]))
+    assert diff > 0
+    for d in range(3):
+        for k in a.d_params[d]:
+            assert torch.equal(a.d[d][k], b.d[d][k]), (d, k)
 
 
 def test_infer_prepare_slice_matches_reference_network_inputs():

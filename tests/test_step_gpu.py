@@ -25,6 +25,21 @@ def _sparse(t, step=8):
     return t.detach()[..., ::step, ::step].cpu()
 
 
+# max-abs <= 1e-3 on CONTINUOUS tensors; a mismatch fraction only for tensors behind a threshold (fine_seg > 0.5 and
+# what is computed from it) or behind the ceil() of the SHRM row bounds (composited images: a height that lands on the other side of an
+# integer moves one row of the paste)
+CONTINUOUS = ('x_stage1', 'fake_B_raw', 'coarse_seg_sigmoid', 'fake_B_mask_sigmoid', 'real_edges')
+
+
+def check_activation(name, got, ref, tol=1e-3, frac_tol=1e-4, ctx=()):
+    d = (got.detach().cpu().float() - ref.detach().cpu().float()).abs()
+    if name in CONTINUOUS:
+        assert d.max().item() <= tol, ctx + (name, 'max-abs', d.max().item())
+    else:
+        frac = (d > tol).float().mean().item()
+        assert frac <= frac_tol, ctx + (name, 'mismatch fraction', frac, d.max().item())
+
+
 @pytest.mark.parametrize('precision,loss_tol,norm_tol', [('fp32', 2e-3, 1e-3), ('fp16', 6e-3, 4e-3)])
 def test_g5_two_train_steps_match_reference_golden(precision, loss_tol, norm_tol, monkeypatch):
     """fp32 = exact-fp32 MFMA parity mode.  fp16 = the benchmarked mode (fp16 MFMA operands, fp32 accumulate/storage): it
@@ -53,12 +68,8 @@ def test_g5_two_train_steps_match_reference_golden(precision, loss_tol, norm_tol
             tol = loss_tol * max(1.0, abs(ref))
             assert abs(losses[k] - ref) <= tol, (step, k, losses[k], ref)
         for k, ref in g['samples%d' % step].items():
-            got = _sparse(getattr(model, k))
-            if k in ('fake_edges',):
-                assert ((got - ref).abs() > 1e-3).float().mean().item() <= 2e-3, k
-            else:
-                frac = ((got - ref).abs() > 1e-3).float().mean().item()
-                assert frac <= 1e-3, (step, k, (got - ref).abs().max().item(), frac)
+            # fp16 operands can move fine_seg across 0.5 at a pixel or two of the 2048 sampled ones (edges follow the thresholded mask)
+            check_activation(k, _sparse(getattr(model, k)), ref, frac_tol=1e-4 if precision == 'fp32' else 2e-3, ctx=(precision, step))
         ph = torch.cat([model.pred1_h, model.pred2_h]).cpu()
         assert (ph - g['pred_h%d' % step]).abs().max().item() <= 1e-2
         for key, ref in g['norms%d' % step].items():
@@ -143,13 +154,13 @@ def test_benchmark_configuration_bs16_matches_live_oracle(precision, loss_tol, a
     got = model.get_current_losses()
     for k, ref in losses.items():
         assert abs(got[k] - ref) <= loss_tol * max(1.0, abs(ref)), (k, got[k], ref)
-    for name in ('fake_B', 'fake_B_coarse', 'x_stage1'):
-        a, b = getattr(model, name).detach().cpu(), outs[name].detach()
-        frac = ((a - b).abs() > act_tol).float().mean().item()
-        assert frac <= 1e-3, (name, (a - b).abs().max().item(), frac)
+    for name in ('fake_B', 'fake_B_coarse', 'x_stage1', 'fake_B_raw', 'coarse_seg_sigmoid', 'fake_B_mask_sigmoid', 'fake_B_local'):
+        ref = outs[{'coarse_seg_sigmoid': 'coarse_seg', 'fake_B_mask_sigmoid': 'fine_seg'}.get(name, name)]
+        check_activation(name, getattr(model, name), ref, tol=act_tol, ctx=(precision,))
     # parameter gradients (relative L2 error per tensor) and, in the exact-fp32 mode, the parameters after the Adam step (Adam's first
     # step moves every weight by ~lr*sign(g): a sign flip of a round-off-level gradient shows as 2*lr, so only a small fraction may differ)
-    gtol = 2e-3 if precision == 'fp32' else 1e-1      # fp16 operands: the layers behind the attention soft-max see 5 % (observed), the rest < 1 %
+    # fp16 operands: observed <= 5 % on matrices (the layers behind the attention soft-max; the rest < 1 %) and <= 14 % on vectors
+    gtol, vtol = (2e-3, 2e-3) if precision == 'fp32' else (6e-2, 1.6e-1)
     for n, sd in (('G', st.g), ('D_1', st.d[0]), ('D_2', st.d[1]), ('D_3', st.d[2])):
         if n == 'D_2' and precision != 'fp32':
             continue      # D_2 is fed the thresholded mask (fine_seg > 0.5): a few flipped pixels change its input, not its arithmetic
@@ -162,15 +173,15 @@ def test_benchmark_configuration_bs16_matches_live_oracle(precision, loss_tol, a
             rel = (g - g_ref).norm().item() / max(g_ref.norm().item(), 1e-12)
             # 1-D tensors (biases, BatchNorm affine) are sums over all pixels with heavy cancellation: fp16 operand rounding upstream shows
             # up as a larger RELATIVE error there (observed up to 14 %), while the fp32 mode stays below 2e-3 everywhere
-            assert rel <= (gtol if (precision == 'fp32' or g.dim() > 1) else 0.3), (n, k, rel)
+            assert rel <= (gtol if g.dim() > 1 else vtol), (n, k, rel)
             if precision == 'fp32':
                 d = (msd[k].detach().cpu() - v.detach()).abs()
                 assert (d > 1e-4).float().mean().item() <= 2e-3, (n, k, d.max().item())
 
 
 def test_graph_recapture_when_the_batch_shape_changes(monkeypatch):
-    """A last, smaller batch of an epoch: the captured graphs are dropped, the new shape warms up eagerly and is captured again;
-    results stay those of eager launches."""
+    """A last, smaller batch of an epoch: the new shape warms up eagerly and gets its own captured graphs; when the full batch size comes
+    back its graphs (and input buffers) are still there -- every shape is captured once.  Results stay those of eager launches."""
     monkeypatch.setenv('HV_PRECISION', 'fp16')
     import hvgan
     from hvgan import synth
@@ -185,12 +196,13 @@ def test_graph_recapture_when_the_batch_shape_changes(monkeypatch):
             model.set_input(synth.make_batch(B, 256, seed=900 + step))
             model.optimize_parameters()
             seen.append(model._graphs is not None)
+            assert model.fake_B.shape[0] == B and model.get_current_visuals()['fake_B_raw'].shape[0] == B   # names follow the active shape
         torch.cuda.synchronize()
         return seen, {k: v.detach().clone() for k, v in model.netG.state_dict().items()}, model.get_current_losses()
 
     se, we, le = run(False)
     sg, wg, lg = run(True)
-    assert sg == [False, False, True, True, False, False, True, False, False, True] and not any(se)
+    assert sg == [False, False, True, True, False, False, True, True, True, True] and not any(se)
     for k in we:
         assert torch.equal(we[k], wg[k]), k
     assert le == lg
@@ -217,8 +229,95 @@ def test_step_at_512_matches_live_oracle(monkeypatch):
     got = model.get_current_losses()
     for k, ref in losses.items():
         assert abs(got[k] - ref) <= 2e-3 * max(1.0, abs(ref)), (k, got[k], ref)
-    for name in ('fake_B', 'fake_B_coarse', 'x_stage1'):
-        a, b = getattr(model, name).detach().cpu(), outs[name].detach()
-        assert a.shape == b.shape == (2, 1, 512, 512)
-        frac = ((a - b).abs() > 1e-3).float().mean().item()
-        assert frac <= 1e-3, (name, (a - b).abs().max().item(), frac)
+    for name in ('fake_B', 'fake_B_coarse', 'x_stage1', 'fake_B_raw', 'coarse_seg_sigmoid', 'fake_B_mask_sigmoid'):
+        ref = outs[{'coarse_seg_sigmoid': 'coarse_seg', 'fake_B_mask_sigmoid': 'fine_seg'}.get(name, name)]
+        assert getattr(model, name).shape == ref.shape == (2, 1, 512, 512)
+        check_activation(name, getattr(model, name), ref, ctx=(512,))
+
+
+@pytest.mark.parametrize('norm,gan_mode', [('instance', 'vanilla'), ('batch', 'lsgan'), ('instance', 'lsgan')])
+def test_train_step_instance_norm_and_lsgan_match_live_oracle(norm, gan_mode, monkeypatch):
+    """The north-star's InstanceNorm+LeakyReLU discriminators (--norm instance) and the least-squares GAN loss (--gan_mode lsgan) through a
+    FULL train step (reference pix2pix_model.py:67 `opt.norm`, networks.py:212-278), fp32 mode, against the CPU oracle on the same weights
+    and batch: 12 losses, activations, every parameter gradient, and the losses of a second step taken from the updated weights."""
+    monkeypatch.setenv('HV_PRECISION', 'fp32')
+    import hvgan
+    from hvgan import synth
+    from hvgan.models.pix2pix_model import Pix2PixModel
+    from oracle import restate as R
+    torch.manual_seed(2024)
+    model = Pix2PixModel(make_opt(norm=norm, gan_mode=gan_mode))
+    sd_g = {k: v.detach().cpu().clone() for k, v in model.netG.state_dict().items()}
+    sd_d = [{k: v.detach().cpu().clone() for k, v in getattr(model, 'netD_%d' % k).state_dict().items()} for k in (1, 2, 3)]
+    st = R.StepState(sd_g, sd_d, lr=2e-4, beta1=0.5, norm=norm, gan_mode=gan_mode, lambda_l1=200.0)
+    for step in range(2):
+        raw = synth.make_batch(2, 256, seed=60 + step)
+        model.set_input(raw)
+        model.optimize_parameters()
+        torch.cuda.synchronize()
+        losses, outs = R.pix2pix_step(st, synth.to_model_inputs(raw))
+        got = model.get_current_losses()
+        for k, ref in losses.items():
+            assert abs(got[k] - ref) <= (2e-3 if step == 0 else 1e-2) * max(1.0, abs(ref)), (step, k, got[k], ref)
+        if step:
+            break
+        for name in ('fake_B', 'x_stage1', 'fake_B_raw', 'coarse_seg_sigmoid', 'fake_B_mask_sigmoid'):
+            ref = outs[{'coarse_seg_sigmoid': 'coarse_seg', 'fake_B_mask_sigmoid': 'fine_seg'}.get(name, name)]
+            check_activation(name, getattr(model, name), ref, ctx=(norm, gan_mode))
+        for n, sd in (('G', st.g), ('D_1', st.d[0]), ('D_2', st.d[1]), ('D_3', st.d[2])):
+            params = dict(getattr(model, 'net' + n).named_parameters())
+            for k, v in sd.items():
+                if v.dtype != torch.float32 or getattr(v, 'grad', None) is None:
+                    continue
+                g_ref, g = v.grad.detach(), params[k].grad.detach().cpu()
+                rel = (g - g_ref).norm().item() / max(g_ref.norm().item(), 1e-12)
+                assert rel <= 2e-3, (norm, gan_mode, n, k, rel)
+
+
+def test_unet_ct_mask_full_size_config1_matches_live_oracle(monkeypatch):
+    """BASELINE config #1 at its real size: UnetG_CT_mask.define_G(3, 1, 64, ...) -- ngf=64, so the 512/1024-channel
+    conv-transpose layers the mini fixture (G6, ngf=4 at 64^2) never reaches -- one 256x256 slice, pix2pix L1 loss, forward + backward +
+    BatchNorm running statistics against the CPU oracle (oracle.restate.unet_forward, pinned by G6) on the same seeded weights."""
+    monkeypatch.setenv('HV_PRECISION', 'fp32')
+    import hvgan  # noqa: F401
+    from hvgan.models.UnetG_CT_mask import define_G
+    from oracle import restate as R
+    torch.manual_seed(64)
+    net = define_G(3, 1, 64, 'unet_256', 'batch', False, 'normal', 0.02, [])
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(1, 3, 256, 256, generator=g) * 2 - 1
+    tgt = torch.rand(1, 1, 256, 256, generator=g) * 2 - 1
+    dev = torch.device('cuda:0')
+    net.cuda().train()
+    net.precision = 'fp32'
+    ct, mk = net(x.to(dev))
+    loss = (ct - tgt.to(dev)).abs().mean()          # criterionL1 of the reference (pix2pix_model.py:125)
+    loss.backward()
+    torch.cuda.synchronize()
+    params = [k for k in sd if (k.endswith('.weight') or k.endswith('.bias'))]
+    for k in params:
+        sd[k].requires_grad_(True)
+    (rct, rmk), upd = R.unet_forward(sd, x, 5, True)
+    rloss = (rct - tgt).abs().mean()
+    rloss.backward()
+    assert (ct.detach().cpu() - rct.detach()).abs().max().item() <= 1e-3
+    assert (mk.detach().cpu() - rmk.detach()).abs().max().item() <= 1e-3
+    assert abs(loss.item() - rloss.item()) <= 1e-4
+    got = dict(net.named_parameters())
+    for k in params:
+        ref = sd[k].grad
+        if ref is None:          # the mask decoder gets no gradient from an L1 loss on the CT output
+            continue
+        rel = (got[k].grad.detach().cpu() - ref).norm().item() / max(ref.norm().item(), 1e-12)
+        assert rel <= 2e-3, (k, rel)
+    now = net.state_dict()
+    for k, v in upd.items():
+        assert (now[k].detach().cpu().double() - v.double()).abs().max().item() <= 1e-4, k
+    net.eval()
+    with torch.no_grad():
+        cte, mke = net(x.to(dev))
+        for k, v in upd.items():
+            sd[k] = v
+        (rcte, rmke), _ = R.unet_forward({k: v.detach() for k, v in sd.items()}, x, 5, False)
+    assert (cte.cpu() - rcte).abs().max().item() <= 1e-3 and (mke.cpu() - rmke).abs().max().item() <= 1e-3
