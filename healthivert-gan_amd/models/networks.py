@@ -351,7 +351,8 @@ class NLayerDiscriminator(nn.Module):
         if torch.is_grad_enabled() and (input.requires_grad or any(p.requires_grad for p in self.parameters())):
             B, _, H, W = input.shape
             P = self.run_forward(input, slot=self._free_plan_slot(B, H, W, input.device))
-            return _DiscFn.apply(input, self, P, P.logits)
+            anchor = next((p for p in self.parameters() if p.requires_grad), None)   # carries the graph edge when only the weights need gradients
+            return _DiscFn.apply(input, anchor, self, P, P.logits)
         return self.run_forward(input).logits.clone()
 
 
@@ -371,7 +372,7 @@ def grads_are_fresh(net):
 
 class _DiscFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, net, plan, logits):
+    def forward(ctx, x, anchor, net, plan, logits):
         import weakref
         ctx.net, ctx.plan, ctx.need_dx = net, plan, x.requires_grad
         ctx.token = _PlanToken()
@@ -391,4 +392,4 @@ class _DiscFn(torch.autograd.Function):
         if pg:
             net.finish()
         plan.pending = None
-        return (dx.clone() if dx is not None else None), None, None, None
+        return (dx.clone() if dx is not None else None), None, None, None, None

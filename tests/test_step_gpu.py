@@ -269,9 +269,13 @@ def test_train_step_instance_norm_and_lsgan_match_live_oracle(norm, gan_mode, mo
             for k, v in sd.items():
                 if v.dtype != torch.float32 or getattr(v, 'grad', None) is None:
                     continue
+                if norm == 'instance' and n != 'G' and k in ('model.2.bias', 'model.5.bias', 'model.8.bias'):
+                    # a conv bias in front of an InstanceNorm (no affine) has an exactly-zero true gradient -- the norm removes the
+                    # per-channel mean: both sides hold uncorrelated round-off noise of the sums there, nothing to compare
+                    continue
                 g_ref, g = v.grad.detach(), params[k].grad.detach().cpu()
-                rel = (g - g_ref).norm().item() / max(g_ref.norm().item(), 1e-12)
-                assert rel <= 2e-3, (norm, gan_mode, n, k, rel)
+                err = (g - g_ref).norm().item()
+                assert err <= 2e-3 * g_ref.norm().item(), (norm, gan_mode, n, k, err, g_ref.norm().item())
 
 
 def test_unet_ct_mask_full_size_config1_matches_live_oracle(monkeypatch):
