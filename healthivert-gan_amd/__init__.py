@@ -9,5 +9,5 @@ __version__ = "0.1.0"
 from . import synth  # noqa: E402,F401  (numpy only)
 from . import lib  # noqa: E402,F401  (ctypes binding; loads libhvgan.so lazily)
 from . import ops  # noqa: E402,F401
-from . import engine, optim, ddp, profiler, evaluation  # noqa: E402,F401
+from . import engine, optim, ddp, profiler, evaluation, eval_metrics  # noqa: E402,F401
 from . import models  # noqa: E402,F401  (drop-in mirror of the reference's `models` package)

@@ -367,5 +367,23 @@ extern "C" int hv_affine(float* y, const float* x, long long n, float a, float b
     return HV_OK;
 }
 
-extern "C" int hv_version(void) { return 100; }
+__global__ void mul_kernel(float* y, const float* x, const float* z, long long n) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long st = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += st) y[i] = z ? (y[i] * x[i]) * z[i] : y[i] * x[i];
+}
+extern "C" int hv_mul(float* y, const float* x, long long n, void* stream) {
+    if (!y || !x || n <= 0) return HV_ERR_ARG;
+    hipLaunchKernelGGL(mul_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, y, x, (const float*)nullptr, n);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+extern "C" int hv_mul3(float* y, const float* x, const float* z, long long n, void* stream) {
+    if (!y || !x || !z || n <= 0) return HV_ERR_ARG;
+    hipLaunchKernelGGL(mul_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, y, x, z, n);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+
+extern "C" int hv_version(void) { return 101; }
 extern "C" const char* hv_arch(void) { return "gfx950"; }

@@ -78,6 +78,28 @@ def parse_header(path=HEADER):
     return structs, protos
 
 
+_CTYPES_NAME = {ctypes.c_int: 'ctypes.c_int', ctypes.c_float: 'ctypes.c_float', ctypes.c_double: 'ctypes.c_double',
+                ctypes.c_longlong: 'ctypes.c_longlong', ctypes.c_size_t: 'ctypes.c_size_t', ctypes.c_void_p: 'ctypes.c_void_p',
+                ctypes.c_char_p: 'ctypes.c_char_p', ctypes.c_char: 'ctypes.c_char'}
+
+
+def ctypes_source(struct_name, path=HEADER, width=118):
+    """Python source of the ctypes mirror of one struct of include/hvgan.h, generated from the header: the snippet INTEGRATION.md shows
+    a maintainer of the reference (tools/gen_integration_stub.py writes it there; tests/test_host_cpu.py checks the two agree)."""
+    structs, _ = parse_header(path)
+    fields = ['("%s", %s)' % (n, _CTYPES_NAME[t]) for n, t in structs[struct_name]._fields_]
+    lines, cur = [], '    _fields_ = ['
+    for i, f in enumerate(fields):
+        piece = f + (', ' if i + 1 < len(fields) else ']')
+        if len(cur) + len(piece) > width:
+            lines.append(cur.rstrip())
+            cur = ' ' * 16
+        cur += piece
+    lines.append(cur)
+    return 'class %s(ctypes.Structure):          # generated from include/hvgan.h (healthivert-gan_amd/lib.py: ctypes_source)\n%s\n' % (
+        struct_name, '\n'.join(lines))
+
+
 class HipLibraryMissing(RuntimeError):
     pass
 

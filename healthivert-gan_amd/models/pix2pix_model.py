@@ -262,8 +262,10 @@ class Pix2PixModel(BaseModel):
             mc[:, :, :, W // 2 - self.half_band:W // 2 + self.half_band] = 1
             self._bufs[('mc', (B, 1, H, W))] = mc
         out = self._buf('real_B_local_early', self.real_B)
-        torch.mul(self.mask, self.real_B, out=out)
-        out.mul_(mc)
+        n = ctypes.c_longlong(out.numel())
+        L = _lib.get()
+        L.call('hv_affine', ptr(out), ptr(self.mask), n, ctypes.c_float(1.0), ctypes.c_float(0.0), stream())
+        L.call('hv_mul3', ptr(out), ptr(self.real_B), ptr(mc), n, stream())      # (mask * real_B) * band, the reference's order
         return out
 
     def backward_D_1(self):

@@ -286,6 +286,20 @@ int hv_threshold(const float* x, float* y, long long n, float thr, float value, 
 int hv_fill(float* p, long long n, float value, void* stream);
 int hv_axpy(float* y, const float* x, long long n, float a, void* stream); /* y += a*x */
 int hv_affine(float* y, const float* x, long long n, float a, float b, void* stream); /* y = a*x + b (e.g. 1 - CAM) */
+int hv_mul(float* y, const float* x, long long n, void* stream);                  /* y *= x (pred_h = pred * maxheight) */
+int hv_mul3(float* y, const float* x, const float* z, long long n, void* stream); /* y = (y*x)*z (mask * image * centre band, pix2pix_model.py:254-263) */
+
+/* ---- in-training evaluation metrics (reference train.py:37-48 dice_score / iou_score, :101-141 per-sample body of evaluate_model;
+ * SURVEY.md section 8f row f3).  All images (B,1,H,W) fp32: `inpainted` = the SHRM-composited stage-2 output (hv_shrm_composite with
+ * pred_h = pred2*maxheight), gt = real_B, coarse_bin / fine_bin = (seg > 0.5) (hv_threshold), normal_vert / label / mask as loaded;
+ * pred_h [B] fp32, height [B] int64.  out[B][5] = { SSIM(gt*mask, inpainted*mask; data_range = max(inpainted) - min(inpainted)),
+ * PSNR(gt*mask, inpainted*mask; data_range = max(inpainted) - min(gt)), dice(coarse_bin, normal_vert), iou(fine_bin, label),
+ * |pred_h - height| / height * 100 }.  SSIM / PSNR follow scikit-image 0.22's published algorithm (7x7 uniform window, sample
+ * covariance, K1 0.01, K2 0.03, 3-pixel border cropped; float64 means) -- see csrc/eval_metrics.hip. */
+size_t hv_eval_metrics_workspace_bytes(int B, int H, int W);
+int hv_eval_metrics(const float* inpainted, const float* gt, const float* mask, const float* coarse_bin, const float* normal_vert,
+                    const float* fine_bin, const float* label, const float* pred_h, const long long* height, int B, int H, int W, float* out,
+                    void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- RHLV quantification (reference evaluation/RHLV_quantification.py:41-147,160-178) ----
  * fake / label: straightened label volumes of the generated and the original vertebra, element (h, w, z) at

@@ -135,6 +135,31 @@ def test_gradient_averaging_two_ranks_gloo():
         assert p.returncode == 0 and b'ok' in out, out.decode()[-2000:]
 
 
+def test_integration_doc_struct_matches_header():
+    """The ctypes structs INTEGRATION.md shows a maintainer are generated from include/hvgan.h (tools/gen_integration_stub.py): the
+    documented `_fields_` must equal what the product's own header parse yields, field for field -- a short struct would make the
+    library read pointers from garbage."""
+    import ctypes
+    import re
+    import hvgan  # noqa: F401
+    from hvgan import lib
+    text = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    blocks = re.findall(r'# >>> generated: (\w+)\n(.*?)# <<< generated', text, flags=re.S)
+    assert blocks, 'INTEGRATION.md has no generated struct block'
+    structs, _ = lib.parse_header()
+    for name, src in blocks:
+        assert src == lib.ctypes_source(name), 'INTEGRATION.md block for %s is stale: run python tools/gen_integration_stub.py' % name
+        ns = {'ctypes': ctypes}
+        exec(src, ns)
+        doc = ns[name]
+        assert [(n, t) for n, t in doc._fields_] == [(n, t) for n, t in structs[name]._fields_], name
+        assert ctypes.sizeof(doc) == ctypes.sizeof(structs[name])
+    # the example call in the same file names only fields the struct has, and all of them
+    call = re.search(r'd = hv_conv_desc\((.*?)\)\n    rc', text, flags=re.S).group(1)
+    used = set(re.findall(r'(\w+)=', call))
+    assert used == {n for n, _ in structs['hv_conv_desc']._fields_}, used ^ {n for n, _ in structs['hv_conv_desc']._fields_}
+
+
 def test_bench_starts_its_own_ranks_dry_run():
     """`python bench.py --gpus 2` from a plain shell (WORLD_SIZE unset) must start two ranks itself and report n_gpus == 2; the
     --dry-run form rehearses exactly that plumbing over gloo on the CPU: launcher, rendezvous on 127.0.0.1, the flat-gradient mean of

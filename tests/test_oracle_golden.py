@@ -201,3 +201,44 @@ def test_g10_inference_slice_oracle_matches_reference_run_model():
         assert np.array_equal(np.asarray(ctf, dtype=np.float64), exp['ct_fake']), name
         n += 1
     assert n >= 6
+
+
+def g11_cases():
+    """(name, model-attribute batch, fake generator outputs, expected dict) for fixture G11 (oracle/make_golden_eval.py)."""
+    import numpy as np
+    import hvgan  # noqa: F401
+    from hvgan import synth
+    from oracle.make_golden_eval import fake_generator_outputs
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'g11_eval.npz'))
+    for name, (B, bseed, oseed) in zip(g['cases'], g['params']):
+        name = str(name)
+        b = synth.to_model_inputs(synth.make_batch(int(B), 256, seed=int(bseed)))
+        outs = fake_generator_outputs(b, int(oseed), name.endswith('tall'))
+        exp = {k[len(name) + 1:]: g[k] for k in g.files if k.startswith(name + '/')}
+        yield name, b, outs, exp
+
+
+def test_g11_eval_metrics_oracle_matches_reference_evaluate_model():
+    """oracle.restate.eval_sample_metrics == the reference's evaluate_model (train.py:50-160) on fixture G11: Dice, IoU and the height
+    error are the reference's own arithmetic; for SSIM / PSNR (skimage: restated, parity unpinned) the fixture pins what the reference
+    feeds them -- the masked, composited operands (checksums + sparse samples) and both data_range values."""
+    import numpy as np
+    for name, b, outs, exp in g11_cases():
+        coarse, fine, _, stage2, _, _, pred2 = outs
+        m, inp = R.eval_sample_metrics(stage2, fine, coarse, pred2, b)
+        assert np.allclose(m[:, 2:], exp['per_sample'][:, 2:], rtol=1e-6, atol=1e-7), name        # dice, iou, diff_h: reference code
+        assert np.allclose(m[:, :2], exp['per_sample'][:, :2], rtol=1e-9), name                   # same restated functions both sides
+        assert np.allclose(m.mean(0), exp['avg'], rtol=1e-5), name
+        for i in range(inp.shape[0]):
+            gt, mk, x = b['real_B'][i].numpy(), b['mask'][i].numpy(), inp[i].numpy()
+            a, y = (gt * mk).squeeze(), (x * mk).squeeze()
+            ops = exp['operands'][i]
+            assert abs(a.astype(np.float64).sum() - ops[0]) <= 1e-9 * max(1, abs(ops[0])) and abs(y.astype(np.float64).sum() - ops[1]) <= 1e-9 * max(1, abs(ops[1]))
+            assert abs(float(x.max() - x.min()) - ops[3]) <= 1e-7 and abs(float(x.max() - gt.min()) - ops[4]) <= 1e-7
+            assert np.array_equal(y[::4, ::4], exp['masked_result_sparse/%d' % i]), (name, i)
+    # a hand case for the SSIM restatement: identical images give 1, and the published closed form on constant images
+    a = np.full((16, 16), 0.25, np.float32)
+    assert abs(R.eval_ssim(a, a, 1.0) - 1.0) < 1e-7
+    c = np.full((16, 16), 0.75, np.float32)
+    want = (2 * 0.25 * 0.75 + 1e-4) / (0.25 ** 2 + 0.75 ** 2 + 1e-4)       # variances vanish: S = luminance term
+    assert abs(R.eval_ssim(a, c, 1.0) - want) < 1e-6
