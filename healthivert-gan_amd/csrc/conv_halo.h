@@ -13,12 +13,13 @@ struct HaloCls {
     uint32_t taps[25];   // (dh-dh_min) | (dw-dw_min)<<8 | widx<<16   (conv_halo_kernel: at most 16, conv_halo2_kernel: up to 5x5)
 };
 struct HaloK {
-    const float* x; const _Float16* w; const float* bias; float* y;
+    const void* x; const _Float16* w; const float* bias; void* y;      // x / y: fp32 or fp16 elements (x_half / y_half)
     int B, Hl, Wl, in_shift, Wp, img_stride, x_ld, x_coff, Cin;
     int Cout, w_row, y_ld, y_coff, Ho, Wo;
     int bstep, boff, ostep;
     float alpha; int act, accumulate, vec_store, ncls;
-    const float* mul_src; int mul_ld, mul_coff, mul_act, mul_vec;   // epilogue factor act'(mul_src[..]) or NULL; mul_vec: 16-B loads are aligned
+    const void* mul_src; int mul_ld, mul_coff, mul_act, mul_vec;   // epilogue factor act'(mul_src[..]) or NULL; mul_vec: vector loads are aligned
+    int x_half, y_half, mul_half;
     unsigned x_bytes, w_bytes;   // buffer descriptor ranges
     HaloCls cls[4];
 };

@@ -15,8 +15,9 @@
 
 #include "conv_halo.h"
 
-template <int TH, int TW, int BN, int WM, int WN, int TG, int CK, int PMAX>
+template <int TH, int TW, int BN, int WM, int WN, int TG, int CK, int PMAX, bool XH>
 __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloK p) {
+    typedef HvSt<XH> XS;                         // storage of the input tensor: fp32 (converted when staged) or fp16 (staged as it is)
     constexpr int BM = TH * TW;
     // halfs per patch pixel / weight row.  With 16-B fragments, a 96-B row stride (CK 32 + 16 pad) maps the 16 lanes of every
     // ds_read_b128 lane group onto all 64 banks exactly once for unit-step pixel reads; stride-2 reads prefer 80 B.
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloK p) {
     const int n_base = blockIdx.y * BN;
     // input coordinate of patch pixel (0,0)
     const int h0 = i0 * p.bstep + p.boff + C.dh_min, w0 = j0 * p.bstep + p.boff + C.dw_min;
-    const float* ximg = p.x + (long long)n_img * p.img_stride + p.x_coff;
+    const void* ximg = hv_eptr(p.x, (long long)n_img * p.img_stride + p.x_coff, XH);
     const int npatch = PH * PW;
     const int wm = wave / WN, wn = wave % WN;
 
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloK p) {
     // offsets are computed once, the tap/chunk part of the address is a scalar buffer offset, rows beyond Cout get an
     // out-of-range offset (the descriptor's range check returns zeros) instead of a branch.
     const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.w), 0, p.w_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
     unsigned wvo[WLOADS];                                    // byte offset of (row n, vector) inside w, without tap / chunk
     int wlo[WLOADS];                                         // LDS offset (halfs) inside one weight buffer, -1 = no element
     int wtg[WLOADS];                                         // tap-in-group of the element
@@ -114,10 +115,10 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloK p) {
     // with the chunk as scalar offset), large ones staged synchronously
     constexpr int PV = CK / 4;
     const bool patch_pf = npatch * PV <= PMAX * 256;
-    u32x4 preg[PMAX];
+    typename XS::R preg[PMAX];
     unsigned pvo[PMAX];          // byte offset of (patch pixel, channel quad) in x, HV_OOB outside the image / patch
     int plo[PMAX];               // LDS offset (halfs), -1 = no element
-    const unsigned xbase = (unsigned)(n_img * p.img_stride + p.x_coff) * 4u;
+    const unsigned xbase = (unsigned)(n_img * p.img_stride + p.x_coff) * XS::B;
     if (patch_pf) {
 #pragma unroll
         for (int i = 0; i < PMAX; ++i) {
@@ -128,20 +129,18 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloK p) {
             const bool in = e < npatch * PV;
             plo[i] = in ? pix * LDP + c4 * 4 : -1;
             pvo[i] = (in && (unsigned)hi < (unsigned)p.Hl && (unsigned)wi < (unsigned)p.Wl)
-                         ? xbase + (unsigned)(((hi >> p.in_shift) * p.Wp + (wi >> p.in_shift)) * p.x_ld + c4 * 4) * 4u : HV_OOB;
+                         ? xbase + (unsigned)(((hi >> p.in_shift) * p.Wp + (wi >> p.in_shift)) * p.x_ld + c4 * 4) * XS::B : HV_OOB;
         }
     }
     auto ppref = [&](int c0) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < PMAX; ++i) preg[i] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, pvo[i], c0 * 4, 0);
+        for (int i = 0; i < PMAX; ++i) preg[i] = XS::ld(xsrc, pvo[i], c0 * (int)XS::B);
     };
     auto pflush = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < PMAX; ++i) {
             if (plo[i] < 0) continue;
-            f16x4v h = {(_Float16)__uint_as_float(preg[i].x), (_Float16)__uint_as_float(preg[i].y),
-                        (_Float16)__uint_as_float(preg[i].z), (_Float16)__uint_as_float(preg[i].w)};
-            *reinterpret_cast<f16x4v*>(patch + plo[i]) = h;
+            *reinterpret_cast<f16x4v*>(patch + plo[i]) = XS::h4(preg[i]);
         }
     };
     auto pload1 = [&](int e, int c0) -> float4 {
@@ -150,7 +149,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloK p) {
         const int hi = h0 + py, wi = w0 + px;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if ((unsigned)hi < (unsigned)p.Hl && (unsigned)wi < (unsigned)p.Wl)
-            v = *reinterpret_cast<const float4*>(ximg + (long long)((hi >> p.in_shift) * p.Wp + (wi >> p.in_shift)) * p.x_ld + c0 + c4 * 4);
+            v = hv_ld4(ximg, (long long)((hi >> p.in_shift) * p.Wp + (wi >> p.in_shift)) * p.x_ld + c0 + c4 * 4, XH);
         return v;
     };
     auto pstore1 = [&](int e, float4 v) {
@@ -206,7 +205,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloK p) {
     }
 
     // ---- epilogue (same contract as conv_igemm_kernel)
-    const HvEpi epi = {p.alpha, p.act, p.accumulate, p.vec_store, p.Cout, p.bias, nullptr, p.mul_act, p.mul_vec};
+    const HvEpi epi = {p.alpha, p.act, p.accumulate, p.vec_store, p.Cout, p.bias, nullptr, p.mul_act, p.mul_vec, p.y_half, p.mul_half};
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int g = wm * MT + m, ty = g / GX, tx = (g % GX) * 16 + (lane & 15);
@@ -214,21 +213,22 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloK p) {
         if (i >= C.Hc || j >= C.Wc) continue;
         const int ho = C.ph + i * p.ostep, wo = C.pw + j * p.ostep;
         const long long opix = (long long)(n_img * p.Ho + ho) * p.Wo + wo;
-        float* yp = p.y + opix * p.y_ld + p.y_coff;
+        void* yp = hv_eptr(p.y, opix * p.y_ld + p.y_coff, p.y_half);
+        const void* mp = p.mul_src ? hv_eptr(p.mul_src, opix * p.mul_ld + p.mul_coff, p.mul_half) : nullptr;
 #pragma unroll
         for (int nn = 0; nn < NT; ++nn) {
             const int ch0 = n_base + wn * (BN / WN) + nn * 16 + (lane >> 4) * 4;
-            hv_conv_epilogue4(epi, acc[nn][m], ch0, yp, p.mul_src ? p.mul_src + opix * p.mul_ld + p.mul_coff : nullptr);
+            hv_conv_epilogue4(epi, acc[nn][m], ch0, yp, mp);
         }
     }
 }
 
-template <int TH, int TW, int BN, int WM, int WN, int TG, int CK, int PMAX>
-static int launch_halo(const HaloK& k, int tiles, int maxpatch, hipStream_t s) {
+template <int TH, int TW, int BN, int WM, int WN, int TG, int CK, int PMAX, bool XH>
+static int launch_halo_t(const HaloK& k, int tiles, int maxpatch, hipStream_t s) {
     constexpr int LDP = CK + ((CK == 32 && PMAX < 16) ? 16 : 8);
     const size_t lds = (size_t)(2 * TG * BN * LDP + maxpatch * LDP) * sizeof(_Float16);
     if (lds > 150 * 1024) return HV_ERR_UNSUPPORTED;
-    auto kern = conv_halo_kernel<TH, TW, BN, WM, WN, TG, CK, PMAX>;
+    auto kern = conv_halo_kernel<TH, TW, BN, WM, WN, TG, CK, PMAX, XH>;
     static int lds_limit = 48 * 1024;   // per instantiation: raise the dynamic-LDS cap once (not a stream operation)
     if ((int)lds > lds_limit) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
@@ -237,10 +237,14 @@ static int launch_halo(const HaloK& k, int tiles, int maxpatch, hipStream_t s) {
     }
     dim3 grid(tiles, hv_cdiv(k.Cout, BN));
     hv_path_note = 2;
-    HV_KNAME("conv_halo_kernel<%d, %d, %d, %d, %d, %d, %d, %d>", TH, TW, BN, WM, WN, TG, CK, PMAX);
+    HV_KNAME("conv_halo_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %s>", TH, TW, BN, WM, WN, TG, CK, PMAX, XH ? "true" : "false");
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, k);
     HV_LAUNCH_CHECK();
     return HV_OK;
+}
+template <int TH, int TW, int BN, int WM, int WN, int TG, int CK, int PMAX>
+static int launch_halo(const HaloK& k, int tiles, int maxpatch, hipStream_t s) {
+    return launch_halo_t<TH, TW, BN, WM, WN, TG, CK, PMAX, true>(k, tiles, maxpatch, s);
 }
 
 template <int TH, int TW, int CK, bool S2>
@@ -272,13 +276,16 @@ static int dispatch_halo_bn(HaloK& k, int maxpatch, hipStream_t s) {
 int hv_conv2d_halo(const hv_conv_desc* d, const void* w_f16, hipStream_t s) {
     if (d->dil != 1 || (d->Cin & 3) || d->w_bstride || d->ch_scale || d->KH * d->KW > 25 || d->stride > 2) return HV_ERR_UNSUPPORTED;
     if ((d->x_ld & 3) || (d->x_coff & 3) || ((uintptr_t)d->x & 15) || ((uintptr_t)w_f16 & 15)) return HV_ERR_UNSUPPORTED;
+    if (!d->x_f16) return HV_ERR_UNSUPPORTED;      // halo-tiled kernels are built for fp16 storage (an fp32 input with fp16 operands: gather kernel)
     HaloK k;
+    k.x_half = d->x_f16 ? 1 : 0; k.y_half = d->y_f16 ? 1 : 0; k.mul_half = d->mul_f16 ? 1 : 0;
+    const size_t xs = k.x_half ? 2 : 4;
     const int Hp = d->H >> d->in_shift, Wp = d->W >> d->in_shift;
     k.x = d->x; k.w = (const _Float16*)w_f16; k.bias = d->bias; k.y = d->y;
     k.B = d->B; k.Hl = d->H; k.Wl = d->W; k.in_shift = d->in_shift; k.Wp = Wp; k.img_stride = Hp * Wp * d->x_ld;
     k.x_ld = d->x_ld; k.x_coff = d->x_coff; k.Cin = d->Cin;
     if ((long long)d->B * k.img_stride >= (1ll << 29) || (long long)d->Cout * d->KH * d->KW * d->Cin >= (1ll << 30)) return HV_ERR_UNSUPPORTED;
-    k.x_bytes = (unsigned)((size_t)d->B * k.img_stride * sizeof(float));
+    k.x_bytes = (unsigned)((size_t)d->B * k.img_stride * xs);
     k.w_bytes = (unsigned)((size_t)d->Cout * d->KH * d->KW * d->Cin * sizeof(_Float16));
     k.Cout = d->Cout; k.w_row = d->KH * d->KW * d->Cin; k.y_ld = d->y_ld; k.y_coff = d->y_coff; k.Ho = d->Ho; k.Wo = d->Wo;
     k.alpha = d->alpha; k.act = d->act; k.accumulate = d->accumulate;

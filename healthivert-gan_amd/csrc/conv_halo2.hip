@@ -35,8 +35,9 @@ template <> struct WLoad<16> {
 // SPAN = filter extent in input pixels of one class (2: stride-2 data-gradient class of a 4x4 filter, 3, 4)
 // CK = channels per staged chunk: 16 (one 16x16x16 MFMA step), 32 (one 16x16x32 step) or 64 (two steps: a lane's two
 // 16-B weight loads then consume a whole 128-B line of its filter row, and barriers halve)
-template <int TH, int TW, int BN, int WM, int WN, int CK, int BSTEP, int SPAN, int D>
+template <int TH, int TW, int BN, int WM, int WN, int CK, int BSTEP, int SPAN, int D, bool XH>
 __global__ __launch_bounds__(256, 2) void conv_halo2_kernel(const HaloK p) {   // two workgroups per CU: at most 256 registers per lane
+    typedef HvSt<XH> XS;                         // storage of the input tensor: fp32 (converted when staged) or fp16 (staged as it is)
     constexpr int NTAPS = SPAN * SPAN;
     constexpr int BM = TH * TW;
     constexpr int FK = CK == 16 ? 16 : 32;                          // channels per MFMA step
@@ -89,17 +90,17 @@ __global__ __launch_bounds__(256, 2) void conv_halo2_kernel(const HaloK p) {   /
         for (int m = 0; m < MT; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.w), 0, p.w_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
     unsigned wvo[NT];            // byte offset of this lane's filter row / k-group, without tap and chunk
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int row = n_base + wn * (BN / WN) + n * 16 + (lane & 15);
         wvo[n] = row < p.Cout ? (unsigned)((row * p.w_row + (lane >> 4) * (FK / 4)) * 2) : HV_OOB;
     }
-    u32x4 preg[PMAX];
+    typename XS::R preg[PMAX];
     unsigned pvo[PMAX];          // byte offset of (patch pixel, channel quad) in x, HV_OOB outside the image / patch
     int plo[PMAX];               // LDS offset (halfs), -1 = no element
-    const unsigned xbase = (unsigned)(n_img * p.img_stride + p.x_coff) * 4u;
+    const unsigned xbase = (unsigned)(n_img * p.img_stride + p.x_coff) * XS::B;
 #pragma unroll
     for (int i = 0; i < PMAX; ++i) {
         const int e = tid + i * 256;
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo2_kernel(const HaloK p) {   /
         const bool in = e < npatch * PV;
         plo[i] = in ? pix * LDP + c4 * 4 : -1;
         pvo[i] = (in && (unsigned)hi < (unsigned)p.Hl && (unsigned)wi < (unsigned)p.Wl)
-                     ? xbase + (unsigned)(((hi >> p.in_shift) * p.Wp + (wi >> p.in_shift)) * p.x_ld + c4 * 4) * 4u : HV_OOB;
+                     ? xbase + (unsigned)(((hi >> p.in_shift) * p.Wp + (wi >> p.in_shift)) * p.x_ld + c4 * 4) * XS::B : HV_OOB;
     }
     // ragged channel counts (Cin % CK != 0, CK == 16 only: a lane's 4 channels are all inside or all outside): lanes beyond Cin
     // read zeros through the range check, for the patch and for the filter rows alike
@@ -119,11 +120,11 @@ __global__ __launch_bounds__(256, 2) void conv_halo2_kernel(const HaloK p) {   /
 #pragma unroll
             for (int i = 0; i < PMAX; ++i) {
                 const int c4 = (tid + i * 256) % PV;
-                preg[i] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, c0 + c4 * 4 < p.Cin ? pvo[i] : HV_OOB, c0 * 4, 0);
+                preg[i] = XS::ld(xsrc, c0 + c4 * 4 < p.Cin ? pvo[i] : HV_OOB, c0 * (int)XS::B);
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < PMAX; ++i) preg[i] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, pvo[i], c0 * 4, 0);
+            for (int i = 0; i < PMAX; ++i) preg[i] = XS::ld(xsrc, pvo[i], c0 * (int)XS::B);
         }
     };
     const int kgc = (lane >> 4) * (FK / 4);          // first channel of this lane's k-group inside an MFMA step
@@ -135,9 +136,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo2_kernel(const HaloK p) {   /
 #pragma unroll
         for (int i = 0; i < PMAX; ++i) {
             if (plo[i] < 0) continue;
-            f16x4v h = {(_Float16)__uint_as_float(preg[i].x), (_Float16)__uint_as_float(preg[i].y),
-                        (_Float16)__uint_as_float(preg[i].z), (_Float16)__uint_as_float(preg[i].w)};
-            *reinterpret_cast<f16x4v*>(dst + plo[i]) = h;
+            *reinterpret_cast<f16x4v*>(dst + plo[i]) = XS::h4(preg[i]);
         }
     };
 
@@ -205,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo2_kernel(const HaloK p) {   /
     }
 
     // ---- epilogue (same contract as conv_halo_kernel)
-    const HvEpi epi = {p.alpha, p.act, p.accumulate, p.vec_store, p.Cout, p.bias, nullptr, p.mul_act, p.mul_vec};
+    const HvEpi epi = {p.alpha, p.act, p.accumulate, p.vec_store, p.Cout, p.bias, nullptr, p.mul_act, p.mul_vec, p.y_half, p.mul_half};
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int g = wm * MT + m, ty = g / GX, tx = (g % GX) * 16 + (lane & 15);
@@ -213,11 +212,12 @@ __global__ __launch_bounds__(256, 2) void conv_halo2_kernel(const HaloK p) {   /
         if (i >= C.Hc || j >= C.Wc) continue;
         const int ho = C.ph + i * p.ostep, wo = C.pw + j * p.ostep;
         const long long opix = (long long)(n_img * p.Ho + ho) * p.Wo + wo;
-        float* yp = p.y + opix * p.y_ld + p.y_coff;
+        void* yp = hv_eptr(p.y, opix * p.y_ld + p.y_coff, p.y_half);
+        const void* mp = p.mul_src ? hv_eptr(p.mul_src, opix * p.mul_ld + p.mul_coff, p.mul_half) : nullptr;
 #pragma unroll
         for (int nn = 0; nn < NT; ++nn) {
             const int ch0 = n_base + wn * (BN / WN) + nn * 16 + (lane >> 4) * 4;
-            hv_conv_epilogue4(epi, acc[nn][m], ch0, yp, p.mul_src ? p.mul_src + opix * p.mul_ld + p.mul_coff : nullptr);
+            hv_conv_epilogue4(epi, acc[nn][m], ch0, yp, mp);
         }
     }
 }
@@ -242,18 +242,18 @@ static int launch2(HaloK& k, hipStream_t s, int th0 = 8, int tw0 = TW) {
         k.cls[c].PW -= (tw0 - TW) * k.bstep;
     }
     const size_t lds = (size_t)2 * PHM * PWM * LDP * sizeof(_Float16);
-    auto kern = conv_halo2_kernel<TH, TW, BN, WM, WN, CK, BSTEP, SPAN, D>;
-    static bool raised = false;   // per instantiation: raise the dynamic-LDS cap once (not a stream operation)
-    if (lds > 48 * 1024 && !raised) {
+    auto kern = conv_halo2_kernel<TH, TW, BN, WM, WN, CK, BSTEP, SPAN, D, true>;      // fp16 storage (hv_conv2d_halo refuses fp32 inputs)
+    static bool raised[2] = {false, false};   // per instantiation: raise the dynamic-LDS cap once (not a stream operation)
+    if (lds > 48 * 1024 && !raised[k.x_half]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (e != hipSuccess) return -1000 - (int)e;
-        raised = true;
+        raised[k.x_half] = true;
     }
     // (an XCD-aware 1-D launch that runs a pixel tile's channel blocks back to back on one XCD -- the input patch fetched into one L2 -- measured
     // 98.9 vs 100.5 us on the 256 -> 512 layer and no step-level gain: this kernel is not bound by the patch fetch.  Not kept.)
     dim3 grid(tiles, hv_cdiv(k.Cout, BN));
     hv_path_note = 3;
-    HV_KNAME("conv_halo2_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %d>", TH, TW, BN, WM, WN, CK, BSTEP, SPAN, D);
+    HV_KNAME("conv_halo2_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %d, %s>", TH, TW, BN, WM, WN, CK, BSTEP, SPAN, D, k.x_half ? "true" : "false");
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, k);
     HV_LAUNCH_CHECK();
     return HV_OK;

@@ -10,13 +10,14 @@
 #include "hv_common.h"
 
 struct HeadK {
-    const float* x; const _Float16* w; float* P;
+    const void* x; const _Float16* w; float* P;        // x: fp32, or fp16 elements with the XH instantiations
     int M, tiles, x_ld, x_coff, K, ntaps, wstride;
 };
 
 // CH = 32-channel MFMA steps per pipeline item (one item's loads are in flight while the previous one is multiplied)
-template <int CH>
+template <int CH, bool XH>
 __global__ __launch_bounds__(256) void head_gemm_kernel(const HeadK p) {
+    typedef typename HvSt<XH>::R XR;               // 4 consecutive channels as loaded (16 B of fp32 or 8 B of fp16)
     extern __shared__ __attribute__((aligned(16))) _Float16 wl[];   // [16 taps][wstride], rows >= ntaps zero
     const int tid = threadIdx.x;
     {
@@ -39,25 +40,24 @@ __global__ __launch_bounds__(256) void head_gemm_kernel(const HeadK p) {
     const int nitems = (t1 - t0) * chunks;
     const _Float16* wrow = wl + col * p.wstride + g * 4;
 
-    float4 bufA[CH * 2], bufB[CH * 2];
-    auto issue = [&](float4 (&buf)[CH * 2], int it) {
+    XR bufA[CH * 2], bufB[CH * 2];
+    auto issue = [&](XR (&buf)[CH * 2], int it) {
         const int t = t0 + it / chunks, c = it - (it / chunks) * chunks;
         const int n = min(t * 16 + col, p.M - 1);
-        const float* xp = p.x + (long long)n * p.x_ld + p.x_coff + c * (32 * CH) + g * 4;
+        const char* xp = reinterpret_cast<const char*>(p.x) + ((long long)n * p.x_ld + p.x_coff + c * (32 * CH) + g * 4) * HvSt<XH>::B;
 #pragma unroll
         for (int ks = 0; ks < CH; ++ks) {
-            buf[2 * ks] = *reinterpret_cast<const float4*>(xp + ks * 32);
-            buf[2 * ks + 1] = *reinterpret_cast<const float4*>(xp + ks * 32 + 16);
+            buf[2 * ks] = *reinterpret_cast<const XR*>(xp + (ks * 32) * HvSt<XH>::B);
+            buf[2 * ks + 1] = *reinterpret_cast<const XR*>(xp + (ks * 32 + 16) * HvSt<XH>::B);
         }
     };
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    auto consume = [&](const float4 (&buf)[CH * 2], int it) {
+    auto consume = [&](const XR (&buf)[CH * 2], int it) {
         const int t = t0 + it / chunks, c = it - (it / chunks) * chunks;
 #pragma unroll
         for (int ks = 0; ks < CH; ++ks) {
-            const float4 lo = buf[2 * ks], hi = buf[2 * ks + 1];
-            const f16x8 xb = {(_Float16)lo.x, (_Float16)lo.y, (_Float16)lo.z, (_Float16)lo.w,
-                              (_Float16)hi.x, (_Float16)hi.y, (_Float16)hi.z, (_Float16)hi.w};
+            const f16x4 lo = HvSt<XH>::h4(buf[2 * ks]), hi = HvSt<XH>::h4(buf[2 * ks + 1]);
+            const f16x8 xb = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             const _Float16* wp = wrow + (c * CH + ks) * 32;
             const f16x4 w0 = *reinterpret_cast<const f16x4*>(wp), w1 = *reinterpret_cast<const f16x4*>(wp + 16);
             const f16x8 wa = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
@@ -81,19 +81,19 @@ __global__ __launch_bounds__(256) void head_gemm_kernel(const HeadK p) {
 }
 
 struct TapSumK {
-    const float* P; const float* bias; float* y; const float* mul_src;
+    const float* P; const float* bias; void* y; const void* mul_src; int y_half, mul_half;
     int B, H, W, KH, KW, stride, pad, transposed, Ho, Wo, y_ld, y_coff;
     float alpha; int act, accumulate, mul_ld, mul_coff, mul_act;
 };
 
 __device__ __forceinline__ void head_store(const TapSumK& p, long long o, float acc) {
-    float* yp = p.y + o * p.y_ld + p.y_coff;
+    const long long yi = o * p.y_ld + p.y_coff;
     float t = acc * p.alpha;
     if (p.bias) t += p.bias[0];
-    if (p.accumulate == 2) t += *yp;
+    if (p.accumulate == 2) t += hv_ld1(p.y, yi, p.y_half);
     t = hv_act(t, p.act);
-    if (p.mul_src) t *= hv_act_grad_from_out(p.mul_src[o * p.mul_ld + p.mul_coff], p.mul_act);
-    *yp = p.accumulate == 1 ? *yp + t : t;
+    if (p.mul_src) t *= hv_act_grad_from_out(hv_ld1(p.mul_src, o * p.mul_ld + p.mul_coff, p.mul_half), p.mul_act);
+    hv_st1(p.y, yi, p.accumulate == 1 ? hv_ld1(p.y, yi, p.y_half) + t : t, p.y_half);
 }
 
 // any filter / stride
@@ -199,13 +199,19 @@ int hv_conv2d_head(const hv_conv_desc* d, hipStream_t s) {
     int blocks = hv_cdiv(k.tiles, 4 * tpw);
     if (blocks < 256) blocks = hv_cdiv(k.tiles, 4);
     hv_path_note = 5;
-    HV_KNAME("head_gemm_kernel<%d>", ch);
-    if (ch == 4) hipLaunchKernelGGL((head_gemm_kernel<4>), dim3(blocks), dim3(256), lds, s, k);
-    else if (ch == 2) hipLaunchKernelGGL((head_gemm_kernel<2>), dim3(blocks), dim3(256), lds, s, k);
-    else hipLaunchKernelGGL((head_gemm_kernel<1>), dim3(blocks), dim3(256), lds, s, k);
+    HV_KNAME("head_gemm_kernel<%d, %s>", ch, d->x_f16 ? "true" : "false");
+    if (d->x_f16) {
+        if (ch == 4) hipLaunchKernelGGL((head_gemm_kernel<4, true>), dim3(blocks), dim3(256), lds, s, k);
+        else if (ch == 2) hipLaunchKernelGGL((head_gemm_kernel<2, true>), dim3(blocks), dim3(256), lds, s, k);
+        else hipLaunchKernelGGL((head_gemm_kernel<1, true>), dim3(blocks), dim3(256), lds, s, k);
+    } else {
+        if (ch == 4) hipLaunchKernelGGL((head_gemm_kernel<4, false>), dim3(blocks), dim3(256), lds, s, k);
+        else if (ch == 2) hipLaunchKernelGGL((head_gemm_kernel<2, false>), dim3(blocks), dim3(256), lds, s, k);
+        else hipLaunchKernelGGL((head_gemm_kernel<1, false>), dim3(blocks), dim3(256), lds, s, k);
+    }
     HV_LAUNCH_CHECK();
     TapSumK t;
-    t.P = k.P; t.bias = d->bias; t.y = d->y; t.mul_src = d->mul_src;
+    t.P = k.P; t.bias = d->bias; t.y = d->y; t.mul_src = d->mul_src; t.y_half = d->y_f16 ? 1 : 0; t.mul_half = d->mul_f16 ? 1 : 0;
     t.B = d->B; t.H = d->H; t.W = d->W; t.KH = d->KH; t.KW = d->KW; t.stride = d->stride; t.pad = d->pad; t.transposed = d->transposed;
     t.Ho = d->Ho; t.Wo = d->Wo; t.y_ld = d->y_ld; t.y_coff = d->y_coff;
     t.alpha = d->alpha; t.act = d->act; t.accumulate = d->accumulate; t.mul_ld = d->mul_ld; t.mul_coff = d->mul_coff; t.mul_act = d->mul_act;

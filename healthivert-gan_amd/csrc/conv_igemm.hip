@@ -42,14 +42,15 @@ struct ConvCls {
     uint32_t taps[HV_MAX_TAPS];  // dh(int8) | dw(int8)<<8 | widx<<16
 };
 struct ConvK {
-    const float* x; const float* w; const float* bias; const float* scale; float* y;
+    const void* x; const float* w; const float* bias; const float* scale; void* y;      // x / y: fp32 or fp16 elements (x_half / y_half)
+    int x_half, y_half, mul_half;
     long long w_bs, scale_bs;
     int B, Hl, Wl, in_shift, Wp, img_stride, x_ld, x_coff, Cin;
     int Cout, w_row, y_ld, y_coff, Ho, Wo;
     int bstep, boff, ostep;
     float alpha; int act, accumulate, vec_store, ncls;
     int xcd_swizzle;   // remap blockIdx.x so that each of the 8 XCDs (round-robin over the linear workgroup id) owns a CONTIGUOUS range of pixel tiles
-    const float* mul_src; int mul_ld, mul_coff, mul_act, mul_vec;   // epilogue factor act'(mul_src[..]) or NULL; mul_vec: 16-B loads are aligned
+    const void* mul_src; int mul_ld, mul_coff, mul_act, mul_vec;   // epilogue factor act'(mul_src[..]) or NULL; mul_vec: vector loads are aligned
     ConvCls cls[4];
 };
 
@@ -120,7 +121,7 @@ template <int MT, int NT> struct Frags<_Float16, MT, NT> {
 };
 
 // ------------------------------------------------------------------------------------------------ forward / transposed
-template <typename T, int BM, int BN, int WM, int WN, bool ASC>
+template <typename T, int BM, int BN, int WM, int WN, bool ASC, bool XH>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
     constexpr int LD = Stage<T>::LD;
     constexpr int APASS = BM / 32;                  // 32 rows x 8 chunks of 4 floats per pass
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (kok && (unsigned)hi < (unsigned)p.Hl && (unsigned)wi < (unsigned)p.Wl) {
                     const int off = a_nb[i] + ((hi >> p.in_shift) * p.Wp + (wi >> p.in_shift)) * p.x_ld + p.x_coff + c;
-                    v = *reinterpret_cast<const float4*>(p.x + off);
+                    v = hv_ld4(p.x, off, XH);
                 }
                 ra[i] = v;
             }
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
                     const int hi = (a_hw[i] >> 16) + dh[e4], wi = (int)(int16_t)(a_hw[i] & 0xffff) + dw[e4];
                     v[e4] = 0.f;
                     if (kok[e4] && (unsigned)hi < (unsigned)p.Hl && (unsigned)wi < (unsigned)p.Wl)
-                        v[e4] = p.x[a_nb[i] + ((hi >> p.in_shift) * p.Wp + (wi >> p.in_shift)) * p.x_ld + p.x_coff + cc[e4]];
+                        v[e4] = hv_ld1(p.x, a_nb[i] + ((hi >> p.in_shift) * p.Wp + (wi >> p.in_shift)) * p.x_ld + p.x_coff + cc[e4], XH);
                 }
                 ra[i] = make_float4(v[0], v[1], v[2], v[3]);
             }
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
 
     // ---- epilogue: lane holds channels ch0..ch0+3 of pixel (lane & 15)
     const float* scale = p.scale ? p.scale + (p.scale_bs ? (long long)sample0 * p.scale_bs : 0ll) : nullptr;
-    const HvEpi epi = {p.alpha, p.act, p.accumulate, p.vec_store, p.Cout, p.bias, scale, p.mul_act, p.mul_vec};
+    const HvEpi epi = {p.alpha, p.act, p.accumulate, p.vec_store, p.Cout, p.bias, scale, p.mul_act, p.mul_vec, p.y_half, p.mul_half};
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int mm = m_base + wm * TMW + m * 16 + (lane & 15);
@@ -282,11 +283,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
         const int ii = rem / Wc, jj = rem - ii * Wc;
         const int ho = ph + ii * p.ostep, wo = pw + jj * p.ostep;
         const long long opix = (long long)(n * p.Ho + ho) * p.Wo + wo;
-        float* yp = p.y + opix * p.y_ld + p.y_coff;
+        void* yp = hv_eptr(p.y, opix * p.y_ld + p.y_coff, p.y_half);
+        const void* mp = p.mul_src ? hv_eptr(p.mul_src, opix * p.mul_ld + p.mul_coff, p.mul_half) : nullptr;
 #pragma unroll
         for (int nn = 0; nn < NT; ++nn) {
             const int ch0 = n_base + wn * TNW + nn * 16 + (lane >> 4) * 4;
-            hv_conv_epilogue4(epi, acc[nn][m], ch0, yp, p.mul_src ? p.mul_src + opix * p.mul_ld + p.mul_coff : nullptr);
+            hv_conv_epilogue4(epi, acc[nn][m], ch0, yp, mp);
         }
     }
 }
@@ -294,8 +296,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
 template <typename T, int BM, int BN, int WM, int WN, bool ASC>
 static int launch_conv(const ConvK& k, int mtiles, hipStream_t s) {
     dim3 grid(mtiles, hv_cdiv(k.Cout, BN));
-    HV_KNAME("conv_igemm_kernel<%s, %d, %d, %d, %d, %s>", sizeof(T) == 2 ? "_Float16" : "float", BM, BN, WM, WN, ASC ? "true" : "false");
-    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN, ASC>), grid, dim3(256), 0, s, k);
+    const bool xh = sizeof(T) == 2 && k.x_half;
+    HV_KNAME("conv_igemm_kernel<%s, %d, %d, %d, %d, %s, %s>", sizeof(T) == 2 ? "_Float16" : "float", BM, BN, WM, WN, ASC ? "true" : "false", xh ? "true" : "false");
+    if constexpr (sizeof(T) == 2) {
+        if (xh) {
+            hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN, ASC, true>), grid, dim3(256), 0, s, k);
+            HV_LAUNCH_CHECK();
+            return HV_OK;
+        }
+    }
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN, ASC, false>), grid, dim3(256), 0, s, k);
     HV_LAUNCH_CHECK();
     return HV_OK;
 }
@@ -358,6 +368,7 @@ static int conv2d_dispatch(const hv_conv_desc* d, void* stream) {
     if (d->x_ld < d->x_coff + d->Cin || d->y_ld < d->y_coff + d->Cout) return HV_ERR_ARG;
     if (d->act < HV_ACT_NONE || d->act > HV_ACT_CLAMP) return HV_ERR_ARG;
     if (d->precision != HV_F32 && d->precision != HV_F16) return HV_ERR_ARG;
+    if (d->precision == HV_F32 && (d->x_f16 || d->y_f16 || d->mul_f16)) return HV_ERR_UNSUPPORTED;   // fp16 storage only under fp16 operands
     const int Hp = d->H >> d->in_shift, Wp = d->W >> d->in_shift;
     if ((long long)d->B * Hp * Wp * d->x_ld >= (1ll << 31) || (long long)d->B * d->Ho * d->Wo * d->y_ld >= (1ll << 31))
         return HV_ERR_UNSUPPORTED;
@@ -388,6 +399,7 @@ static int conv2d_dispatch(const hv_conv_desc* d, void* stream) {
         if (rc != HV_ERR_UNSUPPORTED) return rc;
     }
     ConvK k;
+    k.x_half = d->x_f16 ? 1 : 0; k.y_half = d->y_f16 ? 1 : 0; k.mul_half = d->mul_f16 ? 1 : 0;
     k.x = d->x; k.w = d->w; k.bias = d->bias; k.scale = d->ch_scale; k.y = d->y;
     k.w_bs = d->w_bstride; k.scale_bs = d->ch_scale ? d->ch_scale_bstride : 0;
     k.mul_src = d->mul_src; k.mul_ld = d->mul_ld; k.mul_coff = d->mul_coff; k.mul_act = d->mul_act;
@@ -464,7 +476,8 @@ extern "C" int hv_conv2d(const hv_conv_desc* d, void* stream) {
 // descriptor's range check returns zeros), addresses advance by a constant per pixel when the output width is a
 // power of two (FAST), and the next tile's loads are issued before this tile's MFMAs.
 struct WgradK {
-    const float* x; const float* g; float* out;
+    const void* x; const void* g; float* out;      // x / g: fp32 elements, or fp16 with the SH instantiations (half)
+    int half;
     int B, Hl, Wl, in_shift, Wp, img_stride, x_ld, x_coff, Cin;
     int Ho, Wo, g_ld, g_coff, Cout;
     int KW, stride, pad, dil, J /* taps*Cin */, M /* B*Ho*Wo */, chunk;
@@ -478,8 +491,11 @@ struct WgradK {
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define HV_OOB 0x80000000u       // beyond every descriptor range (tensors are < 2 GiB): the load returns zeros
 
-template <typename T, int BN, int BC, int WN, int WC, int KT, bool FAST>
+template <typename T, int BN, int BC, int WN, int WC, int KT, bool FAST, bool SH>
 __global__ __launch_bounds__(WN * WC * 64) void wgrad_kernel(const WgradK p) {
+    typedef HvSt<SH> SS;                         // storage of x and g: fp32 (converted when staged) or fp16
+    typedef typename SS::R SR;
+    constexpr unsigned SB = SS::B;
     constexpr int NTHR = WN * WC * 64;
     constexpr bool F16 = sizeof(T) == 2;
     // fp32: [pixel][ch] (ch contiguous, padded); fp16: [ch][pixel] (pixel contiguous, +8 pad) so that a lane
@@ -533,8 +549,8 @@ __global__ __launch_bounds__(WN * WC * 64) void wgrad_kernel(const WgradK p) {
     const int gch = n_base + g_cg * 4;
     const bool gok = has_g && gch < p.Cout;  // Cout % 4 == 0 is guaranteed by the host
 
-    const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t gsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.g), 0, p.g_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t gsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.g), 0, p.g_bytes, 0x00020000);
 
     // decode state of this thread's X items (first pixel of the run) for the non-power-of-two path; load_x is called
     // with pix_begin, pix_begin + KT, ... in order and advances it
@@ -550,23 +566,23 @@ __global__ __launch_bounds__(WN * WC * 64) void wgrad_kernel(const WgradK p) {
             xs_wo[it] = rem - xs_ho[it] * p.Wo;
         }
     }
-    u32x4 rg[8], rx[XPT][8];
+    SR rg[8], rx[XPT][8];
     auto load_g = [&](int pix0) __attribute__((always_inline)) {
         const int m0 = pix0 + g_run * 8;
         if (FAST) {   // M % 8 == 0 and chunk % KT == 0: a run is wholly inside or outside the chunk
-            unsigned off = (gok && m0 < pix_end) ? (unsigned)(m0 * p.g_ld + p.g_coff + gch) * 4u : HV_OOB;
-            const unsigned step = (unsigned)p.g_ld * 4u;
+            unsigned off = (gok && m0 < pix_end) ? (unsigned)(m0 * p.g_ld + p.g_coff + gch) * SB : HV_OOB;
+            const unsigned step = (unsigned)p.g_ld * SB;
 #pragma unroll
-            for (int e = 0; e < 8; ++e, off += step) rg[e] = __builtin_amdgcn_raw_buffer_load_b128(gsrc, off, 0, 0);
+            for (int e = 0; e < 8; ++e, off += step) rg[e] = SS::ld(gsrc, off, 0);
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const unsigned off = (gok && m0 + e < pix_end) ? (unsigned)((m0 + e) * p.g_ld + p.g_coff + gch) * 4u : HV_OOB;
-                rg[e] = __builtin_amdgcn_raw_buffer_load_b128(gsrc, off, 0, 0);
+                const unsigned off = (gok && m0 + e < pix_end) ? (unsigned)((m0 + e) * p.g_ld + p.g_coff + gch) * SB : HV_OOB;
+                rg[e] = SS::ld(gsrc, off, 0);
             }
         }
     };
-    auto load_x1 = [&](int pix0, int it, u32x4 (&r)[8]) __attribute__((always_inline)) {
+    auto load_x1 = [&](int pix0, int it, SR (&r)[8]) __attribute__((always_inline)) {
         const int m0 = pix0 + x_run[it] * 8;
         if (FAST) {   // Wo is a power of two >= 8: the 8 pixels of a run share one output row
             const int n = m0 >> p.lhw, ho = (m0 >> p.lw) & (p.Ho - 1), wo0 = m0 & (p.Wo - 1);
@@ -576,8 +592,8 @@ __global__ __launch_bounds__(WN * WC * 64) void wgrad_kernel(const WgradK p) {
             int wi = wo0 * p.stride + dw[it];
 #pragma unroll
             for (int e = 0; e < 8; ++e, wi += p.stride) {
-                const unsigned off = (rok && (unsigned)wi < (unsigned)p.Wl) ? (unsigned)(base + (wi >> p.in_shift) * p.x_ld) * 4u : HV_OOB;
-                r[e] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, off, 0, 0);
+                const unsigned off = (rok && (unsigned)wi < (unsigned)p.Wl) ? (unsigned)(base + (wi >> p.in_shift) * p.x_ld) * SB : HV_OOB;
+                r[e] = SS::ld(xsrc, off, 0);
             }
         } else if (p.Wo >= 8) {   // any output size: the run crosses an output row at most once -- two row bases, one select per pixel
             const int cross = p.Wo - xs_wo[it];                   // pixels e >= cross sit on the next output row
@@ -592,8 +608,8 @@ __global__ __launch_bounds__(WN * WC * 64) void wgrad_kernel(const WgradK p) {
                 const bool nb = e >= cross;
                 const int wi = (xs_wo[it] + e - (nb ? p.Wo : 0)) * p.stride + dw[it];
                 const bool ok = (nb ? rokB : rokA) && m0 + e < pix_end && (unsigned)wi < (unsigned)p.Wl;
-                const unsigned off = ok ? (unsigned)((nb ? baseB : baseA) + (wi >> p.in_shift) * p.x_ld) * 4u : HV_OOB;
-                r[e] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, off, 0, 0);
+                const unsigned off = ok ? (unsigned)((nb ? baseB : baseA) + (wi >> p.in_shift) * p.x_ld) * SB : HV_OOB;
+                r[e] = SS::ld(xsrc, off, 0);
             }
         } else {                  // tiny maps: step pixel by pixel
             int n = xs_n[it], ho = xs_ho[it], wo = xs_wo[it];
@@ -601,8 +617,8 @@ __global__ __launch_bounds__(WN * WC * 64) void wgrad_kernel(const WgradK p) {
             for (int e = 0; e < 8; ++e) {
                 const int hi = ho * p.stride + dh[it], wi = wo * p.stride + dw[it];
                 const bool ok = jok[it] && m0 + e < pix_end && (unsigned)hi < (unsigned)p.Hl && (unsigned)wi < (unsigned)p.Wl;
-                const unsigned off = ok ? (unsigned)(n * p.img_stride + ((hi >> p.in_shift) * p.Wp + (wi >> p.in_shift)) * p.x_ld + p.x_coff + cx[it]) * 4u : HV_OOB;
-                r[e] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, off, 0, 0);
+                const unsigned off = ok ? (unsigned)(n * p.img_stride + ((hi >> p.in_shift) * p.Wp + (wi >> p.in_shift)) * p.x_ld + p.x_coff + cx[it]) * SB : HV_OOB;
+                r[e] = SS::ld(xsrc, off, 0);
                 if (++wo == p.Wo) { wo = 0; if (++ho == p.Ho) { ho = 0; ++n; } }
             }
         }
@@ -617,14 +633,14 @@ __global__ __launch_bounds__(WN * WC * 64) void wgrad_kernel(const WgradK p) {
 #pragma unroll
         for (int it = 0; it < XPT; ++it) load_x1(pix0, it, rx[it]);
     };
-    auto store = [&](T* dst, int ld, const u32x4 (&r)[8], int cg, int run) __attribute__((always_inline)) {
-        if (F16) {
+    auto store = [&](T* dst, int ld, const SR (&r)[8], int cg, int run) __attribute__((always_inline)) {
+        if constexpr (F16) {
             // transpose 8 pixels x 4 channels -> 4 rows of 8 halfs
             f16x8 h0, h1, h2, h3;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                h0[e] = (_Float16)__uint_as_float(r[e].x); h1[e] = (_Float16)__uint_as_float(r[e].y);
-                h2[e] = (_Float16)__uint_as_float(r[e].z); h3[e] = (_Float16)__uint_as_float(r[e].w);
+                const f16x4 q = SS::h4(r[e]);
+                h0[e] = q[0]; h1[e] = q[1]; h2[e] = q[2]; h3[e] = q[3];
             }
             _Float16* base = reinterpret_cast<_Float16*>(dst) + (cg * 4) * ld + (run ^ (cg & 7)) * 8;
             *reinterpret_cast<f16x8*>(base) = h0;
@@ -633,7 +649,7 @@ __global__ __launch_bounds__(WN * WC * 64) void wgrad_kernel(const WgradK p) {
             *reinterpret_cast<f16x8*>(base + 3 * ld) = h3;
         } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) *reinterpret_cast<u32x4*>(reinterpret_cast<float*>(dst) + (run * 8 + e) * ld + cg * 4) = r[e];
+            for (int e = 0; e < 8; ++e) *reinterpret_cast<float4*>(reinterpret_cast<float*>(dst) + (run * 8 + e) * ld + cg * 4) = SS::f4(r[e]);
         }
     };
 
@@ -657,8 +673,8 @@ __global__ __launch_bounds__(WN * WC * 64) void wgrad_kernel(const WgradK p) {
         if (do_bias && has_g) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                bs0 += __uint_as_float(rg[e].x); bs1 += __uint_as_float(rg[e].y);
-                bs2 += __uint_as_float(rg[e].z); bs3 += __uint_as_float(rg[e].w);
+                const float4 q = SS::f4(rg[e]);
+                bs0 += q.x; bs1 += q.y; bs2 += q.z; bs3 += q.w;
             }
         }
         if (has_x) {
@@ -670,7 +686,7 @@ __global__ __launch_bounds__(WN * WC * 64) void wgrad_kernel(const WgradK p) {
             if (has_g) load_g(pix0 + KT);
             if (has_x) load_x(pix0 + KT);
         }
-        if (F16) {
+        if constexpr (F16) {
             const _Float16* G16 = reinterpret_cast<const _Float16*>(Gs);
             const _Float16* X16 = reinterpret_cast<const _Float16*>(Xs);
 #pragma unroll
@@ -807,6 +823,8 @@ static int wgrad_validate(const hv_wgrad_desc* d) {
     if (((uintptr_t)d->x & 15) || ((uintptr_t)d->g & 15)) return HV_ERR_UNSUPPORTED;
     if (d->in_shift < 0 || d->in_shift > 1) return HV_ERR_UNSUPPORTED;
     if (d->precision != HV_F32 && d->precision != HV_F16) return HV_ERR_ARG;
+    // storage follows the compute type: fp16 MFMA operands <=> x and g stored as fp16, exact-fp32 mode <=> fp32 storage
+    if ((d->x_f16 != 0) != (d->g_f16 != 0) || (d->x_f16 != 0) != (d->precision == HV_F16)) return HV_ERR_UNSUPPORTED;
     const int Hp = d->H >> d->in_shift, Wp = d->W >> d->in_shift;
     // byte offsets are 32-bit buffer offsets with 0x80000000 as the out-of-range marker: tensors stay below 2 GiB
     if ((long long)d->B * Hp * Wp * d->x_ld >= (1ll << 29) || (long long)d->B * d->Ho * d->Wo * d->g_ld >= (1ll << 29)) return HV_ERR_UNSUPPORTED;
@@ -833,12 +851,13 @@ static int launch_wgrad(const WgradK& k, const WgradPlan& pl, hipStream_t s) {
         const int bn = pl.BN, bc = pl.BN == 16 || pl.BN == 32 ? 128 : pl.BC, wn = (pl.BN <= 32 || (pl.BN == 64 && pl.BC == 256)) ? 1 : 2;
         HV_KNAME("wgrad_kernel<%s, %d, %d, %d, %d, %d, %s>", F16 ? "_Float16" : "float", bn, bc, wn, 4 / wn, pl.KT, FAST ? "true" : "false");
     }
-    if (pl.BN == 16) hipLaunchKernelGGL((wgrad_kernel<T, 16, 128, 1, 4, KT, FAST>), grid, dim3(256), 0, s, k);
-    else if (pl.BN == 32) hipLaunchKernelGGL((wgrad_kernel<T, 32, 128, 1, 4, KT, FAST>), grid, dim3(256), 0, s, k);
-    else if (pl.BN == 64 && pl.BC == 256) hipLaunchKernelGGL((wgrad_kernel<T, 64, 256, 1, 4, KT, FAST>), grid, dim3(256), 0, s, k);
-    else if (pl.BN == 64) hipLaunchKernelGGL((wgrad_kernel<T, 64, 64, 2, 2, KT64, FAST>), grid, dim3(256), 0, s, k);
-    else if (pl.BC == 128) hipLaunchKernelGGL((wgrad_kernel<T, 128, 128, 2, 2, KT, FAST>), grid, dim3(256), 0, s, k);
-    else hipLaunchKernelGGL((wgrad_kernel<T, 128, 64, 2, 2, KT, FAST>), grid, dim3(256), 0, s, k);
+    constexpr bool SH = F16;        // fp16 compute <=> fp16 storage of x and g (checked by the caller); fp32 compute <=> fp32 storage
+    if (pl.BN == 16) hipLaunchKernelGGL((wgrad_kernel<T, 16, 128, 1, 4, KT, FAST, SH>), grid, dim3(256), 0, s, k);
+    else if (pl.BN == 32) hipLaunchKernelGGL((wgrad_kernel<T, 32, 128, 1, 4, KT, FAST, SH>), grid, dim3(256), 0, s, k);
+    else if (pl.BN == 64 && pl.BC == 256) hipLaunchKernelGGL((wgrad_kernel<T, 64, 256, 1, 4, KT, FAST, SH>), grid, dim3(256), 0, s, k);
+    else if (pl.BN == 64) hipLaunchKernelGGL((wgrad_kernel<T, 64, 64, 2, 2, KT64, FAST, SH>), grid, dim3(256), 0, s, k);
+    else if (pl.BC == 128) hipLaunchKernelGGL((wgrad_kernel<T, 128, 128, 2, 2, KT, FAST, SH>), grid, dim3(256), 0, s, k);
+    else hipLaunchKernelGGL((wgrad_kernel<T, 128, 64, 2, 2, KT, FAST, SH>), grid, dim3(256), 0, s, k);
     HV_LAUNCH_CHECK();
     return HV_OK;
 }
@@ -874,8 +893,10 @@ extern "C" int hv_conv2d_wgrad(const hv_wgrad_desc* d, void* stream) {
     k.KW = d->KW; k.stride = d->stride; k.pad = d->pad; k.dil = d->dil; k.J = d->KH * d->KW * d->Cin;
     k.M = d->B * d->Ho * d->Wo; k.chunk = pl.chunk; k.slab = nW;
     k.bias_out = d->dbias ? d->workspace + (long long)pl.splits * nW : nullptr;
-    k.x_bytes = (unsigned)((size_t)d->B * (d->H >> d->in_shift) * k.Wp * d->x_ld * sizeof(float));
-    k.g_bytes = (unsigned)((size_t)k.M * d->g_ld * sizeof(float));
+    k.half = d->x_f16 ? 1 : 0;
+    const size_t es = k.half ? 2 : 4;
+    k.x_bytes = (unsigned)((size_t)d->B * (d->H >> d->in_shift) * k.Wp * d->x_ld * es);
+    k.g_bytes = (unsigned)((size_t)k.M * d->g_ld * es);
     auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
     const bool fast = pow2(d->Wo) && pow2(d->Ho) && d->Wo >= 8;
     k.lw = k.lhw = 0;

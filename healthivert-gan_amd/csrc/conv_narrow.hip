@@ -7,7 +7,8 @@
 #include "hv_common.h"
 
 struct NarrowK {
-    const float* x; const float* w; const float* bias; float* y;
+    const void* x; const float* w; const float* bias; void* y;      // x / y: fp32 or fp16 elements (x_half / y_half, wave-uniform)
+    int x_half, y_half;
     int B, H, W, in_shift, Wp, img_stride, x_ld, x_coff, Cin;
     int KH, KW, stride, pad, transposed;
     int Ho, Wo, y_ld, y_coff, Cout;
@@ -28,12 +29,12 @@ __device__ __forceinline__ bool narrow_tap(const NarrowK& p, int oy, int ox, int
 }
 
 __device__ __forceinline__ void narrow_store(const NarrowK& p, long long pix, float acc) {
-    float* yp = p.y + pix * p.y_ld + p.y_coff;
+    const long long yi = pix * p.y_ld + p.y_coff;
     float t = acc * p.alpha;
     if (p.bias) t += p.bias[0];
-    if (p.accumulate == 2) t += *yp;
+    if (p.accumulate == 2) t += hv_ld1(p.y, yi, p.y_half);
     t = hv_act(t, p.act);
-    *yp = p.accumulate == 1 ? *yp + t : t;
+    hv_st1(p.y, yi, p.accumulate == 1 ? hv_ld1(p.y, yi, p.y_half) + t : t, p.y_half);
 }
 
 // LPP lanes cooperate on one output pixel: lanes split the channels (16 B each), taps are looped.
@@ -46,15 +47,15 @@ __global__ __launch_bounds__(256) void narrow_fwd_kernel(const NarrowK p) {
     const int ox = blockIdx.x * PPB + threadIdx.x / LPP;
     float acc = 0.f;
     if (ox < p.Wo) {
-        const float* ximg = p.x + (long long)b * p.img_stride + p.x_coff;
+        const long long ximg = (long long)b * p.img_stride + p.x_coff;
         for (int r = 0; r < p.KH; ++r)
             for (int s = 0; s < p.KW; ++s) {
                 int hi, wi;
                 if (!narrow_tap(p, oy, ox, r, s, hi, wi)) continue;
-                const float* xp = ximg + (long long)((hi >> p.in_shift) * p.Wp + (wi >> p.in_shift)) * p.x_ld;
+                const long long xp = ximg + (long long)((hi >> p.in_shift) * p.Wp + (wi >> p.in_shift)) * p.x_ld;
                 const float* wp = p.w + (r * p.KW + s) * p.Cin;
                 for (int c = sub * 4; c < p.Cin; c += LPP * 4) {
-                    const float4 xv = *reinterpret_cast<const float4*>(xp + c), wv = *reinterpret_cast<const float4*>(wp + c);
+                    const float4 xv = hv_ld4(p.x, xp + c, p.x_half), wv = *reinterpret_cast<const float4*>(wp + c);
                     acc += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
                 }
             }
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(256) void narrow3_fwd_kernel(const NarrowK p) {
     const int row = blockIdx.y, b = row / p.Ho, oy = row - b * p.Ho;
     const int ox = blockIdx.x * 256 + threadIdx.x;
     if (ox >= p.Wo) return;
-    const float* ximg = p.x + (long long)b * p.img_stride + p.x_coff;
+    const long long ximg = (long long)b * p.img_stride + p.x_coff;
     float4 xv[9][C4];
     bool ok[9];
 #pragma unroll
@@ -82,9 +83,9 @@ __global__ __launch_bounds__(256) void narrow3_fwd_kernel(const NarrowK p) {
             const int hi = oy * p.stride - p.pad + r, wi = ox * p.stride - p.pad + s;
             ok[r * 3 + s] = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
             const int hc = min(max(hi, 0), p.H - 1), wc = min(max(wi, 0), p.W - 1);
-            const float* xp = ximg + (long long)((hc >> p.in_shift) * p.Wp + (wc >> p.in_shift)) * p.x_ld;
+            const long long xp = ximg + (long long)((hc >> p.in_shift) * p.Wp + (wc >> p.in_shift)) * p.x_ld;
 #pragma unroll
-            for (int c = 0; c < C4; ++c) xv[r * 3 + s][c] = *reinterpret_cast<const float4*>(xp + c * 4);
+            for (int c = 0; c < C4; ++c) xv[r * 3 + s][c] = hv_ld4(p.x, xp + c * 4, p.x_half);
         }
     float acc = 0.f;
 #pragma unroll
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(256) void thin1_fwd_kernel(const NarrowK p) {
         for (int e = 0; e < 4; ++e) bias[e] = p.bias[cg * 4 + e];
     }
     const int row = blockIdx.y, b = row / p.Ho, oy = row - b * p.Ho;
-    const float* ximg = p.x + (long long)b * p.img_stride + p.x_coff;
+    const long long ximg = (long long)b * p.img_stride + p.x_coff;
 #pragma unroll 2
     for (int it = 0; it < PXB; ++it) {
         const int ox = (blockIdx.x * PXB + it) * PPB + pl;
@@ -138,21 +139,23 @@ __global__ __launch_bounds__(256) void thin1_fwd_kernel(const NarrowK p) {
             for (int q = 0; q < KS; ++q) {
                 const int wi = ox * p.stride - p.pad + q;
                 float xv = 0.f;
-                if (rok && (unsigned)wi < (unsigned)p.W) xv = ximg[(long long)((hi >> p.in_shift) * p.Wp + (wi >> p.in_shift)) * p.x_ld];
+                if (rok && (unsigned)wi < (unsigned)p.W) xv = hv_ld1(p.x, ximg + (long long)((hi >> p.in_shift) * p.Wp + (wi >> p.in_shift)) * p.x_ld, p.x_half);
                 const float4 wv = wr[r * KS + q];
                 acc.x += xv * wv.x; acc.y += xv * wv.y; acc.z += xv * wv.z; acc.w += xv * wv.w;
             }
         }
-        float* yp = p.y + ((long long)row * p.Wo + ox) * p.y_ld + p.y_coff + cg * 4;
+        const long long yi = ((long long)row * p.Wo + ox) * p.y_ld + p.y_coff + cg * 4;
         float o[4] = {acc.x, acc.y, acc.z, acc.w};
+        const float4 old4 = p.accumulate ? hv_ld4(p.y, yi, p.y_half) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float old[4] = {old4.x, old4.y, old4.z, old4.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float t = o[e] * p.alpha + bias[e];
-            if (p.accumulate == 2) t += yp[e];
+            if (p.accumulate == 2) t += old[e];
             t = hv_act(t, p.act);
-            o[e] = p.accumulate == 1 ? yp[e] + t : t;
+            o[e] = p.accumulate == 1 ? old[e] + t : t;
         }
-        *reinterpret_cast<float4*>(yp) = make_float4(o[0], o[1], o[2], o[3]);
+        hv_st4(p.y, yi, make_float4(o[0], o[1], o[2], o[3]), p.y_half);
     }
 }
 
@@ -174,10 +177,10 @@ __global__ __launch_bounds__(256) void stem1_mfma_kernel(const NarrowK p, const 
         for (int j = 0; j < 4; ++j) bias[t][j] = (p.bias && t < MT) ? p.bias[t * 16 + g * 4 + j] : 0.f;
     }
     const int row = blockIdx.x, b = row / p.Ho, oy = row - b * p.Ho;
-    const float* ximg = p.x + (long long)b * p.img_stride + p.x_coff;
+    const long long ximg = (long long)b * p.img_stride + p.x_coff;
     const int iy = oy * p.stride - p.pad + g;
     const bool rok = (unsigned)iy < (unsigned)p.H;
-    const float* xrow = ximg + (long long)((rok ? iy : 0) >> p.in_shift) * p.Wp * p.x_ld;
+    const long long xrow = ximg + (long long)((rok ? iy : 0) >> p.in_shift) * p.Wp * p.x_ld;
     for (int ox0 = wave * 16; ox0 < p.Wo; ox0 += 64) {
         const int ox = ox0 + n, ix0 = ox * p.stride - p.pad;
         _Float16 xv[4];
@@ -185,25 +188,27 @@ __global__ __launch_bounds__(256) void stem1_mfma_kernel(const NarrowK p, const 
         for (int e = 0; e < 4; ++e) {
             const int ix = ix0 + e;
             const bool ok = rok && ox < p.Wo && (unsigned)ix < (unsigned)p.W;
-            const float v = xrow[(long long)((ok ? ix : 0) >> p.in_shift) * p.x_ld];
+            const float v = hv_ld1(p.x, xrow + (long long)((ok ? ix : 0) >> p.in_shift) * p.x_ld, p.x_half);
             xv[e] = (_Float16)(ok ? v : 0.f);
         }
         const f16x4 xb = {xv[0], xv[1], xv[2], xv[3]};
-        float* yp = p.y + ((long long)row * p.Wo + ox) * p.y_ld + p.y_coff + g * 4;
+        const long long yi = ((long long)row * p.Wo + ox) * p.y_ld + p.y_coff + g * 4;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             if (t >= MT) break;
             const f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x16f16(wa[t], xb, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);   // all lanes: MFMA ignores EXEC
             if (ox >= p.Wo) continue;                  // ragged last group: columns past the row end are computed on zeros and not stored
             float o[4];
+            const float4 old4 = p.accumulate ? hv_ld4(p.y, yi + t * 16, p.y_half) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float old[4] = {old4.x, old4.y, old4.z, old4.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float v = acc[j] * p.alpha + bias[t][j];
-                if (p.accumulate == 2) v += yp[t * 16 + j];
+                if (p.accumulate == 2) v += old[j];
                 v = hv_act(v, p.act);
-                o[j] = p.accumulate == 1 ? yp[t * 16 + j] + v : v;
+                o[j] = p.accumulate == 1 ? old[j] + v : v;
             }
-            *reinterpret_cast<float4*>(yp + t * 16) = make_float4(o[0], o[1], o[2], o[3]);
+            hv_st4(p.y, yi + t * 16, make_float4(o[0], o[1], o[2], o[3]), p.y_half);
         }
     }
 }
@@ -213,7 +218,7 @@ __global__ __launch_bounds__(256) void stem1_mfma_kernel(const NarrowK p, const 
 // per tap.  No LDS: lane (pixel, k-group) loads its two taps' 4-channel pixels (16 B each) straight from global memory, L1 serves the
 // 25-fold reuse; the lane's accumulators are four consecutive output channels of its pixel.  One workgroup = one output row.
 struct Stem5K {
-    const float* x; const _Float16* w; float* y;
+    const void* x; const _Float16* w; void* y; int x_half;
     int H, W, x_ld, x_coff, img_stride, y_ld, y_coff;
     HvEpi epi;
 };
@@ -232,7 +237,7 @@ __global__ __launch_bounds__(256) void stem5_mfma_kernel(const Stem5K p) {
         wa[j] = v;
     }
     const int row = blockIdx.x, b = row / p.H, oy = row - b * p.H;
-    const float* ximg = p.x + (long long)b * p.img_stride + p.x_coff;
+    const long long ximg = (long long)b * p.img_stride + p.x_coff;
     for (int ox0 = wave * 16; ox0 < p.W; ox0 += 64) {
         const int ox = ox0 + n;
         float4 xv[4][2];
@@ -244,7 +249,7 @@ __global__ __launch_bounds__(256) void stem5_mfma_kernel(const Stem5K p) {
                 const int r = t / 5, q = t - r * 5;
                 const int iy = oy - 2 + r, ix = ox - 2 + q;
                 const bool ok = t < 25 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                const float4 v = *reinterpret_cast<const float4*>(ximg + ((long long)(ok ? iy : 0) * p.W + (ok ? ix : 0)) * p.x_ld);
+                const float4 v = hv_ld4(p.x, ximg + ((long long)(ok ? iy : 0) * p.W + (ok ? ix : 0)) * p.x_ld, p.x_half);
                 xv[j][h] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -254,7 +259,7 @@ __global__ __launch_bounds__(256) void stem5_mfma_kernel(const Stem5K p) {
                               (_Float16)xv[j][1].x, (_Float16)xv[j][1].y, (_Float16)xv[j][1].z, (_Float16)xv[j][1].w};
             acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[j], xb, acc, 0, 0, 0);
         }
-        if (ox < p.W) hv_conv_epilogue4(p.epi, acc, g * 4, p.y + ((long long)row * p.W + ox) * p.y_ld + p.y_coff, nullptr);
+        if (ox < p.W) hv_conv_epilogue4(p.epi, acc, g * 4, hv_eptr(p.y, ((long long)row * p.W + ox) * p.y_ld + p.y_coff, p.epi.y_half), nullptr);
     }
 }
 
@@ -266,10 +271,10 @@ int hv_conv2d_stem5(const hv_conv_desc* d, hipStream_t s) {
         return HV_ERR_UNSUPPORTED;
     if ((d->x_ld & 3) || (d->x_coff & 3) || ((uintptr_t)d->x & 15) || ((uintptr_t)d->w_f16 & 7) || (long long)d->B * d->H >= (1ll << 31)) return HV_ERR_UNSUPPORTED;
     Stem5K k;
-    k.x = d->x; k.w = reinterpret_cast<const _Float16*>(d->w_f16); k.y = d->y;
+    k.x = d->x; k.w = reinterpret_cast<const _Float16*>(d->w_f16); k.y = d->y; k.x_half = d->x_f16 ? 1 : 0;
     k.H = d->H; k.W = d->W; k.x_ld = d->x_ld; k.x_coff = d->x_coff; k.img_stride = d->H * d->W * d->x_ld; k.y_ld = d->y_ld; k.y_coff = d->y_coff;
     k.epi.alpha = d->alpha; k.epi.act = d->act; k.epi.accumulate = d->accumulate; k.epi.Cout = 16; k.epi.bias = d->bias; k.epi.scale = nullptr;
-    k.epi.mul_act = 0; k.epi.mul_vec = 0;
+    k.epi.mul_act = 0; k.epi.mul_vec = 0; k.epi.y_half = d->y_f16 ? 1 : 0; k.epi.mul_half = 0;
     k.epi.vec_store = ((d->y_ld & 3) == 0 && (d->y_coff & 3) == 0 && ((uintptr_t)d->y & 15) == 0) ? 1 : 0;
     hv_path_note = 4;
     HV_KNAME("stem5_mfma_kernel");
@@ -282,7 +287,7 @@ int hv_conv2d_narrow(const hv_conv_desc* d, hipStream_t s) {
     if (d->w_bstride || d->ch_scale || d->dil != 1 || d->stride > 2) return HV_ERR_UNSUPPORTED;
     NarrowK k;
     const int Hp = d->H >> d->in_shift, Wp = d->W >> d->in_shift;
-    k.x = d->x; k.w = d->w; k.bias = d->bias; k.y = d->y;
+    k.x = d->x; k.w = d->w; k.bias = d->bias; k.y = d->y; k.x_half = d->x_f16 ? 1 : 0; k.y_half = d->y_f16 ? 1 : 0;
     k.B = d->B; k.H = d->H; k.W = d->W; k.in_shift = d->in_shift; k.Wp = Wp; k.img_stride = Hp * Wp * d->x_ld;
     k.x_ld = d->x_ld; k.x_coff = d->x_coff; k.Cin = d->Cin;
     k.KH = d->KH; k.KW = d->KW; k.stride = d->stride; k.pad = d->pad; k.transposed = d->transposed;
@@ -321,7 +326,7 @@ int hv_conv2d_thin_in(const hv_conv_desc* d, hipStream_t s) {
     if ((d->y_ld & 3) || (d->y_coff & 3) || ((uintptr_t)d->y & 15) || (long long)d->B * d->Ho > 65535) return HV_ERR_UNSUPPORTED;
     NarrowK k;
     const int Hp = d->H >> d->in_shift, Wp = d->W >> d->in_shift;
-    k.x = d->x; k.w = d->w; k.bias = d->bias; k.y = d->y;
+    k.x = d->x; k.w = d->w; k.bias = d->bias; k.y = d->y; k.x_half = d->x_f16 ? 1 : 0; k.y_half = d->y_f16 ? 1 : 0;
     k.B = d->B; k.H = d->H; k.W = d->W; k.in_shift = d->in_shift; k.Wp = Wp; k.img_stride = Hp * Wp * d->x_ld;
     k.x_ld = d->x_ld; k.x_coff = d->x_coff; k.Cin = d->Cin;
     k.KH = d->KH; k.KW = d->KW; k.stride = d->stride; k.pad = d->pad; k.transposed = 0;

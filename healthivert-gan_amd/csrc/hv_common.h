@@ -72,15 +72,61 @@ __device__ __forceinline__ float hv_block_sum(float v, float* red /* >= 17 float
     return s;
 }
 
+// ---- storage type of activation / gradient tensors: fp32, or fp16 in the HV_F16 storage mode (hv_conv_desc.x_f16 / y_f16 ...).
+// MFMA kernels of the fp16 mode round their operands to fp16 when they stage them, so a tensor that is only consumed that way holds the
+// same operand values either way; fp16 storage halves its bytes in HBM / L2 and drops the conversions from the staging code.
+typedef unsigned int hv_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int hv_u32x2 __attribute__((ext_vector_type(2)));
+template <bool H> struct HvSt;           // H: elements are fp16
+template <> struct HvSt<false> {
+    typedef hv_u32x4 R;                  // 4 consecutive channels in flight
+    static constexpr unsigned B = 4u;    // bytes per element
+    static __device__ __forceinline__ R ld(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0); }
+    static __device__ __forceinline__ f16x4 h4(R v) {
+        return (f16x4){(_Float16)__uint_as_float(v.x), (_Float16)__uint_as_float(v.y), (_Float16)__uint_as_float(v.z), (_Float16)__uint_as_float(v.w)};
+    }
+    static __device__ __forceinline__ float4 f4(R v) { return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)); }
+};
+template <> struct HvSt<true> {
+    typedef hv_u32x2 R;
+    static constexpr unsigned B = 2u;
+    static __device__ __forceinline__ R ld(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0); }
+    static __device__ __forceinline__ f16x4 h4(R v) { return __builtin_bit_cast(f16x4, v); }
+    static __device__ __forceinline__ float4 f4(R v) {
+        const f16x4 h = __builtin_bit_cast(f16x4, v);
+        return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+    }
+};
+// plain-pointer forms for the pointwise kernels (runtime flag, wave-uniform)
+__device__ __forceinline__ float hv_ld1(const void* p, long long i, int half) {
+    return half ? (float)reinterpret_cast<const _Float16*>(p)[i] : reinterpret_cast<const float*>(p)[i];
+}
+__device__ __forceinline__ void hv_st1(void* p, long long i, float v, int half) {
+    if (half) reinterpret_cast<_Float16*>(p)[i] = (_Float16)v; else reinterpret_cast<float*>(p)[i] = v;
+}
+__device__ __forceinline__ float4 hv_ld4(const void* p, long long i, int half) {     // i % 4 == 0 and the base 16-B (8-B) aligned
+    if (half) {
+        const f16x4 h = *reinterpret_cast<const f16x4*>(reinterpret_cast<const _Float16*>(p) + i);
+        return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+    }
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p) + i);
+}
+__device__ __forceinline__ void hv_st4(void* p, long long i, float4 v, int half) {
+    if (half) *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(p) + i) = (f16x4){(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+    else *reinterpret_cast<float4*>(reinterpret_cast<float*>(p) + i) = v;
+}
+
 // Shared conv epilogue for one lane's 4 consecutive output channels (ch0 .. ch0+3) of one output pixel:
 //   t = acc*alpha [*scale] [+bias] [+y if accumulate == 2];  v = act(t) [* act'(mul)];  y = v  or  y += v (accumulate == 1)
 // yp / mp point at the pixel's channel 0 (mp = NULL: no multiplier); scale / bias are per-channel arrays or NULL.
+// y_half / mul_half: the output / the multiplier tensor is stored as fp16 (yp / mp then point at _Float16 elements).
 struct HvEpi {
     float alpha; int act, accumulate, vec_store, Cout;
     const float* bias; const float* scale;
     int mul_act, mul_vec;
+    int y_half, mul_half;
 };
-__device__ __forceinline__ void hv_conv_epilogue4(const HvEpi& e, const f32x4& a, int ch0, float* __restrict__ yp, const float* __restrict__ mp) {
+__device__ __forceinline__ void hv_conv_epilogue4(const HvEpi& e, const f32x4& a, int ch0, void* __restrict__ yp, const void* __restrict__ mp) {
     if (ch0 >= e.Cout) return;
     float v[4];
 #pragma unroll
@@ -90,31 +136,34 @@ __device__ __forceinline__ void hv_conv_epilogue4(const HvEpi& e, const f32x4& a
         if (ch < e.Cout) {
             if (e.scale) t *= e.scale[ch];
             if (e.bias) t += e.bias[ch];
-            if (e.accumulate == 2) t += yp[ch];   // pre-activation accumulate (split-K over concatenated inputs)
+            if (e.accumulate == 2) t += hv_ld1(yp, ch, e.y_half);   // pre-activation accumulate (split-K over concatenated inputs)
         }
         v[r] = hv_act(t, e.act);
     }
     if (mp) {   // hand the producer layer its pre-activation gradient: multiply by act'(its output)
         if (e.mul_vec && ch0 + 3 < e.Cout) {
-            const float4 m4 = *reinterpret_cast<const float4*>(mp + ch0);
+            const float4 m4 = hv_ld4(mp, ch0, e.mul_half);
             v[0] *= hv_act_grad_from_out(m4.x, e.mul_act); v[1] *= hv_act_grad_from_out(m4.y, e.mul_act);
             v[2] *= hv_act_grad_from_out(m4.z, e.mul_act); v[3] *= hv_act_grad_from_out(m4.w, e.mul_act);
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (ch0 + r < e.Cout) v[r] *= hv_act_grad_from_out(mp[ch0 + r], e.mul_act);
+                if (ch0 + r < e.Cout) v[r] *= hv_act_grad_from_out(hv_ld1(mp, ch0 + r, e.mul_half), e.mul_act);
         }
     }
     if (e.vec_store && ch0 + 3 < e.Cout) {
         float4 o = make_float4(v[0], v[1], v[2], v[3]);
         if (e.accumulate == 1) {
-            const float4 old = *reinterpret_cast<const float4*>(yp + ch0);
+            const float4 old = hv_ld4(yp, ch0, e.y_half);
             o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
         }
-        *reinterpret_cast<float4*>(yp + ch0) = o;
+        hv_st4(yp, ch0, o, e.y_half);
     } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            if (ch0 + r < e.Cout) yp[ch0 + r] = e.accumulate == 1 ? yp[ch0 + r] + v[r] : v[r];
+            if (ch0 + r < e.Cout) hv_st1(yp, ch0 + r, e.accumulate == 1 ? hv_ld1(yp, ch0 + r, e.y_half) + v[r] : v[r], e.y_half);
     }
 }
+// byte-wise element address of a tensor whose element size is 2 (half != 0) or 4 bytes
+__device__ __forceinline__ void* hv_eptr(void* base, long long elem, int half) { return reinterpret_cast<char*>(base) + elem * (half ? 2 : 4); }
+__device__ __forceinline__ const void* hv_eptr(const void* base, long long elem, int half) { return reinterpret_cast<const char*>(base) + elem * (half ? 2 : 4); }

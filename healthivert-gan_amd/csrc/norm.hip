@@ -50,7 +50,7 @@ extern "C" size_t hv_norm_workspace_bytes(int B, int HW, int C) {
 }
 
 struct NormK {
-    const float* x; const float* y; const float* dy; float* out;
+    const void* x; const void* y; const void* dy; void* out;      // fp32, or fp16 elements with the H instantiations (all four alike)
     int x_ld, x_coff, y_ld, y_coff, dy_ld, dy_coff, o_ld, o_coff;
     int C, R, rpb, nchunk, act, post_sigmoid, CB, lc;   // CB: lanes per row in the reduction; lc: log2(lanes per row) in the apply pass
     const float* stats; const float* gamma; const float* beta;
@@ -76,7 +76,7 @@ __device__ __forceinline__ float norm_act_bwd(float y, int act, int post_sigmoid
 
 // MODE 0: (sum x, sum x^2);  MODE 1: (sum g, sum g*xhat) with g = dy*act'(y), xhat = (x-mean)*rstd
 // grid (chunk, group, channel slice); V floats per lane; rows of the chunk strided by 256/CB, two rows in flight per lane
-template <int MODE, bool VEC>
+template <int MODE, bool VEC, bool H>
 __global__ __launch_bounds__(256) void norm_reduce_kernel(const NormK k, double* __restrict__ part) {
     constexpr int V = VEC ? 4 : 1;
     __shared__ double sh[256 * 2 * V];
@@ -94,9 +94,9 @@ __global__ __launch_bounds__(256) void norm_reduce_kernel(const NormK k, double*
         a[e] = 0; b[e] = 0; mean[e] = 0.f; rstd[e] = 1.f;
         if (MODE == 1) { mean[e] = k.stats[(long long)g * 2 * C + c0 + e]; rstd[e] = k.stats[(long long)g * 2 * C + C + c0 + e]; }
     }
-    auto ldv = [&](const float* p, long long r, int ld, int coff, float (&o)[V]) __attribute__((always_inline)) {
-        if (VEC) { const float4 v = *reinterpret_cast<const float4*>(p + r * ld + coff + c0); o[0] = v.x; o[V > 1 ? 1 : 0] = v.y; o[V > 2 ? 2 : 0] = v.z; o[V > 3 ? 3 : 0] = v.w; }
-        else o[0] = p[r * ld + coff + c0];
+    auto ldv = [&](const void* p, long long r, int ld, int coff, float (&o)[V]) __attribute__((always_inline)) {
+        if (VEC) { const float4 v = hv_ld4(p, r * ld + coff + c0, H); o[0] = v.x; o[V > 1 ? 1 : 0] = v.y; o[V > 2 ? 2 : 0] = v.z; o[V > 3 ? 3 : 0] = v.w; }
+        else o[0] = hv_ld1(p, r * ld + coff + c0, H);
     };
     auto acc1 = [&](const float (&xs)[V], const float (&ds)[V], const float (&ys)[V]) __attribute__((always_inline)) {
 #pragma unroll
@@ -181,7 +181,7 @@ __global__ void norm_fwd_finalize_kernel(const double* __restrict__ part, int G,
 
 // grid (blocks, group): lanes per row CV = C/V is a power of two <= 256, so a thread keeps its channels over the grid-stride
 // loop: per-channel constants live in registers and the row index is a shift
-template <bool VEC>
+template <bool VEC, bool H>
 __global__ __launch_bounds__(256) void norm_apply_kernel(const NormK k) {
     constexpr int V = VEC ? 4 : 1;
     const int C = k.C, g = blockIdx.y, lc = k.lc;
@@ -198,16 +198,16 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const NormK k) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += st) {
         const long long r = base + (i >> lc);
         float xs[V], o[V];
-        if (VEC) { const float4 xv = *reinterpret_cast<const float4*>(k.x + r * k.x_ld + k.x_coff + c0); xs[0] = xv.x; xs[V > 1 ? 1 : 0] = xv.y; xs[V > 2 ? 2 : 0] = xv.z; xs[V > 3 ? 3 : 0] = xv.w; }
-        else xs[0] = k.x[r * k.x_ld + k.x_coff + c0];
+        if (VEC) { const float4 xv = hv_ld4(k.x, r * k.x_ld + k.x_coff + c0, H); xs[0] = xv.x; xs[V > 1 ? 1 : 0] = xv.y; xs[V > 2 ? 2 : 0] = xv.z; xs[V > 3 ? 3 : 0] = xv.w; }
+        else xs[0] = hv_ld1(k.x, r * k.x_ld + k.x_coff + c0, H);
 #pragma unroll
         for (int e = 0; e < V; ++e) {
             float v = (xs[e] - mean[e]) * rstd[e];
             if (k.gamma) v = v * gam[e] + bet[e];
             o[e] = norm_act_fwd(v, k.act, k.post_sigmoid);
         }
-        if (VEC) *reinterpret_cast<float4*>(k.out + r * k.o_ld + k.o_coff + c0) = make_float4(o[0], o[V > 1 ? 1 : 0], o[V > 2 ? 2 : 0], o[V > 3 ? 3 : 0]);
-        else k.out[r * k.o_ld + k.o_coff + c0] = o[0];
+        if (VEC) hv_st4(k.out, r * k.o_ld + k.o_coff + c0, make_float4(o[0], o[V > 1 ? 1 : 0], o[V > 2 ? 2 : 0], o[V > 3 ? 3 : 0]), H);
+        else hv_st1(k.out, r * k.o_ld + k.o_coff + c0, o[0], H);
     }
 }
 
@@ -237,8 +237,13 @@ extern "C" int hv_norm_act_forward(const hv_norm_desc* d, void* stream) {
     double* part = (double*)d->workspace;
     if (!use_running) {
         dim3 grid(pl.nchunk, pl.G, pl.slices);
-        if (vec) hipLaunchKernelGGL((norm_reduce_kernel<0, true>), grid, dim3(256), 0, s, k, part);
-        else hipLaunchKernelGGL((norm_reduce_kernel<0, false>), grid, dim3(256), 0, s, k, part);
+        if (d->f16) {
+            if (vec) hipLaunchKernelGGL((norm_reduce_kernel<0, true, true>), grid, dim3(256), 0, s, k, part);
+            else hipLaunchKernelGGL((norm_reduce_kernel<0, false, true>), grid, dim3(256), 0, s, k, part);
+        } else {
+            if (vec) hipLaunchKernelGGL((norm_reduce_kernel<0, true, false>), grid, dim3(256), 0, s, k, part);
+            else hipLaunchKernelGGL((norm_reduce_kernel<0, false, false>), grid, dim3(256), 0, s, k, part);
+        }
         HV_LAUNCH_CHECK();
     }
     const int update = d->norm == HV_NORM_BATCH && d->training && d->running_mean && d->running_var;
@@ -247,8 +252,13 @@ extern "C" int hv_norm_act_forward(const hv_norm_desc* d, void* stream) {
     HV_LAUNCH_CHECK();
     const long long n = (long long)pl.R * (vec ? d->C / 4 : d->C);
     const dim3 agrid(apply_grid(n, pl.G), pl.G);
-    if (vec) hipLaunchKernelGGL((norm_apply_kernel<true>), agrid, dim3(256), 0, s, k);
-    else hipLaunchKernelGGL((norm_apply_kernel<false>), agrid, dim3(256), 0, s, k);
+    if (d->f16) {
+        if (vec) hipLaunchKernelGGL((norm_apply_kernel<true, true>), agrid, dim3(256), 0, s, k);
+        else hipLaunchKernelGGL((norm_apply_kernel<false, true>), agrid, dim3(256), 0, s, k);
+    } else {
+        if (vec) hipLaunchKernelGGL((norm_apply_kernel<true, false>), agrid, dim3(256), 0, s, k);
+        else hipLaunchKernelGGL((norm_apply_kernel<false, false>), agrid, dim3(256), 0, s, k);
+    }
     HV_LAUNCH_CHECK();
     return HV_OK;
 }
@@ -278,7 +288,7 @@ __global__ void norm_bwd_finalize_kernel(const double* __restrict__ part, int G,
     if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)ta : (float)ta;
 }
 
-template <bool VEC>
+template <bool VEC, bool H>
 __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const NormK k, const float* __restrict__ ab, int batch_stats) {
     constexpr int V = VEC ? 4 : 1;
     const int C = k.C, g = blockIdx.y, lc = k.lc;
@@ -298,16 +308,16 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const NormK k, cons
         const long long r = base + (i >> lc);
         float xs[V], ds[V], ys[V], o[V];
         if (VEC) {
-            const float4 xv = *reinterpret_cast<const float4*>(k.x + r * k.x_ld + k.x_coff + c0);
-            const float4 dv = *reinterpret_cast<const float4*>(k.dy + r * k.dy_ld + k.dy_coff + c0);
-            const float4 yv = *reinterpret_cast<const float4*>(k.y + r * k.y_ld + k.y_coff + c0);
+            const float4 xv = hv_ld4(k.x, r * k.x_ld + k.x_coff + c0, H);
+            const float4 dv = hv_ld4(k.dy, r * k.dy_ld + k.dy_coff + c0, H);
+            const float4 yv = hv_ld4(k.y, r * k.y_ld + k.y_coff + c0, H);
             xs[0] = xv.x; xs[V > 1 ? 1 : 0] = xv.y; xs[V > 2 ? 2 : 0] = xv.z; xs[V > 3 ? 3 : 0] = xv.w;
             ds[0] = dv.x; ds[V > 1 ? 1 : 0] = dv.y; ds[V > 2 ? 2 : 0] = dv.z; ds[V > 3 ? 3 : 0] = dv.w;
             ys[0] = yv.x; ys[V > 1 ? 1 : 0] = yv.y; ys[V > 2 ? 2 : 0] = yv.z; ys[V > 3 ? 3 : 0] = yv.w;
         } else {
-            xs[0] = k.x[r * k.x_ld + k.x_coff + c0];
-            ds[0] = k.dy[r * k.dy_ld + k.dy_coff + c0];
-            ys[0] = k.y[r * k.y_ld + k.y_coff + c0];
+            xs[0] = hv_ld1(k.x, r * k.x_ld + k.x_coff + c0, H);
+            ds[0] = hv_ld1(k.dy, r * k.dy_ld + k.dy_coff + c0, H);
+            ys[0] = hv_ld1(k.y, r * k.y_ld + k.y_coff + c0, H);
         }
 #pragma unroll
         for (int e = 0; e < V; ++e) {
@@ -321,8 +331,8 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const NormK k, cons
             }
             o[e] = v;
         }
-        if (VEC) *reinterpret_cast<float4*>(k.out + r * k.o_ld + k.o_coff + c0) = make_float4(o[0], o[V > 1 ? 1 : 0], o[V > 2 ? 2 : 0], o[V > 3 ? 3 : 0]);
-        else k.out[r * k.o_ld + k.o_coff + c0] = o[0];
+        if (VEC) hv_st4(k.out, r * k.o_ld + k.o_coff + c0, make_float4(o[0], o[V > 1 ? 1 : 0], o[V > 2 ? 2 : 0], o[V > 3 ? 3 : 0]), H);
+        else hv_st1(k.out, r * k.o_ld + k.o_coff + c0, o[0], H);
     }
 }
 
@@ -349,8 +359,13 @@ extern "C" int hv_norm_act_backward(const hv_norm_bwd_desc* d, void* stream) {
     double* part = (double*)d->workspace;
     float* ab = (float*)((char*)d->workspace + need_part);
     dim3 grid(pl.nchunk, pl.G, pl.slices);
-    if (vec) hipLaunchKernelGGL((norm_reduce_kernel<1, true>), grid, dim3(256), 0, s, k, part);
-    else hipLaunchKernelGGL((norm_reduce_kernel<1, false>), grid, dim3(256), 0, s, k, part);
+    if (d->f16) {
+        if (vec) hipLaunchKernelGGL((norm_reduce_kernel<1, true, true>), grid, dim3(256), 0, s, k, part);
+        else hipLaunchKernelGGL((norm_reduce_kernel<1, false, true>), grid, dim3(256), 0, s, k, part);
+    } else {
+        if (vec) hipLaunchKernelGGL((norm_reduce_kernel<1, true, false>), grid, dim3(256), 0, s, k, part);
+        else hipLaunchKernelGGL((norm_reduce_kernel<1, false, false>), grid, dim3(256), 0, s, k, part);
+    }
     HV_LAUNCH_CHECK();
     hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(d->C), dim3(64), 0, s, part, pl.G, pl.nchunk, d->C, ab, d->dgamma, d->dbeta,
                        d->param_accumulate);
@@ -358,8 +373,13 @@ extern "C" int hv_norm_act_backward(const hv_norm_bwd_desc* d, void* stream) {
     const int batch_stats = (d->norm == HV_NORM_INSTANCE || d->training) ? 1 : 0;
     const long long n = (long long)pl.R * (vec ? d->C / 4 : d->C);
     const dim3 agrid(apply_grid(n, pl.G), pl.G);
-    if (vec) hipLaunchKernelGGL((norm_bwd_apply_kernel<true>), agrid, dim3(256), 0, s, k, ab, batch_stats);
-    else hipLaunchKernelGGL((norm_bwd_apply_kernel<false>), agrid, dim3(256), 0, s, k, ab, batch_stats);
+    if (d->f16) {
+        if (vec) hipLaunchKernelGGL((norm_bwd_apply_kernel<true, true>), agrid, dim3(256), 0, s, k, ab, batch_stats);
+        else hipLaunchKernelGGL((norm_bwd_apply_kernel<false, true>), agrid, dim3(256), 0, s, k, ab, batch_stats);
+    } else {
+        if (vec) hipLaunchKernelGGL((norm_bwd_apply_kernel<true, false>), agrid, dim3(256), 0, s, k, ab, batch_stats);
+        else hipLaunchKernelGGL((norm_bwd_apply_kernel<false, false>), agrid, dim3(256), 0, s, k, ab, batch_stats);
+    }
     HV_LAUNCH_CHECK();
     return HV_OK;
 }

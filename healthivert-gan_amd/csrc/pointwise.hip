@@ -7,35 +7,35 @@ static int pw_grid(long long n, int cap = 8192) { long long b = (n + 255) / 256;
 #define PW_LOOP(i, n) for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long long)gridDim.x * blockDim.x)
 
 // ------------------------------------------------------------------------------------------------ layout
-__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int HW, int dst_ld, int dst_coff, long long n) {
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, void* __restrict__ dst, int dh, int C, int HW, int dst_ld, int dst_coff, long long n) {
     PW_LOOP(i, n) {  // i over dst order (b, p, c)
         const int c = (int)(i % C);
         const long long bp = i / C;
         const long long b = bp / HW, p = bp - b * HW;
-        dst[bp * dst_ld + dst_coff + c] = src[(b * C + c) * HW + p];
+        hv_st1(dst, bp * dst_ld + dst_coff + c, src[(b * C + c) * HW + p], dh);
     }
 }
-__global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int HW, int src_ld, int src_coff, int acc, long long n) {
+__global__ void nhwc_to_nchw_kernel(const void* __restrict__ src, int sh, float* __restrict__ dst, int C, int HW, int src_ld, int src_coff, int acc, long long n) {
     PW_LOOP(i, n) {  // i over dst order (b, c, p)
         const long long p = i % HW;
         const long long bc = i / HW;
         const long long b = bc / C;
         const int c = (int)(bc - b * C);
-        const float v = src[(b * HW + p) * src_ld + src_coff + c];
+        const float v = hv_ld1(src, (b * HW + p) * src_ld + src_coff + c, sh);
         dst[i] = acc ? dst[i] + v : v;
     }
 }
-extern "C" int hv_nchw_to_nhwc(const float* src, float* dst, int B, int C, int H, int W, int dst_ld, int dst_coff, void* stream) {
+extern "C" int hv_nchw_to_nhwc(const float* src, void* dst, int dst_f16, int B, int C, int H, int W, int dst_ld, int dst_coff, void* stream) {
     if (!src || !dst || B <= 0 || C <= 0 || H <= 0 || W <= 0 || dst_ld < dst_coff + C) return HV_ERR_ARG;
     const long long n = (long long)B * C * H * W;
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(pw_grid(n)), dim3(256), 0, (hipStream_t)stream, src, dst, C, H * W, dst_ld, dst_coff, n);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(pw_grid(n)), dim3(256), 0, (hipStream_t)stream, src, dst, dst_f16, C, H * W, dst_ld, dst_coff, n);
     HV_LAUNCH_CHECK();
     return HV_OK;
 }
-extern "C" int hv_nhwc_to_nchw(const float* src, float* dst, int B, int C, int H, int W, int src_ld, int src_coff, int accumulate, void* stream) {
+extern "C" int hv_nhwc_to_nchw(const void* src, int src_f16, float* dst, int B, int C, int H, int W, int src_ld, int src_coff, int accumulate, void* stream) {
     if (!src || !dst || B <= 0 || C <= 0 || H <= 0 || W <= 0 || src_ld < src_coff + C) return HV_ERR_ARG;
     const long long n = (long long)B * C * H * W;
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(pw_grid(n)), dim3(256), 0, (hipStream_t)stream, src, dst, C, H * W, src_ld, src_coff, accumulate, n);
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(pw_grid(n)), dim3(256), 0, (hipStream_t)stream, src, src_f16, dst, C, H * W, src_ld, src_coff, accumulate, n);
     HV_LAUNCH_CHECK();
     return HV_OK;
 }
@@ -43,7 +43,7 @@ extern "C" int hv_nhwc_to_nchw(const float* src, float* dst, int B, int C, int H
 // mode 0 same size; 1 src half size (nearest x2 up); 2 src double size (nearest x1/2: even indices);
 // 3 dst(half) (+)= sum of the 2x2 block of src(full)  [adjoint of 1];  4 dst(full) (+)= src(half) at even idx else 0 [adjoint of 2]
 template <int V>
-__global__ void copy_channels_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int W, int C, int src_ld, int src_coff,
+__global__ void copy_channels_kernel(const void* __restrict__ src, int sh, void* __restrict__ dst, int dh, int H, int W, int C, int src_ld, int src_coff,
                                      int dst_ld, int dst_coff, int mode, int acc, long long n) {
     const int CV = C / V;
     PW_LOOP(i, n) {
@@ -54,9 +54,9 @@ __global__ void copy_channels_kernel(const float* __restrict__ src, float* __res
         const long long b = r / H;
         float v[4] = {0.f, 0.f, 0.f, 0.f};
         auto rd = [&](long long pix) {
-            const float* s = src + pix * src_ld + src_coff + cg * V;
-            if (V == 4) { const float4 t = *reinterpret_cast<const float4*>(s); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
-            else v[0] += s[0];
+            const long long si = pix * src_ld + src_coff + cg * V;
+            if (V == 4) { const float4 t = hv_ld4(src, si, sh); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+            else v[0] += hv_ld1(src, si, sh);
         };
         if (mode == 0) rd((b * H + h) * W + w);
         else if (mode == 1) rd((b * (H >> 1) + (h >> 1)) * (W >> 1) + (w >> 1));
@@ -67,62 +67,61 @@ __global__ void copy_channels_kernel(const float* __restrict__ src, float* __res
         } else {
             if (!((h | w) & 1)) rd((b * (H >> 1) + (h >> 1)) * (W >> 1) + (w >> 1));
         }
-        float* d = dst + ((b * H + h) * W + w) * dst_ld + dst_coff + cg * V;
+        const long long di = ((b * H + h) * W + w) * dst_ld + dst_coff + cg * V;
         if (V == 4) {
             float4 o = make_float4(v[0], v[1], v[2], v[3]);
-            if (acc) { const float4 t = *reinterpret_cast<float4*>(d); o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
-            *reinterpret_cast<float4*>(d) = o;
+            if (acc) { const float4 t = hv_ld4(dst, di, dh); o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
+            hv_st4(dst, di, o, dh);
         } else {
-            d[0] = acc ? d[0] + v[0] : v[0];
+            hv_st1(dst, di, acc ? hv_ld1(dst, di, dh) + v[0] : v[0], dh);
         }
     }
 }
-extern "C" int hv_copy_channels(const float* src, float* dst, int B, int H, int W, int C, int src_ld, int src_coff, int dst_ld,
+extern "C" int hv_copy_channels(const void* src, int src_f16, void* dst, int dst_f16, int B, int H, int W, int C, int src_ld, int src_coff, int dst_ld,
                                 int dst_coff, int mode, int accumulate, void* stream) {
     if (!src || !dst || B <= 0 || H <= 0 || W <= 0 || C <= 0 || mode < 0 || mode > 4) return HV_ERR_ARG;
     if (src_ld < src_coff + C || dst_ld < dst_coff + C) return HV_ERR_ARG;
     if ((mode == 1 || mode == 4) && ((H | W) & 1)) return HV_ERR_UNSUPPORTED;
     const bool vec = !(C & 3) && !(src_ld & 3) && !(src_coff & 3) && !(dst_ld & 3) && !(dst_coff & 3) && !((uintptr_t)src & 15) && !((uintptr_t)dst & 15);
     const long long n = (long long)B * H * W * (vec ? C / 4 : C);
-    if (vec) hipLaunchKernelGGL((copy_channels_kernel<4>), dim3(pw_grid(n)), dim3(256), 0, (hipStream_t)stream, src, dst, H, W, C, src_ld, src_coff, dst_ld, dst_coff, mode, accumulate, n);
-    else hipLaunchKernelGGL((copy_channels_kernel<1>), dim3(pw_grid(n)), dim3(256), 0, (hipStream_t)stream, src, dst, H, W, C, src_ld, src_coff, dst_ld, dst_coff, mode, accumulate, n);
+    if (vec) hipLaunchKernelGGL((copy_channels_kernel<4>), dim3(pw_grid(n)), dim3(256), 0, (hipStream_t)stream, src, src_f16, dst, dst_f16, H, W, C, src_ld, src_coff, dst_ld, dst_coff, mode, accumulate, n);
+    else hipLaunchKernelGGL((copy_channels_kernel<1>), dim3(pw_grid(n)), dim3(256), 0, (hipStream_t)stream, src, src_f16, dst, dst_f16, H, W, C, src_ld, src_coff, dst_ld, dst_coff, mode, accumulate, n);
     HV_LAUNCH_CHECK();
     return HV_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ generator input
 __global__ void gen_input_kernel(const float* __restrict__ x, const float* __restrict__ seg, const float* __restrict__ mask,
-                                 const double* __restrict__ ratio, float* __restrict__ dst, int HW, int CP, int order, long long n) {
+                                 const double* __restrict__ ratio, void* __restrict__ dst, int dh, int HW, int CP, int order, long long n) {
     PW_LOOP(i, n) {
         const long long b = i / HW;
         const float r = (float)ratio[b];
-        float* d = dst + i * CP;
         float c0 = x[i], c1, c2, c3 = 0.f;
         if (order == 0) { c1 = r; c2 = mask[i]; }
         else { c1 = seg[i]; c2 = mask[i]; c3 = r; }
-        *reinterpret_cast<float4*>(d) = make_float4(c0, c1, c2, c3);
-        for (int c = 4; c < CP; ++c) d[c] = 0.f;
+        hv_st4(dst, i * CP, make_float4(c0, c1, c2, c3), dh);
+        for (int c = 4; c < CP; ++c) hv_st1(dst, i * CP + c, 0.f, dh);
     }
 }
-extern "C" int hv_gen_input(const float* x, const float* seg, const float* mask, const double* slice_ratio, float* dst, int B, int H,
+extern "C" int hv_gen_input(const float* x, const float* seg, const float* mask, const double* slice_ratio, void* dst, int dst_f16, int B, int H,
                             int W, int CP, int order, void* stream) {
     if (!x || !mask || !slice_ratio || !dst || B <= 0 || H <= 0 || W <= 0 || CP < 4 || (CP & 3) || (order == 1 && !seg)) return HV_ERR_ARG;
     const long long n = (long long)B * H * W;
-    hipLaunchKernelGGL(gen_input_kernel, dim3(pw_grid(n)), dim3(256), 0, (hipStream_t)stream, x, seg, mask, slice_ratio, dst, H * W, CP, order, n);
+    hipLaunchKernelGGL(gen_input_kernel, dim3(pw_grid(n)), dim3(256), 0, (hipStream_t)stream, x, seg, mask, slice_ratio, dst, dst_f16, H * W, CP, order, n);
     HV_LAUNCH_CHECK();
     return HV_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ pooled height head
 #define GAP_CHUNKS 32
-__global__ __launch_bounds__(256) void gap_partial_kernel(const float* __restrict__ x, int HW, int C, int x_ld, float* __restrict__ part) {
+__global__ __launch_bounds__(256) void gap_partial_kernel(const void* __restrict__ x, int xh, int HW, int C, int x_ld, float* __restrict__ part) {
     __shared__ float sh[256];
     const int b = blockIdx.y, tid = threadIdx.x;
     const int c = tid % C, rp = tid / C, rstep = 256 / C;
     const int rows = (HW + GAP_CHUNKS - 1) / GAP_CHUNKS;
     const int r0 = blockIdx.x * rows, r1 = min(HW, r0 + rows);
     float s = 0.f;
-    for (int r = r0 + rp; r < r1; r += rstep) s += x[((long long)b * HW + r) * x_ld + c];
+    for (int r = r0 + rp; r < r1; r += rstep) s += hv_ld1(x, ((long long)b * HW + r) * x_ld + c, xh);
     sh[tid] = s;
     __syncthreads();
     if (tid < C) {
@@ -146,25 +145,25 @@ __global__ void gap_fc_kernel(const float* __restrict__ part, int HW, int C, con
     if (c == 0) pred[b] = 1.f / (1.f + expf(-(s + bias[0])));
 }
 extern "C" size_t hv_gap_fc_workspace_bytes(int B, int C) { return (size_t)B * GAP_CHUNKS * C * sizeof(float); }
-extern "C" int hv_gap_fc_sigmoid(const float* x, int B, int HW, int C, int x_ld, const float* fc_w, const float* fc_b, float* pooled,
+extern "C" int hv_gap_fc_sigmoid(const void* x, int x_f16, int B, int HW, int C, int x_ld, const float* fc_w, const float* fc_b, float* pooled,
                                  float* pred, float* workspace, size_t workspace_bytes, void* stream) {
     if (!x || !fc_w || !fc_b || !pooled || !pred || B <= 0 || HW <= 0 || C <= 0 || x_ld < C) return HV_ERR_ARG;
     if (C > 256 || (C & (C - 1))) return HV_ERR_UNSUPPORTED;
     if (!workspace || workspace_bytes < hv_gap_fc_workspace_bytes(B, C)) return HV_ERR_WORKSPACE;
-    hipLaunchKernelGGL(gap_partial_kernel, dim3(GAP_CHUNKS, B), dim3(256), 0, (hipStream_t)stream, x, HW, C, x_ld, workspace);
+    hipLaunchKernelGGL(gap_partial_kernel, dim3(GAP_CHUNKS, B), dim3(256), 0, (hipStream_t)stream, x, x_f16, HW, C, x_ld, workspace);
     HV_LAUNCH_CHECK();
     hipLaunchKernelGGL(gap_fc_kernel, dim3(B), dim3(C < 64 ? 64 : C), 0, (hipStream_t)stream, workspace, HW, C, fc_w, fc_b, pooled, pred);
     HV_LAUNCH_CHECK();
     return HV_OK;
 }
-__global__ void gap_bwd_dx_kernel(const float* __restrict__ dpred, const float* __restrict__ pred, const float* __restrict__ w, float* __restrict__ dx,
+__global__ void gap_bwd_dx_kernel(const float* __restrict__ dpred, const float* __restrict__ pred, const float* __restrict__ w, void* __restrict__ dx, int dxh,
                                   int HW, int C, int dx_ld, long long n) {
     PW_LOOP(i, n) {
         const int c = (int)(i % C);
         const long long bp = i / C;
         const long long b = bp / HW;
         const float p = pred[b];
-        dx[bp * dx_ld + c] += dpred[b] * p * (1.f - p) * w[c] / (float)HW;
+        hv_st1(dx, bp * dx_ld + c, hv_ld1(dx, bp * dx_ld + c, dxh) + dpred[b] * p * (1.f - p) * w[c] / (float)HW, dxh);
     }
 }
 __global__ void gap_bwd_param_kernel(const float* __restrict__ dpred, const float* __restrict__ pred, const float* __restrict__ pooled, int B, int C,
@@ -179,11 +178,11 @@ __global__ void gap_bwd_param_kernel(const float* __restrict__ dpred, const floa
     if (c < C) dw[c] = acc ? dw[c] + sw : sw;
     if (c == 0) db[0] = acc ? db[0] + sb : sb;
 }
-extern "C" int hv_gap_fc_sigmoid_backward(const float* dpred, const float* pred, const float* pooled, const float* fc_w, float* dx, int B,
+extern "C" int hv_gap_fc_sigmoid_backward(const float* dpred, const float* pred, const float* pooled, const float* fc_w, void* dx, int dx_f16, int B,
                                           int HW, int C, int dx_ld, float* dw, float* db, int accumulate, void* stream) {
     if (!dpred || !pred || !pooled || !fc_w || !dx || !dw || !db || B <= 0 || HW <= 0 || C <= 0 || C > 1024) return HV_ERR_ARG;
     const long long n = (long long)B * HW * C;
-    hipLaunchKernelGGL(gap_bwd_dx_kernel, dim3(pw_grid(n)), dim3(256), 0, (hipStream_t)stream, dpred, pred, fc_w, dx, HW, C, dx_ld, n);
+    hipLaunchKernelGGL(gap_bwd_dx_kernel, dim3(pw_grid(n)), dim3(256), 0, (hipStream_t)stream, dpred, pred, fc_w, dx, dx_f16, HW, C, dx_ld, n);
     HV_LAUNCH_CHECK();
     hipLaunchKernelGGL(gap_bwd_param_kernel, dim3(1), dim3(C < 64 ? 64 : C), 0, (hipStream_t)stream, dpred, pred, pooled, B, C, dw, db, accumulate);
     HV_LAUNCH_CHECK();
@@ -491,8 +490,9 @@ __global__ __launch_bounds__(256) void gloss_finalize_kernel(const hv_gloss_desc
         const float a1 = d.pred1_h[b] - h, a2 = d.pred2_h[b] - h;
         hsum += (double)(fabsf(a1) / h * 40.f + fabsf(a2) / h * 40.f);
         const float s1 = a1 > 0.f ? 1.f : (a1 < 0.f ? -1.f : 0.f), s2 = a2 > 0.f ? 1.f : (a2 < 0.f ? -1.f : 0.f);
-        if (d.d_pred1) d.d_pred1[b] = 40.f * s1 / h * mh / (float)B;
-        if (d.d_pred2) d.d_pred2[b] = 40.f * s2 / h * mh / (float)B;
+        const float gs = d.grad_scale > 0.f ? d.grad_scale : 1.f;
+        if (d.d_pred1) d.d_pred1[b] = gs * (40.f * s1 / h * mh / (float)B);
+        if (d.d_pred2) d.d_pred2[b] = gs * (40.f * s2 / h * mh / (float)B);
     }
     const float lh = (float)(hsum / B);
     d.losses[0] = l1; d.losses[1] = ldice; d.losses[2] = lcd; d.losses[3] = ledge; d.losses[4] = lh;
@@ -500,7 +500,8 @@ __global__ __launch_bounds__(256) void gloss_finalize_kernel(const hv_gloss_desc
 }
 __global__ void gloss_seed_kernel(const hv_gloss_desc d, const float* __restrict__ coef, long long n) {
     const int HW = d.H * d.W;
-    const float cl1 = coef[0], invB = 1.f / (float)d.B;
+    const float gs = d.grad_scale > 0.f ? d.grad_scale : 1.f;      // power of two: the scaled seeds are exact multiples
+    const float cl1 = coef[0] * gs, invB = gs / (float)d.B;
     PW_LOOP(i, n) {
         const int b = (int)(i / HW);
         const float rb = d.real_B[i];

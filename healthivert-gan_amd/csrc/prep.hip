@@ -170,7 +170,7 @@ extern "C" int hv_weight_prep_backward(const hv_wprep_bwd_layer* d_layers, int n
 // ------------------------------------------------------------------------------------------------ activation gradient
 // vector path: C % 4 == 0 and C/4 a power of two <= 256: thread owns one 4-channel group, rows strided.
 template <bool VEC>
-__global__ __launch_bounds__(256) void act_bwd_kernel(float* __restrict__ dy, const float* __restrict__ y, long long npix, int C,
+__global__ __launch_bounds__(256) void act_bwd_kernel(void* __restrict__ dy, const void* __restrict__ y, int H, int YH, long long npix, int C,
                                                       int dy_ld, int dy_coff, int y_ld, int y_coff, int act,
                                                       float* __restrict__ part, int rows_per_block) {
     __shared__ float sh[256 * 4];
@@ -182,26 +182,25 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(float* __restrict__ dy, co
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
         long long r = r0 + rp;
         for (; r + rstep < r1; r += 2 * rstep) {   // two rows in flight per lane (HBM streaming needs the loads, not the math)
-            float* p0 = dy + r * dy_ld + dy_coff + cg * 4;
-            float* p1 = p0 + (long long)rstep * dy_ld;
-            float4 g0 = *reinterpret_cast<float4*>(p0), g1 = *reinterpret_cast<float4*>(p1);
-            const float4 o0 = *reinterpret_cast<const float4*>(y + r * y_ld + y_coff + cg * 4);
-            const float4 o1 = *reinterpret_cast<const float4*>(y + (r + rstep) * y_ld + y_coff + cg * 4);
+            const long long p0 = r * dy_ld + dy_coff + cg * 4, p1 = p0 + (long long)rstep * dy_ld;
+            float4 g0 = hv_ld4(dy, p0, H), g1 = hv_ld4(dy, p1, H);
+            const float4 o0 = hv_ld4(y, r * y_ld + y_coff + cg * 4, YH);
+            const float4 o1 = hv_ld4(y, (r + rstep) * y_ld + y_coff + cg * 4, YH);
             g0.x *= hv_act_grad_from_out(o0.x, act); g0.y *= hv_act_grad_from_out(o0.y, act);
             g0.z *= hv_act_grad_from_out(o0.z, act); g0.w *= hv_act_grad_from_out(o0.w, act);
             g1.x *= hv_act_grad_from_out(o1.x, act); g1.y *= hv_act_grad_from_out(o1.y, act);
             g1.z *= hv_act_grad_from_out(o1.z, act); g1.w *= hv_act_grad_from_out(o1.w, act);
-            *reinterpret_cast<float4*>(p0) = g0;
-            *reinterpret_cast<float4*>(p1) = g1;
+            hv_st4(dy, p0, g0, H);
+            hv_st4(dy, p1, g1, H);
             s.x += g0.x; s.y += g0.y; s.z += g0.z; s.w += g0.w;
             s.x += g1.x; s.y += g1.y; s.z += g1.z; s.w += g1.w;
         }
         for (; r < r1; r += rstep) {
-            float4 g = *reinterpret_cast<float4*>(dy + r * dy_ld + dy_coff + cg * 4);
-            const float4 o = *reinterpret_cast<const float4*>(y + r * y_ld + y_coff + cg * 4);
+            float4 g = hv_ld4(dy, r * dy_ld + dy_coff + cg * 4, H);
+            const float4 o = hv_ld4(y, r * y_ld + y_coff + cg * 4, YH);
             g.x *= hv_act_grad_from_out(o.x, act); g.y *= hv_act_grad_from_out(o.y, act);
             g.z *= hv_act_grad_from_out(o.z, act); g.w *= hv_act_grad_from_out(o.w, act);
-            *reinterpret_cast<float4*>(dy + r * dy_ld + dy_coff + cg * 4) = g;
+            hv_st4(dy, r * dy_ld + dy_coff + cg * 4, g, H);
             s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
         }
         if (part) {
@@ -220,8 +219,8 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(float* __restrict__ dy, co
         const int c = tid % C, rp = tid / C, rstep = 256 / C;
         float s = 0.f;
         for (long long r = r0 + rp; r < r1; r += rstep) {
-            float g = dy[r * dy_ld + dy_coff + c] * hv_act_grad_from_out(y[r * y_ld + y_coff + c], act);
-            dy[r * dy_ld + dy_coff + c] = g;
+            float g = hv_ld1(dy, r * dy_ld + dy_coff + c, H) * hv_act_grad_from_out(hv_ld1(y, r * y_ld + y_coff + c, YH), act);
+            hv_st1(dy, r * dy_ld + dy_coff + c, g, H);
             s += g;
         }
         if (part) {
@@ -268,7 +267,7 @@ extern "C" size_t hv_act_backward_workspace_bytes(long long npix, int C) {
     return (size_t)act_bwd_blocks(npix, C, &rpb) * C * sizeof(float);
 }
 
-extern "C" int hv_act_backward(float* dy, const float* y, long long npix, int C, int dy_ld, int dy_coff, int y_ld, int y_coff,
+extern "C" int hv_act_backward(void* dy, int dy_f16, const void* y, int y_f16, long long npix, int C, int dy_ld, int dy_coff, int y_ld, int y_coff,
                                int act, float* dbias, int dbias_accumulate, float* workspace, size_t workspace_bytes, void* stream) {
     if (!dy || !y || npix <= 0 || C <= 0) return HV_ERR_ARG;
     const bool aligned = !(dy_ld & 3) && !(dy_coff & 3) && !(y_ld & 3) && !(y_coff & 3) && !((uintptr_t)dy & 15) && !((uintptr_t)y & 15);
@@ -280,12 +279,9 @@ extern "C" int hv_act_backward(float* dy, const float* y, long long npix, int C,
     if (!vec && act_vec_ok(C)) return HV_ERR_UNSUPPORTED;  // vector-shaped C on unaligned views is not needed by the path
     if (dbias && (!workspace || workspace_bytes < (size_t)nb * C * sizeof(float))) return HV_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    if (vec)
-        hipLaunchKernelGGL((act_bwd_kernel<true>), dim3(nb), dim3(256), 0, s, dy, y, npix, C, dy_ld, dy_coff, y_ld, y_coff, act,
-                           dbias ? workspace : nullptr, rpb);
-    else
-        hipLaunchKernelGGL((act_bwd_kernel<false>), dim3(nb), dim3(256), 0, s, dy, y, npix, C, dy_ld, dy_coff, y_ld, y_coff, act,
-                           dbias ? workspace : nullptr, rpb);
+    float* part = dbias ? workspace : nullptr;
+    if (vec) hipLaunchKernelGGL((act_bwd_kernel<true>), dim3(nb), dim3(256), 0, s, dy, y, dy_f16, y_f16, npix, C, dy_ld, dy_coff, y_ld, y_coff, act, part, rpb);
+    else hipLaunchKernelGGL((act_bwd_kernel<false>), dim3(nb), dim3(256), 0, s, dy, y, dy_f16, y_f16, npix, C, dy_ld, dy_coff, y_ld, y_coff, act, part, rpb);
     HV_LAUNCH_CHECK();
     if (dbias) {
         hipLaunchKernelGGL(colsum_finalize_kernel, dim3(C), dim3(64), 0, s, workspace, nb, C, dbias, dbias_accumulate);

@@ -15,7 +15,7 @@
 #include "hv_common.h"
 
 struct WHaloK {
-    const float* x; const float* g; float* slabs;
+    const _Float16* x; const _Float16* g; float* slabs;       // fp16 storage (the fp16 mode's activations and gradients)
     int B, Hl, Wl, in_shift, Wp, img_stride, x_ld, x_coff, Cin;
     int Ho, Wo, g_ld, g_coff, Cout, pad;
     int tiles_x, tiles_per_img, ntiles;
@@ -74,10 +74,11 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const WHaloK p) {
     // one workgroup a CU can hold (100-130 accumulator registers per lane) does not sit idle for an HBM round trip per tile.
     constexpr int GU = (BN / 4) * TH * 4, XU = (BC / 4) * PH * 5;     // staging units of 8 pixels x 4 channels
     constexpr int GPT = (GU + 255) / 256, XPT = (XU + 255) / 256;
-    const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t gsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.g), 0, p.g_bytes, 0x00020000);
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 rg[GPT][8], rx[XPT][8];
+    const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t gsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.g), 0, p.g_bytes, 0x00020000);
+    typedef HvSt<true> SS;
+    typedef SS::R SR;                            // 4 consecutive channels of one pixel: 8 bytes
+    SR rg[GPT][8], rx[XPT][8];
     auto prefetch = [&](int tile) __attribute__((always_inline)) {
         const int n_img = tile / p.tiles_per_img, tr = tile - n_img * p.tiles_per_img;
         const int oy0 = (tr / p.tiles_x) * TH, ox0 = (tr % p.tiles_x) * TW;
@@ -87,10 +88,10 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const WHaloK p) {
             const int cg = u % (BN / 4), rr = u / (BN / 4), run = rr & 3, ty = rr >> 2;
             const int oy = oy0 + ty, co = co0 + cg * 4, ox = ox0 + run * 8;
             const bool rok = u < GU && oy < p.Ho && co < p.Cout;
-            const unsigned base = (unsigned)(((n_img * p.Ho + oy) * p.Wo + ox) * p.g_ld + p.g_coff + co) * 4u;
+            const unsigned base = (unsigned)(((n_img * p.Ho + oy) * p.Wo + ox) * p.g_ld + p.g_coff + co) * SS::B;
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-                rg[i][e] = __builtin_amdgcn_raw_buffer_load_b128(gsrc, (rok && ox + e < p.Wo) ? base + (unsigned)(e * p.g_ld) * 4u : 0x80000000u, 0, 0);
+                rg[i][e] = SS::ld(gsrc, (rok && ox + e < p.Wo) ? base + (unsigned)(e * p.g_ld) * SS::B : 0x80000000u, 0);
         }
 #pragma unroll
         for (int i = 0; i < XPT; ++i) {
@@ -98,17 +99,18 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const WHaloK p) {
             const int cg = u % (BC / 4), rr = u / (BC / 4), run = rr % 5, py = rr / 5;
             const int hi = oy0 - p.pad + py, ci = ci0 + cg * 4, wi0 = ox0 - p.pad + run * 8;
             const bool rok = u < XU && (unsigned)hi < (unsigned)p.Hl && ci < p.Cin;
-            const unsigned base = (unsigned)(n_img * p.img_stride + p.x_coff + (hi >> p.in_shift) * p.Wp * p.x_ld + ci) * 4u;
+            const unsigned base = (unsigned)(n_img * p.img_stride + p.x_coff + (hi >> p.in_shift) * p.Wp * p.x_ld + ci) * SS::B;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int wi = wi0 + e;
-                rx[i][e] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, (rok && (unsigned)wi < (unsigned)p.Wl) ? base + (unsigned)((wi >> p.in_shift) * p.x_ld) * 4u : 0x80000000u, 0, 0);
+                rx[i][e] = SS::ld(xsrc, (rok && (unsigned)wi < (unsigned)p.Wl) ? base + (unsigned)((wi >> p.in_shift) * p.x_ld) * SS::B : 0x80000000u, 0);
             }
         }
     };
-    auto pack4 = [&](const u32x4 (&v)[8], int c) __attribute__((always_inline)) {
-        auto f = [&](int e) { return __uint_as_float(c == 0 ? v[e].x : c == 1 ? v[e].y : c == 2 ? v[e].z : v[e].w); };
-        return make_uint4(hv_pack2(f(0), f(1)), hv_pack2(f(2), f(3)), hv_pack2(f(4), f(5)), hv_pack2(f(6), f(7)));
+    // channel c of 8 consecutive pixels -> 8 halfs (the transpose to [channel][pixel]): 16-bit selects, no conversion
+    auto pack4 = [&](const SR (&v)[8], int c) __attribute__((always_inline)) {
+        auto h = [&](int e) -> uint32_t { const uint32_t w = (c & 2) ? v[e].y : v[e].x; return (c & 1) ? (w >> 16) : (w & 0xffffu); };
+        return make_uint4(h(0) | (h(1) << 16), h(2) | (h(3) << 16), h(4) | (h(5) << 16), h(6) | (h(7) << 16));
     };
     const bool do_bias = p.bias_out != nullptr && blockIdx.z == 0;
     float bsum[GPT][4];
@@ -122,8 +124,8 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const WHaloK p) {
             if (do_bias) {   // bias gradient: fp32 sums of the staged g values (zeros outside the image)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    bsum[i][0] += __uint_as_float(rg[i][e].x); bsum[i][1] += __uint_as_float(rg[i][e].y);
-                    bsum[i][2] += __uint_as_float(rg[i][e].z); bsum[i][3] += __uint_as_float(rg[i][e].w);
+                    const float4 q = SS::f4(rg[i][e]);
+                    bsum[i][0] += q.x; bsum[i][1] += q.y; bsum[i][2] += q.z; bsum[i][3] += q.w;
                 }
             }
             const int cg = u % (BN / 4), rr = u / (BN / 4), run = rr & 3, ty = rr >> 2;
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const WHaloK p) {
 
 struct WHaloPlan { int BN, BC, gx; size_t lds; };
 static bool wgrad_halo_plan(const hv_wgrad_desc* d, WHaloPlan* pl) {
-    if (d->precision != HV_F16 || d->stride != 1 || d->dil != 1 || d->KH != d->KW || d->KH < 3 || d->KH > 5) return false;
+    if (d->precision != HV_F16 || !d->x_f16 || !d->g_f16 || d->stride != 1 || d->dil != 1 || d->KH != d->KW || d->KH < 3 || d->KH > 5) return false;
     if (d->Wo != d->W + 2 * d->pad - d->KW + 1 || d->Ho != d->H + 2 * d->pad - d->KH + 1) return false;
     if (d->KH == 5 && (d->Cout > 16 || d->Cin > 16)) return false;      // 25 taps: 16x16 tiles only (register budget)
     if (d->Cout > 16) return false;   // measured: with more than one 16-wide co tile the gather kernel's larger MFMA tiles win
@@ -330,15 +332,16 @@ int hv_wgrad_halo(const hv_wgrad_desc* d, int* nslabs, hipStream_t s) {
     const size_t need = hv_wgrad_halo_workspace_bytes(d);
     if (!d->workspace || d->workspace_bytes < need) return HV_ERR_WORKSPACE;
     WHaloK k;
-    k.x = d->x; k.g = d->g; k.slabs = d->workspace;
+    if (!d->x_f16 || !d->g_f16) return HV_ERR_UNSUPPORTED;
+    k.x = reinterpret_cast<const _Float16*>(d->x); k.g = reinterpret_cast<const _Float16*>(d->g); k.slabs = d->workspace;
     k.B = d->B; k.Hl = d->H; k.Wl = d->W; k.in_shift = d->in_shift; k.Wp = d->W >> d->in_shift;
     k.img_stride = (d->H >> d->in_shift) * k.Wp * d->x_ld; k.x_ld = d->x_ld; k.x_coff = d->x_coff; k.Cin = d->Cin;
     k.Ho = d->Ho; k.Wo = d->Wo; k.g_ld = d->g_ld; k.g_coff = d->g_coff; k.Cout = d->Cout; k.pad = d->pad;
     k.tiles_x = hv_cdiv(d->Wo, 32); k.tiles_per_img = k.tiles_x * hv_cdiv(d->Ho, 8); k.ntiles = k.tiles_per_img * d->B;
     k.slab = (long long)d->Cout * d->KH * d->KW * d->Cin;
     k.bias_out = d->dbias ? d->workspace + (long long)pl.gx * k.slab : nullptr;
-    k.x_bytes = (unsigned)((size_t)d->B * k.img_stride * sizeof(float));
-    k.g_bytes = (unsigned)((size_t)d->B * d->Ho * d->Wo * d->g_ld * sizeof(float));
+    k.x_bytes = (unsigned)((size_t)d->B * k.img_stride * sizeof(_Float16));
+    k.g_bytes = (unsigned)((size_t)d->B * d->Ho * d->Wo * d->g_ld * sizeof(_Float16));
     *nslabs = pl.gx;
     if (d->KH == 5) return launch_wh<5, 16, 16>(k, pl, d, s);
     if (d->KH == 4) return pl.BC == 16 ? launch_wh<4, 16, 16, true>(k, pl, d, s) : launch_wh<4, 16, 32, true>(k, pl, d, s);

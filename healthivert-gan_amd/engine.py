@@ -19,7 +19,7 @@ from .ops import Act, rup
 def precision_note(precision):
     """What the precision mode means, for bench.py's config record."""
     if precision in ('fp16', 'f16'):
-        return 'fp16 MFMA operands / fp32 accumulate, fp32 storage'
+        return 'fp16 MFMA operands / fp32 accumulate; activations and gradients stored as fp16 (image tensors, attention scores, weights, statistics fp32)'
     return 'fp32 MFMA (v_mfma_f32_16x16x4_f32), fp32 storage'
 
 
@@ -327,6 +327,16 @@ class AttentionPlan:
         reference's inference loop); False = the reference's batched behaviour (sample 0's mask for all, inpaint_networks.py:314)."""
         L_ = _lib.get()
         B, H, W, C, L = self.B, self.H, self.W, self.C, self.L
+        # the attention block keeps fp32 internally (its score matrices feed a x10 soft-max): fp16-stored feature maps are converted
+        # at its boundary (two small copies of the 64-channel map)
+        out_user = None
+        if f.f16:
+            self.f32 = getattr(self, 'f32', None) or Act(torch.zeros(B, H, W, C, dtype=torch.float32, device=f.t.device))
+            ops.copy_channels(f, self.f32, mode=0)
+            f = self.f32
+        if out.f16:
+            self.out32 = getattr(self, 'out32', None) or Act(torch.zeros(B, H, W, C, dtype=torch.float32, device=f.t.device))
+            out_user, out = out, self.out32
         L_.call('hv_ca_patches', ptr(f.t), B, H, W, C, f.ld, ptr(self.fd.t), ptr(self.wp), ptr(self.wpT), ptr(self.norm), ptr(self.rnorm), stream())
         L_.call('hv_ca_raw_patches', ptr(f.t), B, H, W, C, f.ld, ptr(self.raw), ptr(self.rawT), stream())
         if per_sample_mask:
@@ -349,6 +359,8 @@ class AttentionPlan:
             L_.call('hv_ca_softmax', ptr(s.t), ptr(self.mm), ptr(self.A.t), B, L, ctypes.c_float(self.scale),
                     ptr(self.argmax) if want_argmax else None, stream())
         ops.conv2d(self.A, self.rawT, out, 4, 2, 1, 1, transposed=True, alpha=0.25, w_bstride=C * 16 * L, precision=prec)
+        if out_user is not None:
+            ops.copy_channels(out, out_user, mode=0)
 
     def backward(self, dout, df, accumulate, prec):
         """dout: Act grad of the output; df: Act grad of the input feature map (assigned or accumulated)."""
@@ -360,6 +372,14 @@ class AttentionPlan:
                            dS1=Act(z(B, self.h, self.w, L)), dS0=Act(z(B, self.h, self.w, L)), Gs=Act(z(B, self.h, self.w, L)),
                            coef=z(17 * B, L), dwp=Act(z(B, self.h, self.w, 9 * C)))
         bw = self.bw
+        df_user = None
+        if dout.f16:
+            self.dout32 = getattr(self, 'dout32', None) or Act(torch.zeros(B, H, W, C, dtype=torch.float32, device=dout.t.device))
+            ops.copy_channels(dout, self.dout32, mode=0)
+            dout = self.dout32
+        if df.f16:
+            self.df32 = getattr(self, 'df32', None) or Act(torch.zeros(B, H, W, C, dtype=torch.float32, device=dout.t.device))
+            df_user, df, df_acc, accumulate = df, self.df32, accumulate, False
         # through the paste: dA and d(raw patches)
         ops.conv2d(dout, self.raw, bw['dA'], 4, 2, 1, 1, alpha=0.25, w_bstride=L * 16 * C, precision=prec)
         L_.call('hv_transpose_batched', ptr(self.A.t), ptr(bw['AT'].t), B, L, L, stream())
@@ -377,3 +397,5 @@ class AttentionPlan:
         L_.call('hv_ca_score_backward_prep', ptr(ds0.t), ptr(self.S0.t), ptr(self.norm), ptr(self.rnorm), ptr(bw['Gs'].t), ptr(bw['coef']), B, L, stream())
         ops.conv2d(bw['Gs'], self.wpT, bw['dwp'], 1, 1, 0, 1, w_bstride=9 * C * L, precision=prec)
         L_.call('hv_ca_patches_backward', ptr(bw['dwp'].t), ptr(self.wp), ptr(bw['coef']), ptr(df.t), B, H, W, C, df.ld, 1, stream())
+        if df_user is not None:
+            ops.copy_channels(df, df_user, mode=0, accumulate=bool(df_acc))

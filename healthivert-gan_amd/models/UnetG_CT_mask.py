@@ -63,7 +63,8 @@ class UpsampleBlock(nn.Module):
 class _UnetPlan:
     def __init__(self, net, B, H, W, device):
         self.B, self.H, self.W = B, H, W
-        z = lambda h, w, C: Act(torch.zeros(B, h, w, rup(C, 4), dtype=torch.float32, device=device), C, 0)
+        dt = ops.storage_dtype(net.precision)
+        z = lambda h, w, C: Act(torch.zeros(B, h, w, rup(C, 4), dtype=dt, device=device), C, 0)
         self.book = E.GradBook()
         nd = len(net.down_blocks)
         P = net._pset_convs
@@ -142,7 +143,7 @@ class UnetGenerator(nn.Module):
         return self._pset
 
     def _plan(self, B, H, W, device):
-        key = (B, H, W, str(device))
+        key = (B, H, W, str(device), ops.precision_id(self.precision))
         if key not in self._plans:
             if H % (2 ** len(self.down_blocks)) or W % (2 ** len(self.down_blocks)):
                 raise NotImplementedError("UnetGenerator HIP path: H and W divisible by 2^num_downs")
@@ -160,7 +161,7 @@ class UnetGenerator(nn.Module):
         B, C, H, W = x.shape
         P = self._plan(B, H, W, x.device)
         self.paramset().prep(x.device, power_iter=False)
-        _lib.get().call('hv_nchw_to_nhwc', _lib.ptr(x.contiguous().float()), _lib.ptr(P.x_in.t), B, C, H, W, P.x_in.ld, 0, _lib.stream())
+        _lib.get().call('hv_nchw_to_nhwc', _lib.ptr(x.contiguous().float()), _lib.ptr(P.x_in.t), P.x_in.f16, B, C, H, W, P.x_in.ld, 0, _lib.stream())
         P.training = training
         for ent in P.down:
             blk = ent['blk']
@@ -200,7 +201,7 @@ class UnetGenerator(nn.Module):
         for br, seed in (('up_blocks_ct', d_ct), ('up_blocks_mask', d_mask)):
             ents = P.up[br]
             g_out = book.twin(ents[-1]['cat'])
-            _lib.get().call('hv_nchw_to_nhwc', _lib.ptr(seed.contiguous().float()), _lib.ptr(g_out.t), P.B, seed.shape[1], P.H, P.W, g_out.ld, 0, _lib.stream())
+            _lib.get().call('hv_nchw_to_nhwc', _lib.ptr(seed.contiguous().float()), _lib.ptr(g_out.t), g_out.f16, P.B, seed.shape[1], P.H, P.W, g_out.ld, 0, _lib.stream())
             book.mark(g_out)
             for j in range(nd - 1, -1, -1):
                 ent = ents[j]

@@ -208,7 +208,8 @@ class _GenPlan:
         cg, fg = gen.coarse_generator, gen.fine_generator
         c = gen.cnum
         self.B, self.H, self.W, self.dev = B, H, W, device
-        z = lambda h, w, C: Act(torch.zeros(B, h, w, rup(C, 4), dtype=torch.float32, device=device), C, 0)
+        dt = ops.storage_dtype(gen.precision)        # fp16 buffers in the fp16 mode; the (B,1,H,W) image outputs stay fp32
+        z = lambda h, w, C: Act(torch.zeros(B, h, w, rup(C, 4), dtype=dt, device=device), C, 0)
         img = lambda: torch.zeros(B, 1, H, W, dtype=torch.float32, device=device)
         H2, W2, H4, W4 = H // 2, W // 2, H // 4, W // 4
         self.book = E.GradBook()
@@ -347,7 +348,7 @@ class Generator(nn.Module):
         return self._pset
 
     def _plan(self, B, H, W, device):
-        key = (B, H, W, str(device))
+        key = (B, H, W, str(device), ops.precision_id(self.precision))
         if key not in self._plans:
             if H % 8 or W % 8 or H != W:
                 raise NotImplementedError("Generator HIP path expects square inputs with a side divisible by 8")
@@ -425,7 +426,7 @@ class Generator(nn.Module):
         key = id(node)
         if key not in P.tmp_up:
             x = node.x
-            P.tmp_up[key] = Act(torch.zeros(x.B, x.H * 2, x.W * 2, x.ld, dtype=torch.float32, device=x.t.device), node.p.cin_fwd, 0)
+            P.tmp_up[key] = Act(torch.zeros(x.B, x.H * 2, x.W * 2, x.ld, dtype=x.t.dtype, device=x.t.device), node.p.cin_fwd, 0)
         return P.tmp_up[key]
 
     def _head_backward(self, P, node, seed, gname, prec, book, mul_x=None):

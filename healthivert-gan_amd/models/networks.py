@@ -145,7 +145,8 @@ class GANLoss(nn.Module):
 class _DiscPlan:
     def __init__(self, net, B, H, W, device):
         self.B, self.H, self.W = B, H, W
-        z = lambda h, w, C: Act(torch.zeros(B, h, w, rup(C, 4), dtype=torch.float32, device=device), C, 0)
+        dt = ops.storage_dtype(net.precision)        # fp16 buffers in the fp16 mode; input image, logits and dx stay fp32
+        z = lambda h, w, C: Act(torch.zeros(B, h, w, rup(C, 4), dtype=dt, device=device), C, 0)
         self.book = E.GradBook()
         self.x4 = z(H, W, 1)
         self.layers = []
@@ -243,7 +244,7 @@ class NLayerDiscriminator(nn.Module):
         """slot 0 is the explicit executor's plan (Pix2PixModel's fused step); the nn.Module API takes one plan per forward whose
         autograd graph is still alive (slot 1, 2, ...): `pred_fake = D(fake); pred_real = D(real); loss.backward()` -- the
         reference's own backward_D (pix2pix_model.py:267-283) -- keeps both passes' activations until their backward ran."""
-        key = (B, H, W, str(device), slot)
+        key = (B, H, W, str(device), slot, ops.precision_id(self.precision))
         if key not in self._plans:
             self.paramset()
             self._plans[key] = _DiscPlan(self, B, H, W, device)
@@ -252,7 +253,7 @@ class NLayerDiscriminator(nn.Module):
     def _free_plan_slot(self, B, H, W, device):
         slot = 1
         while True:
-            P = self._plans.get((B, H, W, str(device), slot))
+            P = self._plans.get((B, H, W, str(device), slot, ops.precision_id(self.precision)))
             if P is None or P.pending is None or P.pending() is None:
                 return slot
             slot += 1

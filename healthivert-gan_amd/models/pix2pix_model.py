@@ -97,6 +97,13 @@ class Pix2PixModel(BaseModel):
         if self.isTrain:       # every rank starts from rank 0's initial weights (a no-op without a process group)
             ddp.broadcast_parameters([self.netG, self.netD_1, self.netD_2, self.netD_3])
         import os as _os
+        # gradient (loss) scale of the fp16 storage mode: activation gradients of this model are ~1e-5 .. 1e-7, i.e. subnormal or zero in
+        # fp16.  Every gradient seed of the step is multiplied by a power of two S (exact), the whole backward is linear in its seeds, and the
+        # flat parameter-gradient buffer of each network is multiplied by 1/S (exact) before anything reads it.  S = 1 in the fp32 mode.
+        fp16 = ops.default_precision() == _lib.F16
+        self.grad_scale = float(_os.environ.get('HV_GRAD_SCALE', '8192' if fp16 else '1'))
+        if self.grad_scale <= 0 or (self.grad_scale != 1 and not float(self.grad_scale).is_integer()) or int(self.grad_scale) & (int(self.grad_scale) - 1):
+            raise ValueError('HV_GRAD_SCALE must be a power of two')
         self.concurrent_d = _os.environ.get('HV_CONCURRENT_D', '1') != '0'
         self.batch_d = _os.environ.get('HV_BATCH_D', '0') != '0'   # measured: no gain once the three D streams overlap
         self.real_first = _os.environ.get('HV_REAL_FIRST', '1') != '0'   # D real passes overlap the generator forward
@@ -215,18 +222,19 @@ class Pix2PixModel(BaseModel):
             L.call('hv_affine', ptr(x2[B:]), ptr(real), n, ctypes.c_float(1.0), ctypes.c_float(0.0), stream())
             P = net.run_forward(x2, training=True, prep=True, groups=2)
             dz = self._buf('dzz%d' % k, P.logits)
-            ops.gan_loss(P.logits[:B], False, mode, loss=lf, dz=dz[:B], grad_weight=0.5)
-            ops.gan_loss(P.logits[B:], True, mode, loss=lr, dz=dz[B:], grad_weight=0.5)
+            ops.gan_loss(P.logits[:B], False, mode, loss=lf, dz=dz[:B], grad_weight=0.5 * self.grad_scale)
+            ops.gan_loss(P.logits[B:], True, mode, loss=lr, dz=dz[B:], grad_weight=0.5 * self.grad_scale)
             net.run_backward(P, dz, need_dx=False, param_grads=True, accumulate=False)
         else:
             P = net.run_forward(fake, training=True, prep=True)
             dz = self._buf('dz%d' % k, P.logits)
-            ops.gan_loss(P.logits, False, mode, loss=lf, dz=dz, grad_weight=0.5)
+            ops.gan_loss(P.logits, False, mode, loss=lf, dz=dz, grad_weight=0.5 * self.grad_scale)
             net.run_backward(P, dz, need_dx=False, param_grads=True, accumulate=False)
             P = net.run_forward(real, training=True, prep=False)
-            ops.gan_loss(P.logits, True, mode, loss=lr, dz=dz, grad_weight=0.5)
+            ops.gan_loss(P.logits, True, mode, loss=lr, dz=dz, grad_weight=0.5 * self.grad_scale)
             net.run_backward(P, dz, need_dx=False, param_grads=True, accumulate=True)
         net.finish()
+        self._unscale(net)
         setattr(self, 'loss_D_fake_%d' % k, lf)
         setattr(self, 'loss_D_real_%d' % k, lr)
 
@@ -237,7 +245,7 @@ class Pix2PixModel(BaseModel):
         lr = self._loss_slot(2 * k + 1)
         P = net.run_forward(real, training=True, prep=True, stat_order='swapped_first')
         dz = self._buf('dz%d' % k, P.logits)
-        ops.gan_loss(P.logits, True, self.opt.gan_mode, loss=lr, dz=dz, grad_weight=0.5)
+        ops.gan_loss(P.logits, True, self.opt.gan_mode, loss=lr, dz=dz, grad_weight=0.5 * self.grad_scale)
         net.run_backward(P, dz, need_dx=False, param_grads=True, accumulate=False)
         setattr(self, 'loss_D_real_%d' % k, lr)
 
@@ -248,9 +256,10 @@ class Pix2PixModel(BaseModel):
         lf = self._loss_slot(2 * k)
         P = net.run_forward(fake, training=True, prep=False, stat_order='swapped_second')
         dz = self._buf('dz%d' % k, P.logits)
-        ops.gan_loss(P.logits, False, self.opt.gan_mode, loss=lf, dz=dz, grad_weight=0.5)
+        ops.gan_loss(P.logits, False, self.opt.gan_mode, loss=lf, dz=dz, grad_weight=0.5 * self.grad_scale)
         net.run_backward(P, dz, need_dx=False, param_grads=True, accumulate=True)
         net.finish()
+        self._unscale(net)
         setattr(self, 'loss_D_fake_%d' % k, lf)
 
     def _real_local_early(self):
@@ -284,7 +293,7 @@ class Pix2PixModel(BaseModel):
         fake = {1: self.fake_B, 2: self.fake_B_mask_raw, 3: self.fake_B_local}[k]
         P = net.run_forward(fake, training=True, prep=True)
         dz = self._buf('dz%d' % k, P.logits)
-        ops.gan_loss(P.logits, True, self.opt.gan_mode, loss=self._loss_slot(15 + k), loss_weight=1.0 / 6.0, dz=dz, grad_weight=1.0 / 6.0)
+        ops.gan_loss(P.logits, True, self.opt.gan_mode, loss=self._loss_slot(15 + k), loss_weight=1.0 / 6.0, dz=dz, grad_weight=self.grad_scale / 6.0)
         if k != 2:   # D_2 sees a thresholded mask: no gradient path to G (reference :201,:324)
             self._dxs[k] = net.run_backward(P, dz, need_dx=True, param_grads=False)
 
@@ -312,6 +321,7 @@ class Pix2PixModel(BaseModel):
                      ('d_fine_seg', seeds['d_fine_seg']), ('d_coarse_seg', seeds['d_coarse_seg']), ('d_pred1', dp1), ('d_pred2', dp2)):
             setattr(g, f, ptr(t).value)
         g.lambda_L1 = float(self.opt.lambda_L1)
+        g.grad_scale = self.grad_scale
         g.B, g.H, g.W = B, H, W
         need = L.size('hv_generator_losses_workspace_bytes', B)
         ws, _ = ops._ws(need, self.device, slot=1)
@@ -330,6 +340,13 @@ class Pix2PixModel(BaseModel):
                self.half_band, 0, stream())
         L.call('hv_shrm_backward', ptr(seeds['d_fake_B_coarse']), None, None, ptr(self._rows), 1, ptr(d_x1), B, H, W, self.half_band, 0, stream())
         self.netG.run_backward(self._gplan, seeds['d_coarse_seg'], seeds['d_fine_seg'], d_x1, d_x2, dp1, dp2)
+        self._unscale(self.netG)
+
+    def _unscale(self, net):
+        """Take the gradient scale out of a network's parameter gradients (one pass over its flat gradient buffer; exact: 1/S is a power of two)."""
+        if self.grad_scale != 1.0:
+            flat = net.paramset().flat_grad
+            _lib.get().call('hv_affine', ptr(flat), ptr(flat), ctypes.c_longlong(flat.numel()), ctypes.c_float(1.0 / self.grad_scale), ctypes.c_float(0.0), stream())
 
     # ---------------------------------------------------------------- the step, in three device-only phases
     def _phase_a(self):

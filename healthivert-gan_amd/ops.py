@@ -46,31 +46,39 @@ def rup(v, m):
     return (v + m - 1) // m * m
 
 
+def storage_dtype(precision):
+    """Element type of the activation / gradient tensors INSIDE a network for a compute precision: the fp16 mode stores them as
+    fp16 (they are rounded to fp16 as MFMA operands anyway: half the HBM / L2 bytes, no conversions in the staging code), the
+    exact-fp32 parity mode as fp32.  Image-level tensors of the reference API and the attention score matrices are always fp32."""
+    return torch.float16 if precision_id(precision) == F16 else torch.float32
+
+
 class Act:
-    """NHWC fp32 activation view: tensor [B,H,W,ld], channels [coff, coff+C)."""
-    __slots__ = ('t', 'B', 'H', 'W', 'C', 'ld', 'coff')
+    """NHWC activation view: tensor [B,H,W,ld] (fp32, or fp16 in the fp16 storage mode), channels [coff, coff+C)."""
+    __slots__ = ('t', 'B', 'H', 'W', 'C', 'ld', 'coff', 'f16')
 
     def __init__(self, t, C=None, coff=0):
-        assert t.dim() == 4 and t.dtype == torch.float32 and t.is_contiguous(), (t.shape, t.dtype)
+        assert t.dim() == 4 and t.dtype in (torch.float32, torch.float16) and t.is_contiguous(), (t.shape, t.dtype)
         _lib.require_gpu(t)
         self.t = t
+        self.f16 = int(t.dtype == torch.float16)
         self.B, self.H, self.W, self.ld = t.shape
         self.coff = coff
         self.C = self.ld - coff if C is None else C
         assert 0 < self.C and self.coff + self.C <= self.ld
 
     @staticmethod
-    def empty(B, H, W, C, device, ld=None, zero=False):
+    def empty(B, H, W, C, device, ld=None, zero=False, dtype=torch.float32):
         ld = C if ld is None else ld
-        t = (torch.zeros if zero else torch.empty)(B, H, W, ld, dtype=torch.float32, device=device)
+        t = (torch.zeros if zero else torch.empty)(B, H, W, ld, dtype=dtype, device=device)
         return Act(t, C, 0)
 
     def slice(self, coff, C):
         return Act(self.t, C, self.coff + coff)
 
     def like(self, zero=False):
-        return Act.empty(self.B, self.H, self.W, self.ld, self.t.device, zero=zero).slice(self.coff, self.C) \
-            if (self.coff or self.C != self.ld) else Act.empty(self.B, self.H, self.W, self.C, self.t.device, zero=zero)
+        return Act.empty(self.B, self.H, self.W, self.ld, self.t.device, zero=zero, dtype=self.t.dtype).slice(self.coff, self.C) \
+            if (self.coff or self.C != self.ld) else Act.empty(self.B, self.H, self.W, self.C, self.t.device, zero=zero, dtype=self.t.dtype)
 
     @property
     def npix(self):
@@ -78,24 +86,24 @@ class Act:
 
     def nchw(self):
         """Copy out as a (B,C,H,W) tensor (API edge).  C == 1 is a free view."""
-        if self.C == 1 and self.ld == 1:
+        if self.C == 1 and self.ld == 1 and not self.f16:
             return self.t.view(self.B, 1, self.H, self.W)
         out = torch.empty(self.B, self.C, self.H, self.W, dtype=torch.float32, device=self.t.device)
         L = _lib.get()
-        L.call('hv_nhwc_to_nchw', ptr(self.t), ptr(out), self.B, self.C, self.H, self.W, self.ld, self.coff, 0, stream())
+        L.call('hv_nhwc_to_nchw', ptr(self.t), self.f16, ptr(out), self.B, self.C, self.H, self.W, self.ld, self.coff, 0, stream())
         return out
 
 
-def from_nchw(x, CP=None):
-    """(B,C,H,W) tensor -> NHWC Act (C == 1 is a free view; CP pads the channel stride with zeros)."""
+def from_nchw(x, CP=None, dtype=torch.float32):
+    """(B,C,H,W) fp32 tensor -> NHWC Act of `dtype` (C == 1 fp32 is a free view; CP pads the channel stride with zeros)."""
     _lib.require_gpu(x)
     x = x.contiguous().float()
     B, C, H, W = x.shape
-    if C == 1 and CP in (None, 1):
+    if C == 1 and CP in (None, 1) and dtype == torch.float32:
         return Act(x.view(B, H, W, 1))
     ld = C if CP is None else CP
-    a = Act.empty(B, H, W, C, x.device, ld=ld, zero=ld != C)
-    _lib.get().call('hv_nchw_to_nhwc', ptr(x), ptr(a.t), B, C, H, W, ld, 0, stream())
+    a = Act.empty(B, H, W, C, x.device, ld=ld, zero=ld != C, dtype=dtype)
+    _lib.get().call('hv_nchw_to_nhwc', ptr(x), ptr(a.t), a.f16, B, C, H, W, ld, 0, stream())
     return a
 
 
@@ -151,9 +159,10 @@ def conv2d(x, w, y, k, stride=1, pad=0, dil=1, bias=None, act='none', transposed
     d.Ho, d.Wo, d.y_ld, d.y_coff = y.H, y.W, y.ld, y.coff
     d.precision = precision_id(precision)
     d.w_f16 = None if w_h is None else ptr(w_h).value
+    d.x_f16, d.y_f16 = x.f16, y.f16
     if mul is not None:
         m, mact = mul
-        d.mul_src, d.mul_ld, d.mul_coff, d.mul_act = ptr(m.t).value, m.ld, m.coff, ACT[mact]
+        d.mul_src, d.mul_ld, d.mul_coff, d.mul_act, d.mul_f16 = ptr(m.t).value, m.ld, m.coff, ACT[mact], m.f16
     if d.Cout == 1:      # single-channel heads / logits: the [pixel][tap] table of conv_head.hip lives in the per-stream scratch
         need = L.size('hv_conv2d_workspace_bytes', ctypes.byref(d))
         if need:
@@ -163,7 +172,9 @@ def conv2d(x, w, y, k, stride=1, pad=0, dil=1, bias=None, act='none', transposed
         taps = kh * kw if not transposed else max(1, (kh * kw) // (stride * stride))
         flops = 2.0 * y.B * y.H * y.W * d.Cout * taps * d.Cin
         wbytes = (2 if (w_h is not None and d.precision == F16 and not w_bstride) else 4) * d.Cout * kh * kw * d.Cin * (x.B if w_bstride else 1)
-        nbytes = 4 * (x.B * x.H * x.W * d.Cin + y.B * y.H * y.W * d.Cout * (2 if accumulate else 1)) + wbytes + (4 * y.B * y.H * y.W * d.Cout if mul is not None else 0)
+        xb, yb = (2 if x.f16 else 4), (2 if y.f16 else 4)      # algorithmic bytes: every operand once, at its storage width
+        nbytes = xb * x.B * x.H * x.W * d.Cin + yb * y.B * y.H * y.W * d.Cout * (2 if accumulate else 1) + wbytes + \
+            ((2 if mul[0].f16 else 4) * y.B * y.H * y.W * d.Cout if mul is not None else 0)
         _TIMER.wrap(('conv', x.B, d.H, d.W, d.Cin, d.Cout, kh, stride, dil, int(transposed)), flops,
                     lambda: L.call('hv_conv2d', ctypes.byref(d), stream()), nbytes)
         return y
@@ -189,6 +200,7 @@ def conv2d_wgrad(x, g, dw, k, stride=1, pad=0, dil=1, in_shift=0, accumulate=Fal
     d.precision = precision_id(precision)
     d.dbias = None if dbias is None else ptr(dbias).value
     d.dbias_accumulate = int(dbias_accumulate)
+    d.x_f16, d.g_f16 = x.f16, g.f16
     d.workspace, d.workspace_bytes = None, 0
     need = L.size('hv_conv2d_wgrad_workspace_bytes', ctypes.byref(d))
     if need:
@@ -196,7 +208,7 @@ def conv2d_wgrad(x, g, dw, k, stride=1, pad=0, dil=1, in_shift=0, accumulate=Fal
         d.workspace, d.workspace_bytes = ptr(b).value, b.numel()
     if _TIMER is not None:
         flops = 2.0 * g.B * g.H * g.W * d.Cout * kh * kw * d.Cin
-        nbytes = 4 * (x.B * x.H * x.W * d.Cin + g.B * g.H * g.W * d.Cout + d.Cout * kh * kw * d.Cin)     # x and g read once, dW written once
+        nbytes = (2 if x.f16 else 4) * x.B * x.H * x.W * d.Cin + (2 if g.f16 else 4) * g.B * g.H * g.W * d.Cout + 4 * d.Cout * kh * kw * d.Cin   # x and g read once, dW written once
         _TIMER.wrap(('wgrad', x.B, d.H, d.W, d.Cin, d.Cout, kh, stride, dil, 0), flops,
                     lambda: L.call('hv_conv2d_wgrad', ctypes.byref(d), stream()), nbytes)
         return dw
@@ -252,14 +264,14 @@ def act_backward(dy, y, act, dbias=None, dbias_accumulate=False):
     L = _lib.get()
     need = L.size('hv_act_backward_workspace_bytes', ctypes.c_longlong(dy.npix), dy.C) if dbias is not None else 0
     b, nb = _ws(need, dy.t.device)
-    L.call('hv_act_backward', ptr(dy.t), ptr(y.t), ctypes.c_longlong(dy.npix), dy.C, dy.ld, dy.coff, y.ld, y.coff, ACT[act],
+    L.call('hv_act_backward', ptr(dy.t), dy.f16, ptr(y.t), y.f16, ctypes.c_longlong(dy.npix), dy.C, dy.ld, dy.coff, y.ld, y.coff, ACT[act],
            ptr(dbias), int(dbias_accumulate), ptr(b), nb, stream())
 
 
 def copy_channels(src, dst, mode=0, accumulate=False):
     """dst (+)= resample(src); H,W of dst rule (mode: 0 same, 1 up x2, 2 down x1/2, 3 adjoint of 1, 4 adjoint of 2)."""
     assert src.C == dst.C
-    _lib.get().call('hv_copy_channels', ptr(src.t), ptr(dst.t), dst.B, dst.H, dst.W, dst.C, src.ld, src.coff, dst.ld, dst.coff,
+    _lib.get().call('hv_copy_channels', ptr(src.t), src.f16, ptr(dst.t), dst.f16, dst.B, dst.H, dst.W, dst.C, src.ld, src.coff, dst.ld, dst.coff,
                     mode, int(accumulate), stream())
 
 
@@ -273,18 +285,18 @@ def axpy(y, x, a=1.0):
 
 
 def gen_input(x, seg, mask, ratio, dst, order):
-    _lib.get().call('hv_gen_input', ptr(x), ptr(seg), ptr(mask), ptr(ratio), ptr(dst.t), dst.B, dst.H, dst.W, dst.ld, order, stream())
+    _lib.get().call('hv_gen_input', ptr(x), ptr(seg), ptr(mask), ptr(ratio), ptr(dst.t), dst.f16, dst.B, dst.H, dst.W, dst.ld, order, stream())
 
 
 def gap_fc_sigmoid(x, fc_w, fc_b, pooled, pred):
     L = _lib.get()
     need = L.size('hv_gap_fc_workspace_bytes', x.B, x.C)
     b, nb = _ws(need, x.t.device)
-    L.call('hv_gap_fc_sigmoid', ptr(x.t), x.B, x.H * x.W, x.C, x.ld, ptr(fc_w), ptr(fc_b), ptr(pooled), ptr(pred), ptr(b), nb, stream())
+    L.call('hv_gap_fc_sigmoid', ptr(x.t), x.f16, x.B, x.H * x.W, x.C, x.ld, ptr(fc_w), ptr(fc_b), ptr(pooled), ptr(pred), ptr(b), nb, stream())
 
 
 def gap_fc_sigmoid_backward(dpred, pred, pooled, fc_w, dx, dw, db, accumulate=False):
-    _lib.get().call('hv_gap_fc_sigmoid_backward', ptr(dpred), ptr(pred), ptr(pooled), ptr(fc_w), ptr(dx.t), dx.B, dx.H * dx.W, dx.C,
+    _lib.get().call('hv_gap_fc_sigmoid_backward', ptr(dpred), ptr(pred), ptr(pooled), ptr(fc_w), ptr(dx.t), dx.f16, dx.B, dx.H * dx.W, dx.C,
                     dx.ld, ptr(dw), ptr(db), int(accumulate), stream())
 
 
@@ -331,6 +343,8 @@ def norm_act_forward(x, y, norm, training, stats, gamma=None, beta=None, running
                  ('num_batches_tracked', nbt), ('stats', stats)):
         setattr(d, f, None if v is None else ptr(v).value)
     d.act, d.post_sigmoid, d.groups = ACT[act], int(post_sigmoid), int(groups)
+    assert x.f16 == y.f16
+    d.f16 = x.f16
     need = L.size('hv_norm_workspace_bytes', x.B, x.H * x.W, x.C)
     b, _ = _ws(need, x.t.device)
     d.workspace, d.workspace_bytes = ptr(b).value, b.numel()
@@ -353,6 +367,8 @@ def norm_act_backward(dy, y, x, dx, norm, training, stats, gamma=None, act='lrel
     d.dbeta = None if dbeta is None else ptr(dbeta).value
     d.param_accumulate = int(param_accumulate)
     d.groups = int(groups)
+    assert dy.f16 == y.f16 == x.f16 == dx.f16
+    d.f16 = x.f16
     need = L.size('hv_norm_workspace_bytes', x.B, x.H * x.W, x.C)
     b, _ = _ws(need, x.t.device)
     d.workspace, d.workspace_bytes = ptr(b).value, b.numel()

@@ -2,10 +2,12 @@
  * generator / discriminator train + inference hot path.
  *
  * Conventions
- *   - every pointer is a DEVICE pointer unless named h_*; every tensor is fp32, NHWC, dense in W/H with an
+ *   - every pointer is a DEVICE pointer unless named h_*; every tensor is NHWC, dense in W/H with an
  *     explicit channel stride `*_ld` (elements per pixel) and channel offset `*_coff` so a conv can read or
- *     write a channel slice of a wider (concat) buffer.  A (B,1,H,W) NCHW tensor is bit-identical in NHWC, so
- *     all image-level inputs/outputs of the reference API cross the boundary without a copy.
+ *     write a channel slice of a wider (concat) buffer.  Elements are fp32; the activation / gradient tensors INSIDE
+ *     a network may be stored as fp16 instead where an `*_f16` flag says so (precision HV_F16 only: their values
+ *     are rounded to fp16 as MFMA operands anyway).  A (B,1,H,W) NCHW tensor is bit-identical in NHWC, so all
+ *     image-level inputs/outputs of the reference API (always fp32) cross the boundary without a copy.
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  No entry point allocates, frees or
  *     synchronises: the caller owns every buffer, including workspaces sized by the *_workspace_bytes calls,
  *     so every call is legal inside a hipGraph capture.
@@ -78,6 +80,10 @@ typedef struct {
                                          of activation mul_act at the same pixel/channel, applied after act and before accumulate == 1.
                                          Used by data gradients to hand the producer layer its pre-activation gradient directly
                                          (the separate in-place multiply pass over the gradient disappears).  NULL = none */
+    int x_f16, y_f16, mul_f16;        /* storage of x / y / mul_src: 0 = fp32 (pointers are float*), 1 = fp16 (the pointers address _Float16
+                                         elements; *_ld / *_coff stay in elements).  fp16 storage needs precision == HV_F16 (operands are rounded
+                                         to fp16 at staging anyway) and serves the tensors of a network that are only conv / norm operands;
+                                         1-channel image tensors and the attention score matrices stay fp32 */
     void* workspace; size_t workspace_bytes;
                                       /* optional scratch (16-byte aligned) of hv_conv2d_workspace_bytes(d) bytes: enables the two-kernel path for
                                          Cout == 1 with many input channels (PatchGAN logits, data gradient of the 1-channel stem), which
@@ -96,6 +102,7 @@ typedef struct {
     float* dw; int accumulate;
     float* workspace; size_t workspace_bytes;
     int precision;
+    int x_f16, g_f16;                     /* storage of x / g as in hv_conv_desc (both 0 or both 1) */
     float* dbias; int dbias_accumulate;   /* optional: dbias[co] (+)= sum over pixels of g[.., co] (bias gradient of the same conv), folded
                                              into the kernel that already streams g; NULL = not computed */
 } hv_wgrad_desc;
@@ -130,8 +137,8 @@ int hv_weight_prep_backward(const hv_wprep_bwd_layer* d_layers, int n_layers, lo
 /* ---------------------------------------------------------------- activation gradient + bias gradient
  * g[p,c] = dy[p,c] * act'(y[p,c]) in place over dy; dbias[c] (+)= sum_p g[p,c] when dbias != NULL.
  * (autograd of nn.ELU/ReLU/Sigmoid/clamp after the conv, models/inpaint_networks.py:459-474,115,230). */
-int hv_act_backward(float* dy, const float* y, long long npix, int C, int dy_ld, int dy_coff, int y_ld, int y_coff,
-                    int act, float* dbias, int dbias_accumulate, float* workspace, size_t workspace_bytes, void* stream);
+int hv_act_backward(void* dy, int dy_f16, const void* y, int y_f16 /* storage of dy / y: 0 fp32, 1 fp16 */, long long npix, int C, int dy_ld, int dy_coff,
+                    int y_ld, int y_coff, int act, float* dbias, int dbias_accumulate, float* workspace, size_t workspace_bytes, void* stream);
 size_t hv_act_backward_workspace_bytes(long long npix, int C);
 
 /* ---------------------------------------------------------------- normalisation + activation (discriminator, U-Net)
@@ -140,51 +147,53 @@ size_t hv_act_backward_workspace_bytes(long long npix, int C);
  * models/UnetG_CT_mask.py:73-100.  `stats` (2*G*C floats: mean, rstd; G = 1 for batch, B for instance) is kept
  * for the backward. */
 typedef struct {
-    const float* x; float* y; int B, HW, C; int x_ld, x_coff, y_ld, y_coff;
+    const void* x; void* y; int B, HW, C; int x_ld, x_coff, y_ld, y_coff;      /* x, y: fp32, or fp16 elements when f16 != 0 */
     int norm; int training; float eps, momentum;
     const float* gamma; const float* beta; float* running_mean; float* running_var; long long* num_batches_tracked;
     float* stats; int act; int post_sigmoid;
     float* workspace; size_t workspace_bytes;
     int groups;   /* batch norm: the batch is split into `groups` equal parts with separate statistics, running stats updated
                      part by part (fake | real halves of one discriminator launch == two consecutive calls); 0/1 = one group */
+    int f16;      /* storage of x and y (statistics, affine parameters and all arithmetic stay fp32 / fp64) */
 } hv_norm_desc;
 size_t hv_norm_workspace_bytes(int B, int HW, int C);
 int hv_norm_act_forward(const hv_norm_desc* d, void* stream);
 /* dx from dy (gradient wrt the activation output y); dgamma/dbeta (+)= when non-NULL. */
 typedef struct {
-    const float* dy; const float* y; const float* x; float* dx; int B, HW, C;
+    const void* dy; const void* y; const void* x; void* dx; int B, HW, C;     /* fp32, or fp16 elements when f16 != 0 (all four alike) */
     int dy_ld, dy_coff, y_ld, y_coff, x_ld, x_coff, dx_ld, dx_coff;
     int norm; int training; const float* gamma; const float* stats;
     int act; int post_sigmoid;
     float* dgamma; float* dbeta; int param_accumulate;
     float* workspace; size_t workspace_bytes;
     int groups;
+    int f16;
 } hv_norm_bwd_desc;
 int hv_norm_act_backward(const hv_norm_bwd_desc* d, void* stream);
 
 /* ---------------------------------------------------------------- layout / resampling helpers
  * NCHW <-> NHWC (API edge only), nearest x2 upsample + channel concat (F.interpolate + torch.cat,
  * models/inpaint_networks.py:97-99,105-106), channel copies, zero fill. */
-int hv_nchw_to_nhwc(const float* src, float* dst, int B, int C, int H, int W, int dst_ld, int dst_coff, void* stream);
-int hv_nhwc_to_nchw(const float* src, float* dst, int B, int C, int H, int W, int src_ld, int src_coff, int accumulate, void* stream);
+int hv_nchw_to_nhwc(const float* src, void* dst, int dst_f16, int B, int C, int H, int W, int dst_ld, int dst_coff, void* stream);
+int hv_nhwc_to_nchw(const void* src, int src_f16, float* dst, int B, int C, int H, int W, int src_ld, int src_coff, int accumulate, void* stream);
 /* Copies C channels into a channel slice of dst; H,W are the dst size.  mode 0: same size; 1: src is half size
  * (nearest x2 upsample); 2: src is double size (nearest x1/2 downsample, even indices); 3: dst(half) (+)= sum of the
  * 2x2 block of src(full) [adjoint of 1]; 4: dst(full) (+)= src(half) at even indices, 0 elsewhere [adjoint of 2]. */
-int hv_copy_channels(const float* src, float* dst, int B, int H, int W, int C, int src_ld, int src_coff, int dst_ld,
-                     int dst_coff, int mode, int accumulate, void* stream);
+int hv_copy_channels(const void* src, int src_f16, void* dst, int dst_f16, int B, int H, int W, int C, int src_ld, int src_coff, int dst_ld,
+                     int dst_coff, int mode, int accumulate, void* stream);   /* *_f16: storage of src / dst (may differ: the copy converts) */
 
 /* ---------------------------------------------------------------- generator heads and inputs
  * cat[x, ratio-plane, mask] / cat[x, coarse_seg, mask, ratio-plane] (models/inpaint_networks.py:71-77,173-179)
  * written as a CP-channel NHWC buffer (pad channels zero).  order: 0 = coarse, 1 = fine. */
-int hv_gen_input(const float* x, const float* seg, const float* mask, const double* slice_ratio, float* dst,
+int hv_gen_input(const float* x, const float* seg, const float* mask, const double* slice_ratio, void* dst, int dst_f16,
                  int B, int H, int W, int CP, int order, void* stream);
 /* AdaptiveAvgPool2d(1) -> Linear(C,1) -> sigmoid (models/inpaint_networks.py:90-93,211-214). */
 size_t hv_gap_fc_workspace_bytes(int B, int C);
-int hv_gap_fc_sigmoid(const float* x, int B, int HW, int C, int x_ld, const float* fc_w, const float* fc_b,
+int hv_gap_fc_sigmoid(const void* x, int x_f16, int B, int HW, int C, int x_ld, const float* fc_w, const float* fc_b,
                       float* pooled /*[B][C]*/, float* pred /*[B]*/, float* workspace, size_t workspace_bytes, void* stream);
 /* backward: dx[n,p,c] += dpred[n]*pred(1-pred)*w[c]/HW ; dw[c] (+)= sum_n dl_n*pooled[n,c]; db (+)= sum_n dl_n */
 int hv_gap_fc_sigmoid_backward(const float* dpred, const float* pred, const float* pooled, const float* fc_w,
-                               float* dx, int B, int HW, int C, int dx_ld, float* dw, float* db, int accumulate,
+                               void* dx, int dx_f16, int B, int HW, int C, int dx_ld, float* dw, float* db, int accumulate,
                                void* stream);
 
 /* ---------------------------------------------------------------- contextual attention pieces
@@ -265,6 +274,8 @@ typedef struct {
     float* d_pred1; float* d_pred2;
     int B, H, W;
     float* workspace; size_t workspace_bytes;
+    float grad_scale;   /* the six gradient seeds are multiplied by this (0 = 1): the gradient (loss) scale of the fp16 storage mode, a power of two
+                           removed again from the parameter gradients by the caller (the losses themselves are not scaled) */
 } hv_gloss_desc;
 size_t hv_generator_losses_workspace_bytes(int B);
 int hv_generator_losses(const hv_gloss_desc* d, void* stream);

@@ -9,18 +9,23 @@ def dev():
     return torch.device('cuda:0')
 
 
-def to_act(x_nchw, CP=None):
-    """CPU (B,C,H,W) -> device NHWC Act with channel stride CP (zero padded)."""
+def st(prec):
+    """Storage dtype of activation tensors for a compute precision (fp16 mode: fp16 storage)."""
+    return torch.float16 if prec in ('fp16', 'f16') else torch.float32
+
+
+def to_act(x_nchw, CP=None, dtype=torch.float32):
+    """CPU (B,C,H,W) -> device NHWC Act with channel stride CP (zero padded), stored as `dtype`."""
     B, C, H, W = x_nchw.shape
     CP = C if CP is None else CP
     t = torch.zeros(B, H, W, CP)
     t[..., :C] = x_nchw.permute(0, 2, 3, 1)
-    return ops.Act(t.to(dev()).contiguous(), C, 0)
+    return ops.Act(t.to(dev()).to(dtype).contiguous(), C, 0)
 
 
 def from_act(a):
     """device Act -> CPU (B,C,H,W)."""
-    return a.t[..., a.coff:a.coff + a.C].permute(0, 3, 1, 2).contiguous().cpu()
+    return a.t[..., a.coff:a.coff + a.C].permute(0, 3, 1, 2).contiguous().float().cpu()
 
 
 def ohwi(w, CinP=None, CoutF=None):

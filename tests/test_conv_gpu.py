@@ -43,15 +43,16 @@ def _ref_act(y, act):
 @pytest.mark.parametrize('prec,tol', [('fp32', 1e-4), ('fp16', 4e-3)])
 @pytest.mark.parametrize('case', CASES)
 def test_conv_forward(case, prec, tol):
-    from hvtest import to_act, from_act, ohwi, dev, maxerr
+    from hvtest import to_act, from_act, ohwi, dev, maxerr, st
     from hvgan import ops
     B, H, W, Cin, CinP, Cout, k, s, p, d, act = case
     x, w, b = _mk(case)
     ref = _ref_act(F.conv2d(x, w, b, stride=s, padding=p, dilation=d), act)
-    xa = to_act(x, CinP)
+    # fp16 mode: fp16 storage inside the networks; the 1-channel image ends (stem input, head outputs) stay fp32
+    xa = to_act(x, CinP, dtype=st(prec) if Cin > 1 else torch.float32)
     xa = ops.Act(xa.t, CinP, 0) if CinP % 4 == 0 else xa
     Ho, Wo = ref.shape[2], ref.shape[3]
-    ya = ops.Act.empty(B, Ho, Wo, Cout, dev())
+    ya = ops.Act.empty(B, Ho, Wo, Cout, dev(), dtype=st(prec) if Cout > 1 else torch.float32)
     ops.conv2d(xa, ohwi(w, CinP), ya, k, s, p, d, bias=b.to(dev()), act=act, precision=prec)
     torch.cuda.synchronize()
     err = maxerr(from_act(ya), ref)
@@ -62,7 +63,7 @@ def test_conv_forward(case, prec, tol):
 @pytest.mark.parametrize('case', CASES)
 def test_conv_dgrad_is_transposed_gather(case, prec, tol):
     """d/dx of conv == hv_conv2d(transposed=1) with the [Cin][taps][Cout] filter layout."""
-    from hvtest import to_act, from_act, ohwi_T, dev, maxerr
+    from hvtest import to_act, from_act, ohwi_T, dev, maxerr, st
     from hvgan import ops
     B, H, W, Cin, CinP, Cout, k, s, p, d, act = case
     x, w, b = _mk(case)
@@ -71,9 +72,9 @@ def test_conv_dgrad_is_transposed_gather(case, prec, tol):
     g = torch.randn(y.shape, generator=torch.Generator().manual_seed(1))
     y.backward(g)
     CoutP = (Cout + 3) // 4 * 4
-    ga = to_act(g, CoutP)
+    ga = to_act(g, CoutP, dtype=st(prec))
     ga = ops.Act(ga.t, CoutP, 0)
-    dxa = ops.Act.empty(B, H, W, Cin, dev())
+    dxa = ops.Act.empty(B, H, W, Cin, dev(), dtype=st(prec) if Cin > 1 else torch.float32)
     ops.conv2d(ga, ohwi_T(w, CoutP), dxa, k, s, p, d, transposed=True, precision=prec)
     torch.cuda.synchronize()
     err = maxerr(from_act(dxa), x.grad)
@@ -83,7 +84,7 @@ def test_conv_dgrad_is_transposed_gather(case, prec, tol):
 @pytest.mark.parametrize('prec,tol', [('fp32', 2e-4), ('fp16', 6e-3)])
 @pytest.mark.parametrize('case', CASES)
 def test_conv_wgrad(case, prec, tol):
-    from hvtest import to_act, ohwi, dev, maxerr
+    from hvtest import to_act, ohwi, dev, maxerr, st
     from hvgan import ops
     B, H, W, Cin, CinP, Cout, k, s, p, d, act = case
     x, w, b = _mk(case)
@@ -92,9 +93,9 @@ def test_conv_wgrad(case, prec, tol):
     g = torch.randn(y.shape, generator=torch.Generator().manual_seed(2))
     y.backward(g)
     CinP4, CoutP = (CinP + 3) // 4 * 4, (Cout + 3) // 4 * 4
-    xa = to_act(x, CinP4)
+    xa = to_act(x, CinP4, dtype=st(prec))
     xa = ops.Act(xa.t, CinP4, 0)
-    ga = to_act(g, CoutP)
+    ga = to_act(g, CoutP, dtype=st(prec))
     ga = ops.Act(ga.t, CoutP, 0)
     dw = torch.empty(CoutP, k * k, CinP4, device=dev())
     db = torch.full((CoutP,), 7.0, device=dev())
@@ -146,7 +147,7 @@ HALO_CASES = [
 @pytest.mark.parametrize('case', HALO_CASES)
 def test_conv_halo_tiled_fp16_forward_and_dgrad(case):
     """The halo-tiled fp16 kernel (taken when the fp16 weight copy is passed) against torch CPU fp32."""
-    from hvtest import to_act, from_act, ohwi, ohwi_T, dev, maxerr
+    from hvtest import to_act, from_act, ohwi, ohwi_T, dev, maxerr, st
     from hvgan import ops
     B, H, W, Cin, Cout, k, s, p, act, shift = case
     g = torch.Generator().manual_seed(7)
@@ -158,9 +159,9 @@ def test_conv_halo_tiled_fp16_forward_and_dgrad(case):
     y0 = F.conv2d(xin, w, b, stride=s, padding=p)
     ref = _ref_act(y0, act)
     Ho, Wo = ref.shape[2], ref.shape[3]
-    ya = ops.Act.empty(B, Ho, Wo, Cout, dev())
+    ya = ops.Act.empty(B, Ho, Wo, Cout, dev(), dtype=torch.float16)          # fp16 mode: fp16 storage
     wf = ohwi(w)
-    ops.conv2d(to_act(x), wf, ya, k, s, p, 1, bias=b.to(dev()), act=act, in_shift=shift, precision='fp16', w_h=wf.half())
+    ops.conv2d(to_act(x, dtype=torch.float16), wf, ya, k, s, p, 1, bias=b.to(dev()), act=act, in_shift=shift, precision='fp16', w_h=wf.half())
     torch.cuda.synchronize()
     err = maxerr(from_act(ya), ref.detach())
     assert err <= 4e-3 * max(1.0, ref.abs().max().item()), err
@@ -169,8 +170,8 @@ def test_conv_halo_tiled_fp16_forward_and_dgrad(case):
     gy = torch.randn(y0.shape, generator=g)
     y0.backward(gy)
     wb = ohwi_T(w)
-    dxa = ops.Act.empty(B, H, W, Cin, dev())
-    ops.conv2d(to_act(gy), wb, dxa, k, s, p, 1, transposed=True, precision='fp16', w_h=wb.half())
+    dxa = ops.Act.empty(B, H, W, Cin, dev(), dtype=torch.float16)
+    ops.conv2d(to_act(gy, dtype=torch.float16), wb, dxa, k, s, p, 1, transposed=True, precision='fp16', w_h=wb.half())
     torch.cuda.synchronize()
     err = maxerr(from_act(dxa), xin.grad)
     assert err <= 4e-3 * max(1.0, xin.grad.abs().max().item()), err
@@ -189,7 +190,7 @@ HEAD_CASES = [   # B, H, W, Cin, k, stride, pad, transposed, act
 def test_conv_single_output_channel_tap_gemm(case):
     """Cout == 1 with many input channels (conv_head.hip: [pixel][tap] table + tap sum) against torch CPU fp32, incl. the epilogue
     options (bias, activation, accumulate, act' multiplier) and the kernel actually taken."""
-    from hvtest import to_act, from_act, ohwi, ohwi_T, dev, maxerr
+    from hvtest import to_act, from_act, ohwi, ohwi_T, dev, maxerr, st
     from hvgan import ops, lib
     B, H, W, Cin, k, s, p, tr, act = case
     g = torch.Generator().manual_seed(11)
@@ -200,17 +201,18 @@ def test_conv_single_output_channel_tap_gemm(case):
         ref = _ref_act(F.conv2d(x, w, b, stride=s, padding=p), act)
         wf = ohwi(w)
         ya = ops.Act.empty(B, ref.shape[2], ref.shape[3], 1, dev())
-        ops.conv2d(to_act(x), wf, ya, k, s, p, 1, bias=b.to(dev()), act=act, precision='fp16', w_h=wf.half())
+        xh = to_act(x, dtype=torch.float16)                 # the layer's input is a network-internal (fp16) tensor, its 1-channel output an fp32 image
+        ops.conv2d(xh, wf, ya, k, s, p, 1, bias=b.to(dev()), act=act, precision='fp16', w_h=wf.half())
         assert lib.get().size('hv_last_kernel_path') == 5
         torch.cuda.synchronize()
         assert maxerr(from_act(ya), ref) <= 4e-3 * max(1.0, ref.abs().max().item())
         # y += r (accumulate 1) on top of the first result, and y = act(r + y) (accumulate 2)
-        ops.conv2d(to_act(x), wf, ya, k, s, p, 1, bias=b.to(dev()), act=act, accumulate=1, precision='fp16', w_h=wf.half())
+        ops.conv2d(xh, wf, ya, k, s, p, 1, bias=b.to(dev()), act=act, accumulate=1, precision='fp16', w_h=wf.half())
         torch.cuda.synchronize()
         assert maxerr(from_act(ya), 2 * ref) <= 8e-3 * max(1.0, ref.abs().max().item())
         y0 = torch.randn(ref.shape, generator=g)
         yb = to_act(y0)
-        ops.conv2d(to_act(x), wf, yb, k, s, p, 1, act=act, accumulate=2, precision='fp16', w_h=wf.half())
+        ops.conv2d(xh, wf, yb, k, s, p, 1, act=act, accumulate=2, precision='fp16', w_h=wf.half())
         torch.cuda.synchronize()
         ref2 = _ref_act(F.conv2d(x, w, None, stride=s, padding=p) + y0, act)
         assert maxerr(from_act(yb), ref2) <= 4e-3 * max(1.0, ref2.abs().max().item())
@@ -223,7 +225,7 @@ def test_conv_single_output_channel_tap_gemm(case):
     assert tuple(wb.shape) == (1, k * k, Cin)
     m = torch.randn(B, 1, Ho, Wo, generator=g)        # output of a LeakyReLU producer: factor 1 or 0.2
     ya = ops.Act.empty(B, Ho, Wo, 1, dev())
-    ops.conv2d(to_act(x), wb, ya, k, s, p, 1, transposed=True, precision='fp16', w_h=wb.half(), mul=(to_act(m), 'lrelu'))
+    ops.conv2d(to_act(x, dtype=torch.float16), wb, ya, k, s, p, 1, transposed=True, precision='fp16', w_h=wb.half(), mul=(to_act(m), 'lrelu'))
     assert lib.get().size('hv_last_kernel_path') == 5
     torch.cuda.synchronize()
     ref = ref * torch.where(m > 0, torch.ones_like(m), torch.full_like(m, 0.2))
@@ -235,7 +237,7 @@ def test_conv_single_output_channel_tap_gemm(case):
 def test_conv_single_output_channel_data_gradient(case, prec, tol):
     """Data gradient of a Cout == 1 conv: gradient stored channel-padded to 4, act' multiplier of the producer layer and
     accumulate == 1 included."""
-    from hvtest import to_act, from_act, ohwi_T, dev, maxerr
+    from hvtest import to_act, from_act, ohwi_T, dev, maxerr, st
     from hvgan import ops, lib
     B, H, W, C, k, p = case
     g = torch.Generator().manual_seed(5)
@@ -245,12 +247,12 @@ def test_conv_single_output_channel_data_gradient(case, prec, tol):
     gy = torch.randn(y.shape, generator=g)
     y.backward(gy)
     wb = ohwi_T(w, CoutP=4)                                    # [C][taps][4]
-    ga = to_act(gy, 4)
+    ga = to_act(gy, 4, dtype=st(prec))
     ga = ops.Act(ga.t, 4, 0)
     m = torch.randn(B, C, H, W, generator=g)
     fac = torch.where(m > 0, torch.ones_like(m), torch.full_like(m, 0.2))
-    dxa = ops.Act.empty(B, H, W, C, dev())
-    ops.conv2d(ga, wb, dxa, k, 1, p, 1, transposed=True, precision=prec, w_h=wb.half(), mul=(to_act(m), 'lrelu'))
+    dxa = ops.Act.empty(B, H, W, C, dev(), dtype=st(prec))
+    ops.conv2d(ga, wb, dxa, k, 1, p, 1, transposed=True, precision=prec, w_h=wb.half(), mul=(to_act(m, dtype=st(prec)), 'lrelu'))
     torch.cuda.synchronize()
     ref = x.grad * fac
     assert maxerr(from_act(dxa), ref) <= tol * max(1.0, ref.abs().max().item())
@@ -263,7 +265,7 @@ def test_conv_single_output_channel_data_gradient(case, prec, tol):
 def test_conv_one_channel_stem_mfma(case):
     """1-channel image into 16..64 channels, 4x4 filter (PatchGAN stem), fp16 mode with the fp16 filter copy: the 16 taps are the contraction
     of one 16x16x16 MFMA (stem1_mfma_kernel); against torch CPU fp32, incl. ragged row ends, bias, activation and accumulate."""
-    from hvtest import to_act, from_act, ohwi, dev, maxerr
+    from hvtest import to_act, from_act, ohwi, dev, maxerr, st
     from hvgan import ops, lib
     B, H, W, Cout, s, act = case
     g = torch.Generator().manual_seed(21)
@@ -272,7 +274,7 @@ def test_conv_one_channel_stem_mfma(case):
     b = torch.randn(Cout, generator=g) * 0.1
     ref = _ref_act(F.conv2d(x, w, b, stride=s, padding=1), act)
     wf = ohwi(w)
-    ya = ops.Act.empty(B, ref.shape[2], ref.shape[3], Cout, dev())
+    ya = ops.Act.empty(B, ref.shape[2], ref.shape[3], Cout, dev(), dtype=torch.float16)
     ops.conv2d(to_act(x), wf, ya, 4, s, 1, 1, bias=b.to(dev()), act=act, precision='fp16', w_h=wf.half())
     assert (lib.get().cdll.hv_last_kernel_name() or b'').decode() == 'stem1_mfma_kernel'
     torch.cuda.synchronize()
@@ -284,7 +286,7 @@ def test_conv_one_channel_stem_mfma(case):
 
 def test_conv_upsample_fused_and_transposed_conv_layer():
     """in_shift=1 == conv(F.interpolate(x, 2)); transposed=1 == F.conv_transpose2d (k4 s2 p1)."""
-    from hvtest import to_act, from_act, ohwi, dev, maxerr
+    from hvtest import to_act, from_act, ohwi, dev, maxerr, st
     from hvgan import ops
     g = torch.Generator().manual_seed(3)
     x = torch.randn(2, 32, 16, 16, generator=g)
@@ -303,7 +305,7 @@ def test_conv_upsample_fused_and_transposed_conv_layer():
 
 
 def test_conv_per_sample_filters_and_accumulate_modes():
-    from hvtest import to_act, from_act, ohwi, dev, maxerr
+    from hvtest import to_act, from_act, ohwi, dev, maxerr, st
     from hvgan import ops
     g = torch.Generator().manual_seed(4)
     x = torch.randn(2, 16, 16, 16, generator=g)
@@ -328,7 +330,7 @@ def test_conv_per_sample_filters_and_accumulate_modes():
 def test_conv_per_sample_paste_long_contraction(prec, tol):
     """The attention paste shape class: conv_transpose2d(k4, s2, p1) with per-sample filters and a 4 x 1024-long contraction per parity class
     against torch."""
-    from hvtest import to_act, from_act, dev, maxerr
+    from hvtest import to_act, from_act, dev, maxerr, st
     from hvgan import ops
     g = torch.Generator().manual_seed(8)
     B, L, C = 2, 1024, 64
