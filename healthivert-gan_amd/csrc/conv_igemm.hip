@@ -32,6 +32,8 @@ extern "C" int hv_set_kernel_timing(void* ev_start, void* ev_stop) {
 int hv_conv2d_halo(const hv_conv_desc* d, const void* w_f16, hipStream_t s);   // conv_halo.hip
 size_t hv_wgrad_halo_workspace_bytes(const hv_wgrad_desc* d);                  // wgrad_halo.hip
 int hv_wgrad_halo(const hv_wgrad_desc* d, int* nslabs, hipStream_t s);
+size_t hv_wgrad_tr_workspace_bytes(const hv_wgrad_desc* d);                    // wgrad_tr.hip
+int hv_wgrad_tr(const hv_wgrad_desc* d, int* nslabs, hipStream_t s);
 int hv_conv2d_narrow(const hv_conv_desc* d, hipStream_t s);                     // conv_narrow.hip
 int hv_conv2d_thin_in(const hv_conv_desc* d, hipStream_t s);
 int hv_conv2d_stem5(const hv_conv_desc* d, hipStream_t s);
@@ -753,34 +755,50 @@ __global__ __launch_bounds__(WN * WC * 64) void wgrad_kernel(const WgradK p) {
         }
 }
 
-// 256 threads = 64 elements x 4 split groups; fixed summation order (deterministic).  Blocks beyond the dW range fold the
-// per-split bias rows (bslabs [splits][nb]) into dbias.
+// 256 threads = 64 element quads x 4 split groups (16 bytes per lane and slab); fixed summation order (deterministic).  Blocks beyond the
+// dW range fold the per-split bias rows (bslabs [splits][nb]) into dbias.  n and nb are multiples of 4 (channel counts are).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, long long n, int splits, int accumulate,
                                                            const float* __restrict__ bslabs, float* __restrict__ dbias, int nb, int bias_accumulate) {
-    __shared__ float sh[4][64];
+    __shared__ float4 sh[4][64];
     const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const long long wblocks = (n + 63) / 64;
-    const bool bias = (long long)blockIdx.x >= wblocks;
-    const float* src = bias ? bslabs : slabs;
-    const long long nn = bias ? nb : n;
-    const long long i = ((long long)blockIdx.x - (bias ? wblocks : 0)) * 64 + e;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    if (i < nn) {
+    const long long wblocks = (n + 255) / 256;
+    if ((long long)blockIdx.x >= wblocks) {      // bias rows: one element per lane (dbias is a view into the flat gradient buffer: any 4-byte offset)
+        const long long i = ((long long)blockIdx.x - wblocks) * 64 + e;
+        float s = 0.f;
+        if (i < nb)
+            for (int k = grp; k < splits; k += 4) s += bslabs[(long long)k * nb + i];
+        sh[grp][e].x = s;
+        __syncthreads();
+        if (grp == 0 && i < nb) {
+            const float t = (sh[0][e].x + sh[1][e].x) + (sh[2][e].x + sh[3][e].x);
+            dbias[i] = bias_accumulate ? dbias[i] + t : t;
+        }
+        return;
+    }
+    const long long i = ((long long)blockIdx.x * 64 + e) * 4;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+    auto add = [](float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
+    if (i < n) {
         int k = grp;
         for (; k + 12 < splits; k += 16) {
-            s0 += src[(long long)k * nn + i];
-            s1 += src[(long long)(k + 4) * nn + i];
-            s2 += src[(long long)(k + 8) * nn + i];
-            s3 += src[(long long)(k + 12) * nn + i];
+            add(s0, *reinterpret_cast<const float4*>(slabs + (long long)k * n + i));
+            add(s1, *reinterpret_cast<const float4*>(slabs + (long long)(k + 4) * n + i));
+            add(s2, *reinterpret_cast<const float4*>(slabs + (long long)(k + 8) * n + i));
+            add(s3, *reinterpret_cast<const float4*>(slabs + (long long)(k + 12) * n + i));
         }
-        for (; k < splits; k += 4) s0 += src[(long long)k * nn + i];
+        for (; k < splits; k += 4) add(s0, *reinterpret_cast<const float4*>(slabs + (long long)k * n + i));
     }
-    sh[grp][e] = (s0 + s1) + (s2 + s3);
+    add(s0, s1); add(s2, s3); add(s0, s2);
+    sh[grp][e] = s0;
     __syncthreads();
-    if (grp == 0 && i < nn) {
-        const float s = (sh[0][e] + sh[1][e]) + (sh[2][e] + sh[3][e]);
-        if (bias) dbias[i] = bias_accumulate ? dbias[i] + s : s;
-        else dw[i] = accumulate ? dw[i] + s : s;
+    if (grp == 0 && i < n) {
+        float4 s = sh[0][e];
+        add(s, sh[1][e]);
+        float4 t = sh[2][e];
+        add(t, sh[3][e]);
+        add(s, t);
+        if (accumulate) add(s, *reinterpret_cast<const float4*>(dw + i));
+        *reinterpret_cast<float4*>(dw + i) = s;
     }
 }
 
@@ -835,6 +853,8 @@ extern "C" size_t hv_conv2d_wgrad_workspace_bytes(const hv_wgrad_desc* d) {
     if (wgrad_validate(d) != HV_OK) return 0;
     const size_t halo = hv_wgrad_halo_workspace_bytes(d);
     if (halo) return halo;
+    const size_t trb = hv_wgrad_tr_workspace_bytes(d);
+    if (trb) return trb;
     WgradPlan pl;
     wgrad_plan(d, &pl);
     if (pl.splits <= 1 && !d->accumulate && !d->dbias) return 0;
@@ -869,9 +889,10 @@ extern "C" int hv_conv2d_wgrad(const hv_wgrad_desc* d, void* stream) {
     {   // single-output-channel VALU path (conv_narrow.hip), then the halo-tiled fast path (wgrad_halo.hip: 3x3 / 5x5, stride 1, fp16)
         int nslabs = 0;
         rc = hv_wgrad_halo(d, &nslabs, (hipStream_t)stream);   // (measured: the VALU hv_wgrad_narrow is slower than the padded MFMA tiles)
+        if (rc == HV_ERR_UNSUPPORTED) rc = hv_wgrad_tr(d, &nslabs, (hipStream_t)stream);   // transposed-LDS-read form (fp16 storage)
         if (rc == HV_OK) {
             const float* bsl = d->dbias ? d->workspace + (long long)nslabs * nW : nullptr;
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(hv_cdiv(nW, 64) + (d->dbias ? hv_cdiv(d->Cout, 64) : 0)), dim3(256), 0, (hipStream_t)stream,
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(hv_cdiv(nW, 256) + (d->dbias ? hv_cdiv(d->Cout, 64) : 0)), dim3(256), 0, (hipStream_t)stream,
                                d->workspace, d->dw, nW, nslabs, d->accumulate, bsl, d->dbias, d->Cout, d->dbias_accumulate);
             HV_LAUNCH_CHECK();
             return HV_OK;
@@ -909,7 +930,7 @@ extern "C" int hv_conv2d_wgrad(const hv_wgrad_desc* d, void* stream) {
     HV_TIMING_END(s);
     if (rc != HV_OK) return rc;
     if (!direct) {
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(hv_cdiv(nW, 64) + (d->dbias ? hv_cdiv(d->Cout, 64) : 0)), dim3(256), 0, s, d->workspace, d->dw, nW,
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(hv_cdiv(nW, 256) + (d->dbias ? hv_cdiv(d->Cout, 64) : 0)), dim3(256), 0, s, d->workspace, d->dw, nW,
                            pl.splits, d->accumulate, k.bias_out, d->dbias, d->Cout, d->dbias_accumulate);
         HV_LAUNCH_CHECK();
     }

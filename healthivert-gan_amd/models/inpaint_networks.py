@@ -209,7 +209,7 @@ class _GenPlan:
         c = gen.cnum
         self.B, self.H, self.W, self.dev = B, H, W, device
         dt = ops.storage_dtype(gen.precision)        # fp16 buffers in the fp16 mode; the (B,1,H,W) image outputs stay fp32
-        z = lambda h, w, C: Act(torch.zeros(B, h, w, rup(C, 4), dtype=dt, device=device), C, 0)
+        z = lambda h, w, C: Act(torch.zeros(B, h, w, ops.cpad(C), dtype=dt, device=device), C, 0)
         img = lambda: torch.zeros(B, 1, H, W, dtype=torch.float32, device=device)
         H2, W2, H4, W4 = H // 2, W // 2, H // 4, W // 4
         self.book = E.GradBook()
@@ -341,7 +341,7 @@ class Generator(nn.Module):
                 g = getattr(self, gname)
                 for n, m in g.named_children():
                     if isinstance(m, Conv2dBlock):
-                        convs['%s.%s' % (gname, n)] = m.params('%s.%s' % (gname, n), cin_fwd=rup(m.cin, 4))
+                        convs['%s.%s' % (gname, n)] = m.params('%s.%s' % (gname, n), cin_fwd=ops.cpad(m.cin))
             self._pset_convs = convs
             cg, fg = self.coarse_generator, self.fine_generator
             self._pset = E.ParamSet(convs.values(), [cg.fc_height.weight, cg.fc_height.bias, fg.fc_height.weight, fg.fc_height.bias])

@@ -46,6 +46,12 @@ def rup(v, m):
     return (v + m - 1) // m * m
 
 
+def cpad(C):
+    """Channel stride of an activation buffer with C channels: a multiple of 4 (16 bytes of fp32 / 8 bytes of fp16 per lane), and of 8
+    beyond 16 channels so that the fp16 kernels that stage 16-byte items (wgrad_tr_kernel) take the 33- and 65-channel concat buffers too."""
+    return rup(C, 8) if C > 16 else rup(C, 4)
+
+
 def storage_dtype(precision):
     """Element type of the activation / gradient tensors INSIDE a network for a compute precision: the fp16 mode stores them as
     fp16 (they are rounded to fp16 as MFMA operands anyway: half the HBM / L2 bytes, no conversions in the staging code), the

@@ -353,3 +353,48 @@ def test_conv_rejects_bad_arguments():
     ya = ops.Act.empty(1, 7, 8, 8, dev())            # wrong output height
     with pytest.raises(RuntimeError):
         ops.conv2d(to_act(x), ohwi(w), ya, 3, 1, 1, 1)
+
+
+WTR_CASES = [   # B, H, W, Cin, Cout, k, stride, pad
+    (3, 31, 31, 256, 512, 4, 1, 1),       # PatchGAN 256 -> 512 (ragged 31 x 31 map: partial tiles)
+    (2, 64, 64, 64, 128, 4, 2, 1),        # PatchGAN 64 -> 128, stride 2
+    (2, 32, 32, 128, 256, 4, 2, 1),       # PatchGAN 128 -> 256, stride 2
+    (2, 40, 24, 32, 32, 3, 1, 1),         # generator 3x3 layers
+    (2, 33, 47, 64, 64, 3, 1, 1),
+    (2, 32, 32, 16, 32, 3, 1, 1),
+    (2, 32, 32, 64, 32, 3, 1, 1),
+    (4, 16, 16, 24, 40, 3, 1, 1),         # channel counts that are multiples of 8 but not of the tile widths
+    (2, 32, 32, 72, 64, 3, 1, 1),         # the 65 (+7 pad) channel concat input of conv20
+    (2, 32, 32, 32, 64, 3, 2, 1),         # 3x3 stride-2 downsampling layers
+    (2, 64, 48, 16, 32, 3, 2, 1),
+]
+
+
+@pytest.mark.parametrize('case', WTR_CASES)
+def test_wgrad_transposed_lds_read_kernel(case):
+    """wgrad_tr_kernel (fp16 storage, ds_read_b64_tr_b16 operands, input patch staged once for all taps) against torch CPU fp32:
+    weight gradient, the bias gradient folded into the same launch, accumulate, and the kernel actually taken."""
+    from hvtest import to_act, dev, maxerr
+    from hvgan import ops, lib
+    B, H, W, Cin, Cout, k, s, p = case
+    g_ = torch.Generator().manual_seed(31)
+    x = torch.randn(B, Cin, H, W, generator=g_)
+    w = (torch.randn(Cout, Cin, k, k, generator=g_) / (Cin * k * k) ** 0.5).requires_grad_(True)
+    y = F.conv2d(x, w, None, stride=s, padding=p)
+    g = torch.randn(y.shape, generator=g_)
+    y.backward(g)
+    xa, ga = to_act(x, dtype=torch.float16), to_act(g, dtype=torch.float16)
+    dw = torch.empty(Cout, k * k, Cin, device=dev())
+    db = torch.full((Cout,), 3.0, device=dev())
+    ops.conv2d_wgrad(xa, ga, dw, k, s, p, 1, precision='fp16', dbias=db)
+    assert lib.get().size('hv_last_kernel_path') == 12
+    torch.cuda.synchronize()
+    got = dw.cpu().reshape(Cout, k, k, Cin).permute(0, 3, 1, 2)
+    scale = max(1.0, w.grad.abs().max().item())
+    assert maxerr(got, w.grad) <= 6e-3 * scale, maxerr(got, w.grad)
+    gsum = g.half().float().sum(dim=(0, 2, 3))          # the kernel sums the fp16-stored values exactly (fp32 accumulation)
+    assert maxerr(db.cpu(), gsum) <= 1e-3 * max(1.0, g.abs().sum(dim=(0, 2, 3)).max().item())
+    ops.conv2d_wgrad(xa, ga, dw, k, s, p, 1, precision='fp16', accumulate=True, dbias=db, dbias_accumulate=True)
+    torch.cuda.synchronize()
+    assert maxerr(dw.cpu().reshape(Cout, k, k, Cin).permute(0, 3, 1, 2), 2 * w.grad) <= 1.2e-2 * scale
+    assert maxerr(db.cpu(), 2 * gsum) <= 2e-3 * max(1.0, g.abs().sum(dim=(0, 2, 3)).max().item())
