@@ -14,6 +14,7 @@
 // Shapes: the same as conv_halo_kernel with a uniform tap count of 4 (4x4 stride-2 data gradient classes), 9 (3x3) or
 // 16 (4x4); everything else stays on conv_halo_kernel.
 #include <stdlib.h>
+#include <type_traits>
 
 #include "conv_halo.h"
 
@@ -46,12 +47,17 @@ __global__ __launch_bounds__(256, 2) void conv_halo2_kernel(const HaloK p) {   /
     constexpr int LDP = CK + ((CK >= 32 && BSTEP == 1) ? 16 : 8);
     constexpr int MT = BM / WM / 16, NT = BN / WN / 16, GX = TW / 16;
     constexpr int PHM = (TH - 1) * BSTEP + SPAN, PWM = (TW - 1) * BSTEP + SPAN;   // patch extent
-    constexpr int PV = CK / 4;                                                    // float4 loads per patch pixel and chunk
+    // staging items: 4 channels of a patch pixel (16 B of fp32 / 8 B of fp16), or 8 channels (16 B) of an fp16 tensor with whole 32-channel chunks
+    constexpr int IW = (XH && CK >= 32) ? 8 : 4;
+    constexpr int PV = CK / IW;                                                   // items per patch pixel and chunk
     constexpr int PMAX = (PHM * PWM * PV + 255) / 256;
     static_assert(WM * WN == 4 && MT >= 1 && NT >= 1 && TW % 16 == 0 && NTAPS % D == 0, "bad tile");
     typedef typename HFrag<FK>::V V;
+    // stride-2 patches are 4x the output tile: ONE LDS buffer (the next chunk waits in the prefetch registers -- half as many since the
+    // tensors are stored as fp16 -- and is written between two barriers), so that two or three workgroups still fit a CU
+    constexpr bool DBUF = BSTEP == 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    _Float16* patch = reinterpret_cast<_Float16*>(smem);                          // [2][PHM*PWM][LDP]
+    _Float16* patch = reinterpret_cast<_Float16*>(smem);                          // [2 or 1][PHM*PWM][LDP]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int ci = 0;
@@ -97,8 +103,9 @@ __global__ __launch_bounds__(256, 2) void conv_halo2_kernel(const HaloK p) {   /
         const int row = n_base + wn * (BN / WN) + n * 16 + (lane & 15);
         wvo[n] = row < p.Cout ? (unsigned)((row * p.w_row + (lane >> 4) * (FK / 4)) * 2) : HV_OOB;
     }
-    typename XS::R preg[PMAX];
-    unsigned pvo[PMAX];          // byte offset of (patch pixel, channel quad) in x, HV_OOB outside the image / patch
+    typedef typename std::conditional<IW == 8, u32x4, typename XS::R>::type PR;
+    PR preg[PMAX];
+    unsigned pvo[PMAX];          // byte offset of (patch pixel, channel group) in x, HV_OOB outside the image / patch
     int plo[PMAX];               // LDS offset (halfs), -1 = no element
     const unsigned xbase = (unsigned)(n_img * p.img_stride + p.x_coff) * XS::B;
 #pragma unroll
@@ -108,15 +115,18 @@ __global__ __launch_bounds__(256, 2) void conv_halo2_kernel(const HaloK p) {   /
         const int py = pix / PW, px = pix - py * PW;
         const int hi = h0 + py, wi = w0 + px;
         const bool in = e < npatch * PV;
-        plo[i] = in ? pix * LDP + c4 * 4 : -1;
+        plo[i] = in ? pix * LDP + c4 * IW : -1;
         pvo[i] = (in && (unsigned)hi < (unsigned)p.Hl && (unsigned)wi < (unsigned)p.Wl)
-                     ? xbase + (unsigned)(((hi >> p.in_shift) * p.Wp + (wi >> p.in_shift)) * p.x_ld + c4 * 4) * XS::B : HV_OOB;
+                     ? xbase + (unsigned)(((hi >> p.in_shift) * p.Wp + (wi >> p.in_shift)) * p.x_ld + c4 * IW) * XS::B : HV_OOB;
     }
     // ragged channel counts (Cin % CK != 0, CK == 16 only: a lane's 4 channels are all inside or all outside): lanes beyond Cin
     // read zeros through the range check, for the patch and for the filter rows alike
     const bool ragged = (p.Cin % CK) != 0;
     auto ppref = [&](int c0) __attribute__((always_inline)) {
-        if (ragged) {
+        if constexpr (IW == 8) {
+#pragma unroll
+            for (int i = 0; i < PMAX; ++i) preg[i] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, pvo[i], c0 * 2, 0);
+        } else if (ragged) {
 #pragma unroll
             for (int i = 0; i < PMAX; ++i) {
                 const int c4 = (tid + i * 256) % PV;
@@ -136,7 +146,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo2_kernel(const HaloK p) {   /
 #pragma unroll
         for (int i = 0; i < PMAX; ++i) {
             if (plo[i] < 0) continue;
-            *reinterpret_cast<f16x4v*>(dst + plo[i]) = XS::h4(preg[i]);
+            if constexpr (IW == 8) *reinterpret_cast<u32x4*>(dst + plo[i]) = preg[i];
+            else *reinterpret_cast<f16x4v*>(dst + plo[i]) = XS::h4(preg[i]);
         }
     };
 
@@ -152,12 +163,12 @@ __global__ __launch_bounds__(256, 2) void conv_halo2_kernel(const HaloK p) {   /
     pflush(patch);
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
-        const _Float16* pb = patch + (c & 1) * (PHM * PWM * LDP);
+        const _Float16* pb = patch + (DBUF ? (c & 1) : 0) * (PHM * PWM * LDP);
         if (c + 1 < nchunks) ppref((c + 1) * CK);     // next chunk's patch rides behind this chunk's MFMAs
         // The B-fragments of tap q+1 are read from LDS while the MFMAs of tap q run (two register sets): with the reads issued
         // right before their use a wave waited ~100 cycles per pair of MFMAs (PMC: 64 % of the wave cycles in s_waitcnt).
         // (only where the second register set is affordable: up to 8 fragments per tap)
-        constexpr bool DB = KS * MT <= 8;
+        constexpr bool DB = KS * MT <= 8 && BSTEP == 1;      // (stride 2: the patch prefetch registers take the room of the second fragment set)
         V xf[DB ? 2 : 1][KS][MT];
         if (DB) {
 #pragma unroll
@@ -199,7 +210,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo2_kernel(const HaloK p) {   /
                     for (int ks = 0; ks < KS; ++ks) wf[q % D][n][ks] = wld(n, widx[qn], cn * CK, ks);
             }
         }
-        if (c + 1 < nchunks) pflush(patch + ((c + 1) & 1) * (PHM * PWM * LDP));
+        if (!DBUF) __syncthreads();      // every wave is done with this chunk's patch
+        if (c + 1 < nchunks) pflush(patch + (DBUF ? ((c + 1) & 1) : 0) * (PHM * PWM * LDP));
         __syncthreads();
     }
 
@@ -241,7 +253,7 @@ static int launch2(HaloK& k, hipStream_t s, int th0 = 8, int tw0 = TW) {
         k.cls[c].PH -= (th0 - TH) * k.bstep;
         k.cls[c].PW -= (tw0 - TW) * k.bstep;
     }
-    const size_t lds = (size_t)2 * PHM * PWM * LDP * sizeof(_Float16);
+    const size_t lds = (size_t)(BSTEP == 1 ? 2 : 1) * PHM * PWM * LDP * sizeof(_Float16);
     auto kern = conv_halo2_kernel<TH, TW, BN, WM, WN, CK, BSTEP, SPAN, D, true>;      // fp16 storage (hv_conv2d_halo refuses fp32 inputs)
     static bool raised[2] = {false, false};   // per instantiation: raise the dynamic-LDS cap once (not a stream operation)
     if (lds > 48 * 1024 && !raised[k.x_half]) {
@@ -274,6 +286,11 @@ int hv_halo2_launch(HaloK& k, int TW, int KH, int KW, int maxpatch, hipStream_t 
         // 64-channel blocks when 128-channel blocks would leave a CU with a single workgroup (512 -> 256 data gradient: 102 vs 112 us)
         const long long wgs128 = (long long)k.B * hv_cdiv(k.cls[0].Hc, 8) * hv_cdiv(k.cls[0].Wc, 16) * hv_cdiv(k.Cout, 128);
         return wgs128 < 512 ? launch2<8, 16, 64, 1, 4, 32, 1, 4, 4>(k, s) : launch2<8, 16, 128, 1, 4, 32, 1, 4, 4>(k, s);
+    }
+    // 4x4 stride-2 forward (PatchGAN 64 -> 128 -> 256) with a single-buffered patch (see the kernel): HV_HALO2_S2F=1, A/B knob
+    static const int s2f = getenv("HV_HALO2_S2F") ? atoi(getenv("HV_HALO2_S2F")) : 0;   // measured equal to conv_halo_kernel at step level (11.99 vs 11.99 ms, three A/B pairs): off
+    if (s2f && ntaps == 16 && KH == 4 && KW == 4 && TW == 16 && k.bstep == 2 && k.Cin % 32 == 0 && k.Cout >= 64) {
+        return launch2<8, 16, 64, 1, 4, 32, 2, 4, 4>(k, s);      // (128-channel blocks spill: 10 prefetch items + 64 accumulators + the weight ring)
     }
     // PatchGAN logits layer (512 -> 1): the single output channel rides in a 16-channel MFMA tile, the input is staged once
     if (ntaps == 16 && KH == 4 && KW == 4 && TW == 16 && k.Cout <= 16 && k.bstep == 1 && k.Cin % 32 == 0) {
