@@ -287,11 +287,11 @@ int hv_halo2_launch(HaloK& k, int TW, int KH, int KW, int maxpatch, hipStream_t 
         const long long wgs128 = (long long)k.B * hv_cdiv(k.cls[0].Hc, 8) * hv_cdiv(k.cls[0].Wc, 16) * hv_cdiv(k.Cout, 128);
         return wgs128 < 512 ? launch2<8, 16, 64, 1, 4, 32, 1, 4, 4>(k, s) : launch2<8, 16, 128, 1, 4, 32, 1, 4, 4>(k, s);
     }
-    // 4x4 stride-2 forward (PatchGAN 64 -> 128 -> 256) with a single-buffered patch (see the kernel): HV_HALO2_S2F=1, A/B knob
-    static const int s2f = getenv("HV_HALO2_S2F") ? atoi(getenv("HV_HALO2_S2F")) : 0;   // measured equal to conv_halo_kernel at step level (11.99 vs 11.99 ms, three A/B pairs): off
-    if (s2f && ntaps == 16 && KH == 4 && KW == 4 && TW == 16 && k.bstep == 2 && k.Cin % 32 == 0 && k.Cout >= 64) {
+    // 4x4 stride-2 forward with a single-buffered patch (see the kernel).  Measured alone, same device: 128 -> 256 @64^2 41.8 -> 34.9 us,
+    // 64 -> 128 @128^2 47.5 -> 49.3 us: taken from 128 input channels (HV_HALO2_S2F: 0 never, 2 always)
+    static const int s2f = getenv("HV_HALO2_S2F") ? atoi(getenv("HV_HALO2_S2F")) : 1;
+    if (s2f && ntaps == 16 && KH == 4 && KW == 4 && TW == 16 && k.bstep == 2 && k.Cin % 32 == 0 && k.Cout >= 64 && (k.Cin >= 128 || s2f == 2))
         return launch2<8, 16, 64, 1, 4, 32, 2, 4, 4>(k, s);      // (128-channel blocks spill: 10 prefetch items + 64 accumulators + the weight ring)
-    }
     // PatchGAN logits layer (512 -> 1): the single output channel rides in a 16-channel MFMA tile, the input is staged once
     if (ntaps == 16 && KH == 4 && KW == 4 && TW == 16 && k.Cout <= 16 && k.bstep == 1 && k.Cin % 32 == 0) {
         // small maps: 4-row tiles double the workgroup count (31 x 31 logits: 128 -> 256 workgroups)

@@ -26,10 +26,10 @@ def main():
             Ho, Wo = H * 2, W * 2
     else:
         Ho, Wo = ops.conv_out_size(H, k, s, p, 1), ops.conv_out_size(W, k, s, p, 1)
-    x = ops.Act(torch.randn(B, H, W, Cin, generator=g).to(dev))
+    x = ops.Act(torch.randn(B, H, W, Cin, generator=g).to(dev).to(ops.storage_dtype(prec)))
     w = (torch.randn(Cout, k * k, Cin, generator=g) / (Cin * k * k) ** 0.5).to(dev)
     wh = w.half()
-    y = ops.Act.empty(B, Ho, Wo, Cout, dev)
+    y = ops.Act.empty(B, Ho, Wo, Cout, dev, dtype=ops.storage_dtype(prec))
     for _ in range(3):
         ops.conv2d(x, w, y, k, s, p, 1, transposed=bool(tr), precision=prec, w_h=wh)
     torch.cuda.synchronize()

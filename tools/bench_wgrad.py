@@ -20,8 +20,8 @@ def main():
     dev = torch.device('cuda:0')
     g = torch.Generator(device='cpu').manual_seed(0)
     Ho, Wo = ops.conv_out_size(H, k, s, p, 1), ops.conv_out_size(W, k, s, p, 1)
-    x = ops.Act(torch.randn(B, H, W, Cin, generator=g).to(dev))
-    gy = ops.Act(torch.randn(B, Ho, Wo, Cout, generator=g).to(dev))
+    x = ops.Act(torch.randn(B, H, W, Cin, generator=g).to(dev).to(ops.storage_dtype(prec)))
+    gy = ops.Act(torch.randn(B, Ho, Wo, Cout, generator=g).to(dev).to(ops.storage_dtype(prec)))
     dw = torch.empty(Cout, k * k, Cin, device=dev)
     for _ in range(3):
         ops.conv2d_wgrad(x, gy, dw, k, s, p, 1, precision=prec)
