@@ -197,6 +197,8 @@ def main():
     import torch
     import torch.distributed as dist
     os.environ['HV_PRECISION'] = args.precision
+    if torch.cuda.device_count() and local_rank >= torch.cuda.device_count():
+        local_rank %= torch.cuda.device_count()      # rehearsal of N ranks on fewer devices (HV_DDP_BACKEND=gloo)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
 

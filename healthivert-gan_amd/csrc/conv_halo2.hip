@@ -285,6 +285,11 @@ int hv_halo2_launch(HaloK& k, int TW, int KH, int KW, int maxpatch, hipStream_t 
     if (ntaps == 16 && KH == 4 && KW == 4 && TW == 16 && k.Cout > 64 && k.bstep == 1 && k.Cin % 32 == 0) {
         // 64-channel blocks when 128-channel blocks would leave a CU with a single workgroup (512 -> 256 data gradient: 102 vs 112 us)
         const long long wgs128 = (long long)k.B * hv_cdiv(k.cls[0].Hc, 8) * hv_cdiv(k.cls[0].Wc, 16) * hv_cdiv(k.Cout, 128);
+        // weight-ring depth (taps in flight): vmcnt retires in order, so the first wait on a filter row issued AFTER the next chunk's patch
+        // prefetch also waits for that prefetch (an HBM round trip); a deeper ring moves that wait further behind the prefetch.  HV_HALO2_RING
+        static const int ring = getenv("HV_HALO2_RING") ? atoi(getenv("HV_HALO2_RING")) : 4;
+        if (ring == 8) return wgs128 < 512 ? launch2<8, 16, 64, 1, 4, 32, 1, 4, 8>(k, s) : launch2<8, 16, 128, 1, 4, 32, 1, 4, 8>(k, s);
+        if (ring == 16) return wgs128 < 512 ? launch2<8, 16, 64, 1, 4, 32, 1, 4, 16>(k, s) : launch2<8, 16, 128, 1, 4, 32, 1, 4, 8>(k, s);
         return wgs128 < 512 ? launch2<8, 16, 64, 1, 4, 32, 1, 4, 4>(k, s) : launch2<8, 16, 128, 1, 4, 32, 1, 4, 4>(k, s);
     }
     // 4x4 stride-2 forward with a single-buffered patch (see the kernel).  Measured alone, same device: 128 -> 256 @64^2 41.8 -> 34.9 us,

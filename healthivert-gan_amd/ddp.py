@@ -28,6 +28,9 @@ def init_from_env():
     if world <= 1 or not dist.is_available():
         return None
     local = int(os.environ.get('LOCAL_RANK', os.environ.get('RANK', '0')))
+    ndev = torch.cuda.device_count()
+    if ndev and local >= ndev:      # rehearsal of N ranks on fewer devices (gloo backend; RCCL refuses two ranks on one device)
+        local %= ndev
     if not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
