@@ -282,6 +282,8 @@ def main():
     }
     if rank == 0:
         out['roofline'] = prof.roofline(args.precision, MFMA_PEAK_TFLOPS[args.precision])
+        if out['roofline'] is None:
+            raise SystemExit('bench.py: the roofline leg timed no kernel launch')
         # HBM bytes per launch from the committed PMC passes of this round (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate
         # passes over a serial bench run; mean per launch of this instantiation)
         pdir = os.path.join(ROOT, 'profiles')

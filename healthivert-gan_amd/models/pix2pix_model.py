@@ -91,6 +91,7 @@ class Pix2PixModel(BaseModel):
         self._shapes, self._cur = {}, None      # per batch shape: input buffers, warm-up count, captured graphs
         self._graphs = None
         self._dp_graphs = None
+        self._dp_replay = True
         self._eager_steps = 0
         self.use_graph = _os_environ_graph()
         self.grad_sync = ddp.GradSync() if self.isTrain else None
@@ -500,7 +501,7 @@ class Pix2PixModel(BaseModel):
 
     def _dp_run(self, name, st):
         with torch.cuda.stream(st):
-            g = self._dp_graphs.get(name) if self._dp_graphs else None
+            g = self._dp_graphs.get(name) if (self._dp_graphs and self._dp_replay) else None
             if g is not None:
                 g.replay()
             else:
@@ -522,6 +523,7 @@ class Pix2PixModel(BaseModel):
                 self._capture_data_parallel()
             except RuntimeError as e:
                 self._graph_failed(e)
+        self._dp_replay = bool(graphable)           # an active kernel timer / HV_GRAPH=0: launch the phases eagerly
         for k in (1, 2, 3):
             on(k).wait_stream(main)                 # the batch (set_input copies) and last step's readers of D_k's outputs
             self._dp_run('real%d' % k, on(k))

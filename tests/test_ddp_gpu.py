@@ -153,3 +153,21 @@ def test_rccl_exchange_path_single_rank(tmp_path):
     for n in outs[0]:
         for k in outs[0][n]:
             assert torch.equal(outs[0][n][k], outs[1][n][k]), (n, k)
+
+
+def test_bench_two_ranks_rehearsal_over_gloo():
+    """`python bench.py --gpus 2` from a plain shell, the whole flow the driver's scaling run takes -- launcher, process group from the
+    environment, broadcast, the data-parallel step with its twelve phase graphs, survey / timed / roofline legs, MAX-over-ranks clock, one
+    JSON line from rank 0 -- with the gloo transport so that both ranks can share this box's one GPU (RCCL refuses two ranks per device)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(HV_DDP_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '3', '--no-cpu-baseline'],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1, p.stdout.decode()[-2000:]
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['config']['global_batch'] == 32 and rec['config']['parallelism'] == 'dp2'
+    assert rec['config']['launch'].startswith('hipGraph replay (12 graphs/step)')
+    assert rec['roofline'] and rec['roofline']['launches'] > 0 and 'fine_generator_forward' in rec
