@@ -105,7 +105,7 @@ class KernelTimer:
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
-KERNEL_NAMES = {0: 'conv_igemm_kernel', 1: 'narrow_fwd_kernel', 2: 'conv_halo_kernel', 3: 'conv_halo2_kernel', 4: 'thin1_fwd_kernel', 5: 'head_gemm_kernel', 10: 'wgrad_kernel',
+KERNEL_NAMES = {0: 'conv_igemm_kernel', 1: 'narrow_fwd_kernel', 2: 'conv_halo_kernel', 3: 'conv_halo2_kernel', 4: 'thin1_fwd_kernel', 5: 'head_gemm_kernel', 6: 'conv_s2t_kernel', 10: 'wgrad_kernel',
                 11: 'wgrad_halo_kernel', 12: 'wgrad_tr_kernel'}
 
 

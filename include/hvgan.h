@@ -40,7 +40,7 @@ enum { HV_NORM_NONE = 0, HV_NORM_BATCH = 1, HV_NORM_INSTANCE = 2 };
 int hv_version(void);
 const char* hv_arch(void); /* "gfx950" */
 /* which kernel family the calling thread's most recent hv_conv2d / hv_conv2d_wgrad launched (profiling labels):
- * 0 conv_igemm_kernel, 1 narrow_fwd_kernel, 2 conv_halo_kernel, 3 conv_halo2_kernel, 4 thin1_fwd_kernel, 5 head_gemm_kernel, 10 wgrad_kernel,
+ * 0 conv_igemm_kernel, 1 narrow_fwd_kernel, 2 conv_halo_kernel, 3 conv_halo2_kernel, 4 thin1_fwd_kernel, 5 head_gemm_kernel, 6 conv_s2t_kernel, 10 wgrad_kernel,
  * 11 wgrad_halo_kernel, 12 wgrad_tr_kernel */
 int hv_last_kernel_path(void);
 /* name of that kernel instantiation as rocprofv3 prints it, e.g. "conv_halo2_kernel<8, 16, 128, 1, 4, 32, 1, 4, 4>" (the gather and weight-
@@ -49,6 +49,9 @@ const char* hv_last_kernel_name(void);
 /* profiling: the calling thread's NEXT hv_conv2d or hv_conv2d_wgrad records these two hipEvent_t right around its kernel launch (for a weight
  * gradient: around the main kernel; the slab reduction that follows is a separate kernel); the pair is consumed by that call.  NULL, NULL cancels. */
 int hv_set_kernel_timing(void* ev_start, void* ev_stop);
+/* tuning (tests and A/B tools): which stride-2 data gradients take the fused-parity kernel (path 6): 0 none, 1 the 3x3 filters (default;
+ * environment HV_S2T), 2 also the 4x4 filters.  Process-wide; returns the previous mode. */
+int hv_set_s2t_mode(int mode);
 
 /* ---------------------------------------------------------------- convolution (implicit GEMM on MFMA)
  * Replaces F.conv2d / F.conv_transpose2d as called by Conv2dBlock.forward (models/inpaint_networks.py:494-503),

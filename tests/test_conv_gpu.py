@@ -398,3 +398,46 @@ def test_wgrad_transposed_lds_read_kernel(case):
     torch.cuda.synchronize()
     assert maxerr(dw.cpu().reshape(Cout, k, k, Cin).permute(0, 3, 1, 2), 2 * w.grad) <= 1.2e-2 * scale
     assert maxerr(db.cpu(), 2 * gsum) <= 2e-3 * max(1.0, g.abs().sum(dim=(0, 2, 3)).max().item())
+
+
+S2T_CASES = [   # B, H (conv input = gradient output size), W, Cin, Cout (of the forward conv), k
+    (2, 64, 64, 64, 128, 4),       # PatchGAN 64 -> 128 (data gradient 128 -> 64 at 64 x 64)
+    (2, 32, 32, 128, 256, 4),
+    (16, 32, 32, 16, 32, 3),       # generator 3x3 stride-2 layers: parity classes of 1, 2, 2 and 4 taps
+    (2, 48, 32, 32, 64, 3),
+    (2, 16, 48, 16, 16, 3),
+    (3, 24, 40, 40, 72, 4),        # channel counts off the tile widths, ragged tiles
+]
+
+
+@pytest.mark.parametrize('case', S2T_CASES)
+def test_conv_stride2_data_gradient_fused_parity_classes(case):
+    """conv_s2t_kernel (the four output parities of a stride-2 data gradient in one workgroup, one wave each) against torch CPU fp32,
+    with the producer's act' multiplier and accumulate, and the kernel actually taken."""
+    from hvtest import to_act, from_act, ohwi_T, dev, maxerr
+    from hvgan import ops, lib
+    B, H, W, Cin, Cout, k = case
+    g_ = torch.Generator().manual_seed(17)
+    x = torch.randn(B, Cin, H, W, generator=g_, requires_grad=True)
+    w = torch.randn(Cout, Cin, k, k, generator=g_) / (Cin * k * k) ** 0.5
+    y = F.conv2d(x, w, None, stride=2, padding=1)
+    gy = torch.randn(y.shape, generator=g_)
+    y.backward(gy)
+    m = torch.randn(B, Cin, H, W, generator=g_)
+    fac = torch.where(m > 0, torch.ones_like(m), torch.full_like(m, 0.2))
+    wb = ohwi_T(w)
+    dxa = ops.Act.empty(B, H, W, Cin, dev(), dtype=torch.float16)
+    ga = to_act(gy, dtype=torch.float16)
+    prev = lib.get().size('hv_set_s2t_mode', 2)   # the 4x4 filters take it only in mode 2
+    try:
+        ops.conv2d(ga, wb, dxa, k, 2, 1, 1, transposed=True, precision='fp16', w_h=wb.half(), mul=(to_act(m, dtype=torch.float16), 'lrelu'))
+        assert lib.get().size('hv_last_kernel_path') == 6
+        torch.cuda.synchronize()
+        ref = x.grad * fac
+        scale = max(1.0, ref.abs().max().item())
+        assert maxerr(from_act(dxa), ref) <= 4e-3 * scale, maxerr(from_act(dxa), ref)
+        ops.conv2d(ga, wb, dxa, k, 2, 1, 1, transposed=True, precision='fp16', w_h=wb.half(), accumulate=1)
+        torch.cuda.synchronize()
+        assert maxerr(from_act(dxa), ref + x.grad) <= 8e-3 * scale
+    finally:
+        lib.get().size('hv_set_s2t_mode', prev)
