@@ -760,51 +760,68 @@ __global__ __launch_bounds__(WN * WC * 64) void wgrad_kernel(const WgradK p) {
         }
 }
 
-// 256 threads = 64 element quads x 4 split groups (16 bytes per lane and slab); fixed summation order (deterministic).  Blocks beyond the
-// dW range fold the per-split bias rows (bslabs [splits][nb]) into dbias.  n and nb are multiples of 4 (channel counts are).
+// Sum of the split-K slabs, in a fixed order (deterministic).  256 threads = Q element quads (16 bytes per lane and slab) x G split groups, Q * G =
+// 256: the layers with a small dW are the ones cut into many slabs (up to 512), and with 4 groups a lane walked 128 dependent-latency iterations
+// (measured 30 us for 19 MB, twice the weight-gradient kernel itself); G follows the slab count so that a lane issues <= 8 loads, all in flight.
+// Blocks beyond the dW range fold the per-split bias rows (bslabs [splits][nb]) into dbias.  n and nb are multiples of 4 (channel counts are).
+template <int G>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, long long n, int splits, int accumulate,
                                                            const float* __restrict__ bslabs, float* __restrict__ dbias, int nb, int bias_accumulate) {
-    __shared__ float4 sh[4][64];
-    const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const long long wblocks = (n + 255) / 256;
-    if ((long long)blockIdx.x >= wblocks) {      // bias rows: one element per lane (dbias is a view into the flat gradient buffer: any 4-byte offset)
-        const long long i = ((long long)blockIdx.x - wblocks) * 64 + e;
-        float s = 0.f;
-        if (i < nb)
-            for (int k = grp; k < splits; k += 4) s += bslabs[(long long)k * nb + i];
-        sh[grp][e].x = s;
-        __syncthreads();
-        if (grp == 0 && i < nb) {
-            const float t = (sh[0][e].x + sh[1][e].x) + (sh[2][e].x + sh[3][e].x);
-            dbias[i] = bias_accumulate ? dbias[i] + t : t;
-        }
-        return;
-    }
-    const long long i = ((long long)blockIdx.x * 64 + e) * 4;
-    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+    constexpr int Q = 256 / G;
+    __shared__ float4 sh[G][Q];
+    const int e = threadIdx.x % Q, grp = threadIdx.x / Q;
+    const long long wblocks = (n / 4 + Q - 1) / Q;
     auto add = [](float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
-    if (i < n) {
+    const bool bias_block = (long long)blockIdx.x >= wblocks;       // block-uniform
+    // bias rows: one element per lane (dbias is a view into the flat gradient buffer: any 4-byte offset)
+    const long long i = bias_block ? ((long long)blockIdx.x - wblocks) * Q + e : ((long long)blockIdx.x * Q + e) * 4;
+    const bool live = i < (bias_block ? (long long)nb : n);
+    float4 acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
         int k = grp;
-        for (; k + 12 < splits; k += 16) {
-            add(s0, *reinterpret_cast<const float4*>(slabs + (long long)k * n + i));
-            add(s1, *reinterpret_cast<const float4*>(slabs + (long long)(k + 4) * n + i));
-            add(s2, *reinterpret_cast<const float4*>(slabs + (long long)(k + 8) * n + i));
-            add(s3, *reinterpret_cast<const float4*>(slabs + (long long)(k + 12) * n + i));
+        if (bias_block) {
+            for (; k + 3 * G < splits; k += 4 * G)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[u].x += bslabs[(long long)(k + u * G) * nb + i];
+            for (; k < splits; k += G) acc[0].x += bslabs[(long long)k * nb + i];
+        } else {
+            for (; k + 3 * G < splits; k += 4 * G)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) add(acc[u], *reinterpret_cast<const float4*>(slabs + (long long)(k + u * G) * n + i));
+            for (; k < splits; k += G) add(acc[0], *reinterpret_cast<const float4*>(slabs + (long long)k * n + i));
         }
-        for (; k < splits; k += 4) add(s0, *reinterpret_cast<const float4*>(slabs + (long long)k * n + i));
     }
-    add(s0, s1); add(s2, s3); add(s0, s2);
-    sh[grp][e] = s0;
+    add(acc[0], acc[1]); add(acc[2], acc[3]); add(acc[0], acc[2]);
+    sh[grp][e] = acc[0];
     __syncthreads();
-    if (grp == 0 && i < n) {
-        float4 s = sh[0][e];
-        add(s, sh[1][e]);
-        float4 t = sh[2][e];
-        add(t, sh[3][e]);
-        add(s, t);
-        if (accumulate) add(s, *reinterpret_cast<const float4*>(dw + i));
-        *reinterpret_cast<float4*>(dw + i) = s;
+#pragma unroll
+    for (int h = G / 2; h >= 1; h >>= 1) {
+        if (grp < h) add(sh[grp][e], sh[grp + h][e]);
+        __syncthreads();
     }
+    if (grp == 0 && live) {
+        float4 t = sh[0][e];
+        if (bias_block) dbias[i] = bias_accumulate ? dbias[i] + t.x : t.x;
+        else {
+            if (accumulate) add(t, *reinterpret_cast<const float4*>(dw + i));
+            *reinterpret_cast<float4*>(dw + i) = t;
+        }
+    }
+}
+
+static int launch_wgrad_reduce(const float* slabs, float* dw, long long n, int splits, int accumulate, const float* bslabs, float* dbias, int nb,
+                                int bias_accumulate, hipStream_t s) {
+#define HV_RED(G_)                                                                                                                          \
+    hipLaunchKernelGGL(wgrad_reduce_kernel<G_>, dim3(hv_cdiv(n / 4, 256 / G_) + (dbias ? hv_cdiv(nb, 256 / G_) : 0)), dim3(256), 0, s, slabs, dw, n, splits, \
+                       accumulate, bslabs, dbias, nb, bias_accumulate)
+    if (splits <= 16) HV_RED(4);
+    else if (splits <= 64) HV_RED(16);
+    else HV_RED(32);
+#undef HV_RED
+    HV_LAUNCH_CHECK();
+    return HV_OK;
 }
 
 struct WgradPlan { int BN, BC, KT, splits, chunk; };
@@ -897,10 +914,7 @@ extern "C" int hv_conv2d_wgrad(const hv_wgrad_desc* d, void* stream) {
         if (rc == HV_ERR_UNSUPPORTED) rc = hv_wgrad_tr(d, &nslabs, (hipStream_t)stream);   // transposed-LDS-read form (fp16 storage)
         if (rc == HV_OK) {
             const float* bsl = d->dbias ? d->workspace + (long long)nslabs * nW : nullptr;
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(hv_cdiv(nW, 256) + (d->dbias ? hv_cdiv(d->Cout, 64) : 0)), dim3(256), 0, (hipStream_t)stream,
-                               d->workspace, d->dw, nW, nslabs, d->accumulate, bsl, d->dbias, d->Cout, d->dbias_accumulate);
-            HV_LAUNCH_CHECK();
-            return HV_OK;
+            return launch_wgrad_reduce(d->workspace, d->dw, nW, nslabs, d->accumulate, bsl, d->dbias, d->Cout, d->dbias_accumulate, (hipStream_t)stream);
         }
         if (rc != HV_ERR_UNSUPPORTED) return rc;
     }
@@ -935,9 +949,7 @@ extern "C" int hv_conv2d_wgrad(const hv_wgrad_desc* d, void* stream) {
     HV_TIMING_END(s);
     if (rc != HV_OK) return rc;
     if (!direct) {
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(hv_cdiv(nW, 256) + (d->dbias ? hv_cdiv(d->Cout, 64) : 0)), dim3(256), 0, s, d->workspace, d->dw, nW,
-                           pl.splits, d->accumulate, k.bias_out, d->dbias, d->Cout, d->dbias_accumulate);
-        HV_LAUNCH_CHECK();
+        return launch_wgrad_reduce(d->workspace, d->dw, nW, pl.splits, d->accumulate, k.bias_out, d->dbias, d->Cout, d->dbias_accumulate, s);
     }
     return HV_OK;
 }

@@ -59,7 +59,8 @@ class GradSync:
 
     def exchange_stream(self, device):
         if self.stream is None:
-            self.stream = torch.cuda.Stream(device=device, priority=-1)
+            from . import engine
+            self.stream = engine.named_stream('exchange', device, priority=-1)
         return self.stream
 
     def reduce(self, flat, after=None):

@@ -157,6 +157,22 @@ class ConvNode:
 # the train step (three chains already run concurrently there, and a fork nested inside a forked stream crashes
 # hipStreamEndCapture on ROCm 7.2 when the step is captured as a graph)
 NO_FORK_STREAMS = set()
+_named_streams = {}
+
+
+def named_stream(name, device, priority=0):
+    """Process-wide HIP stream for a role (a discriminator's stream, the capture stream, the weight-gradient side stream of a parent stream ...).
+    torch hands out streams from a pool of 32 per device and priority, round-robin: models that each create their own streams wrap that
+    pool after a few instances, two roles then share one HIP stream handle and handle-keyed state (NO_FORK_STREAMS, the per-stream scratch
+    buffers) changes the launch order from one model to the next.  A role keeps one stream for the life of the process instead."""
+    dev = torch.device(device)
+    key = (name, dev.index if dev.index is not None else torch.cuda.current_device(), priority)
+    st = _named_streams.get(key)
+    if st is None:
+        st = _named_streams[key] = torch.cuda.Stream(device=dev, priority=priority)
+    return st
+
+
 FUSE_DBIAS = os.environ.get('HV_FUSE_DBIAS', '1') != '0'   # bias gradients computed inside the weight-gradient kernels
 SERIAL = False            # True: no side streams at all (per-kernel timing with HIP events needs the GPU to itself)
 
@@ -168,6 +184,7 @@ class GradBook:
         self.twins = {}
         self.written = set()
         self.side = None          # side HIP stream for weight gradients (they overlap the data-gradient chain)
+        self._side_of = None      # ... of this parent stream
         self.overlap = os.environ.get('HV_OVERLAP_WGRAD', '1') != '0'
 
     def can_fork(self):
@@ -176,8 +193,8 @@ class GradBook:
     def fork(self):
         """Side stream, ordered after everything queued so far on the current stream."""
         cur = torch.cuda.current_stream()
-        if self.side is None:
-            self.side = torch.cuda.Stream(device=cur.device)
+        if self.side is None or self._side_of != cur.cuda_stream:
+            self.side, self._side_of = named_stream('wgrad-side-of-%x' % cur.cuda_stream, cur.device), cur.cuda_stream
         self.side.wait_stream(cur)
         return self.side
 
@@ -270,7 +287,7 @@ def branch_stream():
     key = cur.device.index
     st = _branch_streams.get(key)
     if st is None:
-        st = _branch_streams[key] = torch.cuda.Stream(device=cur.device)
+        st = _branch_streams[key] = named_stream('generator-branch', cur.device)
         NO_FORK_STREAMS.add(st.cuda_stream)
     return st
 

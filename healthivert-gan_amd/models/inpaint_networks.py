@@ -540,7 +540,7 @@ def _generator_eval_replay(self, x, mask, CAM, slice_ratio):
         torch.cuda.synchronize(dev)
         g = torch.cuda.CUDAGraph()
         try:
-            with torch.cuda.graph(g, stream=torch.cuda.Stream(device=dev), capture_error_mode='thread_local'):
+            with torch.cuda.graph(g, stream=E.named_stream('capture', dev), capture_error_mode='thread_local'):
                 P = self.run_forward(*static)
         except RuntimeError:
             self.use_graph = False

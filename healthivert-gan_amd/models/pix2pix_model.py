@@ -356,7 +356,7 @@ class Pix2PixModel(BaseModel):
         overlap on the 256 CUs)."""
         main = torch.cuda.current_stream(self.device)
         if getattr(self, '_d_streams', None) is None:
-            self._d_streams = [torch.cuda.Stream(device=self.device) for _ in range(3)]
+            self._d_streams = [engine.named_stream('discriminator-%d' % k, self.device) for k in (1, 2, 3)]
             engine.NO_FORK_STREAMS.update(st.cuda_stream for st in self._d_streams)
         self._dxs = {}
         split = self.real_first and not self.batch_d
@@ -489,7 +489,7 @@ class Pix2PixModel(BaseModel):
 
     def _dp_setup(self):
         if getattr(self, '_d_streams', None) is None:
-            self._d_streams = [torch.cuda.Stream(device=self.device) for _ in range(3)]
+            self._d_streams = [engine.named_stream('discriminator-%d' % k, self.device) for k in (1, 2, 3)]
             engine.NO_FORK_STREAMS.update(st.cuda_stream for st in self._d_streams)
         if getattr(self, '_dp_ph', None) is None:
             self._dp_ph = self._dp_phases()
@@ -550,7 +550,7 @@ class Pix2PixModel(BaseModel):
 
     def _capture_data_parallel(self):
         if getattr(self, '_capture_stream', None) is None:
-            self._capture_stream = torch.cuda.Stream(device=self.device)
+            self._capture_stream = engine.named_stream('capture', self.device)
         torch.cuda.synchronize(self.device)
         graphs = {}
         for name, fn in self._dp_ph.items():
@@ -565,7 +565,7 @@ class Pix2PixModel(BaseModel):
 
     def _capture(self):
         if getattr(self, '_capture_stream', None) is None:
-            self._capture_stream = torch.cuda.Stream(device=self.device)
+            self._capture_stream = engine.named_stream('capture', self.device)
         torch.cuda.synchronize(self.device)
         graphs, pool = [], None
         for phase in (self._phase_a, self._phase_b, self._phase_c):

@@ -203,8 +203,8 @@ def test_graph_recapture_when_the_batch_shape_changes(monkeypatch):
     se, we, le = run(False)
     sg, wg, lg = run(True)
     assert sg == [False, False, True, True, False, False, True, True, True, True] and not any(se)
-    for k in we:
-        assert torch.equal(we[k], wg[k]), k
+    bad = [(k, (we[k].float() - wg[k].float()).abs().max().item()) for k in we if not torch.equal(we[k], wg[k])]
+    assert not bad, ('%d of %d tensors differ' % (len(bad), len(we)), bad[:8])
     assert le == lg
 
 
