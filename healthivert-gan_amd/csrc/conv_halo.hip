@@ -279,6 +279,11 @@ int hv_conv2d_halo(const hv_conv_desc* d, const void* w_f16, hipStream_t s) {
     if (!d->x_f16) return HV_ERR_UNSUPPORTED;      // halo-tiled kernels are built for fp16 storage (an fp32 input with fp16 operands: gather kernel)
     HaloK k;
     k.x_half = d->x_f16 ? 1 : 0; k.y_half = d->y_f16 ? 1 : 0; k.mul_half = d->mul_f16 ? 1 : 0;
+    {   // fragment-ordered filters (A/B knob HV_W_TILED=0: plain rows)
+        static const int tiled = getenv("HV_W_TILED") ? atoi(getenv("HV_W_TILED")) : 1;
+        k.wt = (tiled && d->w_f16_tiled && !((uintptr_t)d->w_f16_tiled & 15)) ? reinterpret_cast<const _Float16*>(d->w_f16_tiled) : nullptr;
+        k.wt_bytes = (unsigned)((size_t)hv_cdiv(d->Cout, 16) * 16 * d->KH * d->KW * d->Cin * sizeof(_Float16));
+    }
     const size_t xs = k.x_half ? 2 : 4;
     const int Hp = d->H >> d->in_shift, Wp = d->W >> d->in_shift;
     k.x = d->x; k.w = (const _Float16*)w_f16; k.bias = d->bias; k.y = d->y;

@@ -95,13 +95,19 @@ __global__ __launch_bounds__(256, 2) void conv_halo2_kernel(const HaloK p) {   /
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.w), 0, p.w_bytes, 0x00020000);
+    // filters: plain rows [Cout][taps][Cin], or (p.wt) MFMA-fragment order: a fragment = 16 rows x FK channels is one contiguous piece, lane l
+    // owns bytes [l * FK/2, (l+1) * FK/2) of it (include/hvgan.h, hv_weight_tile_f16).  Plain rows make a wave's fragment load 16 rows x 64 B that
+    // lie a whole filter row (8 KB at 4x4x256) apart -- 16 half-used cache lines on ONE L2 channel; measured 93 -> 76 us on the 256 -> 512 layer
+    const bool tiledw = p.wt != nullptr;                                  // scalar
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(tiledw ? p.wt : p.w), 0, tiledw ? p.wt_bytes : p.w_bytes, 0x00020000);
+    const int wsc = tiledw ? 32 : 2;                                      // bytes per (tap, channel) step: a 16-row fragment column vs one row
     const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
     unsigned wvo[NT];            // byte offset of this lane's filter row / k-group, without tap and chunk
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int row = n_base + wn * (BN / WN) + n * 16 + (lane & 15);
         wvo[n] = row < p.Cout ? (unsigned)((row * p.w_row + (lane >> 4) * (FK / 4)) * 2) : HV_OOB;
+        if (tiledw) wvo[n] = row < ((p.Cout + 15) & ~15) ? (unsigned)((row >> 4) * (16 * p.w_row * 2) + lane * (FK / 2)) : HV_OOB;
     }
     typedef typename std::conditional<IW == 8, u32x4, typename XS::R>::type PR;
     PR preg[PMAX];
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo2_kernel(const HaloK p) {   /
     const int kgc = (lane >> 4) * (FK / 4);          // first channel of this lane's k-group inside an MFMA step
     auto wld = [&](int n, int widx_, int c0, int ks) __attribute__((always_inline)) {
         const unsigned vo = (ragged && c0 + ks * FK + kgc >= p.Cin) ? HV_OOB : wvo[n];
-        return WLoad<FK>::ld(wsrc, vo, (widx_ * p.Cin + c0 + ks * FK) * 2);
+        return WLoad<FK>::ld(wsrc, vo, (widx_ * p.Cin + c0 + ks * FK) * wsc);
     };
     auto pflush = [&](_Float16* dst) __attribute__((always_inline)) {
 #pragma unroll
@@ -253,6 +259,8 @@ static int launch2(HaloK& k, hipStream_t s, int th0 = 8, int tw0 = TW) {
         k.cls[c].PH -= (th0 - TH) * k.bstep;
         k.cls[c].PW -= (tw0 - TW) * k.bstep;
     }
+    // the tiled filter table is cut in fragments of 32 channels when Cin % 32 == 0, else 16: usable only by the matching instantiation
+    if (k.wt && (k.Cin % CK != 0 || (k.Cin % 32 == 0 ? 32 : 16) != (CK == 16 ? 16 : 32))) k.wt = nullptr;
     const size_t lds = (size_t)(BSTEP == 1 ? 2 : 1) * PHM * PWM * LDP * sizeof(_Float16);
     auto kern = conv_halo2_kernel<TH, TW, BN, WM, WN, CK, BSTEP, SPAN, D, true>;      // fp16 storage (hv_conv2d_halo refuses fp32 inputs)
     static bool raised[2] = {false, false};   // per instantiation: raise the dynamic-LDS cap once (not a stream operation)

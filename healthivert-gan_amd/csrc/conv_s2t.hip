@@ -22,6 +22,7 @@ struct S2TK {
     float alpha; int act, accumulate, vec_store;
     const void* mul_src; int mul_ld, mul_coff, mul_act, mul_vec, y_half, mul_half;
     unsigned x_bytes, w_bytes;
+    const _Float16* wt; unsigned wt_bytes;      // filters in MFMA-fragment order (hv_conv_desc.w_f16_tiled) or NULL
 };
 
 template <int KS, int TH, int BN, int CK>
@@ -57,13 +58,16 @@ __global__ __launch_bounds__(256, 2) void conv_s2t_kernel(const S2TK p) {
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.w), 0, p.w_bytes, 0x00020000);
+    const bool tiledw = p.wt != nullptr;        // scalar; layouts as in conv_halo2_kernel
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(tiledw ? p.wt : p.w), 0, tiledw ? p.wt_bytes : p.w_bytes, 0x00020000);
+    const int wsc = tiledw ? 32 : 2;
     const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.x), 0, p.x_bytes, 0x00020000);
     unsigned wvo[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int row = n_base + n * 16 + (lane & 15);
         wvo[n] = row < p.Cout ? (unsigned)((row * p.w_row + (lane >> 4) * (FK / 4)) * 2) : HV_OOB;
+        if (tiledw) wvo[n] = row < ((p.Cout + 15) & ~15) ? (unsigned)((row >> 4) * (16 * p.w_row * 2) + lane * (FK / 2)) : HV_OOB;
     }
     u32x4 preg[PMAX];
     unsigned pvo[PMAX];
@@ -94,10 +98,10 @@ __global__ __launch_bounds__(256, 2) void conv_s2t_kernel(const S2TK p) {
     const int kgc = (lane >> 4) * (FK / 4);
     auto wld = [&](int n, int widx_, int c0) __attribute__((always_inline)) {
         const unsigned vo = (ragged && c0 + kgc >= p.Cin) ? HV_OOB : wvo[n];
-        if constexpr (FK == 32) return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(wsrc, vo, (widx_ * p.Cin + c0) * 2, 0));
+        if constexpr (FK == 32) return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(wsrc, vo, (widx_ * p.Cin + c0) * wsc, 0));
         else {
             typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));
-            return __builtin_bit_cast(f16x4v, (u32x2_)__builtin_amdgcn_raw_buffer_load_b64(wsrc, vo, (widx_ * p.Cin + c0) * 2, 0));
+            return __builtin_bit_cast(f16x4v, (u32x2_)__builtin_amdgcn_raw_buffer_load_b64(wsrc, vo, (widx_ * p.Cin + c0) * wsc, 0));
         }
     };
     // LDS offsets (halfs) of this lane's pixel (tile row m, column lane & 15) at shift (0, 0) of the padded patch
@@ -198,6 +202,11 @@ int hv_conv2d_s2t(const hv_conv_desc* d, hipStream_t s) {
     k.x_bytes = (unsigned)((size_t)d->B * k.img_stride * sizeof(_Float16));
     k.w_bytes = (unsigned)((size_t)d->Cout * k.w_row * sizeof(_Float16));
     const bool ck32 = (d->Cin & 31) == 0;
+    {   // the tiled table needs whole chunks (Cin % 16 == 0; fragments of 32 channels exactly when Cin % 32 == 0, as the CK choice below)
+        static const int tiled = getenv("HV_W_TILED") ? atoi(getenv("HV_W_TILED")) : 1;
+        k.wt = (tiled && d->w_f16_tiled && !((uintptr_t)d->w_f16_tiled & 15) && (d->Cin & 15) == 0) ? reinterpret_cast<const _Float16*>(d->w_f16_tiled) : nullptr;
+        k.wt_bytes = (unsigned)((size_t)hv_cdiv(d->Cout, 16) * 16 * k.w_row * sizeof(_Float16));
+    }
     const long long wgs8 = (long long)d->B * hv_cdiv(d->H, 8) * hv_cdiv(d->W, 16) * hv_cdiv(d->Cout, 64);
     const bool th4 = wgs8 < 512;            // small maps: 4-row tiles double the workgroups
     const int bn = d->Cout > 32 ? 64 : d->Cout > 16 ? 32 : 16;

@@ -80,6 +80,39 @@ __global__ __launch_bounds__(PREP_THREADS) void weight_prep_kernel(const hv_wpre
 
 // phase 2, grid-parallel over (chunk, layer): W/sigma written in the kernels' layouts
 // (rows/channels beyond the real extent are written as zero)
+// half index of (row, tap, k) in the MFMA-fragment order documented at hv_weight_tile_f16 (include/hvgan.h); T = fragment width (32 or 16)
+static __device__ __forceinline__ long long tiled_index(int row, int tap, int k, int taps, int K, int T) {
+    const int q = T >> 2, kk = k % T;
+    return (long long)(row >> 4) * 16 * taps * K + (long long)((tap * K + k) / T) * 16 * T + ((kk / q) * 16 + (row & 15)) * q + kk % q;
+}
+static __host__ __device__ __forceinline__ int tile_width(int K) { return (K % 32 == 0) ? 32 : (K % 16 == 0) ? 16 : 0; }
+
+extern "C" size_t hv_weight_tiled_elems(int rows, int taps, int K) {
+    if (rows <= 0 || taps <= 0 || K <= 0 || !tile_width(K)) return 0;
+    return (size_t)((rows + 15) / 16 * 16) * taps * K;
+}
+
+__global__ __launch_bounds__(256) void weight_tile_kernel(const _Float16* __restrict__ w, _Float16* __restrict__ wt, int rows, int taps, int K, int T) {
+    const long long n = (long long)((rows + 15) / 16 * 16) * taps * K;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;       // index into the padded plain table
+    if (i >= n) return;
+    const int k = (int)(i % K);
+    const long long r = i / K;
+    const int tap = (int)(r % taps), row = (int)(r / taps);
+    wt[tiled_index(row, tap, k, taps, K, T)] = row < rows ? w[i] : (_Float16)0.f;
+}
+
+extern "C" int hv_weight_tile_f16(const void* w_f16, void* w_tiled, int rows, int taps, int K, void* stream) {
+    if (!w_f16 || !w_tiled || rows <= 0 || taps <= 0 || K <= 0) return HV_ERR_ARG;
+    const int T = tile_width(K);
+    if (!T) return HV_ERR_UNSUPPORTED;
+    const long long n = (long long)((rows + 15) / 16 * 16) * taps * K;
+    hipLaunchKernelGGL(weight_tile_kernel, dim3(hv_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const _Float16*>(w_f16),
+                       reinterpret_cast<_Float16*>(w_tiled), rows, taps, K, T);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+
 __global__ __launch_bounds__(256) void weight_layout_kernel(const hv_wprep_layer* __restrict__ layers) {
     const hv_wprep_layer L = layers[blockIdx.y];
     const long long nf = (long long)L.CoutF * L.taps * L.CinP;
@@ -98,6 +131,7 @@ __global__ __launch_bounds__(256) void weight_layout_kernel(const hv_wprep_layer
             if (co < L.Cout && ci < L.Cin) val = L.w_orig[wsrc_index(L, co, ci, tap)] / sigma;
             L.w_fwd[i] = val;
             if (L.w_fwd_h) reinterpret_cast<_Float16*>(L.w_fwd_h)[i] = (_Float16)val;
+            if (L.w_fwd_t && tile_width(L.CinP)) reinterpret_cast<_Float16*>(L.w_fwd_t)[tiled_index(co, tap, ci, L.taps, L.CinP, tile_width(L.CinP))] = (_Float16)val;
         } else if (i < nf + nb) {
             i -= nf;
             const int co = (int)(i % L.CoutP);
@@ -107,6 +141,7 @@ __global__ __launch_bounds__(256) void weight_layout_kernel(const hv_wprep_layer
             if (co < L.Cout && ci < L.Cin) val = L.w_orig[wsrc_index(L, co, ci, tap)] / sigma;
             L.w_bwd[i] = val;
             if (L.w_bwd_h) reinterpret_cast<_Float16*>(L.w_bwd_h)[i] = (_Float16)val;
+            if (L.w_bwd_t && tile_width(L.CoutP)) reinterpret_cast<_Float16*>(L.w_bwd_t)[tiled_index(ci, tap, co, L.taps, L.CoutP, tile_width(L.CoutP))] = (_Float16)val;
         }
     }
 }

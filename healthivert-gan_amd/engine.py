@@ -41,6 +41,7 @@ class ConvParams:
         self.sn = u is not None
         self.transposed_src = transposed_src
         self.w_fwd = self.w_bwd = self.sigma = self.dw = None
+        self.w_fwd_t = self.w_bwd_t = None      # fp16 tables in MFMA-fragment order (None: the shape has no tiled form)
 
     def sizes(self):
         return (self.cout * self.taps * self.cin_fwd, self.cin_fwd * self.taps * self.coutP, self.coutP * self.taps * self.cin_wg)
@@ -95,6 +96,15 @@ class ParamSet:
             c.w_fwd_h = hstore[off:off + a]; off += (a + 7) // 8 * 8
             c.w_bwd_h = hstore[off:off + b]; off += (b + 7) // 8 * 8
         self._hstore = hstore
+        # the same fp16 tables in MFMA-fragment order, for the kernels that fetch filter rows straight into MFMA registers (zero-filled once:
+        # the prep kernel never writes the padding rows)
+        tsz = [(ops.tiled_elems(c.cout, c.taps, c.cin_fwd), ops.tiled_elems(c.cin_fwd, c.taps, c.coutP)) for c in self.convs]
+        tstore = torch.zeros(sum(a + b for a, b in tsz) + 8, dtype=torch.float16, device=device)
+        off = 0
+        for c, (a, b) in zip(self.convs, tsz):
+            c.w_fwd_t = tstore[off:off + a] if a else None; off += a
+            c.w_bwd_t = tstore[off:off + b] if b else None; off += b
+        self._tstore = tstore
         # flat gradients; .grad of every trainable tensor is a view into it
         ps = self.trainable()
         n = sum(p.numel() for p in ps)
@@ -107,7 +117,7 @@ class ParamSet:
             rows = []
             for c in self.convs:
                 rows.append(dict(w_orig=c.weight.data, u=c.u if c.sn else None, v=c.v if c.sn else None, sigma=c.sigma,
-                                 w_fwd=c.w_fwd, w_bwd=c.w_bwd, w_fwd_h=c.w_fwd_h, w_bwd_h=c.w_bwd_h, Cout=c.cout, Cin=c.cin, taps=c.taps, CinP=c.cin_fwd,
+                                 w_fwd=c.w_fwd, w_bwd=c.w_bwd, w_fwd_h=c.w_fwd_h, w_bwd_h=c.w_bwd_h, w_fwd_t=c.w_fwd_t, w_bwd_t=c.w_bwd_t, Cout=c.cout, Cin=c.cin, taps=c.taps, CinP=c.cin_fwd,
                                  CoutF=c.cout, CoutP=c.coutP, CinB=c.cin_fwd, sn=int(c.sn), power_iter=int(pi and c.sn),
                                  transposed_src=int(c.transposed_src)))
             self.t_prep[pi].update(rows, key, device)
@@ -149,7 +159,7 @@ class ConvNode:
     def forward(self, prec):
         p = self.p
         xin = Act(self.x.t, p.cin_fwd, self.x.coff)
-        ops.conv2d(xin, p.w_fwd, self.y, self.k, self.s, self.pad, self.d, bias=p.bias if self.use_bias else None, act=self.act, w_h=p.w_fwd_h,
+        ops.conv2d(xin, p.w_fwd, self.y, self.k, self.s, self.pad, self.d, bias=p.bias if self.use_bias else None, act=self.act, w_h=p.w_fwd_h, w_t=p.w_fwd_t,
                    in_shift=self.shift, transposed=self.transposed, precision=prec, cout=p.cout)
 
 
@@ -258,16 +268,16 @@ def conv_backward(node, book, prec, dbias_accumulate=False, wgrad_accumulate=Fal
     if node.need_dx and node.transposed:
         gx = book.twin(node.x)
         gx = Act(gx.t, p.cin_fwd, gx.coff)
-        ops.conv2d(gfull, p.w_bwd, gx, node.k, node.s, node.pad, node.d, transposed=False, accumulate=int(book.mark(gx)), precision=prec, w_h=p.w_bwd_h)
+        ops.conv2d(gfull, p.w_bwd, gx, node.k, node.s, node.pad, node.d, transposed=False, accumulate=int(book.mark(gx)), precision=prec, w_h=p.w_bwd_h, w_t=p.w_bwd_t)
     elif node.need_dx:
         gx = book.twin(node.x)
         gx = Act(gx.t, p.cin_fwd, gx.coff)
         if node.shift:
             full = tmp_full
-            ops.conv2d(gfull, p.w_bwd, full, node.k, node.s, node.pad, node.d, transposed=True, precision=prec, w_h=p.w_bwd_h)
+            ops.conv2d(gfull, p.w_bwd, full, node.k, node.s, node.pad, node.d, transposed=True, precision=prec, w_h=p.w_bwd_h, w_t=p.w_bwd_t)
             ops.copy_channels(full, gx, mode=3, accumulate=book.mark(gx))
         else:
-            ops.conv2d(gfull, p.w_bwd, gx, node.k, node.s, node.pad, node.d, transposed=True, accumulate=int(book.mark(gx)), w_h=p.w_bwd_h,
+            ops.conv2d(gfull, p.w_bwd, gx, node.k, node.s, node.pad, node.d, transposed=True, accumulate=int(book.mark(gx)), w_h=p.w_bwd_h, w_t=p.w_bwd_t,
                        precision=prec, mul=(Act(node.x.t, p.cin_fwd, node.x.coff), mul_x) if mul_x else None)
 
 

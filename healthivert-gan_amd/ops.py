@@ -145,7 +145,7 @@ def conv_out_size(n, k, stride, pad, dil):
 
 
 def conv2d(x, w, y, k, stride=1, pad=0, dil=1, bias=None, act='none', transposed=False, in_shift=0, alpha=1.0,
-           accumulate=0, ch_scale=None, w_bstride=0, ch_scale_bstride=0, precision=None, cin=None, cout=None, w_h=None, mul=None):
+           accumulate=0, ch_scale=None, w_bstride=0, ch_scale_bstride=0, precision=None, cin=None, cout=None, w_h=None, mul=None, w_t=None):
     """y = act(alpha*ch_scale*conv(x, w) + bias)  [* act'(m) with mul = (Act m, activation name): see hv_conv_desc.mul_src].  x,y: Act; w: prepared [CoutF][k*k][CinP] tensor (or [B][...] with
     w_bstride).  cin/cout default to the view widths (x.C consumed, y.C produced)."""
     L = _lib.get()
@@ -165,6 +165,7 @@ def conv2d(x, w, y, k, stride=1, pad=0, dil=1, bias=None, act='none', transposed
     d.Ho, d.Wo, d.y_ld, d.y_coff = y.H, y.W, y.ld, y.coff
     d.precision = precision_id(precision)
     d.w_f16 = None if w_h is None else ptr(w_h).value
+    d.w_f16_tiled = None if (w_t is None or w_h is None) else ptr(w_t).value      # w_h in MFMA-fragment order (tile_weights / hv_weight_prep)
     d.x_f16, d.y_f16 = x.f16, y.f16
     if mul is not None:
         m, mact = mul
@@ -252,6 +253,21 @@ class LayerTable:
 
     def ptr(self):
         return ptr(self.dev)
+
+
+def tiled_elems(rows, taps, K):
+    """halfs of the MFMA-fragment-ordered copy of an fp16 filter table [rows][taps][K] (0: this shape has none)."""
+    return _lib.get().size('hv_weight_tiled_elems', int(rows), int(taps), int(K))
+
+
+def tile_weights(w_h, rows, taps, K):
+    """fp16 filter table [rows][taps][K] -> its MFMA-fragment-ordered copy (hv_conv_desc.w_f16_tiled), or None when the shape has none."""
+    n = tiled_elems(rows, taps, K)
+    if not n:
+        return None
+    out = torch.empty(n, dtype=torch.float16, device=w_h.device)
+    _lib.get().call('hv_weight_tile_f16', ptr(w_h), ptr(out), int(rows), int(taps), int(K), stream())
+    return out
 
 
 def weight_prep(table, max_numel):

@@ -78,6 +78,10 @@ typedef struct {
     int precision;
     const void* w_f16;                /* optional fp16 copy of w (same layout, from hv_weight_prep): enables the
                                          halo-tiled kernel for HV_F16, dilation 1, Cin % 16 == 0, shared filters */
+    const void* w_f16_tiled;          /* optional: the same fp16 filters in MFMA-fragment order (hv_weight_prep's w_fwd_t / w_bwd_t, or
+                                         hv_weight_tile_f16; needs w_f16 too).  The kernels that fetch filter rows straight into MFMA operand
+                                         registers then read 1-KB contiguous pieces instead of 16 rows x 64 B that lie a whole filter row apart
+                                         (and on one L2 channel): 256 -> 512 4x4 PatchGAN layer 93 -> 76 us.  NULL = plain rows */
     const float* mul_src; int mul_ld, mul_coff, mul_act;
                                       /* optional epilogue factor: r *= act'(m) with m = mul_src[pixel*mul_ld + mul_coff + channel] the OUTPUT
                                          of activation mul_act at the same pixel/channel, applied after act and before accumulate == 1.
@@ -124,10 +128,21 @@ typedef struct {
     float* w_fwd;         /* [CoutF][taps][CinP]  rows >= Cout and channels >= Cin are zero */
     float* w_bwd;         /* [CinB][taps][CoutP]  or NULL */
     void* w_fwd_h; void* w_bwd_h;   /* optional fp16 copies of w_fwd / w_bwd (same layouts) or NULL */
+    void* w_fwd_t; void* w_bwd_t;   /* optional fp16 copies in MFMA-fragment order (hv_conv_desc.w_f16_tiled; layout at hv_weight_tile_f16) or NULL;
+                                       hv_weight_tiled_elems(CoutF, taps, CinP) / (CinB, taps, CoutP) halfs, zero-filled once by the caller */
     int Cout, Cin, taps, CinP, CoutF, CoutP, CinB;
     int sn, power_iter, transposed_src;
 } hv_wprep_layer;
 int hv_weight_prep(const hv_wprep_layer* d_layers, int n_layers, long long max_numel, void* stream); /* d_layers: DEVICE array; max_numel = largest w_fwd+w_bwd element count of a layer */
+
+/* MFMA-fragment order of an fp16 filter table w[rows][taps][K] (K = padded input channels; T = 32 when K % 32 == 0, 16 when K % 16 == 0, otherwise
+ * there is no tiled form): element (row, tap, k) lives at half index
+ *     (row / 16) * 16 * taps * K  +  ((tap * K + k) / T) * 16 * T  +  (((k % T) / (T/4)) * 16 + row % 16) * (T/4)  +  k % (T/4)
+ * i.e. per 16-row block one contiguous 16 x T fragment per (tap, T-channel chunk), stored so that lane l of a wave reads bytes [l*T/2, (l+1)*T/2)
+ * of it as its `v_mfma_f32_16x16x{32,16}_f16` A operand.  Rows are padded to a multiple of 16 with zeros.
+ * hv_weight_tiled_elems: halfs the tiled table takes (0: no tiled form).  hv_weight_tile_f16: plain -> tiled (writes the zero rows too). */
+size_t hv_weight_tiled_elems(int rows, int taps, int K);
+int hv_weight_tile_f16(const void* w_f16, void* w_tiled, int rows, int taps, int K, void* stream);
 
 /* Backward of the above: dw_orig = (dWsn - <dWsn, Wsn> u v^T) / sigma  (sn=1) or a layout transform (sn=0).
  * dw_ohwi is the hv_conv2d_wgrad output [Cout][taps][CinP]. */

@@ -165,6 +165,14 @@ def test_conv_halo_tiled_fp16_forward_and_dgrad(case):
     torch.cuda.synchronize()
     err = maxerr(from_act(ya), ref.detach())
     assert err <= 4e-3 * max(1.0, ref.abs().max().item()), err
+    # the same filters in MFMA-fragment order (hv_conv_desc.w_f16_tiled): same arithmetic in the same order, so the same bits
+    wt = ops.tile_weights(wf.half(), Cout, k * k, Cin)
+    assert (wt is None) == (Cin % 16 != 0)
+    if wt is not None:
+        yt = ops.Act.empty(B, Ho, Wo, Cout, dev(), dtype=torch.float16)
+        ops.conv2d(to_act(x, dtype=torch.float16), wf, yt, k, s, p, 1, bias=b.to(dev()), act=act, in_shift=shift, precision='fp16', w_h=wf.half(), w_t=wt)
+        torch.cuda.synchronize()
+        assert torch.equal(yt.t, ya.t)
     if shift or Cout % 16:
         return
     gy = torch.randn(y0.shape, generator=g)
@@ -175,6 +183,59 @@ def test_conv_halo_tiled_fp16_forward_and_dgrad(case):
     torch.cuda.synchronize()
     err = maxerr(from_act(dxa), xin.grad)
     assert err <= 4e-3 * max(1.0, xin.grad.abs().max().item()), err
+    wbt = ops.tile_weights(wb.half(), Cin, k * k, Cout)
+    dxt = ops.Act.empty(B, H, W, Cin, dev(), dtype=torch.float16)
+    ops.conv2d(to_act(gy, dtype=torch.float16), wb, dxt, k, s, p, 1, transposed=True, precision='fp16', w_h=wb.half(), w_t=wbt)
+    torch.cuda.synchronize()
+    assert torch.equal(dxt.t, dxa.t)
+
+
+@pytest.mark.parametrize('rows,taps,K', [(512, 16, 256), (20, 9, 48), (4, 25, 16), (64, 9, 36), (1, 16, 512)])
+def test_weight_table_in_mfma_fragment_order(rows, taps, K):
+    """hv_weight_tile_f16 / hv_weight_tiled_elems against the index formula documented in include/hvgan.h (rows padded to 16 with zeros;
+    no tiled form unless K % 16 == 0), and hv_weight_prep's own tiled output against the tiling of its plain fp16 output."""
+    import numpy as np
+    from hvtest import dev
+    from hvgan import ops
+    T = 32 if K % 32 == 0 else 16 if K % 16 == 0 else 0
+    n = ops.tiled_elems(rows, taps, K)
+    assert n == (0 if not T else (rows + 15) // 16 * 16 * taps * K)
+    w = torch.randn(rows, taps, K, generator=torch.Generator().manual_seed(3)).half()
+    wt = ops.tile_weights(w.to(dev()), rows, taps, K)
+    if not T:
+        assert wt is None
+        return
+    torch.cuda.synchronize()
+    r, t, k = np.meshgrid(np.arange(rows), np.arange(taps), np.arange(K), indexing='ij')
+    q = T // 4
+    idx = (r // 16) * 16 * taps * K + ((t * K + k) // T) * 16 * T + (((k % T) // q) * 16 + r % 16) * q + k % q
+    ref = np.zeros(n, dtype=np.float16)
+    ref[idx.ravel()] = w.numpy().ravel()
+    assert np.array_equal(wt.cpu().numpy(), ref)
+
+
+def test_weight_prep_writes_the_fragment_ordered_tables():
+    """hv_weight_prep's w_fwd_t / w_bwd_t are the tilings of its w_fwd_h / w_bwd_h (spectral-norm layer and plain layer)."""
+    from hvtest import dev
+    from hvgan import ops, engine
+    import torch.nn as nn
+    torch.manual_seed(5)
+    convs = []
+    for i, (cin, cout, k) in enumerate([(32, 48, 3), (16, 64, 4), (4, 16, 5)]):
+        m = nn.Conv2d(cin, cout, k).to(dev())
+        u = torch.randn(cout, device=dev()) if i == 0 else None
+        v = torch.randn(cin * k * k, device=dev()) if i == 0 else None
+        convs.append(engine.ConvParams('c%d' % i, m.weight, m.bias, cin, cout, k, u=u, v=v))
+    ps = engine.ParamSet(convs)
+    ps.prep(dev(), power_iter=True)
+    torch.cuda.synchronize()
+    for c in convs:
+        for plain, tiled, rows, K in ((c.w_fwd_h, c.w_fwd_t, c.cout, c.cin_fwd), (c.w_bwd_h, c.w_bwd_t, c.cin_fwd, c.coutP)):
+            want = ops.tile_weights(plain.contiguous(), rows, c.taps, K)
+            assert (want is None) == (tiled is None), (c.name, rows, K)
+            if want is not None:
+                torch.cuda.synchronize()
+                assert torch.equal(want, tiled), c.name
 
 
 HEAD_CASES = [   # B, H, W, Cin, k, stride, pad, transposed, act
@@ -439,5 +500,13 @@ def test_conv_stride2_data_gradient_fused_parity_classes(case):
         ops.conv2d(ga, wb, dxa, k, 2, 1, 1, transposed=True, precision='fp16', w_h=wb.half(), accumulate=1)
         torch.cuda.synchronize()
         assert maxerr(from_act(dxa), ref + x.grad) <= 8e-3 * scale
+        wbt = ops.tile_weights(wb.half(), Cin, k * k, Cout)       # fragment-ordered filters: the same bits
+        if wbt is not None:
+            d0, d1 = (ops.Act.empty(B, H, W, Cin, dev(), dtype=torch.float16) for _ in range(2))
+            ops.conv2d(ga, wb, d0, k, 2, 1, 1, transposed=True, precision='fp16', w_h=wb.half())
+            ops.conv2d(ga, wb, d1, k, 2, 1, 1, transposed=True, precision='fp16', w_h=wb.half(), w_t=wbt)
+            assert lib.get().size('hv_last_kernel_path') == 6
+            torch.cuda.synchronize()
+            assert torch.equal(d0.t, d1.t)
     finally:
         lib.get().size('hv_set_s2t_mode', prev)

@@ -29,14 +29,15 @@ def main():
     x = ops.Act(torch.randn(B, H, W, Cin, generator=g).to(dev).to(ops.storage_dtype(prec)))
     w = (torch.randn(Cout, k * k, Cin, generator=g) / (Cin * k * k) ** 0.5).to(dev)
     wh = w.half()
+    wt = ops.tile_weights(wh, Cout, k * k, Cin) if os.environ.get('HV_W_TILED', '1') != '0' else None
     y = ops.Act.empty(B, Ho, Wo, Cout, dev, dtype=ops.storage_dtype(prec))
     for _ in range(3):
-        ops.conv2d(x, w, y, k, s, p, 1, transposed=bool(tr), precision=prec, w_h=wh)
+        ops.conv2d(x, w, y, k, s, p, 1, transposed=bool(tr), precision=prec, w_h=wh, w_t=wt)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        ops.conv2d(x, w, y, k, s, p, 1, transposed=bool(tr), precision=prec, w_h=wh)
+        ops.conv2d(x, w, y, k, s, p, 1, transposed=bool(tr), precision=prec, w_h=wh, w_t=wt)
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / iters * 1e3
