@@ -98,8 +98,10 @@ __global__ __launch_bounds__(256, 2) void conv_halo2_kernel(const HaloK p) {   /
     // filters: plain rows [Cout][taps][Cin], or (p.wt) MFMA-fragment order: a fragment = 16 rows x FK channels is one contiguous piece, lane l
     // owns bytes [l * FK/2, (l+1) * FK/2) of it (include/hvgan.h, hv_weight_tile_f16).  Plain rows make a wave's fragment load 16 rows x 64 B that
     // lie a whole filter row (8 KB at 4x4x256) apart -- 16 half-used cache lines on ONE L2 channel; measured 93 -> 76 us on the 256 -> 512 layer
+    // (the launcher has put the tiled table in p.w / p.w_bytes: a select between two pointers here lands the descriptor in vector registers
+    // and every filter load in a waterfall loop)
     const bool tiledw = p.wt != nullptr;                                  // scalar
-    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(tiledw ? p.wt : p.w), 0, tiledw ? p.wt_bytes : p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.w), 0, p.w_bytes, 0x00020000);
     const int wsc = tiledw ? 32 : 2;                                      // bytes per (tap, channel) step: a 16-row fragment column vs one row
     const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
     unsigned wvo[NT];            // byte offset of this lane's filter row / k-group, without tap and chunk
@@ -274,7 +276,9 @@ static int launch2(HaloK& k, hipStream_t s, int th0 = 8, int tw0 = TW) {
     dim3 grid(tiles, hv_cdiv(k.Cout, BN));
     hv_path_note = 3;
     HV_KNAME("conv_halo2_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %d, %s>", TH, TW, BN, WM, WN, CK, BSTEP, SPAN, D, k.x_half ? "true" : "false");
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, k);
+    HaloK kk = k;       // the kernel's view: the tiled table IS its filter table (k itself stays as it is for a fallback kernel)
+    if (kk.wt) { kk.w = kk.wt; kk.w_bytes = kk.wt_bytes; }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, kk);
     HV_LAUNCH_CHECK();
     return HV_OK;
 }
@@ -298,6 +302,12 @@ int hv_halo2_launch(HaloK& k, int TW, int KH, int KW, int maxpatch, hipStream_t 
         static const int ring = getenv("HV_HALO2_RING") ? atoi(getenv("HV_HALO2_RING")) : 4;
         if (ring == 8) return wgs128 < 512 ? launch2<8, 16, 64, 1, 4, 32, 1, 4, 8>(k, s) : launch2<8, 16, 128, 1, 4, 32, 1, 4, 8>(k, s);
         if (ring == 16) return wgs128 < 512 ? launch2<8, 16, 64, 1, 4, 32, 1, 4, 16>(k, s) : launch2<8, 16, 128, 1, 4, 32, 1, 4, 8>(k, s);
+        // wave arrangement (HV_HALO2_WM: bit 0 -> 64-channel blocks as 2 x 2 waves, bit 1 -> 128-channel blocks as 2 x 2).  With 1 x 4 waves every
+        // wave reads the whole 128-pixel patch for its 16 channels: at 64-channel blocks that is 8 LDS fragment reads per 8 MFMAs, the LDS peak.
+        // Measured (512 -> 256 data gradient @31^2): 85.7 -> 80.9 us with 2 x 2; the 128-channel blocks show no difference (74.6 / 73.5 us)
+        static const int wm = getenv("HV_HALO2_WM") ? atoi(getenv("HV_HALO2_WM")) : 1;
+        if (wgs128 < 512 && (wm & 1)) return launch2<8, 16, 64, 2, 2, 32, 1, 4, 4>(k, s);
+        if (wgs128 >= 512 && (wm & 2)) return launch2<8, 16, 128, 2, 2, 32, 1, 4, 4>(k, s);
         return wgs128 < 512 ? launch2<8, 16, 64, 1, 4, 32, 1, 4, 4>(k, s) : launch2<8, 16, 128, 1, 4, 32, 1, 4, 4>(k, s);
     }
     // 4x4 stride-2 forward with a single-buffered patch (see the kernel).  Measured alone, same device: 128 -> 256 @64^2 41.8 -> 34.9 us,

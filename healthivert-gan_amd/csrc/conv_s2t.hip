@@ -58,8 +58,8 @@ __global__ __launch_bounds__(256, 2) void conv_s2t_kernel(const S2TK p) {
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const bool tiledw = p.wt != nullptr;        // scalar; layouts as in conv_halo2_kernel
-    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(tiledw ? p.wt : p.w), 0, tiledw ? p.wt_bytes : p.w_bytes, 0x00020000);
+    const bool tiledw = p.wt != nullptr;        // scalar; layouts as in conv_halo2_kernel (the host has put the tiled table in p.w / p.w_bytes)
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.w), 0, p.w_bytes, 0x00020000);
     const int wsc = tiledw ? 32 : 2;
     const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.x), 0, p.x_bytes, 0x00020000);
     unsigned wvo[NT];
@@ -206,6 +206,7 @@ int hv_conv2d_s2t(const hv_conv_desc* d, hipStream_t s) {
         static const int tiled = getenv("HV_W_TILED") ? atoi(getenv("HV_W_TILED")) : 1;
         k.wt = (tiled && d->w_f16_tiled && !((uintptr_t)d->w_f16_tiled & 15) && (d->Cin & 15) == 0) ? reinterpret_cast<const _Float16*>(d->w_f16_tiled) : nullptr;
         k.wt_bytes = (unsigned)((size_t)hv_cdiv(d->Cout, 16) * 16 * k.w_row * sizeof(_Float16));
+        if (k.wt) { k.w = k.wt; k.w_bytes = k.wt_bytes; }
     }
     const long long wgs8 = (long long)d->B * hv_cdiv(d->H, 8) * hv_cdiv(d->W, 16) * hv_cdiv(d->Cout, 64);
     const bool th4 = wgs8 < 512;            // small maps: 4-row tiles double the workgroups
