@@ -299,16 +299,20 @@ int hv_halo2_launch(HaloK& k, int TW, int KH, int KW, int maxpatch, hipStream_t 
         const long long wgs128 = (long long)k.B * hv_cdiv(k.cls[0].Hc, 8) * hv_cdiv(k.cls[0].Wc, 16) * hv_cdiv(k.Cout, 128);
         // weight-ring depth (taps in flight): vmcnt retires in order, so the first wait on a filter row issued AFTER the next chunk's patch
         // prefetch also waits for that prefetch (an HBM round trip); a deeper ring moves that wait further behind the prefetch.  HV_HALO2_RING
+        // (alone a ring of 8 is 3-4 % faster than 4; inside the step, three discriminators in flight: 11.47 vs 11.54 ms -- default stays 4)
         static const int ring = getenv("HV_HALO2_RING") ? atoi(getenv("HV_HALO2_RING")) : 4;
-        if (ring == 8) return wgs128 < 512 ? launch2<8, 16, 64, 1, 4, 32, 1, 4, 8>(k, s) : launch2<8, 16, 128, 1, 4, 32, 1, 4, 8>(k, s);
-        if (ring == 16) return wgs128 < 512 ? launch2<8, 16, 64, 1, 4, 32, 1, 4, 16>(k, s) : launch2<8, 16, 128, 1, 4, 32, 1, 4, 8>(k, s);
         // wave arrangement (HV_HALO2_WM: bit 0 -> 64-channel blocks as 2 x 2 waves, bit 1 -> 128-channel blocks as 2 x 2).  With 1 x 4 waves every
         // wave reads the whole 128-pixel patch for its 16 channels: at 64-channel blocks that is 8 LDS fragment reads per 8 MFMAs, the LDS peak.
-        // Measured (512 -> 256 data gradient @31^2): 85.7 -> 80.9 us with 2 x 2; the 128-channel blocks show no difference (74.6 / 73.5 us)
+        // Measured with fragment-ordered filters (256 -> 512 forward @32^2 / 512 -> 256 data gradient @31^2): ring 4: 74.9 / 82.2 us (2 x 2; 85.7 as
+        // 1 x 4), ring 8: 72.0 / 79.9 us, ring 16 (64-channel blocks, 1 x 4): 78.0 us; 128-channel blocks as 2 x 2: no difference
         static const int wm = getenv("HV_HALO2_WM") ? atoi(getenv("HV_HALO2_WM")) : 1;
-        if (wgs128 < 512 && (wm & 1)) return launch2<8, 16, 64, 2, 2, 32, 1, 4, 4>(k, s);
-        if (wgs128 >= 512 && (wm & 2)) return launch2<8, 16, 128, 2, 2, 32, 1, 4, 4>(k, s);
-        return wgs128 < 512 ? launch2<8, 16, 64, 1, 4, 32, 1, 4, 4>(k, s) : launch2<8, 16, 128, 1, 4, 32, 1, 4, 4>(k, s);
+        if (wgs128 < 512) {
+            if (wm & 1) return ring >= 8 ? launch2<8, 16, 64, 2, 2, 32, 1, 4, 8>(k, s) : launch2<8, 16, 64, 2, 2, 32, 1, 4, 4>(k, s);
+            if (ring == 16) return launch2<8, 16, 64, 1, 4, 32, 1, 4, 16>(k, s);
+            return ring == 8 ? launch2<8, 16, 64, 1, 4, 32, 1, 4, 8>(k, s) : launch2<8, 16, 64, 1, 4, 32, 1, 4, 4>(k, s);
+        }
+        if (wm & 2) return launch2<8, 16, 128, 2, 2, 32, 1, 4, 4>(k, s);
+        return ring >= 8 ? launch2<8, 16, 128, 1, 4, 32, 1, 4, 8>(k, s) : launch2<8, 16, 128, 1, 4, 32, 1, 4, 4>(k, s);
     }
     // 4x4 stride-2 forward with a single-buffered patch (see the kernel).  Measured alone, same device: 128 -> 256 @64^2 41.8 -> 34.9 us,
     // 64 -> 128 @128^2 47.5 -> 49.3 us: taken from 128 input channels (HV_HALO2_S2F: 0 never, 2 always)
