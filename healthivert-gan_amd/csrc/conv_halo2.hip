@@ -306,6 +306,7 @@ int hv_halo2_launch(HaloK& k, int TW, int KH, int KW, int maxpatch, hipStream_t 
         // Measured with fragment-ordered filters (256 -> 512 forward @32^2 / 512 -> 256 data gradient @31^2): ring 4: 74.9 / 82.2 us (2 x 2; 85.7 as
         // 1 x 4), ring 8: 72.0 / 79.9 us, ring 16 (64-channel blocks, 1 x 4): 78.0 us; 128-channel blocks as 2 x 2: no difference
         static const int wm = getenv("HV_HALO2_WM") ? atoi(getenv("HV_HALO2_WM")) : 1;
+        // (4x16-pixel tiles for these layers: 75.6 -> 87.3 us forward, 80.0 -> 102.9 us data gradient -- twice the filter fetches per MFMA.  Not kept)
         if (wgs128 < 512) {
             if (wm & 1) return ring >= 8 ? launch2<8, 16, 64, 2, 2, 32, 1, 4, 8>(k, s) : launch2<8, 16, 64, 2, 2, 32, 1, 4, 4>(k, s);
             if (ring == 16) return launch2<8, 16, 64, 1, 4, 32, 1, 4, 16>(k, s);
@@ -330,6 +331,18 @@ int hv_halo2_launch(HaloK& k, int TW, int KH, int KW, int maxpatch, hipStream_t 
     // data gradient of the 4x4 stride-2 layers: four output-parity classes of 2x2 taps each
     static const int m4 = getenv("HV_HALO2_S2T") ? atoi(getenv("HV_HALO2_S2T")) : 1;
     if (m4 && ntaps == 4 && KH == 4 && KW == 4 && k.bstep == 1 && k.Cin % 32 == 0 && k.Cout > 32) {
+        // Tile and wave arrangement, measured alone (HV_HALO2_T2=0: 8x16 tiles with 1 x 4 waves everywhere; 2: also the 4x16 tiles below -- inside the
+        // step the three discriminators' kernels share the GPU, the small grids are filled anyway and the 4x16 tiles' doubled filter traffic shows no
+        // gain there: 11.17 vs 11.22 ms, so only the LDS-saving 2 x 2 arrangement is on by default):
+        //   64 <- 128 @64^2 (64-channel blocks): 8x16 tiles, 2 x 2 waves 42.7 -> 36.3 us (1 x 4 waves read 8 LDS fragments per 8 MFMAs)
+        //   128 <- 256 @64^2 (512 workgroups of 8x16 pixels): 4x16 tiles 36.3 -> 27.7 us (64-channel blocks as 2 x 2: 28.5 us); 256 <- 512 @32^2: 47.3 -> 32.0 us
+        static const int t2 = getenv("HV_HALO2_T2") ? atoi(getenv("HV_HALO2_T2")) : 1;
+        if (TW == 16 && t2) {
+            if (k.Cout <= 64) return launch2<8, 16, 64, 2, 2, 32, 1, 2, 4>(k, s);
+            long long wgs = 0;
+            for (int c = 0; c < k.ncls; ++c) wgs += (long long)k.B * hv_cdiv(k.cls[c].Hc, 8) * hv_cdiv(k.cls[c].Wc, 16) * hv_cdiv(k.Cout, 128);
+            if (wgs < 1024 && t2 == 2) return launch2<4, 16, 128, 1, 4, 32, 1, 2, 4>(k, s, 8, 16);
+        }
         if (TW == 32) return k.Cout <= 64 ? launch2<8, 32, 64, 1, 4, 32, 1, 2, 4>(k, s) : launch2<8, 32, 128, 1, 4, 32, 1, 2, 4>(k, s);
         return k.Cout <= 64 ? launch2<8, 16, 64, 1, 4, 32, 1, 2, 4>(k, s) : launch2<8, 16, 128, 1, 4, 32, 1, 2, 4>(k, s);
     }
@@ -356,6 +369,13 @@ int hv_halo2_launch(HaloK& k, int TW, int KH, int KW, int maxpatch, hipStream_t 
         }
         if (cls == 1) return launch2<8, 16, 16, 4, 1, 32, 1, 3, 3>(k, s);
         if (cls == 2) return launch2<8, 16, 32, 2, 2, 32, 1, 3, 3>(k, s);
+        // 64-channel blocks: 4x16-pixel tiles (HV_HALO2_T3=0: 8x16; 2: 8x16 with 2 x 2 waves; 3: 4x16 with 2 x 2).  Alone: 64 -> 64 @64^2 15.0 -> 12.9 us (2: 14.6,
+        // 3: 13.6), 128 -> 64 @64^2 20.7 -> 18.2 us, 32 -> 64 @128^2 33.4 -> 29.9 us: these layers are latency chains of 1-4 chunks, more and smaller
+        // workgroups overlap them better
+        static const int t3 = getenv("HV_HALO2_T3") ? atoi(getenv("HV_HALO2_T3")) : 1;
+        if (cls == 4 && t3 == 1) return launch2<4, 16, 64, 1, 4, 32, 1, 3, 3>(k, s, 8, 16);
+        if (cls == 4 && t3 == 2) return launch2<8, 16, 64, 2, 2, 32, 1, 3, 3>(k, s);
+        if (cls == 4 && t3 == 3) return launch2<4, 16, 64, 2, 2, 32, 1, 3, 3>(k, s, 8, 16);
         if (cls == 4) return launch2<8, 16, 64, 1, 4, 32, 1, 3, 3>(k, s);
         return launch2<8, 16, 128, 1, 4, 32, 1, 3, 3>(k, s);
     }
