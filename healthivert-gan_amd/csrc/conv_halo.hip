@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloK p) {
 #pragma unroll
         for (int nn = 0; nn < NT; ++nn) {
             const int ch0 = n_base + wn * (BN / WN) + nn * 16 + (lane >> 4) * 4;
-            hv_conv_epilogue4(epi, acc[nn][m], ch0, yp, mp);
+            hv_conv_epilogue4<true>(epi, acc[nn][m], ch0, yp, mp);
         }
     }
 }

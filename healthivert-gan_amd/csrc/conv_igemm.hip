@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
 #pragma unroll
         for (int nn = 0; nn < NT; ++nn) {
             const int ch0 = n_base + wn * TNW + nn * 16 + (lane >> 4) * 4;
-            hv_conv_epilogue4(epi, acc[nn][m], ch0, yp, mp);
+            hv_conv_epilogue4<!std::is_same<T, float>::value>(epi, acc[nn][m], ch0, yp, mp);       // fp16 operands: hardware exp2 / rcp activations
         }
     }
 }

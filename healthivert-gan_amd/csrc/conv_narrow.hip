@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void stem5_mfma_kernel(const Stem5K p) {
                               (_Float16)xv[j][1].x, (_Float16)xv[j][1].y, (_Float16)xv[j][1].z, (_Float16)xv[j][1].w};
             acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[j], xb, acc, 0, 0, 0);
         }
-        if (ox < p.W) hv_conv_epilogue4(p.epi, acc, g * 4, hv_eptr(p.y, ((long long)row * p.W + ox) * p.y_ld + p.y_coff, p.epi.y_half), nullptr);
+        if (ox < p.W) hv_conv_epilogue4<true>(p.epi, acc, g * 4, hv_eptr(p.y, ((long long)row * p.W + ox) * p.y_ld + p.y_coff, p.epi.y_half), nullptr);
     }
 }
 

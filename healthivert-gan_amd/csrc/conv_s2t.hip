@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void conv_s2t_kernel(const S2TK p) {
         void* yp = hv_eptr(p.y, opix * p.y_ld + p.y_coff, p.y_half);
         const void* mp = p.mul_src ? hv_eptr(p.mul_src, opix * p.mul_ld + p.mul_coff, p.mul_half) : nullptr;
 #pragma unroll
-        for (int n = 0; n < NT; ++n) hv_conv_epilogue4(epi, acc[n][m], n_base + n * 16 + (lane >> 4) * 4, yp, mp);
+        for (int n = 0; n < NT; ++n) hv_conv_epilogue4<true>(epi, acc[n][m], n_base + n * 16 + (lane >> 4) * 4, yp, mp);
     }
 }
 

@@ -26,19 +26,39 @@ def main():
             Ho, Wo = H * 2, W * 2
     else:
         Ho, Wo = ops.conv_out_size(H, k, s, p, 1), ops.conv_out_size(W, k, s, p, 1)
-    x = ops.Act(torch.randn(B, H, W, Cin, generator=g).to(dev).to(ops.storage_dtype(prec)))
+    rot = int(os.environ.get('ROTATE', '1'))       # ROTATE=n: n input/output buffer pairs visited in turn (n * size > L2 + MALL: cold reads, as inside a step)
+    xs = [ops.Act(torch.randn(B, H, W, Cin, generator=g).to(dev).to(ops.storage_dtype(prec))) for _ in range(rot)]
+    x = xs[0]
     w = (torch.randn(Cout, k * k, Cin, generator=g) / (Cin * k * k) ** 0.5).to(dev)
     wh = w.half()
     wt = ops.tile_weights(wh, Cout, k * k, Cin) if os.environ.get('HV_W_TILED', '1') != '0' else None
-    y = ops.Act.empty(B, Ho, Wo, Cout, dev, dtype=ops.storage_dtype(prec))
-    for _ in range(3):
-        ops.conv2d(x, w, y, k, s, p, 1, transposed=bool(tr), precision=prec, w_h=wh, w_t=wt)
+    ys = [ops.Act.empty(B, Ho, Wo, Cout, dev, dtype=ops.storage_dtype(prec)) for _ in range(rot)]
+    y = ys[0]
+    act = os.environ.get('ACT', 'none')            # epilogue as inside the step: ACT=elu BIAS=1 (forward), MUL=elu ACC=1 (data gradient with act' factor)
+    bias = torch.randn(Cout, generator=g).to(dev) if os.environ.get('BIAS') == '1' else None
+    mul = (ops.Act(torch.randn(B, Ho, Wo, Cout, generator=g).to(dev).to(ops.storage_dtype(prec))), os.environ['MUL']) if os.environ.get('MUL') else None
+    acc = int(os.environ.get('ACC', '0'))
+    run = lambda i: ops.conv2d(xs[i % rot], w, ys[i % rot], k, s, p, 1, transposed=bool(tr), precision=prec, w_h=wh, w_t=wt, act=act, bias=bias,
+                               mul=mul, accumulate=acc)
+    for i in range(3):
+        run(i)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        ops.conv2d(x, w, y, k, s, p, 1, transposed=bool(tr), precision=prec, w_h=wh, w_t=wt)
-    e1.record()
+    if os.environ.get('HV_BENCH_GRAPH', '1') != '0':      # replayed from a hipGraph: the host's launch rate is out of the measurement
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            for i in range(iters):
+                run(i)
+        gr.replay()
+        torch.cuda.synchronize()
+        e0.record()
+        gr.replay()
+        e1.record()
+    else:
+        e0.record()
+        for i in range(iters):
+            run(i)
+        e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / iters * 1e3
     taps = k * k if not tr else max(1, k * k // (s * s))
