@@ -234,3 +234,27 @@ def test_infer_prepare_slice_matches_reference_network_inputs():
         assert torch.equal(torch.from_numpy(p['mask'])[None], R.to_tensor_u8(exp['in_mask'], False)), name
         assert torch.equal(torch.from_numpy(p['cam'])[None], R.to_tensor_u8(exp['in_cam'], False)), name
         assert torch.equal(torch.from_numpy(p['ori_ct'])[None], q['ori_ct']), name
+
+
+def test_no_kernel_spills_to_scratch():
+    """The build records every kernel's registers / scratch bytes / occupancy from the compiler's resource-usage remarks
+    (healthivert-gan_amd/csrc/build/*.resources.json).  A kernel that spills to scratch memory still computes the right numbers, only several
+    times slower (a two-bodied activation epilogue once put the accumulators of every conv kernel in scratch and doubled the step time
+    with all parity tests green), so spills are a test failure.  Allowed: instantiations no dispatch path takes."""
+    import glob
+    import json
+    not_dispatched = (
+        '_Z16conv_halo_kernelILi8ELi32ELi128ELi2ELi2ELi2ELi16ELi11ELb1EEv5HaloK',     # 8x32 tiles x 128 channels: the dispatch takes 8x16 tiles there
+        '_Z16conv_halo_kernelILi8ELi32ELi128ELi2ELi2ELi2ELi32ELi11ELb1EEv5HaloK',
+        '_Z17conv_halo2_kernelILi8ELi32ELi128ELi1ELi4ELi32ELi1ELi2ELi4ELb1EEv5HaloK',  # stride-2 data-gradient classes run on 8x16 tiles (HV_HALO_TW16X)
+        '_Z15wgrad_tr_kernelILi4ELi2ELi64ELi32EEv4WTrK',                               # stride 2 with 64-channel blocks is planned with BC = 16
+    )
+    files = glob.glob(os.path.join(ROOT, 'healthivert-gan_amd', 'csrc', 'build', '*.resources.json'))
+    if not files:
+        pytest.skip('no resource records: the library was not built here by healthivert-gan_amd/csrc/build.py')
+    seen = 0
+    for f in files:
+        for name, r in json.load(open(f)).items():
+            seen += 1
+            assert not r.get('scratch') or name in not_dispatched, (os.path.basename(f), name, r)
+    assert seen > 200
