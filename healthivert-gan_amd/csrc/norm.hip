@@ -103,28 +103,29 @@ __global__ __launch_bounds__(256) void norm_reduce_kernel(const NormK k, double*
         for (int e = 0; e < V; ++e) {
             if (MODE == 0) { a[e] += xs[e]; b[e] += (double)xs[e] * xs[e]; }
             else {
-                const float gq = ds[e] * norm_act_bwd(ys[e], k.act, k.post_sigmoid);
+                const float gq = (k.act != HV_ACT_NONE || k.post_sigmoid) ? ds[e] * norm_act_bwd(ys[e], k.act, k.post_sigmoid) : ds[e];
                 a[e] += gq;
                 b[e] += (double)gq * ((xs[e] - mean[e]) * rstd[e]);
             }
         }
     };
+    // act == none (the incoming gradient already carries act'(y): the consumer's data-gradient epilogue applied it): y is not read at all
+    const bool need_y = MODE == 1 && (k.act != HV_ACT_NONE || k.post_sigmoid);
     long long r = r0 + rp;
     for (; r + rstep < r1; r += 2 * rstep) {     // two independent rows per iteration
-        float x0[V], x1[V], d0[V], d1[V], y0[V], y1[V];
+        float x0[V], x1[V], d0[V], d1[V], y0[V] = {}, y1[V] = {};
         ldv(k.x, r, k.x_ld, k.x_coff, x0);
         ldv(k.x, r + rstep, k.x_ld, k.x_coff, x1);
-        if (MODE == 1) {
-            ldv(k.dy, r, k.dy_ld, k.dy_coff, d0); ldv(k.dy, r + rstep, k.dy_ld, k.dy_coff, d1);
-            ldv(k.y, r, k.y_ld, k.y_coff, y0); ldv(k.y, r + rstep, k.y_ld, k.y_coff, y1);
-        }
+        if (MODE == 1) { ldv(k.dy, r, k.dy_ld, k.dy_coff, d0); ldv(k.dy, r + rstep, k.dy_ld, k.dy_coff, d1); }
+        if (need_y) { ldv(k.y, r, k.y_ld, k.y_coff, y0); ldv(k.y, r + rstep, k.y_ld, k.y_coff, y1); }
         acc1(x0, d0, y0);
         acc1(x1, d1, y1);
     }
     if (r < r1) {
-        float x0[V], d0[V], y0[V];
+        float x0[V], d0[V], y0[V] = {};
         ldv(k.x, r, k.x_ld, k.x_coff, x0);
-        if (MODE == 1) { ldv(k.dy, r, k.dy_ld, k.dy_coff, d0); ldv(k.y, r, k.y_ld, k.y_coff, y0); }
+        if (MODE == 1) ldv(k.dy, r, k.dy_ld, k.dy_coff, d0);
+        if (need_y) ldv(k.y, r, k.y_ld, k.y_coff, y0);
         acc1(x0, d0, y0);
     }
 #pragma unroll
@@ -303,6 +304,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const NormK k, cons
         sa[e] = ab[(long long)g * 2 * C + c0 + e];
         sb[e] = ab[(long long)g * 2 * C + C + c0 + e];
     }
+    const bool need_y = k.act != HV_ACT_NONE || k.post_sigmoid;      // (see norm_reduce_kernel)
     const long long base = (long long)g * k.R, n = (long long)k.R << lc, st = (long long)gridDim.x * 256;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += st) {
         const long long r = base + (i >> lc);
@@ -310,18 +312,18 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const NormK k, cons
         if (VEC) {
             const float4 xv = hv_ld4(k.x, r * k.x_ld + k.x_coff + c0, H);
             const float4 dv = hv_ld4(k.dy, r * k.dy_ld + k.dy_coff + c0, H);
-            const float4 yv = hv_ld4(k.y, r * k.y_ld + k.y_coff + c0, H);
+            const float4 yv = need_y ? hv_ld4(k.y, r * k.y_ld + k.y_coff + c0, H) : make_float4(0.f, 0.f, 0.f, 0.f);
             xs[0] = xv.x; xs[V > 1 ? 1 : 0] = xv.y; xs[V > 2 ? 2 : 0] = xv.z; xs[V > 3 ? 3 : 0] = xv.w;
             ds[0] = dv.x; ds[V > 1 ? 1 : 0] = dv.y; ds[V > 2 ? 2 : 0] = dv.z; ds[V > 3 ? 3 : 0] = dv.w;
             ys[0] = yv.x; ys[V > 1 ? 1 : 0] = yv.y; ys[V > 2 ? 2 : 0] = yv.z; ys[V > 3 ? 3 : 0] = yv.w;
         } else {
             xs[0] = hv_ld1(k.x, r * k.x_ld + k.x_coff + c0, H);
             ds[0] = hv_ld1(k.dy, r * k.dy_ld + k.dy_coff + c0, H);
-            ys[0] = hv_ld1(k.y, r * k.y_ld + k.y_coff + c0, H);
+            ys[0] = need_y ? hv_ld1(k.y, r * k.y_ld + k.y_coff + c0, H) : 0.f;
         }
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-            const float gq = ds[e] * norm_act_bwd(ys[e], k.act, k.post_sigmoid);
+            const float gq = need_y ? ds[e] * norm_act_bwd(ys[e], k.act, k.post_sigmoid) : ds[e];
             float v;
             if (batch_stats) {
                 const float xhat = (xs[e] - mean[e]) * rstd[e];
@@ -337,11 +339,13 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const NormK k, cons
 }
 
 extern "C" int hv_norm_act_backward(const hv_norm_bwd_desc* d, void* stream) {
-    if (!d || !d->dy || !d->y || !d->x || !d->dx || !d->stats || d->B <= 0 || d->HW <= 0 || d->C <= 0) return HV_ERR_ARG;
+    if (!d || !d->dy || !d->x || !d->dx || !d->stats || d->B <= 0 || d->HW <= 0 || d->C <= 0) return HV_ERR_ARG;
+    const bool need_y = d->act != HV_ACT_NONE || d->post_sigmoid;     // act none: dy is the gradient at the normalisation's output, y is not read
+    if (need_y && !d->y) return HV_ERR_ARG;
     if (d->norm != HV_NORM_BATCH && d->norm != HV_NORM_INSTANCE) return HV_ERR_ARG;
     if (!n_shape_ok(d->C)) return HV_ERR_UNSUPPORTED;
-    const bool aligned = !((d->x_ld | d->x_coff | d->y_ld | d->y_coff | d->dy_ld | d->dy_coff | d->dx_ld | d->dx_coff) & 3) &&
-                         !(((uintptr_t)d->x | (uintptr_t)d->y | (uintptr_t)d->dy | (uintptr_t)d->dx) & 15);
+    const bool aligned = !((d->x_ld | d->x_coff | d->dy_ld | d->dy_coff | d->dx_ld | d->dx_coff) & 3) && (!need_y || !((d->y_ld | d->y_coff) & 3)) &&
+                         !(((uintptr_t)d->x | (uintptr_t)(need_y ? d->y : nullptr) | (uintptr_t)d->dy | (uintptr_t)d->dx) & 15);
     const bool vec = n_vec_ok(d->C) && aligned;
     if (!vec && !(n_pow2(d->C) && d->C <= 256)) return HV_ERR_UNSUPPORTED;
     NormPlan pl = norm_plan(d->B, d->HW, d->C, d->norm, d->groups, vec);

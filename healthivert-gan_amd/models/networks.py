@@ -8,6 +8,7 @@ Generators/discriminators the hot path never instantiates (ResNet/U-Net G, pixel
 out of scope and raise NotImplementedError.
 """
 import functools
+import os
 
 import torch
 import torch.nn as nn
@@ -142,6 +143,9 @@ class GANLoss(nn.Module):
 
 
 # ================================================================================================ PatchGAN
+FUSE_NORM_ACT = os.environ.get('HV_FUSE_NORM_ACT', '1') != '0'     # A/B knob, see _DiscPlan-based run_backward
+
+
 class _DiscPlan:
     def __init__(self, net, B, H, W, device):
         self.B, self.H, self.W = B, H, W
@@ -313,9 +317,13 @@ class NLayerDiscriminator(nn.Module):
         P._in_id = id(P.x_in.t)
         book.twins[P._in_id] = P.dx.view(B, P.H, P.W, 1)
         fuse0 = E.FUSE_ACT and len(P.layers) > 1 and P.layers[0]['node'].act != 'none' and not P.layers[1]['node'].shift
+        # a normalised layer's LeakyReLU' rides in the data-gradient epilogue of the layer that consumes its output z (one consumer), so the
+        # normalisation's backward starts from the gradient at ITS output and never reads z (HV_FUSE_NORM_ACT=0: the norm kernels apply it)
+        fuse_n = E.FUSE_ACT and FUSE_NORM_ACT
         for li in range(len(P.layers) - 1, -1, -1):
             ent = P.layers[li]
             L, node = ent['spec'], ent['node']
+            prev_normed = li >= 2 and not P.layers[li - 1]['spec']['last'] and not node.shift       # layer li - 1 has a norm + LeakyReLU
             if li == 0:
                 x4 = None
                 if param_grads:
@@ -329,13 +337,13 @@ class NLayerDiscriminator(nn.Module):
                 gy, gz = book.twin(ent['y']), book.twin(ent['z'])
                 bn = self.norm_kind == 'batch'
                 ops.norm_act_backward(gy, ent['y'], ent['z'], gz, self.norm_kind, P.training, ent['stats'],
-                                      gamma=nm.weight if bn else None, act='lrelu',
+                                      gamma=nm.weight if bn else None, act='none' if fuse_n else 'lrelu',
                                       dgamma=nm.weight.grad if (bn and param_grads) else None,
                                       dbeta=nm.bias.grad if (bn and param_grads) else None, param_accumulate=accumulate,
                                       groups=P.groups)
             # the stem's output has one consumer (layer 1): its LeakyReLU' rides in layer 1's data-gradient epilogue
             E.conv_backward(node, book, prec, dbias_accumulate=accumulate, wgrad_accumulate=accumulate, wgrad=param_grads,
-                            mul_x=P.layers[0]['node'].act if (li == 1 and fuse0) else None)
+                            mul_x=P.layers[0]['node'].act if (li == 1 and fuse0) else ('lrelu' if (prev_normed and fuse_n) else None))
         if need_dx:
             g = book.twin(P.x_in)
             return g.t.view(B, 1, P.H, P.W)

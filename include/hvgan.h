@@ -176,7 +176,9 @@ typedef struct {
 } hv_norm_desc;
 size_t hv_norm_workspace_bytes(int B, int HW, int C);
 int hv_norm_act_forward(const hv_norm_desc* d, void* stream);
-/* dx from dy (gradient wrt the activation output y); dgamma/dbeta (+)= when non-NULL. */
+/* dx from dy (gradient wrt the activation output y); dgamma/dbeta (+)= when non-NULL.  act == HV_ACT_NONE (and no post_sigmoid): dy is the
+ * gradient at the normalisation's own output -- the consumer's data-gradient epilogue already applied act'(y) through hv_conv_desc.mul_src -- and
+ * y is never read (may be NULL): one tensor less in both passes. */
 typedef struct {
     const void* dy; const void* y; const void* x; void* dx; int B, HW, C;     /* fp32, or fp16 elements when f16 != 0 (all four alike) */
     int dy_ld, dy_coff, y_ld, y_coff, x_ld, x_coff, dx_ld, dx_coff;

@@ -1,7 +1,11 @@
 """GPU idle analysis of a rocprofv3 --kernel-trace CSV: busy union, concurrency, largest idle gaps by (prev -> next) kernel.
 
-    python tools/trace_gaps.py <kernel_trace.csv> [tail_fraction=0.25]
+    python tools/trace_gaps.py <kernel_trace.csv> [tail_fraction=0.25 | dense:<ms>]
+
+dense:<ms> analyses the <ms>-long window that holds the most kernel launches -- in a bench.py trace that is the graph-replayed timed
+region (the eager survey / roofline steps around it launch far fewer kernels per millisecond).
 """
+import bisect
 import collections
 import csv
 import statistics
@@ -10,11 +14,21 @@ import sys
 
 def main():
     rows = list(csv.DictReader(open(sys.argv[1])))
-    frac = float(sys.argv[2]) if len(sys.argv) > 2 else 0.25
+    arg = sys.argv[2] if len(sys.argv) > 2 else '0.25'
     iv = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'][:60]) for r in rows)
     t0, t1 = iv[0][0], max(e for _, e, _ in iv)
-    lo = t0 + (t1 - t0) * (1 - frac)
-    sel = [x for x in iv if x[0] >= lo]
+    if arg.startswith('dense:'):
+        w = float(arg[6:]) * 1e6
+        starts = [x[0] for x in iv]
+        best, lo = -1, t0
+        for i, s0 in enumerate(starts):
+            n = bisect.bisect_left(starts, s0 + w) - i
+            if n > best:
+                best, lo = n, s0
+        sel = [x for x in iv if lo <= x[0] < lo + w]
+    else:
+        lo = t0 + (t1 - t0) * (1 - float(arg))
+        sel = [x for x in iv if x[0] >= lo]
     span = max(e for _, e, _ in sel) - sel[0][0]
     busy, tot = 0, sum(e - s for s, e, _ in sel)
     cs, ce = sel[0][0], sel[0][1]
