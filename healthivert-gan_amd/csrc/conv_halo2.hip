@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo2_kernel(const HaloK p) {   /
     constexpr int FK = CK == 16 ? 16 : 32;                          // channels per MFMA step
     constexpr int KS = CK / FK;                                     // MFMA steps per chunk
     // patch row stride (halfs): 96 B (CK 32) and 160 B (CK 64) rows are conflict-free for unit-step b128 reads; 80 B for stride 2
-    constexpr int LDP = CK + ((CK >= 32 && BSTEP == 1) ? 16 : 8);
+    constexpr int LDP = CK + ((CK == 32 && BSTEP == 1) ? 16 : 8);     // 96-B / 48-B / 144-B pixel rows: 16 lanes x 16 B land on distinct banks
     constexpr int MT = BM / WM / 16, NT = BN / WN / 16, GX = TW / 16;
     constexpr int PHM = (TH - 1) * BSTEP + SPAN, PWM = (TW - 1) * BSTEP + SPAN;   // patch extent
     // staging items: 4 channels of a patch pixel (16 B of fp32 / 8 B of fp16), or 8 channels (16 B) of an fp16 tensor with whole 32-channel chunks
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo2_kernel(const HaloK p) {   /
 
 template <int TH, int TW, int BN, int WM, int WN, int CK, int BSTEP, int SPAN, int D>
 static int launch2(HaloK& k, hipStream_t s, int th0 = 8, int tw0 = TW) {
-    constexpr int LDP = CK + ((CK >= 32 && BSTEP == 1) ? 16 : 8);
+    constexpr int LDP = CK + ((CK == 32 && BSTEP == 1) ? 16 : 8);     // 96-B / 48-B / 144-B pixel rows: 16 lanes x 16 B land on distinct banks
     constexpr int PHM = (TH - 1) * BSTEP + SPAN, PWM = (TW - 1) * BSTEP + SPAN;
     int tiles = 0;
     for (int c = 0; c < k.ncls; ++c) {
@@ -373,6 +373,7 @@ int hv_halo2_launch(HaloK& k, int TW, int KH, int KW, int maxpatch, hipStream_t 
         // 3: 13.6), 128 -> 64 @64^2 20.7 -> 18.2 us, 32 -> 64 @128^2 33.4 -> 29.9 us: these layers are latency chains of 1-4 chunks, more and smaller
         // workgroups overlap them better
         static const int t3 = getenv("HV_HALO2_T3") ? atoi(getenv("HV_HALO2_T3")) : 1;
+        // (64-channel chunks -- the whole K of a 64-channel layer behind one barrier -- measured 16.9 -> 21.6 us: not kept)
         if (cls == 4 && t3 == 1) return launch2<4, 16, 64, 1, 4, 32, 1, 3, 3>(k, s, 8, 16);
         if (cls == 4 && t3 == 2) return launch2<8, 16, 64, 2, 2, 32, 1, 3, 3>(k, s);
         if (cls == 4 && t3 == 3) return launch2<4, 16, 64, 2, 2, 32, 1, 3, 3>(k, s, 8, 16);

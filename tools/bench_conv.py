@@ -63,7 +63,13 @@ def main():
     us = e0.elapsed_time(e1) / iters * 1e3
     taps = k * k if not tr else max(1, k * k // (s * s))
     fl = 2.0 * B * Ho * Wo * Cout * taps * Cin
-    print('%s B%d %dx%d Cin%d->Cout%d k%d s%d %s: %.1f us  %.1f TF' % ('T' if tr else 'F', B, H, W, Cin, Cout, k, s, prec, us, fl / us / 1e6))
+    chk = ''
+    if os.environ.get('CHECK') == '1':      # digest of the first output buffer: A/B runs of two kernel variants must print the same
+        run(0)
+        torch.cuda.synchronize()
+        t = ys[0].t.float()
+        chk = '  sum %.6e  abs %.6e' % (t.double().sum().item(), t.double().abs().sum().item())
+    print('%s B%d %dx%d Cin%d->Cout%d k%d s%d %s: %.1f us  %.1f TF%s' % ('T' if tr else 'F', B, H, W, Cin, Cout, k, s, prec, us, fl / us / 1e6, chk))
 
 
 if __name__ == '__main__':
