@@ -33,7 +33,8 @@ __global__ __launch_bounds__(PREP_THREADS) void weight_prep_kernel(const hv_wpre
             float ss = 0.f;
             for (int k = tid; k < K; k += PREP_THREADS) {
                 float t = 0.f;
-                for (int co = 0; co < L.Cout; ++co) t += W[(long long)co * K + k] * u_s[co];
+#pragma unroll 8
+                for (int co = 0; co < L.Cout; ++co) t += W[(long long)co * K + k] * u_s[co];      // (same summation order; the loads run ahead)
                 v_s[k] = t;
                 ss += t * t;
             }
@@ -47,6 +48,7 @@ __global__ __launch_bounds__(PREP_THREADS) void weight_prep_kernel(const hv_wpre
         float ss = 0.f;
         for (int co = wave; co < L.Cout; co += nwave) {
             float t = 0.f;
+#pragma unroll 8
             for (int k = lane; k < K; k += 64) t += W[(long long)co * K + k] * v_s[k];
             t = hv_wave_sum(t);
             if (lane == 0) {
@@ -78,8 +80,7 @@ __global__ __launch_bounds__(PREP_THREADS) void weight_prep_kernel(const hv_wpre
     if (tid == 0 && L.sigma) L.sigma[0] = sigma;
 }
 
-// phase 2, grid-parallel over (chunk, layer): W/sigma written in the kernels' layouts
-// (rows/channels beyond the real extent are written as zero)
+// phase 2, grid-parallel over the layers' work items: W/sigma written in the kernels' layouts (rows/channels beyond the real extent are zero)
 // half index of (row, tap, k) in the MFMA-fragment order documented at hv_weight_tile_f16 (include/hvgan.h); T = fragment width (32 or 16)
 static __device__ __forceinline__ long long tiled_index(int row, int tap, int k, int taps, int K, int T) {
     const int q = T >> 2, kk = k % T;
@@ -113,35 +114,73 @@ extern "C" int hv_weight_tile_f16(const void* w_f16, void* w_tiled, int rows, in
     return HV_OK;
 }
 
-__global__ __launch_bounds__(256) void weight_layout_kernel(const hv_wprep_layer* __restrict__ layers) {
+// Forward tables.  A work item = (filter co, chunk of input channels): its source elements w_orig[co][ci0 .. ci0+cn)[taps] are ONE contiguous piece,
+// read coalesced into LDS and written out tap-major.  (Indexing the threads by the destination and gathering the source -- the first version --
+// read 36 .. 64-byte-strided floats: every XCD's L2 fetched the same lines again, 178 MB of fabric reads per launch for 16 MB of weights.)
+// conv_transpose sources (transposed_src) have no such contiguity and keep the gather.
+__global__ __launch_bounds__(256) void weight_layout_fwd_kernel(const hv_wprep_layer* __restrict__ layers) {
     const hv_wprep_layer L = layers[blockIdx.y];
-    const long long nf = (long long)L.CoutF * L.taps * L.CinP;
-    const long long nb = L.w_bwd ? (long long)L.CinB * L.taps * L.CoutP : 0;
-    const long long base = (long long)blockIdx.x * 1024;
-    if (base >= nf + nb) return;
+    __shared__ float sh[4096 + 256];
+    const int taps = L.taps, ldt = taps + 1;                                    // LDS rows [ci][taps + 1]: the tap-major read-out is conflict-free
+    int CC = 256;
+    while (CC > 1 && CC * ldt > 4096 + 256) CC >>= 1;                           // 256 channels up to 4x4 filters, 128 for 5x5, 64 for 7x7 ...
+    const int nch = (L.CinP + CC - 1) / CC;
+    const long long work = (long long)L.CoutF * nch;
     const float sigma = L.sigma[0];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        long long i = base + k * 256 + threadIdx.x;
-        if (i < nf) {
-            const int ci = (int)(i % L.CinP);
-            const long long r = i / L.CinP;
-            const int tap = (int)(r % L.taps), co = (int)(r / L.taps);
-            float val = 0.f;
-            if (co < L.Cout && ci < L.Cin) val = L.w_orig[wsrc_index(L, co, ci, tap)] / sigma;
+    const int T = L.w_fwd_t ? tile_width(L.CinP) : 0;
+    for (long long w = blockIdx.x; w < work; w += gridDim.x) {
+        const int co = (int)(w / nch), ci0 = (int)(w % nch) * CC;
+        const int cn = min(CC, L.CinP - ci0);                                   // destination channels of this item
+        const int cs = (co < L.Cout) ? max(0, min(cn, L.Cin - ci0)) : 0;        // ... of which real
+        __syncthreads();
+        if (!L.transposed_src) {
+            const float* src = L.w_orig + ((long long)co * L.Cin + ci0) * taps;
+            for (int i = threadIdx.x; i < cs * taps; i += 256) sh[(i / taps) * ldt + i % taps] = src[i];
+        } else {
+            for (int i = threadIdx.x; i < cs * taps; i += 256) sh[(i / taps) * ldt + i % taps] = L.w_orig[wsrc_index(L, co, ci0 + i / taps, i % taps)];
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < cn * taps; j += 256) {
+            const int tap = j / cn, cil = j - tap * cn;
+            const float val = cil < cs ? sh[cil * ldt + tap] / sigma : 0.f;
+            const long long i = ((long long)co * taps + tap) * L.CinP + ci0 + cil;
             L.w_fwd[i] = val;
             if (L.w_fwd_h) reinterpret_cast<_Float16*>(L.w_fwd_h)[i] = (_Float16)val;
-            if (L.w_fwd_t && tile_width(L.CinP)) reinterpret_cast<_Float16*>(L.w_fwd_t)[tiled_index(co, tap, ci, L.taps, L.CinP, tile_width(L.CinP))] = (_Float16)val;
-        } else if (i < nf + nb) {
-            i -= nf;
-            const int co = (int)(i % L.CoutP);
-            const long long r = i / L.CoutP;
-            const int tap = (int)(r % L.taps), ci = (int)(r / L.taps);
-            float val = 0.f;
-            if (co < L.Cout && ci < L.Cin) val = L.w_orig[wsrc_index(L, co, ci, tap)] / sigma;
+            if (T) reinterpret_cast<_Float16*>(L.w_fwd_t)[tiled_index(co, tap, ci0 + cil, taps, L.CinP, T)] = (_Float16)val;
+        }
+    }
+}
+
+// Data-gradient tables: w_bwd[ci][tap][co] = w_fwd[co][tap][ci], a 32 x 32 LDS tile transpose per tap (both sides 128-byte rows); runs after the
+// forward tables of the same call (stream order).
+__global__ __launch_bounds__(256) void weight_layout_bwd_kernel(const hv_wprep_layer* __restrict__ layers) {
+    const hv_wprep_layer L = layers[blockIdx.y];
+    if (!L.w_bwd) return;
+    __shared__ float sh[32][33];
+    const int taps = L.taps, tco = (L.CoutP + 31) / 32, tci = (L.CinB + 31) / 32;
+    const long long work = (long long)taps * tco * tci;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int T = L.w_bwd_t ? tile_width(L.CoutP) : 0;
+    for (long long w = blockIdx.x; w < work; w += gridDim.x) {
+        const int tap = (int)(w % taps);
+        const long long r = w / taps;
+        const int co0 = (int)(r % tco) * 32, ci0 = (int)(r / tco) * 32;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int co = co0 + ty + 8 * k, ci = ci0 + tx;
+            sh[ty + 8 * k][tx] = (co < L.Cout && co < L.CoutF && ci < L.Cin && ci < L.CinP) ? L.w_fwd[((long long)co * taps + tap) * L.CinP + ci] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ci = ci0 + ty + 8 * k, co = co0 + tx;
+            if (ci >= L.CinB || co >= L.CoutP) continue;
+            const float val = sh[tx][ty + 8 * k];
+            const long long i = ((long long)ci * taps + tap) * L.CoutP + co;
             L.w_bwd[i] = val;
             if (L.w_bwd_h) reinterpret_cast<_Float16*>(L.w_bwd_h)[i] = (_Float16)val;
-            if (L.w_bwd_t && tile_width(L.CoutP)) reinterpret_cast<_Float16*>(L.w_bwd_t)[tiled_index(ci, tap, co, L.taps, L.CoutP, tile_width(L.CoutP))] = (_Float16)val;
+            if (T) reinterpret_cast<_Float16*>(L.w_bwd_t)[tiled_index(ci, tap, co, taps, L.CoutP, T)] = (_Float16)val;
         }
     }
 }
@@ -150,7 +189,11 @@ extern "C" int hv_weight_prep(const hv_wprep_layer* d_layers, int n_layers, long
     if (!d_layers || n_layers <= 0 || max_numel <= 0) return HV_ERR_ARG;
     hipLaunchKernelGGL(weight_prep_kernel, dim3(n_layers), dim3(PREP_THREADS), 0, (hipStream_t)stream, d_layers);
     HV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(weight_layout_kernel, dim3(hv_cdiv(max_numel, 1024), n_layers), dim3(256), 0, (hipStream_t)stream, d_layers);
+    // grid-stride over the layers' work items (the host knows only the largest table, not every layer's shape)
+    const int gx = hv_cdiv(max_numel, 2048) < 1 ? 1 : hv_cdiv(max_numel, 2048);
+    hipLaunchKernelGGL(weight_layout_fwd_kernel, dim3(gx, n_layers), dim3(256), 0, (hipStream_t)stream, d_layers);
+    HV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(weight_layout_bwd_kernel, dim3(gx, n_layers), dim3(256), 0, (hipStream_t)stream, d_layers);
     HV_LAUNCH_CHECK();
     return HV_OK;
 }
@@ -161,8 +204,28 @@ __global__ __launch_bounds__(PREP_THREADS) void weight_prep_bwd_dot_kernel(const
     if (!L.sn) return;
     __shared__ float red[20];
     const long long n = (long long)L.Cout * L.taps * L.CinP;
-    float dot = 0.f;
-    for (long long i = threadIdx.x; i < n; i += PREP_THREADS) dot += L.dw_ohwi[i] * L.w_fwd[i];
+    // one workgroup per layer: four independent 16-byte streams per lane keep the loads in flight (a scalar loop was a chain of load latencies:
+    // 63 us for the generator's 147 K-element layers); n is a multiple of 4 (padded channel counts) and both tables are 16-byte aligned
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+    const long long n4 = n / 4;
+    const float4* ga = reinterpret_cast<const float4*>(L.dw_ohwi);
+    const float4* wa = reinterpret_cast<const float4*>(L.w_fwd);
+    const bool vec = !(n & 3) && !(((uintptr_t)L.dw_ohwi | (uintptr_t)L.w_fwd) & 15);
+    if (vec) {
+        long long i = threadIdx.x;
+        for (; i + 3 * PREP_THREADS < n4; i += 4 * PREP_THREADS) {
+            const float4 a0 = ga[i], a1 = ga[i + PREP_THREADS], a2 = ga[i + 2 * PREP_THREADS], a3 = ga[i + 3 * PREP_THREADS];
+            const float4 b0 = wa[i], b1 = wa[i + PREP_THREADS], b2 = wa[i + 2 * PREP_THREADS], b3 = wa[i + 3 * PREP_THREADS];
+            d0 += a0.x * b0.x + a0.y * b0.y + a0.z * b0.z + a0.w * b0.w;
+            d1 += a1.x * b1.x + a1.y * b1.y + a1.z * b1.z + a1.w * b1.w;
+            d2 += a2.x * b2.x + a2.y * b2.y + a2.z * b2.z + a2.w * b2.w;
+            d3 += a3.x * b3.x + a3.y * b3.y + a3.z * b3.z + a3.w * b3.w;
+        }
+        for (; i < n4; i += PREP_THREADS) { const float4 a0 = ga[i], b0 = wa[i]; d0 += a0.x * b0.x + a0.y * b0.y + a0.z * b0.z + a0.w * b0.w; }
+    } else {
+        for (long long i = threadIdx.x; i < n; i += PREP_THREADS) d0 += L.dw_ohwi[i] * L.w_fwd[i];
+    }
+    float dot = (d0 + d1) + (d2 + d3);
     dot = hv_block_sum(dot, red);
     if (threadIdx.x == 0) const_cast<float*>(L.sigma)[1] = dot;
 }
