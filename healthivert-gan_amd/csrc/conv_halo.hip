@@ -274,7 +274,22 @@ static int dispatch_halo_bn(HaloK& k, int maxpatch, hipStream_t s) {
 // Called by hv_conv2d when the fp16 weight copy is present and the shape qualifies; returns HV_ERR_UNSUPPORTED to
 // fall back to the gather kernel.
 int hv_conv2d_halo(const hv_conv_desc* d, const void* w_f16, hipStream_t s) {
-    if (d->dil != 1 || (d->Cin & 3) || d->w_bstride || d->ch_scale || d->KH * d->KW > 25 || d->stride > 2) return HV_ERR_UNSUPPORTED;
+    // Dilation d in {2, 4, 8} of a same-size 3x3 layer: the output pixels of one residue class (y mod d, x mod d) only read input pixels of the same
+    // class, so the layer is d*d independent UNDILATED 3x3 convolutions on sub-grids of H/d x W/d pixels whose neighbours lie d pixels apart.
+    // conv_halo2_kernel tiles a sub-grid like an image (pixel step d in its address arithmetic only); the gather kernel these layers used to take
+    // re-reads the input per tap through L2 (64 -> 64 channels @64^2: 29 us against 13-20 us; d = 16 leaves 4x4-pixel sub-grids: gather kernel)
+    const int dil = d->dil;
+    hv_conv_desc dd;
+    const int Hf = d->H, Wf = d->W, Hof = d->Ho, Wof = d->Wo;
+    if (dil != 1) {
+        static const int dilated = getenv("HV_HALO_DILATED") ? atoi(getenv("HV_HALO_DILATED")) : 1;      // A/B knob
+        if (!dilated || (dil != 2 && dil != 4 && dil != 8) || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != dil || d->in_shift) return HV_ERR_UNSUPPORTED;
+        if (d->H % dil || d->W % dil || d->Ho != d->H || d->Wo != d->W || (d->Cin & 31) || d->Cout > 64 || d->Cout <= 32) return HV_ERR_UNSUPPORTED;
+        dd = *d;
+        dd.H /= dil; dd.W /= dil; dd.Ho /= dil; dd.Wo /= dil; dd.pad = 1; dd.dil = 1;
+        d = &dd;          // from here on: the undilated convolution of ONE sub-grid; the image-level strides are put back below
+    }
+    if ((d->Cin & 3) || d->w_bstride || d->ch_scale || d->KH * d->KW > 25 || d->stride > 2) return HV_ERR_UNSUPPORTED;
     if ((d->x_ld & 3) || (d->x_coff & 3) || ((uintptr_t)d->x & 15) || ((uintptr_t)w_f16 & 15)) return HV_ERR_UNSUPPORTED;
     if (!d->x_f16) return HV_ERR_UNSUPPORTED;      // halo-tiled kernels are built for fp16 storage (an fp32 input with fp16 operands: gather kernel)
     HaloK k;
@@ -362,6 +377,13 @@ int hv_conv2d_halo(const hv_conv_desc* d, const void* w_f16, hipStream_t s) {
         if (C.PH * C.PW > maxpatch) maxpatch = C.PH * C.PW;
     }
     const bool ck32 = (d->Cin & 31) == 0;
+    k.dil = dil;
+    if (dil != 1) {     // image-level addressing of the sub-grid convolution (bounds stay those of the sub-grid: k.Hl, k.Wl, cls[].Hc / Wc)
+        k.Wp = Wf; k.img_stride = Hf * Wf * d->x_ld; k.Ho = Hof; k.Wo = Wof; k.ostep = dil;
+        if ((long long)d->B * k.img_stride >= (1ll << 29)) return HV_ERR_UNSUPPORTED;
+        k.x_bytes = (unsigned)((size_t)d->B * k.img_stride * xs);
+        return hv_halo2_launch(k, TW, d->KH, d->KW, maxpatch, s);      // (conv_halo_kernel has no pixel step)
+    }
     static const bool halo2 = !(getenv("HV_HALO2") && atoi(getenv("HV_HALO2")) == 0);   // A/B knob
     if (halo2) {   // weights-in-registers form where an instantiation exists
         const int rc = hv_halo2_launch(k, TW, d->KH, d->KW, maxpatch, s);

@@ -67,6 +67,13 @@ __global__ __launch_bounds__(256, 2) void conv_halo2_kernel(const HaloK p) {   /
     const HaloCls& C = p.cls[ci];
     const int PW = C.PW, npatch = C.PH * C.PW;
     int t = (int)blockIdx.x - C.t0;
+    // dilation: residue class (ry, rx) of this workgroup's sub-grid (see hv_conv2d_halo); all classes have the same tiling
+    int ry = 0, rx = 0;
+    if (p.dil > 1) {
+        const int per = C.tiles * p.B, rid = t / per;
+        t -= rid * per;
+        ry = rid / p.dil; rx = rid - ry * p.dil;
+    }
     const int n_img = t / C.tiles;
     t -= n_img * C.tiles;
     const int tile_y = t / C.tiles_x, tile_x = t - tile_y * C.tiles_x;
@@ -125,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo2_kernel(const HaloK p) {   /
         const bool in = e < npatch * PV;
         plo[i] = in ? pix * LDP + c4 * IW : -1;
         pvo[i] = (in && (unsigned)hi < (unsigned)p.Hl && (unsigned)wi < (unsigned)p.Wl)
-                     ? xbase + (unsigned)(((hi >> p.in_shift) * p.Wp + (wi >> p.in_shift)) * p.x_ld + c4 * IW) * XS::B : HV_OOB;
+                     ? xbase + (unsigned)((((ry + hi * p.dil) >> p.in_shift) * p.Wp + ((rx + wi * p.dil) >> p.in_shift)) * p.x_ld + c4 * IW) * XS::B : HV_OOB;
     }
     // ragged channel counts (Cin % CK != 0, CK == 16 only: a lane's 4 channels are all inside or all outside): lanes beyond Cin
     // read zeros through the range check, for the patch and for the filter rows alike
@@ -230,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo2_kernel(const HaloK p) {   /
         const int g = wm * MT + m, ty = g / GX, tx = (g % GX) * 16 + (lane & 15);
         const int i = i0 + ty, j = j0 + tx;
         if (i >= C.Hc || j >= C.Wc) continue;
-        const int ho = C.ph + i * p.ostep, wo = C.pw + j * p.ostep;
+        const int ho = C.ph + ry + i * p.ostep, wo = C.pw + rx + j * p.ostep;
         const long long opix = (long long)(n_img * p.Ho + ho) * p.Wo + wo;
         void* yp = hv_eptr(p.y, opix * p.y_ld + p.y_coff, p.y_half);
         const void* mp = p.mul_src ? hv_eptr(p.mul_src, opix * p.mul_ld + p.mul_coff, p.mul_half) : nullptr;
@@ -273,7 +280,7 @@ static int launch2(HaloK& k, hipStream_t s, int th0 = 8, int tw0 = TW) {
     }
     // (an XCD-aware 1-D launch that runs a pixel tile's channel blocks back to back on one XCD -- the input patch fetched into one L2 -- measured
     // 98.9 vs 100.5 us on the 256 -> 512 layer and no step-level gain: this kernel is not bound by the patch fetch.  Not kept.)
-    dim3 grid(tiles, hv_cdiv(k.Cout, BN));
+    dim3 grid(tiles * (k.dil > 1 ? k.dil * k.dil : 1), hv_cdiv(k.Cout, BN));
     hv_path_note = 3;
     HV_KNAME("conv_halo2_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %d, %s>", TH, TW, BN, WM, WN, CK, BSTEP, SPAN, D, k.x_half ? "true" : "false");
     HaloK kk = k;       // the kernel's view: the tiled table IS its filter table (k itself stays as it is for a fallback kernel)

@@ -190,6 +190,43 @@ def test_conv_halo_tiled_fp16_forward_and_dgrad(case):
     assert torch.equal(dxt.t, dxa.t)
 
 
+@pytest.mark.parametrize('dil,H,W', [(2, 32, 32), (4, 32, 48), (8, 64, 64), (2, 20, 12)])
+def test_conv_dilated_3x3_as_residue_subgrids(dil, H, W):
+    """Dilated same-size 3x3 layers (the generators' d = 2, 4, 8 blocks): conv_halo2_kernel runs the d*d residue classes as undilated
+    convolutions on sub-grids with pixel step d -- forward (bias + ELU) and data gradient (with the act' factor) against torch CPU fp32,
+    plain and fragment-ordered filters bit-identical, and the kernel actually taken (path 3)."""
+    from hvtest import to_act, from_act, ohwi, ohwi_T, dev, maxerr
+    from hvgan import ops, lib
+    B, Cin, Cout, k = 2, 64, 64, 3
+    g = torch.Generator().manual_seed(11 + dil)
+    x = torch.randn(B, Cin, H, W, generator=g, requires_grad=True)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    y0 = F.conv2d(x, w, b, stride=1, padding=dil, dilation=dil)
+    ref = F.elu(y0)
+    wf = ohwi(w)
+    ya, yt = (ops.Act.empty(B, H, W, Cout, dev(), dtype=torch.float16) for _ in range(2))
+    ops.conv2d(to_act(x.detach(), dtype=torch.float16), wf, ya, k, 1, dil, dil, bias=b.to(dev()), act='elu', precision='fp16', w_h=wf.half())
+    assert lib.get().size('hv_last_kernel_path') == 3
+    ops.conv2d(to_act(x.detach(), dtype=torch.float16), wf, yt, k, 1, dil, dil, bias=b.to(dev()), act='elu', precision='fp16', w_h=wf.half(),
+               w_t=ops.tile_weights(wf.half(), Cout, k * k, Cin))
+    torch.cuda.synchronize()
+    assert maxerr(from_act(ya), ref.detach()) <= 4e-3 * max(1.0, ref.abs().max().item())
+    assert torch.equal(ya.t, yt.t)
+    gy = torch.randn(y0.shape, generator=g)
+    y0.backward(gy)
+    m = torch.randn(B, Cin, H, W, generator=g)
+    fac = torch.where(m > 0, torch.ones_like(m), m + 1.0)          # ELU' from the producer's output
+    wb = ohwi_T(w)
+    dxa = ops.Act.empty(B, H, W, Cin, dev(), dtype=torch.float16)
+    ops.conv2d(to_act(gy, dtype=torch.float16), wb, dxa, k, 1, dil, dil, transposed=True, precision='fp16', w_h=wb.half(),
+               mul=(to_act(m, dtype=torch.float16), 'elu'))
+    assert lib.get().size('hv_last_kernel_path') == 3
+    torch.cuda.synchronize()
+    want = x.grad * fac
+    assert maxerr(from_act(dxa), want) <= 4e-3 * max(1.0, want.abs().max().item())
+
+
 @pytest.mark.parametrize('rows,taps,K', [(512, 16, 256), (20, 9, 48), (4, 25, 16), (64, 9, 36), (1, 16, 512)])
 def test_weight_table_in_mfma_fragment_order(rows, taps, K):
     """hv_weight_tile_f16 / hv_weight_tiled_elems against the index formula documented in include/hvgan.h (rows padded to 16 with zeros;

@@ -25,7 +25,8 @@ def main():
         if s == 2 and k in (3, 4):      # data gradient of a pad-1 stride-2 conv on an even-sized map
             Ho, Wo = H * 2, W * 2
     else:
-        Ho, Wo = ops.conv_out_size(H, k, s, p, 1), ops.conv_out_size(W, k, s, p, 1)
+        dil_ = int(os.environ.get('DIL', '1'))
+        Ho, Wo = ops.conv_out_size(H, k, s, p, dil_), ops.conv_out_size(W, k, s, p, dil_)
     rot = int(os.environ.get('ROTATE', '1'))       # ROTATE=n: n input/output buffer pairs visited in turn (n * size > L2 + MALL: cold reads, as inside a step)
     xs = [ops.Act(torch.randn(B, H, W, Cin, generator=g).to(dev).to(ops.storage_dtype(prec))) for _ in range(rot)]
     x = xs[0]
@@ -34,11 +35,12 @@ def main():
     wt = ops.tile_weights(wh, Cout, k * k, Cin) if os.environ.get('HV_W_TILED', '1') != '0' else None
     ys = [ops.Act.empty(B, Ho, Wo, Cout, dev, dtype=ops.storage_dtype(prec)) for _ in range(rot)]
     y = ys[0]
+    dil = int(os.environ.get('DIL', '1'))          # DIL=d: dilation (pass pad = d for a same-size 3x3 layer)
     act = os.environ.get('ACT', 'none')            # epilogue as inside the step: ACT=elu BIAS=1 (forward), MUL=elu ACC=1 (data gradient with act' factor)
     bias = torch.randn(Cout, generator=g).to(dev) if os.environ.get('BIAS') == '1' else None
     mul = (ops.Act(torch.randn(B, Ho, Wo, Cout, generator=g).to(dev).to(ops.storage_dtype(prec))), os.environ['MUL']) if os.environ.get('MUL') else None
     acc = int(os.environ.get('ACC', '0'))
-    run = lambda i: ops.conv2d(xs[i % rot], w, ys[i % rot], k, s, p, 1, transposed=bool(tr), precision=prec, w_h=wh, w_t=wt, act=act, bias=bias,
+    run = lambda i: ops.conv2d(xs[i % rot], w, ys[i % rot], k, s, p, dil, transposed=bool(tr), precision=prec, w_h=wh, w_t=wt, act=act, bias=bias,
                                mul=mul, accumulate=acc)
     for i in range(3):
         run(i)
