@@ -258,3 +258,15 @@ def test_no_kernel_spills_to_scratch():
             seen += 1
             assert not r.get('scratch') or name in not_dispatched, (os.path.basename(f), name, r)
     assert seen > 200
+
+
+def test_tiled_filter_table_size_is_host_arithmetic():
+    """hv_weight_tiled_elems (include/hvgan.h: rows padded to 16, a tiled form only when K % 16 == 0) is plain host code: callable without a GPU."""
+    import hvgan  # noqa: F401
+    from hvgan import lib
+    if not lib.available():
+        pytest.skip('libhvgan.so not built')
+    L = lib.get()
+    for rows, taps, K, want in ((512, 16, 256, 512 * 16 * 256), (20, 9, 48, 32 * 9 * 48), (4, 25, 16, 16 * 25 * 16), (64, 9, 36, 0), (1, 16, 512, 16 * 16 * 512),
+                                (0, 9, 32, 0), (8, 0, 32, 0)):
+        assert L.size('hv_weight_tiled_elems', rows, taps, K) == want, (rows, taps, K)
