@@ -1,0 +1,183 @@
+// Batched "NT" GEMM on fp16 MFMA for the contextual-attention contractions, and the fold (col2im) of 4x4 stride-2 patches.
+//
+//   C[b][m][n] = alpha * colscale[b][n] * sum_k A[b][m][k] * B[b][n][k]          (A, B, C fp32 in memory; products on v_mfma_f32_16x16x32_f16)
+//
+// The five big contractions of ContextualAttention (reference models/inpaint_networks.py:327-381 and their autograd) are plain matrix products
+// between per-sample matrices that already exist with the contraction index contiguous:
+//   scores   S[p][l]    = rnorm[l] * <wp[p][:], wp[l][:]>             K = 9C    (the conv input's 3x3 patches ARE the filters: f == b)
+//   paste    O[p][(t,c)] = <A[p][:], rawT[(c,t)][:]>                  K = L     then fold: out[y,x,c] = 1/4 sum of the 4 taps that reach (y, x)
+//            (rows of rawT taken in (tap, channel) order -- b_split -- so that the fold reads whole channel rows)
+//   dA       dA[p][l]   = 1/4 <dOraw[p][:], raw[l][:]>                K = 16C
+//   d raw    dR[l][(t,c)] = <AT[l][:], dOrawT[(c,t)][:]>              K = L     then the same fold into the feature-map gradient
+//   d wp     dwp[p][k]  = <Gs[p][:], wpT[k][:]>                       K = L
+// Run as convolutions with per-sample filters they went through the gather kernel: every 64-pixel tile re-read its sample's whole filter matrix (the
+// paste moved 1.1 GB per launch for 140 MB of operands, 164 us).  Here a workgroup owns a 128 x 128 tile of C, both operand tiles go global ->
+// registers (fp32, 16 B per lane, converted) -> LDS as fp16 with 80-byte rows (a 16-lane group's 16-byte fragment reads hit every bank once), double
+// buffered with one barrier per 32-deep k-step, and all tiles of one sample run on one XCD (its L2 fetches the sample's operands once).
+#include <stdlib.h>
+
+#include "hv_common.h"
+
+struct BgemmK {
+    const float* A; const float* B; float* C; const float* colscale;
+    long long sA, sB, sC, sS;      // batch strides (elements)
+    int lda, ldb, ldc;
+    int M, N, K, batch;
+    int tiles_m, tiles_n, swizzle;
+    int b_split;                   // > 0: logical row n = t * b_split + c of B is stored as row c * (N / b_split) + t (see hv_bgemm_nt)
+    float alpha;
+};
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void bgemm_nt_kernel(const BgemmK p) {
+    constexpr int LD = 40;                      // halfs per LDS row: 32 + 8 (80 B)
+    constexpr int AP = BM / 32, BP = BN / 32;   // staging passes: 256 threads = 32 rows x 8 float4 per pass
+    constexpr int MT = BM / 2 / 16, NT = BN / 2 / 16;
+    __shared__ __attribute__((aligned(16))) _Float16 As[2][BM * LD];
+    __shared__ __attribute__((aligned(16))) _Float16 Bs[2][BN * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    // tile -> (batch, m block, n block); with `swizzle` the 8 XCDs (round-robin over the linear workgroup id) each take whole batches
+    const int per = p.tiles_m * p.tiles_n;
+    int id = blockIdx.x, b, t;
+    if (p.swizzle) {
+        const int xcd = id & 7, slot = id >> 3;
+        b = (slot / per) * 8 + xcd;
+        t = slot % per;
+    } else {
+        b = id / per;
+        t = id % per;
+    }
+    const int m_base = (t / p.tiles_n) * BM, n_base = (t % p.tiles_n) * BN;
+    const float* A = p.A + b * p.sA;
+    const float* B = p.B + b * p.sB;
+    const int r0 = tid >> 3, k4 = (tid & 7) * 4;
+    const float* ap[AP];
+    const float* bp[BP];
+#pragma unroll
+    for (int i = 0; i < AP; ++i) ap[i] = A + (long long)min(m_base + r0 + 32 * i, p.M - 1) * p.lda + k4;      // rows beyond M / N: clamped (never stored)
+#pragma unroll
+    for (int i = 0; i < BP; ++i) {
+        int n = min(n_base + r0 + 32 * i, p.N - 1);
+        if (p.b_split) n = (n % p.b_split) * (p.N / p.b_split) + n / p.b_split;
+        bp[i] = B + (long long)n * p.ldb + k4;
+    }
+    float4 ra[AP], rb[BP];
+    auto gload = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < AP; ++i) ra[i] = *reinterpret_cast<const float4*>(ap[i] + k0);
+#pragma unroll
+        for (int i = 0; i < BP; ++i) rb[i] = *reinterpret_cast<const float4*>(bp[i] + k0);
+    };
+    auto lstore = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < AP; ++i)
+            *reinterpret_cast<f16x4*>(&As[buf][(r0 + 32 * i) * LD + k4]) = (f16x4){(_Float16)ra[i].x, (_Float16)ra[i].y, (_Float16)ra[i].z, (_Float16)ra[i].w};
+#pragma unroll
+        for (int i = 0; i < BP; ++i)
+            *reinterpret_cast<f16x4*>(&Bs[buf][(r0 + 32 * i) * LD + k4]) = (f16x4){(_Float16)rb[i].x, (_Float16)rb[i].y, (_Float16)rb[i].z, (_Float16)rb[i].w};
+    };
+    // The MFMA's first operand carries the rows of B (n), the second the rows of A (m): a lane's four accumulators are then four CONSECUTIVE n of one
+    // m -- one 16-byte store into row-major C.
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int fo = (lane & 15) * LD + (lane >> 4) * 8;      // this lane's fragment piece inside a 16-row block
+    const int nk = p.K / 32;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload((kt + 1) * 32);            // next k-step's operands fly behind this step's MFMAs
+        f16x8 fa[MT], fb[NT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) fa[m] = *reinterpret_cast<const f16x8*>(&As[buf][(wm * (BM / 2) + m * 16) * LD + fo]);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) fb[n] = *reinterpret_cast<const f16x8*>(&Bs[buf][(wn * (BN / 2) + n * 16) * LD + fo]);
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[n], fa[m], acc[n][m], 0, 0, 0);
+        if (kt + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    float* C = p.C + b * p.sC;
+    const float* cs = p.colscale ? p.colscale + b * p.sS : nullptr;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int row = m_base + wm * (BM / 2) + m * 16 + (lane & 15);
+        if (row >= p.M) continue;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int col = n_base + wn * (BN / 2) + n * 16 + (lane >> 4) * 4;
+            if (col >= p.N) continue;                       // N % 4 == 0: a lane's four columns are all inside or all outside
+            float4 v = make_float4(acc[n][m][0] * p.alpha, acc[n][m][1] * p.alpha, acc[n][m][2] * p.alpha, acc[n][m][3] * p.alpha);
+            if (cs) { const float4 s4 = *reinterpret_cast<const float4*>(cs + col); v.x *= s4.x; v.y *= s4.y; v.z *= s4.z; v.w *= s4.w; }
+            *reinterpret_cast<float4*>(C + (long long)row * p.ldc + col) = v;
+        }
+    }
+}
+
+extern "C" int hv_bgemm_nt(const float* A, int lda, long long strideA, const float* B, int ldb, long long strideB, float* C, int ldc, long long strideC,
+                           int M, int N, int K, int batch, float alpha, const float* colscale, long long strideS, int b_split, void* stream) {
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || b_split < 0 || (b_split && N % b_split)) return HV_ERR_ARG;
+    if ((K & 31) || (N & 3) || (lda & 3) || (ldb & 3) || (ldc & 3) || lda < K || ldb < K || ldc < N) return HV_ERR_UNSUPPORTED;
+    if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)colscale) & 15) return HV_ERR_UNSUPPORTED;
+    if ((strideA | strideB | strideC | strideS) & 3) return HV_ERR_UNSUPPORTED;
+    BgemmK k;
+    k.A = A; k.B = B; k.C = C; k.colscale = colscale;
+    k.sA = strideA; k.sB = strideB; k.sC = strideC; k.sS = strideS;
+    k.lda = lda; k.ldb = ldb; k.ldc = ldc; k.M = M; k.N = N; k.K = K; k.batch = batch; k.alpha = alpha; k.b_split = b_split;
+    const int BN = N % 128 == 0 ? 128 : 64;      // N = 576 (the 3x3 patch gradient): nine 64-column tiles instead of a half-empty fifth 128-column one
+    k.tiles_m = hv_cdiv(M, 128); k.tiles_n = hv_cdiv(N, BN);
+    const long long tiles = (long long)k.tiles_m * k.tiles_n * batch;
+    if (tiles >= (1ll << 31)) return HV_ERR_UNSUPPORTED;
+    static const int xcd = getenv("HV_XCD") ? atoi(getenv("HV_XCD")) : 1;
+    k.swizzle = (xcd && batch % 8 == 0) ? 1 : 0;
+    if (BN == 128) hipLaunchKernelGGL((bgemm_nt_kernel<128, 128>), dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, k);
+    else hipLaunchKernelGGL((bgemm_nt_kernel<128, 64>), dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, k);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+
+// fold (col2im) of 4x4 stride-2 pad-1 patches: src[b][p][tap][c] (p over the (H/2) x (W/2) patch grid, tap = r*4 + s) ->
+//   dst[b][y][x][c] (+)= alpha * sum over the taps (r, s) with (y + 1 - r), (x + 1 - s) even and the patch position inside the grid
+// = F.conv_transpose2d(A, raw patches, stride 2, padding 1) after the contraction over the patches, and equally the adjoint of hv_ca_raw_patches.
+__global__ __launch_bounds__(256) void ca_fold_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int W, int C, int dst_ld, float alpha,
+                                                      int accumulate, long long n) {
+    const int h = H >> 1, w = W >> 1;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        long long r = i / C;
+        const int x = (int)(r % W);
+        r /= W;
+        const int y = (int)(r % H);
+        const long long b = r / H;
+        float s = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int rr = ((y + 1) & 1) + 2 * a, py = (y + 1 - rr) >> 1;         // filter rows of this output parity
+            if ((unsigned)py >= (unsigned)h) continue;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int ss = ((x + 1) & 1) + 2 * q, px = (x + 1 - ss) >> 1;
+                if ((unsigned)px >= (unsigned)w) continue;
+                s += src[(((b * h + py) * w + px) * 16 + rr * 4 + ss) * C + c];
+            }
+        }
+        float* d = dst + ((b * H + y) * W + x) * dst_ld + c;
+        *d = accumulate ? *d + alpha * s : alpha * s;
+    }
+}
+
+extern "C" int hv_ca_fold(const float* src, float* dst, int B, int H, int W, int C, int dst_ld, float alpha, int accumulate, void* stream) {
+    if (!src || !dst || B <= 0 || H <= 0 || W <= 0 || C <= 0 || ((H | W) & 1) || dst_ld < C) return HV_ERR_ARG;
+    const long long n = (long long)B * H * W * C;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(ca_fold_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst, H, W, C, dst_ld, alpha, accumulate, n);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}

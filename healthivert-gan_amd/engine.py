@@ -327,6 +327,15 @@ def conv_backward_chain(nodes, book, prec, tmp_full=None, premultiplied_first=Fa
 
 
 # ================================================================================================ contextual attention
+CA_GEMM = os.environ.get('HV_CA_GEMM', '1') != '0'     # fp16 mode: the attention block's five contractions as batched NT GEMMs (csrc/bgemm.hip)
+
+
+def _bgemm(A, B, C, M, N, K, batch, alpha=1.0, colscale=None, b_split=0):
+    """C[b] = alpha * colscale[b] (.) A[b] @ B[b]^T over contiguous per-sample matrices A [batch][M][K], B [batch][N][K], C [batch][M][N]."""
+    _lib.get().call('hv_bgemm_nt', ptr(A), K, ctypes.c_longlong(M * K), ptr(B), K, ctypes.c_longlong(N * K), ptr(C), N, ctypes.c_longlong(M * N),
+                    M, N, K, batch, ctypes.c_float(alpha), ptr(colscale), ctypes.c_longlong(N if colscale is not None else 0), int(b_split), stream())
+
+
 class AttentionPlan:
     """ContextualAttention(ksize=3, stride=1, rate=2, fuse_k=3, softmax_scale=10, fuse=True) on an NHWC feature map
     (reference models/inpaint_networks.py:235-410)."""
@@ -373,7 +382,12 @@ class AttentionPlan:
                     self.h, self.w, ptr(self.mm_b), stream())
         else:
             L_.call('hv_ca_mask', ptr(mask_img), self.img_hw[0], self.img_hw[1], self.h, self.w, ptr(self.mm), stream())
-        ops.conv2d(self.fd, self.wp, self.S0, 3, 1, 1, 1, w_bstride=L * 9 * C, ch_scale=self.rnorm, ch_scale_bstride=L, precision=prec)
+        gemm = CA_GEMM and ops.precision_id(prec) == ops.F16 and (9 * C) % 32 == 0 and L % 32 == 0
+        self.gemm = gemm
+        if gemm:    # the 3x3 patches of the (zero-padded) map are both the conv's input columns and its filters: scores = rnorm (.) wp wp^T
+            _bgemm(self.wp, self.wp, self.S0.t, L, L, 9 * C, B, colscale=self.rnorm)
+        else:
+            ops.conv2d(self.fd, self.wp, self.S0, 3, 1, 1, 1, w_bstride=L * 9 * C, ch_scale=self.rnorm, ch_scale_bstride=L, precision=prec)
         if self.fuse:
             L_.call('hv_ca_fuse', ptr(self.S0.t), ptr(self.S1.t), B, self.h, self.w, 0, stream())
             s = self.S1
@@ -385,7 +399,13 @@ class AttentionPlan:
         else:
             L_.call('hv_ca_softmax', ptr(s.t), ptr(self.mm), ptr(self.A.t), B, L, ctypes.c_float(self.scale),
                     ptr(self.argmax) if want_argmax else None, stream())
-        ops.conv2d(self.A, self.rawT, out, 4, 2, 1, 1, transposed=True, alpha=0.25, w_bstride=C * 16 * L, precision=prec)
+        if gemm:    # paste = (A rawT^T) folded: O[p][(c, tap)], then every output pixel sums the 4 taps that reach it
+            if getattr(self, 'O', None) is None:
+                self.O = torch.zeros(B, L, 16 * C, dtype=torch.float32, device=out.t.device)
+            _bgemm(self.A.t, self.rawT, self.O, L, 16 * C, L, B, b_split=C)          # rows of rawT [c][tap] taken as (tap, c): O[p][tap][c]
+            L_.call('hv_ca_fold', ptr(self.O), ptr(out.t), B, H, W, C, out.ld, ctypes.c_float(0.25), 0, stream())
+        else:
+            ops.conv2d(self.A, self.rawT, out, 4, 2, 1, 1, transposed=True, alpha=0.25, w_bstride=C * 16 * L, precision=prec)
         if out_user is not None:
             ops.copy_channels(out, out_user, mode=0)
 
@@ -408,11 +428,21 @@ class AttentionPlan:
             self.df32 = getattr(self, 'df32', None) or Act(torch.zeros(B, H, W, C, dtype=torch.float32, device=dout.t.device))
             df_user, df, df_acc, accumulate = df, self.df32, accumulate, False
         # through the paste: dA and d(raw patches)
-        ops.conv2d(dout, self.raw, bw['dA'], 4, 2, 1, 1, alpha=0.25, w_bstride=L * 16 * C, precision=prec)
-        L_.call('hv_transpose_batched', ptr(self.A.t), ptr(bw['AT'].t), B, L, L, stream())
-        L_.call('hv_ca_raw_patches', ptr(dout.t), B, H, W, C, dout.ld, None, ptr(bw['dOrawT']), stream())
-        ops.conv2d(bw['AT'], bw['dOrawT'], df, 4, 2, 1, 1, transposed=True, alpha=0.25, w_bstride=C * 16 * L,
-                   accumulate=int(accumulate), precision=prec)
+        gemm = getattr(self, 'gemm', False) and ops.precision_id(prec) == ops.F16
+        if gemm:
+            if 'dOraw' not in bw:
+                bw['dOraw'] = torch.zeros(B, L, 16 * C, dtype=torch.float32, device=dout.t.device)
+            L_.call('hv_ca_raw_patches', ptr(dout.t), B, H, W, C, dout.ld, ptr(bw['dOraw']), ptr(bw['dOrawT']), stream())
+            _bgemm(bw['dOraw'], self.raw, bw['dA'].t, L, L, 16 * C, B, alpha=0.25)
+            L_.call('hv_transpose_batched', ptr(self.A.t), ptr(bw['AT'].t), B, L, L, stream())
+            _bgemm(bw['AT'].t, bw['dOrawT'], self.O, L, 16 * C, L, B, b_split=C)      # d(raw patches)[l][tap][c] (the forward's O buffer is free by now)
+            L_.call('hv_ca_fold', ptr(self.O), ptr(df.t), B, H, W, C, df.ld, ctypes.c_float(0.25), int(bool(accumulate)), stream())
+        else:
+            ops.conv2d(dout, self.raw, bw['dA'], 4, 2, 1, 1, alpha=0.25, w_bstride=L * 16 * C, precision=prec)
+            L_.call('hv_transpose_batched', ptr(self.A.t), ptr(bw['AT'].t), B, L, L, stream())
+            L_.call('hv_ca_raw_patches', ptr(dout.t), B, H, W, C, dout.ld, None, ptr(bw['dOrawT']), stream())
+            ops.conv2d(bw['AT'], bw['dOrawT'], df, 4, 2, 1, 1, transposed=True, alpha=0.25, w_bstride=C * 16 * L,
+                       accumulate=int(accumulate), precision=prec)
         # through softmax and score fusion
         L_.call('hv_ca_softmax_backward', ptr(bw['dA'].t), ptr(self.A.t), ptr(self.mm), ptr(bw['dS1'].t), B, L, ctypes.c_float(self.scale), stream())
         if self.fuse:
@@ -422,7 +452,10 @@ class AttentionPlan:
             ds0 = bw['dS1']
         # through the normalised patch matching (patches act as both filters and inputs)
         L_.call('hv_ca_score_backward_prep', ptr(ds0.t), ptr(self.S0.t), ptr(self.norm), ptr(self.rnorm), ptr(bw['Gs'].t), ptr(bw['coef']), B, L, stream())
-        ops.conv2d(bw['Gs'], self.wpT, bw['dwp'], 1, 1, 0, 1, w_bstride=9 * C * L, precision=prec)
+        if gemm:
+            _bgemm(bw['Gs'].t, self.wpT, bw['dwp'].t, L, 9 * C, L, B)
+        else:
+            ops.conv2d(bw['Gs'], self.wpT, bw['dwp'], 1, 1, 0, 1, w_bstride=9 * C * L, precision=prec)
         L_.call('hv_ca_patches_backward', ptr(bw['dwp'].t), ptr(self.wp), ptr(bw['coef']), ptr(df.t), B, H, W, C, df.ld, 1, stream())
         if df_user is not None:
             ops.copy_channels(df, df_user, mode=0, accumulate=bool(df_acc))

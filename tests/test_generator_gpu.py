@@ -223,3 +223,74 @@ def test_discriminator_module_api_two_forwards_then_one_backward(norm):
     with pytest.raises(RuntimeError, match='overwrote'):
         o1[0].sum().backward()
     o2[0].sum().backward()
+
+
+@pytest.mark.parametrize('M,N,K,batch,scaled,split', [(1024, 1024, 576, 8, True, 0), (1024, 576, 1024, 3, False, 0), (200, 68, 64, 2, True, 0),
+                                                      (128, 128, 32, 16, False, 0), (256, 1024, 128, 8, False, 64)])
+def test_batched_nt_gemm_against_torch(M, N, K, batch, scaled, split):
+    """hv_bgemm_nt (the fp16 mode's attention contractions): operands rounded to fp16, fp32 accumulation -- against torch on the same rounded
+    operands in fp64; ragged tile edges, the column scale, the XCD batch swizzle (batch % 8 == 0) and the plain mapping."""
+    import ctypes
+    from hvgan import lib
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(batch, M, K, generator=g)
+    Bm = torch.randn(batch, N, K, generator=g)
+    cs = (torch.rand(batch, N, generator=g) + 0.5) if scaled else None
+    C = torch.full((batch, M, N), float('nan'), device=dev)
+    Ad, Bd, csd = A.to(dev), Bm.to(dev), (cs.to(dev) if scaled else None)
+    lib.get().call('hv_bgemm_nt', lib.ptr(Ad), K, ctypes.c_longlong(M * K), lib.ptr(Bd), K, ctypes.c_longlong(N * K), lib.ptr(C), N,
+                   ctypes.c_longlong(M * N), M, N, K, batch, ctypes.c_float(0.25), lib.ptr(csd), ctypes.c_longlong(N if scaled else 0), split, lib.stream())
+    torch.cuda.synchronize()
+    Bl = Bm
+    if split:       # logical row t * split + c is stored as row c * (N / split) + t
+        Bl = Bm.view(batch, split, N // split, K).transpose(1, 2).reshape(batch, N, K)
+    ref = 0.25 * torch.bmm(A.half().double(), Bl.half().double().transpose(1, 2))
+    if scaled:
+        ref = ref * cs.double()[:, None, :]
+    err = (C.cpu().double() - ref).abs().max().item()
+    assert err <= 2e-5 * K ** 0.5 * max(1.0, ref.abs().max().item()), err        # fp32 accumulation of K exact fp16 x fp16 products
+
+
+def test_fold_of_stride2_patches_is_conv_transpose_tail():
+    """hv_ca_fold against F.fold (= the overlap-add that ends F.conv_transpose2d(stride 2, padding 1) with 4x4 filters), assign and accumulate."""
+    import ctypes
+    import torch.nn.functional as F
+    from hvgan import lib
+    dev = torch.device('cuda:0')
+    B, H, W, C = 2, 16, 24, 8
+    h, w = H // 2, W // 2
+    g = torch.Generator().manual_seed(9)
+    src = torch.randn(B, h * w, 16, C, generator=g)                      # [b][p][tap][c]
+    cols = src.permute(0, 3, 2, 1).reshape(B, C * 16, h * w)             # F.fold wants [b][c * 16 + tap][p]
+    ref = 0.25 * F.fold(cols, (H, W), kernel_size=4, stride=2, padding=1)          # (B, C, H, W)
+    dst = torch.ones(B, H, W, C, device=dev)
+    for acc in (0, 1):
+        lib.get().call('hv_ca_fold', lib.ptr(src.to(dev)), lib.ptr(dst), B, H, W, C, C, ctypes.c_float(0.25), acc, lib.stream())
+        torch.cuda.synchronize()
+        want = ref.permute(0, 2, 3, 1) * (1 + acc)
+        assert (dst.cpu() - want).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item())
+
+
+def test_g2_contextual_attention_fp16_gemm_route(monkeypatch):
+    """fp16 mode: the attention block with its contractions as batched GEMMs (engine.CA_GEMM) against the G2 fixture at the fp16 mode's tolerance and
+    against the same block with the contractions as per-sample-filter convolutions (both round their operands to fp16; only the summation order differs)."""
+    from hvgan import engine
+    from hvgan.models.inpaint_networks import ContextualAttention
+    monkeypatch.setenv('HV_PRECISION', 'fp16')
+    g = load_golden('g2_attention')
+    dev = torch.device('cuda:0')
+    outs = {}
+    for gemm in (True, False):
+        monkeypatch.setattr(engine, 'CA_GEMM', gemm)
+        ca = ContextualAttention(True, ksize=3, stride=1, rate=2, fuse_k=3, softmax_scale=10, fuse=True)
+        f = g['f'].to(dev).requires_grad_(True)
+        y, _ = ca(f, f, g['mask'].to(dev))
+        (y * g['coef'].to(dev)).sum().backward()
+        outs[gemm] = (y.detach().float().cpu(), f.grad.detach().float().cpu())
+    ys, gs = max(1.0, g['y'].abs().max().item()), max(1.0, g['grad_f'].abs().max().item())
+    for gemm in (True, False):
+        assert _err(outs[gemm][0], g['y']) <= 2e-2 * ys, (gemm, _err(outs[gemm][0], g['y']))
+        assert _err(outs[gemm][1], g['grad_f']) <= 4e-2 * gs, (gemm, _err(outs[gemm][1], g['grad_f']))
+    assert _err(outs[True][0], outs[False][0]) <= 5e-3 * ys
+    assert _err(outs[True][1], outs[False][1]) <= 1e-2 * gs
