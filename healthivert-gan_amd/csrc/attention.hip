@@ -69,8 +69,8 @@ extern "C" int hv_transpose_batched(const float* src, float* dst, int B, int R, 
 // layouts 4 bytes at a 4-KB stride: 81 / 93 us for 38 / 134 MB).  One workgroup = 64 patch positions x 64 channels of one tap:
 // rows are read (and the [l][tap][c] copy written) 16 bytes per lane along the channels, the [c][tap][l] copy is written along l from
 // the transposed tile.  KS x KS taps, stride ST, pad 1 (3x3 / 1 on the down-sampled map, 4x4 / 2 on the full map).
-template <int KS, int ST>
-__global__ __launch_bounds__(256) void ca_patch_tile_kernel(const float* __restrict__ src, float* __restrict__ lt, float* __restrict__ tl,
+template <int KS, int ST, typename OT = float>       // OT = _Float16: both copies written as fp16 (operands of the batched GEMMs only)
+__global__ __launch_bounds__(256) void ca_patch_tile_kernel(const float* __restrict__ src, OT* __restrict__ lt, OT* __restrict__ tl,
                                                             int Hs, int Ws, int w, int L, int C, int s_ld) {
     __shared__ float tile[64][65];
     constexpr int T = KS * KS;
@@ -84,7 +84,10 @@ __global__ __launch_bounds__(256) void ca_patch_tile_kernel(const float* __restr
         if (l < L && c < C) {
             const int y = ST * (l / w) + dy, x = ST * (l % w) + dx;
             if ((unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws) v = *reinterpret_cast<const float4*>(src + ((b * Hs + y) * Ws + x) * s_ld + c);
-            if (lt) *reinterpret_cast<float4*>(lt + ((b * L + l) * T + tap) * C + c) = v;
+            if (lt) {
+                if constexpr (sizeof(OT) == 2) *reinterpret_cast<f16x4*>(lt + ((b * L + l) * T + tap) * C + c) = (f16x4){(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+                else *reinterpret_cast<float4*>(lt + ((b * L + l) * T + tap) * C + c) = v;
+            }
         }
         tile[ll][(t & 15) * 4 + 0] = v.x; tile[ll][(t & 15) * 4 + 1] = v.y; tile[ll][(t & 15) * 4 + 2] = v.z; tile[ll][(t & 15) * 4 + 3] = v.w;
     }
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(256) void ca_patch_tile_kernel(const float* __restr
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int cc = (t >> 6) + 4 * k;
-        if (l0 + ll < L && c0 + cc < C) tl[((b * C + c0 + cc) * T + tap) * L + l0 + ll] = tile[ll][cc];
+        if (l0 + ll < L && c0 + cc < C) tl[((b * C + c0 + cc) * T + tap) * L + l0 + ll] = (OT)tile[ll][cc];
     }
 }
 static bool ca_tile_ok(const float* src, int C, int s_ld, const float* lt) {
@@ -132,6 +135,16 @@ extern "C" int hv_ca_raw_patches(const float* f, int B, int H, int W, int C, int
                            f, raw, rawT, H, W, W / 2, (H / 2) * (W / 2), C, f_ld);
     else
         hipLaunchKernelGGL(ca_raw_kernel, dim3(at_grid(n)), dim3(256), 0, (hipStream_t)stream, f, raw, rawT, H, W, C, f_ld, n);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+
+// the same two patch tables stored as fp16 (operands of hv_bgemm_nt only; the fp32 tables feed the per-sample-filter convolutions of the fp32 mode)
+extern "C" int hv_ca_raw_patches_f16(const float* f, int B, int H, int W, int C, int f_ld, void* raw_h, void* rawT_h, void* stream) {
+    if (!f || (!raw_h && !rawT_h) || B <= 0 || H <= 0 || W <= 0 || C <= 0 || ((H | W) & 1) || f_ld < C) return HV_ERR_ARG;
+    if (!ca_tile_ok(f, C, f_ld, (const float*)raw_h) || B > 65535 || ((uintptr_t)raw_h & 7)) return HV_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((ca_patch_tile_kernel<4, 2, _Float16>), dim3(hv_cdiv((H / 2) * (W / 2), 64), 16 * hv_cdiv(C, 64), B), dim3(256), 0, (hipStream_t)stream,
+                       f, (_Float16*)raw_h, (_Float16*)rawT_h, H, W, W / 2, (H / 2) * (W / 2), C, f_ld);
     HV_LAUNCH_CHECK();
     return HV_OK;
 }
@@ -390,7 +403,8 @@ extern "C" int hv_ca_softmax_backward(const float* dA, const float* A, const flo
 }
 
 // ---- batched transpose (32x32 LDS tiles) ----------------------------------------------------------------
-__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int C) {
+template <typename OT = float>
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, OT* __restrict__ dst, int R, int C) {
     __shared__ float t[32][33];
     const long long b = blockIdx.z;
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -398,11 +412,17 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
         if (r0 + k < R && c0 + tx < C) t[k][tx] = src[(b * R + r0 + k) * C + c0 + tx];
     __syncthreads();
     for (int k = ty; k < 32; k += 8)
-        if (c0 + k < C && r0 + tx < R) dst[(b * C + c0 + k) * R + r0 + tx] = t[tx][k];
+        if (c0 + k < C && r0 + tx < R) dst[(b * C + c0 + k) * R + r0 + tx] = (OT)t[tx][k];
 }
 extern "C" int hv_transpose_batched(const float* src, float* dst, int B, int R, int C, void* stream) {
     if (!src || !dst || B <= 0 || R <= 0 || C <= 0) return HV_ERR_ARG;
-    hipLaunchKernelGGL(transpose_kernel, dim3(hv_cdiv(C, 32), hv_cdiv(R, 32), B), dim3(256), 0, (hipStream_t)stream, src, dst, R, C);
+    hipLaunchKernelGGL(transpose_kernel<float>, dim3(hv_cdiv(C, 32), hv_cdiv(R, 32), B), dim3(256), 0, (hipStream_t)stream, src, dst, R, C);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+extern "C" int hv_transpose_batched_f16(const float* src, void* dst_h, int B, int R, int C, void* stream) {      // the transpose stored as fp16
+    if (!src || !dst_h || B <= 0 || R <= 0 || C <= 0) return HV_ERR_ARG;
+    hipLaunchKernelGGL(transpose_kernel<_Float16>, dim3(hv_cdiv(C, 32), hv_cdiv(R, 32), B), dim3(256), 0, (hipStream_t)stream, src, (_Float16*)dst_h, R, C);
     HV_LAUNCH_CHECK();
     return HV_OK;
 }

@@ -19,7 +19,7 @@
 #include "hv_common.h"
 
 struct BgemmK {
-    const float* A; const float* B; float* C; const float* colscale;
+    const void* A; const void* B; float* C; const float* colscale;     // A / B: fp32, or fp16 elements with the AH / BH instantiations
     long long sA, sB, sC, sS;      // batch strides (elements)
     int lda, ldb, ldc;
     int M, N, K, batch;
@@ -28,10 +28,56 @@ struct BgemmK {
     float alpha;
 };
 
-template <int BM, int BN>
+// one operand tile's staging: BR rows x 32 k.  fp32 source: 256 threads = 32 rows x 8 float4 per pass, converted when written to LDS;
+// fp16 source: 64 rows x 4 sixteen-byte items per pass, copied as they are
+template <int BR, bool H> struct BgStage;
+template <int BR> struct BgStage<BR, false> {
+    static constexpr int P = BR / 32;
+    const float* ptr[P];
+    float4 r[P];
+    __device__ __forceinline__ void init(const void* base, int row0, int rows, int ld, int tid, int split) {
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            int n = min(row0 + (tid >> 3) + 32 * i, rows - 1);          // rows beyond the matrix: clamped (never stored)
+            if (split) n = (n % split) * (rows / split) + n / split;
+            ptr[i] = reinterpret_cast<const float*>(base) + (long long)n * ld + (tid & 7) * 4;
+        }
+    }
+    __device__ __forceinline__ void load(int k0) {
+#pragma unroll
+        for (int i = 0; i < P; ++i) r[i] = *reinterpret_cast<const float4*>(ptr[i] + k0);
+    }
+    __device__ __forceinline__ void store(_Float16* tile, int tid) const {
+#pragma unroll
+        for (int i = 0; i < P; ++i)
+            *reinterpret_cast<f16x4*>(tile + ((tid >> 3) + 32 * i) * 40 + (tid & 7) * 4) = (f16x4){(_Float16)r[i].x, (_Float16)r[i].y, (_Float16)r[i].z, (_Float16)r[i].w};
+    }
+};
+template <int BR> struct BgStage<BR, true> {
+    static constexpr int P = BR / 64;
+    const _Float16* ptr[P];
+    hv_u32x4 r[P];
+    __device__ __forceinline__ void init(const void* base, int row0, int rows, int ld, int tid, int split) {
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            int n = min(row0 + (tid >> 2) + 64 * i, rows - 1);
+            if (split) n = (n % split) * (rows / split) + n / split;
+            ptr[i] = reinterpret_cast<const _Float16*>(base) + (long long)n * ld + (tid & 3) * 8;
+        }
+    }
+    __device__ __forceinline__ void load(int k0) {
+#pragma unroll
+        for (int i = 0; i < P; ++i) r[i] = *reinterpret_cast<const hv_u32x4*>(ptr[i] + k0);
+    }
+    __device__ __forceinline__ void store(_Float16* tile, int tid) const {
+#pragma unroll
+        for (int i = 0; i < P; ++i) *reinterpret_cast<hv_u32x4*>(tile + ((tid >> 2) + 64 * i) * 40 + (tid & 3) * 8) = r[i];
+    }
+};
+
+template <int BM, int BN, bool AH, bool BH>
 __global__ __launch_bounds__(256, 2) void bgemm_nt_kernel(const BgemmK p) {
     constexpr int LD = 40;                      // halfs per LDS row: 32 + 8 (80 B)
-    constexpr int AP = BM / 32, BP = BN / 32;   // staging passes: 256 threads = 32 rows x 8 float4 per pass
     constexpr int MT = BM / 2 / 16, NT = BN / 2 / 16;
     __shared__ __attribute__((aligned(16))) _Float16 As[2][BM * LD];
     __shared__ __attribute__((aligned(16))) _Float16 Bs[2][BN * LD];
@@ -48,34 +94,12 @@ __global__ __launch_bounds__(256, 2) void bgemm_nt_kernel(const BgemmK p) {
         t = id % per;
     }
     const int m_base = (t / p.tiles_n) * BM, n_base = (t % p.tiles_n) * BN;
-    const float* A = p.A + b * p.sA;
-    const float* B = p.B + b * p.sB;
-    const int r0 = tid >> 3, k4 = (tid & 7) * 4;
-    const float* ap[AP];
-    const float* bp[BP];
-#pragma unroll
-    for (int i = 0; i < AP; ++i) ap[i] = A + (long long)min(m_base + r0 + 32 * i, p.M - 1) * p.lda + k4;      // rows beyond M / N: clamped (never stored)
-#pragma unroll
-    for (int i = 0; i < BP; ++i) {
-        int n = min(n_base + r0 + 32 * i, p.N - 1);
-        if (p.b_split) n = (n % p.b_split) * (p.N / p.b_split) + n / p.b_split;
-        bp[i] = B + (long long)n * p.ldb + k4;
-    }
-    float4 ra[AP], rb[BP];
-    auto gload = [&](int k0) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < AP; ++i) ra[i] = *reinterpret_cast<const float4*>(ap[i] + k0);
-#pragma unroll
-        for (int i = 0; i < BP; ++i) rb[i] = *reinterpret_cast<const float4*>(bp[i] + k0);
-    };
-    auto lstore = [&](int buf) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < AP; ++i)
-            *reinterpret_cast<f16x4*>(&As[buf][(r0 + 32 * i) * LD + k4]) = (f16x4){(_Float16)ra[i].x, (_Float16)ra[i].y, (_Float16)ra[i].z, (_Float16)ra[i].w};
-#pragma unroll
-        for (int i = 0; i < BP; ++i)
-            *reinterpret_cast<f16x4*>(&Bs[buf][(r0 + 32 * i) * LD + k4]) = (f16x4){(_Float16)rb[i].x, (_Float16)rb[i].y, (_Float16)rb[i].z, (_Float16)rb[i].w};
-    };
+    BgStage<BM, AH> sa;
+    BgStage<BN, BH> sb;
+    sa.init(reinterpret_cast<const char*>(p.A) + b * p.sA * (AH ? 2 : 4), m_base, p.M, p.lda, tid, 0);
+    sb.init(reinterpret_cast<const char*>(p.B) + b * p.sB * (BH ? 2 : 4), n_base, p.N, p.ldb, tid, p.b_split);
+    auto gload = [&](int k0) __attribute__((always_inline)) { sa.load(k0); sb.load(k0); };
+    auto lstore = [&](int buf) __attribute__((always_inline)) { sa.store(As[buf], tid); sb.store(Bs[buf], tid); };
     // The MFMA's first operand carries the rows of B (n), the second the rows of A (m): a lane's four accumulators are then four CONSECUTIVE n of one
     // m -- one 16-byte store into row-major C.
     f32x4 acc[NT][MT];
@@ -120,12 +144,14 @@ __global__ __launch_bounds__(256, 2) void bgemm_nt_kernel(const BgemmK p) {
     }
 }
 
-extern "C" int hv_bgemm_nt(const float* A, int lda, long long strideA, const float* B, int ldb, long long strideB, float* C, int ldc, long long strideC,
-                           int M, int N, int K, int batch, float alpha, const float* colscale, long long strideS, int b_split, void* stream) {
+extern "C" int hv_bgemm_nt(const void* A, int a_f16, int lda, long long strideA, const void* B, int b_f16, int ldb, long long strideB, float* C, int ldc,
+                           long long strideC, int M, int N, int K, int batch, float alpha, const float* colscale, long long strideS, int b_split, void* stream) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || b_split < 0 || (b_split && N % b_split)) return HV_ERR_ARG;
-    if ((K & 31) || (N & 3) || (lda & 3) || (ldb & 3) || (ldc & 3) || lda < K || ldb < K || ldc < N) return HV_ERR_UNSUPPORTED;
+    const int va = a_f16 ? 7 : 3, vb = b_f16 ? 7 : 3;        // 16-byte items: 8 halfs / 4 floats
+    if ((K & 31) || (N & 3) || (lda & va) || (ldb & vb) || (ldc & 3) || lda < K || ldb < K || ldc < N) return HV_ERR_UNSUPPORTED;
     if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)colscale) & 15) return HV_ERR_UNSUPPORTED;
-    if ((strideA | strideB | strideC | strideS) & 3) return HV_ERR_UNSUPPORTED;
+    if ((strideA & va) || (strideB & vb) || ((strideC | strideS) & 3)) return HV_ERR_UNSUPPORTED;
+    if (a_f16 && !b_f16) return HV_ERR_UNSUPPORTED;          // (no caller: fp32 x fp32, fp32 x fp16 and fp16 x fp16 are instantiated)
     BgemmK k;
     k.A = A; k.B = B; k.C = C; k.colscale = colscale;
     k.sA = strideA; k.sB = strideB; k.sC = strideC; k.sS = strideS;
@@ -136,8 +162,17 @@ extern "C" int hv_bgemm_nt(const float* A, int lda, long long strideA, const flo
     if (tiles >= (1ll << 31)) return HV_ERR_UNSUPPORTED;
     static const int xcd = getenv("HV_XCD") ? atoi(getenv("HV_XCD")) : 1;
     k.swizzle = (xcd && batch % 8 == 0) ? 1 : 0;
-    if (BN == 128) hipLaunchKernelGGL((bgemm_nt_kernel<128, 128>), dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, k);
-    else hipLaunchKernelGGL((bgemm_nt_kernel<128, 64>), dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, k);
+    const dim3 grid((unsigned)tiles);
+    hipStream_t s = (hipStream_t)stream;
+#define HV_BG(BN_)                                                                                                       \
+    do {                                                                                                                 \
+        if (a_f16) hipLaunchKernelGGL((bgemm_nt_kernel<128, BN_, true, true>), grid, dim3(256), 0, s, k);                \
+        else if (b_f16) hipLaunchKernelGGL((bgemm_nt_kernel<128, BN_, false, true>), grid, dim3(256), 0, s, k);          \
+        else hipLaunchKernelGGL((bgemm_nt_kernel<128, BN_, false, false>), grid, dim3(256), 0, s, k);                    \
+    } while (0)
+    if (BN == 128) HV_BG(128);
+    else HV_BG(64);
+#undef HV_BG
     HV_LAUNCH_CHECK();
     return HV_OK;
 }

@@ -331,9 +331,11 @@ CA_GEMM = os.environ.get('HV_CA_GEMM', '1') != '0'     # fp16 mode: the attentio
 
 
 def _bgemm(A, B, C, M, N, K, batch, alpha=1.0, colscale=None, b_split=0):
-    """C[b] = alpha * colscale[b] (.) A[b] @ B[b]^T over contiguous per-sample matrices A [batch][M][K], B [batch][N][K], C [batch][M][N]."""
-    _lib.get().call('hv_bgemm_nt', ptr(A), K, ctypes.c_longlong(M * K), ptr(B), K, ctypes.c_longlong(N * K), ptr(C), N, ctypes.c_longlong(M * N),
-                    M, N, K, batch, ctypes.c_float(alpha), ptr(colscale), ctypes.c_longlong(N if colscale is not None else 0), int(b_split), stream())
+    """C[b] = alpha * colscale[b] (.) A[b] @ B[b]^T over contiguous per-sample matrices A [batch][M][K], B [batch][N][K] (fp32 or fp16),
+    C [batch][M][N] fp32; b_split: B's rows taken in (outer, inner = b_split) order (hv_bgemm_nt)."""
+    _lib.get().call('hv_bgemm_nt', ptr(A), int(A.dtype == torch.float16), K, ctypes.c_longlong(M * K), ptr(B), int(B.dtype == torch.float16), K,
+                    ctypes.c_longlong(N * K), ptr(C), N, ctypes.c_longlong(M * N), M, N, K, batch, ctypes.c_float(alpha), ptr(colscale),
+                    ctypes.c_longlong(N if colscale is not None else 0), int(b_split), stream())
 
 
 class AttentionPlan:
@@ -373,8 +375,21 @@ class AttentionPlan:
         if out.f16:
             self.out32 = getattr(self, 'out32', None) or Act(torch.zeros(B, H, W, C, dtype=torch.float32, device=f.t.device))
             out_user, out = out, self.out32
-        L_.call('hv_ca_patches', ptr(f.t), B, H, W, C, f.ld, ptr(self.fd.t), ptr(self.wp), ptr(self.wpT), ptr(self.norm), ptr(self.rnorm), stream())
-        L_.call('hv_ca_raw_patches', ptr(f.t), B, H, W, C, f.ld, ptr(self.raw), ptr(self.rawT), stream())
+        gemm = CA_GEMM and ops.precision_id(prec) == ops.F16 and (9 * C) % 32 == 0 and L % 32 == 0 and C % 4 == 0
+        self.gemm = gemm
+        if gemm:
+            # GEMM route: the patch tables that are only GEMM operands are stored as fp16 (half the bytes through the vector memory path, no
+            # conversion when staged); wp stays fp32 (norms, the patch gradient's coefficient term), its transpose is written as fp16
+            if getattr(self, 'raw_h', None) is None:
+                hz = lambda *s: torch.zeros(*s, dtype=torch.float16, device=f.t.device)
+                self.raw_h, self.rawT_h, self.wpT_h = hz(B, L, 16 * C), hz(B, 16 * C, L), hz(B, 9 * C, L)
+                self.O = torch.zeros(B, L, 16 * C, dtype=torch.float32, device=f.t.device)
+            L_.call('hv_ca_patches', ptr(f.t), B, H, W, C, f.ld, ptr(self.fd.t), ptr(self.wp), None, ptr(self.norm), ptr(self.rnorm), stream())
+            L_.call('hv_transpose_batched_f16', ptr(self.wp), ptr(self.wpT_h), B, L, 9 * C, stream())
+            L_.call('hv_ca_raw_patches_f16', ptr(f.t), B, H, W, C, f.ld, ptr(self.raw_h), ptr(self.rawT_h), stream())
+        else:
+            L_.call('hv_ca_patches', ptr(f.t), B, H, W, C, f.ld, ptr(self.fd.t), ptr(self.wp), ptr(self.wpT), ptr(self.norm), ptr(self.rnorm), stream())
+            L_.call('hv_ca_raw_patches', ptr(f.t), B, H, W, C, f.ld, ptr(self.raw), ptr(self.rawT), stream())
         if per_sample_mask:
             if self.mm_b is None:
                 self.mm_b = torch.zeros(B, L, dtype=torch.float32, device=self.mm.device)
@@ -382,8 +397,6 @@ class AttentionPlan:
                     self.h, self.w, ptr(self.mm_b), stream())
         else:
             L_.call('hv_ca_mask', ptr(mask_img), self.img_hw[0], self.img_hw[1], self.h, self.w, ptr(self.mm), stream())
-        gemm = CA_GEMM and ops.precision_id(prec) == ops.F16 and (9 * C) % 32 == 0 and L % 32 == 0
-        self.gemm = gemm
         if gemm:    # the 3x3 patches of the (zero-padded) map are both the conv's input columns and its filters: scores = rnorm (.) wp wp^T
             _bgemm(self.wp, self.wp, self.S0.t, L, L, 9 * C, B, colscale=self.rnorm)
         else:
@@ -400,9 +413,7 @@ class AttentionPlan:
             L_.call('hv_ca_softmax', ptr(s.t), ptr(self.mm), ptr(self.A.t), B, L, ctypes.c_float(self.scale),
                     ptr(self.argmax) if want_argmax else None, stream())
         if gemm:    # paste = (A rawT^T) folded: O[p][(c, tap)], then every output pixel sums the 4 taps that reach it
-            if getattr(self, 'O', None) is None:
-                self.O = torch.zeros(B, L, 16 * C, dtype=torch.float32, device=out.t.device)
-            _bgemm(self.A.t, self.rawT, self.O, L, 16 * C, L, B, b_split=C)          # rows of rawT [c][tap] taken as (tap, c): O[p][tap][c]
+            _bgemm(self.A.t, self.rawT_h, self.O, L, 16 * C, L, B, b_split=C)          # rows of rawT [c][tap] taken as (tap, c): O[p][tap][c]
             L_.call('hv_ca_fold', ptr(self.O), ptr(out.t), B, H, W, C, out.ld, ctypes.c_float(0.25), 0, stream())
         else:
             ops.conv2d(self.A, self.rawT, out, 4, 2, 1, 1, transposed=True, alpha=0.25, w_bstride=C * 16 * L, precision=prec)
@@ -430,12 +441,13 @@ class AttentionPlan:
         # through the paste: dA and d(raw patches)
         gemm = getattr(self, 'gemm', False) and ops.precision_id(prec) == ops.F16
         if gemm:
-            if 'dOraw' not in bw:
-                bw['dOraw'] = torch.zeros(B, L, 16 * C, dtype=torch.float32, device=dout.t.device)
-            L_.call('hv_ca_raw_patches', ptr(dout.t), B, H, W, C, dout.ld, ptr(bw['dOraw']), ptr(bw['dOrawT']), stream())
-            _bgemm(bw['dOraw'], self.raw, bw['dA'].t, L, L, 16 * C, B, alpha=0.25)
-            L_.call('hv_transpose_batched', ptr(self.A.t), ptr(bw['AT'].t), B, L, L, stream())
-            _bgemm(bw['AT'].t, bw['dOrawT'], self.O, L, 16 * C, L, B, b_split=C)      # d(raw patches)[l][tap][c] (the forward's O buffer is free by now)
+            if 'dOraw_h' not in bw:
+                hz = lambda *s: torch.zeros(*s, dtype=torch.float16, device=dout.t.device)
+                bw['dOraw_h'], bw['dOrawT_h'], bw['AT_h'] = hz(B, L, 16 * C), hz(B, 16 * C, L), hz(B, L, L)
+            L_.call('hv_ca_raw_patches_f16', ptr(dout.t), B, H, W, C, dout.ld, ptr(bw['dOraw_h']), ptr(bw['dOrawT_h']), stream())
+            _bgemm(bw['dOraw_h'], self.raw_h, bw['dA'].t, L, L, 16 * C, B, alpha=0.25)
+            L_.call('hv_transpose_batched_f16', ptr(self.A.t), ptr(bw['AT_h']), B, L, L, stream())
+            _bgemm(bw['AT_h'], bw['dOrawT_h'], self.O, L, 16 * C, L, B, b_split=C)      # d(raw patches)[l][tap][c] (the forward's O buffer is free by now)
             L_.call('hv_ca_fold', ptr(self.O), ptr(df.t), B, H, W, C, df.ld, ctypes.c_float(0.25), int(bool(accumulate)), stream())
         else:
             ops.conv2d(dout, self.raw, bw['dA'], 4, 2, 1, 1, alpha=0.25, w_bstride=L * 16 * C, precision=prec)
@@ -453,7 +465,7 @@ class AttentionPlan:
         # through the normalised patch matching (patches act as both filters and inputs)
         L_.call('hv_ca_score_backward_prep', ptr(ds0.t), ptr(self.S0.t), ptr(self.norm), ptr(self.rnorm), ptr(bw['Gs'].t), ptr(bw['coef']), B, L, stream())
         if gemm:
-            _bgemm(bw['Gs'].t, self.wpT, bw['dwp'].t, L, 9 * C, L, B)
+            _bgemm(bw['Gs'].t, self.wpT_h, bw['dwp'].t, L, 9 * C, L, B)
         else:
             ops.conv2d(bw['Gs'], self.wpT, bw['dwp'], 1, 1, 0, 1, w_bstride=9 * C * L, precision=prec)
         L_.call('hv_ca_patches_backward', ptr(bw['dwp'].t), ptr(self.wp), ptr(bw['coef']), ptr(df.t), B, H, W, C, df.ld, 1, stream())

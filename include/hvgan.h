@@ -244,7 +244,9 @@ int hv_ca_softmax_batched(const float* S, const float* mm, long long mm_bstride,
 int hv_ca_flow(const int* argmax, int B, int h, int w, int up, float* flow, void* stream);
 int hv_ca_softmax_backward(const float* dA, const float* A, const float* mm, float* dS, int B, int L, float scale, void* stream);
 int hv_transpose_batched(const float* src, float* dst, int B, int R, int C, void* stream); /* dst[b][c][r] = src[b][r][c] */
-/* Batched "NT" matrix product on fp16 MFMA (operands converted from fp32 when staged, fp32 accumulation and result):
+/* Batched "NT" matrix product on fp16 MFMA (fp32 accumulation and result; A / B are fp32 -- converted when staged -- or, with a_f16 / b_f16, fp16
+ * tables such as hv_ca_raw_patches_f16 / hv_transpose_batched_f16 write: half the operand bytes through the vector memory path, which bounds the
+ * fp32-operand form):
  *   C[b][m][n] = alpha * colscale[b][n] * sum_k A[b][m][k] * B[b][n][k]        (colscale may be NULL; strides in elements)
  * The fp16 mode's route for ContextualAttention's five big contractions (scores, paste, and their three gradients): they are plain products of
  * per-sample matrices that exist with the contraction index contiguous (csrc/bgemm.hip lists them).  K % 32 == 0, N % 4 == 0, 16-byte aligned rows.
@@ -252,9 +254,12 @@ int hv_transpose_batched(const float* src, float* dst, int B, int R, int C, void
  * tables consumed in [tap][channel] order, so that C's rows hold whole channel vectors per tap).
  * hv_ca_fold: col2im of 4x4 stride-2 pad-1 patches src[b][p][tap][c] into dst[b][y][x][c] (+)= alpha * (the 4 taps reaching the pixel) -- the tail of
  * F.conv_transpose2d(..., stride=2, padding=1) (models/inpaint_networks.py:379) after the contraction, and the adjoint of hv_ca_raw_patches. */
-int hv_bgemm_nt(const float* A, int lda, long long strideA, const float* B, int ldb, long long strideB, float* C, int ldc, long long strideC,
-                int M, int N, int K, int batch, float alpha, const float* colscale, long long strideS, int b_split, void* stream);
+int hv_bgemm_nt(const void* A, int a_f16, int lda, long long strideA, const void* B, int b_f16, int ldb, long long strideB, float* C, int ldc,
+                long long strideC, int M, int N, int K, int batch, float alpha, const float* colscale, long long strideS, int b_split, void* stream);
 int hv_ca_fold(const float* src, float* dst, int B, int H, int W, int C, int dst_ld, float alpha, int accumulate, void* stream);
+/* fp16-stored forms of two operand producers (same layouts as hv_ca_raw_patches / hv_transpose_batched) */
+int hv_ca_raw_patches_f16(const float* f, int B, int H, int W, int C, int f_ld, void* raw_h, void* rawT_h, void* stream);
+int hv_transpose_batched_f16(const float* src, void* dst_h, int B, int R, int C, void* stream);
 /* Gs[b][i][j] = dS[b][j][i]*rnorm[b][i] + dS[b][i][j]*rnorm[b][j];  coef[b][l] = -(sum_p dS[p][l]*S0[p][l])/norm[l]^2.
  * coef must hold 17*B*L floats: the first B*L are the result, the rest is scratch for the row-chunk partial sums. */
 int hv_ca_score_backward_prep(const float* dS, const float* S0, const float* norm, const float* rnorm, float* Gs, float* coef,

@@ -239,9 +239,17 @@ def test_batched_nt_gemm_against_torch(M, N, K, batch, scaled, split):
     cs = (torch.rand(batch, N, generator=g) + 0.5) if scaled else None
     C = torch.full((batch, M, N), float('nan'), device=dev)
     Ad, Bd, csd = A.to(dev), Bm.to(dev), (cs.to(dev) if scaled else None)
-    lib.get().call('hv_bgemm_nt', lib.ptr(Ad), K, ctypes.c_longlong(M * K), lib.ptr(Bd), K, ctypes.c_longlong(N * K), lib.ptr(C), N,
-                   ctypes.c_longlong(M * N), M, N, K, batch, ctypes.c_float(0.25), lib.ptr(csd), ctypes.c_longlong(N if scaled else 0), split, lib.stream())
-    torch.cuda.synchronize()
+    for a16, b16 in ((0, 0), (0, 1), (1, 1)):          # fp32 operands converted when staged / fp16 tables copied as they are: the same products
+        C.fill_(float('nan'))
+        Ax, Bx = (Ad.half() if a16 else Ad), (Bd.half() if b16 else Bd)
+        lib.get().call('hv_bgemm_nt', lib.ptr(Ax), a16, K, ctypes.c_longlong(M * K), lib.ptr(Bx), b16, K, ctypes.c_longlong(N * K), lib.ptr(C), N,
+                       ctypes.c_longlong(M * N), M, N, K, batch, ctypes.c_float(0.25), lib.ptr(csd), ctypes.c_longlong(N if scaled else 0), split,
+                       lib.stream())
+        torch.cuda.synchronize()
+        if (a16, b16) == (0, 0):
+            C0 = C.clone()
+        else:
+            assert torch.equal(C, C0), (a16, b16)
     Bl = Bm
     if split:       # logical row t * split + c is stored as row c * (N / split) + t
         Bl = Bm.view(batch, split, N // split, K).transpose(1, 2).reshape(batch, N, K)
