@@ -37,6 +37,14 @@ for _ in range(N):
 e1.record()
 torch.cuda.synchronize()
 print('overlapped step: %.2f ms' % (e0.elapsed_time(e1) / N))
+if os.environ.get('PHASE'):      # replay ONE phase graph over and over (for a kernel trace of that phase alone: tools/trace_gaps.py ... dense:<ms>)
+    g = m._dp_graphs[os.environ['PHASE']]
+    torch.cuda.synchronize()
+    for _ in range(30):
+        g.replay()
+    torch.cuda.synchronize()
+    dist.destroy_process_group()
+    sys.exit(0)
 if os.environ.get('ONLY_STEPS') == '1':       # for a kernel trace of the overlapped schedule (tools/trace_gaps.py ... dense:<ms>)
     dist.destroy_process_group()
     sys.exit(0)
