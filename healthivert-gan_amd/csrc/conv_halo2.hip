@@ -314,7 +314,8 @@ int hv_halo2_launch(HaloK& k, int TW, int KH, int KW, int maxpatch, hipStream_t 
         // 1 x 4), ring 8: 72.0 / 79.9 us, ring 16 (64-channel blocks, 1 x 4): 78.0 us; 128-channel blocks as 2 x 2: no difference
         static const int wm = getenv("HV_HALO2_WM") ? atoi(getenv("HV_HALO2_WM")) : 1;
         // (4x16-pixel tiles for these layers: 75.6 -> 87.3 us forward, 80.0 -> 102.9 us data gradient -- twice the filter fetches per MFMA.  Not kept)
-        if (wgs128 < 512) {
+        static const int thr128 = getenv("HV_HALO2_THR128") ? atoi(getenv("HV_HALO2_THR128")) : 512;     // (256: 128-channel blocks for the 512 -> 256 data gradient: alone 89 -> 97 us, step 10.71 vs 10.69 ms)
+        if (wgs128 < thr128) {
             if (wm & 1) return ring >= 8 ? launch2<8, 16, 64, 2, 2, 32, 1, 4, 8>(k, s) : launch2<8, 16, 64, 2, 2, 32, 1, 4, 4>(k, s);
             if (ring == 16) return launch2<8, 16, 64, 1, 4, 32, 1, 4, 16>(k, s);
             return ring == 8 ? launch2<8, 16, 64, 1, 4, 32, 1, 4, 8>(k, s) : launch2<8, 16, 64, 1, 4, 32, 1, 4, 4>(k, s);

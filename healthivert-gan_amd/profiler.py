@@ -72,11 +72,23 @@ class KernelTimer:
         name, a = max(bk.items(), key=lambda kv: kv[1][0])
         return name, a[3]
 
-    def roofline(self, precision, peak_tflops, total_ms=None):
+    def dominant_mfma(self, peak_tflops):
+        """(kernel name, [shape keys]) of the MFMA-bound instantiation (arithmetic intensity above the ridge) with the largest total time."""
+        ridge = peak_tflops * 1e12 / (HBM_PEAK_GBS * 1e9)
+        best = None
+        for name, (ms, n, flops, keys) in self.by_kernel().items():
+            nbytes = sum(self.bytes.get(k, 0) * self.summary()[k][1] for k in keys)
+            if nbytes and flops / nbytes >= ridge and (best is None or ms > best[0]):
+                best = (ms, name, keys)
+        return (best[1], best[2]) if best else None
+
+    def roofline(self, precision, peak_tflops, total_ms=None, name=None):
         bk = self.by_kernel()
-        if not bk:
+        if not bk or (name is not None and name not in bk):
             return None
-        name, (ms, n, flops, keys) = max(bk.items(), key=lambda kv: kv[1][0])
+        if name is None:
+            name = max(bk.items(), key=lambda kv: kv[1][0])[0]
+        ms, n, flops, keys = bk[name]
         agg = self.summary()
         achieved = flops / (ms * 1e-3) / 1e12
         ridge = peak_tflops * 1e12 / (HBM_PEAK_GBS * 1e9)
