@@ -102,6 +102,20 @@ __global__ __launch_bounds__(256, 2) void conv_halo2_kernel(const HaloK p) {   /
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // this lane's bias values, fetched now: read in the epilogue they were four dependent global loads per fragment at the kernel's very end
+    // (only where registers are plentiful: with 16 accumulator fragments, or the stride-2 patch prefetch, the extra live registers spilled)
+    constexpr bool BPF = MT * NT <= 8 && BSTEP == 1;
+    f32x4 bias_r[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int ch0 = n_base + wn * (BN / WN) + n * 16 + (lane >> 4) * 4;
+        bias_r[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (BPF && p.bias) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (ch0 + r < p.Cout) bias_r[n][r] = p.bias[ch0 + r];
+        }
+    }
     // filters: plain rows [Cout][taps][Cin], or (p.wt) MFMA-fragment order: a fragment = 16 rows x FK channels is one contiguous piece, lane l
     // owns bytes [l * FK/2, (l+1) * FK/2) of it (include/hvgan.h, hv_weight_tile_f16).  Plain rows make a wave's fragment load 16 rows x 64 B that
     // lie a whole filter row (8 KB at 4x4x256) apart -- 16 half-used cache lines on ONE L2 channel; measured 93 -> 76 us on the 256 -> 512 layer
@@ -231,7 +245,54 @@ __global__ __launch_bounds__(256, 2) void conv_halo2_kernel(const HaloK p) {   /
     }
 
     // ---- epilogue (same contract as conv_halo_kernel)
-    const HvEpi epi = {p.alpha, p.act, p.accumulate, p.vec_store, p.Cout, p.bias, nullptr, p.mul_act, p.mul_vec, p.y_half, p.mul_half};
+    // (alpha == 1, every biased layer of the networks: the prefetched bias is added to the accumulators here, exactly what the shared epilogue code
+    // would compute from the pointer; other alphas keep the pointer)
+    const bool bias_folded = BPF && p.bias && p.alpha == 1.f;
+    const HvEpi epi = {p.alpha, p.act, p.accumulate, p.vec_store, p.Cout, bias_folded ? nullptr : p.bias, nullptr, p.mul_act, p.mul_vec, p.y_half, p.mul_half};
+    if (bias_folded) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[n][m][r] += bias_r[n][r];
+    }
+    if (p.ep16) {
+        // fp16 output, no accumulate: the tile goes through LDS (the patch buffers are free: the main loop ends behind a barrier) and leaves as
+        // 16-byte pieces, a pixel's channel row contiguous.  A lane's own values are 4 channels = 8 bytes of one pixel, so the direct stores below
+        // write 32-byte fragments of every 128-byte pixel row from four different waves at four different times: timing-only builds put the
+        // direct epilogue at 7.4 of the 17.1 us of a 64 -> 64 channel 3x3 layer at 64x64, bs 16 (main loop 4.4 us).
+        constexpr int LDO = BN + 8;                                   // halfs per pixel row in LDS: 16-byte pieces, rows 16 bytes apart in banks
+        _Float16* ot = patch;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int g = wm * MT + m, ty = g / GX, tx = (g % GX) * 16 + (lane & 15);
+            const int i = i0 + ty, j = j0 + tx;
+            const bool inside = i < C.Hc && j < C.Wc;
+            const int ho = C.ph + ry + i * p.ostep, wo = C.pw + rx + j * p.ostep;
+            const long long opix = (long long)(n_img * p.Ho + ho) * p.Wo + wo;
+            const void* mp = (p.mul_src && inside) ? hv_eptr(p.mul_src, opix * p.mul_ld + p.mul_coff, p.mul_half) : nullptr;
+#pragma unroll
+            for (int nn = 0; nn < NT; ++nn) {
+                const int cl = wn * (BN / WN) + nn * 16 + (lane >> 4) * 4;
+                const f32x4 v = hv_conv_value4<true>(epi, acc[nn][m], n_base + cl, mp);
+                *reinterpret_cast<f16x4v*>(ot + (g * 16 + (lane & 15)) * LDO + cl) = (f16x4v){(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+            }
+        }
+        __syncthreads();
+        constexpr int PIECES = BN / 8;
+        _Float16* yb = reinterpret_cast<_Float16*>(p.y);
+        for (int it = tid; it < TH * TW * PIECES; it += 256) {
+            const int q = it / PIECES, pc = it - q * PIECES;
+            const int g = q >> 4, ty = g / GX, tx = (g % GX) * 16 + (q & 15);
+            const int i = i0 + ty, j = j0 + tx, ch = n_base + pc * 8;
+            if (i >= C.Hc || j >= C.Wc || ch >= p.Cout) continue;                  // Cout % 8 == 0 (host): a piece is wholly inside or outside
+            const int ho = C.ph + ry + i * p.ostep, wo = C.pw + rx + j * p.ostep;
+            const long long opix = (long long)(n_img * p.Ho + ho) * p.Wo + wo;
+            *reinterpret_cast<u32x4*>(yb + opix * p.y_ld + p.y_coff + ch) = *reinterpret_cast<const u32x4*>(ot + q * LDO + pc * 8);
+        }
+        return;
+    }
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int g = wm * MT + m, ty = g / GX, tx = (g % GX) * 16 + (lane & 15);
@@ -284,6 +345,11 @@ static int launch2(HaloK& k, hipStream_t s, int th0 = 8, int tw0 = TW) {
     hv_path_note = 3;
     HV_KNAME("conv_halo2_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %d, %s>", TH, TW, BN, WM, WN, CK, BSTEP, SPAN, D, k.x_half ? "true" : "false");
     HaloK kk = k;       // the kernel's view: the tiled table IS its filter table (k itself stays as it is for a fallback kernel)
+    {   // coalesced fp16 epilogue through LDS (HV_HALO2_EP16=0: direct 8-byte stores)
+        static const int ep16 = getenv("HV_HALO2_EP16") ? atoi(getenv("HV_HALO2_EP16")) : 1;
+        kk.ep16 = (ep16 && kk.y_half && kk.accumulate == 0 && !(kk.Cout & 7) && !(kk.y_ld & 7) && !(kk.y_coff & 7) && !((uintptr_t)kk.y & 15) &&
+                   lds >= (size_t)TH * TW * (BN + 8) * sizeof(_Float16)) ? 1 : 0;
+    }
     if (kk.wt) { kk.w = kk.wt; kk.w_bytes = kk.wt_bytes; }
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, kk);
     HV_LAUNCH_CHECK();

@@ -180,6 +180,34 @@ __device__ __forceinline__ void hv_conv_epilogue4(const HvEpi& e, const f32x4& a
             if (ch0 + r < e.Cout) hv_st1(yp, ch0 + r, e.accumulate == 1 ? hv_ld1(yp, ch0 + r, e.y_half) + v[r] : v[r], e.y_half);
     }
 }
+// The values of hv_conv_epilogue4 without its store, for epilogues that hand the tile to LDS first (accumulate == 0 only):
+//   v = act(acc*alpha [*scale] [+bias]) [* act'(mul)]; channels >= Cout give 0
+template <bool FAST>
+__device__ __forceinline__ f32x4 hv_conv_value4(const HvEpi& e, const f32x4& a, int ch0, const void* __restrict__ mp) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int ch = ch0 + r;
+        if (ch < e.Cout) {
+            float t = a[r] * e.alpha;
+            if (e.scale) t *= e.scale[ch];
+            if (e.bias) t += e.bias[ch];
+            v[r] = FAST ? hv_act_fast(t, e.act) : hv_act(t, e.act);
+        }
+    }
+    if (mp) {
+        if (e.mul_vec && ch0 + 3 < e.Cout) {
+            const float4 m4 = hv_ld4(mp, ch0, e.mul_half);
+            v[0] *= hv_act_grad_from_out(m4.x, e.mul_act); v[1] *= hv_act_grad_from_out(m4.y, e.mul_act);
+            v[2] *= hv_act_grad_from_out(m4.z, e.mul_act); v[3] *= hv_act_grad_from_out(m4.w, e.mul_act);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (ch0 + r < e.Cout) v[r] *= hv_act_grad_from_out(hv_ld1(mp, ch0 + r, e.mul_half), e.mul_act);
+        }
+    }
+    return v;
+}
 // byte-wise element address of a tensor whose element size is 2 (half != 0) or 4 bytes
 __device__ __forceinline__ void* hv_eptr(void* base, long long elem, int half) { return reinterpret_cast<char*>(base) + elem * (half ? 2 : 4); }
 __device__ __forceinline__ const void* hv_eptr(const void* base, long long elem, int half) { return reinterpret_cast<const char*>(base) + elem * (half ? 2 : 4); }
