@@ -23,6 +23,7 @@ struct S2TK {
     const void* mul_src; int mul_ld, mul_coff, mul_act, mul_vec, y_half, mul_half;
     unsigned x_bytes, w_bytes;
     const _Float16* wt; unsigned wt_bytes;      // filters in MFMA-fragment order (hv_conv_desc.w_f16_tiled) or NULL
+    int ep16;                                   // fp16 output tile handed through LDS, stored as 16-byte pieces
 };
 
 template <int KS, int TH, int BN, int CK>
@@ -145,6 +146,38 @@ __global__ __launch_bounds__(256, 2) void conv_s2t_kernel(const S2TK p) {
     }
 
     const HvEpi epi = {p.alpha, p.act, p.accumulate, p.vec_store, p.Cout, p.bias, nullptr, p.mul_act, p.mul_vec, p.y_half, p.mul_half};
+    if (p.ep16) {
+        // The four parity waves' pixels interleave in the output: a wave's direct stores touch every other pixel of every other row, 8 bytes per
+        // lane.  Through LDS (the patch buffers are free behind the loop's last barrier) the 2TH x 32-pixel tile leaves as whole channel rows.
+        constexpr int LDO = BN + 8, OW = 2 * TW;
+        _Float16* ot = patch;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int i = ty0 + m, j = tx0 + (lane & 15);
+            const int ho = 2 * i + ph, wo = 2 * j + pw;
+            const bool inside = i < p.Hi && j < p.Wi && ho < p.Ho && wo < p.Wo;
+            const long long opix = (long long)(n_img * p.Ho + ho) * p.Wo + wo;
+            const void* mp = (p.mul_src && inside) ? hv_eptr(p.mul_src, opix * p.mul_ld + p.mul_coff, p.mul_half) : nullptr;
+            const int q = (2 * m + ph) * OW + 2 * (lane & 15) + pw;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int cl = n * 16 + (lane >> 4) * 4;
+                const f32x4 v = hv_conv_value4<true>(epi, acc[n][m], n_base + cl, mp);
+                *reinterpret_cast<f16x4v*>(ot + q * LDO + cl) = (f16x4v){(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+            }
+        }
+        __syncthreads();
+        constexpr int PIECES = BN / 8;
+        _Float16* yb = reinterpret_cast<_Float16*>(p.y);
+        for (int it = tid; it < 2 * TH * OW * PIECES; it += 256) {
+            const int q = it / PIECES, pc = it - q * PIECES;
+            const int ho = 2 * ty0 + q / OW, wo = 2 * tx0 + q % OW, ch = n_base + pc * 8;
+            if (ho >= p.Ho || wo >= p.Wo || ch >= p.Cout) continue;
+            const long long opix = (long long)(n_img * p.Ho + ho) * p.Wo + wo;
+            *reinterpret_cast<u32x4*>(yb + opix * p.y_ld + p.y_coff + ch) = *reinterpret_cast<const u32x4*>(ot + q * LDO + pc * 8);
+        }
+        return;
+    }
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int i = ty0 + m, j = tx0 + (lane & 15);
@@ -163,11 +196,25 @@ static int launch_s2t(S2TK& k, hipStream_t s) {
     constexpr int LDP = CK + (CK >= 32 ? 16 : 8);
     k.tiles_x = hv_cdiv(k.Wi, 16);
     k.tiles = k.tiles_x * hv_cdiv(k.Hi, TH);
-    const size_t lds = (size_t)2 * (TH + 2) * 18 * LDP * sizeof(_Float16);
+    size_t lds = (size_t)2 * (TH + 2) * 18 * LDP * sizeof(_Float16);
+    {   // coalesced fp16 epilogue through LDS (HV_HALO2_EP16=0: direct stores); the output tile may need more LDS than the two patch buffers
+        static const int ep16 = getenv("HV_HALO2_EP16") ? atoi(getenv("HV_HALO2_EP16")) : 1;
+        k.ep16 = (ep16 && k.y_half && k.accumulate == 0 && !(k.Cout & 7) && !(k.y_ld & 7) && !(k.y_coff & 7) && !((uintptr_t)k.y & 15) && k.Ho == 2 * k.Hi &&
+                  k.Wo == 2 * k.Wi) ? 1 : 0;
+        const size_t need = (size_t)2 * TH * 32 * (BN + 8) * sizeof(_Float16);
+        if (k.ep16 && need > lds) lds = need;
+    }
+    auto kern = conv_s2t_kernel<KS, TH, BN, CK>;
+    static int lds_limit = 48 * 1024;       // per instantiation
+    if ((int)lds > lds_limit) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e != hipSuccess) return -1000 - (int)e;
+        lds_limit = 150 * 1024;
+    }
     dim3 grid(k.tiles * k.B, hv_cdiv(k.Cout, BN));
     hv_path_note = 6;
     HV_KNAME("conv_s2t_kernel<%d, %d, %d, %d>", KS, TH, BN, CK);
-    hipLaunchKernelGGL((conv_s2t_kernel<KS, TH, BN, CK>), grid, dim3(256), lds, s, k);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, k);
     HV_LAUNCH_CHECK();
     return HV_OK;
 }
