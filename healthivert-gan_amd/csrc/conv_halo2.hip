@@ -271,7 +271,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo2_kernel(const HaloK p) {   /
             const bool inside = i < C.Hc && j < C.Wc;
             const int ho = C.ph + ry + i * p.ostep, wo = C.pw + rx + j * p.ostep;
             const long long opix = (long long)(n_img * p.Ho + ho) * p.Wo + wo;
-            const void* mp = (p.mul_src && inside) ? hv_eptr(p.mul_src, opix * p.mul_ld + p.mul_coff, p.mul_half) : nullptr;
+            // (ep16 == 2: the act' multiplier is applied in the second stage from 16-byte loads)
+            const void* mp = (p.mul_src && inside && p.ep16 == 1) ? hv_eptr(p.mul_src, opix * p.mul_ld + p.mul_coff, p.mul_half) : nullptr;
 #pragma unroll
             for (int nn = 0; nn < NT; ++nn) {
                 const int cl = wn * (BN / WN) + nn * 16 + (lane >> 4) * 4;
@@ -289,7 +290,15 @@ __global__ __launch_bounds__(256, 2) void conv_halo2_kernel(const HaloK p) {   /
             if (i >= C.Hc || j >= C.Wc || ch >= p.Cout) continue;                  // Cout % 8 == 0 (host): a piece is wholly inside or outside
             const int ho = C.ph + ry + i * p.ostep, wo = C.pw + rx + j * p.ostep;
             const long long opix = (long long)(n_img * p.Ho + ho) * p.Wo + wo;
-            *reinterpret_cast<u32x4*>(yb + opix * p.y_ld + p.y_coff + ch) = *reinterpret_cast<const u32x4*>(ot + q * LDO + pc * 8);
+            u32x4 o = *reinterpret_cast<const u32x4*>(ot + q * LDO + pc * 8);
+            if (p.ep16 == 2) {      // v * act'(m), m = the producer's fp16 output at the same pixel / channels (the tile value was rounded to fp16 once before)
+                const f16x8 m8 = *reinterpret_cast<const f16x8*>(reinterpret_cast<const _Float16*>(p.mul_src) + opix * p.mul_ld + p.mul_coff + ch);
+                f16x8 v8 = __builtin_bit_cast(f16x8, o);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v8[e] = (_Float16)((float)v8[e] * hv_act_grad_from_out((float)m8[e], p.mul_act));
+                o = __builtin_bit_cast(u32x4, v8);
+            }
+            *reinterpret_cast<u32x4*>(yb + opix * p.y_ld + p.y_coff + ch) = o;
         }
         return;
     }
@@ -349,6 +358,8 @@ static int launch2(HaloK& k, hipStream_t s, int th0 = 8, int tw0 = TW) {
         static const int ep16 = getenv("HV_HALO2_EP16") ? atoi(getenv("HV_HALO2_EP16")) : 1;
         kk.ep16 = (ep16 && kk.y_half && kk.accumulate == 0 && !(kk.Cout & 7) && !(kk.y_ld & 7) && !(kk.y_coff & 7) && !((uintptr_t)kk.y & 15) &&
                    lds >= (size_t)TH * TW * (BN + 8) * sizeof(_Float16)) ? 1 : 0;
+        // the act' multiplier read as 16-byte pieces in the second stage (a lane's own 8-byte loads are 32-byte fragments of the rows, like its stores)
+        if (kk.ep16 && kk.mul_src && kk.mul_half && !(kk.mul_ld & 7) && !(kk.mul_coff & 7) && !((uintptr_t)kk.mul_src & 15)) kk.ep16 = 2;
     }
     if (kk.wt) { kk.w = kk.wt; kk.w_bytes = kk.wt_bytes; }
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, kk);

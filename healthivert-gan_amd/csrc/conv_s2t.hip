@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void conv_s2t_kernel(const S2TK p) {
             const int ho = 2 * i + ph, wo = 2 * j + pw;
             const bool inside = i < p.Hi && j < p.Wi && ho < p.Ho && wo < p.Wo;
             const long long opix = (long long)(n_img * p.Ho + ho) * p.Wo + wo;
-            const void* mp = (p.mul_src && inside) ? hv_eptr(p.mul_src, opix * p.mul_ld + p.mul_coff, p.mul_half) : nullptr;
+            const void* mp = (p.mul_src && inside && p.ep16 == 1) ? hv_eptr(p.mul_src, opix * p.mul_ld + p.mul_coff, p.mul_half) : nullptr;     // (2: second stage)
             const int q = (2 * m + ph) * OW + 2 * (lane & 15) + pw;
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
@@ -174,7 +174,15 @@ __global__ __launch_bounds__(256, 2) void conv_s2t_kernel(const S2TK p) {
             const int ho = 2 * ty0 + q / OW, wo = 2 * tx0 + q % OW, ch = n_base + pc * 8;
             if (ho >= p.Ho || wo >= p.Wo || ch >= p.Cout) continue;
             const long long opix = (long long)(n_img * p.Ho + ho) * p.Wo + wo;
-            *reinterpret_cast<u32x4*>(yb + opix * p.y_ld + p.y_coff + ch) = *reinterpret_cast<const u32x4*>(ot + q * LDO + pc * 8);
+            u32x4 o = *reinterpret_cast<const u32x4*>(ot + q * LDO + pc * 8);
+            if (p.ep16 == 2) {      // act' multiplier from 16-byte loads (as in conv_halo2_kernel)
+                const f16x8 m8 = *reinterpret_cast<const f16x8*>(reinterpret_cast<const _Float16*>(p.mul_src) + opix * p.mul_ld + p.mul_coff + ch);
+                f16x8 v8 = __builtin_bit_cast(f16x8, o);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v8[e] = (_Float16)((float)v8[e] * hv_act_grad_from_out((float)m8[e], p.mul_act));
+                o = __builtin_bit_cast(u32x4, v8);
+            }
+            *reinterpret_cast<u32x4*>(yb + opix * p.y_ld + p.y_coff + ch) = o;
         }
         return;
     }
@@ -201,6 +209,7 @@ static int launch_s2t(S2TK& k, hipStream_t s) {
         static const int ep16 = getenv("HV_HALO2_EP16") ? atoi(getenv("HV_HALO2_EP16")) : 1;
         k.ep16 = (ep16 && k.y_half && k.accumulate == 0 && !(k.Cout & 7) && !(k.y_ld & 7) && !(k.y_coff & 7) && !((uintptr_t)k.y & 15) && k.Ho == 2 * k.Hi &&
                   k.Wo == 2 * k.Wi) ? 1 : 0;
+        if (k.ep16 && k.mul_src && k.mul_half && !(k.mul_ld & 7) && !(k.mul_coff & 7) && !((uintptr_t)k.mul_src & 15)) k.ep16 = 2;
         const size_t need = (size_t)2 * TH * 32 * (BN + 8) * sizeof(_Float16);
         if (k.ep16 && need > lds) lds = need;
     }
