@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo2_kernel(const HaloK p) {   /
                 for (int r = 0; r < 4; ++r) acc[n][m][r] += bias_r[n][r];
     }
     if (p.ep16) {
-        // fp16 output, no accumulate: the tile goes through LDS (the patch buffers are free: the main loop ends behind a barrier) and leaves as
+        // fp16 output (assigned, or added to y: accumulate == 1): the tile goes through LDS (the patch buffers are free: the main loop ends behind a barrier) and leaves as
         // 16-byte pieces, a pixel's channel row contiguous.  A lane's own values are 4 channels = 8 bytes of one pixel, so the direct stores below
         // write 32-byte fragments of every 128-byte pixel row from four different waves at four different times: timing-only builds put the
         // direct epilogue at 7.4 of the 17.1 us of a 64 -> 64 channel 3x3 layer at 64x64, bs 16 (main loop 4.4 us).
@@ -296,6 +296,13 @@ __global__ __launch_bounds__(256, 2) void conv_halo2_kernel(const HaloK p) {   /
                 f16x8 v8 = __builtin_bit_cast(f16x8, o);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v8[e] = (_Float16)((float)v8[e] * hv_act_grad_from_out((float)m8[e], p.mul_act));
+                o = __builtin_bit_cast(u32x4, v8);
+            }
+            if (p.accumulate) {     // y += v (a gradient buffer's later writers)
+                const f16x8 y8 = *reinterpret_cast<const f16x8*>(yb + opix * p.y_ld + p.y_coff + ch);
+                f16x8 v8 = __builtin_bit_cast(f16x8, o);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v8[e] = (_Float16)((float)v8[e] + (float)y8[e]);
                 o = __builtin_bit_cast(u32x4, v8);
             }
             *reinterpret_cast<u32x4*>(yb + opix * p.y_ld + p.y_coff + ch) = o;
@@ -356,7 +363,7 @@ static int launch2(HaloK& k, hipStream_t s, int th0 = 8, int tw0 = TW) {
     HaloK kk = k;       // the kernel's view: the tiled table IS its filter table (k itself stays as it is for a fallback kernel)
     {   // coalesced fp16 epilogue through LDS (HV_HALO2_EP16=0: direct 8-byte stores)
         static const int ep16 = getenv("HV_HALO2_EP16") ? atoi(getenv("HV_HALO2_EP16")) : 1;
-        kk.ep16 = (ep16 && kk.y_half && kk.accumulate == 0 && !(kk.Cout & 7) && !(kk.y_ld & 7) && !(kk.y_coff & 7) && !((uintptr_t)kk.y & 15) &&
+        kk.ep16 = (ep16 && kk.y_half && kk.accumulate <= 1 && !(kk.Cout & 7) && !(kk.y_ld & 7) && !(kk.y_coff & 7) && !((uintptr_t)kk.y & 15) &&
                    lds >= (size_t)TH * TW * (BN + 8) * sizeof(_Float16)) ? 1 : 0;
         // the act' multiplier read as 16-byte pieces in the second stage (a lane's own 8-byte loads are 32-byte fragments of the rows, like its stores)
         if (kk.ep16 && kk.mul_src && kk.mul_half && !(kk.mul_ld & 7) && !(kk.mul_coff & 7) && !((uintptr_t)kk.mul_src & 15)) kk.ep16 = 2;

@@ -180,7 +180,7 @@ __device__ __forceinline__ void hv_conv_epilogue4(const HvEpi& e, const f32x4& a
             if (ch0 + r < e.Cout) hv_st1(yp, ch0 + r, e.accumulate == 1 ? hv_ld1(yp, ch0 + r, e.y_half) + v[r] : v[r], e.y_half);
     }
 }
-// The values of hv_conv_epilogue4 without its store, for epilogues that hand the tile to LDS first (accumulate == 0 only):
+// The values of hv_conv_epilogue4 without its store, for epilogues that hand the tile to LDS first (accumulate 0 or 1; 2 adds y BEFORE the activation):
 //   v = act(acc*alpha [*scale] [+bias]) [* act'(mul)]; channels >= Cout give 0
 template <bool FAST>
 __device__ __forceinline__ f32x4 hv_conv_value4(const HvEpi& e, const f32x4& a, int ch0, const void* __restrict__ mp) {
