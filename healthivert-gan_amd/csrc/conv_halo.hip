@@ -206,6 +206,55 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloK p) {
 
     // ---- epilogue (same contract as conv_igemm_kernel)
     const HvEpi epi = {p.alpha, p.act, p.accumulate, p.vec_store, p.Cout, p.bias, nullptr, p.mul_act, p.mul_vec, p.y_half, p.mul_half};
+    if (p.ep16) {
+        // fp16 output tile through LDS, stored as 16-byte pieces of whole channel rows (as in conv_halo2_kernel: the direct 8-byte stores below were
+        // 13.5 of the 46 us of the 64 -> 128 stride-2 PatchGAN layer).  All LDS buffers are free: the last tap group ends behind a barrier.
+        constexpr int LDO = BN + 8;
+        _Float16* ot = reinterpret_cast<_Float16*>(smem);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int g = wm * MT + m, ty = g / GX, tx = (g % GX) * 16 + (lane & 15);
+            const int i = i0 + ty, j = j0 + tx;
+            const bool inside = i < C.Hc && j < C.Wc;
+            const int ho = C.ph + i * p.ostep, wo = C.pw + j * p.ostep;
+            const long long opix = (long long)(n_img * p.Ho + ho) * p.Wo + wo;
+            const void* mp = (p.mul_src && inside && p.ep16 == 1) ? hv_eptr(p.mul_src, opix * p.mul_ld + p.mul_coff, p.mul_half) : nullptr;
+#pragma unroll
+            for (int nn = 0; nn < NT; ++nn) {
+                const int cl = wn * (BN / WN) + nn * 16 + (lane >> 4) * 4;
+                const f32x4 v = hv_conv_value4<true>(epi, acc[nn][m], n_base + cl, mp);
+                *reinterpret_cast<f16x4v*>(ot + (g * 16 + (lane & 15)) * LDO + cl) = (f16x4v){(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+            }
+        }
+        __syncthreads();
+        constexpr int PIECES = BN / 8;
+        _Float16* yb = reinterpret_cast<_Float16*>(p.y);
+        for (int it = tid; it < TH * TW * PIECES; it += 256) {
+            const int q = it / PIECES, pc = it - q * PIECES;
+            const int g = q >> 4, ty = g / GX, tx = (g % GX) * 16 + (q & 15);
+            const int i = i0 + ty, j = j0 + tx, ch = n_base + pc * 8;
+            if (i >= C.Hc || j >= C.Wc || ch >= p.Cout) continue;
+            const int ho = C.ph + i * p.ostep, wo = C.pw + j * p.ostep;
+            const long long opix = (long long)(n_img * p.Ho + ho) * p.Wo + wo;
+            u32x4 o = *reinterpret_cast<const u32x4*>(ot + q * LDO + pc * 8);
+            if (p.ep16 == 2) {
+                const f16x8 m8 = *reinterpret_cast<const f16x8*>(reinterpret_cast<const _Float16*>(p.mul_src) + opix * p.mul_ld + p.mul_coff + ch);
+                f16x8 v8 = __builtin_bit_cast(f16x8, o);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v8[e] = (_Float16)((float)v8[e] * hv_act_grad_from_out((float)m8[e], p.mul_act));
+                o = __builtin_bit_cast(u32x4, v8);
+            }
+            if (p.accumulate) {
+                const f16x8 y8 = *reinterpret_cast<const f16x8*>(yb + opix * p.y_ld + p.y_coff + ch);
+                f16x8 v8 = __builtin_bit_cast(f16x8, o);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v8[e] = (_Float16)((float)v8[e] + (float)y8[e]);
+                o = __builtin_bit_cast(u32x4, v8);
+            }
+            *reinterpret_cast<u32x4*>(yb + opix * p.y_ld + p.y_coff + ch) = o;
+        }
+        return;
+    }
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int g = wm * MT + m, ty = g / GX, tx = (g % GX) * 16 + (lane & 15);
@@ -238,7 +287,14 @@ static int launch_halo_t(const HaloK& k, int tiles, int maxpatch, hipStream_t s)
     dim3 grid(tiles, hv_cdiv(k.Cout, BN));
     hv_path_note = 2;
     HV_KNAME("conv_halo_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %s>", TH, TW, BN, WM, WN, TG, CK, PMAX, XH ? "true" : "false");
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, k);
+    HaloK kk = k;
+    {   // coalesced fp16 epilogue through LDS (HV_HALO2_EP16=0: direct 8-byte stores)
+        static const int ep16 = getenv("HV_HALO2_EP16") ? atoi(getenv("HV_HALO2_EP16")) : 1;
+        kk.ep16 = (ep16 && kk.y_half && kk.accumulate <= 1 && !(kk.Cout & 7) && !(kk.y_ld & 7) && !(kk.y_coff & 7) && !((uintptr_t)kk.y & 15) &&
+                   lds >= (size_t)TH * TW * (BN + 8) * sizeof(_Float16)) ? 1 : 0;
+        if (kk.ep16 && kk.mul_src && kk.mul_half && !(kk.mul_ld & 7) && !(kk.mul_coff & 7) && !((uintptr_t)kk.mul_src & 15)) kk.ep16 = 2;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, kk);
     HV_LAUNCH_CHECK();
     return HV_OK;
 }
