@@ -188,6 +188,15 @@ def test_conv_halo_tiled_fp16_forward_and_dgrad(case):
     ops.conv2d(to_act(gy, dtype=torch.float16), wb, dxt, k, s, p, 1, transposed=True, precision='fp16', w_h=wb.half(), w_t=wbt)
     torch.cuda.synchronize()
     assert torch.equal(dxt.t, dxa.t)
+    # a second writer of the same gradient buffer (accumulate = 1) with the producer's act' factor: y += v * act'(m)
+    m = torch.randn(B, Cin, H, W, generator=g).half().float()        # the kernel sees the fp16-stored value (a tiny positive m may round to 0)
+    fac = torch.where(m > 0, torch.ones_like(m), torch.full_like(m, 0.2))
+    ops.conv2d(to_act(gy, dtype=torch.float16), wb, dxt, k, s, p, 1, transposed=True, precision='fp16', w_h=wb.half(), w_t=wbt, accumulate=1,
+               mul=(to_act(m, dtype=torch.float16), 'lrelu'))
+    torch.cuda.synchronize()
+    want = xin.grad * (1.0 + fac)
+    err = maxerr(from_act(dxt), want)
+    assert err <= 6e-3 * max(1.0, want.abs().max().item()), err
 
 
 @pytest.mark.parametrize('dil,H,W', [(2, 32, 32), (4, 32, 48), (8, 64, 64), (2, 20, 12)])
