@@ -279,19 +279,20 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(void* __restrict__ dy, con
         const int C4 = C >> 2, cg = tid % C4, rp = tid / C4, rstep = 256 / C4;
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
         long long r = r0 + rp;
-        for (; r + rstep < r1; r += 2 * rstep) {   // two rows in flight per lane (HBM streaming needs the loads, not the math)
-            const long long p0 = r * dy_ld + dy_coff + cg * 4, p1 = p0 + (long long)rstep * dy_ld;
-            float4 g0 = hv_ld4(dy, p0, H), g1 = hv_ld4(dy, p1, H);
-            const float4 o0 = hv_ld4(y, r * y_ld + y_coff + cg * 4, YH);
-            const float4 o1 = hv_ld4(y, (r + rstep) * y_ld + y_coff + cg * 4, YH);
-            g0.x *= hv_act_grad_from_out(o0.x, act); g0.y *= hv_act_grad_from_out(o0.y, act);
-            g0.z *= hv_act_grad_from_out(o0.z, act); g0.w *= hv_act_grad_from_out(o0.w, act);
-            g1.x *= hv_act_grad_from_out(o1.x, act); g1.y *= hv_act_grad_from_out(o1.y, act);
-            g1.z *= hv_act_grad_from_out(o1.z, act); g1.w *= hv_act_grad_from_out(o1.w, act);
-            hv_st4(dy, p0, g0, H);
-            hv_st4(dy, p1, g1, H);
-            s.x += g0.x; s.y += g0.y; s.z += g0.z; s.w += g0.w;
-            s.x += g1.x; s.y += g1.y; s.z += g1.z; s.w += g1.w;
+        for (; r + 3 * rstep < r1; r += 4 * rstep) {   // four rows in flight per lane (HBM streaming needs the loads, not the math)
+            float4 g[4], o[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                g[u] = hv_ld4(dy, (r + u * rstep) * dy_ld + dy_coff + cg * 4, H);
+                o[u] = hv_ld4(y, (r + u * rstep) * y_ld + y_coff + cg * 4, YH);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                g[u].x *= hv_act_grad_from_out(o[u].x, act); g[u].y *= hv_act_grad_from_out(o[u].y, act);
+                g[u].z *= hv_act_grad_from_out(o[u].z, act); g[u].w *= hv_act_grad_from_out(o[u].w, act);
+                hv_st4(dy, (r + u * rstep) * dy_ld + dy_coff + cg * 4, g[u], H);
+                s.x += g[u].x; s.y += g[u].y; s.z += g[u].z; s.w += g[u].w;
+            }
         }
         for (; r < r1; r += rstep) {
             float4 g = hv_ld4(dy, r * dy_ld + dy_coff + cg * 4, H);
@@ -316,7 +317,22 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(void* __restrict__ dy, con
     } else {  // scalar path: C a power of two <= 256
         const int c = tid % C, rp = tid / C, rstep = 256 / C;
         float s = 0.f;
-        for (long long r = r0 + rp; r < r1; r += rstep) {
+        long long r = r0 + rp;
+        for (; r + 3 * rstep < r1; r += 4 * rstep) {       // four rows in flight (the 1-channel image tensors: a lane's loop was a chain of load latencies)
+            float g[4], o[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                g[u] = hv_ld1(dy, (r + u * rstep) * dy_ld + dy_coff + c, H);
+                o[u] = hv_ld1(y, (r + u * rstep) * y_ld + y_coff + c, YH);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                g[u] *= hv_act_grad_from_out(o[u], act);
+                hv_st1(dy, (r + u * rstep) * dy_ld + dy_coff + c, g[u], H);
+                s += g[u];
+            }
+        }
+        for (; r < r1; r += rstep) {
             float g = hv_ld1(dy, r * dy_ld + dy_coff + c, H) * hv_act_grad_from_out(hv_ld1(y, r * y_ld + y_coff + c, YH), act);
             hv_st1(dy, r * dy_ld + dy_coff + c, g, H);
             s += g;
@@ -347,7 +363,7 @@ static bool act_vec_ok(int C) { return (C % 4 == 0) && pow2(C / 4) && C / 4 <= 2
 // rows handled per block (multiple of the row step of the thread mapping) and the block count
 static int act_bwd_blocks(long long npix, int C, int* rows_per_block) {
     const int rstep = act_vec_ok(C) ? 256 / (C / 4) : 256 / C;
-    long long rpb = (long long)rstep * 16;
+    long long rpb = (long long)rstep * 4;       // one 4-row batch per lane unless that exceeds the block cap below (256 blocks = one per CU was a latency chain)
     long long nb = (npix + rpb - 1) / rpb;
     static const int ab = getenv("HV_ACT_BLOCKS") ? atoi(getenv("HV_ACT_BLOCKS")) : 2048;   // tuning knob
     if (nb > ab) {   // ~8 workgroups per CU keep enough loads in flight to stream from HBM
