@@ -19,6 +19,7 @@ CASES = [
     (2, 32, 32, 1, 1, 64, 4, 2, 1, 1, 'lrelu'),
     (2, 32, 32, 8, 8, 1, 3, 1, 1, 1, 'sigmoid'),
     (2, 32, 32, 9, 12, 1, 3, 1, 1, 1, 'clamp'),
+    (2, 9, 300, 12, 12, 1, 3, 1, 1, 1, 'sigmoid'),      # 1-channel head over two 256-pixel row segments (LDS-staged rows), ragged end
     (2, 32, 32, 65, 68, 64, 3, 1, 1, 1, 'elu'),
     (3, 31, 31, 128, 128, 256, 4, 1, 1, 1, 'none'),
     (2, 16, 16, 256, 256, 1, 4, 1, 1, 1, 'none'),
