@@ -308,6 +308,51 @@ __global__ __launch_bounds__(256) void stem5_mfma_kernel(const Stem5K p) {
     }
 }
 
+// The same with the five input rows of a 256-pixel output segment staged once in LDS as they are stored (fp16 input): a lane's eight operand
+// pixels per 16-pixel group come from LDS (no conversion), one global round trip per workgroup instead of one per group (56 us for 75 MB).
+__global__ __launch_bounds__(256) void stem5_lds_kernel(const Stem5K p) {
+    constexpr int SEG = 256, PWID = SEG + 4;
+    __shared__ __attribute__((aligned(8))) f16x4 xs[5 * PWID];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
+    f16x8 wa[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k0 = 32 * j + 8 * g;
+        f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (k0 + 8 <= 100) v = *reinterpret_cast<const f16x8*>(p.w + n * 100 + k0);
+        else if (k0 < 100) {
+            const f16x4 h = *reinterpret_cast<const f16x4*>(p.w + n * 100 + k0);
+            v = f16x8{h[0], h[1], h[2], h[3], 0, 0, 0, 0};
+        }
+        wa[j] = v;
+    }
+    const int row = blockIdx.y, b = row / p.H, oy = row - b * p.H, x0 = blockIdx.x * SEG;
+    const long long ximg = (long long)b * p.img_stride + p.x_coff;
+    const _Float16* xh = reinterpret_cast<const _Float16*>(p.x);
+    for (int e = threadIdx.x; e < 5 * PWID; e += 256) {
+        const int r = e / PWID, c = e - r * PWID;
+        const int iy = oy - 2 + r, ix = x0 - 2 + c;
+        f16x4 v = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+        if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) v = *reinterpret_cast<const f16x4*>(xh + ximg + ((long long)iy * p.W + ix) * p.x_ld);
+        xs[e] = v;
+    }
+    __syncthreads();
+    for (int ox0 = wave * 16; ox0 < SEG && x0 + ox0 < p.W; ox0 += 64) {
+        const int oxl = ox0 + n, ox = x0 + oxl;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f16x4 lo = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f}, hi = lo;
+            const int t0 = 8 * j + 2 * g, t1 = t0 + 1;                 // tap indices (25..31: padding)
+            if (t0 < 25) lo = xs[(t0 / 5) * PWID + oxl + t0 % 5];
+            if (t1 < 25) hi = xs[(t1 / 5) * PWID + oxl + t1 % 5];
+            const f16x8 xb = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[j], xb, acc, 0, 0, 0);
+        }
+        if (ox < p.W) hv_conv_epilogue4<true>(p.epi, acc, g * 4, hv_eptr(p.y, ((long long)row * p.W + ox) * p.y_ld + p.y_coff, p.epi.y_half), nullptr);
+    }
+}
+
 // 4 -> 16 channels, 5x5, stride 1, 'same' padding, fp16 filter copy [16][25][4]
 int hv_conv2d_stem5(const hv_conv_desc* d, hipStream_t s) {
     static const int enabled = getenv("HV_STEM5") ? atoi(getenv("HV_STEM5")) : 1;   // A/B knob
@@ -322,6 +367,13 @@ int hv_conv2d_stem5(const hv_conv_desc* d, hipStream_t s) {
     k.epi.mul_act = 0; k.epi.mul_vec = 0; k.epi.y_half = d->y_f16 ? 1 : 0; k.epi.mul_half = 0;
     k.epi.vec_store = ((d->y_ld & 3) == 0 && (d->y_coff & 3) == 0 && ((uintptr_t)d->y & 15) == 0) ? 1 : 0;
     hv_path_note = 4;
+    static const int lds5 = getenv("HV_STEM5_LDS") ? atoi(getenv("HV_STEM5_LDS")) : 1;       // A/B knob
+    if (lds5 && k.x_half && (long long)d->B * d->H <= 65535) {
+        HV_KNAME("stem5_lds_kernel");
+        hipLaunchKernelGGL(stem5_lds_kernel, dim3(hv_cdiv(d->W, 256), d->B * d->H), dim3(256), 0, s, k);
+        HV_LAUNCH_CHECK();
+        return HV_OK;
+    }
     HV_KNAME("stem5_mfma_kernel");
     hipLaunchKernelGGL(stem5_mfma_kernel, dim3(d->B * d->H), dim3(256), 0, s, k);
     HV_LAUNCH_CHECK();
