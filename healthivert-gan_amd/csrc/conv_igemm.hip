@@ -37,6 +37,7 @@ int hv_wgrad_tr(const hv_wgrad_desc* d, int* nslabs, hipStream_t s);
 int hv_conv2d_narrow(const hv_conv_desc* d, hipStream_t s);                     // conv_narrow.hip
 int hv_conv2d_thin_in(const hv_conv_desc* d, hipStream_t s);
 int hv_conv2d_stem5(const hv_conv_desc* d, hipStream_t s);
+int hv_conv2d_stem5_dgrad(const hv_conv_desc* d, hipStream_t s);
 int hv_conv2d_head(const hv_conv_desc* d, hipStream_t s);                       // conv_head.hip
 int hv_conv2d_s2t(const hv_conv_desc* d, hipStream_t s);                        // conv_s2t.hip
 
@@ -395,6 +396,10 @@ static int conv2d_dispatch(const hv_conv_desc* d, void* stream) {
     }
     if (d->Cin == 4 && d->KH == 5 && d->precision == HV_F16 && d->w_f16) {   // 5x5 stems of the generators: (tap, channel) as one MFMA contraction
         const int rc = hv_conv2d_stem5(d, (hipStream_t)stream);
+        if (rc != HV_ERR_UNSUPPORTED) return rc;
+    }
+    if (d->Cout == 4 && d->Cin == 16 && d->KH == 5 && d->transposed && d->precision == HV_F16 && d->w_f16) {   // ... and their data gradient
+        const int rc = hv_conv2d_stem5_dgrad(d, (hipStream_t)stream);
         if (rc != HV_ERR_UNSUPPORTED) return rc;
     }
     if (d->precision == HV_F16 && d->w_f16 && d->transposed && d->stride == 2) {   // stride-2 data gradients: the four parity classes in one workgroup

@@ -353,6 +353,51 @@ __global__ __launch_bounds__(256) void stem5_lds_kernel(const Stem5K p) {
     }
 }
 
+// Data gradient of the same stems (16 -> 4 channels, the gather form of conv_transpose): K = 25 taps x 16 channels = 400 -> thirteen 16x16x32
+// MFMAs per 16 pixels with the four output channels in rows 0..3 of the A operand (filters [4][25][16], rows 4..15 zero), the (8 + 4) x (64 + 4) gradient
+// pixels of an 8 x 64-pixel output tile staged once in LDS as stored.  The halo-tiled kernel spends a quarter-filled 16-deep MFMA per tap and 4-channel block
+// (60 us for 54 MB); this one reads every operand fragment with one 16-byte LDS load.
+template <int TH, int SEG>       // a workgroup owns TH output rows x SEG pixels: (TH + 4) x (SEG + 4) gradient pixels staged once
+__global__ __launch_bounds__(256) void stem5_dgrad_kernel(const Stem5K p) {
+    constexpr int PWID = SEG + 4, PH = TH + 4, CG = 16, KSTEPS = 13, GPR = SEG / 16;
+    __shared__ __attribute__((aligned(16))) _Float16 xs[PH * PWID * CG];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
+    f16x8 wa[KSTEPS];                                  // row n of the filter matrix [4][400] (zero rows 4..15, zero past k = 400)
+#pragma unroll
+    for (int j = 0; j < KSTEPS; ++j) {
+        const int k0 = 32 * j + 8 * g;
+        f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (n < 4 && k0 + 8 <= 400) v = *reinterpret_cast<const f16x8*>(p.w + n * 400 + k0);
+        wa[j] = v;
+    }
+    const int tiles_y = (p.H + TH - 1) / TH;
+    const int b = blockIdx.y / tiles_y, y0 = (blockIdx.y - b * tiles_y) * TH, x0 = blockIdx.x * SEG;
+    const long long ximg = (long long)b * p.img_stride + p.x_coff;
+    const _Float16* xh = reinterpret_cast<const _Float16*>(p.x);
+    for (int e = threadIdx.x; e < PH * PWID * 2; e += 256) {
+        const int half8 = e & 1, q = e >> 1, r = q / PWID, c = q - r * PWID;
+        const int iy = y0 - 2 + r, ix = x0 - 2 + c;
+        hv_u32x4 v = {0u, 0u, 0u, 0u};
+        if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+            v = *reinterpret_cast<const hv_u32x4*>(xh + ximg + ((long long)iy * p.W + ix) * p.x_ld + half8 * 8);
+        *reinterpret_cast<hv_u32x4*>(xs + q * CG + half8 * 8) = v;
+    }
+    __syncthreads();
+    for (int grp = wave; grp < TH * GPR; grp += 4) {
+        const int ty = grp / GPR, oxl = (grp - ty * GPR) * 16 + n, oy = y0 + ty, ox = x0 + oxl;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < KSTEPS; ++j) {
+            const int k0 = 32 * j + 8 * g, t = k0 >> 4, c0 = k0 & 15;          // tap (r, q) reads the gradient at (oy + 2 - r, ox + 2 - q)
+            f16x8 xb = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (t < 25) xb = *reinterpret_cast<const f16x8*>(xs + ((ty + 4 - t / 5) * PWID + oxl + 4 - t % 5) * CG + c0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[j], xb, acc, 0, 0, 0);
+        }
+        if (oy < p.H && ox < p.W)
+            hv_conv_epilogue4<true>(p.epi, acc, g * 4, hv_eptr(p.y, (((long long)b * p.H + oy) * p.W + ox) * p.y_ld + p.y_coff, p.epi.y_half), nullptr);
+    }
+}
+
 // 4 -> 16 channels, 5x5, stride 1, 'same' padding, fp16 filter copy [16][25][4]
 int hv_conv2d_stem5(const hv_conv_desc* d, hipStream_t s) {
     static const int enabled = getenv("HV_STEM5") ? atoi(getenv("HV_STEM5")) : 1;   // A/B knob
@@ -376,6 +421,26 @@ int hv_conv2d_stem5(const hv_conv_desc* d, hipStream_t s) {
     }
     HV_KNAME("stem5_mfma_kernel");
     hipLaunchKernelGGL(stem5_mfma_kernel, dim3(d->B * d->H), dim3(256), 0, s, k);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+
+// data gradient of those stems: 16 -> 4 channels, transposed, fp16 filter copy [4][25][16], fp16 gradient input
+int hv_conv2d_stem5_dgrad(const hv_conv_desc* d, hipStream_t s) {
+    static const int enabled = getenv("HV_STEM5_DGRAD") ? atoi(getenv("HV_STEM5_DGRAD")) : 1;   // A/B knob
+    if (!enabled || d->precision != HV_F16 || !d->w_f16 || !d->transposed || d->in_shift || d->w_bstride || d->ch_scale || d->mul_src || d->dil != 1 ||
+        d->Cin != 16 || d->Cout != 4 || d->KH != 5 || d->KW != 5 || d->stride != 1 || d->pad != 2 || d->Ho != d->H || d->Wo != d->W || !d->x_f16 || d->bias)
+        return HV_ERR_UNSUPPORTED;
+    if ((d->x_ld & 7) || (d->x_coff & 7) || ((uintptr_t)d->x & 15) || ((uintptr_t)d->w_f16 & 15) || (long long)d->B * hv_cdiv(d->H, 8) > 65535) return HV_ERR_UNSUPPORTED;
+    Stem5K k;
+    k.x = d->x; k.w = reinterpret_cast<const _Float16*>(d->w_f16); k.y = d->y; k.x_half = 1;
+    k.H = d->H; k.W = d->W; k.x_ld = d->x_ld; k.x_coff = d->x_coff; k.img_stride = d->H * d->W * d->x_ld; k.y_ld = d->y_ld; k.y_coff = d->y_coff;
+    k.epi.alpha = d->alpha; k.epi.act = d->act; k.epi.accumulate = d->accumulate; k.epi.Cout = 4; k.epi.bias = nullptr; k.epi.scale = nullptr;
+    k.epi.mul_act = 0; k.epi.mul_vec = 0; k.epi.y_half = d->y_f16 ? 1 : 0; k.epi.mul_half = 0;
+    k.epi.vec_store = ((d->y_ld & 3) == 0 && (d->y_coff & 3) == 0 && ((uintptr_t)d->y & 15) == 0) ? 1 : 0;
+    hv_path_note = 4;
+    HV_KNAME("stem5_dgrad_kernel");
+    hipLaunchKernelGGL((stem5_dgrad_kernel<8, 64>), dim3(hv_cdiv(d->W, 64), d->B * hv_cdiv(d->H, 8)), dim3(256), 0, s, k);
     HV_LAUNCH_CHECK();
     return HV_OK;
 }
