@@ -257,12 +257,104 @@ __global__ __launch_bounds__(256) void ca_fuse_p2_kernel(const float* __restrict
         ob[i] = acc;
     }
 }
+// Forward fuse for the 32 x 32 attention map, tiled: an output tile = one grid row of p (32 consecutive rows) x one grid row of l (32 columns).
+// For each column-order shift d the source rows itr(tr(p) + d) of the tile are CONSECUTIVE again (p + d*w inside the map; 1 + px when the last
+// grid row wraps to the top of the next column; (h-1)*w - 1 + px for the first one), and so are the columns: three 34 x 34 pieces of S (one halo
+// row / column for the row-order shift e) are staged in LDS once and every output is nine LDS reads -- the kernel above reads each source row of S
+// nine times through L2 (250 MB of fabric traffic for 128 MB of operands, 110 us).  Terms are added in the same (d, e) order: the same bits.
+__global__ __launch_bounds__(256) void ca_fuse_tile32_kernel(const float* __restrict__ S, float* __restrict__ out) {
+    constexpr int W = 32, HH = 32, L = W * HH, TS = 34, LDT = 35;
+    __shared__ float T[3][TS * LDT];
+    const float* Sb = S + (long long)blockIdx.z * L * L;
+    float* ob = out + (long long)blockIdx.z * L * L;
+    const int py0 = blockIdx.y, ly0 = blockIdx.x, p0 = py0 * W, l0 = ly0 * W;
+    int pb[3], lb[3];
+    pb[0] = py0 >= 1 ? p0 - W : (HH - 1) * W - 1;  pb[1] = p0;  pb[2] = py0 < HH - 1 ? p0 + W : 1;
+    lb[0] = ly0 >= 1 ? l0 - W : (HH - 1) * W - 1;  lb[1] = l0;  lb[2] = ly0 < HH - 1 ? l0 + W : 1;
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+        for (int e = threadIdx.x; e < TS * TS; e += 256) {
+            const int i = e / TS, j = e - i * TS;
+            const int pr = pb[d] - 1 + i, lc = lb[d] - 1 + j;
+            T[d][i * LDT + j] = ((unsigned)pr < (unsigned)L && (unsigned)lc < (unsigned)L) ? Sb[(long long)pr * L + lc] : 0.f;
+        }
+    __syncthreads();
+    const int r = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * 4;
+    float o[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int c = c0 + u;
+        float acc = 0.f;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            // tr(p) + d and tr(l) + d inside [0, L): only the first / last grid row can fall out, at px = 0 / w - 1 (resp. lx)
+            const bool vp = d == 1 || (d == 0 ? (py0 >= 1 || r >= 1) : (py0 < HH - 1 || r + 1 < W));
+            const bool vl = d == 1 || (d == 0 ? (ly0 >= 1 || c >= 1) : (ly0 < HH - 1 || c + 1 < W));
+            if (!(vp && vl)) continue;
+            acc += T[d][r * LDT + c];
+            acc += T[d][(r + 1) * LDT + c + 1];
+            acc += T[d][(r + 2) * LDT + c + 2];
+        }
+        o[u] = acc;
+    }
+    *reinterpret_cast<float4*>(ob + (long long)(p0 + r) * L + l0 + c0) = make_float4(o[0], o[1], o[2], o[3]);
+}
+// The adjoint on the same tiles: out[p][l] = sum_e U[p+e][l+e] with U[q][m] = sum_d S[itr(tr(q)+d)][itr(tr(m)+d)].  The 34 rows q = p0-1 .. p0+32
+// (the two halo rows belong to the neighbouring grid rows, whose wrap cases differ) get their three source rows from a small index table built by
+// the first lanes; columns alike.  Terms are added in the (e, d) order of ca_fuse_p2_kernel<true>: the same bits.
+__global__ __launch_bounds__(256) void ca_fuse_adj_tile32_kernel(const float* __restrict__ S, float* __restrict__ out) {
+    constexpr int W = 32, HH = 32, L = W * HH, TS = 34, LDT = 35;
+    __shared__ float T[3][TS * LDT];
+    __shared__ int prow[3][TS], pcol[3][TS];           // source row / column of (d, i), -1 = outside
+    const float* Sb = S + (long long)blockIdx.z * L * L;
+    float* ob = out + (long long)blockIdx.z * L * L;
+    const int p0 = blockIdx.y * W, l0 = blockIdx.x * W;
+    if (threadIdx.x < 2 * 3 * TS) {
+        const int which = threadIdx.x / (3 * TS), e = threadIdx.x % (3 * TS), d = e / TS, i = e % TS;
+        const int q = (which ? l0 : p0) - 1 + i;
+        int src = -1;
+        if ((unsigned)q < (unsigned)L) {
+            const int a = (q & (W - 1)) * HH + (q >> 5) + (d - 1);          // tr(q) + d
+            if ((unsigned)a < (unsigned)L) src = (a & (HH - 1)) * W + (a >> 5);     // itr
+        }
+        (which ? pcol : prow)[d][i] = src;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+        for (int e = threadIdx.x; e < TS * TS; e += 256) {
+            const int i = e / TS, j = e - i * TS;
+            const int pr = prow[d][i], lc = pcol[d][j];
+            T[d][i * LDT + j] = (pr >= 0 && lc >= 0) ? Sb[(long long)pr * L + lc] : 0.f;
+        }
+    __syncthreads();
+    const int r = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * 4;
+    float o[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int c = c0 + u;
+        float acc = 0.f;
+#pragma unroll
+        for (int e = 0; e < 3; ++e)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) acc += T[d][(r + e) * LDT + c + e];
+        o[u] = acc;
+    }
+    *reinterpret_cast<float4*>(ob + (long long)(p0 + r) * L + l0 + c0) = make_float4(o[0], o[1], o[2], o[3]);
+}
 // (A variant with the nine index maps tabulated in LDS -- nine table reads instead of ~150 integer instructions per element -- measured
 // 204 / 220 us against 109 / 117 us: the dependent LDS read in front of every global load costs more than the arithmetic.  Not kept.)
 static bool at_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 extern "C" int hv_ca_fuse(const float* S, float* out, int B, int h, int w, int adjoint, void* stream) {
     if (!S || !out || S == out || B <= 0 || h <= 0 || w <= 0) return HV_ERR_ARG;
     if (at_pow2(h) && at_pow2(w) && (long long)h * w <= 32768) {
+        static const int tile32 = getenv("HV_CA_FUSE_TILE") ? atoi(getenv("HV_CA_FUSE_TILE")) : 1;      // A/B knob
+        if (tile32 && h == 32 && w == 32 && B <= 65535 && !((uintptr_t)out & 15)) {
+            if (adjoint) hipLaunchKernelGGL(ca_fuse_adj_tile32_kernel, dim3(32, 32, B), dim3(256), 0, (hipStream_t)stream, S, out);
+            else hipLaunchKernelGGL(ca_fuse_tile32_kernel, dim3(32, 32, B), dim3(256), 0, (hipStream_t)stream, S, out);
+            HV_LAUNCH_CHECK();
+            return HV_OK;
+        }
         const int lh = __builtin_ctz(h), lw = __builtin_ctz(w);
         const dim3 grid(at_grid((long long)h * w * h * w, 4096), B);
         if (adjoint) hipLaunchKernelGGL((ca_fuse_p2_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, S, out, lh, lw);

@@ -302,3 +302,50 @@ def test_g2_contextual_attention_fp16_gemm_route(monkeypatch):
         assert _err(outs[gemm][1], g['grad_f']) <= 4e-2 * gs, (gemm, _err(outs[gemm][1], g['grad_f']))
     assert _err(outs[True][0], outs[False][0]) <= 5e-3 * ys
     assert _err(outs[True][1], outs[False][1]) <= 1e-2 * gs
+
+
+@pytest.mark.parametrize('adjoint', [0, 1])
+def test_score_fusion_tiles_match_the_index_formula(adjoint):
+    """hv_ca_fuse on the 32 x 32 map (LDS-tiled kernels) against the defining double sum evaluated with numpy in the same order of additions:
+    forward  out[p][l] = sum_d sum_e S[itr(tr(p)+d)+e][itr(tr(l)+d)+e],  adjoint  out[p][l] = sum_e sum_d S[itr(tr(p+e)+d)][itr(tr(l+e)+d)]
+    (terms with an index outside [0, L) dropped) -- bit for bit."""
+    import ctypes
+    import numpy as np
+    from hvgan import lib
+    B, h, w = 2, 32, 32
+    L = h * w
+    S = torch.randn(B, L, L, generator=torch.Generator().manual_seed(21 + adjoint))
+    out = torch.empty(B, L, L, device='cuda')
+    lib.get().call('hv_ca_fuse', lib.ptr(S.cuda()), lib.ptr(out), B, h, w, adjoint, lib.stream())
+    torch.cuda.synchronize()
+    Sn = S.numpy()
+    idx = np.arange(L)
+    tr = lambda a: (a % w) * h + a // w
+    itr = lambda a: (a % h) * w + a // h
+    ref = np.zeros((B, L, L), dtype=np.float32)
+
+    def add(rows, cols, rok, cok):      # ref[:, p, l] += S[:, rows[p], cols[l]] where both are valid
+        r = np.where(rok, rows, 0)
+        c = np.where(cok, cols, 0)
+        term = Sn[:, r][:, :, c] * (rok[:, None] & cok[None, :])[None].astype(np.float32)
+        ref.__iadd__(term.astype(np.float32))
+
+    if not adjoint:
+        for d in (-1, 0, 1):
+            a = tr(idx) + d
+            ok_d = (a >= 0) & (a < L)
+            base = itr(np.clip(a, 0, L - 1))
+            for e in (-1, 0, 1):
+                rows = base + e
+                ok = ok_d & (rows >= 0) & (rows < L)
+                add(np.clip(rows, 0, L - 1), np.clip(rows, 0, L - 1), ok, ok)
+    else:
+        for e in (-1, 0, 1):
+            q = idx + e
+            ok_e = (q >= 0) & (q < L)
+            for d in (-1, 0, 1):
+                a = tr(np.clip(q, 0, L - 1)) + d
+                ok = ok_e & (a >= 0) & (a < L)
+                rows = itr(np.clip(a, 0, L - 1))
+                add(rows, rows, ok, ok)
+    assert np.array_equal(out.cpu().numpy(), ref)
