@@ -271,13 +271,25 @@ __global__ __launch_bounds__(256) void ca_fuse_tile32_kernel(const float* __rest
     int pb[3], lb[3];
     pb[0] = py0 >= 1 ? p0 - W : (HH - 1) * W - 1;  pb[1] = p0;  pb[2] = py0 < HH - 1 ? p0 + W : 1;
     lb[0] = ly0 >= 1 ? l0 - W : (HH - 1) * W - 1;  lb[1] = l0;  lb[2] = ly0 < HH - 1 ? l0 + W : 1;
+    {   // all of a lane's loads are issued before the first LDS store (the pieces are 3 x 34 rows of 136 bytes: latency, not bandwidth)
+        constexpr int NIT = (TS * TS + 255) / 256;
+        float v[3][NIT];
 #pragma unroll
-    for (int d = 0; d < 3; ++d)
-        for (int e = threadIdx.x; e < TS * TS; e += 256) {
-            const int i = e / TS, j = e - i * TS;
-            const int pr = pb[d] - 1 + i, lc = lb[d] - 1 + j;
-            T[d][i * LDT + j] = ((unsigned)pr < (unsigned)L && (unsigned)lc < (unsigned)L) ? Sb[(long long)pr * L + lc] : 0.f;
-        }
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int e = threadIdx.x + it * 256, i = e / TS, j = e - i * TS;
+                const int pr = pb[d] - 1 + i, lc = lb[d] - 1 + j;
+                v[d][it] = (e < TS * TS && (unsigned)pr < (unsigned)L && (unsigned)lc < (unsigned)L) ? Sb[(long long)pr * L + lc] : 0.f;
+            }
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int e = threadIdx.x + it * 256, i = e / TS, j = e - i * TS;
+                if (e < TS * TS) T[d][i * LDT + j] = v[d][it];
+            }
+    }
     __syncthreads();
     const int r = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * 4;
     float o[4];
@@ -320,13 +332,25 @@ __global__ __launch_bounds__(256) void ca_fuse_adj_tile32_kernel(const float* __
         (which ? pcol : prow)[d][i] = src;
     }
     __syncthreads();
+    {
+        constexpr int NIT = (TS * TS + 255) / 256;
+        float v[3][NIT];
 #pragma unroll
-    for (int d = 0; d < 3; ++d)
-        for (int e = threadIdx.x; e < TS * TS; e += 256) {
-            const int i = e / TS, j = e - i * TS;
-            const int pr = prow[d][i], lc = pcol[d][j];
-            T[d][i * LDT + j] = (pr >= 0 && lc >= 0) ? Sb[(long long)pr * L + lc] : 0.f;
-        }
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int e = threadIdx.x + it * 256, i = e / TS, j = e - i * TS;
+                const int pr = e < TS * TS ? prow[d][i] : -1, lc = e < TS * TS ? pcol[d][j] : -1;
+                v[d][it] = (pr >= 0 && lc >= 0) ? Sb[(long long)pr * L + lc] : 0.f;
+            }
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int e = threadIdx.x + it * 256, i = e / TS, j = e - i * TS;
+                if (e < TS * TS) T[d][i * LDT + j] = v[d][it];
+            }
+    }
     __syncthreads();
     const int r = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * 4;
     float o[4];
