@@ -42,3 +42,5 @@ template <> struct HFrag<16> {
 
 // conv_halo2.hip: returns HV_ERR_UNSUPPORTED when no instantiation covers the shape (the caller falls back to conv_halo_kernel)
 int hv_halo2_launch(HaloK& k, int TW, int KH, int KW, int maxpatch, hipStream_t s);
+// conv_lf.hip: filters resident in LDS, 16x16-pixel tiles (3x3 stride-1 layers); HV_ERR_UNSUPPORTED -> the caller goes on to hv_halo2_launch
+int hv_convlf_launch(HaloK& k, int KH, int KW, hipStream_t s);

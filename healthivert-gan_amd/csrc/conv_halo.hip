@@ -438,9 +438,17 @@ int hv_conv2d_halo(const hv_conv_desc* d, const void* w_f16, hipStream_t s) {
         k.Wp = Wf; k.img_stride = Hf * Wf * d->x_ld; k.Ho = Hof; k.Wo = Wof; k.ostep = dil;
         if ((long long)d->B * k.img_stride >= (1ll << 29)) return HV_ERR_UNSUPPORTED;
         k.x_bytes = (unsigned)((size_t)d->B * k.img_stride * xs);
+        if (dil <= 4) {
+            const int rc = hv_convlf_launch(k, d->KH, d->KW, s);
+            if (rc != HV_ERR_UNSUPPORTED) return rc;
+        }
         return hv_halo2_launch(k, TW, d->KH, d->KW, maxpatch, s);      // (conv_halo_kernel has no pixel step)
     }
     static const bool halo2 = !(getenv("HV_HALO2") && atoi(getenv("HV_HALO2")) == 0);   // A/B knob
+    {   // filters-in-LDS form (3x3 stride-1 layers with whole-chunk channel counts)
+        const int rc = hv_convlf_launch(k, d->KH, d->KW, s);
+        if (rc != HV_ERR_UNSUPPORTED) return rc;
+    }
     if (halo2) {   // weights-in-registers form where an instantiation exists
         const int rc = hv_halo2_launch(k, TW, d->KH, d->KW, maxpatch, s);
         if (rc != HV_ERR_UNSUPPORTED) return rc;

@@ -1,0 +1,320 @@
+// Halo-tiled implicit-GEMM convolution, third form: the whole filter bank of the workgroup lives in LDS.
+//
+// conv_halo2_kernel fetches a wave's filter rows from L2 into MFMA operand registers, tap by tap, for every 64-pixel tile: a 64 -> 64 channel
+// 3x3 layer re-reads its 73 KB of filters once per 64 output pixels (75 MB of L2 -> CU traffic for 16.8 MB of activations at 64x64, bs 16)
+// and every workgroup is one chain of dependent round trips (chunk 0 patch -> barrier -> tap ring refills -> chunk 1 ...); its prologue and
+// epilogue cost more than its MFMA loop.  The generator's stride-1 3x3 layers have at most 64 x 64 (x 9) filter elements
+// per 64-channel output block, so here
+//   * ONE workgroup of 8 waves owns a 16 x 16-pixel output tile (4x the pixels per filter fetch) and all CO output channels of its block;
+//   * its filters (MFMA-fragment order, hv_weight_tile_f16: one contiguous piece per workgroup) and its WHOLE input patch (18 x 18 pixels, every
+//     input channel) are requested up front -- every load of the workgroup is in flight before the first wait: one memory round trip, one barrier;
+//   * both MFMA operands come from LDS: a wave computes 2 pixel rows x CO channels (A fragments are 1-KB linear pieces, B fragments are read from
+//     96-byte (48-byte at 16-channel planes) pixel rows: conflict-free for ds_read_b128 / b64 lane groups);
+//   * the fp16 output tile leaves through LDS as 16-byte pieces (whole channel rows per pixel), like conv_halo2_kernel's epilogue, with the same
+//     act' multiplier / accumulate forms, so the kernel serves the layers' data gradients (filters = the transposed table) as well.
+// Same argument block (HaloK) and tap table as the other halo kernels; dilation d runs as d*d residue sub-grids, a fused nearest x2 upsample of the
+// input is address arithmetic (in_shift), exactly as in conv_halo2_kernel.
+#include <stdlib.h>
+
+#include "conv_halo.h"
+
+template <int CIN, int CO, int TH>
+struct LfCfg {
+    static constexpr int T = (CIN % 32 == 0) ? 32 : 16;      // channels per plane = per MFMA step (the tiled filter table's fragment width)
+    static constexpr int NPL = CIN / T;                      // channel planes of the patch
+    static constexpr int LDP = T + (T == 32 ? 16 : 8);       // halfs per patch pixel row: 96 B / 48 B
+    static constexpr int TW = 16, NW = 8, NTHR = NW * 64;
+    static constexpr int MT = TH / NW;                       // pixel rows (16-pixel MFMA groups) per wave
+    static constexpr int NT = CO / 16;
+    static constexpr int PH = TH + 2, PW = TW + 2;
+    static constexpr int PLANE = PH * PW * LDP;              // halfs
+    static constexpr int WHALFS = CO * 9 * CIN;              // filter halfs of the workgroup
+    static constexpr int LDO = CO + 8;                       // output staging: halfs per pixel row
+    static constexpr int PATCH_HALFS = NPL * PLANE;
+    static constexpr int OST_HALFS = TH * TW * LDO;
+    static constexpr int TAIL_HALFS = PATCH_HALFS > OST_HALFS ? PATCH_HALFS : OST_HALFS;
+    static constexpr size_t LDS_BYTES = (size_t)(WHALFS + TAIL_HALFS) * 2;
+    static constexpr int WITEMS = (WHALFS * 2 / 16 + NTHR - 1) / NTHR;           // 16-byte filter items per thread
+    static constexpr int PITEMS = (PH * PW * (CIN / 8) + NTHR - 1) / NTHR;       // 16-byte patch items per thread
+};
+
+template <int CIN, int CO, int TH, int WPS>
+__global__ __launch_bounds__(512, WPS) void conv_lf_kernel(const HaloK p) {
+    typedef LfCfg<CIN, CO, TH> G;
+    constexpr int T = G::T, NPL = G::NPL, LDP = G::LDP, MT = G::MT, NT = G::NT, PW = G::PW, PH = G::PH, TW = G::TW;
+    typedef typename HFrag<T>::V V;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    _Float16* wl = reinterpret_cast<_Float16*>(smem);                 // [CO/16][9][NPL][16 * T]  (the tiled table's own order)
+    _Float16* patch = wl + G::WHALFS;                                 // [NPL][PH * PW][LDP]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef LF_STAMPS     // diagnostic build only (tools/lf_stamps.sh): phase times of one workgroup, written over the first bytes of y
+    unsigned long long st[8];
+#define LF_STAMP(i) st[i] = __builtin_amdgcn_s_memrealtime()
+#else
+#define LF_STAMP(i)
+#endif
+    LF_STAMP(0);
+    const HaloCls& C = p.cls[0];
+    int t = (int)blockIdx.x;
+    int ry = 0, rx = 0;
+    if (p.dil > 1) {
+        const int per = C.tiles * p.B, rid = t / per;
+        t -= rid * per;
+        ry = rid / p.dil; rx = rid - ry * p.dil;
+    }
+    const int n_img = t / C.tiles;
+    t -= n_img * C.tiles;
+    const int tile_y = t / C.tiles_x, tile_x = t - tile_y * C.tiles_x;
+    const int i0 = tile_y * TH, j0 = tile_x * TW;
+    const int n_base = blockIdx.y * CO;
+    const int h0 = i0 + p.boff + C.dh_min, w0 = j0 + p.boff + C.dw_min;
+
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.w), 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
+
+    // ---- every load of the workgroup, issued before the first wait; plane by plane (a plane = T input channels of the filters and of the patch),
+    // so that the MFMAs of plane 0 run while plane 1 is still landing
+    constexpr int FB = 16 * T * 2, IPF = FB / 16;                                 // bytes / 16-byte items of one filter fragment
+    constexpr int WPI = ((CO / 16) * 9 * IPF + G::NTHR - 1) / G::NTHR;            // filter items per plane and thread
+    constexpr int PPI = (PH * PW * (T / 8) + G::NTHR - 1) / G::NTHR;              // patch items per plane and thread
+    u32x4 wreg[NPL][WPI], preg[NPL][PPI];
+    int plo[PPI];
+    unsigned pvo[PPI];
+    const unsigned wbase = (unsigned)(n_base / 16) * (unsigned)(16 * 9 * CIN * 2);
+    const unsigned xbase = (unsigned)(n_img * p.img_stride + p.x_coff) * 2u;
+#pragma unroll
+    for (int i = 0; i < PPI; ++i) {
+        const int e = tid + i * G::NTHR;
+        const int c8 = e % (T / 8), pix = e / (T / 8);
+        const int py = pix / PW, px = pix - py * PW;
+        const int hi = h0 + py, wi = w0 + px;
+        const bool in = pix < PH * PW;
+        plo[i] = in ? pix * LDP + c8 * 8 : -1;
+        pvo[i] = (in && (unsigned)hi < (unsigned)p.Hl && (unsigned)wi < (unsigned)p.Wl)
+                     ? xbase + (unsigned)((((ry + hi * p.dil) >> p.in_shift) * p.Wp + ((rx + wi * p.dil) >> p.in_shift)) * p.x_ld + c8 * 8) * 2u : HV_OOB;
+    }
+#pragma unroll
+    for (int kc = 0; kc < NPL; ++kc) {
+#pragma unroll
+        for (int i = 0; i < WPI; ++i) {
+            const int e = tid + i * G::NTHR;
+            wreg[kc][i] = __builtin_amdgcn_raw_buffer_load_b128(wsrc, e < (CO / 16) * 9 * IPF ? wbase + (unsigned)(((e / IPF) * NPL + kc) * FB + (e % IPF) * 16) : HV_OOB, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < PPI; ++i) preg[kc][i] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, pvo[i], kc * T * 2, 0);
+    }
+    // scalar tap table
+    int toff[9], widx[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        const uint32_t e = C.taps[q];
+        toff[q] = ((int)(e & 0xff) * PW + (int)((e >> 8) & 0xff)) * LDP;
+        widx[q] = (int)(e >> 16);
+    }
+    // bias (branch-free: lanes beyond Cout read zeros through the range check)
+    const __amdgpu_buffer_rsrc_t bsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.bias ? (unsigned)p.Cout * 4u : 0u, 0x00020000);
+    f32x4 bias_r[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+        bias_r[n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bsrc, (unsigned)(n_base + n * 16 + (lane >> 4) * 4) * 4u, 0, 0));
+    LF_STAMP(1);
+    // ---- MFMA loop: wave = MT pixel rows x CO channels
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int poff = (wave * MT * PW + (lane & 15)) * LDP + (lane >> 4) * (T / 4);
+    const int aoff = lane * (T / 4);
+    // per plane: its filters and patch rows -> LDS, one barrier, then a software pipeline over its 9 taps (the fragments of tap q + 1 are requested
+    // before the MFMAs of tap q)
+    V a[2][NT], b[2][MT];
+#pragma unroll
+    for (int kc = 0; kc < NPL; ++kc) {
+#pragma unroll
+        for (int i = 0; i < WPI; ++i) {
+            const int e = tid + i * G::NTHR;
+            if (e < (CO / 16) * 9 * IPF) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(wl) + ((e / IPF) * NPL + kc) * FB + (e % IPF) * 16) = wreg[kc][i];
+        }
+#pragma unroll
+        for (int i = 0; i < PPI; ++i)
+            if (plo[i] >= 0) *reinterpret_cast<u32x4*>(patch + kc * G::PLANE + plo[i]) = preg[kc][i];
+        __syncthreads();
+        if (kc == 0) { LF_STAMP(2); }
+        auto frags = [&](int q, int buf) __attribute__((always_inline)) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) a[buf][n] = *reinterpret_cast<const V*>(wl + ((n * 9 + widx[q]) * NPL + kc) * (16 * T) + aoff);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) b[buf][m] = *reinterpret_cast<const V*>(patch + kc * G::PLANE + poff + m * PW * LDP + toff[q]);
+        };
+        frags(0, 0);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            if (q + 1 < 9) frags(q + 1, (q + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);      // (the scheduler would sink the reads to their use)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[n][m] = HFrag<T>::mma(a[q & 1][n], b[q & 1][m], acc[n][m]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    LF_STAMP(3);
+    constexpr int PIECES = CO / 8;
+    constexpr int OITEMS = TH * TW * PIECES / G::NTHR;
+    static_assert(TH * TW * PIECES % G::NTHR == 0, "output pieces per thread");
+    const __amdgpu_buffer_rsrc_t msrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.mul_src), 0, p.mul_src ? 0x7ffffff0u : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ysrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.accumulate ? 0x7ffffff0u : 0u, 0x00020000);
+    // this thread's pieces of the act' multiplier and of the gradient buffer it adds to (data-gradient forms): requested now, they land behind the
+    // activation arithmetic of the staging pass
+    u32x4 mreg[OITEMS], yreg[OITEMS];
+    long long ooff[OITEMS];         // element offset of the piece in y (-1: outside the image / beyond Cout)
+#pragma unroll
+    for (int k = 0; k < OITEMS; ++k) {
+        const int it = tid + k * G::NTHR;
+        const int q = it / PIECES, pc = it - q * PIECES;
+        const int i = i0 + (q >> 4), j = j0 + (q & 15), ch = n_base + pc * 8;
+        const bool ok = i < C.Hc && j < C.Wc && ch < p.Cout;
+        const int ho = C.ph + ry + i * p.ostep, wo = C.pw + rx + j * p.ostep;
+        const long long opix = (long long)(n_img * p.Ho + ho) * p.Wo + wo;
+        ooff[k] = ok ? opix * p.y_ld + p.y_coff + ch : -1;
+        mreg[k] = __builtin_amdgcn_raw_buffer_load_b128(msrc, ok ? (unsigned)((opix * p.mul_ld + p.mul_coff + ch) * 2) : HV_OOB, 0, 0);
+        yreg[k] = __builtin_amdgcn_raw_buffer_load_b128(ysrc, ok ? (unsigned)(ooff[k] * 2) : HV_OOB, 0, 0);
+    }
+    __syncthreads();          // every wave is done with the patch: its room becomes the output staging tile
+
+    // ---- epilogue: (alpha, +bias, activation) -> fp16 tile in LDS -> 16-byte pieces (act' multiplier / accumulate forms applied there).
+    // The activation is chosen ONCE (scalar switch around the whole tile) and its body is branch-free: the shared per-element epilogue code of the
+    // other kernels (a scalar switch, range checks and a pointer path per value) is ~25 instructions x 32 values per lane here.
+    _Float16* ot = patch;
+    constexpr int LDO = G::LDO;
+    auto stage = [&](auto actf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int q = (wave * MT + m) * 16 + (lane & 15);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                f16x4v h;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h[r] = (_Float16)actf(acc[n][m][r] * p.alpha + bias_r[n][r]);
+                *reinterpret_cast<f16x4v*>(ot + q * LDO + n * 16 + (lane >> 4) * 4) = h;
+            }
+        }
+    };
+    switch (p.act) {
+        case HV_ACT_ELU:        // hv_act_fast's ELU as selects
+            stage([](float v) { const float e = __builtin_amdgcn_exp2f(v * 1.44269504f) - 1.f, sm = v + 0.5f * v * v; return v > 0.f ? v : (v > -0.00390625f ? sm : e); });
+            break;
+        case HV_ACT_RELU: stage([](float v) { return v > 0.f ? v : 0.f; }); break;
+        case HV_ACT_LRELU: stage([](float v) { return v > 0.f ? v : 0.2f * v; }); break;
+        case HV_ACT_SIGMOID: stage([](float v) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-v * 1.44269504f)); }); break;
+        case HV_ACT_CLAMP: stage([](float v) { return fminf(fmaxf(v, -1.f), 1.f); }); break;
+        default: stage([](float v) { return v; }); break;
+    }
+    __syncthreads();
+    LF_STAMP(4);
+    _Float16* yb = reinterpret_cast<_Float16*>(p.y);
+    u32x4 o[OITEMS];
+#pragma unroll
+    for (int k = 0; k < OITEMS; ++k) {
+        const int it = tid + k * G::NTHR;
+        const int q = it / PIECES, pc = it - q * PIECES;
+        o[k] = *reinterpret_cast<const u32x4*>(ot + q * LDO + pc * 8);
+    }
+    if (p.mul_src) {        // v * act'(m), m = the producer's fp16 output at the same pixel / channels (scalar switch around the tile, branch-free bodies)
+        auto mulf = [&](auto gradf) __attribute__((always_inline)) {
+#pragma unroll
+            for (int k = 0; k < OITEMS; ++k) {
+                const f16x8 m8 = __builtin_bit_cast(f16x8, mreg[k]);
+                f16x8 v8 = __builtin_bit_cast(f16x8, o[k]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v8[e] = (_Float16)((float)v8[e] * gradf((float)m8[e]));
+                o[k] = __builtin_bit_cast(u32x4, v8);
+            }
+        };
+        switch (p.mul_act) {
+            case HV_ACT_ELU: mulf([](float y) { return y > 0.f ? 1.f : y + 1.f; }); break;
+            case HV_ACT_RELU: mulf([](float y) { return y > 0.f ? 1.f : 0.f; }); break;
+            case HV_ACT_LRELU: mulf([](float y) { return y > 0.f ? 1.f : 0.2f; }); break;
+            case HV_ACT_SIGMOID: mulf([](float y) { return y * (1.f - y); }); break;
+            case HV_ACT_CLAMP: mulf([](float y) { return (y > -1.f && y < 1.f) ? 1.f : 0.f; }); break;
+            default: break;
+        }
+    }
+    if (p.accumulate) {
+#pragma unroll
+        for (int k = 0; k < OITEMS; ++k) {
+            const f16x8 y8 = __builtin_bit_cast(f16x8, yreg[k]);
+            f16x8 v8 = __builtin_bit_cast(f16x8, o[k]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v8[e] = (_Float16)((float)v8[e] + (float)y8[e]);
+            o[k] = __builtin_bit_cast(u32x4, v8);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < OITEMS; ++k)
+        if (ooff[k] >= 0) *reinterpret_cast<u32x4*>(yb + ooff[k]) = o[k];
+#ifdef LF_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);
+    LF_STAMP(5);
+    if (tid == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0) {
+        unsigned long long* d = reinterpret_cast<unsigned long long*>(p.y);
+        for (int i = 0; i < 6; ++i) d[i] = st[i];
+    }
+#endif
+}
+
+template <int CIN, int CO, int TH, int WPS>
+static int launch_lf(HaloK& k, hipStream_t s) {
+    typedef LfCfg<CIN, CO, TH> G;
+    static_assert(G::LDS_BYTES <= 160 * 1024, "filters + patch exceed the LDS");
+    HaloK kk = k;
+    HaloCls& C = kk.cls[0];
+    C.tiles_x = hv_cdiv(C.Wc, G::TW);
+    C.tiles = C.tiles_x * hv_cdiv(C.Hc, TH);
+    C.t0 = 0;
+    C.PH = G::PH; C.PW = G::PW;
+    kk.w = kk.wt; kk.w_bytes = kk.wt_bytes;
+    auto kern = conv_lf_kernel<CIN, CO, TH, WPS>;
+    static bool raised = false;
+    if (G::LDS_BYTES > 48 * 1024 && !raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return -1000 - (int)e;
+        raised = true;
+    }
+    dim3 grid(C.tiles * kk.B * (kk.dil > 1 ? kk.dil * kk.dil : 1), hv_cdiv(kk.Cout, CO));
+    hv_path_note = 6;
+    HV_KNAME("conv_lf_kernel<%d, %d, %d, %d>", CIN, CO, TH, WPS);
+    hipLaunchKernelGGL(kern, grid, dim3(G::NTHR), G::LDS_BYTES, s, kk);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+
+// 3x3 stride-1 layers (forward, or the data gradient = the same convolution with the transposed filter table) whose input and output are fp16
+// NHWC views with 16-byte aligned channel rows.  Returns HV_ERR_UNSUPPORTED for everything else (the caller goes on to conv_halo2_kernel).
+int hv_convlf_launch(HaloK& k, int KH, int KW, hipStream_t s) {
+    static const int on = getenv("HV_CONV_LF") ? atoi(getenv("HV_CONV_LF")) : 1;
+    if (!on || KH != 3 || KW != 3 || k.ncls != 1 || k.bstep != 1 || k.cls[0].ntaps != 9) return HV_ERR_UNSUPPORTED;
+    if (!k.wt || ((uintptr_t)k.wt & 15) || !k.x_half || !k.y_half || k.accumulate > 1) return HV_ERR_UNSUPPORTED;
+    if ((k.x_ld & 7) || (k.x_coff & 7) || ((uintptr_t)k.x & 15) || (k.Cout & 7) || (k.y_ld & 7) || (k.y_coff & 7) || ((uintptr_t)k.y & 15)) return HV_ERR_UNSUPPORTED;
+    if (k.mul_src && (!k.mul_half || (k.mul_ld & 7) || (k.mul_coff & 7) || ((uintptr_t)k.mul_src & 15))) return HV_ERR_UNSUPPORTED;
+    // the 3x3 taps must span dh, dw in 0..2 around (dh_min, dw_min) -- true for pad-1 forward and its data gradient
+    const int Cin = k.Cin, Cout = k.Cout;
+    // HV_CONV_LF_MASK: bit per (Cin class 16 / 32 / 64) x (Cout class <= 16 / <= 32 / > 32), an A/B knob
+    static const int mask = getenv("HV_CONV_LF_MASK") ? atoi(getenv("HV_CONV_LF_MASK")) : 0x1ff;
+    const int ci = Cin == 16 ? 0 : Cin == 32 ? 1 : Cin == 64 ? 2 : -1, co = Cout <= 16 ? 0 : Cout <= 32 ? 1 : 2;
+    if (ci < 0 || !((mask >> (ci * 3 + co)) & 1)) return HV_ERR_UNSUPPORTED;
+    switch (ci * 3 + co) {
+        case 0: return launch_lf<16, 16, 16, 4>(k, s);
+        case 1: return launch_lf<16, 32, 16, 4>(k, s);
+        case 2: return HV_ERR_UNSUPPORTED;      // (no such layer)
+        case 3: return launch_lf<32, 16, 16, 4>(k, s);
+        case 4: return launch_lf<32, 32, 16, 4>(k, s);
+        case 5: return launch_lf<32, 64, 16, 4>(k, s);
+        case 6: return launch_lf<64, 16, 16, 2>(k, s);
+        case 7: return launch_lf<64, 32, 16, 2>(k, s);
+        default: return launch_lf<64, 64, 16, 2>(k, s);
+    }
+    return HV_ERR_UNSUPPORTED;
+}
