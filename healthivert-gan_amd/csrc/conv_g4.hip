@@ -1,0 +1,358 @@
+// 4x4 stride-2 convolution and its data gradient (the PatchGAN / U-Net down-sampling layers) as a pipelined implicit GEMM.
+//
+// These layers are GEMM-sized (64 -> 128 @128^2: M = 65 536 output pixels, N = 128, K = 1 024; 17.2 GFLOP per launch at bs 16) but ran at 12-21 % of
+// the fp16 MFMA peak: conv_halo_kernel / conv_halo2_kernel stage a stride-2 patch (18 x 34 pixels for 8 x 16 outputs, 4x the pixels of a stride-1
+// patch) per 32-channel chunk, read MFMA B fragments at a pixel stride of 2 and fetch a 64-128 KB filter slice per 128-pixel tile.  Here
+//   forward (MODE 0): the convolution is read as a 2x2-tap STRIDE-1 convolution over the space-to-depth view x'[r][c][(dy, dx, ch)] =
+//     x[2r - 1 + dy][2c - 1 + dx][ch] (never materialised: a 32-channel chunk of x' is a 64-byte piece of one real pixel), so a K-chunk's patch is
+//     (TH + 1) x (TW + 1) pixels and fragments are unit-stride;
+//   data gradient (MODE 1): the four output-parity classes are 2x2-tap stride-1 convolutions over the SAME gradient patch; a workgroup computes two
+//     (class, 64-channel) slots, every wave one slot;
+//   both: a workgroup of 8 waves owns TH x 16 pixels x 128 GEMM columns (8 row blocks of the fragment-ordered filter table); K runs in chunks of
+//     32 operand channels x 4 taps; per chunk the 32 KB filter slice and the patch go global -> registers -> LDS, double-buffered, the loads of chunk
+//     c + 1 in flight behind the MFMAs of chunk c, one barrier per chunk; a wave computes (TH/4 rows x 16 pixels) x 64 columns: 4 A + TH/4 B fragment
+//     reads per TH MFMAs; the fp16 output tile leaves through LDS as 16-byte pieces.
+// Optional epilogue: per-channel sum / sum of squares of the (fp16-rounded) outputs of the workgroup's tile (hv_conv_desc.stats), the BatchNorm
+// statistics the separate reduction pass used to re-read the tensor for.
+#include <stdlib.h>
+
+#include "conv_halo.h"
+
+struct G4K {
+    const void* x; const _Float16* w; const float* bias; void* y; const void* mul_src;
+    float* stats;                              // [tiles_total][Cstat][2] partial sums (or NULL)
+    int B, H, W, x_ld, x_coff, Cin;            // operand tensor (forward: x, data gradient: g) and its channel count (the GEMM's K source)
+    int Ho, Wo, y_ld, y_coff, Cout;
+    int mul_ld, mul_coff, mul_act, act, accumulate;
+    float alpha;
+    int tiles_x, tiles;                        // tiles per image on the low-resolution grid (forward: outputs; data gradient: g pixels)
+    int Hc, Wc;                                // extent of that grid
+    unsigned x_bytes, w_bytes, w_rb;           // w_rb: bytes of one 16-row block of the filter table
+};
+
+template <int MODE, int MT>
+__global__ __launch_bounds__(512, 2) void conv_g4_kernel(const G4K p) {
+    constexpr int TW = 16, TH = 4 * MT, NTHR = 512;
+    constexpr int PH = TH + 1 + MODE, PW = TW + 1 + MODE, LDP = 48;            // 96-byte patch pixel rows
+    constexpr int PITEMS = (PH * PW * 4 + NTHR - 1) / NTHR;
+    constexpr int ABUF = 32 * 512;                                            // halfs: 8 row blocks x 4 taps x (16 x 32) fragment
+    constexpr int BBUF = PH * PW * LDP;
+    constexpr int LDO = 128 + 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    _Float16* As = reinterpret_cast<_Float16*>(smem);                         // [2][ABUF]
+    _Float16* Bs = As + 2 * ABUF;                                             // [2][BBUF]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int t = (int)blockIdx.x;
+    const int n_img = t / p.tiles;
+    t -= n_img * p.tiles;
+    const int tile_y = t / p.tiles_x, tile_x = t - tile_y * p.tiles_x;
+    const int i0 = tile_y * TH, j0 = tile_x * TW;
+    const int Cin = p.Cin, KC = Cin >> 5;
+    const int NCH = MODE == 0 ? 4 * KC : KC;
+
+    // the two 64-column slots of the workgroup: forward = output channels n_base + 64 wn; data gradient = (parity class, channel block) pairs
+    int cls_s[2], cob_s[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        if (MODE == 0) { cls_s[s] = 0; cob_s[s] = (int)blockIdx.y * 128 + s * 64; }
+        else {
+            const int nco = p.Cout >> 6, sl = (int)blockIdx.y * 2 + s;
+            cls_s[s] = sl / nco; cob_s[s] = (sl - cls_s[s] * nco) * 64;
+        }
+    }
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.w), 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
+
+    // ---- patch staging items of this thread (chunk-independent part)
+    int plo[PITEMS], pbase[PITEMS], pval[PITEMS];
+    const int xbase = (n_img * p.H * p.W * p.x_ld + p.x_coff) * 2;
+#pragma unroll
+    for (int i = 0; i < PITEMS; ++i) {
+        const int e = tid + i * NTHR;
+        const int pix = e >> 2, c8 = e & 3;
+        const int pr = pix / PW, pc = pix - pr * PW;
+        const bool in = pix < PH * PW;
+        plo[i] = in ? pix * LDP + c8 * 8 : -1;
+        if (MODE == 0) {
+            const int r0 = 2 * (i0 + pr) - 1, c0 = 2 * (j0 + pc) - 1;
+            pbase[i] = xbase + ((r0 * p.W + c0) * p.x_ld + c8 * 8) * 2;
+            int v = 0;
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd)
+                if (in && (unsigned)(r0 + (dd >> 1)) < (unsigned)p.H && (unsigned)(c0 + (dd & 1)) < (unsigned)p.W) v |= 1 << dd;
+            pval[i] = v;
+        } else {
+            const int r0 = i0 - 1 + pr, c0 = j0 - 1 + pc;
+            pbase[i] = xbase + ((r0 * p.W + c0) * p.x_ld + c8 * 8) * 2;
+            pval[i] = (in && (unsigned)r0 < (unsigned)p.H && (unsigned)c0 < (unsigned)p.W) ? 15 : 0;
+        }
+    }
+    u32x4 areg[4], breg[PITEMS];
+    auto issue = [&](int c) __attribute__((always_inline)) {
+        int dy = 0, dx = 0, kc = c;
+        if (MODE == 0) { dy = c / (2 * KC); const int rem = c - dy * 2 * KC; dx = rem / KC; kc = rem - dx * KC; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = wave + 8 * i, rbw = f >> 2, tt = f & 3, s = rbw >> 2;
+            int rb, tap;
+            if (MODE == 0) { rb = (cob_s[s] >> 4) + (rbw & 3); tap = (2 * (tt >> 1) + dy) * 4 + 2 * (tt & 1) + dx; }
+            else { rb = (cob_s[s] >> 4) + (rbw & 3); const int py = cls_s[s] >> 1, px = cls_s[s] & 1; tap = (1 - py + 2 * (tt >> 1)) * 4 + (1 - px + 2 * (tt & 1)); }
+            areg[i] = __builtin_amdgcn_raw_buffer_load_b128(wsrc, (unsigned)lane * 16u, rb * (int)p.w_rb + (tap * Cin + kc * 32) * 32, 0);
+        }
+        const int coff = MODE == 0 ? ((dy * p.W + dx) * p.x_ld + kc * 32) * 2 : kc * 64;
+        const int vb = MODE == 0 ? dy * 2 + dx : 0;
+#pragma unroll
+        for (int i = 0; i < PITEMS; ++i)
+            breg[i] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, ((pval[i] >> vb) & 1) ? (unsigned)(pbase[i] + coff) : HV_OOB, 0, 0);
+    };
+    auto flush = [&](int b) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(As + b * ABUF + (wave + 8 * i) * 512 + lane * 8) = areg[i];
+#pragma unroll
+        for (int i = 0; i < PITEMS; ++i)
+            if (plo[i] >= 0) *reinterpret_cast<u32x4*>(Bs + b * BBUF + plo[i]) = breg[i];
+    };
+
+    // tap offsets inside the patch for this wave's slot
+    int toff[4];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+        int dh, dw;
+        if (MODE == 0) { dh = tt >> 1; dw = tt & 1; }
+        else { const int py = cls_s[wn] >> 1, px = cls_s[wn] & 1; dh = py - (tt >> 1) + 1; dw = px - (tt & 1) + 1; }
+        toff[tt] = (dh * PW + dw) * LDP;
+    }
+    f32x4 acc[4][MT];
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int poff = (wm * MT * PW + (lane & 15)) * LDP + (lane >> 4) * 8;
+    const int aoff = (wn * 16) * 512 + lane * 8;
+
+    issue(0);
+    flush(0);
+    __syncthreads();
+    f16x8 a[2][4], bf[2][MT];
+    for (int c = 0; c < NCH; ++c) {
+        const _Float16* Ab = As + (c & 1) * ABUF + aoff;
+        const _Float16* Bb = Bs + (c & 1) * BBUF + poff;
+        if (c + 1 < NCH) issue(c + 1);
+        auto frags = [&](int tt, int buf) __attribute__((always_inline)) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n) a[buf][n] = *reinterpret_cast<const f16x8*>(Ab + (n * 4 + tt) * 512);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) bf[buf][m] = *reinterpret_cast<const f16x8*>(Bb + m * PW * LDP + toff[tt]);
+        };
+        frags(0, 0);
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            if (tt + 1 < 4) frags(tt + 1, (tt + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[tt & 1][n], bf[tt & 1][m], acc[n][m], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (c + 1 < NCH) flush((c + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: this thread's output pieces (act' multiplier, old gradient) requested first, then (alpha, +bias, activation) -> fp16 tile in
+    // LDS -> 16-byte pieces
+    constexpr int OITEMS = TH * TW * 16 / NTHR;
+    const __amdgpu_buffer_rsrc_t msrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.mul_src), 0, p.mul_src ? 0x7ffffff0u : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ysrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.accumulate ? 0x7ffffff0u : 0u, 0x00020000);
+    u32x4 mreg[OITEMS], yreg[OITEMS];
+    long long ooff[OITEMS];
+#pragma unroll
+    for (int k = 0; k < OITEMS; ++k) {
+        const int it = tid + k * NTHR;
+        const int q = it >> 4, pc = it & 15, s = pc >> 3;
+        const int i = i0 + (q >> 4), j = j0 + (q & 15);
+        const int ch = cob_s[s] + (pc & 7) * 8;
+        const bool ok = i < p.Hc && j < p.Wc && ch < p.Cout;
+        int ho = i, wo = j;
+        if (MODE == 1) { ho = 2 * i + (cls_s[s] >> 1); wo = 2 * j + (cls_s[s] & 1); }
+        const long long opix = (long long)(n_img * p.Ho + ho) * p.Wo + wo;
+        ooff[k] = ok ? opix * p.y_ld + p.y_coff + ch : -1;
+        mreg[k] = __builtin_amdgcn_raw_buffer_load_b128(msrc, ok ? (unsigned)((opix * p.mul_ld + p.mul_coff + ch) * 2) : HV_OOB, 0, 0);
+        yreg[k] = __builtin_amdgcn_raw_buffer_load_b128(ysrc, ok ? (unsigned)(ooff[k] * 2) : HV_OOB, 0, 0);
+    }
+    const __amdgpu_buffer_rsrc_t bsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.bias ? (unsigned)p.Cout * 4u : 0u, 0x00020000);
+    f32x4 bias_r[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+        bias_r[n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bsrc, (unsigned)(cob_s[wn] + n * 16 + (lane >> 4) * 4) * 4u, 0, 0));
+    _Float16* ot = As;         // the whole LDS is free behind the loop's last barrier: [TH * TW][LDO]
+    auto stage = [&](auto actf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int q = (wm * MT + m) * 16 + (lane & 15);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                f16x4v h;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h[r] = (_Float16)actf(acc[n][m][r] * p.alpha + bias_r[n][r]);
+                *reinterpret_cast<f16x4v*>(ot + q * LDO + wn * 64 + n * 16 + (lane >> 4) * 4) = h;
+            }
+        }
+    };
+    switch (p.act) {
+        case HV_ACT_ELU:
+            stage([](float v) { const float e = __builtin_amdgcn_exp2f(v * 1.44269504f) - 1.f, sm = v + 0.5f * v * v; return v > 0.f ? v : (v > -0.00390625f ? sm : e); });
+            break;
+        case HV_ACT_RELU: stage([](float v) { return v > 0.f ? v : 0.f; }); break;
+        case HV_ACT_LRELU: stage([](float v) { return v > 0.f ? v : 0.2f * v; }); break;
+        case HV_ACT_SIGMOID: stage([](float v) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-v * 1.44269504f)); }); break;
+        case HV_ACT_CLAMP: stage([](float v) { return fminf(fmaxf(v, -1.f), 1.f); }); break;
+        default: stage([](float v) { return v; }); break;
+    }
+    __syncthreads();
+    _Float16* yb = reinterpret_cast<_Float16*>(p.y);
+    u32x4 o[OITEMS];
+#pragma unroll
+    for (int k = 0; k < OITEMS; ++k) {
+        const int it = tid + k * NTHR;
+        o[k] = *reinterpret_cast<const u32x4*>(ot + (it >> 4) * LDO + (it & 15) * 8);
+    }
+    if (MODE == 0 && p.stats) {
+        // BatchNorm statistics of this tile: thread (q-lane, piece) sums its OITEMS pixels' 8 channels (piece = it & 15 is the same for all of a
+        // thread's items), then the 32 threads that share a piece are folded through LDS; invalid pixels / channels contribute zeros
+        float s1[8], s2[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+#pragma unroll
+        for (int k = 0; k < OITEMS; ++k) {
+            if (ooff[k] < 0) continue;
+            const f16x8 v8 = __builtin_bit_cast(f16x8, o[k]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float v = (float)v8[e]; s1[e] += v; s2[e] += v * v; }
+        }
+        __syncthreads();                       // the staging tile has been read into registers by every thread
+        float* red = reinterpret_cast<float*>(smem);       // [32 rows][16 pieces][16]
+        float* mine = red + ((tid >> 4) * 16 + (tid & 15)) * 16;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { mine[e] = s1[e]; mine[8 + e] = s2[e]; }
+        __syncthreads();
+        if (tid < 256) {      // 128 channels x {sum, sum of squares}
+            const int pc = tid >> 4, e = tid & 15;
+            float s = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < 32; ++r) s += red[(r * 16 + pc) * 16 + e];
+            const int ch = (int)blockIdx.y * 128 + pc * 8 + (e & 7);
+            if (ch < p.Cout) p.stats[((long long)blockIdx.x * p.Cout + ch) * 2 + (e >> 3)] = s;
+        }
+    }
+    if (p.mul_src) {
+        auto mulf = [&](auto gradf) __attribute__((always_inline)) {
+#pragma unroll
+            for (int k = 0; k < OITEMS; ++k) {
+                const f16x8 m8 = __builtin_bit_cast(f16x8, mreg[k]);
+                f16x8 v8 = __builtin_bit_cast(f16x8, o[k]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v8[e] = (_Float16)((float)v8[e] * gradf((float)m8[e]));
+                o[k] = __builtin_bit_cast(u32x4, v8);
+            }
+        };
+        switch (p.mul_act) {
+            case HV_ACT_ELU: mulf([](float y) { return y > 0.f ? 1.f : y + 1.f; }); break;
+            case HV_ACT_RELU: mulf([](float y) { return y > 0.f ? 1.f : 0.f; }); break;
+            case HV_ACT_LRELU: mulf([](float y) { return y > 0.f ? 1.f : 0.2f; }); break;
+            case HV_ACT_SIGMOID: mulf([](float y) { return y * (1.f - y); }); break;
+            case HV_ACT_CLAMP: mulf([](float y) { return (y > -1.f && y < 1.f) ? 1.f : 0.f; }); break;
+            default: break;
+        }
+    }
+    if (p.accumulate) {
+#pragma unroll
+        for (int k = 0; k < OITEMS; ++k) {
+            const f16x8 y8 = __builtin_bit_cast(f16x8, yreg[k]);
+            f16x8 v8 = __builtin_bit_cast(f16x8, o[k]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v8[e] = (_Float16)((float)v8[e] + (float)y8[e]);
+            o[k] = __builtin_bit_cast(u32x4, v8);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < OITEMS; ++k)
+        if (ooff[k] >= 0) *reinterpret_cast<u32x4*>(yb + ooff[k]) = o[k];
+}
+
+template <int MODE, int MT>
+static int launch_g4(G4K& k, int ny, hipStream_t s) {
+    constexpr int TH = 4 * MT, PH = TH + 1 + MODE, PW = 17 + MODE;
+    constexpr size_t lds_loop = (size_t)(2 * 32 * 512 + 2 * PH * PW * 48) * 2, lds_out = (size_t)TH * 16 * 136 * 2, lds_red = 32 * 16 * 16 * 4;
+    constexpr size_t lds = lds_loop > lds_out ? (lds_loop > lds_red ? lds_loop : lds_red) : (lds_out > lds_red ? lds_out : lds_red);
+    static_assert(lds <= 160 * 1024, "LDS");
+    k.tiles_x = hv_cdiv(k.Wc, 16);
+    k.tiles = k.tiles_x * hv_cdiv(k.Hc, TH);
+    auto kern = conv_g4_kernel<MODE, MT>;
+    static bool raised = false;
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return -1000 - (int)e;
+        raised = true;
+    }
+    hv_path_note = 8;
+    HV_KNAME("conv_g4_kernel<%d, %d>", MODE, MT);
+    hipLaunchKernelGGL(kern, dim3(k.tiles * k.B, ny), dim3(512), lds, s, k);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+
+// workgroups of a launch and floats of its statistics output (hv_conv2d_stats_floats)
+static int g4_tile_rows(int B, int Hc, int Wc, int ny) {
+    static const int force = getenv("HV_G4_MT") ? atoi(getenv("HV_G4_MT")) : 0;
+    if (force == 2 || force == 4) return 4 * force;
+    return (long long)B * hv_cdiv(Hc, 16) * hv_cdiv(Wc, 16) * ny >= 200 ? 16 : 8;
+}
+
+// 4x4, stride 2, pad 1, dilation 1, fp16 NHWC views with 16-byte aligned channel rows, fragment-ordered filters.  HV_ERR_UNSUPPORTED otherwise.
+int hv_conv2d_g4(const hv_conv_desc* d, hipStream_t s) {
+    static const int on = getenv("HV_CONV_G4") ? atoi(getenv("HV_CONV_G4")) : 3;      // bit 0: forward, bit 1: data gradient
+    if (!(on & (d->transposed ? 2 : 1))) return HV_ERR_UNSUPPORTED;
+    if (d->KH != 4 || d->KW != 4 || d->stride != 2 || d->pad != 1 || d->dil != 1 || d->in_shift || d->w_bstride || d->ch_scale) return HV_ERR_UNSUPPORTED;
+    if (d->precision != HV_F16 || !d->w_f16_tiled || !d->x_f16 || !d->y_f16 || d->accumulate > 1) return HV_ERR_UNSUPPORTED;
+    if ((d->Cin & 31) || (d->Cout & 63) || (!d->transposed && (d->Cout & 127))) return HV_ERR_UNSUPPORTED;
+    if ((d->x_ld & 7) || (d->x_coff & 7) || ((uintptr_t)d->x & 15) || (d->y_ld & 7) || (d->y_coff & 7) || ((uintptr_t)d->y & 15) || ((uintptr_t)d->w_f16_tiled & 15))
+        return HV_ERR_UNSUPPORTED;
+    if (d->mul_src && (!d->mul_f16 || (d->mul_ld & 7) || (d->mul_coff & 7) || ((uintptr_t)d->mul_src & 15))) return HV_ERR_UNSUPPORTED;
+    if (!d->transposed && (d->Ho != d->H / 2 || d->Wo != d->W / 2 || (d->H & 1) || (d->W & 1))) return HV_ERR_UNSUPPORTED;
+    if (d->transposed && (d->Ho != 2 * d->H || d->Wo != 2 * d->W)) return HV_ERR_UNSUPPORTED;
+    if ((long long)d->B * d->H * d->W * d->x_ld >= (1ll << 30) || (long long)d->B * d->Ho * d->Wo * d->y_ld >= (1ll << 30)) return HV_ERR_UNSUPPORTED;
+    G4K k;
+    k.x = d->x; k.w = reinterpret_cast<const _Float16*>(d->w_f16_tiled); k.bias = d->bias; k.y = d->y; k.mul_src = d->mul_src;
+    k.stats = d->transposed ? nullptr : d->stats;
+    k.B = d->B; k.H = d->H; k.W = d->W; k.x_ld = d->x_ld; k.x_coff = d->x_coff; k.Cin = d->Cin;
+    k.Ho = d->Ho; k.Wo = d->Wo; k.y_ld = d->y_ld; k.y_coff = d->y_coff; k.Cout = d->Cout;
+    k.mul_ld = d->mul_ld; k.mul_coff = d->mul_coff; k.mul_act = d->mul_act; k.act = d->act; k.accumulate = d->accumulate; k.alpha = d->alpha;
+    k.x_bytes = (unsigned)((size_t)d->B * d->H * d->W * d->x_ld * 2);
+    k.w_rb = (unsigned)(16 * 16 * d->Cin * 2);
+    k.w_bytes = (unsigned)((size_t)hv_cdiv(d->Cout, 16) * k.w_rb);
+    if (!d->transposed) {
+        k.Hc = d->Ho; k.Wc = d->Wo;
+        const int ny = d->Cout / 128;
+        return g4_tile_rows(d->B, k.Hc, k.Wc, ny) == 16 ? launch_g4<0, 4>(k, ny, s) : launch_g4<0, 2>(k, ny, s);
+    }
+    k.Hc = d->H; k.Wc = d->W;
+    const int ny = 2 * (d->Cout / 64);
+    return g4_tile_rows(d->B, k.Hc, k.Wc, ny) == 16 ? launch_g4<1, 4>(k, ny, s) : launch_g4<1, 2>(k, ny, s);
+}
+
+// floats of the statistics partials hv_conv2d writes for this descriptor when d->stats is set: [workgroups along x][Cout][2]; 0 = this shape's
+// kernel has no statistics epilogue (the caller runs its reduction pass)
+size_t hv_conv2d_g4_stats_floats(const hv_conv_desc* d, int* nparts) {
+    hv_conv_desc t = *d;
+    if (t.transposed || t.KH != 4 || t.KW != 4 || t.stride != 2 || t.pad != 1 || t.dil != 1 || t.in_shift || t.w_bstride || t.ch_scale) return 0;
+    if (t.precision != HV_F16 || !t.w_f16_tiled || !t.x_f16 || !t.y_f16 || t.accumulate || (t.Cin & 31) || (t.Cout & 127)) return 0;
+    static const int on = getenv("HV_CONV_G4") ? atoi(getenv("HV_CONV_G4")) : 3;
+    if (!(on & 1) || (t.H & 1) || (t.W & 1)) return 0;
+    const int th = g4_tile_rows(t.B, t.Ho, t.Wo, t.Cout / 128);
+    const int parts = t.B * hv_cdiv(t.Ho, th) * hv_cdiv(t.Wo, 16);
+    if (nparts) *nparts = parts;
+    return (size_t)parts * t.Cout * 2;
+}

@@ -176,6 +176,13 @@ static bool head_ok(const hv_conv_desc* d) {
 }
 
 // bytes of hv_conv_desc.workspace the single-output-channel path needs for this convolution (0: it does not apply)
+size_t hv_conv2d_g4_stats_floats(const hv_conv_desc* d, int* nparts);   // conv_g4.hip
+extern "C" size_t hv_conv2d_stats_parts(const hv_conv_desc* d) {
+    int parts = 0;
+    if (!d || !hv_conv2d_g4_stats_floats(d, &parts)) return 0;
+    return (size_t)parts;
+}
+
 extern "C" size_t hv_conv2d_workspace_bytes(const hv_conv_desc* d) {
     if (!d || !head_ok(d)) return 0;
     return (size_t)d->B * d->H * d->W * 16 * sizeof(float);

@@ -284,7 +284,7 @@ static int launch_lf(HaloK& k, hipStream_t s) {
         raised = true;
     }
     dim3 grid(C.tiles * kk.B * (kk.dil > 1 ? kk.dil * kk.dil : 1), hv_cdiv(kk.Cout, CO));
-    hv_path_note = 6;
+    hv_path_note = 7;
     HV_KNAME("conv_lf_kernel<%d, %d, %d, %d>", CIN, CO, TH, WPS);
     hipLaunchKernelGGL(kern, grid, dim3(G::NTHR), G::LDS_BYTES, s, kk);
     HV_LAUNCH_CHECK();

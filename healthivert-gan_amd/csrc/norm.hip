@@ -144,9 +144,10 @@ __global__ __launch_bounds__(256) void norm_reduce_kernel(const NormK k, double*
 
 // one wave per channel; groups are visited in order so that several batch-norm groups in one launch (fake | real halves of a
 // discriminator batch) update the running statistics exactly like consecutive forward calls
+// fpart != NULL: the sums come from the producing conv's epilogue (hv_conv_desc.stats: [nchunk][C][2] floats, G == 1) instead of norm_reduce_kernel
 __global__ void norm_fwd_finalize_kernel(const double* __restrict__ part, int G, int nchunk, int C, int R, float eps, float momentum,
                                          float* __restrict__ stats, float* running_mean, float* running_var, long long* nbt,
-                                         int use_running, int update_running) {
+                                         int use_running, int update_running, const float* __restrict__ fpart) {
     const int c = blockIdx.x;
     if (c >= C) return;
     for (int g = 0; g < G; ++g) {
@@ -158,9 +159,16 @@ __global__ void norm_fwd_finalize_kernel(const double* __restrict__ part, int G,
             continue;
         }
         double s = 0, q = 0;
-        for (int k = threadIdx.x; k < nchunk; k += 64) {
-            s += part[((long long)g * nchunk + k) * 2 * C + c];
-            q += part[((long long)g * nchunk + k) * 2 * C + C + c];
+        if (fpart) {
+            for (int k = threadIdx.x; k < nchunk; k += 64) {
+                const float2 v = *reinterpret_cast<const float2*>(fpart + ((long long)k * C + c) * 2);
+                s += v.x; q += v.y;
+            }
+        } else {
+            for (int k = threadIdx.x; k < nchunk; k += 64) {
+                s += part[((long long)g * nchunk + k) * 2 * C + c];
+                q += part[((long long)g * nchunk + k) * 2 * C + C + c];
+            }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
@@ -242,7 +250,7 @@ extern "C" int hv_norm_act_forward(const hv_norm_desc* d, void* stream) {
     const bool use_running = d->norm == HV_NORM_BATCH && !d->training;
     if (use_running && (!d->running_mean || !d->running_var)) return HV_ERR_ARG;
     const size_t need = (size_t)pl.G * pl.nchunk * 2 * d->C * sizeof(double);
-    if (!use_running && (!d->workspace || d->workspace_bytes < need || ((uintptr_t)d->workspace & 7))) return HV_ERR_WORKSPACE;
+    if (!use_running && !(d->partials && d->n_partials > 0) && (!d->workspace || d->workspace_bytes < need || ((uintptr_t)d->workspace & 7))) return HV_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     NormK k = {};
     k.x = d->x; k.out = d->y; k.x_ld = d->x_ld; k.x_coff = d->x_coff; k.o_ld = d->y_ld; k.o_coff = d->y_coff;
@@ -250,7 +258,9 @@ extern "C" int hv_norm_act_forward(const hv_norm_desc* d, void* stream) {
     k.CB = pl.CB; k.lc = n_log2(vec ? d->C / 4 : d->C);
     k.stats = d->stats; k.gamma = d->norm == HV_NORM_BATCH ? d->gamma : nullptr; k.beta = d->beta;
     double* part = (double*)d->workspace;
-    if (!use_running) {
+    // statistics handed over by the producing conv (hv_conv_desc.stats): no reduction pass over x
+    const bool handed = d->partials && d->n_partials > 0 && d->norm == HV_NORM_BATCH && !use_running && pl.G == 1;
+    if (!use_running && !handed) {
         dim3 grid(pl.nchunk, pl.G, pl.slices);
         if (d->f16) {
             if (vec) hipLaunchKernelGGL((norm_reduce_kernel<0, true, true>), grid, dim3(256), 0, s, k, part);
@@ -262,8 +272,9 @@ extern "C" int hv_norm_act_forward(const hv_norm_desc* d, void* stream) {
         HV_LAUNCH_CHECK();
     }
     const int update = d->norm == HV_NORM_BATCH && d->training && d->running_mean && d->running_var;
-    hipLaunchKernelGGL(norm_fwd_finalize_kernel, dim3(d->C), dim3(64), 0, s, part, pl.G, pl.nchunk, d->C, pl.R,
-                       d->eps, d->momentum, d->stats, d->running_mean, d->running_var, d->num_batches_tracked, use_running ? 1 : 0, update);
+    hipLaunchKernelGGL(norm_fwd_finalize_kernel, dim3(d->C), dim3(64), 0, s, part, pl.G, handed ? d->n_partials : pl.nchunk, d->C, pl.R,
+                       d->eps, d->momentum, d->stats, d->running_mean, d->running_var, d->num_batches_tracked, use_running ? 1 : 0, update,
+                       handed ? d->partials : nullptr);
     HV_LAUNCH_CHECK();
     const long long n = (long long)pl.R * (vec ? d->C / 4 : d->C);
     const dim3 agrid(apply_grid(n, pl.G), pl.G);

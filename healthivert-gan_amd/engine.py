@@ -150,11 +150,14 @@ class ParamSet:
 
 class ConvNode:
     """conv (+bias +activation) between two NHWC views; knows how to run forward and backward."""
-    __slots__ = ('p', 'x', 'y', 'k', 's', 'pad', 'd', 'act', 'shift', 'need_dx', 'transposed', 'use_bias')
+    __slots__ = ('p', 'x', 'y', 'k', 's', 'pad', 'd', 'act', 'shift', 'need_dx', 'transposed', 'use_bias', 'dx_c')
 
-    def __init__(self, p, x, y, s=1, pad=0, d=1, act='none', shift=0, need_dx=True, transposed=False, use_bias=True):
+    def __init__(self, p, x, y, s=1, pad=0, d=1, act='none', shift=0, need_dx=True, transposed=False, use_bias=True, dx_c=None):
         self.p, self.x, self.y, self.k, self.s, self.pad, self.d = p, x, y, p.k, s, pad, d
         self.act, self.shift, self.need_dx, self.transposed, self.use_bias = act, shift, need_dx, transposed, use_bias
+        # dx_c: only the first dx_c input channels' gradient is wanted (a concat input whose tail channels are network inputs): the data
+        # gradient is then a convolution with fewer output channels (the first dx_c rows of the transposed filter table)
+        self.dx_c = dx_c
 
     def forward(self, prec):
         p = self.p
@@ -271,7 +274,7 @@ def conv_backward(node, book, prec, dbias_accumulate=False, wgrad_accumulate=Fal
         ops.conv2d(gfull, p.w_bwd, gx, node.k, node.s, node.pad, node.d, transposed=False, accumulate=int(book.mark(gx)), precision=prec, w_h=p.w_bwd_h, w_t=p.w_bwd_t)
     elif node.need_dx:
         gx = book.twin(node.x)
-        gx = Act(gx.t, p.cin_fwd, gx.coff)
+        gx = Act(gx.t, node.dx_c or p.cin_fwd, gx.coff)
         if node.shift:
             full = tmp_full
             ops.conv2d(gfull, p.w_bwd, full, node.k, node.s, node.pad, node.d, transposed=True, precision=prec, w_h=p.w_bwd_h, w_t=p.w_bwd_t)

@@ -238,10 +238,10 @@ class _GenPlan:
             N(P['coarse_generator.conv10_atrous'], a['c9'], a['c10'], 1, 16, 16, 'elu'),
             N(P['coarse_generator.conv11'], a['c10'], a['c11'], 1, 1, 1, 'elu'),
             N(P['coarse_generator.conv12'], a['c11'], a['c12'], 1, 1, 1, 'elu'),
-            N(P['coarse_generator.conv20'], a['cat20'], a['c20'], 1, 1, 1, 'elu'),
+            N(P['coarse_generator.conv20'], a['cat20'], a['c20'], 1, 1, 1, 'elu', dx_c=4 * c),      # (the CAM channel is an input: no gradient)
             N(P['coarse_generator.conv13'], a['c20'], a['c13'], 1, 1, 1, 'elu'),
             N(P['coarse_generator.conv14'], a['c13'], a['c14'], 1, 1, 1, 'elu'),
-            N(P['coarse_generator.conv19'], a['cat19'], a['c19'], 1, 1, 1, 'elu'),
+            N(P['coarse_generator.conv19'], a['cat19'], a['c19'], 1, 1, 1, 'elu', dx_c=2 * c),
             N(P['coarse_generator.conv15'], a['c19'], a['c15'], 1, 1, 1, 'elu'),
             N(P['coarse_generator.conv16'], a['c15'], a['c16'], 1, 1, 1, 'elu'),
             N(P['coarse_generator.conv17'], a['c16'], xs1, 1, 1, 1, 'clamp'),

@@ -95,9 +95,14 @@ typedef struct {
                                       /* optional scratch (16-byte aligned) of hv_conv2d_workspace_bytes(d) bytes: enables the two-kernel path for
                                          Cout == 1 with many input channels (PatchGAN logits, data gradient of the 1-channel stem), which
                                          streams x once into a [pixel][tap] table and sums the taps afterwards.  NULL = other kernels */
+    float* stats;                     /* optional: per-channel partial sums of the OUTPUT as stored (fp16-rounded, after act), written by the conv's own
+                                         epilogue: stats[(part * Cout + c) * 2 + {0: sum, 1: sum of squares}] for part < hv_conv2d_stats_parts(d).
+                                         Feeds hv_norm_desc.partials (BatchNorm statistics without a reduction pass over the tensor).  Only the
+                                         kernels that hv_conv2d_stats_parts reports (> 0) write it; NULL = not wanted */
 } hv_conv_desc;
 int hv_conv2d(const hv_conv_desc* d, void* stream);
 size_t hv_conv2d_workspace_bytes(const hv_conv_desc* d);   /* 0 when no kernel for this shape wants scratch */
+size_t hv_conv2d_stats_parts(const hv_conv_desc* d);       /* parts of hv_conv_desc.stats this call would write (0: its kernel has no statistics epilogue) */
 
 /* Weight gradient: dw[co][(r,s)][ci] = sum_{n,ho,wo} g[n,ho,wo,co] * x[n, ho*stride-pad+r*dil, ..., ci].
  * (autograd of the convs above; for a transposed conv swap the roles of x and g on the caller side).
@@ -173,6 +178,9 @@ typedef struct {
     int groups;   /* batch norm: the batch is split into `groups` equal parts with separate statistics, running stats updated
                      part by part (fake | real halves of one discriminator launch == two consecutive calls); 0/1 = one group */
     int f16;      /* storage of x and y (statistics, affine parameters and all arithmetic stay fp32 / fp64) */
+    const float* partials; int n_partials;
+                  /* optional (batch norm, training, groups <= 1): the producing conv's hv_conv_desc.stats -- [n_partials][C][2] partial sums of x.
+                     The reduction pass over x is skipped; the partials are folded in double precision in a fixed order.  NULL = reduce x here */
 } hv_norm_desc;
 size_t hv_norm_workspace_bytes(int B, int HW, int C);
 int hv_norm_act_forward(const hv_norm_desc* d, void* stream);
