@@ -28,6 +28,7 @@ struct G4K {
     int tiles_x, tiles;                        // tiles per image on the low-resolution grid (forward: outputs; data gradient: g pixels)
     int Hc, Wc;                                // extent of that grid
     unsigned x_bytes, w_bytes, w_rb;           // w_rb: bytes of one 16-row block of the filter table
+    int dbg;                                   // diagnostic builds (G4_STAMPS): bit 0 no loads / LDS writes in the loop, bit 1 no barriers, bit 2 no MFMAs, bit 3 no fragment reads
 };
 
 template <int MODE, int MT>
@@ -43,6 +44,13 @@ __global__ __launch_bounds__(512, 2) void conv_g4_kernel(const G4K p) {
     _Float16* Bs = As + 2 * ABUF;                                             // [2][BBUF]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef G4_STAMPS     // diagnostic build only (tools/g4_stamps.py): phase times of one workgroup, written over the first bytes of y
+    unsigned long long st[8];
+#define G4_STAMP(i) st[i] = __builtin_amdgcn_s_memrealtime()
+#else
+#define G4_STAMP(i)
+#endif
+    G4_STAMP(0);
     const int wm = wave >> 1, wn = wave & 1;
     int t = (int)blockIdx.x;
     const int n_img = t / p.tiles;
@@ -89,8 +97,9 @@ __global__ __launch_bounds__(512, 2) void conv_g4_kernel(const G4K p) {
             pval[i] = (in && (unsigned)r0 < (unsigned)p.H && (unsigned)c0 < (unsigned)p.W) ? 15 : 0;
         }
     }
-    u32x4 areg[4], breg[PITEMS];
-    auto issue = [&](int c) __attribute__((always_inline)) {
+    // two register sets: the loads of chunk c + 2 are issued before the MFMAs of chunk c (one chunk of MFMAs is shorter than a loaded memory round trip)
+    u32x4 areg[2][4], breg[2][PITEMS];
+    auto issue = [&](int c, int rs) __attribute__((always_inline)) {
         int dy = 0, dx = 0, kc = c;
         if (MODE == 0) { dy = c / (2 * KC); const int rem = c - dy * 2 * KC; dx = rem / KC; kc = rem - dx * KC; }
 #pragma unroll
@@ -99,20 +108,20 @@ __global__ __launch_bounds__(512, 2) void conv_g4_kernel(const G4K p) {
             int rb, tap;
             if (MODE == 0) { rb = (cob_s[s] >> 4) + (rbw & 3); tap = (2 * (tt >> 1) + dy) * 4 + 2 * (tt & 1) + dx; }
             else { rb = (cob_s[s] >> 4) + (rbw & 3); const int py = cls_s[s] >> 1, px = cls_s[s] & 1; tap = (1 - py + 2 * (tt >> 1)) * 4 + (1 - px + 2 * (tt & 1)); }
-            areg[i] = __builtin_amdgcn_raw_buffer_load_b128(wsrc, (unsigned)lane * 16u, rb * (int)p.w_rb + (tap * Cin + kc * 32) * 32, 0);
+            areg[rs][i] = __builtin_amdgcn_raw_buffer_load_b128(wsrc, (unsigned)lane * 16u, rb * (int)p.w_rb + (tap * Cin + kc * 32) * 32, 0);
         }
         const int coff = MODE == 0 ? ((dy * p.W + dx) * p.x_ld + kc * 32) * 2 : kc * 64;
         const int vb = MODE == 0 ? dy * 2 + dx : 0;
 #pragma unroll
         for (int i = 0; i < PITEMS; ++i)
-            breg[i] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, ((pval[i] >> vb) & 1) ? (unsigned)(pbase[i] + coff) : HV_OOB, 0, 0);
+            breg[rs][i] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, ((pval[i] >> vb) & 1) ? (unsigned)(pbase[i] + coff) : HV_OOB, 0, 0);
     };
-    auto flush = [&](int b) __attribute__((always_inline)) {
+    auto flush = [&](int b, int rs) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(As + b * ABUF + (wave + 8 * i) * 512 + lane * 8) = areg[i];
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(As + b * ABUF + (wave + 8 * i) * 512 + lane * 8) = areg[rs][i];
 #pragma unroll
         for (int i = 0; i < PITEMS; ++i)
-            if (plo[i] >= 0) *reinterpret_cast<u32x4*>(Bs + b * BBUF + plo[i]) = breg[i];
+            if (plo[i] >= 0) *reinterpret_cast<u32x4*>(Bs + b * BBUF + plo[i]) = breg[rs][i];
     };
 
     // tap offsets inside the patch for this wave's slot
@@ -132,14 +141,17 @@ __global__ __launch_bounds__(512, 2) void conv_g4_kernel(const G4K p) {
     const int poff = (wm * MT * PW + (lane & 15)) * LDP + (lane >> 4) * 8;
     const int aoff = (wn * 16) * 512 + lane * 8;
 
-    issue(0);
-    flush(0);
-    __syncthreads();
     f16x8 a[2][4], bf[2][MT];
-    for (int c = 0; c < NCH; ++c) {
-        const _Float16* Ab = As + (c & 1) * ABUF + aoff;
-        const _Float16* Bb = Bs + (c & 1) * BBUF + poff;
-        if (c + 1 < NCH) issue(c + 1);
+    // chunk c: MFMAs on LDS buffer c & 1; the loads of chunk c + 2 go out first, chunk c + 1 (requested a chunk ago) is written to the other LDS
+    // buffer between the 2nd and 3rd tap so that its ds_writes run behind MFMAs
+    auto chunk = [&](int c, int par) __attribute__((always_inline)) {
+        const _Float16* Ab = As + par * ABUF + aoff;
+        const _Float16* Bb = Bs + par * BBUF + poff;
+#ifdef G4_STAMPS
+        if (c + 2 < NCH && !(p.dbg & 1)) issue(c + 2, par);
+#else
+        if (c + 2 < NCH) issue(c + 2, par);
+#endif
         auto frags = [&](int tt, int buf) __attribute__((always_inline)) {
 #pragma unroll
             for (int n = 0; n < 4; ++n) a[buf][n] = *reinterpret_cast<const f16x8*>(Ab + (n * 4 + tt) * 512);
@@ -149,6 +161,20 @@ __global__ __launch_bounds__(512, 2) void conv_g4_kernel(const G4K p) {
         frags(0, 0);
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
+#ifdef G4_STAMPS
+            if (tt + 1 < 4 && !(p.dbg & 8)) frags(tt + 1, (tt + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(p.dbg & 4)) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[tt & 1][n], bf[tt & 1][m], acc[n][m], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (tt == 1 && c + 1 < NCH && !(p.dbg & 1)) { flush(par ^ 1, par ^ 1); __builtin_amdgcn_sched_barrier(0); }
+        }
+        if (!(p.dbg & 2)) __syncthreads();
+#else
             if (tt + 1 < 4) frags(tt + 1, (tt + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -156,10 +182,22 @@ __global__ __launch_bounds__(512, 2) void conv_g4_kernel(const G4K p) {
 #pragma unroll
                 for (int n = 0; n < 4; ++n) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[tt & 1][n], bf[tt & 1][m], acc[n][m], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+            if (tt == 1 && c + 1 < NCH) { flush(par ^ 1, par ^ 1); __builtin_amdgcn_sched_barrier(0); }
         }
-        if (c + 1 < NCH) flush((c + 1) & 1);
         __syncthreads();
+#endif
+    };
+    issue(0, 0);
+    if (NCH > 1) issue(1, 1);
+    G4_STAMP(1);
+    flush(0, 0);
+    __syncthreads();
+    G4_STAMP(2);
+    for (int c = 0; c < NCH; c += 2) {
+        chunk(c, 0);
+        if (c + 1 < NCH) chunk(c + 1, 1);
     }
+    G4_STAMP(3);
 
     // ---- epilogue: this thread's output pieces (act' multiplier, old gradient) requested first, then (alpha, +bias, activation) -> fp16 tile in
     // LDS -> 16-byte pieces
@@ -212,6 +250,7 @@ __global__ __launch_bounds__(512, 2) void conv_g4_kernel(const G4K p) {
         default: stage([](float v) { return v; }); break;
     }
     __syncthreads();
+    G4_STAMP(4);
     _Float16* yb = reinterpret_cast<_Float16*>(p.y);
     u32x4 o[OITEMS];
 #pragma unroll
@@ -280,6 +319,14 @@ __global__ __launch_bounds__(512, 2) void conv_g4_kernel(const G4K p) {
 #pragma unroll
     for (int k = 0; k < OITEMS; ++k)
         if (ooff[k] >= 0) *reinterpret_cast<u32x4*>(yb + ooff[k]) = o[k];
+#ifdef G4_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);
+    G4_STAMP(5);
+    if (tid == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0) {
+        unsigned long long* d = reinterpret_cast<unsigned long long*>(p.y);
+        for (int i = 0; i < 6; ++i) d[i] = st[i];
+    }
+#endif
 }
 
 template <int MODE, int MT>
@@ -325,6 +372,7 @@ int hv_conv2d_g4(const hv_conv_desc* d, hipStream_t s) {
     if (d->transposed && (d->Ho != 2 * d->H || d->Wo != 2 * d->W)) return HV_ERR_UNSUPPORTED;
     if ((long long)d->B * d->H * d->W * d->x_ld >= (1ll << 30) || (long long)d->B * d->Ho * d->Wo * d->y_ld >= (1ll << 30)) return HV_ERR_UNSUPPORTED;
     G4K k;
+    k.dbg = getenv("HV_G4_DBG") ? atoi(getenv("HV_G4_DBG")) : 0;
     k.x = d->x; k.w = reinterpret_cast<const _Float16*>(d->w_f16_tiled); k.bias = d->bias; k.y = d->y; k.mul_src = d->mul_src;
     k.stats = d->transposed ? nullptr : d->stats;
     k.B = d->B; k.H = d->H; k.W = d->W; k.x_ld = d->x_ld; k.x_coff = d->x_coff; k.Cin = d->Cin;

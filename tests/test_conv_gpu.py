@@ -169,11 +169,16 @@ def test_conv_halo_tiled_fp16_forward_and_dgrad(case):
     # the same filters in MFMA-fragment order (hv_conv_desc.w_f16_tiled): same arithmetic in the same order, so the same bits
     wt = ops.tile_weights(wf.half(), Cout, k * k, Cin)
     assert (wt is None) == (Cin % 16 != 0)
+    from hvgan import lib
+    pa = lib.get().size('hv_last_kernel_path')
     if wt is not None:
         yt = ops.Act.empty(B, Ho, Wo, Cout, dev(), dtype=torch.float16)
         ops.conv2d(to_act(x, dtype=torch.float16), wf, yt, k, s, p, 1, bias=b.to(dev()), act=act, in_shift=shift, precision='fp16', w_h=wf.half(), w_t=wt)
         torch.cuda.synchronize()
-        assert torch.equal(yt.t, ya.t)
+        if lib.get().size('hv_last_kernel_path') == 8:      # the 4x4 stride-2 layers take conv_g4_kernel with the tiled table: another summation order
+            assert pa != 8 and maxerr(from_act(yt), ref.detach()) <= 4e-3 * max(1.0, ref.abs().max().item())
+        else:
+            assert torch.equal(yt.t, ya.t)
     if shift or Cout % 16:
         return
     gy = torch.randn(y0.shape, generator=g)
@@ -188,7 +193,10 @@ def test_conv_halo_tiled_fp16_forward_and_dgrad(case):
     dxt = ops.Act.empty(B, H, W, Cin, dev(), dtype=torch.float16)
     ops.conv2d(to_act(gy, dtype=torch.float16), wb, dxt, k, s, p, 1, transposed=True, precision='fp16', w_h=wb.half(), w_t=wbt)
     torch.cuda.synchronize()
-    assert torch.equal(dxt.t, dxa.t)
+    if lib.get().size('hv_last_kernel_path') == 8:
+        assert maxerr(from_act(dxt), xin.grad) <= 4e-3 * max(1.0, xin.grad.abs().max().item())
+    else:
+        assert torch.equal(dxt.t, dxa.t)
     # a second writer of the same gradient buffer (accumulate = 1) with the producer's act' factor: y += v * act'(m)
     m = torch.randn(B, Cin, H, W, generator=g).half().float()        # the kernel sees the fp16-stored value (a tiny positive m may round to 0)
     fac = torch.where(m > 0, torch.ones_like(m), torch.full_like(m, 0.2))
