@@ -61,11 +61,10 @@ def parse():
 def launch_ranks(args):
     """Plain `python bench.py --gpus N`: start the N ranks as children through torch.distributed.run and hand back their
     exit status.  Nothing in this (parent) process has initialised the GPU, and it never does."""
-    with socket.socket() as s:
-        s.bind(('127.0.0.1', 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: torchrun's own c10d rendezvous picks AND HOLDS a free port on this host (a port found by bind(0) / close() here could be taken
+    # by another job before the ranks meet)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--standalone', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--local-addr', '127.0.0.1',
+           os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
     return subprocess.run(cmd, env=env).returncode
 

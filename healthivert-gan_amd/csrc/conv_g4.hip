@@ -31,17 +31,33 @@ struct G4K {
     int dbg;                                   // diagnostic builds (G4_STAMPS): bit 0 no loads / LDS writes in the loop, bit 1 no barriers, bit 2 no MFMAs, bit 3 no fragment reads
 };
 
+typedef __attribute__((address_space(3))) void* lds_ptr;
+// LDS-DMA: 16 bytes per lane, global -> LDS at dst + 16 * lane (out-of-range lanes write zeros).  In its own device-only body: with the builtin inside the
+// kernel template hipcc's host pass silently drops the kernel's host stub (undefined symbol at load time).
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t r, lds_ptr dst, unsigned voff, int soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 16, voff, soff, 0, 0);
+#endif
+}
+
 template <int MODE, int MT>
 __global__ __launch_bounds__(512, 2) void conv_g4_kernel(const G4K p) {
     constexpr int TW = 16, TH = 4 * MT, NTHR = 512;
-    constexpr int PH = TH + 1 + MODE, PW = TW + 1 + MODE, LDP = 48;            // 96-byte patch pixel rows
-    constexpr int PITEMS = (PH * PW * 4 + NTHR - 1) / NTHR;
+    constexpr int PH = TH + 1 + MODE, PW = TW + 1 + MODE;
+    // LDS: three buffers of {A: 32 fragments of 1 KB, linear; B: the patch as 64-byte pixel rows, 16 pixels per 1-KB piece}, both filled by LDS-DMA
+    // (buffer_load ... lds: 1 KB per wave instruction, no registers, no ds_write pass).  A piece's LDS image is lane-linear, so the patch rows cannot be
+    // padded; instead slot s of pixel pp holds its 16-byte channel piece s ^ 2((pp >> 2) & 1) (the permutation goes on the SOURCE address): the 16
+    // lanes of every ds_read_b128 lane group of a B-fragment read -- 16 consecutive pixels from any start, two adjacent channel pieces -- then hit 16
+    // different 16-byte columns of the 256-byte LDS line (checked exhaustively over start offsets, tools/lds_swizzle_check.py).
+    constexpr int NBP = (PH * PW + 15) / 16;                                  // 1-KB pieces of the patch
+    constexpr int BPW = (NBP + 7) / 8;                                        // ... per wave
     constexpr int ABUF = 32 * 512;                                            // halfs: 8 row blocks x 4 taps x (16 x 32) fragment
-    constexpr int BBUF = PH * PW * LDP;
+    constexpr int BBUF = NBP * 512;                                           // halfs
+    constexpr int NBUF = 3;
     constexpr int LDO = 128 + 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    _Float16* As = reinterpret_cast<_Float16*>(smem);                         // [2][ABUF]
-    _Float16* Bs = As + 2 * ABUF;                                             // [2][BBUF]
+    _Float16* As = reinterpret_cast<_Float16*>(smem);                         // [3][ABUF]
+    _Float16* Bs = As + NBUF * ABUF;                                          // [3][BBUF]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef G4_STAMPS     // diagnostic build only (tools/g4_stamps.py): phase times of one workgroup, written over the first bytes of y
@@ -73,16 +89,15 @@ __global__ __launch_bounds__(512, 2) void conv_g4_kernel(const G4K p) {
     const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.w), 0, p.w_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
 
-    // ---- patch staging items of this thread (chunk-independent part)
-    int plo[PITEMS], pbase[PITEMS], pval[PITEMS];
+    // ---- this lane's part of the wave's patch pieces (chunk-independent): piece j = wave + 8 i covers pixels 16 j .. 16 j + 15, lane -> (pixel, slot)
+    int pbase[BPW], pval[BPW];
     const int xbase = (n_img * p.H * p.W * p.x_ld + p.x_coff) * 2;
 #pragma unroll
-    for (int i = 0; i < PITEMS; ++i) {
-        const int e = tid + i * NTHR;
-        const int pix = e >> 2, c8 = e & 3;
+    for (int i = 0; i < BPW; ++i) {
+        const int pix = (wave + 8 * i) * 16 + (lane >> 2);
+        const int c8 = (lane & 3) ^ (((pix >> 2) & 1) << 1);                  // the channel piece this LDS slot holds
         const int pr = pix / PW, pc = pix - pr * PW;
-        const bool in = pix < PH * PW;
-        plo[i] = in ? pix * LDP + c8 * 8 : -1;
+        const bool in = pix < PH * PW && wave + 8 * i < NBP;
         if (MODE == 0) {
             const int r0 = 2 * (i0 + pr) - 1, c0 = 2 * (j0 + pc) - 1;
             pbase[i] = xbase + ((r0 * p.W + c0) * p.x_ld + c8 * 8) * 2;
@@ -97,106 +112,119 @@ __global__ __launch_bounds__(512, 2) void conv_g4_kernel(const G4K p) {
             pval[i] = (in && (unsigned)r0 < (unsigned)p.H && (unsigned)c0 < (unsigned)p.W) ? 15 : 0;
         }
     }
-    // two register sets: the loads of chunk c + 2 are issued before the MFMAs of chunk c (one chunk of MFMAs is shorter than a loaded memory round trip)
-    u32x4 areg[2][4], breg[2][PITEMS];
-    auto issue = [&](int c, int rs) __attribute__((always_inline)) {
+    // every wave issues the same number of LDS-DMA instructions per chunk (4 filter fragments + BPW patch pieces; a piece index beyond the patch is
+    // sent with every lane out of range and lands in a spare KB), so that the counted vmcnt below means the same thing in every wave
+    constexpr int DMA_PER_CHUNK = 4 + BPW;
+    auto issue = [&](int c, int b) __attribute__((always_inline)) {
         int dy = 0, dx = 0, kc = c;
         if (MODE == 0) { dy = c / (2 * KC); const int rem = c - dy * 2 * KC; dx = rem / KC; kc = rem - dx * KC; }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int f = wave + 8 * i, rbw = f >> 2, tt = f & 3, s = rbw >> 2;
-            int rb, tap;
-            if (MODE == 0) { rb = (cob_s[s] >> 4) + (rbw & 3); tap = (2 * (tt >> 1) + dy) * 4 + 2 * (tt & 1) + dx; }
-            else { rb = (cob_s[s] >> 4) + (rbw & 3); const int py = cls_s[s] >> 1, px = cls_s[s] & 1; tap = (1 - py + 2 * (tt >> 1)) * 4 + (1 - px + 2 * (tt & 1)); }
-            areg[rs][i] = __builtin_amdgcn_raw_buffer_load_b128(wsrc, (unsigned)lane * 16u, rb * (int)p.w_rb + (tap * Cin + kc * 32) * 32, 0);
+            const int rb = (cob_s[s] >> 4) + (rbw & 3);
+            int tap;
+            if (MODE == 0) tap = (2 * (tt >> 1) + dy) * 4 + 2 * (tt & 1) + dx;
+            else { const int py = cls_s[s] >> 1, px = cls_s[s] & 1; tap = (1 - py + 2 * (tt >> 1)) * 4 + (1 - px + 2 * (tt & 1)); }
+            lds_dma16(wsrc, (lds_ptr)(As + b * ABUF + f * 512), (unsigned)lane * 16u, rb * (int)p.w_rb + (tap * Cin + kc * 32) * 32);
         }
         const int coff = MODE == 0 ? ((dy * p.W + dx) * p.x_ld + kc * 32) * 2 : kc * 64;
         const int vb = MODE == 0 ? dy * 2 + dx : 0;
 #pragma unroll
-        for (int i = 0; i < PITEMS; ++i)
-            breg[rs][i] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, ((pval[i] >> vb) & 1) ? (unsigned)(pbase[i] + coff) : HV_OOB, 0, 0);
-    };
-    auto flush = [&](int b, int rs) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(As + b * ABUF + (wave + 8 * i) * 512 + lane * 8) = areg[rs][i];
-#pragma unroll
-        for (int i = 0; i < PITEMS; ++i)
-            if (plo[i] >= 0) *reinterpret_cast<u32x4*>(Bs + b * BBUF + plo[i]) = breg[rs][i];
+        for (int i = 0; i < BPW; ++i) {
+            _Float16* dst = wave + 8 * i < NBP ? Bs + b * BBUF + (wave + 8 * i) * 512 : Bs + NBUF * BBUF;      // (the spare KB behind the three buffers)
+            lds_dma16(xsrc, (lds_ptr)dst, ((pval[i] >> vb) & 1) ? (unsigned)(pbase[i] + coff) : HV_OOB, 0);
+        }
     };
 
-    // tap offsets inside the patch for this wave's slot
-    int toff[4];
+    // B-fragment addresses of this lane: pixel row m of the wave, tap tt (the slot permutation depends on the pixel, i.e. on the tap)
+    int boffs[4][MT];
 #pragma unroll
     for (int tt = 0; tt < 4; ++tt) {
         int dh, dw;
         if (MODE == 0) { dh = tt >> 1; dw = tt & 1; }
         else { const int py = cls_s[wn] >> 1, px = cls_s[wn] & 1; dh = py - (tt >> 1) + 1; dw = px - (tt & 1) + 1; }
-        toff[tt] = (dh * PW + dw) * LDP;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int pix = (wm * MT + m + dh) * PW + (lane & 15) + dw;
+            boffs[tt][m] = pix * 32 + (((lane >> 4) ^ (((pix >> 2) & 1) << 1)) << 3);      // halfs
+        }
     }
     f32x4 acc[4][MT];
 #pragma unroll
     for (int n = 0; n < 4; ++n)
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int poff = (wm * MT * PW + (lane & 15)) * LDP + (lane >> 4) * 8;
     const int aoff = (wn * 16) * 512 + lane * 8;
 
     f16x8 a[2][4], bf[2][MT];
-    // chunk c: MFMAs on LDS buffer c & 1; the loads of chunk c + 2 go out first, chunk c + 1 (requested a chunk ago) is written to the other LDS
-    // buffer between the 2nd and 3rd tap so that its ds_writes run behind MFMAs
-    auto chunk = [&](int c, int par) __attribute__((always_inline)) {
-        const _Float16* Ab = As + par * ABUF + aoff;
-        const _Float16* Bb = Bs + par * BBUF + poff;
+    auto frags = [&](int b, int tt, int buf) __attribute__((always_inline)) {
+        const _Float16* Ab = As + b * ABUF + aoff;
+        const _Float16* Bb = Bs + b * BBUF;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) a[buf][n] = *reinterpret_cast<const f16x8*>(Ab + (n * 4 + tt) * 512);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) bf[buf][m] = *reinterpret_cast<const f16x8*>(Bb + boffs[tt][m]);
+    };
+    auto mfmas = [&](int buf) __attribute__((always_inline)) {
 #ifdef G4_STAMPS
-        if (c + 2 < NCH && !(p.dbg & 1)) issue(c + 2, par);
-#else
-        if (c + 2 < NCH) issue(c + 2, par);
+        if (p.dbg & 4) return;
 #endif
-        auto frags = [&](int tt, int buf) __attribute__((always_inline)) {
 #pragma unroll
-            for (int n = 0; n < 4; ++n) a[buf][n] = *reinterpret_cast<const f16x8*>(Ab + (n * 4 + tt) * 512);
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int m = 0; m < MT; ++m) bf[buf][m] = *reinterpret_cast<const f16x8*>(Bb + m * PW * LDP + toff[tt]);
-        };
-        frags(0, 0);
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
+            for (int n = 0; n < 4; ++n) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[buf][n], bf[buf][m], acc[n][m], 0, 0, 0);
+    };
+    // Chunk c computes on LDS buffer c % 3 while the DMA of chunks c + 1 and c + 2 is in flight.  The barrier sits BEFORE the last tap's MFMAs: by then
+    // the wave holds all its fragments of chunk c in registers (lgkmcnt(0)) and has waited for its OWN pieces of chunk c + 1 (requested a whole chunk
+    // earlier), so behind the barrier chunk c + 1 is complete in LDS and buffer c % 3 is free; the first fragments of chunk c + 1 are then read behind
+    // the last tap's MFMAs instead of at the head of the next chunk with every wave of the workgroup waiting for LDS at once.
+    auto chunk = [&](int c, int b) __attribute__((always_inline)) {
+        const int bn = b == 2 ? 0 : b + 1;
 #ifdef G4_STAMPS
-            if (tt + 1 < 4 && !(p.dbg & 8)) frags(tt + 1, (tt + 1) & 1);
+        if (c + 2 < NCH && !(p.dbg & 1)) issue(c + 2, b == 0 ? 2 : b - 1);
+#else
+        if (c + 2 < NCH) issue(c + 2, b == 0 ? 2 : b - 1);
+#endif
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt) {
             __builtin_amdgcn_sched_barrier(0);
-            if (!(p.dbg & 4)) {
+            frags(b, tt + 1, (tt + 1) & 1);
+            mfmas(tt & 1);
+            // one fragment read per two MFMAs: a burst of 8 reads from each of the 8 barrier-aligned waves is 64 KB the LDS serves in 256 cycles
+            // during which no wave can issue an MFMA
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int n = 0; n < 4; ++n) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[tt & 1][n], bf[tt & 1][m], acc[n][m], 0, 0, 0);
+            for (int i = 0; i < 4 + MT; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, (4 * MT) / (4 + MT), 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (tt == 1 && c + 1 < NCH && !(p.dbg & 1)) { flush(par ^ 1, par ^ 1); __builtin_amdgcn_sched_barrier(0); }
         }
-        if (!(p.dbg & 2)) __syncthreads();
-#else
-            if (tt + 1 < 4) frags(tt + 1, (tt + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);
+        if (c + 2 < NCH) __builtin_amdgcn_s_waitcnt(0x0070 | (DMA_PER_CHUNK & 15) | ((DMA_PER_CHUNK >> 4) << 14));     // lgkmcnt(0), vmcnt(DMA_PER_CHUNK): chunk c + 1 landed, c + 2 in flight
+        else __builtin_amdgcn_s_waitcnt(0x0070);                                                                     // lgkmcnt(0), vmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        if (c + 1 < NCH) frags(bn, 0, 0);
+        mfmas(1);
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int n = 0; n < 4; ++n) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[tt & 1][n], bf[tt & 1][m], acc[n][m], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (tt == 1 && c + 1 < NCH) { flush(par ^ 1, par ^ 1); __builtin_amdgcn_sched_barrier(0); }
+        for (int i = 0; i < 4 + MT; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, (4 * MT) / (4 + MT), 0);
         }
-        __syncthreads();
-#endif
+        __builtin_amdgcn_sched_barrier(0);
     };
     issue(0, 0);
     if (NCH > 1) issue(1, 1);
     G4_STAMP(1);
-    flush(0, 0);
-    __syncthreads();
+    if (NCH > 1) __builtin_amdgcn_s_waitcnt(0x0F70 | (DMA_PER_CHUNK & 15) | ((DMA_PER_CHUNK >> 4) << 14));
+    else __builtin_amdgcn_s_waitcnt(0x0F70);
+    __builtin_amdgcn_s_barrier();
     G4_STAMP(2);
-    for (int c = 0; c < NCH; c += 2) {
+    frags(0, 0, 0);
+    for (int c = 0; c < NCH; c += 3) {
         chunk(c, 0);
         if (c + 1 < NCH) chunk(c + 1, 1);
+        if (c + 2 < NCH) chunk(c + 2, 2);
     }
+    __syncthreads();
     G4_STAMP(3);
 
     // ---- epilogue: this thread's output pieces (act' multiplier, old gradient) requested first, then (alpha, +bias, activation) -> fp16 tile in
@@ -332,7 +360,7 @@ __global__ __launch_bounds__(512, 2) void conv_g4_kernel(const G4K p) {
 template <int MODE, int MT>
 static int launch_g4(G4K& k, int ny, hipStream_t s) {
     constexpr int TH = 4 * MT, PH = TH + 1 + MODE, PW = 17 + MODE;
-    constexpr size_t lds_loop = (size_t)(2 * 32 * 512 + 2 * PH * PW * 48) * 2, lds_out = (size_t)TH * 16 * 136 * 2, lds_red = 32 * 16 * 16 * 4;
+    constexpr size_t lds_loop = (size_t)(3 * 32 * 512 + (3 * ((PH * PW + 15) / 16) + 1) * 512) * 2, lds_out = (size_t)TH * 16 * 136 * 2, lds_red = 32 * 16 * 16 * 4;
     constexpr size_t lds = lds_loop > lds_out ? (lds_loop > lds_red ? lds_loop : lds_red) : (lds_out > lds_red ? lds_out : lds_red);
     static_assert(lds <= 160 * 1024, "LDS");
     k.tiles_x = hv_cdiv(k.Wc, 16);

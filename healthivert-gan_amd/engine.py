@@ -159,11 +159,18 @@ class ConvNode:
         # gradient is then a convolution with fewer output channels (the first dx_c rows of the transposed filter table)
         self.dx_c = dx_c
 
-    def forward(self, prec):
+    def forward(self, prec, stats=None):
         p = self.p
         xin = Act(self.x.t, p.cin_fwd, self.x.coff)
         ops.conv2d(xin, p.w_fwd, self.y, self.k, self.s, self.pad, self.d, bias=p.bias if self.use_bias else None, act=self.act, w_h=p.w_fwd_h, w_t=p.w_fwd_t,
-                   in_shift=self.shift, transposed=self.transposed, precision=prec, cout=p.cout)
+                   in_shift=self.shift, transposed=self.transposed, precision=prec, cout=p.cout, stats=stats)
+
+    def stats_parts(self, prec):
+        """Partial-sum rows this node's forward kernel writes when handed a statistics buffer (0: that kernel has no such epilogue)."""
+        p = self.p
+        xin = Act(self.x.t, p.cin_fwd, self.x.coff)
+        return ops.conv2d_stats_parts(xin, p.w_fwd, self.y, self.k, self.s, self.pad, self.d, bias=p.bias if self.use_bias else None, act=self.act,
+                                      w_h=p.w_fwd_h, w_t=p.w_fwd_t, in_shift=self.shift, transposed=self.transposed, precision=prec, cout=p.cout)
 
 
 # streams on which weight gradients stay in line instead of forking to a side stream: the per-discriminator streams of

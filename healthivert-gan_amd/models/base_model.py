@@ -71,6 +71,7 @@ class BaseModel(ABC):
         return self.image_paths
 
     def update_learning_rate(self):
+        self.sync_tail()      # an optimiser step still queued on another stream (data-parallel schedule) must read the OLD learning rate
         old_lr = self.optimizers[0].param_groups[0]['lr']
         for s in self.schedulers:
             if self.opt.lr_policy == 'plateau':

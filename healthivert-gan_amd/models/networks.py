@@ -143,6 +143,7 @@ class GANLoss(nn.Module):
 
 
 # ================================================================================================ PatchGAN
+CONV_STATS = os.environ.get('HV_CONV_STATS', '1') != '0'     # A/B knob: BatchNorm statistics from the producing conv's epilogue
 FUSE_NORM_ACT = os.environ.get('HV_FUSE_NORM_ACT', '1') != '0'     # A/B knob, see _DiscPlan-based run_backward
 
 
@@ -289,14 +290,23 @@ class NLayerDiscriminator(nn.Module):
                 ent['node'] = E.ConvNode(ent['p'], xin, ent['y'], L['stride'], 1, 1, 'lrelu', use_bias=True)
                 ent['node'].forward(prec)
                 continue
-            ent['node'].forward(prec)
             if L['last']:
+                ent['node'].forward(prec)
                 break
             nm = self.model[L['norm']]
+            # BatchNorm statistics out of the conv's own epilogue where its kernel has one (the 4x4 stride-2 layers): the normalisation then
+            # skips its reduction pass over z (HV_CONV_STATS=0: always reduce)
+            parts = 0
+            if CONV_STATS and self.norm_kind == 'batch' and training and groups <= 1:
+                if 'parts' not in ent:
+                    ent['parts'] = int(ent['node'].stats_parts(prec))
+                    ent['partials'] = torch.zeros(max(1, ent['parts']) * ent['p'].cout * 2, dtype=torch.float32, device=x.device)
+                parts = ent['parts']
+            ent['node'].forward(prec, stats=ent['partials'] if parts else None)
             if self.norm_kind == 'batch':
                 ops.norm_act_forward(ent['z'], ent['y'], 'batch', training, ent['stats'], nm.weight, nm.bias, nm.running_mean,
                                      nm.running_var, nm.num_batches_tracked, act='lrelu', eps=nm.eps, momentum=_stat_momentum(nm.momentum, stat_order),
-                                     groups=groups)
+                                     groups=groups, partials=ent['partials'] if parts else None, n_partials=parts)
             else:
                 ops.norm_act_forward(ent['z'], ent['y'], 'instance', training, ent['stats'], act='lrelu', eps=nm.eps)
         P.training, P.groups = training, groups
@@ -373,9 +383,10 @@ def grads_are_fresh(net):
     """True when nothing has been written into the net's gradients since the last zero_grad(): the next backward ASSIGNS, later
     ones accumulate -- torch.autograd's .grad semantics for the nn.Module API of the explicit-backward networks.  FusedAdam.zero_grad
     flags the first parameter; torch optimisers either drop .grad (set_to_none) or zero it (then accumulating is right anyway)."""
-    p0 = next(net.parameters())
-    fresh = getattr(p0, '_hv_fresh', False) or p0.grad is None
-    p0._hv_fresh = False
+    ps = list(net.parameters())
+    fresh = getattr(ps[0], '_hv_fresh', False) or ps[0].grad is None
+    for p in ps:
+        p._hv_fresh = False
     return fresh
 
 

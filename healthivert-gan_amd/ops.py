@@ -145,9 +145,12 @@ def conv_out_size(n, k, stride, pad, dil):
 
 
 def conv2d(x, w, y, k, stride=1, pad=0, dil=1, bias=None, act='none', transposed=False, in_shift=0, alpha=1.0,
-           accumulate=0, ch_scale=None, w_bstride=0, ch_scale_bstride=0, precision=None, cin=None, cout=None, w_h=None, mul=None, w_t=None):
+           accumulate=0, ch_scale=None, w_bstride=0, ch_scale_bstride=0, precision=None, cin=None, cout=None, w_h=None, mul=None, w_t=None,
+           stats=None, _parts_only=False):
     """y = act(alpha*ch_scale*conv(x, w) + bias)  [* act'(m) with mul = (Act m, activation name): see hv_conv_desc.mul_src].  x,y: Act; w: prepared [CoutF][k*k][CinP] tensor (or [B][...] with
-    w_bstride).  cin/cout default to the view widths (x.C consumed, y.C produced)."""
+    w_bstride).  cin/cout default to the view widths (x.C consumed, y.C produced).
+    stats: float tensor of conv2d_stats_parts(...) * Cout * 2 elements that receives the per-channel partial sums of the stored output
+    (hv_conv_desc.stats; feeds norm_act_forward(partials=...))."""
     L = _lib.get()
     d = L.hv_conv_desc()
     kh, kw = (k, k) if isinstance(k, int) else k
@@ -170,6 +173,10 @@ def conv2d(x, w, y, k, stride=1, pad=0, dil=1, bias=None, act='none', transposed
     if mul is not None:
         m, mact = mul
         d.mul_src, d.mul_ld, d.mul_coff, d.mul_act, d.mul_f16 = ptr(m.t).value, m.ld, m.coff, ACT[mact], m.f16
+    if _parts_only:
+        return L.size('hv_conv2d_stats_parts', ctypes.byref(d))
+    if stats is not None:
+        d.stats = ptr(stats).value
     if d.Cout == 1:      # single-channel heads / logits: the [pixel][tap] table of conv_head.hip lives in the per-stream scratch
         need = L.size('hv_conv2d_workspace_bytes', ctypes.byref(d))
         if need:
@@ -187,6 +194,11 @@ def conv2d(x, w, y, k, stride=1, pad=0, dil=1, bias=None, act='none', transposed
         return y
     L.call('hv_conv2d', ctypes.byref(d), stream())
     return y
+
+
+def conv2d_stats_parts(*args, **kw):
+    """Partial-sum rows the conv2d call with these arguments would write into `stats` (0: its kernel has no statistics epilogue)."""
+    return conv2d(*args, _parts_only=True, **kw)
 
 
 def conv2d_wgrad(x, g, dw, k, stride=1, pad=0, dil=1, in_shift=0, accumulate=False, precision=None, cin=None, cout=None, dbias=None,
@@ -354,7 +366,7 @@ def adam_step(table, max_numel, lr_dev, beta1, beta2, eps, step_dev):
 
 # ------------------------------------------------------------------------------------------------ norm + activation
 def norm_act_forward(x, y, norm, training, stats, gamma=None, beta=None, running_mean=None, running_var=None, nbt=None,
-                     act='lrelu', post_sigmoid=False, eps=1e-5, momentum=0.1, groups=1):
+                     act='lrelu', post_sigmoid=False, eps=1e-5, momentum=0.1, groups=1, partials=None, n_partials=0):
     L = _lib.get()
     d = L.hv_norm_desc()
     d.x, d.y = ptr(x.t).value, ptr(y.t).value
@@ -367,6 +379,8 @@ def norm_act_forward(x, y, norm, training, stats, gamma=None, beta=None, running
     d.act, d.post_sigmoid, d.groups = ACT[act], int(post_sigmoid), int(groups)
     assert x.f16 == y.f16
     d.f16 = x.f16
+    if partials is not None and n_partials:      # the producing conv's own statistics (hv_conv_desc.stats): no reduction pass over x
+        d.partials, d.n_partials = ptr(partials).value, int(n_partials)
     need = L.size('hv_norm_workspace_bytes', x.B, x.H * x.W, x.C)
     b, _ = _ws(need, x.t.device)
     d.workspace, d.workspace_bytes = ptr(b).value, b.numel()

@@ -63,6 +63,9 @@ class FusedAdam(torch.optim.Optimizer):
 
     def zero_grad(self, set_to_none=False):
         """Gradients are (re)assigned by the explicit backward; nothing to clear.  The first parameter is flagged so that the
-        nn.Module-API autograd bridges know the next backward assigns and later ones accumulate (networks.grads_are_fresh)."""
-        self.param_groups[0]['params'][0]._hv_fresh = True
+        nn.Module-API autograd bridges know the next backward assigns and later ones accumulate (networks.grads_are_fresh).  EVERY parameter
+        of every group is flagged: one optimiser may span several networks (itertools.chain of their parameters)."""
+        for g in self.param_groups:
+            for p in g['params']:
+                p._hv_fresh = True
         return None

@@ -216,6 +216,13 @@ def g5_full_step(p2p, out, synth):
             for k, v in getattr(model, 'net' + n).state_dict().items():
                 norms['%s/%s' % (n, k)] = np.float64(v.double().norm())
         res['norms%d' % step] = norms
+        # every 97th element of every floating-point tensor after the step: a missing or wrong Adam update shows in the elements, not in the norms
+        elems = {}
+        for n in ('G', 'D_1', 'D_2', 'D_3'):
+            for k, v in getattr(model, 'net' + n).state_dict().items():
+                if v.is_floating_point():
+                    elems['%s/%s' % (n, k)] = v.detach().flatten()[::97].clone()
+        res['elems%d' % step] = elems
     save(out, 'g5_full_step', **res)
     return model
 
@@ -236,6 +243,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--ref', default='/root/reference')
     ap.add_argument('--out', default=os.path.join(ROOT, 'tests', 'golden'))
+    ap.add_argument('--only', default='', help='comma-separated subset of g1,g2,g3,g4,g5,g6,g7')
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     sys.path.insert(0, ROOT)
@@ -243,13 +251,14 @@ def main():
     from hvgan import synth
     torch.set_num_threads(8)
     inp, nets, edge, unet, p2p = import_reference(args.ref)
-    g1_generator(inp, args.out)
-    g2_attention(inp, args.out)
-    g3_discriminator(nets, args.out)
-    g4_small_ops(edge, nets, p2p, args.out)
-    g6_unet(unet, args.out)
-    g7_inference(inp, args.out, synth)
-    g5_full_step(p2p, args.out, synth)
+    want = lambda n: not args.only or n in args.only.split(',')
+    if want('g1'): g1_generator(inp, args.out)
+    if want('g2'): g2_attention(inp, args.out)
+    if want('g3'): g3_discriminator(nets, args.out)
+    if want('g4'): g4_small_ops(edge, nets, p2p, args.out)
+    if want('g6'): g6_unet(unet, args.out)
+    if want('g7'): g7_inference(inp, args.out, synth)
+    if want('g5'): g5_full_step(p2p, args.out, synth)
 
 
 if __name__ == '__main__':

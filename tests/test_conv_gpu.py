@@ -560,8 +560,11 @@ def test_conv_stride2_data_gradient_fused_parity_classes(case):
             d0, d1 = (ops.Act.empty(B, H, W, Cin, dev(), dtype=torch.float16) for _ in range(2))
             ops.conv2d(ga, wb, d0, k, 2, 1, 1, transposed=True, precision='fp16', w_h=wb.half())
             ops.conv2d(ga, wb, d1, k, 2, 1, 1, transposed=True, precision='fp16', w_h=wb.half(), w_t=wbt)
-            assert lib.get().size('hv_last_kernel_path') == 6
+            path = lib.get().size('hv_last_kernel_path')
             torch.cuda.synchronize()
-            assert torch.equal(d0.t, d1.t)
+            if k == 4 and Cout % 32 == 0 and Cin % 64 == 0:      # with the tiled table the 4x4 layers take conv_g4_kernel (another summation order)
+                assert path == 8 and maxerr(from_act(d1), x.grad) <= 4e-3 * max(1.0, x.grad.abs().max().item())
+            else:
+                assert path == 6 and torch.equal(d0.t, d1.t)
     finally:
         lib.get().size('hv_set_s2t_mode', prev)

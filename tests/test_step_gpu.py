@@ -77,6 +77,22 @@ def test_g5_two_train_steps_match_reference_golden(precision, loss_tol, norm_tol
             v = getattr(model, 'net' + n).state_dict()[k]
             got = float(v.double().norm())
             assert abs(got - float(ref)) <= norm_tol * max(1.0, float(ref)), (step, key, got, float(ref))
+        # sampled ELEMENTS of every tensor after the step (every 97th).  Adam's first updates are +-lr = 2e-4 per element whatever the gradient's
+        # size (m / sqrt(v) = sign(g)), so a missing, doubled or mis-scaled update of a tensor moves ALL its elements by ~2e-4 and hides inside the
+        # norm tolerance above; here it does not.  The same property makes an element whose gradient is at rounding-noise level land on the other
+        # side (2 lr away) now and then: the gate is the FRACTION of sampled elements beyond a tenth of lr, plus a hard bound of a few lr.
+        lr, bad, tot, worst = 2e-4, 0, 0, 0.0
+        for key, ref in g['elems%d' % step].items():
+            n, k = key.split('/', 1)
+            if 'running' in k or 'num_batches' in k:
+                continue
+            v = getattr(model, 'net' + n).state_dict()[k].detach().flatten()[::97].cpu().float()
+            e = (v - ref.float()).abs()
+            frac = (e > 0.1 * lr).float().mean().item()
+            assert frac <= (0.02 if precision == 'fp32' else 0.25), (precision, step, key, 'fraction of sampled weights off by > lr/10', frac)
+            bad += int((e > 0.1 * lr).sum()); tot += e.numel(); worst = max(worst, e.max().item())
+        assert worst <= 2.5 * lr * (step + 1), (precision, step, worst)
+        assert bad <= (0.002 if precision == 'fp32' else 0.05) * tot, (precision, step, bad, tot)
 
 
 def test_g7_eval_forward_bs1_matches_reference_golden():
