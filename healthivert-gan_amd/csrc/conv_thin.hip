@@ -1,0 +1,98 @@
+// Data gradient of a 3x3 stride-1 convolution with <= 4 gradient channels and <= 16 output channels: the generators' 1-channel heads handing their
+// gradient back to the 8 / 12-channel layer below (hv_conv2d, transposed = 1, Cin <= 4 -- the head's output channel padded to 4).
+//
+// These launches are 1.2 GFLOP and 25-33 MB: pure HBM work that ran through conv_halo2_kernel's ragged 16-channel MFMA tiles at 34-36 us.  Here a
+// lane owns one output pixel: the 3x3 neighbourhood of the gradient (nine 8-byte loads, out-of-image -> zero through the buffer range check), the
+// filters in LDS as floats (broadcast reads), Cout fp32 accumulators, then the act' multiplier / accumulate forms of the shared epilogue on the
+// lane's own 16- or 24-byte channel row and one store.  fp32 arithmetic on the fp16-stored operands (exact products, fp32 sums).
+#include "conv_halo.h"
+
+struct ThinK {
+    const _Float16* g; const float* w; void* y; const _Float16* mul;
+    int B, H, W, g_ld, g_coff, Cin, Cout, w_row;       // w: [Cout][9][w_row / 9] floats (the data-gradient table)
+    int y_ld, y_coff, mul_ld, mul_coff, mul_act, accumulate, pad;
+    float alpha;
+    unsigned g_bytes;
+};
+
+template <int CO>        // output channels per lane: 8, 12 or 16
+__global__ __launch_bounds__(256) void thin_dgrad_kernel(const ThinK p) {
+    __shared__ float wl[CO * 9 * 4];
+    const int CinP = p.w_row / 9;
+    for (int i = threadIdx.x; i < CO * 9 * 4; i += 256) {
+        const int co = i / 36, r = i - co * 36, tap = r >> 2, ci = r & 3;
+        wl[i] = (co < p.Cout && ci < p.Cin) ? p.w[co * p.w_row + tap * CinP + ci] : 0.f;
+    }
+    __syncthreads();
+    const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long npix = (long long)p.B * p.H * p.W;
+    if (pix >= npix) return;
+    const int x = (int)(pix % p.W);
+    const long long t = pix / p.W;
+    const int y = (int)(t % p.H), n = (int)(t / p.H);
+    const __amdgpu_buffer_rsrc_t gsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.g), 0, p.g_bytes, 0x00020000);
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 gv[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {      // gather form of the transposed conv: input pixel = output pixel + pad - tap offset
+        const int hi = y + p.pad - tap / 3, wi = x + p.pad - tap % 3;
+        const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+        gv[tap] = __builtin_amdgcn_raw_buffer_load_b64(gsrc, ok ? (unsigned)((((long long)n * p.H + hi) * p.W + wi) * p.g_ld + p.g_coff) * 2u : HV_OOB, 0, 0);
+    }
+    float acc[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[c] = 0.f;
+#pragma unroll 1      // (fully unrolled the compiler hoists all 9 x CO filter reads: 256 registers + scratch)
+    for (int tap = 0; tap < 9; ++tap) {
+        const f16x4v h = __builtin_bit_cast(f16x4v, gv[tap]);
+        const float g0 = (float)h[0], g1 = (float)h[1], g2 = (float)h[2], g3 = (float)h[3];
+#pragma unroll
+        for (int c = 0; c < CO; ++c) {
+            const float4 w4 = *reinterpret_cast<const float4*>(wl + c * 36 + tap * 4);
+            acc[c] += g0 * w4.x + g1 * w4.y + g2 * w4.z + g3 * w4.w;
+        }
+    }
+    _Float16* yp = reinterpret_cast<_Float16*>(p.y) + pix * p.y_ld + p.y_coff;
+    const _Float16* mp = p.mul ? p.mul + pix * p.mul_ld + p.mul_coff : nullptr;
+#pragma unroll
+    for (int c0 = 0; c0 < CO; c0 += 4) {
+        if (c0 >= p.Cout) break;
+        f16x4v o;
+        f16x4v m4 = {(_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0}, y4 = m4;
+        if (mp) m4 = *reinterpret_cast<const f16x4v*>(mp + c0);
+        if (p.accumulate) y4 = *reinterpret_cast<const f16x4v*>(yp + c0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = acc[c0 + r] * p.alpha;
+            v = (float)(_Float16)v;                                           // the tile value is rounded to fp16 before the multiplier (as the MFMA kernels' second stage does)
+            if (mp) v = (float)(_Float16)(v * hv_act_grad_from_out((float)m4[r], p.mul_act));
+            if (p.accumulate) v += (float)y4[r];
+            o[r] = (_Float16)v;
+        }
+        *reinterpret_cast<f16x4v*>(yp + c0) = o;
+    }
+}
+
+// hv_conv2d: transposed, 3x3, stride 1, dilation 1, Cin <= 4 (channel stride 4), Cout in {8, 12, 16}, fp16 views, no bias / activation of its own
+int hv_conv2d_thin_dgrad(const hv_conv_desc* d, hipStream_t s) {
+    static const int on = getenv("HV_THIN_DGRAD") ? atoi(getenv("HV_THIN_DGRAD")) : 1;
+    if (!on || !d->transposed || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->dil != 1 || d->in_shift || d->w_bstride || d->ch_scale) return HV_ERR_UNSUPPORTED;
+    if (d->Cin > 4 || (d->x_ld & 3) || (d->x_coff & 3) || !d->x_f16 || !d->y_f16 || d->bias || d->act != HV_ACT_NONE || d->accumulate > 1) return HV_ERR_UNSUPPORTED;
+    if (d->Cout > 16 || (d->Cout & 3) || (d->y_ld & 3) || (d->y_coff & 3) || ((uintptr_t)d->y & 7) || ((uintptr_t)d->x & 7) || d->Ho != d->H || d->Wo != d->W) return HV_ERR_UNSUPPORTED;
+    if (d->mul_src && (!d->mul_f16 || (d->mul_ld & 3) || (d->mul_coff & 3) || ((uintptr_t)d->mul_src & 7))) return HV_ERR_UNSUPPORTED;
+    const long long npix = (long long)d->B * d->H * d->W;
+    if (npix * d->x_ld >= (1ll << 30) || npix >= (1ll << 31) - 256) return HV_ERR_UNSUPPORTED;
+    ThinK k;
+    k.g = reinterpret_cast<const _Float16*>(d->x); k.w = d->w; k.y = d->y; k.mul = reinterpret_cast<const _Float16*>(d->mul_src);
+    k.B = d->B; k.H = d->H; k.W = d->W; k.g_ld = d->x_ld; k.g_coff = d->x_coff; k.Cin = d->Cin; k.Cout = d->Cout; k.w_row = 9 * d->Cin;
+    k.y_ld = d->y_ld; k.y_coff = d->y_coff; k.mul_ld = d->mul_ld; k.mul_coff = d->mul_coff; k.mul_act = d->mul_act; k.accumulate = d->accumulate; k.pad = d->pad;
+    k.alpha = d->alpha;
+    k.g_bytes = (unsigned)(npix * d->x_ld * 2);
+    const dim3 grid((unsigned)((npix + 255) / 256));
+    hv_path_note = 9;
+    if (d->Cout <= 8) { HV_KNAME("thin_dgrad_kernel<8>"); hipLaunchKernelGGL(thin_dgrad_kernel<8>, grid, dim3(256), 0, s, k); }
+    else if (d->Cout <= 12) { HV_KNAME("thin_dgrad_kernel<12>"); hipLaunchKernelGGL(thin_dgrad_kernel<12>, grid, dim3(256), 0, s, k); }
+    else { HV_KNAME("thin_dgrad_kernel<16>"); hipLaunchKernelGGL(thin_dgrad_kernel<16>, grid, dim3(256), 0, s, k); }
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}

@@ -247,5 +247,7 @@ class _UnetFn(torch.autograd.Function):
     def backward(ctx, g_ct, g_mk):
         if ctx.plan.generation != ctx.generation:
             raise RuntimeError("UnetGenerator: a later forward pass of the same shape overwrote this pass's activations before its backward ran")
-        ctx.net.run_backward(ctx.plan, g_ct, g_mk)
+        S = ops.bridge_grad_scale(ctx.net.precision)       # fp16 storage mode: scaled seeds, parameter gradients unscaled afterwards
+        ctx.net.run_backward(ctx.plan, g_ct * S if (S != 1.0 and g_ct is not None) else g_ct, g_mk * S if (S != 1.0 and g_mk is not None) else g_mk)
+        ops.scale_inplace(ctx.net.paramset().flat_grad, 1.0 / S)
         return (None,) * 5

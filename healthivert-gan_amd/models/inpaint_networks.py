@@ -575,5 +575,8 @@ class _GeneratorFn(torch.autograd.Function):
         if ctx.plan.generation != ctx.generation:
             raise RuntimeError("Generator: a later forward pass of the same shape overwrote this pass's activations before its backward ran "
                                "(one activation plan per input shape); run backward before the next forward")
-        ctx.gen.run_backward(ctx.plan, g_cs, g_fs, g_x1, g_x2, g_p1, g_p2)
+        S = ops.bridge_grad_scale(ctx.gen.precision)       # fp16 storage mode: scaled seeds, parameter gradients unscaled afterwards
+        sc = (lambda t: None if t is None else t * S) if S != 1.0 else (lambda t: t)
+        ctx.gen.run_backward(ctx.plan, sc(g_cs), sc(g_fs), sc(g_x1), sc(g_x2), sc(g_p1), sc(g_p2))
+        ops.scale_inplace(ctx.gen.paramset().flat_grad, 1.0 / S)
         return (None,) * 9

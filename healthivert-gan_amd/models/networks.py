@@ -408,8 +408,17 @@ class _DiscFn(torch.autograd.Function):
         acc = pg and not grads_are_fresh(net)
         if pg:
             net.paramset().attach_grads()
-        dx = net.run_backward(plan, g.contiguous(), need_dx=ctx.need_dx, param_grads=pg, accumulate=acc)
+        # fp16 storage mode: scaled seeds (ops.bridge_grad_scale); gradients already in .grad are scaled up first when this call accumulates
+        S = ops.bridge_grad_scale(net.precision)
+        flat = net.paramset().flat_grad if pg else None
+        if acc:
+            ops.scale_inplace(flat, S)
+        dx = net.run_backward(plan, g.contiguous() * S if S != 1.0 else g.contiguous(), need_dx=ctx.need_dx, param_grads=pg, accumulate=acc)
         if pg:
             net.finish()
+            ops.scale_inplace(flat, 1.0 / S)
         plan.pending = None
-        return (dx.clone() if dx is not None else None), None, None, None, None
+        if dx is not None:
+            dx = dx.clone()
+            ops.scale_inplace(dx, 1.0 / S)
+        return dx, None, None, None, None

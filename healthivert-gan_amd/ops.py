@@ -52,6 +52,22 @@ def cpad(C):
     return rup(C, 8) if C > 16 else rup(C, 4)
 
 
+def bridge_grad_scale(precision):
+    """Power-of-two gradient scale of the nn.Module autograd bridges (`loss.backward()` on module outputs) in the fp16 storage mode: the
+    activation gradients of these networks are 1e-5 .. 1e-7 -- subnormal or zero in fp16 -- so the incoming seeds are multiplied by S, the
+    backward is linear in them, and the parameter gradients / the input gradient are multiplied by 1/S afterwards (exact).  1 in the fp32 mode."""
+    if precision_id(precision) != F16:
+        return 1.0
+    s = float(os.environ.get('HV_GRAD_SCALE', '8192'))
+    return s if s > 0 else 1.0
+
+
+def scale_inplace(t, factor):
+    """t *= factor on the current stream (fp32 tensor)."""
+    if factor != 1.0 and t is not None and t.numel():
+        _lib.get().call('hv_affine', ptr(t), ptr(t), ctypes.c_longlong(t.numel()), ctypes.c_float(factor), ctypes.c_float(0.0), stream())
+
+
 def storage_dtype(precision):
     """Element type of the activation / gradient tensors INSIDE a network for a compute precision: the fp16 mode stores them as
     fp16 (they are rounded to fp16 as MFMA operands anyway: half the HBM / L2 bytes, no conversions in the staging code), the

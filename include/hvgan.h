@@ -246,6 +246,11 @@ int hv_ca_fuse(const float* S, float* out, int B, int h, int w, int adjoint, voi
 int hv_ca_softmax(const float* S, const float* mm, float* A, int B, int L, float scale, int* argmax, void* stream);
 int hv_ca_softmax_batched(const float* S, const float* mm, long long mm_bstride, float* A, int B, int L, float scale, int* argmax,
                           void* stream);   /* mm_bstride = L: per-sample masks from hv_ca_mask_batched; 0: shared */
+/* hv_ca_fuse (forward) + hv_ca_softmax[_batched] in one pass for the 32 x 32 attention map: the fused scores never reach memory.  S = the raw
+ * scores [B][L][L]; writes A (fp32) and, when A_f16 != NULL, its fp16 copy (operand of the paste GEMM).  HV_ERR_UNSUPPORTED for other map sizes
+ * (callers then run the two kernels). */
+int hv_ca_fuse_softmax(const float* S, const float* mm, long long mm_bstride, float* A, void* A_f16, int B, int h, int w, float scale,
+                       int* argmax, void* stream);
 /* offset_flow of the reference's 7-tuple (:368,:389-410 + inpaint_tools.flow_to_image/compute_color :73-100,181-211): the arg-max offsets
  * coloured with the Middlebury wheel (double precision, running maximum radius over samples 0..b like the reference's batch loop), as
  * uint8/255 and nearest-upsampled x`up` (rate*4): flow[B][3][h*up][w*up] (NCHW like the reference's tensor). */

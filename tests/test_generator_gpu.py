@@ -225,6 +225,48 @@ def test_discriminator_module_api_two_forwards_then_one_backward(norm):
     o2[0].sum().backward()
 
 
+def test_module_api_backward_in_fp16_storage_mode_scales_its_gradients():
+    """The nn.Module autograd bridges in the fp16 storage mode: a loss with small seeds (mean over the logits times 1e-2: ~1e-6 per logit, the
+    size of this model's real activation gradients) backpropagated through `loss.backward()`.  Without the bridges' power-of-two gradient scale
+    these gradients are subnormal or zero in the fp16 gradient buffers; with it the parameter gradients and the input gradient follow the
+    oracle's (relative L2, fp16 operands), also when a second backward accumulates into .grad."""
+    import hvgan  # noqa: F401
+    from hvgan.models import networks
+    from hvgan.optim import FusedAdam
+    from oracle import restate as R
+    g = load_golden('g3_disc_batch')
+    dev = torch.device('cuda:0')
+    net = networks.define_D(1, 8, 'basic', 3, 'batch', 'normal', 0.02, [])
+    net.load_state_dict(g['sd'])
+    net.cuda().train()
+    net.precision = 'fp16'
+    opt = FusedAdam(net.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    sd = {k: v.clone() for k, v in g['sd'].items()}
+    params = [k for k in sd if k.endswith('.weight') or k.endswith('.bias')]
+    for k in params:
+        sd[k].requires_grad_(True)
+    x0, x1 = g['x']['0'], g['x']['1']
+    opt.zero_grad()
+    xa = x0.to(dev).requires_grad_(True)
+    (net(xa).mean() * 1e-2).backward()
+    (net(x1.to(dev)).mean() * 1e-2).backward()          # accumulates into .grad (scaled up, added to, scaled down again)
+    torch.cuda.synchronize()
+    xr = x0.clone().requires_grad_(True)
+    r0, u = R.disc_forward(sd, xr, 'batch', True)
+    with torch.no_grad():
+        for k, v in u.items():
+            sd[k].copy_(v)
+    r1, _ = R.disc_forward(sd, x1, 'batch', True)
+    (r0.mean() * 1e-2 + r1.mean() * 1e-2).backward()
+    got = dict(net.named_parameters())
+    for k in params:
+        ref, gk = sd[k].grad, got[k].grad.cpu()
+        rel = (gk - ref).norm().item() / max(ref.norm().item(), 1e-30)
+        assert rel <= 0.05, (k, rel, ref.norm().item(), gk.norm().item())
+    rel = (xa.grad.cpu() - xr.grad).norm().item() / xr.grad.norm().item()
+    assert rel <= 0.05 and xr.grad.abs().max().item() < 1e-4, (rel, xr.grad.abs().max().item())
+
+
 @pytest.mark.parametrize('M,N,K,batch,scaled,split', [(1024, 1024, 576, 8, True, 0), (1024, 576, 1024, 3, False, 0), (200, 68, 64, 2, True, 0),
                                                       (128, 128, 32, 16, False, 0), (256, 1024, 128, 8, False, 64)])
 def test_batched_nt_gemm_against_torch(M, N, K, batch, scaled, split):

