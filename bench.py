@@ -52,6 +52,7 @@ def parse():
     ap.add_argument('--precision', default=os.environ.get('HV_PRECISION', 'fp16'), choices=['fp16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-inference', action='store_true', help='skip the config-#4 inference sub-record')
+    ap.add_argument('--no-extra', action='store_true', help='skip the device-loader and fp32-mode sub-records')
     ap.add_argument('--serial', action='store_true', help='one HIP stream for the whole run (profiling: per-kernel durations without stream-level overlap)')
     ap.add_argument('--no-graph', action='store_true', help='launch kernels eagerly instead of replaying captured hipGraphs')
     ap.add_argument('--dry-run', action='store_true', help='CPU-only rehearsal of the multi-rank path over gloo (no GPU, no kernels)')
@@ -116,10 +117,23 @@ def dry_run(args, rank, world):
         dist.destroy_process_group()
 
 
-def cpu_baseline(model, size, seed, batch_size=4, warm=1, timed=3):
-    """The CPU oracle (oracle/restate.py, kind 'port') on the same weights: `warm` untimed + `timed` timed full train steps at a
-    bounded batch size (about 10-30 s of CPU work in all; slices/s of the CPU step depends little on the batch size: BASELINE.md
-    section 3 measured 0.71 at bs=2 and 0.82 at bs=16 on 8 cores)."""
+def physical_cores():
+    """Physical cores of the host (distinct (physical id, core id) pairs of /proc/cpuinfo); None when unknown."""
+    try:
+        seen, phys = set(), None
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('physical id'):
+                phys = line.split(':')[1].strip()
+            elif line.startswith('core id'):
+                seen.add((phys, line.split(':')[1].strip()))
+        return len(seen) or None
+    except OSError:
+        return None
+
+
+def cpu_baseline(model, size, seed, batch_size=16, warm=1, timed=3):
+    """The CPU oracle (oracle/restate.py, kind 'port') on the same weights: `warm` untimed + `timed` timed full train steps at the benchmarked
+    batch size (bs = 16, 1 warm-up + >= 3 timed; about two minutes on a 128-core host)."""
     import torch
     from hvgan import synth
     from oracle import restate as R
@@ -134,10 +148,77 @@ def cpu_baseline(model, size, seed, batch_size=4, warm=1, timed=3):
         if i >= warm:
             times.append(time.time() - t0)
     dt = sum(times) / len(times)
-    return dict(value=round(batch_size / dt, 3), unit='slices/s', cores=torch.get_num_threads(), kind='port',
-                sample='%d warm-up + %d timed full train steps (G + 3xD) at bs=%d, %dx%d, fp32, CPU oracle oracle/restate.py'
-                       % (warm, timed, batch_size, size, size),
+    return dict(value=round(batch_size / dt, 3), unit='slices/s', cores=torch.get_num_threads(), physical_cores=physical_cores(),
+                logical_cpus=os.cpu_count(), kind='port',
+                sample='%d warm-up + %d timed full train steps (G + 3xD) at bs=%d, %dx%d, fp32, CPU oracle oracle/restate.py, %d torch threads'
+                       % (warm, timed, batch_size, size, size, torch.get_num_threads()),
                 seconds_per_step=[round(t, 2) for t in times], gflops=round(GFLOP_PER_SLICE * batch_size / dt, 1))
+
+
+def fp32_record(args, dev, local_rank):
+    """The same step in the exact-fp32 parity mode (the reference's own arithmetic: fp32 MFMA, fp32 storage): 3 warm-up + 10 timed steps."""
+    import torch
+    from hvgan import synth
+    from hvgan.models.pix2pix_model import Pix2PixModel
+    prev = os.environ.get('HV_PRECISION')
+    os.environ['HV_PRECISION'] = 'fp32'
+    try:
+        torch.manual_seed(1234)
+        opt = make_opt('fp32')
+        opt.gpu_ids = [local_rank]
+        m = Pix2PixModel(opt)
+        m.setup(opt)
+        m.strict_graph = True
+        m.set_input(synth.make_batch(args.batch, args.size, seed=1234))
+        for _ in range(max(3, m.GRAPH_WARMUP + 1)):
+            m.optimize_parameters()
+        torch.cuda.synchronize()
+        n, t0 = 10, time.perf_counter()
+        for _ in range(n):
+            m.optimize_parameters()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        return {'ms_per_step': round(dt * 1e3, 3), 'slices_s': round(args.batch / dt, 1), 'steps': n,
+                'precision': 'fp32 MFMA (v_mfma_f32_16x16x4_f32), fp32 storage: the |d| <= 1e-3 parity mode'}
+    finally:
+        if prev is None:
+            os.environ.pop('HV_PRECISION', None)
+        else:
+            os.environ['HV_PRECISION'] = prev
+
+
+def device_loader_record(model, args, dev):
+    """The real train loop: every step assembles 16 FRESH slices on the device from resident synthetic volumes (batch_assembly.DeviceBatchAssembler,
+    SURVEY.md section 8f row f1) and hands them to set_input before optimize_parameters -- the bench's timed region replays one resident batch."""
+    import numpy as np
+    import torch
+    from hvgan import synth
+    from hvgan.batch_assembly import VertebraVolume, DeviceBatchAssembler
+    nvol = 32
+    raw = [synth.make_spine_volume(s, H=args.size, W=args.size, Z=48, pitch=48) for s in range(4)]
+    vols = [VertebraVolume(*raw[i % 4], 11 + i % 3, ['10', '14'], path='v%d' % i) for i in range(nvol)]
+    asm = DeviceBatchAssembler(vols, str(dev))
+    rng = np.random.RandomState(0)
+    order = rng.permutation(nvol)
+    state = np.random.get_state()
+    np.random.seed(0)
+
+    def step(i):
+        model.set_input(asm.batch([int(order[(args.batch * i + j) % nvol]) for j in range(args.batch)]))
+        model.optimize_parameters()
+    try:
+        for i in range(4):
+            step(i)
+        torch.cuda.synchronize()
+        n, t0 = 10, time.perf_counter()
+        for i in range(n):
+            step(4 + i)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+    finally:
+        np.random.set_state(state)
+    return {'ms_per_step': round(dt * 1e3, 3), 'slices_s': round(args.batch / dt, 1), 'steps': n,
+            'what': 'set_input(DeviceBatchAssembler.batch(16 fresh slice draws)) + optimize_parameters per step, %d resident volumes' % nvol}
 
 
 def inference_record(dev, precision):
@@ -243,12 +324,16 @@ def main():
     dom_mfma = prof.dominant_mfma(MFMA_PEAK_TFLOPS[args.precision])      # the largest MFMA-bound instantiation (the PatchGAN 4x4 layers), timed beside it
     prof.disable()
     engine.SERIAL = serial0
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):       # the timed region: K steps (graph replays unless --no-graph)
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
+    # the timed region: K steps (graph replays unless --no-graph) between barrier + synchronize on both sides -- run three times back to back,
+    # the MEDIAN region is reported (all three are on the record: `regions_ms_per_step`)
+    region_dt = []
+    for _ in range(3):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        region_dt.append(time.perf_counter() - t0)
     # roofline leg: the same K steps once more, launched eagerly on ONE stream with HIP events around the dominant
     # kernel's launches (a captured graph cannot carry timing events, and with other streams busy an event pair would
     # also time the wait for free CUs); `bench.py --serial` under rocprofv3 gives the matching per-kernel averages.
@@ -263,10 +348,11 @@ def main():
     fine = model.netG.time_fine
     model.netG.time_fine = None
     engine.SERIAL = serial0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:      # MAX over ranks, region by region
+        t = torch.tensor(region_dt, device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        region_dt = [float(v) for v in t.tolist()]
+    dt = sorted(region_dt)[1]
     ms = dt / args.steps * 1e3
     value = world * args.batch * args.steps / dt
 
@@ -279,6 +365,10 @@ def main():
                                % (args.size, args.size, args.batch),
                    'global_batch': world * args.batch, 'precision': engine.precision_note(args.precision), 'parallelism': 'dp%d' % world},
         'achieved_tflops': round(GFLOP_PER_SLICE * value / 1e3, 2),
+        'regions_ms_per_step': [round(r / args.steps * 1e3, 3) for r in region_dt],
+        # what the collective layer actually saw (an N-GPU record must show N ranks behind RCCL)
+        'comm': {'backend': (dist.get_backend() if dist.is_initialized() else None), 'world_size': (dist.get_world_size() if dist.is_initialized() else 1),
+                 'grad_exchange': ('flat all-reduce (mean) per network on a side stream' if world > 1 else 'none (single rank)')},
     }
     if rank == 0:
         out['roofline'] = prof.roofline(args.precision, MFMA_PEAK_TFLOPS[args.precision], name=dom[0] if dom else None)
@@ -320,6 +410,9 @@ def main():
         out['losses'] = {k: round(v, 4) for k, v in model.get_current_losses().items()}
         if world == 1 and not args.no_inference and args.size == 256:
             out['inference'] = inference_record(dev, args.precision)
+        if world == 1 and not args.no_extra and args.precision == 'fp16':
+            out['device_loader'] = device_loader_record(model, args, dev)
+            out['fp32'] = fp32_record(args, dev, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(model, args.size, 1234)
         print(json.dumps(out), flush=True)

@@ -499,135 +499,10 @@ extern "C" int hv_ca_softmax_batched(const float* S, const float* mm, long long 
     HV_LAUNCH_CHECK();
     return HV_OK;
 }
-// ---- score fusion + masked scaled softmax in one pass (32 x 32 attention map) ---------------------------------------------------------------
-// hv_ca_fuse writes the fused scores (64 MB at bs 16), hv_ca_softmax reads them back and writes A (another 64 MB): 58 + 41 us.  Here a workgroup owns
-// one grid row of p (32 consecutive score rows) and walks the 32 column tiles with ca_fuse_tile32_kernel's three 34 x 34 pieces per tile (next
-// tile's pieces in flight in registers behind this tile's sums); the fused rows stay in LDS ([32][1024] floats), then every wave runs the masked
-// x scale softmax of 8 rows from LDS and writes A (fp32, for the backward) and, when asked, its fp16 copy (the paste GEMM's operand: half the bytes
-// through its staging path) plus the arg-max.  Fusion sums in ca_fuse_tile32_kernel's (d, e) order; the softmax's row sum is a wave-level sum.
-__global__ __launch_bounds__(256) void ca_fuse_softmax32_kernel(const float* __restrict__ S, const float* __restrict__ mm, long long mm_bs,
-                                                                float* __restrict__ A, _Float16* __restrict__ Ah, float scale, int* __restrict__ argmax) {
-    constexpr int W = 32, HH = 32, L = W * HH, TS = 34, LDT = 35, LDR = L + 4, NIT = (TS * TS + 255) / 256;
-    extern __shared__ __attribute__((aligned(16))) float fs_smem[];
-    float* rowbuf = fs_smem;                       // [32][LDR]
-    float* T = fs_smem + 32 * LDR;                 // [3][TS * LDT]
-    const int b = blockIdx.y, py0 = blockIdx.x, p0 = py0 * W;
-    const float* Sb = S + (long long)b * L * L;
-    int pb[3];
-    pb[0] = py0 >= 1 ? p0 - W : (HH - 1) * W - 1;  pb[1] = p0;  pb[2] = py0 < HH - 1 ? p0 + W : 1;
-    float v[3][NIT];
-    auto load = [&](int ly0) __attribute__((always_inline)) {
-        const int l0 = ly0 * W;
-        int lb[3];
-        lb[0] = ly0 >= 1 ? l0 - W : (HH - 1) * W - 1;  lb[1] = l0;  lb[2] = ly0 < HH - 1 ? l0 + W : 1;
-#pragma unroll
-        for (int d = 0; d < 3; ++d)
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int e = threadIdx.x + it * 256, i = e / TS, j = e - i * TS;
-                const int pr = pb[d] - 1 + i, lc = lb[d] - 1 + j;
-                v[d][it] = (e < TS * TS && (unsigned)pr < (unsigned)L && (unsigned)lc < (unsigned)L) ? Sb[(long long)pr * L + lc] : 0.f;
-            }
-    };
-    load(0);
-    const int r = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * 4;
-    for (int ly0 = 0; ly0 < HH; ++ly0) {
-#pragma unroll
-        for (int d = 0; d < 3; ++d)
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int e = threadIdx.x + it * 256, i = e / TS, j = e - i * TS;
-                if (e < TS * TS) T[d * TS * LDT + i * LDT + j] = v[d][it];
-            }
-        __syncthreads();
-        if (ly0 + 1 < HH) load(ly0 + 1);
-        float o[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int c = c0 + u;
-            float acc = 0.f;
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                const bool vp = d == 1 || (d == 0 ? (py0 >= 1 || r >= 1) : (py0 < HH - 1 || r + 1 < W));
-                const bool vl = d == 1 || (d == 0 ? (ly0 >= 1 || c >= 1) : (ly0 < HH - 1 || c + 1 < W));
-                if (!(vp && vl)) continue;
-                acc += T[d * TS * LDT + r * LDT + c];
-                acc += T[d * TS * LDT + (r + 1) * LDT + c + 1];
-                acc += T[d * TS * LDT + (r + 2) * LDT + c + 2];
-            }
-            o[u] = acc;
-        }
-        *reinterpret_cast<float4*>(rowbuf + r * LDR + ly0 * W + c0) = make_float4(o[0], o[1], o[2], o[3]);
-        __syncthreads();
-    }
-    // masked x scale softmax: wave w -> rows 8w .. 8w + 7; lane -> columns 4 lane + 256 k
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float* mrow = mm + (long long)b * mm_bs;
-    float m[16];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const float4 m4 = *reinterpret_cast<const float4*>(mrow + k * 256 + lane * 4);
-        m[k * 4] = m4.x; m[k * 4 + 1] = m4.y; m[k * 4 + 2] = m4.z; m[k * 4 + 3] = m4.w;
-    }
-    for (int rr = 0; rr < 8; ++rr) {
-        const int row = wave * 8 + rr;
-        float x[16];
-        float mx = -3.0e38f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float4 s4 = *reinterpret_cast<const float4*>(rowbuf + row * LDR + k * 256 + lane * 4);
-            x[k * 4] = s4.x * m[k * 4] * scale; x[k * 4 + 1] = s4.y * m[k * 4 + 1] * scale;
-            x[k * 4 + 2] = s4.z * m[k * 4 + 2] * scale; x[k * 4 + 3] = s4.w * m[k * 4 + 3] * scale;
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, x[i]);
-        mx = hv_wave_max(mx);
-        float sum = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { x[i] = expf(x[i] - mx); sum += x[i]; }
-        sum = hv_wave_sum(sum);
-        float best = -1.f;
-        int bi = 0x7fffffff;
-        const long long orow = ((long long)b * L + p0 + row) * L;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float o4[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                o4[u] = x[k * 4 + u] / sum * m[k * 4 + u];
-                if (o4[u] > best) { best = o4[u]; bi = k * 256 + lane * 4 + u; }
-            }
-            *reinterpret_cast<float4*>(A + orow + k * 256 + lane * 4) = make_float4(o4[0], o4[1], o4[2], o4[3]);
-            if (Ah) *reinterpret_cast<f16x4*>(Ah + orow + k * 256 + lane * 4) = (f16x4){(_Float16)o4[0], (_Float16)o4[1], (_Float16)o4[2], (_Float16)o4[3]};
-        }
-        if (argmax) {      // first index of the maximum (torch.argmax tie rule on CPU)
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const float ob = __shfl_xor(best, o, 64);
-                const int oi = __shfl_xor(bi, o, 64);
-                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-            }
-            if (lane == 0) argmax[(long long)b * L + p0 + row] = bi;
-        }
-    }
-}
-extern "C" int hv_ca_fuse_softmax(const float* S, const float* mm, long long mm_bstride, float* A, void* A_f16, int B, int h, int w, float scale,
-                                  int* argmax, void* stream) {
-    if (!S || !mm || !A || B <= 0 || mm_bstride < 0) return HV_ERR_ARG;
-    if (h != 32 || w != 32 || B > 65535 || ((uintptr_t)A & 15) || ((uintptr_t)A_f16 & 7) || ((uintptr_t)mm & 15) || (mm_bstride & 3)) return HV_ERR_UNSUPPORTED;
-    constexpr size_t lds = (size_t)(32 * (1024 + 4) + 3 * 34 * 35) * sizeof(float);
-    static bool raised = false;
-    if (!raised) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ca_fuse_softmax32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return -1000 - (int)e;
-        raised = true;
-    }
-    hipLaunchKernelGGL(ca_fuse_softmax32_kernel, dim3(32, B), dim3(256), lds, (hipStream_t)stream, S, mm, mm_bstride, A, reinterpret_cast<_Float16*>(A_f16),
-                       scale, argmax);
-    HV_LAUNCH_CHECK();
-    return HV_OK;
-}
-
+// (Measured and not kept, round 3: score fusion + softmax as ONE kernel -- a workgroup per grid row of p walking the 32 column tiles with the fused
+// rows held in LDS ([32][1024] floats), then the softmax from LDS: 128 us against 58 + 41 us for the two kernels.  The 131 KB row buffer leaves one
+// 4-wave workgroup per CU, and the tile loop (15 four-byte loads, 15 LDS stores, 36 LDS reads per lane and tile) is then fully exposed; the two
+// separate kernels run at 8 workgroups per CU and the extra 128 MB round trip of the fused scores costs less than that.)
 // dS[p][l] = scale*mm[l]*A[p][l]*(dA[p][l] - sum_l' dA[p][l']*A[p][l'])   (A already carries the mask)
 __global__ __launch_bounds__(256) void ca_softmax_bwd_kernel(const float* __restrict__ dA, const float* __restrict__ A, const float* __restrict__ mm,
                                                              float* __restrict__ dS, int L, float scale) {

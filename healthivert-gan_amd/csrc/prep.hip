@@ -430,6 +430,63 @@ __global__ __launch_bounds__(256) void adam_kernel(const hv_adam_tensor* __restr
     }
 }
 
+// ---- guarded form (fp16 storage mode: the gradients carry a loss scale and may have overflowed to inf / nan in an fp16 gradient buffer)
+// state[0] = step count, [1] = "this gradient is not finite" (set by the check, consumed by the tick), [2] = skipped steps so far, [3] = skip THIS step
+__global__ __launch_bounds__(256) void grad_finite_check_kernel(const float* __restrict__ g, long long n, float* __restrict__ state) {
+    bool bad = false;
+    for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * 1024) {
+        if (i + 3 < n) {
+            const float4 v = *reinterpret_cast<const float4*>(g + i);
+            bad |= !(fabsf(v.x) <= 3.0e38f) | !(fabsf(v.y) <= 3.0e38f) | !(fabsf(v.z) <= 3.0e38f) | !(fabsf(v.w) <= 3.0e38f);      // false for inf AND nan
+        } else {
+            for (long long j = i; j < n; ++j) bad |= !(fabsf(g[j]) <= 3.0e38f);
+        }
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) state[1] = 1.f;      // every writer stores the same value
+}
+__global__ void adam_guard_tick_kernel(float* state) {
+    const bool bad = state[1] != 0.f;
+    if (bad) state[2] += 1.f; else state[0] += 1.f;
+    state[3] = bad ? 1.f : 0.f;
+    state[1] = 0.f;
+}
+__global__ __launch_bounds__(256) void adam_guarded_kernel(const hv_adam_tensor* __restrict__ ts, const float* __restrict__ lr_p, float beta1,
+                                                           float beta2, float eps, const float* __restrict__ state) {
+    if (state[3] != 0.f) return;          // a non-finite gradient: weights, moments and step count stay as they are
+    const hv_adam_tensor t = ts[blockIdx.y];
+    const long long base = (long long)blockIdx.x * 1024;
+    if (base >= t.n) return;
+    const float step = state[0], lr = lr_p[0];
+    const float bc1 = 1.f - powf(beta1, step), bc2 = 1.f - powf(beta2, step);
+    const float step_size = lr / bc1, bc2_sqrt = sqrtf(bc2);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long long i = base + k * 256 + threadIdx.x;
+        if (i < t.n) {
+            const float g = t.g[i];
+            const float m = t.m[i] + (g - t.m[i]) * (1.f - beta1);
+            const float v = t.v[i] * beta2 + (1.f - beta2) * g * g;
+            t.m[i] = m;
+            t.v[i] = v;
+            const float denom = sqrtf(v) / bc2_sqrt + eps;
+            t.p[i] = t.p[i] - step_size * (m / denom);
+        }
+    }
+}
+extern "C" int hv_adam_step_guarded(const hv_adam_tensor* d_tensors, int n_tensors, long long max_numel, const float* d_lr, float beta1,
+                                    float beta2, float eps, float* d_state, const float* flat_grad, long long n_grad, void* stream) {
+    if (!d_tensors || n_tensors <= 0 || max_numel <= 0 || !d_lr || !d_state || !flat_grad || n_grad <= 0 || ((uintptr_t)flat_grad & 15)) return HV_ERR_ARG;
+    const int blocks = (int)(n_grad / 4096 + 1 < 512 ? n_grad / 4096 + 1 : 512);
+    hipLaunchKernelGGL(grad_finite_check_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, flat_grad, n_grad, d_state);
+    HV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(adam_guard_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, d_state);
+    HV_LAUNCH_CHECK();
+    dim3 grid(hv_cdiv(max_numel, 1024), n_tensors);
+    hipLaunchKernelGGL(adam_guarded_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_tensors, d_lr, beta1, beta2, eps, d_state);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+
 extern "C" int hv_adam_step(const hv_adam_tensor* d_tensors, int n_tensors, long long max_numel, const float* d_lr, float beta1,
                             float beta2, float eps, float* d_step, void* stream) {
     if (!d_tensors || n_tensors <= 0 || max_numel <= 0 || !d_lr || !d_step) return HV_ERR_ARG;

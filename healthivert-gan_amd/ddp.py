@@ -25,15 +25,24 @@ def init_from_env():
     nobody has joined it yet.  Returns the local device index this rank must drive, or None when the process is not part
     of a multi-process job.  Backend: RCCL ('nccl' IS RCCL on ROCm); HV_DDP_BACKEND=gloo for dry runs / tests."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world <= 1 or not dist.is_available():
+    force = os.environ.get('HV_DDP_FORCE') == '1'       # a one-rank group: the exact data-parallel schedule (phase graphs, exchange stream, RCCL calls) on one GPU
+    if (world <= 1 and not force) or not dist.is_available():
         return None
+    if world <= 1:
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('LOCAL_RANK', '0')
+        world = 1
     local = int(os.environ.get('LOCAL_RANK', os.environ.get('RANK', '0')))
     ndev = torch.cuda.device_count()
     if ndev and local >= ndev:      # rehearsal of N ranks on fewer devices (gloo backend; RCCL refuses two ranks on one device)
         local %= ndev
     if not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29500')
+        if 'MASTER_PORT' not in os.environ:      # (no launcher: a one-rank rehearsal) any free port of this host
+            import socket
+            with socket.socket() as sk:
+                sk.bind(('127.0.0.1', 0))
+                os.environ['MASTER_PORT'] = str(sk.getsockname()[1])
         backend = os.environ.get('HV_DDP_BACKEND', 'nccl')
         kw = {}
         if backend == 'nccl':

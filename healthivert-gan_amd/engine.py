@@ -337,7 +337,6 @@ def conv_backward_chain(nodes, book, prec, tmp_full=None, premultiplied_first=Fa
 
 
 # ================================================================================================ contextual attention
-CA_FUSED = os.environ.get('HV_CA_FUSED', '1') != '0'   # score fusion + softmax as one kernel (32 x 32 maps)
 CA_GEMM = os.environ.get('HV_CA_GEMM', '1') != '0'     # fp16 mode: the attention block's five contractions as batched NT GEMMs (csrc/bgemm.hip)
 
 
@@ -412,31 +411,19 @@ class AttentionPlan:
             _bgemm(self.wp, self.wp, self.S0.t, L, L, 9 * C, B, colscale=self.rnorm)
         else:
             ops.conv2d(self.fd, self.wp, self.S0, 3, 1, 1, 1, w_bstride=L * 9 * C, ch_scale=self.rnorm, ch_scale_bstride=L, precision=prec)
-        # score fusion + softmax in one pass where the map is 32 x 32 (the fused scores stay in LDS; A also written as fp16 for the paste GEMM)
-        fused = False
-        if self.fuse and CA_FUSED and self.h == 32 and self.w == 32:
-            if gemm and getattr(self, 'A_h', None) is None:
-                self.A_h = torch.zeros(B, L, L, dtype=torch.float16, device=f.t.device)
-            rc = L_.cdll.hv_ca_fuse_softmax(ptr(self.S0.t), ptr(self.mm_b if per_sample_mask else self.mm), ctypes.c_longlong(L if per_sample_mask else 0),
-                                            ptr(self.A.t), ptr(self.A_h) if gemm else None, B, self.h, self.w, ctypes.c_float(self.scale),
-                                            ptr(self.argmax) if want_argmax else None, stream())
-            if rc not in (0, -2):      # -2 = HV_ERR_UNSUPPORTED: another map size, the two-kernel path below
-                raise RuntimeError('hv_ca_fuse_softmax failed: %d' % rc)
-            fused = rc == 0
-        if not fused:
-            if self.fuse:
-                L_.call('hv_ca_fuse', ptr(self.S0.t), ptr(self.S1.t), B, self.h, self.w, 0, stream())
-                s = self.S1
-            else:
-                s = self.S0
-            if per_sample_mask:
-                L_.call('hv_ca_softmax_batched', ptr(s.t), ptr(self.mm_b), ctypes.c_longlong(L), ptr(self.A.t), B, L, ctypes.c_float(self.scale),
-                        ptr(self.argmax) if want_argmax else None, stream())
-            else:
-                L_.call('hv_ca_softmax', ptr(s.t), ptr(self.mm), ptr(self.A.t), B, L, ctypes.c_float(self.scale),
-                        ptr(self.argmax) if want_argmax else None, stream())
+        if self.fuse:
+            L_.call('hv_ca_fuse', ptr(self.S0.t), ptr(self.S1.t), B, self.h, self.w, 0, stream())
+            s = self.S1
+        else:
+            s = self.S0
+        if per_sample_mask:
+            L_.call('hv_ca_softmax_batched', ptr(s.t), ptr(self.mm_b), ctypes.c_longlong(L), ptr(self.A.t), B, L, ctypes.c_float(self.scale),
+                    ptr(self.argmax) if want_argmax else None, stream())
+        else:
+            L_.call('hv_ca_softmax', ptr(s.t), ptr(self.mm), ptr(self.A.t), B, L, ctypes.c_float(self.scale),
+                    ptr(self.argmax) if want_argmax else None, stream())
         if gemm:    # paste = (A rawT^T) folded: O[p][(c, tap)], then every output pixel sums the 4 taps that reach it
-            _bgemm(self.A_h if fused else self.A.t, self.rawT_h, self.O, L, 16 * C, L, B, b_split=C)          # rows of rawT [c][tap] taken as (tap, c): O[p][tap][c]
+            _bgemm(self.A.t, self.rawT_h, self.O, L, 16 * C, L, B, b_split=C)          # rows of rawT [c][tap] taken as (tap, c): O[p][tap][c]
             L_.call('hv_ca_fold', ptr(self.O), ptr(out.t), B, H, W, C, out.ld, ctypes.c_float(0.25), 0, stream())
         else:
             ops.conv2d(self.A, self.rawT, out, 4, 2, 1, 1, transposed=True, alpha=0.25, w_bstride=C * 16 * L, precision=prec)

@@ -393,7 +393,7 @@ class Pix2PixModel(BaseModel):
             if side is not main:
                 side.wait_stream(main)
             with torch.cuda.stream(side):
-                getattr(self, 'optimizer_D_%d' % k).step(sync_lr=False)
+                self._opt_step(getattr(self, 'optimizer_D_%d' % k), getattr(self, 'netD_%d' % k))
                 self._g_step_D(k)
         self._join_d(main)
         self.set_requires_grad([self.netD_1, self.netD_2, self.netD_3], False)
@@ -401,7 +401,19 @@ class Pix2PixModel(BaseModel):
         self.backward_G(d_done=True)
 
     def _phase_c(self):
-        self.optimizer_G.step(sync_lr=False)
+        self._opt_step(self.optimizer_G, self.netG)
+
+    def _opt_step(self, optimizer, net):
+        """Adam step; in the fp16 storage mode behind the device-side overflow guard: the scaled gradients of a step may overflow an fp16 gradient
+        buffer (inf / nan), which then reach every parameter gradient of the network -- such a step is skipped (weights, moments, step count
+        unchanged; under data parallelism the check runs on the reduced gradient, so every rank takes the same decision) and counted
+        (overflow_steps()).  The scale itself is static (HV_GRAD_SCALE, a power of two; head room in DESIGN.md section 3)."""
+        optimizer.step(sync_lr=False, guard_flat=net.paramset().flat_grad if self.grad_scale != 1.0 else None)
+
+    def overflow_steps(self):
+        """{network: optimiser steps skipped by the overflow guard so far} (a host read)."""
+        self.sync_tail()
+        return {n: getattr(self, 'optimizer_' + n).skipped_steps() for n in ('G', 'D_1', 'D_2', 'D_3')}
 
     def _join_d(self, main):
         if self.concurrent_d and not engine.SERIAL:
@@ -474,7 +486,7 @@ class Pix2PixModel(BaseModel):
 
         def dstep(k):
             def f():
-                getattr(self, 'optimizer_D_%d' % k).step(sync_lr=False)
+                self._opt_step(getattr(self, 'optimizer_D_%d' % k), getattr(self, 'netD_%d' % k))
                 self._g_step_D(k)
             return f
 

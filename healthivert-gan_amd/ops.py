@@ -374,8 +374,13 @@ def gan_loss(z, target_is_real, mode='vanilla', loss=None, loss_weight=1.0, loss
            ptr(loss), int(loss_accumulate), ctypes.c_float(grad_weight), ptr(dz), stream())
 
 
-def adam_step(table, max_numel, lr_dev, beta1, beta2, eps, step_dev):
+def adam_step(table, max_numel, lr_dev, beta1, beta2, eps, step_dev, guard_flat=None):
     L = _lib.get()
+    if guard_flat is not None:      # step_dev: 4 floats (hv_adam_step_guarded)
+        L.call('hv_adam_step_guarded', ctypes.cast(table.ptr(), ctypes.POINTER(L.hv_adam_tensor)), table.n, ctypes.c_longlong(max_numel),
+               ptr(lr_dev), ctypes.c_float(beta1), ctypes.c_float(beta2), ctypes.c_float(eps), ptr(step_dev), ptr(guard_flat),
+               ctypes.c_longlong(guard_flat.numel()), stream())
+        return
     L.call('hv_adam_step', ctypes.cast(table.ptr(), ctypes.POINTER(L.hv_adam_tensor)), table.n, ctypes.c_longlong(max_numel),
            ptr(lr_dev), ctypes.c_float(beta1), ctypes.c_float(beta2), ctypes.c_float(eps), ptr(step_dev), stream())
 

@@ -46,7 +46,7 @@ class FusedAdam(torch.optim.Optimizer):
         lr = float(self.param_groups[0]['lr'])
         if self._lr is None:
             dev = self.param_groups[0]['params'][0].device
-            self._step = torch.zeros(1, dtype=torch.float32, device=dev)
+            self._step = torch.zeros(4, dtype=torch.float32, device=dev)      # [0] step count; [1..3]: the overflow guard's state (hv_adam_step_guarded)
             self._lr = torch.zeros(1, dtype=torch.float32, device=dev)
             self._lr_host = None
         if lr != self._lr_host:
@@ -54,12 +54,18 @@ class FusedAdam(torch.optim.Optimizer):
             self._lr_host = lr
 
     @torch.no_grad()
-    def step(self, closure=None, sync_lr=True):
+    def step(self, closure=None, sync_lr=True, guard_flat=None):
+        """guard_flat: the flat gradient buffer behind the parameters' .grad views (fp16 storage mode): the update is skipped on the device when it
+        holds an inf / nan (scaled gradients that overflowed an fp16 gradient buffer); skipped_steps() counts those."""
         self._ensure()
         if sync_lr:
             self.sync_lr()
         g = self.param_groups[0]
-        ops.adam_step(self._table, self._max, self._lr, g['betas'][0], g['betas'][1], g['eps'], self._step)
+        ops.adam_step(self._table, self._max, self._lr, g['betas'][0], g['betas'][1], g['eps'], self._step, guard_flat=guard_flat)
+
+    def skipped_steps(self):
+        """Steps the overflow guard skipped so far (a host read: call it between steps, not inside them)."""
+        return 0 if self._step is None else int(self._step[2].item())
 
     def zero_grad(self, set_to_none=False):
         """Gradients are (re)assigned by the explicit backward; nothing to clear.  The first parameter is flagged so that the

@@ -246,11 +246,6 @@ int hv_ca_fuse(const float* S, float* out, int B, int h, int w, int adjoint, voi
 int hv_ca_softmax(const float* S, const float* mm, float* A, int B, int L, float scale, int* argmax, void* stream);
 int hv_ca_softmax_batched(const float* S, const float* mm, long long mm_bstride, float* A, int B, int L, float scale, int* argmax,
                           void* stream);   /* mm_bstride = L: per-sample masks from hv_ca_mask_batched; 0: shared */
-/* hv_ca_fuse (forward) + hv_ca_softmax[_batched] in one pass for the 32 x 32 attention map: the fused scores never reach memory.  S = the raw
- * scores [B][L][L]; writes A (fp32) and, when A_f16 != NULL, its fp16 copy (operand of the paste GEMM).  HV_ERR_UNSUPPORTED for other map sizes
- * (callers then run the two kernels). */
-int hv_ca_fuse_softmax(const float* S, const float* mm, long long mm_bstride, float* A, void* A_f16, int B, int h, int w, float scale,
-                       int* argmax, void* stream);
 /* offset_flow of the reference's 7-tuple (:368,:389-410 + inpaint_tools.flow_to_image/compute_color :73-100,181-211): the arg-max offsets
  * coloured with the Middlebury wheel (double precision, running maximum radius over samples 0..b like the reference's batch loop), as
  * uint8/255 and nearest-upsampled x`up` (rate*4): flow[B][3][h*up][w*up] (NCHW like the reference's tensor). */
@@ -340,6 +335,12 @@ int hv_shrm_backward(const float* d_fake, const float* d_local, const float* mas
 typedef struct { float* p; const float* g; float* m; float* v; long long n; } hv_adam_tensor;
 int hv_adam_step(const hv_adam_tensor* d_tensors, int n_tensors, long long max_numel, const float* d_lr, float beta1,
                  float beta2, float eps, float* d_step, void* stream);
+/* The same behind an overflow guard (fp16 storage mode: scaled gradients may have overflowed to inf / nan in an fp16 gradient buffer):
+ * flat_grad[n_grad] -- the network's flat gradient buffer, after any all-reduce -- is checked first; if it holds a non-finite value the whole step is
+ * skipped (weights, moments and step count unchanged) and d_state[2] counts it.  d_state: 4 floats {step count, scratch, skipped steps, scratch},
+ * zero-initialised by the caller.  Device-side only (no host read): safe inside a captured graph. */
+int hv_adam_step_guarded(const hv_adam_tensor* d_tensors, int n_tensors, long long max_numel, const float* d_lr, float beta1,
+                         float beta2, float eps, float* d_state, const float* flat_grad, long long n_grad, void* stream);
 
 /* misc */
 int hv_threshold(const float* x, float* y, long long n, float thr, float value, void* stream); /* y = x > thr ? value : 0 (torch.where(seg > 0.5, ...)) */

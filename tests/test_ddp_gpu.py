@@ -171,3 +171,33 @@ def test_bench_two_ranks_rehearsal_over_gloo():
     assert rec['n_gpus'] == 2 and rec['config']['global_batch'] == 32 and rec['config']['parallelism'] == 'dp2'
     assert rec['config']['launch'].startswith('hipGraph replay (12 graphs/step)')
     assert rec['roofline'] and rec['roofline']['launches'] > 0 and 'fine_generator_forward' in rec
+
+
+def _bench(extra_env, args, launcher=None):
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'HV_DDP_FORCE', 'HV_DDP_BACKEND')}
+    env.update(extra_env)
+    cmd = (launcher or [sys.executable]) + [os.path.join(ROOT, 'bench.py')] + args + ['--no-cpu-baseline', '--no-inference', '--no-extra']
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1, p.stdout.decode()[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_data_parallel_dress_rehearsal_on_one_device():
+    """The driver's multi-GPU bench without a node: (a) the real bench with the data-parallel SCHEDULE (twelve phase graphs, exchange stream, RCCL
+    all-reduce calls) in a one-rank RCCL group against the plain three-graph step on the same device -- the schedule itself must cost < 10 %;
+    (b) the real bench started as TWO ranks by torch.distributed.run on this one device (gloo transport -- RCCL refuses two ranks on one device):
+    the JSON line must report what the collective layer saw (n_gpus, global batch, backend, world size)."""
+    plain = _bench({}, ['--steps', '10', '--warmup', '3'])
+    assert plain['n_gpus'] == 1 and plain['comm']['world_size'] == 1 and '3 graphs' in plain['config']['launch'], plain['config']
+    assert len(plain['regions_ms_per_step']) == 3 and plain['ms_per_step'] == sorted(plain['regions_ms_per_step'])[1]
+    one = _bench({'HV_DDP_FORCE': '1'}, ['--steps', '10', '--warmup', '3'])
+    assert one['comm']['backend'] == 'nccl' and one['comm']['world_size'] == 1 and '12 graphs' in one['config']['launch'], (one['comm'], one['config'])
+    assert one['ms_per_step'] <= 1.10 * plain['ms_per_step'], ('data-parallel schedule vs single-rank step', one['ms_per_step'], plain['ms_per_step'])
+    two = _bench({'HV_DDP_BACKEND': 'gloo'}, ['--gpus', '2', '--steps', '4', '--warmup', '3'],
+                 launcher=[sys.executable, '-m', 'torch.distributed.run', '--standalone', '--nnodes=1', '--nproc-per-node', '2', '--local-addr', '127.0.0.1'])
+    assert two['n_gpus'] == 2 and two['config']['global_batch'] == 32 and two['config']['parallelism'] == 'dp2', two['config']
+    assert two['comm']['backend'] == 'gloo' and two['comm']['world_size'] == 2, two['comm']
+    assert two['value'] > 0 and two['scaling'] == 'weak' and '12 graphs' in two['config']['launch']

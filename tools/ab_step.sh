@@ -6,6 +6,6 @@ for i in $(seq $pairs); do
   for v in $off $on; do
     export $var=$v
     printf "%s=%s " $var $v
-    python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-inference 2>/dev/null | python -c "import sys,json; print(json.loads(sys.stdin.readlines()[-1])['ms_per_step'])" || exit 1
+    python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-inference --no-extra 2>/dev/null | python -c "import sys,json; print(json.loads(sys.stdin.readlines()[-1])['ms_per_step'])" || exit 1
   done
 done

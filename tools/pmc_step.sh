@@ -6,7 +6,7 @@ tag=${1:-r01}
 export TMPDIR=/tmp
 out=gpurun_out/traffic_step_$tag
 mkdir -p $out
-args="bench.py --serial --no-graph --steps 2 --warmup 1 --no-cpu-baseline --no-inference"
+args="bench.py --serial --no-graph --steps 2 --warmup 1 --no-cpu-baseline --no-inference --no-extra"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/f -o f --output-format csv -- python3 $args > $out/f.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/w -o w --output-format csv -- python3 $args > $out/w.log 2>&1 || exit 1
 python3 tools/pmc_step_summary.py $out $out/${tag}_traffic_step.json

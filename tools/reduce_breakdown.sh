@@ -5,7 +5,7 @@ pat=${1:-wgrad_reduce_kernel}
 export TMPDIR=/tmp
 out=gpurun_out/rb
 rm -rf $out; mkdir -p $out
-rocprofv3 --kernel-trace --output-format csv -d $out -o t -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-inference --serial > $out/log.txt 2>&1 || exit 1
+rocprofv3 --kernel-trace --output-format csv -d $out -o t -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-inference --no-extra --serial > $out/log.txt 2>&1 || exit 1
 python3 - "$pat" $out/t_kernel_trace.csv <<'PY'
 import csv, sys, collections
 pat, path = sys.argv[1], sys.argv[2]
