@@ -175,6 +175,25 @@ def g6_unet(unet, out):
          sd_after={k: v for k, v in sd1.items() if 'running' in k or 'tracked' in k}, ct_eval=cte, mk_eval=mke)
 
 
+def g6b_unet_dropout(unet, out):
+    """G6b: the use_dropout=True quirk of UnetG_CT_mask (models/UnetG_CT_mask.py:73-78,112-114): `nn.Dropout(dropout)` receives the BOOLEAN, i.e.
+    p = 1.0 -- in train mode the blocks that carry it output zeros (deterministic), in eval mode nothing changes."""
+    torch.manual_seed(304)
+    net = unet.define_G(3, 1, 4, 'unet_256', 'batch', True, 'normal', 0.02, [])
+    sd0 = np_sd(net.state_dict())
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+    net.train()
+    with torch.no_grad():
+        ct, mk = net(x)
+    sd1 = np_sd(net.state_dict())
+    net.eval()
+    with torch.no_grad():
+        cte, mke = net(x)
+    save(out, 'g6b_unet_dropout', sd=sd0, x=x, ct=ct, mk=mk, sd_after={k: v for k, v in sd1.items() if 'running' in k or 'tracked' in k},
+         ct_eval=cte, mk_eval=mke)
+
+
 def make_opt(**kw):
     o = Namespace(gpu_ids=[], isTrain=True, checkpoints_dir='/tmp/hv_ckpt', name='golden', preprocess='none',
                   input_nc=1, output_nc=1, ngf=64, ndf=64, netD='basic', netG='unet_256', n_layers_D=3, norm='batch',
@@ -243,7 +262,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--ref', default='/root/reference')
     ap.add_argument('--out', default=os.path.join(ROOT, 'tests', 'golden'))
-    ap.add_argument('--only', default='', help='comma-separated subset of g1,g2,g3,g4,g5,g6,g7')
+    ap.add_argument('--only', default='', help='comma-separated subset of g1,g2,g3,g4,g5,g6,g6b,g7')
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     sys.path.insert(0, ROOT)
@@ -257,6 +276,7 @@ def main():
     if want('g3'): g3_discriminator(nets, args.out)
     if want('g4'): g4_small_ops(edge, nets, p2p, args.out)
     if want('g6'): g6_unet(unet, args.out)
+    if want('g6b'): g6b_unet_dropout(unet, args.out)
     if want('g7'): g7_inference(inp, args.out, synth)
     if want('g5'): g5_full_step(p2p, args.out, synth)
 

@@ -165,6 +165,35 @@ def test_g6_unet_ct_mask_forward_backward():
     assert _err(cte, g['ct_eval']) <= TOL and _err(mke, g['mk_eval']) <= TOL
 
 
+def test_g6b_unet_use_dropout_true_quirk():
+    """UnetG_CT_mask with use_dropout=True: the reference hands the boolean to nn.Dropout (p = 1.0), so in train mode the inner blocks output zeros and
+    in eval mode the network is the plain one (fixture G6b = the reference's outputs).  The backward of that train mode is all zeros through those
+    blocks; the HIP path refuses it loudly rather than computing something else."""
+    from hvgan.models.UnetG_CT_mask import define_G
+    g = load_golden('g6b_unet_dropout')
+    dev = torch.device('cuda:0')
+    net = define_G(3, 1, 4, 'unet_256', 'batch', True, 'normal', 0.02, [])
+    net.load_state_dict(g['sd'])
+    net.cuda()
+    net.precision = 'fp32'
+    net.train()
+    x = g['x'].to(dev)
+    with torch.no_grad():
+        ct, mk = net(x)
+    assert _err(ct, g['ct']) <= TOL and _err(mk, g['mk']) <= TOL
+    sd = net.state_dict()
+    for k, v in g['sd_after'].items():
+        assert _err(sd[k].double(), v) <= 1e-4, k
+    net.eval()
+    with torch.no_grad():
+        cte, mke = net(x)
+    assert _err(cte, g['ct_eval']) <= TOL and _err(mke, g['mk_eval']) <= TOL
+    net.train()
+    ct, mk = net(x)
+    with pytest.raises(NotImplementedError):
+        (ct.sum() + mk.sum()).backward()
+
+
 @pytest.mark.parametrize('norm', ['batch', 'instance'])
 def test_discriminator_module_api_two_forwards_then_one_backward(norm):
     """The reference's own discriminator update through the nn.Module API (pix2pix_model.py:267-283): pred_fake = D(fake.detach());

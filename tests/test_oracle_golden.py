@@ -118,6 +118,23 @@ def test_g6_unet():
         close(mke, g['mk_eval'])
 
 
+def test_g6b_unet_dropout_quirk():
+    """use_dropout=True hands nn.Dropout the boolean (p = 1.0): zeros in train mode, identity in eval mode (reference models/UnetG_CT_mask.py:73-78)."""
+    g = load_golden('g6b_unet_dropout')
+    sd = {k: v.clone() for k, v in g['sd'].items()}
+    with torch.no_grad():
+        (ct, mk), upd = R.unet_forward(sd, g['x'], 5, True, use_dropout=True)
+        close(ct, g['ct'])
+        close(mk, g['mk'])
+        for k, v in upd.items():
+            sd[k] = v
+        for k, v in g['sd_after'].items():
+            close(sd[k].double(), v.double(), 1e-5)
+        (cte, mke), _ = R.unet_forward(sd, g['x'], 5, False, use_dropout=True)
+        close(cte, g['ct_eval'])
+        close(mke, g['mk_eval'])
+
+
 def test_g8_rhlv_oracle_matches_reference_outputs():
     """RHLV restatement (oracle.restate.rhlv / rhlv_volume) against the reference's calculate_rhlv / calculate_heights outputs (G8)."""
     import numpy as np

@@ -410,3 +410,94 @@ def test_learning_rate_schedule_reaches_the_captured_graphs(policy, monkeypatch)
     for n in ('G', 'D_1', 'D_3'):
         d = (fin_m[n] - fin_o[n]).abs()
         assert (d > 5e-5).float().mean().item() <= 0.02, (policy, n, d.max().item())
+
+
+def test_fp16_overflow_guard_skips_the_step_and_counts_it(monkeypatch):
+    """fp16 storage mode: the gradient seeds carry a power-of-two scale; if a scaled activation gradient overflows an fp16 buffer, inf / nan reach
+    the network's parameter gradients.  The Adam step then must not happen at all (weights, moments, step count), on the device, and be counted.
+    Forced here with an absurd scale (2^40) for one step; with the normal scale the next step updates every network and the count stays."""
+    monkeypatch.setenv('HV_PRECISION', 'fp16')
+    import hvgan
+    from hvgan import synth
+    from hvgan.models.pix2pix_model import Pix2PixModel
+    torch.manual_seed(31)
+    model = Pix2PixModel(make_opt())
+    nets = ('G', 'D_1', 'D_2', 'D_3')
+    snap = lambda: {n: torch.cat([p.detach().flatten().clone() for p in getattr(model, 'net' + n).parameters()]) for n in nets}
+    w0 = snap()
+    assert model.grad_scale == 8192.0
+    model.grad_scale = float(2 ** 40)
+    model.set_input(synth.make_batch(2, 256, seed=5))
+    model.optimize_parameters()
+    torch.cuda.synchronize()
+    assert model.overflow_steps() == {n: 1 for n in nets}, model.overflow_steps()
+    w1 = snap()
+    for n in nets:
+        assert torch.equal(w0[n], w1[n]), n
+        o = getattr(model, 'optimizer_' + n)
+        assert float(o._step[0].item()) == 0.0 and float(o._m.abs().max().item()) == 0.0 and float(o._v.abs().max().item()) == 0.0, n
+    model.grad_scale = 8192.0
+    model.set_input(synth.make_batch(2, 256, seed=6))
+    model.optimize_parameters()
+    torch.cuda.synchronize()
+    w2 = snap()
+    assert model.overflow_steps() == {n: 1 for n in nets}
+    for n in nets:
+        assert torch.isfinite(w2[n]).all() and (w2[n] - w1[n]).abs().max().item() > 1e-5, n
+        assert float(getattr(model, 'optimizer_' + n)._step[0].item()) == 1.0
+
+
+def test_guarded_adam_equals_torch_adam_and_ignores_a_poisoned_gradient():
+    import hvgan
+    from hvgan.optim import FusedAdam
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(3)
+    flat_p = torch.randn(5000, generator=g).to(dev)
+    flat_g = torch.zeros(5000, device=dev)
+    ps = [torch.nn.Parameter(flat_p[:3000].view(30, 100)), torch.nn.Parameter(flat_p[3000:])]
+    ps[0].grad, ps[1].grad = flat_g[:3000].view(30, 100), flat_g[3000:]
+    ref = [torch.nn.Parameter(p.detach().cpu().clone()) for p in ps]
+    opt, ropt = FusedAdam(ps, lr=2e-4, betas=(0.5, 0.999)), torch.optim.Adam(ref, lr=2e-4, betas=(0.5, 0.999))
+    for it in range(4):
+        gr = torch.randn(5000, generator=g)
+        if it == 1:
+            gr[4321] = float('inf') if True else 0.0
+        if it == 2:
+            gr[17] = float('nan')
+        flat_g.copy_(gr)
+        opt.step(guard_flat=flat_g)
+        if it in (0, 3):
+            ref[0].grad, ref[1].grad = gr[:3000].view(30, 100).clone(), gr[3000:].clone()
+            ropt.step()
+        torch.cuda.synchronize()
+        for p, r in zip(ps, ref):
+            assert (p.detach().cpu() - r.detach()).abs().max().item() <= 1e-6, it
+    assert opt.skipped_steps() == 2 and float(opt._step[0].item()) == 2.0
+
+
+def test_step_at_512_fp16_mode_matches_live_oracle(monkeypatch):
+    """BASELINE config #5's slice size in the benchmarked fp16 mode (the fp32-mode 512^2 test is above): one full train step, B = 2, against the
+    CPU oracle on the same weights -- continuous activations within |d| <= 1e-3, the 12 losses within the fp16-mode tolerances."""
+    monkeypatch.setenv('HV_PRECISION', 'fp16')
+    import hvgan
+    from hvgan import synth
+    from hvgan.models.pix2pix_model import Pix2PixModel
+    from oracle import restate as R
+    torch.manual_seed(512)
+    model = Pix2PixModel(make_opt())
+    sd_g = {k: v.detach().cpu().clone() for k, v in model.netG.state_dict().items()}
+    sd_d = [{k: v.detach().cpu().clone() for k, v in getattr(model, 'netD_%d' % k).state_dict().items()} for k in (1, 2, 3)]
+    raw = synth.make_batch(2, 512, seed=99)
+    model.set_input(raw)
+    model.optimize_parameters()
+    torch.cuda.synchronize()
+    st = R.StepState(sd_g, sd_d, lr=2e-4, beta1=0.5, norm='batch', gan_mode='vanilla', lambda_l1=200.0)
+    losses, outs = R.pix2pix_step(st, synth.to_model_inputs(raw))
+    got = model.get_current_losses()
+    for k, ref in losses.items():
+        tol = 3e-2 if k in ('edge', 'D_real_2', 'D_fake_2', 'G_GAN') else 6e-3        # behind the fine_seg > 0.5 threshold: a few flipped pixels
+        assert abs(got[k] - ref) <= tol * max(1.0, abs(ref)), (k, got[k], ref)
+    for name in ('x_stage1', 'fake_B_raw', 'coarse_seg_sigmoid', 'fake_B_mask_sigmoid'):
+        ref = outs[{'coarse_seg_sigmoid': 'coarse_seg', 'fake_B_mask_sigmoid': 'fine_seg'}.get(name, name)]
+        check_activation(name, getattr(model, name), ref, tol=1e-3, ctx=('fp16', 512))
+    assert model.overflow_steps() == {n: 0 for n in ('G', 'D_1', 'D_2', 'D_3')}
