@@ -201,7 +201,13 @@ static bool wgrad_tr_plan(const hv_wgrad_desc* d, WTrPlan* pl) {
     pl->lds = (size_t)128 * wtr_stride(pl->BN, 1) + (size_t)PH * PW * wtr_stride(pl->BC, d->stride);
     const long long ntiles = (long long)d->B * hv_cdiv(d->Ho, 8) * hv_cdiv(d->Wo, 16);
     const long long pairs = (long long)hv_cdiv(d->Cout, pl->BN) * hv_cdiv(d->Cin, pl->BC);
-    static const int want = getenv("HV_WGRAD_TR_WGS") ? atoi(getenv("HV_WGRAD_TR_WGS")) : 512;   // two workgroups per CU
+    // workgroups wanted per launch (split over pixel chunks): every chunk writes a whole slab of dW, so a layer with a small dW tile count (the
+    // generators' 64-channel layers: 2 tiles, 256 slabs of 147 KB = 38 MB for 17 MB of operands) is bound by its slab traffic, not by its MFMAs
+    // (step-level A/B, round 3, same box: PatchGAN layers 512 -> 256 workgroups 9.43 -> 9.25 ms (their slabs are 8 MB each); 192: 9.23; the
+    // generators' layers 512 / 256: no difference, 128: +0.2 ms)
+    static const int want_big = getenv("HV_WGRAD_TR_WGS") ? atoi(getenv("HV_WGRAD_TR_WGS")) : 256;
+    static const int want_small = getenv("HV_WGRAD_TR_WGS_SMALL") ? atoi(getenv("HV_WGRAD_TR_WGS_SMALL")) : 512;
+    const int want = pairs <= 4 ? want_small : want_big;
     long long gx = (want + pairs - 1) / pairs;
     if (gx > ntiles) gx = ntiles;
     if (gx < 1) gx = 1;
