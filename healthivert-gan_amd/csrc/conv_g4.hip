@@ -15,6 +15,7 @@
 // Optional epilogue: per-channel sum / sum of squares of the (fp16-rounded) outputs of the workgroup's tile (hv_conv_desc.stats), the BatchNorm
 // statistics the separate reduction pass used to re-read the tensor for.
 #include <stdlib.h>
+#include <type_traits>
 
 #include "conv_halo.h"
 
@@ -38,6 +39,137 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t r, lds_ptr dst,
 #if defined(__HIP_DEVICE_COMPILE__)
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 16, voff, soff, 0, 0);
 #endif
+}
+
+// Shared epilogue of the pipelined-GEMM kernels: the workgroup's TH x 16 pixels x 128 columns (two 64-column slots) -> (alpha, +bias, activation) ->
+// fp16 tile in LDS -> 16-byte pieces with the act' multiplier / accumulate forms; optional per-channel statistics of the stored tile.
+// MODE 1 (stride-2 data gradient): slot s is the output-parity class cls_s[s] -- pixel (i, j) of the tile lands at (2 i + py, 2 j + px).
+template <int MODE, int MT>
+__device__ __forceinline__ void g4_epilogue(const G4K& p, f32x4 (&acc)[4][MT], char* smem, const int (&cls_s)[2], const int (&cob_s)[2], int n_img, int i0,
+                                            int j0) {
+    constexpr int TW = 16, TH = 4 * MT, NTHR = 512, LDO = 128 + 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    _Float16* As = reinterpret_cast<_Float16*>(smem);
+    // ---- epilogue: this thread's output pieces (act' multiplier, old gradient) requested first, then (alpha, +bias, activation) -> fp16 tile in
+    // LDS -> 16-byte pieces
+    constexpr int OITEMS = TH * TW * 16 / NTHR;
+    const __amdgpu_buffer_rsrc_t msrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.mul_src), 0, p.mul_src ? 0x7ffffff0u : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ysrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.accumulate ? 0x7ffffff0u : 0u, 0x00020000);
+    u32x4 mreg[OITEMS], yreg[OITEMS];
+    long long ooff[OITEMS];
+#pragma unroll
+    for (int k = 0; k < OITEMS; ++k) {
+        const int it = tid + k * NTHR;
+        const int q = it >> 4, pc = it & 15, s = pc >> 3;
+        const int i = i0 + (q >> 4), j = j0 + (q & 15);
+        const int ch = cob_s[s] + (pc & 7) * 8;
+        const bool ok = i < p.Hc && j < p.Wc && ch < p.Cout;
+        int ho = i, wo = j;
+        if (MODE == 1) { ho = 2 * i + (cls_s[s] >> 1); wo = 2 * j + (cls_s[s] & 1); }
+        const long long opix = (long long)(n_img * p.Ho + ho) * p.Wo + wo;
+        ooff[k] = ok ? opix * p.y_ld + p.y_coff + ch : -1;
+        mreg[k] = __builtin_amdgcn_raw_buffer_load_b128(msrc, ok ? (unsigned)((opix * p.mul_ld + p.mul_coff + ch) * 2) : HV_OOB, 0, 0);
+        yreg[k] = __builtin_amdgcn_raw_buffer_load_b128(ysrc, ok ? (unsigned)(ooff[k] * 2) : HV_OOB, 0, 0);
+    }
+    const __amdgpu_buffer_rsrc_t bsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.bias ? (unsigned)p.Cout * 4u : 0u, 0x00020000);
+    f32x4 bias_r[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+        bias_r[n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bsrc, (unsigned)(cob_s[wn] + n * 16 + (lane >> 4) * 4) * 4u, 0, 0));
+    _Float16* ot = As;         // the whole LDS is free behind the loop's last barrier: [TH * TW][LDO]
+    auto stage = [&](auto actf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int q = (wm * MT + m) * 16 + (lane & 15);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                f16x4v h;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h[r] = (_Float16)actf(acc[n][m][r] * p.alpha + bias_r[n][r]);
+                *reinterpret_cast<f16x4v*>(ot + q * LDO + wn * 64 + n * 16 + (lane >> 4) * 4) = h;
+            }
+        }
+    };
+    switch (p.act) {
+        case HV_ACT_ELU:
+            stage([](float v) { const float e = __builtin_amdgcn_exp2f(v * 1.44269504f) - 1.f, sm = v + 0.5f * v * v; return v > 0.f ? v : (v > -0.00390625f ? sm : e); });
+            break;
+        case HV_ACT_RELU: stage([](float v) { return v > 0.f ? v : 0.f; }); break;
+        case HV_ACT_LRELU: stage([](float v) { return v > 0.f ? v : 0.2f * v; }); break;
+        case HV_ACT_SIGMOID: stage([](float v) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-v * 1.44269504f)); }); break;
+        case HV_ACT_CLAMP: stage([](float v) { return fminf(fmaxf(v, -1.f), 1.f); }); break;
+        default: stage([](float v) { return v; }); break;
+    }
+    __syncthreads();
+    _Float16* yb = reinterpret_cast<_Float16*>(p.y);
+    u32x4 o[OITEMS];
+#pragma unroll
+    for (int k = 0; k < OITEMS; ++k) {
+        const int it = tid + k * NTHR;
+        o[k] = *reinterpret_cast<const u32x4*>(ot + (it >> 4) * LDO + (it & 15) * 8);
+    }
+    if (MODE != 1 && p.stats) {
+        // BatchNorm statistics of this tile: thread (q-lane, piece) sums its OITEMS pixels' 8 channels (piece = it & 15 is the same for all of a
+        // thread's items), then the 32 threads that share a piece are folded through LDS; invalid pixels / channels contribute zeros
+        float s1[8], s2[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+#pragma unroll
+        for (int k = 0; k < OITEMS; ++k) {
+            if (ooff[k] < 0) continue;
+            const f16x8 v8 = __builtin_bit_cast(f16x8, o[k]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float v = (float)v8[e]; s1[e] += v; s2[e] += v * v; }
+        }
+        __syncthreads();                       // the staging tile has been read into registers by every thread
+        float* red = reinterpret_cast<float*>(smem);       // [32 rows][16 pieces][16]
+        float* mine = red + ((tid >> 4) * 16 + (tid & 15)) * 16;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { mine[e] = s1[e]; mine[8 + e] = s2[e]; }
+        __syncthreads();
+        if (tid < 256) {      // 128 channels x {sum, sum of squares}
+            const int pc = tid >> 4, e = tid & 15;
+            float s = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < 32; ++r) s += red[(r * 16 + pc) * 16 + e];
+            const int ch = (int)blockIdx.y * 128 + pc * 8 + (e & 7);
+            if (ch < p.Cout) p.stats[((long long)blockIdx.x * p.Cout + ch) * 2 + (e >> 3)] = s;
+        }
+    }
+    if (p.mul_src) {
+        auto mulf = [&](auto gradf) __attribute__((always_inline)) {
+#pragma unroll
+            for (int k = 0; k < OITEMS; ++k) {
+                const f16x8 m8 = __builtin_bit_cast(f16x8, mreg[k]);
+                f16x8 v8 = __builtin_bit_cast(f16x8, o[k]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v8[e] = (_Float16)((float)v8[e] * gradf((float)m8[e]));
+                o[k] = __builtin_bit_cast(u32x4, v8);
+            }
+        };
+        switch (p.mul_act) {
+            case HV_ACT_ELU: mulf([](float y) { return y > 0.f ? 1.f : y + 1.f; }); break;
+            case HV_ACT_RELU: mulf([](float y) { return y > 0.f ? 1.f : 0.f; }); break;
+            case HV_ACT_LRELU: mulf([](float y) { return y > 0.f ? 1.f : 0.2f; }); break;
+            case HV_ACT_SIGMOID: mulf([](float y) { return y * (1.f - y); }); break;
+            case HV_ACT_CLAMP: mulf([](float y) { return (y > -1.f && y < 1.f) ? 1.f : 0.f; }); break;
+            default: break;
+        }
+    }
+    if (p.accumulate) {
+#pragma unroll
+        for (int k = 0; k < OITEMS; ++k) {
+            const f16x8 y8 = __builtin_bit_cast(f16x8, yreg[k]);
+            f16x8 v8 = __builtin_bit_cast(f16x8, o[k]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v8[e] = (_Float16)((float)v8[e] + (float)y8[e]);
+            o[k] = __builtin_bit_cast(u32x4, v8);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < OITEMS; ++k)
+        if (ooff[k] >= 0) *reinterpret_cast<u32x4*>(yb + ooff[k]) = o[k];
 }
 
 template <int MODE, int MT>
@@ -227,126 +359,7 @@ __global__ __launch_bounds__(512, 2) void conv_g4_kernel(const G4K p) {
     __syncthreads();
     G4_STAMP(3);
 
-    // ---- epilogue: this thread's output pieces (act' multiplier, old gradient) requested first, then (alpha, +bias, activation) -> fp16 tile in
-    // LDS -> 16-byte pieces
-    constexpr int OITEMS = TH * TW * 16 / NTHR;
-    const __amdgpu_buffer_rsrc_t msrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.mul_src), 0, p.mul_src ? 0x7ffffff0u : 0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ysrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.accumulate ? 0x7ffffff0u : 0u, 0x00020000);
-    u32x4 mreg[OITEMS], yreg[OITEMS];
-    long long ooff[OITEMS];
-#pragma unroll
-    for (int k = 0; k < OITEMS; ++k) {
-        const int it = tid + k * NTHR;
-        const int q = it >> 4, pc = it & 15, s = pc >> 3;
-        const int i = i0 + (q >> 4), j = j0 + (q & 15);
-        const int ch = cob_s[s] + (pc & 7) * 8;
-        const bool ok = i < p.Hc && j < p.Wc && ch < p.Cout;
-        int ho = i, wo = j;
-        if (MODE == 1) { ho = 2 * i + (cls_s[s] >> 1); wo = 2 * j + (cls_s[s] & 1); }
-        const long long opix = (long long)(n_img * p.Ho + ho) * p.Wo + wo;
-        ooff[k] = ok ? opix * p.y_ld + p.y_coff + ch : -1;
-        mreg[k] = __builtin_amdgcn_raw_buffer_load_b128(msrc, ok ? (unsigned)((opix * p.mul_ld + p.mul_coff + ch) * 2) : HV_OOB, 0, 0);
-        yreg[k] = __builtin_amdgcn_raw_buffer_load_b128(ysrc, ok ? (unsigned)(ooff[k] * 2) : HV_OOB, 0, 0);
-    }
-    const __amdgpu_buffer_rsrc_t bsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.bias ? (unsigned)p.Cout * 4u : 0u, 0x00020000);
-    f32x4 bias_r[4];
-#pragma unroll
-    for (int n = 0; n < 4; ++n)
-        bias_r[n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bsrc, (unsigned)(cob_s[wn] + n * 16 + (lane >> 4) * 4) * 4u, 0, 0));
-    _Float16* ot = As;         // the whole LDS is free behind the loop's last barrier: [TH * TW][LDO]
-    auto stage = [&](auto actf) __attribute__((always_inline)) {
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const int q = (wm * MT + m) * 16 + (lane & 15);
-#pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                f16x4v h;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) h[r] = (_Float16)actf(acc[n][m][r] * p.alpha + bias_r[n][r]);
-                *reinterpret_cast<f16x4v*>(ot + q * LDO + wn * 64 + n * 16 + (lane >> 4) * 4) = h;
-            }
-        }
-    };
-    switch (p.act) {
-        case HV_ACT_ELU:
-            stage([](float v) { const float e = __builtin_amdgcn_exp2f(v * 1.44269504f) - 1.f, sm = v + 0.5f * v * v; return v > 0.f ? v : (v > -0.00390625f ? sm : e); });
-            break;
-        case HV_ACT_RELU: stage([](float v) { return v > 0.f ? v : 0.f; }); break;
-        case HV_ACT_LRELU: stage([](float v) { return v > 0.f ? v : 0.2f * v; }); break;
-        case HV_ACT_SIGMOID: stage([](float v) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-v * 1.44269504f)); }); break;
-        case HV_ACT_CLAMP: stage([](float v) { return fminf(fmaxf(v, -1.f), 1.f); }); break;
-        default: stage([](float v) { return v; }); break;
-    }
-    __syncthreads();
-    G4_STAMP(4);
-    _Float16* yb = reinterpret_cast<_Float16*>(p.y);
-    u32x4 o[OITEMS];
-#pragma unroll
-    for (int k = 0; k < OITEMS; ++k) {
-        const int it = tid + k * NTHR;
-        o[k] = *reinterpret_cast<const u32x4*>(ot + (it >> 4) * LDO + (it & 15) * 8);
-    }
-    if (MODE == 0 && p.stats) {
-        // BatchNorm statistics of this tile: thread (q-lane, piece) sums its OITEMS pixels' 8 channels (piece = it & 15 is the same for all of a
-        // thread's items), then the 32 threads that share a piece are folded through LDS; invalid pixels / channels contribute zeros
-        float s1[8], s2[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
-#pragma unroll
-        for (int k = 0; k < OITEMS; ++k) {
-            if (ooff[k] < 0) continue;
-            const f16x8 v8 = __builtin_bit_cast(f16x8, o[k]);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { const float v = (float)v8[e]; s1[e] += v; s2[e] += v * v; }
-        }
-        __syncthreads();                       // the staging tile has been read into registers by every thread
-        float* red = reinterpret_cast<float*>(smem);       // [32 rows][16 pieces][16]
-        float* mine = red + ((tid >> 4) * 16 + (tid & 15)) * 16;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { mine[e] = s1[e]; mine[8 + e] = s2[e]; }
-        __syncthreads();
-        if (tid < 256) {      // 128 channels x {sum, sum of squares}
-            const int pc = tid >> 4, e = tid & 15;
-            float s = 0.f;
-#pragma unroll 8
-            for (int r = 0; r < 32; ++r) s += red[(r * 16 + pc) * 16 + e];
-            const int ch = (int)blockIdx.y * 128 + pc * 8 + (e & 7);
-            if (ch < p.Cout) p.stats[((long long)blockIdx.x * p.Cout + ch) * 2 + (e >> 3)] = s;
-        }
-    }
-    if (p.mul_src) {
-        auto mulf = [&](auto gradf) __attribute__((always_inline)) {
-#pragma unroll
-            for (int k = 0; k < OITEMS; ++k) {
-                const f16x8 m8 = __builtin_bit_cast(f16x8, mreg[k]);
-                f16x8 v8 = __builtin_bit_cast(f16x8, o[k]);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v8[e] = (_Float16)((float)v8[e] * gradf((float)m8[e]));
-                o[k] = __builtin_bit_cast(u32x4, v8);
-            }
-        };
-        switch (p.mul_act) {
-            case HV_ACT_ELU: mulf([](float y) { return y > 0.f ? 1.f : y + 1.f; }); break;
-            case HV_ACT_RELU: mulf([](float y) { return y > 0.f ? 1.f : 0.f; }); break;
-            case HV_ACT_LRELU: mulf([](float y) { return y > 0.f ? 1.f : 0.2f; }); break;
-            case HV_ACT_SIGMOID: mulf([](float y) { return y * (1.f - y); }); break;
-            case HV_ACT_CLAMP: mulf([](float y) { return (y > -1.f && y < 1.f) ? 1.f : 0.f; }); break;
-            default: break;
-        }
-    }
-    if (p.accumulate) {
-#pragma unroll
-        for (int k = 0; k < OITEMS; ++k) {
-            const f16x8 y8 = __builtin_bit_cast(f16x8, yreg[k]);
-            f16x8 v8 = __builtin_bit_cast(f16x8, o[k]);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v8[e] = (_Float16)((float)v8[e] + (float)y8[e]);
-            o[k] = __builtin_bit_cast(u32x4, v8);
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < OITEMS; ++k)
-        if (ooff[k] >= 0) *reinterpret_cast<u32x4*>(yb + ooff[k]) = o[k];
+    g4_epilogue<MODE, MT>(p, acc, smem, cls_s, cob_s, n_img, i0, j0);
 #ifdef G4_STAMPS
     __builtin_amdgcn_s_waitcnt(0);
     G4_STAMP(5);
@@ -355,6 +368,166 @@ __global__ __launch_bounds__(512, 2) void conv_g4_kernel(const G4K p) {
         for (int i = 0; i < 6; ++i) d[i] = st[i];
     }
 #endif
+}
+
+// 4x4 STRIDE-1 convolution (DG = 0: pad 1, output (H - 1) x (W - 1)) and its data gradient (DG = 1: the same correlation with the taps mirrored,
+// output (H + 1) x (W + 1)) -- the PatchGAN 256 <-> 512 layers, 64.5 GFLOP per launch -- on the same pipelined-GEMM core: TH x 16 pixels x 128
+// columns per workgroup, K in sub-chunks of 32 channels x ONE filter row (its 4 taps): the 32 KB filter slice of a sub-chunk arrives by LDS-DMA into
+// a ring of three buffers, the (TH + 3) x 20-pixel patch of a 32-channel chunk arrives ONCE for its four filter rows (two buffers).  conv_halo2_kernel
+// fetched 1 MB of filters per 128-pixel x 64/128-channel tile straight into registers (537 MB of L2 -> CU traffic per launch, 2x the tensors'
+// HBM bytes); a 256-pixel x 128-channel tile halves that and both operands come from LDS.
+template <int DG, int MT>
+__global__ __launch_bounds__(512, 2) void conv_g4s1_kernel(const G4K p) {
+    constexpr int TW = 16, TH = 4 * MT, PH = TH + 3, PW = 20;                // patch rows of 20 pixels (19 used): a row shift moves the swizzle phase by its parity only
+    constexpr int NBP = (PH * PW + 15) / 16, BPW = (NBP + 7) / 8;
+    constexpr int ABUF = 32 * 512, BBUF = NBP * 512;                          // halfs
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    _Float16* As = reinterpret_cast<_Float16*>(smem);                         // [3][ABUF]
+    _Float16* Bs = As + 3 * ABUF;                                             // [2][BBUF] + one spare KB
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int t = (int)blockIdx.x;
+    const int n_img = t / p.tiles;
+    t -= n_img * p.tiles;
+    const int tile_y = t / p.tiles_x, tile_x = t - tile_y * p.tiles_x;
+    const int i0 = tile_y * TH, j0 = tile_x * TW;
+    const int Cin = p.Cin, KC = Cin >> 5, NS = 4 * KC;
+    int cls_s[2] = {0, 0}, cob_s[2] = {(int)blockIdx.y * 128, (int)blockIdx.y * 128 + 64};
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.w), 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
+    // patch origin: forward reads x[i - 1 + kh], the data gradient g[i + 1 - kh] = g[i - 2 + (3 - kh)]
+    constexpr int ORG = DG ? 2 : 1;
+    unsigned pvo[BPW];
+    const int xbase = (n_img * p.H * p.W * p.x_ld + p.x_coff) * 2;
+#pragma unroll
+    for (int i = 0; i < BPW; ++i) {
+        const int pix = (wave + 8 * i) * 16 + (lane >> 2);
+        const int c8 = (lane & 3) ^ (((pix >> 2) & 1) << 1);
+        const int pr = pix / PW, pc = pix - pr * PW;
+        const int r0 = i0 - ORG + pr, c0 = j0 - ORG + pc;
+        const bool ok = wave + 8 * i < NBP && pr < PH && pc < PW - 1 && (unsigned)r0 < (unsigned)p.H && (unsigned)c0 < (unsigned)p.W;
+        pvo[i] = ok ? (unsigned)(xbase + ((r0 * p.W + c0) * p.x_ld + c8 * 8) * 2) : HV_OOB;
+    }
+    auto issueA = [&](int kc, int kh, int ab) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = wave + 8 * i, rbw = f >> 2, kw = f & 3;
+            const int rb = (cob_s[rbw >> 2] >> 4) + (rbw & 3);
+            lds_dma16(wsrc, (lds_ptr)(As + ab * ABUF + f * 512), (unsigned)lane * 16u, rb * (int)p.w_rb + ((kh * 4 + kw) * Cin + kc * 32) * 32);
+        }
+    };
+    auto issueB = [&](int kc, int bb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < BPW; ++i) {
+            _Float16* dst = wave + 8 * i < NBP ? Bs + bb * BBUF + (wave + 8 * i) * 512 : Bs + 2 * BBUF;
+            lds_dma16(xsrc, (lds_ptr)dst, pvo[i], kc * 64);
+        }
+    };
+    // B-fragment addresses (halfs) of this lane without the filter row's shift, for even and odd row shifts (the slot permutation flips with the
+    // parity of the shift: 20 pixels per row = 5 groups of 4); the shift itself is an immediate (kh is unrolled)
+    int bo[2][4][MT];
+#pragma unroll
+    for (int kw = 0; kw < 4; ++kw)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int pix = (wm * MT + m) * PW + (lane & 15) + (DG ? 3 - kw : kw);
+            const int s0 = (pix >> 2) & 1;
+            bo[0][kw][m] = pix * 32 + (((lane >> 4) ^ (s0 << 1)) << 3);
+            bo[1][kw][m] = pix * 32 + (((lane >> 4) ^ ((s0 ^ 1) << 1)) << 3);
+        }
+    f32x4 acc[4][MT];
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int aoff = (wn * 16) * 512 + lane * 8;
+    f16x8 a[2][4], bf[2][MT];
+    // one sub-chunk = (32-channel chunk kc, filter row kh): 4 taps x (4 x MT) MFMAs per wave.  DMA of sub-chunk s + 2 goes out at the head of s; before
+    // the barrier at the end of s every wave waits for its own pieces of s + 1 (counted vmcnt: the newer pieces of s + 2 stay in flight).
+    auto sub = [&](int kc, auto KH, int ab) __attribute__((always_inline)) {
+        constexpr int kh = decltype(KH)::value;
+        constexpr int rs = DG ? 3 - kh : kh;                                  // row shift of this filter row inside the patch
+        const int s_ = kc * 4 + kh;
+        // what goes out now: filters of sub-chunk s + 2, and (kh == 2) the patch of chunk kc + 1
+        constexpr int kh2 = (kh + 2) & 3;
+        const int kc2 = kc + (kh >= 2 ? 1 : 0);
+        const int ab2 = ab == 0 ? 2 : ab - 1;                                 // (s + 2) % 3
+        if (s_ + 2 < NS) {
+            issueA(kc2, kh2, ab2);
+            if (kh == 2) issueB(kc + 1, (kc + 1) & 1);
+        }
+        const _Float16* Ab = As + ab * ABUF + aoff;
+        const _Float16* Bb = Bs + (kc & 1) * BBUF + rs * PW * 32;
+        auto frags = [&](int kw, int buf) __attribute__((always_inline)) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n) a[buf][n] = *reinterpret_cast<const f16x8*>(Ab + (n * 4 + kw) * 512);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) bf[buf][m] = *reinterpret_cast<const f16x8*>(Bb + bo[rs & 1][kw][m]);
+        };
+        frags(0, 0);
+#pragma unroll
+        for (int kw = 0; kw < 4; ++kw) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (kw + 1 < 4) frags(kw + 1, (kw + 1) & 1);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[kw & 1][n], bf[kw & 1][m], acc[n][m], 0, 0, 0);
+            if (kw + 1 < 4) {
+#pragma unroll
+                for (int i = 0; i < 4 + MT; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, (4 * MT) / (4 + MT), 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // newest DMA instructions of this wave that may stay in flight: those of sub-chunk s + 2 (issued above)
+        if (s_ + 2 < NS) {
+            if (kh == 2) __builtin_amdgcn_s_waitcnt(0x0070 | ((4 + BPW) & 15));
+            else __builtin_amdgcn_s_waitcnt(0x0070 | 4);
+        } else {
+            __builtin_amdgcn_s_waitcnt(0x0070);
+        }
+        __builtin_amdgcn_s_barrier();
+    };
+    // prologue: sub-chunks 0 and 1 (+ the patch of chunk 0) in flight; wait for sub-chunk 0's
+    issueB(0, 0);
+    issueA(0, 0, 0);
+    issueA(0, 1, 1);
+    __builtin_amdgcn_s_waitcnt(0x0F70 | 4);
+    __builtin_amdgcn_s_barrier();
+    int ab = 0;
+    for (int kc = 0; kc < KC; ++kc) {
+        sub(kc, std::integral_constant<int, 0>(), ab); ab = ab == 2 ? 0 : ab + 1;
+        sub(kc, std::integral_constant<int, 1>(), ab); ab = ab == 2 ? 0 : ab + 1;
+        sub(kc, std::integral_constant<int, 2>(), ab); ab = ab == 2 ? 0 : ab + 1;
+        sub(kc, std::integral_constant<int, 3>(), ab); ab = ab == 2 ? 0 : ab + 1;
+    }
+    __syncthreads();
+    g4_epilogue<0, MT>(p, acc, smem, cls_s, cob_s, n_img, i0, j0);
+}
+
+template <int DG, int MT>
+static int launch_g4s1(G4K& k, int ny, hipStream_t s) {
+    constexpr int TH = 4 * MT, PH = TH + 3, NBP = (PH * 20 + 15) / 16;
+    constexpr size_t lds_loop = (size_t)(3 * 32 * 512 + (2 * NBP + 1) * 512) * 2, lds_out = (size_t)TH * 16 * 136 * 2, lds_red = 32 * 16 * 16 * 4;
+    constexpr size_t lds = lds_loop > lds_out ? (lds_loop > lds_red ? lds_loop : lds_red) : (lds_out > lds_red ? lds_out : lds_red);
+    static_assert(lds <= 160 * 1024, "LDS");
+    k.tiles_x = hv_cdiv(k.Wc, 16);
+    k.tiles = k.tiles_x * hv_cdiv(k.Hc, TH);
+    auto kern = conv_g4s1_kernel<DG, MT>;
+    static bool raised = false;
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return -1000 - (int)e;
+        raised = true;
+    }
+    hv_path_note = 8;
+    HV_KNAME("conv_g4s1_kernel<%d, %d>", DG, MT);
+    hipLaunchKernelGGL(kern, dim3(k.tiles * k.B, ny), dim3(512), lds, s, k);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
 }
 
 template <int MODE, int MT>
@@ -390,14 +563,19 @@ static int g4_tile_rows(int B, int Hc, int Wc, int ny) {
 int hv_conv2d_g4(const hv_conv_desc* d, hipStream_t s) {
     static const int on = getenv("HV_CONV_G4") ? atoi(getenv("HV_CONV_G4")) : 3;      // bit 0: forward, bit 1: data gradient
     if (!(on & (d->transposed ? 2 : 1))) return HV_ERR_UNSUPPORTED;
-    if (d->KH != 4 || d->KW != 4 || d->stride != 2 || d->pad != 1 || d->dil != 1 || d->in_shift || d->w_bstride || d->ch_scale) return HV_ERR_UNSUPPORTED;
+    if (d->KH != 4 || d->KW != 4 || (d->stride != 2 && d->stride != 1) || d->pad != 1 || d->dil != 1 || d->in_shift || d->w_bstride || d->ch_scale) return HV_ERR_UNSUPPORTED;
     if (d->precision != HV_F16 || !d->w_f16_tiled || !d->x_f16 || !d->y_f16 || d->accumulate > 1) return HV_ERR_UNSUPPORTED;
+    if (d->stride == 1) {
+        static const int s1 = getenv("HV_CONV_G4S1") ? atoi(getenv("HV_CONV_G4S1")) : 3;      // bit 0: forward, bit 1: data gradient
+        if (!(s1 & (d->transposed ? 2 : 1)) || (d->Cout & 127) || (d->Cin & 31)) return HV_ERR_UNSUPPORTED;
+    }
     if ((d->Cin & 31) || (d->Cout & 63) || (!d->transposed && (d->Cout & 127))) return HV_ERR_UNSUPPORTED;
     if ((d->x_ld & 7) || (d->x_coff & 7) || ((uintptr_t)d->x & 15) || (d->y_ld & 7) || (d->y_coff & 7) || ((uintptr_t)d->y & 15) || ((uintptr_t)d->w_f16_tiled & 15))
         return HV_ERR_UNSUPPORTED;
     if (d->mul_src && (!d->mul_f16 || (d->mul_ld & 7) || (d->mul_coff & 7) || ((uintptr_t)d->mul_src & 15))) return HV_ERR_UNSUPPORTED;
-    if (!d->transposed && (d->Ho != d->H / 2 || d->Wo != d->W / 2 || (d->H & 1) || (d->W & 1))) return HV_ERR_UNSUPPORTED;
-    if (d->transposed && (d->Ho != 2 * d->H || d->Wo != 2 * d->W)) return HV_ERR_UNSUPPORTED;
+    if (d->stride == 2 && !d->transposed && (d->Ho != d->H / 2 || d->Wo != d->W / 2 || (d->H & 1) || (d->W & 1))) return HV_ERR_UNSUPPORTED;
+    if (d->stride == 2 && d->transposed && (d->Ho != 2 * d->H || d->Wo != 2 * d->W)) return HV_ERR_UNSUPPORTED;
+    if (d->stride == 1 && (d->Ho != d->H + (d->transposed ? 1 : -1) || d->Wo != d->W + (d->transposed ? 1 : -1) || d->Ho < 1 || d->Wo < 1)) return HV_ERR_UNSUPPORTED;
     if ((long long)d->B * d->H * d->W * d->x_ld >= (1ll << 30) || (long long)d->B * d->Ho * d->Wo * d->y_ld >= (1ll << 30)) return HV_ERR_UNSUPPORTED;
     G4K k;
     k.dbg = getenv("HV_G4_DBG") ? atoi(getenv("HV_G4_DBG")) : 0;
@@ -409,6 +587,13 @@ int hv_conv2d_g4(const hv_conv_desc* d, hipStream_t s) {
     k.x_bytes = (unsigned)((size_t)d->B * d->H * d->W * d->x_ld * 2);
     k.w_rb = (unsigned)(16 * 16 * d->Cin * 2);
     k.w_bytes = (unsigned)((size_t)hv_cdiv(d->Cout, 16) * k.w_rb);
+    if (d->stride == 1) {
+        k.Hc = d->Ho; k.Wc = d->Wo;
+        const int ny = d->Cout / 128;
+        k.stats = d->transposed ? nullptr : d->stats;
+        if (g4_tile_rows(d->B, k.Hc, k.Wc, ny) == 16) return d->transposed ? launch_g4s1<1, 4>(k, ny, s) : launch_g4s1<0, 4>(k, ny, s);
+        return d->transposed ? launch_g4s1<1, 2>(k, ny, s) : launch_g4s1<0, 2>(k, ny, s);
+    }
     if (!d->transposed) {
         k.Hc = d->Ho; k.Wc = d->Wo;
         const int ny = d->Cout / 128;
@@ -423,10 +608,11 @@ int hv_conv2d_g4(const hv_conv_desc* d, hipStream_t s) {
 // kernel has no statistics epilogue (the caller runs its reduction pass)
 size_t hv_conv2d_g4_stats_floats(const hv_conv_desc* d, int* nparts) {
     hv_conv_desc t = *d;
-    if (t.transposed || t.KH != 4 || t.KW != 4 || t.stride != 2 || t.pad != 1 || t.dil != 1 || t.in_shift || t.w_bstride || t.ch_scale) return 0;
+    if (t.transposed || t.KH != 4 || t.KW != 4 || (t.stride != 2 && t.stride != 1) || t.pad != 1 || t.dil != 1 || t.in_shift || t.w_bstride || t.ch_scale) return 0;
     if (t.precision != HV_F16 || !t.w_f16_tiled || !t.x_f16 || !t.y_f16 || t.accumulate || (t.Cin & 31) || (t.Cout & 127)) return 0;
     static const int on = getenv("HV_CONV_G4") ? atoi(getenv("HV_CONV_G4")) : 3;
-    if (!(on & 1) || (t.H & 1) || (t.W & 1)) return 0;
+    static const int s1 = getenv("HV_CONV_G4S1") ? atoi(getenv("HV_CONV_G4S1")) : 3;
+    if (!(on & 1) || (t.stride == 2 && ((t.H & 1) || (t.W & 1))) || (t.stride == 1 && !(s1 & 1))) return 0;
     const int th = g4_tile_rows(t.B, t.Ho, t.Wo, t.Cout / 128);
     const int parts = t.B * hv_cdiv(t.Ho, th) * hv_cdiv(t.Wo, 16);
     if (nparts) *nparts = parts;

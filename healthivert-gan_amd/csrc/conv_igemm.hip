@@ -409,7 +409,7 @@ static int conv2d_dispatch(const hv_conv_desc* d, void* stream) {
         const int rc = hv_conv2d_thin_dgrad(d, (hipStream_t)stream);
         if (rc != HV_ERR_UNSUPPORTED) return rc;
     }
-    if (d->precision == HV_F16 && d->w_f16 && d->stride == 2 && d->KH == 4) {   // 4x4 stride-2 layers and their data gradients as a pipelined implicit GEMM
+    if (d->precision == HV_F16 && d->w_f16 && d->KH == 4 && d->w_f16_tiled) {   // 4x4 layers (stride 2 and stride 1) and their data gradients as a pipelined implicit GEMM
         const int rc = hv_conv2d_g4(d, (hipStream_t)stream);
         if (rc != HV_ERR_UNSUPPORTED) return rc;
     }
