@@ -73,6 +73,9 @@ __global__ __launch_bounds__(256) void thin_dgrad_kernel(const ThinK p) {
     }
 }
 
+// (Measured and not kept, round 3: the same lane-per-pixel form for the PatchGAN logits layer's data gradient (4x4, 1 -> 512 channels; fp16 filters in
+// LDS as [tap][ci][Cout], a lane = 8 channels of 4 pixels, persistent workgroups): step 9.04 -> 9.15 ms against the gather kernel's 26.7 us launches --
+// 64 LDS filter reads per lane and pixel group cost more than the gather kernel's MFMA tiles save.)
 // hv_conv2d: transposed, 3x3, stride 1, dilation 1, Cin <= 4 (channel stride 4), Cout in {8, 12, 16}, fp16 views, no bias / activation of its own
 int hv_conv2d_thin_dgrad(const hv_conv_desc* d, hipStream_t s) {
     static const int on = getenv("HV_THIN_DGRAD") ? atoi(getenv("HV_THIN_DGRAD")) : 1;
