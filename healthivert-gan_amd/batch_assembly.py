@@ -42,7 +42,15 @@ class VertebraVolume:
     ct_data, label_data, cam_data: [H, W, Z] arrays as `nib.load(...).get_fdata()` returns them (cam unscaled; the reference multiplies
     it by 255 at :167).  normal_vert_list: ids (str or int) of the patient's normal vertebrae (:178, :190-196)."""
 
-    def __init__(self, ct_data, label_data, cam_data, vert_id, normal_vert_list, path='', maxheight=40):
+    def __init__(self, ct_data, label_data, cam_data, vert_id, normal_vert_list, path='', maxheight=40, view='sagittal'):
+        # view: which in-plane axis the slices run along.  'sagittal' = the reference loader's `[:, :, z]` (data/aligned_dataset.py:149-200);
+        # 'coronal' = the axis-swapped slicing `[:, z, :]` of the reference's coronal scripts (evaluation/RHLV_quantification_coronal.py:51-54,
+        # generation_eval_coronal.py) -- BASELINE config #5 feeds the same networks slices of both views
+        if view not in ('sagittal', 'coronal'):
+            raise ValueError("view must be 'sagittal' or 'coronal'")
+        self.view = view
+        if view == 'coronal':
+            ct_data, label_data, cam_data = (np.swapaxes(np.asarray(v), 1, 2) for v in (ct_data, label_data, cam_data))
         label_data = np.asarray(label_data, dtype=np.float64)
         self.path, self.vert_id, self.maxheight = path, int(vert_id), maxheight
         self.H, self.W, self.Z = label_data.shape

@@ -41,12 +41,21 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t r, lds_ptr dst,
 #endif
 }
 
+// this lane's bias values (channels cob + 16 n + 4 (lane >> 4) ..), requested in the kernel's prologue: fetched in the epilogue they were a memory round
+// trip in front of the activation pass (no bias: the descriptor's range is empty, the loads return zeros)
+__device__ __forceinline__ void g4_load_bias(const G4K& p, int cob, int lane, f32x4 (&bias_r)[4]) {
+    const __amdgpu_buffer_rsrc_t bsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.bias ? (unsigned)p.Cout * 4u : 0u, 0x00020000);
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+        bias_r[n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bsrc, (unsigned)(cob + n * 16 + (lane >> 4) * 4) * 4u, 0, 0));
+}
+
 // Shared epilogue of the pipelined-GEMM kernels: the workgroup's TH x 16 pixels x 128 columns (two 64-column slots) -> (alpha, +bias, activation) ->
 // fp16 tile in LDS -> 16-byte pieces with the act' multiplier / accumulate forms; optional per-channel statistics of the stored tile.
 // MODE 1 (stride-2 data gradient): slot s is the output-parity class cls_s[s] -- pixel (i, j) of the tile lands at (2 i + py, 2 j + px).
 template <int MODE, int MT>
 __device__ __forceinline__ void g4_epilogue(const G4K& p, f32x4 (&acc)[4][MT], char* smem, const int (&cls_s)[2], const int (&cob_s)[2], int n_img, int i0,
-                                            int j0) {
+                                            int j0, const f32x4 (&bias_r)[4]) {
     constexpr int TW = 16, TH = 4 * MT, NTHR = 512, LDO = 128 + 8;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -72,11 +81,6 @@ __device__ __forceinline__ void g4_epilogue(const G4K& p, f32x4 (&acc)[4][MT], c
         mreg[k] = __builtin_amdgcn_raw_buffer_load_b128(msrc, ok ? (unsigned)((opix * p.mul_ld + p.mul_coff + ch) * 2) : HV_OOB, 0, 0);
         yreg[k] = __builtin_amdgcn_raw_buffer_load_b128(ysrc, ok ? (unsigned)(ooff[k] * 2) : HV_OOB, 0, 0);
     }
-    const __amdgpu_buffer_rsrc_t bsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.bias ? (unsigned)p.Cout * 4u : 0u, 0x00020000);
-    f32x4 bias_r[4];
-#pragma unroll
-    for (int n = 0; n < 4; ++n)
-        bias_r[n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bsrc, (unsigned)(cob_s[wn] + n * 16 + (lane >> 4) * 4) * 4u, 0, 0));
     _Float16* ot = As;         // the whole LDS is free behind the loop's last barrier: [TH * TW][LDO]
     auto stage = [&](auto actf) __attribute__((always_inline)) {
 #pragma unroll
@@ -220,6 +224,8 @@ __global__ __launch_bounds__(512, 2) void conv_g4_kernel(const G4K p) {
     }
     const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.w), 0, p.w_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
+    f32x4 bias_r[4];
+    g4_load_bias(p, cob_s[wn], lane, bias_r);
 
     // ---- this lane's part of the wave's patch pieces (chunk-independent): piece j = wave + 8 i covers pixels 16 j .. 16 j + 15, lane -> (pixel, slot)
     int pbase[BPW], pval[BPW];
@@ -359,7 +365,7 @@ __global__ __launch_bounds__(512, 2) void conv_g4_kernel(const G4K p) {
     __syncthreads();
     G4_STAMP(3);
 
-    g4_epilogue<MODE, MT>(p, acc, smem, cls_s, cob_s, n_img, i0, j0);
+    g4_epilogue<MODE, MT>(p, acc, smem, cls_s, cob_s, n_img, i0, j0, bias_r);
 #ifdef G4_STAMPS
     __builtin_amdgcn_s_waitcnt(0);
     G4_STAMP(5);
@@ -395,6 +401,8 @@ __global__ __launch_bounds__(512, 2) void conv_g4s1_kernel(const G4K p) {
     int cls_s[2] = {0, 0}, cob_s[2] = {(int)blockIdx.y * 128, (int)blockIdx.y * 128 + 64};
     const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.w), 0, p.w_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
+    f32x4 bias_r[4];
+    g4_load_bias(p, cob_s[wn], lane, bias_r);
     // patch origin: forward reads x[i - 1 + kh], the data gradient g[i + 1 - kh] = g[i - 2 + (3 - kh)]
     constexpr int ORG = DG ? 2 : 1;
     unsigned pvo[BPW];
@@ -505,7 +513,7 @@ __global__ __launch_bounds__(512, 2) void conv_g4s1_kernel(const G4K p) {
         sub(kc, std::integral_constant<int, 3>(), ab); ab = ab == 2 ? 0 : ab + 1;
     }
     __syncthreads();
-    g4_epilogue<0, MT>(p, acc, smem, cls_s, cob_s, n_img, i0, j0);
+    g4_epilogue<0, MT>(p, acc, smem, cls_s, cob_s, n_img, i0, j0, bias_r);
 }
 
 template <int DG, int MT>

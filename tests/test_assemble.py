@@ -120,3 +120,68 @@ def test_assembled_batch_drives_a_train_step():
     losses = model.get_current_losses()
     assert all(np.isfinite(v) for v in losses.values()), losses
     assert torch.equal(model.real_B.cpu(), batch['A'].cpu()) and torch.equal(model.mask.cpu(), batch['mask'].cpu())
+
+
+def _cubic_spine(seed, n=128):
+    """Synthetic volume whose BOTH in-plane axes can serve as the slicing axis (config #5: sagittal + coronal slices of one volume)."""
+    from hvgan import synth
+    return synth.make_spine_volume(seed, H=n, W=n, Z=n, pitch=24, n_vert=4)
+
+
+def test_coronal_view_is_the_axis_swapped_volume():
+    """view='coronal' slices along the reference's axis 1 (`[:, z, :]`, evaluation/RHLV_quantification_coronal.py:51-54): the planes are those of the
+    sagittal construction on the axis-swapped arrays, and a draw follows the reference's item arithmetic on them (oracle.restate.dataset_item_u8)."""
+    from hvgan.batch_assembly import VertebraVolume
+    from oracle import restate as R
+    ct, label, cam = _cubic_spine(5, 64)
+    vc = VertebraVolume(ct, label, cam, 11, ['10', '12'], view='coronal')
+    sw = lambda v: np.swapaxes(v, 1, 2)
+    vs = VertebraVolume(sw(ct), sw(label), sw(cam), 11, ['10', '12'])
+    for a in ('ct', 'cam', 'normal', 'vert'):
+        assert np.array_equal(getattr(vc, a), getattr(vs, a)), a
+    assert (vc.H, vc.W, vc.Z) == (64, 64, 64) and vc.view == 'coronal'
+    np.random.seed(9)
+    z, ratio, x1, x2 = vc.draw()
+    np.random.seed(9)
+    ref = R.dataset_item_u8(sw(ct).astype(np.float64), sw(label).astype(np.float64), sw(cam).astype(np.float64) * 255, 11, ['10', '12'])
+    assert (x1, x2) == (ref['x1'], ref['x2']) and np.array_equal(vc.ct[z], ref['A'])
+    with pytest.raises(ValueError):
+        VertebraVolume(ct, label, cam, 11, [], view='axial')
+
+
+@pytest.mark.gpu
+def test_sagittal_and_coronal_feed_at_512_drives_train_steps(monkeypatch):
+    """BASELINE config #5's feed: slices of BOTH views of the same volumes at 512 x 512 (h2 = 80), assembled on the device, alternately through the
+    same train step (fp16 mode, graph replay from the third step on).  The coronal batch equals the oracle's item arithmetic on the axis-swapped
+    volume float for float; the losses stay finite and no step is skipped by the overflow guard."""
+    monkeypatch.setenv('HV_PRECISION', 'fp16')
+    import bench
+    from oracle import restate as R
+    from hvgan import synth
+    from hvgan.batch_assembly import VertebraVolume, DeviceBatchAssembler
+    from hvgan.models.pix2pix_model import Pix2PixModel
+    # (a cubic 512^3 float volume would be 0.5 GB per array: a 512 x 512 x 24 sagittal stack and a 512 x 24 x 512 coronal one stand for the two views)
+    cs, ls, ms = synth.make_spine_volume(7, H=512, W=512, Z=24, pitch=96, n_vert=4)
+    cc, lc, mc = (np.swapaxes(v, 1, 2) for v in synth.make_spine_volume(8, H=512, W=512, Z=24, pitch=96, n_vert=4))       # [H, Z', W]: coronal slicing axis = 1
+    sag = [VertebraVolume(cs, ls, ms, 11, ['10', '12'], maxheight=80), VertebraVolume(cs, ls, ms, 12, ['11'], maxheight=80)]
+    cor = [VertebraVolume(cc, lc, mc, 11, ['10', '12'], maxheight=80, view='coronal'), VertebraVolume(cc, lc, mc, 12, ['11'], maxheight=80, view='coronal')]
+    a_s, a_c = DeviceBatchAssembler(sag, 'cuda:0'), DeviceBatchAssembler(cor, 'cuda:0')
+    np.random.seed(4)
+    b = a_c.batch([0])
+    np.random.seed(4)
+    sw = lambda v: np.swapaxes(v, 1, 2)
+    ref = R.dataset_item(sw(cc).astype(np.float64), sw(lc).astype(np.float64), sw(mc).astype(np.float64) * 255, 11, ['10', '12'], maxheight=80)
+    for k in KEYS:
+        assert torch.equal(b[k][0].cpu(), ref[k]), k
+    torch.manual_seed(0)
+    opt = bench.make_opt('fp16')
+    model = Pix2PixModel(opt)
+    model.setup(opt)
+    np.random.seed(2)
+    for it in range(4):
+        model.set_input((a_s if it % 2 == 0 else a_c).batch([0, 1]))
+        model.optimize_parameters()
+    torch.cuda.synchronize()
+    losses = model.get_current_losses()
+    assert all(np.isfinite(v) for v in losses.values()), losses
+    assert model.real_B.shape[-2:] == (512, 512) and sum(model.overflow_steps().values()) == 0

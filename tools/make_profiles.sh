@@ -10,7 +10,7 @@ mkdir -p $out
 export TMPDIR=/tmp
 python3 bench.py --steps 20 --warmup 3 > $out/${tag}_bench_fp16.log 2>&1 || exit 1
 grep '^{' $out/${tag}_bench_fp16.log | tail -1 > $out/${tag}_bench_fp16.json
-python3 bench.py --steps 20 --warmup 3 --precision fp32 --no-cpu-baseline > $out/${tag}_bench_fp32.log 2>&1 || exit 1
+python3 bench.py --steps 20 --warmup 3 --precision fp32 --no-cpu-baseline --no-inference > $out/${tag}_bench_fp32.log 2>&1 || exit 1
 grep '^{' $out/${tag}_bench_fp32.log | tail -1 > $out/${tag}_bench_fp32.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/p1 -o p1 -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-inference --no-extra > $out/p1.log 2>&1 || exit 1
 cp $out/p1/p1_kernel_stats.csv $out/${tag}_bench_fp16_kernel_stats.csv
