@@ -348,6 +348,18 @@ def main():
     fine = model.netG.time_fine
     model.netG.time_fine = None
     engine.SERIAL = serial0
+    # the same event pair with the step's real stream structure (the refinement generator's dilated-conv branch and attention branch on two
+    # streams, as inside the captured graphs): a few eager steps with the side streams on
+    fine2 = None
+    if not args.serial:
+        ug, model.use_graph = model.use_graph, False
+        model.netG.time_fine = []
+        for _ in range(5):
+            step()
+        barrier()
+        fine2 = model.netG.time_fine
+        model.netG.time_fine = None
+        model.use_graph = ug
     if world > 1:      # MAX over ranks, region by region
         t = torch.tensor(region_dt, device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -404,6 +416,11 @@ def main():
                                              'tflops': round(tf, 1), 'frac_of_mfma_peak': round(tf / MFMA_PEAK_TFLOPS[args.precision], 4),
                                              'timed_in': 'the same eager single-stream steps: HIP events around FineGenerator (training forward, '
                                                          'both branches + contextual attention in line), mean of %d' % len(fine)}
+        if fine2:
+            f2 = sum(s_.elapsed_time(e_) for s_, e_ in fine2) / len(fine2)
+            tf2 = GFLOP_FINE_FWD * args.batch * (args.size / 256.0) ** 2 / f2
+            out['fine_generator_forward']['two_streams'] = {'ms': round(f2, 3), 'tflops': round(tf2, 1), 'frac_of_mfma_peak': round(tf2 / MFMA_PEAK_TFLOPS[args.precision], 4),
+                                                            'timed_in': 'eager steps with the step\'s own streams (the two branches concurrent, discriminator streams busy beside them), mean of %d' % len(fine2)}
         ngraphs = len(model._dp_graphs or ()) or len(model._graphs or ())
         out['config']['launch'] = ('hipGraph replay (%d graphs/step)' % ngraphs if model.use_graph else 'eager') + \
                                   (', one stream' if args.serial else ', %d streams' % (5 if world > 1 else 4))

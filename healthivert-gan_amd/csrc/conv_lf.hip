@@ -303,6 +303,8 @@ int hv_convlf_launch(HaloK& k, int KH, int KW, hipStream_t s) {
     const int Cin = k.Cin, Cout = k.Cout;
     // HV_CONV_LF_MASK: bit per (Cin class 16 / 32 / 64) x (Cout class <= 16 / <= 32 / > 32), an A/B knob
     static const int mask = getenv("HV_CONV_LF_MASK") ? atoi(getenv("HV_CONV_LF_MASK")) : 0x1ff;
+    // (Measured and not kept, round 3: the two concat layers (32 + 1 / 64 + 1 input channels) with their buffers widened to 48 / 80 channels and
+    // <48, 32, 16> / <80, 64, 8> instantiations on 16-channel planes: step 8.76 vs 8.78 ms -- no gain over conv_halo2's ragged 16-channel chunks.)
     const int ci = Cin == 16 ? 0 : Cin == 32 ? 1 : Cin == 64 ? 2 : -1, co = Cout <= 16 ? 0 : Cout <= 32 ? 1 : 2;
     if (ci < 0 || !((mask >> (ci * 3 + co)) & 1)) return HV_ERR_UNSUPPORTED;
     switch (ci * 3 + co) {
