@@ -127,31 +127,45 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(const WTrK p) {
         flush();
         __syncthreads();
         if (tile + (int)gridDim.x < p.ntiles) prefetch(tile + gridDim.x);   // next tile's loads fly behind this tile's MFMAs
-#pragma unroll
-        for (int ks = 0; ks < TH / 2; ++ks) {
-            f16x8 a[NT];
+        // software pipeline over the (k-step, tap slot) pairs of the tile: the transposed LDS reads of the next pair are issued before the MFMAs of
+        // the current one (with the reads right in front of their MFMAs a wave alternated ~130 cycles of LDS latency with 128 cycles of MFMAs; at
+        // one workgroup per CU nothing else filled the gaps)
+        auto lda = [&](int ks, f16x8 (&a)[NT]) __attribute__((always_inline)) {
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 const f16x4 lo = tr_read(ga + ((2 * ks) * TW * SG + n * 32) / 2), hi = tr_read(ga + ((2 * ks + 1) * TW * SG + n * 32) / 2);
                 a[n] = (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             }
+        };
+        auto ldb = [&](int ks, int sl, f16x8 (&bb)[CT]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const f16x4 lo = tr_read(xa[sl] + ((2 * ks) * ST * PW * SX + c * 32) / 2), hi = tr_read(xa[sl] + ((2 * ks + 1) * ST * PW * SX + c * 32) / 2);
+                bb[c] = (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+        };
+        f16x8 aq[2][NT], bq[2][CT];
+        lda(0, aq[0]);
+        ldb(0, 0, bq[0]);
+#pragma unroll
+        for (int ks = 0; ks < TH / 2; ++ks) {
             if (do_bias) {
 #pragma unroll
-                for (int n = 0; n < NT; ++n) bacc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[n], ones, bacc[n], 0, 0, 0);
+                for (int n = 0; n < NT; ++n) bacc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aq[ks & 1][n], ones, bacc[n], 0, 0, 0);
             }
 #pragma unroll
-            for (int s = 0; s < SLOTS; ++s) {
-                if (wave + 4 * s >= TAPS) continue;     // wave-uniform (scalar) branch: MFMA ignores EXEC
-                f16x8 b[CT];
+            for (int sl = 0; sl < SLOTS; ++sl) {
+                const int idx = ks * SLOTS + sl;
+                __builtin_amdgcn_sched_barrier(0);
+                if (sl + 1 < SLOTS) ldb(ks, sl + 1, bq[(idx + 1) & 1]);
+                else if (ks + 1 < TH / 2) { lda(ks + 1, aq[(ks + 1) & 1]); ldb(ks + 1, 0, bq[(idx + 1) & 1]); }
+                __builtin_amdgcn_sched_barrier(0);
+                if (wave + 4 * sl < TAPS) {     // wave-uniform (scalar) branch: MFMA ignores EXEC
 #pragma unroll
-                for (int c = 0; c < CT; ++c) {
-                    const f16x4 lo = tr_read(xa[s] + ((2 * ks) * ST * PW * SX + c * 32) / 2), hi = tr_read(xa[s] + ((2 * ks + 1) * ST * PW * SX + c * 32) / 2);
-                    b[c] = (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    for (int n = 0; n < NT; ++n)
+#pragma unroll
+                        for (int c = 0; c < CT; ++c) acc[sl][n][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aq[ks & 1][n], bq[idx & 1][c], acc[sl][n][c], 0, 0, 0);
                 }
-#pragma unroll
-                for (int n = 0; n < NT; ++n)
-#pragma unroll
-                    for (int c = 0; c < CT; ++c) acc[s][n][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[n], b[c], acc[s][n][c], 0, 0, 0);
             }
         }
     }
