@@ -32,6 +32,7 @@ extern "C" int hv_set_kernel_timing(void* ev_start, void* ev_stop) {
 int hv_conv2d_halo(const hv_conv_desc* d, const void* w_f16, hipStream_t s);   // conv_halo.hip
 int hv_conv2d_g4(const hv_conv_desc* d, hipStream_t s);                        // conv_g4.hip
 int hv_conv2d_thin_dgrad(const hv_conv_desc* d, hipStream_t s);                // conv_thin.hip
+int hv_conv2d_logits_dgrad(const hv_conv_desc* d, hipStream_t s);
 size_t hv_conv2d_g4_stats_floats(const hv_conv_desc* d, int* nparts);
 size_t hv_wgrad_halo_workspace_bytes(const hv_wgrad_desc* d);                  // wgrad_halo.hip
 int hv_wgrad_halo(const hv_wgrad_desc* d, int* nslabs, hipStream_t s);
@@ -403,6 +404,10 @@ static int conv2d_dispatch(const hv_conv_desc* d, void* stream) {
     }
     if (d->Cout == 4 && d->Cin == 16 && d->KH == 5 && d->transposed && d->precision == HV_F16 && d->w_f16) {   // ... and their data gradient
         const int rc = hv_conv2d_stem5_dgrad(d, (hipStream_t)stream);
+        if (rc != HV_ERR_UNSUPPORTED) return rc;
+    }
+    if (d->precision == HV_F16 && d->transposed && d->Cin == 4 && d->KH == 4 && d->stride == 1) {   // the PatchGAN logits layer's data gradient (taps as the MFMA contraction)
+        const int rc = hv_conv2d_logits_dgrad(d, (hipStream_t)stream);
         if (rc != HV_ERR_UNSUPPORTED) return rc;
     }
     if (d->precision == HV_F16 && d->transposed && d->Cin <= 4 && d->KH == 3) {   // the 1-channel heads' data gradient: one lane per pixel (conv_thin.hip)

@@ -73,6 +73,138 @@ __global__ __launch_bounds__(256) void thin_dgrad_kernel(const ThinK p) {
     }
 }
 
+// Data gradient of the PatchGAN logits layer (4x4, stride 1, pad 1; the 1-channel logit gradient, stored with a channel stride of 4, back to 512
+// channels): 4 GFLOP, 15.7 MB written + 15.7 MB of act' multiplier read -- the gather kernel took 27 us, eight times per step at the head of every
+// discriminator backward.  The 16 taps are the contraction of ONE v_mfma_f32_16x16x16_f16 per (16 pixels, 16 channels, gradient channel): A = the
+// filters [channel][tap] (from an LDS copy [gradient channel][channel][tap], transposed once per workgroup), B = the lane's row of the 4x4 window
+// (lane = (pixel, filter row): four 2-byte loads); a wave turns 16 pixels into all Cout channels (32 MFMAs per gradient channel at 512), stages
+// them in LDS and writes whole channel rows as 16-byte pieces with the act' multiplier / accumulate applied there.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+template <int NP>        // a workgroup's channel slice CQ = 32 * NP (128, or all of a 32/64-channel layer); blockIdx & (nq - 1) picks the slice
+__global__ __launch_bounds__(256) void logits_dgrad_kernel(const ThinK p, const _Float16* __restrict__ wh, int nq, int nq_log) {
+    constexpr int CQ = 32 * NP, LDW = CQ * 16, LDS_ROW = CQ + 8, NTL = CQ / 16, PPR = CQ / 8;   // PPR: 16-byte pieces per pixel row of the slice
+    __shared__ __attribute__((aligned(16))) _Float16 wl[4 * LDW];        // [gradient channel][channel][tap]
+    __shared__ __attribute__((aligned(16))) _Float16 st[4 * 16 * LDS_ROW];   // [wave][16 pixels][CQ + 8]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, gq = lane >> 4;
+    const int cb = (blockIdx.x & (nq - 1)) * CQ;                         // first channel of the slice
+    {                                                                    // source [channel][tap][4]: one 16-byte item = 2 taps x 4 gradient channels
+        f16x8 v[NP];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) v[j] = *reinterpret_cast<const f16x8*>(wh + (long long)cb * 64 + (long long)(threadIdx.x + 256 * j) * 8);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int i = threadIdx.x + 256 * j, co = i >> 3, t0 = (i & 7) * 2;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) *reinterpret_cast<f16x2*>(wl + c * LDW + co * 16 + t0) = f16x2{v[j][c], v[j][4 + c]};
+        }
+    }
+    __syncthreads();
+    const int Hi = p.H - 1, Wi = p.W - 1;                                // gradient (input) size; p.H, p.W = output size
+    const int gpr = (p.W + 15) >> 4;                                     // 16-pixel groups per output row
+    const int ngroups = p.B * p.H * gpr;
+    _Float16* mine = st + wave * 16 * LDS_ROW;
+    for (int grp = (blockIdx.x >> nq_log) * 4 + wave; grp < ngroups; grp += (gridDim.x >> nq_log) * 4) {
+        const int xg = grp % gpr, t = grp / gpr, y = t % p.H, b = t / p.H;
+        const int x = xg * 16 + n;
+        // B fragments: k = 4 * kh + kw with kh = gq: g[y + 1 - kh][x + 1 - kw][c]
+        const int hi = y + 1 - gq;
+        f16x4 g4[4];
+#pragma unroll
+        for (int kw = 0; kw < 4; ++kw) {
+            const int wi = x + 1 - kw;
+            g4[kw] = f16x4{0, 0, 0, 0};
+            if ((unsigned)hi < (unsigned)Hi && (unsigned)wi < (unsigned)Wi && x < p.W)
+                g4[kw] = *reinterpret_cast<const f16x4*>(p.g + (((long long)b * Hi + hi) * Wi + wi) * p.g_ld + p.g_coff);
+        }
+        // second-stage operands, all in flight before the MFMA section: piece it = lane + 64 j -> pixel q = it / PPR, piece pc = it % PPR
+        const long long pix0 = ((long long)b * p.H + y) * p.W + xg * 16;
+        f16x8 m8[NP], y8[NP];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int it = lane + 64 * j, q = it / PPR, pc = it % PPR;
+            m8[j] = f16x8{0, 0, 0, 0, 0, 0, 0, 0}; y8[j] = m8[j];
+            if (xg * 16 + q < p.W) {
+                if (p.mul) m8[j] = *reinterpret_cast<const f16x8*>(p.mul + (pix0 + q) * p.mul_ld + p.mul_coff + cb + pc * 8);
+                if (p.accumulate) y8[j] = *reinterpret_cast<const f16x8*>(reinterpret_cast<const _Float16*>(p.y) + (pix0 + q) * p.y_ld + p.y_coff + cb + pc * 8);
+            }
+        }
+        f16x4 bfr[4];
+        bool live[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            bfr[c] = f16x4{g4[0][c], g4[1][c], g4[2][c], g4[3][c]};
+            const bool nz = (float)bfr[c][0] != 0.f || (float)bfr[c][1] != 0.f || (float)bfr[c][2] != 0.f || (float)bfr[c][3] != 0.f;
+            live[c] = __builtin_amdgcn_ballot_w64(nz) != 0;             // wave-uniform: an all-zero gradient channel (the padding of a 1-channel head) adds nothing
+        }
+#pragma unroll
+        for (int tl = 0; tl < NTL; ++tl) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (!live[c]) continue;
+                const f16x4 a4 = *reinterpret_cast<const f16x4*>(wl + c * LDW + (tl * 16 + n) * 16 + gq * 4);
+                acc = __builtin_amdgcn_mfma_f32_16x16x16f16(a4, bfr[c], acc, 0, 0, 0);
+            }
+            // D: row (channel) = 4 gq + r, column (pixel) = n
+            *reinterpret_cast<f16x4*>(mine + n * LDS_ROW + tl * 16 + gq * 4) =
+                f16x4{(_Float16)(acc[0] * p.alpha), (_Float16)(acc[1] * p.alpha), (_Float16)(acc[2] * p.alpha), (_Float16)(acc[3] * p.alpha)};
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                              // lgkmcnt(0): the wave's own LDS writes (no other wave reads them)
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int it = lane + 64 * j, q = it / PPR, pc = it % PPR;
+            if (xg * 16 + q >= p.W) continue;
+            f16x8 v8 = *reinterpret_cast<const f16x8*>(mine + q * LDS_ROW + pc * 8);
+            if (p.mul) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v8[e] = (_Float16)((float)v8[e] * hv_act_grad_from_out((float)m8[j][e], p.mul_act));
+            }
+            if (p.accumulate) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v8[e] = (_Float16)((float)v8[e] + (float)y8[j][e]);
+            }
+            *reinterpret_cast<f16x8*>(reinterpret_cast<_Float16*>(p.y) + (pix0 + q) * p.y_ld + p.y_coff + cb + pc * 8) = v8;
+        }
+    }
+}
+
+template <int NP>
+static int launch_logits(const ThinK& k, const _Float16* wh, int groups, hipStream_t s) {
+    const int nq = k.Cout / (32 * NP);                                   // a power of two (checked by the caller)
+    int nq_log = 0;
+    while ((1 << nq_log) < nq) ++nq_log;
+    int gb = (groups + 3) / 4;                                           // workgroups per slice: 4 pixel groups each, at most ~8 workgroups per CU in all
+    if (gb * nq > 2048) gb = 2048 / nq;
+    HV_KNAME("logits_dgrad_kernel");
+    hipLaunchKernelGGL(logits_dgrad_kernel<NP>, dim3(gb * nq), dim3(256), 0, s, k, wh, nq, nq_log);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+
+// hv_conv2d: transposed, 4x4, stride 1, pad 1, gradient channel stride 4 (<= 4 live channels), Cout % 16 == 0 (<= 512), fp16 views + fp16 filter copy
+int hv_conv2d_logits_dgrad(const hv_conv_desc* d, hipStream_t s) {
+    static const int on = getenv("HV_LOGITS_DGRAD") ? atoi(getenv("HV_LOGITS_DGRAD")) : 1;
+    if (!on || !d->transposed || d->KH != 4 || d->KW != 4 || d->stride != 1 || d->pad != 1 || d->dil != 1 || d->in_shift || d->w_bstride || d->ch_scale || !d->w_f16)
+        return HV_ERR_UNSUPPORTED;
+    if (d->Cin != 4 || d->x_ld != 4 || (d->x_coff & 3) || !d->x_f16 || !d->y_f16 || d->bias || d->act != HV_ACT_NONE || d->accumulate > 1) return HV_ERR_UNSUPPORTED;
+    if (d->Cout > 512 || (d->Cout & 31) || (d->Cout & (d->Cout - 1)) || ((uintptr_t)d->w_f16 & 15) || (d->y_ld & 7) || (d->y_coff & 7) || ((uintptr_t)d->y & 15) || ((uintptr_t)d->x & 7) ||
+        d->Ho != d->H + 1 || d->Wo != d->W + 1)
+        return HV_ERR_UNSUPPORTED;
+    if (d->mul_src && (!d->mul_f16 || (d->mul_ld & 7) || (d->mul_coff & 7) || ((uintptr_t)d->mul_src & 15))) return HV_ERR_UNSUPPORTED;
+    if ((long long)d->B * d->Ho * d->Wo * d->y_ld >= (1ll << 31)) return HV_ERR_UNSUPPORTED;
+    ThinK k;
+    k.g = reinterpret_cast<const _Float16*>(d->x); k.w = d->w; k.y = d->y; k.mul = reinterpret_cast<const _Float16*>(d->mul_src);
+    k.B = d->B; k.H = d->Ho; k.W = d->Wo; k.g_ld = d->x_ld; k.g_coff = d->x_coff; k.Cin = d->Cin; k.Cout = d->Cout; k.w_row = 16 * d->Cin;
+    k.y_ld = d->y_ld; k.y_coff = d->y_coff; k.mul_ld = d->mul_ld; k.mul_coff = d->mul_coff; k.mul_act = d->mul_act; k.accumulate = d->accumulate; k.pad = d->pad;
+    k.alpha = d->alpha; k.g_bytes = 0;
+    const int groups = d->B * d->Ho * ((d->Wo + 15) / 16);
+    const _Float16* wh = reinterpret_cast<const _Float16*>(d->w_f16);
+    hv_path_note = 9;
+    if (d->Cout == 32) return launch_logits<1>(k, wh, groups, s);
+    if (d->Cout == 64) return launch_logits<2>(k, wh, groups, s);
+    return launch_logits<4>(k, wh, groups, s);                           // 128-channel slices
+}
+
 // (Measured and not kept, round 3: the same lane-per-pixel form for the PatchGAN logits layer's data gradient (4x4, 1 -> 512 channels; fp16 filters in
 // LDS as [tap][ci][Cout], a lane = 8 channels of 4 pixels, persistent workgroups): step 9.04 -> 9.15 ms against the gather kernel's 26.7 us launches --
 // 64 LDS filter reads per lane and pixel group cost more than the gather kernel's MFMA tiles save.)

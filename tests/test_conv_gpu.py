@@ -377,6 +377,40 @@ def test_conv_single_output_channel_data_gradient(case, prec, tol):
     assert maxerr(from_act(dxa), ref + x.grad) <= 2 * tol * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize('case', [(2, 7, 7, 32, 1), (2, 18, 21, 64, 3), (3, 31, 31, 512, 1), (2, 33, 17, 256, 4)])
+def test_conv_logits_data_gradient_taps_as_mfma_contraction(case):
+    """logits_dgrad_kernel: data gradient of a 4x4 / stride 1 / pad 1 conv with <= 4 output channels (gradient stored with a channel stride
+    of 4) back to 32..512 channels, the 16 taps as the contraction of one 16x16x16 MFMA; ragged 16-pixel groups, 1..4 live gradient channels,
+    act' multiplier and both accumulate modes, against torch CPU fp32."""
+    from hvtest import to_act, from_act, dev, maxerr
+    from hvgan import ops, lib
+    B, H, W, C, live = case
+    g = torch.Generator().manual_seed(11 + C)
+    x = torch.randn(B, C, H, W, generator=g, requires_grad=True)
+    w = torch.randn(live, C, 4, 4, generator=g) / (C * 16) ** 0.5
+    y = F.conv2d(x, w.half().float(), None, stride=1, padding=1)
+    gy = torch.randn(y.shape, generator=g).half().float()
+    y.backward(gy)
+    wb = torch.zeros(C, 16, 4)
+    wb[:, :, :live] = w.reshape(live, C, 16).permute(1, 2, 0)          # [C][taps][4]
+    wb = wb.to(dev())
+    gp = torch.zeros(B, 4, H - 1, W - 1)
+    gp[:, :live] = gy
+    ga = to_act(gp, dtype=torch.float16)
+    m = torch.randn(B, C, H, W, generator=g)
+    fac = torch.where(m > 0, torch.ones_like(m), torch.full_like(m, 0.2))
+    dxa = ops.Act.empty(B, H, W, C, dev(), dtype=torch.float16)
+    ops.conv2d(ga, wb, dxa, 4, 1, 1, 1, transposed=True, precision='fp16', w_h=wb.half(), mul=(to_act(m, dtype=torch.float16), 'lrelu'))
+    assert lib.get().size('hv_last_kernel_path') == 9
+    torch.cuda.synchronize()
+    ref = x.grad * fac
+    scale = max(1.0, ref.abs().max().item())
+    assert maxerr(from_act(dxa), ref) <= 3e-3 * scale
+    ops.conv2d(ga, wb, dxa, 4, 1, 1, 1, transposed=True, precision='fp16', w_h=wb.half(), accumulate=1)
+    torch.cuda.synchronize()
+    assert maxerr(from_act(dxa), ref + x.grad) <= 6e-3 * scale
+
+
 @pytest.mark.parametrize('case', [(16, 256, 256, 64, 2, 'lrelu'), (2, 37, 41, 32, 2, 'none'), (3, 20, 22, 16, 1, 'elu'), (2, 70, 50, 64, 2, 'lrelu')])
 def test_conv_one_channel_stem_mfma(case):
     """1-channel image into 16..64 channels, 4x4 filter (PatchGAN stem), fp16 mode with the fp16 filter copy: the 16 taps are the contraction
