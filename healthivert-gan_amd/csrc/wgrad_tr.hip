@@ -18,6 +18,8 @@
 // accumulator tiles and reads every A fragment once per k-step.  One slab per workgroup, summed by wgrad_reduce_kernel (fixed order).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "hv_common.h"
 
 typedef __fp16 hv_fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
@@ -31,6 +33,7 @@ struct WTrK {
     long long slab;              // floats per slab = Cout * KS*KS * Cin
     unsigned x_bytes, g_bytes;   // buffer descriptor ranges
     float* bias_out;             // per-workgroup column sums of g (bias gradient), [gridDim.x][Cout], or NULL
+    int dbg;                     // diagnostic builds (WT_STAMPS), timing only: bit 0 no DMA after the first tile, bit 1 no MFMAs, bit 2 no fragment reads
 };
 
 __device__ __forceinline__ f16x4 tr_read(const _Float16* lds_addr) {
@@ -198,7 +201,294 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(const WTrK p) {
     }
 }
 
-struct WTrPlan { int BN, BC, gx; size_t lds; };
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// The same product with the tiles brought in by LDS-DMA (buffer_load ... lds, 16 bytes per lane) into TWO buffers: no staging registers, no
+// flush pass, one barrier per pixel tile, and the next tile's bytes fly behind this tile's MFMAs.  (In-kernel phase stamps of the kernel above
+// on PatchGAN 256 -> 512, 32 tiles per workgroup: 76.6 us loop = 48.0 MFMA section (27 of MFMAs) + 16.5 issuing the prefetch (its index
+// arithmetic) + 7.2 flush and barrier + 2.2 first barrier; stride 2: 30 us = 14.8 (6.8) + 8.6 + 4.3 + 0.4.)  The DMA writes 64 x 16 bytes
+// lane-linear, so the LDS images cannot carry the odd row strides used above; instead the SOURCE side permutes 16-byte pieces:
+//   G   [128 pixels][128 B]:  piece j of tile pixel (ty, tx) holds channel piece j ^ 2 ((tx >> 1) & 3)
+//   X   stride 1: [PH][24 pixels][64 B], piece j of patch pixel (py, px) holds channel piece j ^ 2 ((px >> 2) & 1)
+//       stride 2: [PH][40 pixels][32 B], patch pixel pp = 40 py + px sits in row pp ^ ((pp >> 3) & 1)
+// (patch rows padded to a multiple of 8 pixels so that the keys depend on px alone; the pad pixels are out-of-range lanes of the DMA = zeros,
+// never read).  Each transposed read's eight pixel rows of a 32-lane half then cover all 64 banks once for every tap and k-step (brute-forced
+// over all (tap, k-step, fragment) address sets).  The per-lane address of a fragment is (lane base) ^ (fragment << 5) + an immediate.
+// Index arithmetic of the DMA is hoisted: per item a tile-invariant relative offset + its (py, px); a tile adds one scalar base and four bounds.
+// Fragments are double-buffered over stages of 8 MFMAs (the next stage's reads are issued before the current stage's MFMAs).
+// The DMA is issued from inline assembly: through the builtin the compiler knows that LDS is written and puts s_waitcnt vmcnt(0) in front of
+// the next transposed read (it cannot tell that the read goes to the OTHER buffer), i.e. it waited for the next tile's bytes before the first
+// MFMA of this one.  Here only the explicit s_waitcnt vmcnt(0) in front of the tile barrier orders the DMA.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void wtr_dma16(i32x4 rsrc, unsigned lds_byte, unsigned voff) {      // 16 bytes per lane -> LDS at lds_byte + 16 * lane; out-of-range lanes write zeros
+    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(__builtin_amdgcn_readfirstlane(lds_byte)), "v"(voff), "s"(rsrc) : "memory", "m0");
+}
+__device__ __forceinline__ i32x4 wtr_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    return (i32x4){(int)__builtin_amdgcn_readfirstlane((unsigned)a), (int)__builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu),
+                   (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000};
+}
+
+template <int KS, int ST>
+struct WTrdCfg {
+    static constexpr int BN = 64, BC = ST == 1 ? 32 : 16, TH = 8, TW = 16, TAPS = KS * KS, SLOTS = (TAPS + 3) / 4;
+    static constexpr int PH = (TH - 1) * ST + KS, PW = (TW - 1) * ST + KS, PWP = ST == 1 ? 24 : 40;
+    static constexpr int NT = BN / 16, CT = BC / 16, XPR = BC / 8, XROW = BC * 2;
+    static constexpr int XI = PH * PWP * XPR, XINS = (XI + 63) / 64, XPT = (XINS + 3) / 4;
+    static constexpr int GBUF = TH * TW * 128, XBUF = XINS * 1024, BUFSZ = GBUF + XBUF;
+    static constexpr int SPS = CT == 2 ? 2 : 4;          // tap slots per stage (16 MFMAs)
+};
+
+template <int KS, int ST>
+__global__ __launch_bounds__(512, 1) void wgrad_trd_kernel(const WTrK p) {
+    using C = WTrdCfg<KS, ST>;
+    constexpr int BN = C::BN, BC = C::BC, TH = C::TH, TW = C::TW, TAPS = C::TAPS, SLOTS = C::SLOTS, PW = C::PW, PWP = C::PWP;
+    constexpr int NT = C::NT, CT = C::CT, XPR = C::XPR, XROW = C::XROW, XI = C::XI, XINS = C::XINS, XPT = C::XPT, GBUF = C::GBUF, BUFSZ = C::BUFSZ;
+    constexpr int SPS = SLOTS < C::SPS ? SLOTS : C::SPS, NSTG = (SLOTS + SPS - 1) / SPS;     // stages per k-step
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // [2][GBUF | XBUF]
+    // waves 0-3 run the MFMAs (one per SIMD, the taps dealt round-robin as above); waves 4-7 are the loaders: an LDS-DMA instruction holds the issuing
+    // wave for ~100-200 cycles while the memory pipe takes its 8-16 lines (stamps: 9 instructions per wave and tile = 1.05 us against 1.43 us of
+    // MFMAs at the clock the chip holds under this load), so the issue sits in a wave that has nothing else to do
+    const int tid = threadIdx.x, lane = tid & 63, wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave8 >= 4;
+    const int wave = wave8 & 3;
+    const int co0 = blockIdx.y * BN, ci0 = blockIdx.z * BC;
+    const int grp = lane >> 4, sub = lane & 15, qr = sub >> 2, pc = sub & 3, tx_l = 4 * grp + qr;
+
+    f32x4 acc[SLOTS][NT][CT];
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int c = 0; c < CT; ++c) acc[s][n][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = p.bias_out != nullptr && blockIdx.z == 0 && wave8 == 4;      // wave-uniform: the first loader wave also sums g (the bias gradient)
+    f32x4 bacc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) bacc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ---- per-lane LDS byte addresses of the transposed reads (buffer 0; buffer 1 and the k-step rows are immediates)
+    const int ga0 = tx_l * 128 + (((tx_l >> 1) & 3) << 5) + pc * 8;                  // fragment n: ga0 ^ (n << 5)
+    int xa0[SLOTS];                                                                  // fragment c: xa0 ^ (c << 5)
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const int t = wave + 4 * s, tt = t < TAPS ? t : 0, r = tt / KS, q = tt - r * KS;
+        const int px = tx_l * ST + q;
+        if (ST == 1) xa0[s] = GBUF + (r * PWP + px) * XROW + (((px >> 2) & 1) << 5) + pc * 8;
+        else xa0[s] = GBUF + (((r * PWP + px) ^ (((r & 1) + (px >> 3)) & 1)) * XROW) + pc * 8;
+    }
+
+    // ---- tile-invariant part of the DMA items: wave w issues G instructions 4w .. 4w+3 and X instructions w, w+4, ...
+    constexpr int NOPE = -(1 << 30);
+    int grel[4], xrel[XPT], xpp[XPT];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = (wave * 4 + i) * 64 + lane, pix = e >> 3, j = e & 7, ty = pix >> 4, tx = pix & 15;
+        const int co = co0 + ((j ^ (((tx >> 1) & 3) << 1)) << 3);
+        grel[i] = co < p.Cout ? (ty * p.Wo + tx) * p.g_ld + p.g_coff + co : NOPE;
+    }
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+        const int e = (wave + 4 * i) * 64 + lane, row = e / XPR, j = e % XPR;
+        const int pp = ST == 1 ? row : row ^ ((row >> 3) & 1);
+        const int py = pp / PWP, px = pp - py * PWP;
+        const int ci = ci0 + ((ST == 1 ? j ^ (((px >> 2) & 1) << 1) : j) << 3);
+        const bool ok = e < XI && px < PW && ci < p.Cin;
+        xrel[i] = ok ? (py * p.Wl + px) * p.x_ld + p.x_coff + ci : NOPE;
+        xpp[i] = (py << 8) | px;
+    }
+    const i32x4 xsrc = wtr_rsrc(p.x, p.x_bytes), gsrc = wtr_rsrc(p.g, p.g_bytes);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+    // the DMA of one tile: 4 + XPT instructions per loader wave
+    struct TileAt { int hmax, wmax, gbase, y0, x0, xbase; };
+    auto tile_at = [&](int tile) __attribute__((always_inline)) {
+        TileAt t;
+        const int n_img = tile / p.tiles_per_img, tr = tile - n_img * p.tiles_per_img;
+        const int ty0 = tr / p.tiles_x, oy0 = ty0 * TH, ox0 = (tr - ty0 * p.tiles_x) * TW;
+        t.hmax = p.Ho - oy0; t.wmax = p.Wo - ox0;
+        t.gbase = ((n_img * p.Ho + oy0) * p.Wo + ox0) * p.g_ld;
+        t.y0 = oy0 * ST - p.pad; t.x0 = ox0 * ST - p.pad;
+        t.xbase = n_img * p.img_stride + (t.y0 * p.Wl + t.x0) * p.x_ld;
+        return t;
+    };
+    constexpr int NPART = 4 + XPT;
+    auto issue_part = [&](const TileAt& t, int buf, int part) __attribute__((always_inline)) {
+        const unsigned dstb = lds0 + buf * BUFSZ;
+        if (part < 4) {
+            const int i = part, k = wave * 4 + i, pix = k * 8 + (lane >> 3), ty = pix >> 4, tx = pix & 15;
+            const bool ok = grel[i] >= 0 && ty < t.hmax && tx < t.wmax;
+            wtr_dma16(gsrc, dstb + k * 1024, ok ? (unsigned)(t.gbase + grel[i]) * 2u : 0x80000000u);
+        } else {
+            const int i = part - 4, k = wave + 4 * i;
+            if (k < XINS) {
+                const int hi = t.y0 + (xpp[i] >> 8), wi = t.x0 + (xpp[i] & 255);
+                const bool ok = xrel[i] > NOPE / 2 && (unsigned)hi < (unsigned)p.Hl && (unsigned)wi < (unsigned)p.Wl;
+                wtr_dma16(xsrc, dstb + GBUF + k * 1024, ok ? (unsigned)(t.xbase + xrel[i]) * 2u : 0x80000000u);
+            }
+        }
+    };
+
+    const f16x8 ones = {1, 1, 1, 1, 1, 1, 1, 1};
+    // fragments of one stage: A halves (the k-step's NT fragments are fetched NT / NSTG per stage of the PREVIOUS k-step) and SPS x CT B fragments
+    f16x8 aq[2][NT], bq[2][SPS][CT];
+    // (one loop body for both buffers: with the body unrolled per buffer the two loop exits cost a shuffle of all accumulators through scratch)
+    auto lda = [&](int BUFC, int ks, int n, f16x8 (&a)[NT]) __attribute__((always_inline)) {
+        const _Float16* base = reinterpret_cast<const _Float16*>(smem + ((ga0 + BUFC) ^ (n << 5)));
+        const f16x4 lo = tr_read(base + ((2 * ks) * TW * 128) / 2), hi = tr_read(base + ((2 * ks + 1) * TW * 128) / 2);
+        a[n] = (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+    auto ldb = [&](int BUFC, int ks, int sl, f16x8 (&bb)[CT]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const _Float16* base = reinterpret_cast<const _Float16*>(smem + ((xa0[sl] + BUFC) ^ (c << 5)));
+            const f16x4 lo = tr_read(base + ((2 * ks) * ST * PWP * XROW) / 2), hi = tr_read(base + ((2 * ks + 1) * ST * PWP * XROW) / 2);
+            bb[c] = (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+    };
+    // stage index g = ks * NSTG + j over the tile; loads of stage g + 1 go in front of the MFMAs of stage g
+    auto load_stage = [&](int BUFC, int g) __attribute__((always_inline)) {
+        const int ks = g / NSTG, j = g - ks * NSTG;
+#pragma unroll
+        for (int u = 0; u < SPS; ++u)
+            if (j * SPS + u < SLOTS) ldb(BUFC, ks, j * SPS + u, bq[g & 1][u]);
+    };
+    auto load_a_part = [&](int BUFC, int ks, int j) __attribute__((always_inline)) {     // part j of NSTG of k-step ks's A fragments
+        constexpr int PER = (NT + NSTG - 1) / NSTG;
+#pragma unroll
+        for (int n = j * PER; n < (j + 1) * PER && n < NT; ++n) lda(BUFC, ks, n, aq[ks & 1]);
+    };
+    // One stage = the reads of the next stage's fragments dealt one per MFMA among this stage's 16 MFMAs (issued in a block in front of them they
+    // kept the MFMA pipe idle for their ~60-100 issue cycles per stage: MFMAs alone 43 us, with the reads in front 54 us on the 256 -> 512 layer).
+#define WTD_MIX()                                                                                                                       \
+    do {                                                                                                                                \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                             \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                             \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                             \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                             \
+    } while (0)
+    auto tile_body = [&](int BUFC) __attribute__((always_inline)) {      // BUFC: byte offset of the tile's buffer
+        constexpr int NG = (TH / 2) * NSTG;
+#pragma unroll
+        for (int j = 0; j < NSTG; ++j) load_a_part(BUFC, 0, j);
+        load_stage(BUFC, 0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int ks = g / NSTG, j = g - ks * NSTG;
+            __builtin_amdgcn_sched_barrier(0);
+#ifdef WT_STAMPS
+            if (!(p.dbg & 4))
+#endif
+            if (g + 1 < NG) {
+                load_stage(BUFC, g + 1);
+                if (ks + 1 < TH / 2) load_a_part(BUFC, ks + 1, j);
+            }
+#pragma unroll
+            for (int u = 0; u < SPS; ++u) {
+                const int sl = j * SPS + u;
+#ifdef WT_STAMPS
+                if (p.dbg & 2) continue;
+#endif
+                if (sl < SLOTS && wave + 4 * sl < TAPS) {     // wave-uniform (scalar) branch (folds away for 4 x 4 taps): MFMA ignores EXEC
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+#pragma unroll
+                        for (int c = 0; c < CT; ++c) acc[sl][n][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aq[ks & 1][n], bq[g & 1][u][c], acc[sl][n][c], 0, 0, 0);
+                }
+            }
+            WTD_MIX(); WTD_MIX(); WTD_MIX(); WTD_MIX();
+        }
+    };
+    // the bias gradient (column sums of g) by the first loader wave, after it has issued the next tile's DMA: ones-products on the G image
+    auto bias_tile = [&](int BUFC) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ks = 0; ks < TH / 2; ++ks) {
+            f16x8 a[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) lda(BUFC, ks, n, a);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) bacc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[n], ones, bacc[n], 0, 0, 0);
+        }
+    };
+
+#ifdef WT_STAMPS      // diagnostic build only (tools/wtr_stamps.py): phase sums of one workgroup's wave 0, printed at the end
+    unsigned long long wt_t[4], wt_sum[3] = {0, 0, 0}, wt_begin = __builtin_amdgcn_s_memrealtime();
+#define WTD_STAMP(i) wt_t[i] = __builtin_amdgcn_s_memrealtime()
+#define WTD_ACC() do { __builtin_amdgcn_sched_barrier(0); WTD_STAMP(3); for (int i_ = 0; i_ < 3; ++i_) wt_sum[i_] += wt_t[i_ + 1] - wt_t[i_]; } while (0)
+#else
+#define WTD_STAMP(i)
+#define WTD_ACC()
+#endif
+    const int step = gridDim.x;
+    auto issue_tile = [&](int t, int buf) __attribute__((always_inline)) {
+        const TileAt at = tile_at(t);
+#pragma unroll
+        for (int q = 0; q < NPART; ++q) issue_part(at, buf, q);
+    };
+    // two disjoint loops with the same barrier count (the loaders' registers and the accumulators never share a path); barrier t: buffer t & 1 is whole
+    // (each loader waited for its own DMA) and buffer (t + 1) & 1 is no longer read
+    if (loader) {
+        int tile = blockIdx.x, buf = 0;
+        if (tile < p.ntiles) issue_tile(tile, 0);
+        for (; tile < p.ntiles; tile += step, buf ^= 1) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0)
+            __builtin_amdgcn_s_barrier();
+#ifdef WT_STAMPS
+            if (p.dbg & 1) continue;
+#endif
+            if (tile + step < p.ntiles) issue_tile(tile + step, buf ^ 1);
+            if (do_bias) bias_tile(buf * BUFSZ);
+        }
+    } else {
+        int bufoff = 0;
+        for (int tile = blockIdx.x; tile < p.ntiles; tile += step, bufoff ^= BUFSZ) {
+            WTD_STAMP(0);
+            __syncthreads();
+            WTD_STAMP(1);
+            WTD_STAMP(2);
+            tile_body(bufoff);
+            WTD_ACC();
+        }
+    }
+#ifdef WT_STAMPS
+    const unsigned long long wt_loop_end = __builtin_amdgcn_s_memrealtime();
+#endif
+    // ---- one slab per workgroup; D layout: row (= co) = (lane>>4)*4 + r, col (= ci) = lane & 15
+    float* out = p.slabs + (long long)blockIdx.x * p.slab;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const int t = wave + 4 * s;
+        if (t >= TAPS || loader) continue;
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const int ci = ci0 + c * 16 + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = co0 + n * 16 + (lane >> 4) * 4 + r;
+                    if (co < p.Cout && ci < p.Cin) out[((long long)co * TAPS + t) * p.Cin + ci] = acc[s][n][c][r];
+                }
+            }
+    }
+    if (do_bias && (lane & 15) == 0) {     // every column of the ones-product holds the row sums: take column 0
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + n * 16 + (lane >> 4) * 4 + r;
+                if (co < p.Cout) p.bias_out[(long long)blockIdx.x * p.Cout + co] = bacc[n][r];
+            }
+    }
+#ifdef WT_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);
+    if (tid == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2 && blockIdx.z == 0)
+        printf("wtrd<%d,%d> grid %d x %d x %d: barrier %.2f  tile scalars %.2f  mfma section (+dma issue) %.2f  | loop %.2f  slab write %.2f us\n", KS, ST,
+               (int)gridDim.x, (int)gridDim.y, (int)gridDim.z, wt_sum[0] / 100.0, wt_sum[1] / 100.0, wt_sum[2] / 100.0,
+               (wt_loop_end - wt_begin) / 100.0, (__builtin_amdgcn_s_memrealtime() - wt_loop_end) / 100.0);
+#endif
+}
+
+struct WTrPlan { int BN, BC, gx; size_t lds; bool dma; };
 
 static bool wgrad_tr_plan(const hv_wgrad_desc* d, WTrPlan* pl) {
     static const int enabled = getenv("HV_WGRAD_TR") ? atoi(getenv("HV_WGRAD_TR")) : 1;   // A/B knob
@@ -213,6 +503,14 @@ static bool wgrad_tr_plan(const hv_wgrad_desc* d, WTrPlan* pl) {
     if (d->stride == 2 && pl->BN == 64) pl->BC = 16;      // the stride-2 patch is 3x larger: its prefetch registers leave room for 16 accumulator tiles
     const int PH = 7 * d->stride + d->KH, PW = 15 * d->stride + d->KW;
     pl->lds = (size_t)128 * wtr_stride(pl->BN, 1) + (size_t)PH * PW * wtr_stride(pl->BC, d->stride);
+    // the LDS-DMA form: 64-channel output blocks, its fixed input block (32 channels at stride 1, 16 at stride 2), no fused upsampling
+    static const int dma_on = getenv("HV_WGRAD_TRD") ? atoi(getenv("HV_WGRAD_TRD")) : 1;   // A/B knob
+    pl->dma = dma_on && pl->BN == 64 && pl->BC == (d->stride == 1 ? 32 : 16) && d->in_shift == 0;
+    const bool dma_candidate = pl->dma;
+    if (pl->dma) {
+        const int PWP = d->stride == 1 ? 24 : 40, XI = PH * PWP * (pl->BC / 8);
+        pl->lds = (size_t)2 * (8 * 16 * 128 + (XI + 63) / 64 * 1024);
+    }
     const long long ntiles = (long long)d->B * hv_cdiv(d->Ho, 8) * hv_cdiv(d->Wo, 16);
     const long long pairs = (long long)hv_cdiv(d->Cout, pl->BN) * hv_cdiv(d->Cin, pl->BC);
     // workgroups wanted per launch (split over pixel chunks): every chunk writes a whole slab of dW, so a layer with a small dW tile count (the
@@ -226,6 +524,12 @@ static bool wgrad_tr_plan(const hv_wgrad_desc* d, WTrPlan* pl) {
     if (gx > ntiles) gx = ntiles;
     if (gx < 1) gx = 1;
     pl->gx = (int)gx;
+    // the DMA form pays a longer prologue (8 waves, hoisted DMA indices): it needs a few tiles per workgroup to win (generator 64 -> 64 at 64 x 64, 2 tiles
+    // per workgroup: 22.8 us against 16.1)
+    if (dma_candidate && ntiles < 4 * gx) {
+        pl->dma = false;
+        pl->lds = (size_t)128 * wtr_stride(pl->BN, 1) + (size_t)PH * PW * wtr_stride(pl->BC, d->stride);
+    }
     return true;
 }
 
@@ -254,6 +558,25 @@ static int launch_wtr(const WTrK& k, const WTrPlan& pl, const hv_wgrad_desc* d, 
     return HV_OK;
 }
 
+template <int KS, int ST>
+static int launch_wtrd(const WTrK& k, const WTrPlan& pl, const hv_wgrad_desc* d, hipStream_t s) {
+    auto kern = wgrad_trd_kernel<KS, ST>;
+    static bool raised = false;
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e != hipSuccess) return -1000 - (int)e;
+        raised = true;
+    }
+    dim3 grid(pl.gx, hv_cdiv(d->Cout, 64), hv_cdiv(d->Cin, WTrdCfg<KS, ST>::BC));
+    hv_path_note = 13;
+    HV_KNAME("wgrad_trd_kernel<%d, %d>", KS, ST);
+    HV_TIMING_BEGIN(s);
+    hipLaunchKernelGGL(kern, grid, dim3(512), pl.lds, s, k);
+    HV_TIMING_END(s);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+
 // returns HV_ERR_UNSUPPORTED when the shape does not qualify; on success the slabs (*nslabs of them) are in d->workspace
 int hv_wgrad_tr(const hv_wgrad_desc* d, int* nslabs, hipStream_t s) {
     WTrPlan pl;
@@ -268,11 +591,16 @@ int hv_wgrad_tr(const hv_wgrad_desc* d, int* nslabs, hipStream_t s) {
     k.tiles_x = hv_cdiv(d->Wo, 16); k.tiles_per_img = k.tiles_x * hv_cdiv(d->Ho, 8); k.ntiles = k.tiles_per_img * d->B;
     k.slab = (long long)d->Cout * d->KH * d->KW * d->Cin;
     k.bias_out = d->dbias ? d->workspace + (long long)pl.gx * k.slab : nullptr;
+    k.dbg = 0;
+#ifdef WT_STAMPS
+    if (getenv("HV_WTR_DBG")) k.dbg = atoi(getenv("HV_WTR_DBG"));
+#endif
     k.x_bytes = (unsigned)((size_t)d->B * k.img_stride * sizeof(_Float16));
     k.g_bytes = (unsigned)((size_t)d->B * d->Ho * d->Wo * d->g_ld * sizeof(_Float16));
     *nslabs = pl.gx;
 #define WTR(KS_, ST_)                                                                                     \
     do {                                                                                                  \
+        if (pl.dma) return launch_wtrd<KS_, ST_>(k, pl, d, s);                                            \
         if (pl.BN == 64 && pl.BC == 32) return launch_wtr<KS_, ST_, 64, 32>(k, pl, d, s);                 \
         if (pl.BN == 64 && pl.BC == 16) return launch_wtr<KS_, ST_, 64, 16>(k, pl, d, s);                 \
         if (pl.BN == 32 && pl.BC == 32) return launch_wtr<KS_, ST_, 32, 32>(k, pl, d, s);                 \
