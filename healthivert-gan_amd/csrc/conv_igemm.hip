@@ -13,6 +13,8 @@
 //
 // Precision: float -> v_mfma_f32_16x16x4_f32 (exact fp32, the parity mode);
 //            _Float16 -> v_mfma_f32_16x16x32_f16 with fp32 accumulation.
+#include <string.h>
+
 #include "hv_common.h"
 #include <stdlib.h>
 
@@ -382,6 +384,12 @@ static int conv2d_dispatch(const hv_conv_desc* d, void* stream) {
         return HV_ERR_UNSUPPORTED;
     if (d->H > 16000 || d->W > 16000 || (d->KH - 1) * d->dil > 120 || (d->KW - 1) * d->dil > 120) return HV_ERR_UNSUPPORTED;
 
+    if (d->pool2) {      // pooled data gradient: the filters-in-LDS kernel or nothing (the caller keeps the conv + copy form)
+        if (d->precision != HV_F16 || !d->w_f16 || !d->y_f16 || (d->Ho & 1) || (d->Wo & 1) || d->dil != 1 || d->stride != 1 || d->KH != 3 || d->KW != 3 || d->bias ||
+            d->act != HV_ACT_NONE || d->in_shift || d->stats)
+            return HV_ERR_UNSUPPORTED;
+        return hv_conv2d_halo(d, d->w_f16, (hipStream_t)stream);
+    }
     // single-channel heads / logits: VALU kernels (conv_narrow.hip), except where the halo-tiled MFMA kernel stages the input
     // once instead of once per tap (many input channels, fp16 mode)
     static const int narrow_max_cin = getenv("HV_NARROW_MAX_CIN") ? atoi(getenv("HV_NARROW_MAX_CIN")) : 15;   // A/B knob
@@ -834,6 +842,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 static int launch_wgrad_reduce(const float* slabs, float* dw, long long n, int splits, int accumulate, const float* bslabs, float* dbias, int nb,
                                 int bias_accumulate, hipStream_t s) {
+    static const int skip_red = getenv("HV_DIAG_SKIP") && strstr(getenv("HV_DIAG_SKIP"), "wgrad_reduce") ? 1 : 0;     // timing-only diagnostic (wrong results)
+    if (skip_red) return HV_OK;
 #define HV_RED(G_)                                                                                                                          \
     hipLaunchKernelGGL(wgrad_reduce_kernel<G_>, dim3(hv_cdiv(n / 4, 256 / G_) + (dbias ? hv_cdiv(nb, 256 / G_) : 0)), dim3(256), 0, s, slabs, dw, n, splits, \
                        accumulate, bslabs, dbias, nb, bias_accumulate)

@@ -170,17 +170,37 @@ __global__ __launch_bounds__(512, WPS) void conv_lf_kernel(const HaloK p) {
     // activation arithmetic of the staging pass
     u32x4 mreg[OITEMS], yreg[OITEMS];
     long long ooff[OITEMS];         // element offset of the piece in y (-1: outside the image / beyond Cout)
+    // pooled form (hv_conv_desc.pool2): the tile leaves as (TH / 2) x (TW / 2) pixels, each the sum of its four fp16-rounded values; a thread's item
+    // k < PITEMS is then (pooled pixel, piece) and y / mul_src are the pooled tensors
+    constexpr int PPIX = (TH / 2) * (TW / 2), PITEMS = (PPIX * PIECES + G::NTHR - 1) / G::NTHR;
+    const bool pooled = p.pool2 != 0;      // scalar
+    if (!pooled) {
 #pragma unroll
-    for (int k = 0; k < OITEMS; ++k) {
-        const int it = tid + k * G::NTHR;
-        const int q = it / PIECES, pc = it - q * PIECES;
-        const int i = i0 + (q >> 4), j = j0 + (q & 15), ch = n_base + pc * 8;
-        const bool ok = i < C.Hc && j < C.Wc && ch < p.Cout;
-        const int ho = C.ph + ry + i * p.ostep, wo = C.pw + rx + j * p.ostep;
-        const long long opix = (long long)(n_img * p.Ho + ho) * p.Wo + wo;
-        ooff[k] = ok ? opix * p.y_ld + p.y_coff + ch : -1;
-        mreg[k] = __builtin_amdgcn_raw_buffer_load_b128(msrc, ok ? (unsigned)((opix * p.mul_ld + p.mul_coff + ch) * 2) : HV_OOB, 0, 0);
-        yreg[k] = __builtin_amdgcn_raw_buffer_load_b128(ysrc, ok ? (unsigned)(ooff[k] * 2) : HV_OOB, 0, 0);
+        for (int k = 0; k < OITEMS; ++k) {
+            const int it = tid + k * G::NTHR;
+            const int q = it / PIECES, pc = it - q * PIECES;
+            const int i = i0 + (q >> 4), j = j0 + (q & 15), ch = n_base + pc * 8;
+            const bool ok = i < C.Hc && j < C.Wc && ch < p.Cout;
+            const int ho = C.ph + ry + i * p.ostep, wo = C.pw + rx + j * p.ostep;
+            const long long opix = (long long)(n_img * p.Ho + ho) * p.Wo + wo;
+            ooff[k] = ok ? opix * p.y_ld + p.y_coff + ch : -1;
+            mreg[k] = __builtin_amdgcn_raw_buffer_load_b128(msrc, ok ? (unsigned)((opix * p.mul_ld + p.mul_coff + ch) * 2) : HV_OOB, 0, 0);
+            yreg[k] = __builtin_amdgcn_raw_buffer_load_b128(ysrc, ok ? (unsigned)(ooff[k] * 2) : HV_OOB, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int k = PITEMS; k < OITEMS; ++k) { ooff[k] = -1; mreg[k] = yreg[k] = (u32x4){0u, 0u, 0u, 0u}; }
+#pragma unroll
+        for (int k = 0; k < PITEMS; ++k) {
+            const int it = tid + k * G::NTHR;
+            const int q = it / PIECES, pc = it - q * PIECES;
+            const int il = (i0 >> 1) + q / (TW / 2), jl = (j0 >> 1) + q % (TW / 2), ch = n_base + pc * 8;
+            const bool ok = q < PPIX && il < p.Ho && jl < p.Wo && ch < p.Cout;
+            const long long opix = (long long)(n_img * p.Ho + il) * p.Wo + jl;
+            ooff[k] = ok ? opix * p.y_ld + p.y_coff + ch : -1;
+            mreg[k] = __builtin_amdgcn_raw_buffer_load_b128(msrc, ok ? (unsigned)((opix * p.mul_ld + p.mul_coff + ch) * 2) : HV_OOB, 0, 0);
+            yreg[k] = __builtin_amdgcn_raw_buffer_load_b128(ysrc, ok ? (unsigned)(ooff[k] * 2) : HV_OOB, 0, 0);
+        }
     }
     __syncthreads();          // every wave is done with the patch: its room becomes the output staging tile
 
@@ -216,11 +236,40 @@ __global__ __launch_bounds__(512, WPS) void conv_lf_kernel(const HaloK p) {
     LF_STAMP(4);
     _Float16* yb = reinterpret_cast<_Float16*>(p.y);
     u32x4 o[OITEMS];
+    if (!pooled) {
 #pragma unroll
-    for (int k = 0; k < OITEMS; ++k) {
-        const int it = tid + k * G::NTHR;
-        const int q = it / PIECES, pc = it - q * PIECES;
-        o[k] = *reinterpret_cast<const u32x4*>(ot + q * LDO + pc * 8);
+        for (int k = 0; k < OITEMS; ++k) {
+            const int it = tid + k * G::NTHR;
+            const int q = it / PIECES, pc = it - q * PIECES;
+            o[k] = *reinterpret_cast<const u32x4*>(ot + q * LDO + pc * 8);
+        }
+    } else {
+#pragma unroll
+        for (int k = PITEMS; k < OITEMS; ++k) o[k] = (u32x4){0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int k = 0; k < PITEMS; ++k) {
+            const int it = tid + k * G::NTHR;
+            const int q = it / PIECES, pc = it - q * PIECES;
+            const int r2 = 2 * (q / (TW / 2)), c2 = 2 * (q % (TW / 2));
+            float sum[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum[e] = 0.f;
+            if (q < PPIX) {
+#pragma unroll
+                for (int dd = 0; dd < 4; ++dd) {
+                    const int rr = r2 + (dd >> 1), cc = c2 + (dd & 1);
+                    if (i0 + rr < C.Hc && j0 + cc < C.Wc) {      // tile pixels beyond the convolution's grid are not part of the sum
+                        const f16x8 v8 = *reinterpret_cast<const f16x8*>(ot + (rr * TW + cc) * LDO + pc * 8);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) sum[e] += (float)v8[e];
+                    }
+                }
+            }
+            f16x8 h8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) h8[e] = (_Float16)sum[e];
+            o[k] = __builtin_bit_cast(u32x4, h8);
+        }
     }
     if (p.mul_src) {        // v * act'(m), m = the producer's fp16 output at the same pixel / channels (scalar switch around the tile, branch-free bodies)
         auto mulf = [&](auto gradf) __attribute__((always_inline)) {

@@ -3,6 +3,8 @@
 // fp64 (per-thread partials -> per-block -> finalize) so var = E[x^2]-E[x]^2 is safe.
 #include <stdlib.h>
 
+#include <string.h>
+
 #include "hv_common.h"
 
 static bool n_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
@@ -278,6 +280,8 @@ extern "C" int hv_norm_act_forward(const hv_norm_desc* d, void* stream) {
     HV_LAUNCH_CHECK();
     const long long n = (long long)pl.R * (vec ? d->C / 4 : d->C);
     const dim3 agrid(apply_grid(n, pl.G), pl.G);
+    static const int skip_apply = getenv("HV_DIAG_SKIP") && strstr(getenv("HV_DIAG_SKIP"), "norm_apply") ? 1 : 0;     // timing-only diagnostic (wrong results)
+    if (skip_apply) return HV_OK;
     if (d->f16) {
         if (vec) hipLaunchKernelGGL((norm_apply_kernel<true, true>), agrid, dim3(256), 0, s, k);
         else hipLaunchKernelGGL((norm_apply_kernel<false, true>), agrid, dim3(256), 0, s, k);
@@ -417,6 +421,8 @@ extern "C" int hv_norm_act_backward(const hv_norm_bwd_desc* d, void* stream) {
     const int batch_stats = (d->norm == HV_NORM_INSTANCE || d->training) ? 1 : 0;
     const long long n = (long long)pl.R * (vec ? d->C / 4 : d->C);
     const dim3 agrid(apply_grid(n, pl.G), pl.G);
+    static const int skip_bapply = getenv("HV_DIAG_SKIP") && strstr(getenv("HV_DIAG_SKIP"), "norm_bwd") ? 1 : 0;     // timing-only diagnostic (wrong results)
+    if (skip_bapply) return HV_OK;
     if (d->f16) {
         if (vec) hipLaunchKernelGGL((norm_bwd_apply_kernel<true, true>), agrid, dim3(256), 0, s, k, ab, batch_stats);
         else hipLaunchKernelGGL((norm_bwd_apply_kernel<false, true>), agrid, dim3(256), 0, s, k, ab, batch_stats);

@@ -157,13 +157,15 @@ extern "C" int hv_gap_fc_sigmoid(const void* x, int x_f16, int B, int HW, int C,
     return HV_OK;
 }
 __global__ void gap_bwd_dx_kernel(const float* __restrict__ dpred, const float* __restrict__ pred, const float* __restrict__ w, void* __restrict__ dx, int dxh,
-                                  int HW, int C, int dx_ld, long long n) {
+                                  int HW, int C, int dx_ld, long long n, const void* __restrict__ mul, int mulh, int mul_ld, int mul_act) {
     PW_LOOP(i, n) {
         const int c = (int)(i % C);
         const long long bp = i / C;
         const long long b = bp / HW;
         const float p = pred[b];
-        hv_st1(dx, bp * dx_ld + c, hv_ld1(dx, bp * dx_ld + c, dxh) + dpred[b] * p * (1.f - p) * w[c] / (float)HW, dxh);
+        float g = dpred[b] * p * (1.f - p) * w[c] / (float)HW;
+        if (mul) g *= hv_act_grad_from_out(hv_ld1(mul, bp * mul_ld + c, mulh), mul_act);      // dx holds PRE-activation gradients (its other writers applied act' too)
+        hv_st1(dx, bp * dx_ld + c, hv_ld1(dx, bp * dx_ld + c, dxh) + g, dxh);
     }
 }
 __global__ void gap_bwd_param_kernel(const float* __restrict__ dpred, const float* __restrict__ pred, const float* __restrict__ pooled, int B, int C,
@@ -179,10 +181,13 @@ __global__ void gap_bwd_param_kernel(const float* __restrict__ dpred, const floa
     if (c == 0) db[0] = acc ? db[0] + sb : sb;
 }
 extern "C" int hv_gap_fc_sigmoid_backward(const float* dpred, const float* pred, const float* pooled, const float* fc_w, void* dx, int dx_f16, int B,
-                                          int HW, int C, int dx_ld, float* dw, float* db, int accumulate, void* stream) {
+                                          int HW, int C, int dx_ld, float* dw, float* db, int accumulate, const void* mul_src, int mul_f16, int mul_ld,
+                                          int mul_act, void* stream) {
     if (!dpred || !pred || !pooled || !fc_w || !dx || !dw || !db || B <= 0 || HW <= 0 || C <= 0 || C > 1024) return HV_ERR_ARG;
+    if (mul_src && (mul_ld < C || mul_act < HV_ACT_NONE || mul_act > HV_ACT_CLAMP)) return HV_ERR_ARG;
     const long long n = (long long)B * HW * C;
-    hipLaunchKernelGGL(gap_bwd_dx_kernel, dim3(pw_grid(n)), dim3(256), 0, (hipStream_t)stream, dpred, pred, fc_w, dx, dx_f16, HW, C, dx_ld, n);
+    hipLaunchKernelGGL(gap_bwd_dx_kernel, dim3(pw_grid(n)), dim3(256), 0, (hipStream_t)stream, dpred, pred, fc_w, dx, dx_f16, HW, C, dx_ld, n, mul_src, mul_f16, mul_ld,
+                       mul_act);
     HV_LAUNCH_CHECK();
     hipLaunchKernelGGL(gap_bwd_param_kernel, dim3(1), dim3(C < 64 ? 64 : C), 0, (hipStream_t)stream, dpred, pred, pooled, B, C, dw, db, accumulate);
     HV_LAUNCH_CHECK();

@@ -150,7 +150,7 @@ class ParamSet:
 
 class ConvNode:
     """conv (+bias +activation) between two NHWC views; knows how to run forward and backward."""
-    __slots__ = ('p', 'x', 'y', 'k', 's', 'pad', 'd', 'act', 'shift', 'need_dx', 'transposed', 'use_bias', 'dx_c')
+    __slots__ = ('p', 'x', 'y', 'k', 's', 'pad', 'd', 'act', 'shift', 'need_dx', 'transposed', 'use_bias', 'dx_c', 'pool_to')
 
     def __init__(self, p, x, y, s=1, pad=0, d=1, act='none', shift=0, need_dx=True, transposed=False, use_bias=True, dx_c=None):
         self.p, self.x, self.y, self.k, self.s, self.pad, self.d = p, x, y, p.k, s, pad, d
@@ -158,6 +158,9 @@ class ConvNode:
         # dx_c: only the first dx_c input channels' gradient is wanted (a concat input whose tail channels are network inputs): the data
         # gradient is then a convolution with fewer output channels (the first dx_c rows of the transposed filter table)
         self.dx_c = dx_c
+        # pool_to = (Act low, activation of low's producer): x is a concat buffer whose first dx_c channels are the nearest x2 up-sampling of `low`;
+        # set by the owner of the plan when the pooled data gradient can serve it (conv_backward)
+        self.pool_to = None
 
     def forward(self, prec, stats=None):
         p = self.p
@@ -282,8 +285,22 @@ def conv_backward(node, book, prec, dbias_accumulate=False, wgrad_accumulate=Fal
     elif node.need_dx:
         gx = book.twin(node.x)
         gx = Act(gx.t, node.dx_c or p.cin_fwd, gx.coff)
-        if node.shift:
-            full = tmp_full
+        if node.pool_to is not None:
+            # node.x is a concat buffer whose first channels are the nearest x2 up-sampling of pool_to[0]: that part of the data gradient is written
+            # 2x2-pooled straight into the small tensor's gradient, times act' of the small tensor (the caller runs its producer premultiplied)
+            low, low_act = node.pool_to
+            gl = book.twin(low)
+            gl = Act(gl.t, node.dx_c or low.C, gl.coff)
+            ops.conv2d(gfull, p.w_bwd, gl, node.k, node.s, node.pad, node.d, transposed=True, pool2=True, accumulate=int(book.mark(gl)), precision=prec,
+                       w_h=p.w_bwd_h, w_t=p.w_bwd_t, mul=(Act(low.t, gl.C, low.coff), low_act) if low_act != 'none' else None)
+        elif node.shift and _pool2_node_ok(node, gfull, gx, prec):
+            # fused up-sampling in the forward: the data gradient leaves 2x2 sum-pooled from the conv's own epilogue (no full-resolution gradient in
+            # memory, no hv_copy_channels mode 3 pass), times act'(node.x) when the chain asks for it
+            ops.conv2d(gfull, p.w_bwd, gx, node.k, node.s, node.pad, node.d, transposed=True, pool2=True, accumulate=int(book.mark(gx)), precision=prec,
+                       w_h=p.w_bwd_h, w_t=p.w_bwd_t, mul=(Act(node.x.t, p.cin_fwd, node.x.coff), mul_x) if mul_x else None)
+        elif node.shift:
+            assert not mul_x
+            full = tmp_full() if callable(tmp_full) else tmp_full      # (the full-resolution buffer is only built where this fallback runs)
             ops.conv2d(gfull, p.w_bwd, full, node.k, node.s, node.pad, node.d, transposed=True, precision=prec, w_h=p.w_bwd_h, w_t=p.w_bwd_t)
             ops.copy_channels(full, gx, mode=3, accumulate=book.mark(gx))
         else:
@@ -315,9 +332,22 @@ def branch_stream():
 FUSE_ACT = os.environ.get('HV_FUSE_ACT', '1') != '0'   # act' of the producer layer applied in the consumer's data-gradient epilogue
 
 
-def chain_link(n, nxt):
-    """True when n's data gradient can carry act' of nxt (the producer of n.x): see conv_backward_chain."""
-    return bool(FUSE_ACT and nxt is not None and n.need_dx and not n.transposed and not n.shift and nxt.act != 'none'
+def _pool2_node_ok(node, gfull, gx, prec):
+    p = node.p
+    return ops.pool2_ok(gfull, gx, node.k, node.s, node.pad, node.d, prec, p.w_bwd_h, p.w_bwd_t)
+
+
+def chain_link(n, nxt, prec=None):
+    """True when n's data gradient can carry act' of nxt (the producer of n.x): see conv_backward_chain.  A node with fused up-sampling links when
+    its data gradient can leave pooled (conv_backward)."""
+    if n.shift and nxt is not None and n.need_dx and not n.transposed:
+        p = n.p
+        gy = Act(n.y.t, p.coutP, n.y.coff)
+        if prec is None or not _pool2_node_ok(n, gy, Act(n.x.t, p.cin_fwd, n.x.coff), prec):
+            return False
+    elif n.shift:
+        return False
+    return bool(FUSE_ACT and nxt is not None and n.need_dx and not n.transposed and nxt.act != 'none'
                 and n.x.t is nxt.y.t and n.x.coff == nxt.y.coff and n.p.cin_fwd <= nxt.y.t.shape[-1] - nxt.y.coff)
 
 
@@ -331,7 +361,7 @@ def conv_backward_chain(nodes, book, prec, tmp_full=None, premultiplied_first=Fa
     pre = premultiplied_first and FUSE_ACT     # every writer of nodes[0]'s output gradient already applied its act'
     for i, n in enumerate(nodes):
         nxt = nodes[i + 1] if i + 1 < len(nodes) else stop_before
-        link = chain_link(n, nxt)
+        link = chain_link(n, nxt, prec)
         conv_backward(n, book, prec, premultiplied=pre, mul_x=nxt.act if link else None, tmp_full=(tmp_full or {}).get(id(n)))
         pre = link
 

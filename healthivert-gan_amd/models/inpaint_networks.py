@@ -459,13 +459,15 @@ class Generator(nn.Module):
         ops.copy_channels(Act(d_x_stage1.view(B, H, W, 1)), Act(d_xs1_total.view(B, H, W, 1)), mode=0)
         ops.copy_channels(gcat17.slice(c // 2, 1), Act(d_xs1_total.view(B, H, W, 1)), mode=0, accumulate=True)
         # pure links (single producer, single consumer): the consumer's data gradient applies the producer's act'
-        E.conv_backward_chain([M[6], M[5]], book, prec, tmp_full={id(M[5]): self._tmp_up(P, M[5])})
-        E.conv_backward_chain([M[4], M[3]], book, prec, tmp_full={id(M[3]): self._tmp_up(P, M[3])})
-        E.conv_backward_chain([M[2], M[1]], book, prec)        # a11 (input of M[1]) also feeds the height head: not fused
+        # (M[5] and M[3] read their input up-sampled: they link too where their data gradient can leave pooled, otherwise the chain breaks there)
+        E.conv_backward_chain([M[6], M[5], M[4], M[3], M[2], M[1]], book, prec, stop_before=M[0],
+                              tmp_full={id(M[5]): lambda: self._tmp_up(P, M[5]), id(M[3]): lambda: self._tmp_up(P, M[3])})
+        # a11 (allconv11's output, input of M[1]) also feeds the height head: both writers of its gradient apply elu'(a11)
+        pre11 = E.chain_link(M[1], M[0], prec)
         ops.gap_fc_sigmoid_backward(d_pred2, P.pred2, P.f_pool, fg.fc_height.weight, book.twin(a['a11']),
-                                    fg.fc_height.weight.grad, fg.fc_height.bias.grad)
+                                    fg.fc_height.weight.grad, fg.fc_height.bias.grad, mul=(a['a11'], M[0].act) if pre11 else None)
         # cat11 = [conv10_atrous | pmconv10], both ELU: allconv11's data gradient applies elu' for both producers
-        E.conv_backward(M[0], book, prec, mul_x='elu' if E.FUSE_ACT else None)
+        E.conv_backward(M[0], book, prec, premultiplied=pre11, mul_x='elu' if E.FUSE_ACT else None)
         # the two branches run concurrently; both end in the gradient of f_in: the attention branch stops before its first conv,
         # which is run after the join (assign / accumulate order of the shared buffer stays that of the single-stream schedule)
         side = E.branch_stream()
@@ -481,7 +483,7 @@ class Generator(nn.Module):
         E.conv_backward_chain(list(reversed(P.f_nodes_conv)), book, prec, premultiplied_first=True)
         if side is not None:
             main.wait_stream(side)
-            E.conv_backward(pm_rev[-1], book, prec, premultiplied=E.chain_link(pm_rev[-2], pm_rev[-1]))
+            E.conv_backward(pm_rev[-1], book, prec, premultiplied=E.chain_link(pm_rev[-2], pm_rev[-1], prec))
         # coarse_seg enters the fine generator as channel 1 of its input
         d_cs_total = P.__dict__.setdefault('d_cs_total', torch.zeros_like(P.coarse_seg))
         ops.copy_channels(Act(d_coarse_seg.view(B, H, W, 1)), Act(d_cs_total.view(B, H, W, 1)), mode=0)
@@ -491,16 +493,29 @@ class Generator(nn.Module):
         # both heads read c16 (output of conv16, ELU): each applies elu'(c16) to its share of the gradient
         self._head_backward(P, C[18], d_xs1_total, 'c17', prec, book, mul_x='elu')
         self._head_backward(P, C[19], d_cs_total, 'c18', prec, book, mul_x='elu')
+        # conv19 / conv20 read [up-sampled c14 / c12 | CAM]: where the pooled data gradient serves the shape (fp16 mode) the gradient of the small tensor
+        # comes 2x2-pooled and times elu' straight from the conv's epilogue; otherwise full-resolution gradient + adjoint-of-up-sampling pass
+        def pooled(node, low):
+            pn = node.p
+            g = E.Act(book.twin(node.y).t, pn.coutP, node.y.coff)
+            ok = E.FUSE_ACT and ops.pool2_ok(g, E.Act(book.twin(low).t, node.dx_c, low.coff), node.k, node.s, node.pad, node.d, prec, pn.w_bwd_h, pn.w_bwd_t)
+            node.pool_to = (low, 'elu') if ok else None
+            return ok
+        p19 = pooled(C[15], a['c14'])
         E.conv_backward_chain([C[17], C[16], C[15]], book, prec, premultiplied_first=True)
-        g14 = book.twin(a['c14'])
-        ops.copy_channels(book.twin(a['cat19']).slice(0, 2 * c), g14, mode=3, accumulate=book.mark(g14))
-        E.conv_backward_chain([C[14], C[13], C[12]], book, prec)
-        g12 = book.twin(a['c12'])
-        ops.copy_channels(book.twin(a['cat20']).slice(0, 4 * c), g12, mode=3, accumulate=book.mark(g12))
-        E.conv_backward_chain([C[11], C[10]], book, prec)
+        if not p19:
+            g14 = book.twin(a['c14'])
+            ops.copy_channels(book.twin(a['cat19']).slice(0, 2 * c), g14, mode=3, accumulate=book.mark(g14))
+        p20 = pooled(C[12], a['c12'])
+        E.conv_backward_chain([C[14], C[13], C[12]], book, prec, premultiplied_first=p19)
+        if not p20:
+            g12 = book.twin(a['c12'])
+            ops.copy_channels(book.twin(a['cat20']).slice(0, 4 * c), g12, mode=3, accumulate=book.mark(g12))
+        E.conv_backward_chain([C[11], C[10]], book, prec, premultiplied_first=p20, stop_before=C[9])
+        pre10 = E.chain_link(C[10], C[9], prec)      # c10 feeds conv11 and the height head: both apply elu'(c10)
         ops.gap_fc_sigmoid_backward(d_pred1, P.pred1, P.c_pool, cg.fc_height.weight, book.twin(a['c10']),
-                                    cg.fc_height.weight.grad, cg.fc_height.bias.grad)
-        E.conv_backward_chain(list(reversed(C[:10])), book, prec)
+                                    cg.fc_height.weight.grad, cg.fc_height.bias.grad, mul=(a['c10'], C[9].act) if pre10 else None)
+        E.conv_backward_chain(list(reversed(C[:10])), book, prec, premultiplied_first=pre10)
         book.join()     # side-stream weight gradients
         self.paramset().finish_backward(accumulate=False)
         self.paramset().attach_grads()

@@ -162,11 +162,13 @@ def conv_out_size(n, k, stride, pad, dil):
 
 def conv2d(x, w, y, k, stride=1, pad=0, dil=1, bias=None, act='none', transposed=False, in_shift=0, alpha=1.0,
            accumulate=0, ch_scale=None, w_bstride=0, ch_scale_bstride=0, precision=None, cin=None, cout=None, w_h=None, mul=None, w_t=None,
-           stats=None, _parts_only=False):
+           stats=None, _parts_only=False, pool2=False):
     """y = act(alpha*ch_scale*conv(x, w) + bias)  [* act'(m) with mul = (Act m, activation name): see hv_conv_desc.mul_src].  x,y: Act; w: prepared [CoutF][k*k][CinP] tensor (or [B][...] with
     w_bstride).  cin/cout default to the view widths (x.C consumed, y.C produced).
     stats: float tensor of conv2d_stats_parts(...) * Cout * 2 elements that receives the per-channel partial sums of the stored output
-    (hv_conv_desc.stats; feeds norm_act_forward(partials=...))."""
+    (hv_conv_desc.stats; feeds norm_act_forward(partials=...)).
+    pool2: y (and mul's tensor) hold the 2x2 sum-pooled output, i.e. half the convolution's own output size (hv_conv_desc.pool2; raises
+    RuntimeError 'unsupported' unless the filters-in-LDS kernel serves the shape: pool2_ok())."""
     L = _lib.get()
     d = L.hv_conv_desc()
     kh, kw = (k, k) if isinstance(k, int) else k
@@ -181,7 +183,8 @@ def conv2d(x, w, y, k, stride=1, pad=0, dil=1, bias=None, act='none', transposed
     d.ch_scale_bstride = ch_scale_bstride
     d.alpha, d.act, d.accumulate = alpha, ACT[act], int(accumulate)
     d.y = ptr(y.t).value
-    d.Ho, d.Wo, d.y_ld, d.y_coff = y.H, y.W, y.ld, y.coff
+    d.Ho, d.Wo, d.y_ld, d.y_coff = (y.H << 1 if pool2 else y.H), (y.W << 1 if pool2 else y.W), y.ld, y.coff
+    d.pool2 = int(bool(pool2))
     d.precision = precision_id(precision)
     d.w_f16 = None if w_h is None else ptr(w_h).value
     d.w_f16_tiled = None if (w_t is None or w_h is None) else ptr(w_t).value      # w_h in MFMA-fragment order (tile_weights / hv_weight_prep)
@@ -210,6 +213,17 @@ def conv2d(x, w, y, k, stride=1, pad=0, dil=1, bias=None, act='none', transposed
         return y
     L.call('hv_conv2d', ctypes.byref(d), stream())
     return y
+
+
+POOL2 = os.environ.get('HV_POOL2', '1') != '0'      # A/B knob: data gradients of up-sampled inputs written pooled by the conv itself
+
+
+def pool2_ok(g, y_low, k, stride, pad, dil, precision, w_h, w_t, cout=None):
+    """Can conv2d(..., transposed=True, pool2=True) serve this data gradient?  (mirror of the checks in conv2d_dispatch / hv_convlf_launch)"""
+    co = y_low.C if cout is None else cout
+    return bool(POOL2 and precision_id(precision) == F16 and w_h is not None and w_t is not None and k == 3 and stride == 1 and pad == 1 and dil == 1
+                and g.f16 and y_low.f16 and g.C in (16, 32, 64) and g.ld % 8 == 0 and g.coff % 8 == 0 and co % 8 == 0 and y_low.ld % 8 == 0
+                and y_low.coff % 8 == 0 and g.H == 2 * y_low.H and g.W == 2 * y_low.W and not (g.C == 16 and co > 32))
 
 
 def conv2d_stats_parts(*args, **kw):
@@ -309,8 +323,13 @@ def weight_prep_backward(table, max_numel, any_sn):
 
 
 # ------------------------------------------------------------------------------------------------ pointwise
+_DIAG_SKIP = os.environ.get('HV_DIAG_SKIP', '')      # timing-only diagnostics (tools/marginal_step.sh): the named passes are not launched, results are wrong
+
+
 def act_backward(dy, y, act, dbias=None, dbias_accumulate=False):
     """In place: dy *= act'(y); dbias (+)= column sums."""
+    if 'act_bwd' in _DIAG_SKIP:
+        return
     L = _lib.get()
     need = L.size('hv_act_backward_workspace_bytes', ctypes.c_longlong(dy.npix), dy.C) if dbias is not None else 0
     b, nb = _ws(need, dy.t.device)
@@ -320,6 +339,8 @@ def act_backward(dy, y, act, dbias=None, dbias_accumulate=False):
 
 def copy_channels(src, dst, mode=0, accumulate=False):
     """dst (+)= resample(src); H,W of dst rule (mode: 0 same, 1 up x2, 2 down x1/2, 3 adjoint of 1, 4 adjoint of 2)."""
+    if 'copy_channels' in _DIAG_SKIP:
+        return
     assert src.C == dst.C
     _lib.get().call('hv_copy_channels', ptr(src.t), src.f16, ptr(dst.t), dst.f16, dst.B, dst.H, dst.W, dst.C, src.ld, src.coff, dst.ld, dst.coff,
                     mode, int(accumulate), stream())
@@ -345,9 +366,12 @@ def gap_fc_sigmoid(x, fc_w, fc_b, pooled, pred):
     L.call('hv_gap_fc_sigmoid', ptr(x.t), x.f16, x.B, x.H * x.W, x.C, x.ld, ptr(fc_w), ptr(fc_b), ptr(pooled), ptr(pred), ptr(b), nb, stream())
 
 
-def gap_fc_sigmoid_backward(dpred, pred, pooled, fc_w, dx, dw, db, accumulate=False):
+def gap_fc_sigmoid_backward(dpred, pred, pooled, fc_w, dx, dw, db, accumulate=False, mul=None):
+    """mul = (Act m, activation name): the contribution to dx is multiplied by act'(m) (dx holds pre-activation gradients, see conv2d's mul)."""
+    m, mact = mul if mul is not None else (None, 'none')
     _lib.get().call('hv_gap_fc_sigmoid_backward', ptr(dpred), ptr(pred), ptr(pooled), ptr(fc_w), ptr(dx.t), dx.f16, dx.B, dx.H * dx.W, dx.C,
-                    dx.ld, ptr(dw), ptr(db), int(accumulate), stream())
+                    dx.ld, ptr(dw), ptr(db), int(accumulate), None if m is None else ptr(m.t), 0 if m is None else m.f16, 0 if m is None else m.ld,
+                    ACT[mact], stream())
 
 
 def sobel(img, out=None):

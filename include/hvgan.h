@@ -99,6 +99,11 @@ typedef struct {
                                          epilogue: stats[(part * Cout + c) * 2 + {0: sum, 1: sum of squares}] for part < hv_conv2d_stats_parts(d).
                                          Feeds hv_norm_desc.partials (BatchNorm statistics without a reduction pass over the tensor).  Only the
                                          kernels that hv_conv2d_stats_parts reports (> 0) write it; NULL = not wanted */
+    int pool2;                        /* 1: the output is stored 2x2 sum-pooled -- y, mul_src (and the accumulate operand) are (Ho/2) x (Wo/2) tensors and
+                                         y[n][i][j][c] (+)= act'(mul_src[n][i][j][c]) * sum of the four fp16-rounded conv outputs at (2i + {0,1}, 2j + {0,1}):
+                                         the data gradient of a convolution whose input was the nearest x2 up-sampling of a smaller tensor, without the
+                                         full-resolution gradient in memory (replaces conv + hv_copy_channels mode 3 + the in-place act' pass).  Ho, Wo keep
+                                         the convolution's own output size (even).  Served by the filters-in-LDS 3x3 kernel only: HV_ERR_UNSUPPORTED otherwise */
 } hv_conv_desc;
 int hv_conv2d(const hv_conv_desc* d, void* stream);
 size_t hv_conv2d_workspace_bytes(const hv_conv_desc* d);   /* 0 when no kernel for this shape wants scratch */
@@ -219,10 +224,11 @@ int hv_gen_input(const float* x, const float* seg, const float* mask, const doub
 size_t hv_gap_fc_workspace_bytes(int B, int C);
 int hv_gap_fc_sigmoid(const void* x, int x_f16, int B, int HW, int C, int x_ld, const float* fc_w, const float* fc_b,
                       float* pooled /*[B][C]*/, float* pred /*[B]*/, float* workspace, size_t workspace_bytes, void* stream);
-/* backward: dx[n,p,c] += dpred[n]*pred(1-pred)*w[c]/HW ; dw[c] (+)= sum_n dl_n*pooled[n,c]; db (+)= sum_n dl_n */
+/* backward: dx[n,p,c] += dpred[n]*pred(1-pred)*w[c]/HW [* act'(mul_src[n,p,c]) when mul_src: dx then holds the gradient wrt the PRE-activation of the
+ * pooled tensor, like hv_conv_desc.mul_src]; dw[c] (+)= sum_n dl_n*pooled[n,c]; db (+)= sum_n dl_n */
 int hv_gap_fc_sigmoid_backward(const float* dpred, const float* pred, const float* pooled, const float* fc_w,
                                void* dx, int dx_f16, int B, int HW, int C, int dx_ld, float* dw, float* db, int accumulate,
-                               void* stream);
+                               const void* mul_src, int mul_f16, int mul_ld, int mul_act, void* stream);
 
 /* ---------------------------------------------------------------- contextual attention pieces
  * (models/inpaint_networks.py:247-410).  The two big contractions (patch matching :348, patch pasting :379) and

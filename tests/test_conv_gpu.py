@@ -377,6 +377,44 @@ def test_conv_single_output_channel_data_gradient(case, prec, tol):
     assert maxerr(from_act(dxa), ref + x.grad) <= 2 * tol * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize('case', [(2, 32, 32, 32, 32, 'elu'), (2, 16, 48, 64, 64, 'elu'), (3, 24, 16, 16, 32, 'none'), (2, 32, 32, 64, 32, 'relu'), (2, 16, 16, 32, 64, 'elu')])
+def test_conv_data_gradient_of_upsampled_input_leaves_pooled(case):
+    """hv_conv_desc.pool2: the data gradient of a 3x3 conv whose input was the nearest x2 up-sampling of a smaller tensor, written 2x2 sum-pooled
+    by the conv's own epilogue, times act' of the small tensor, assigned and accumulated -- against torch autograd through
+    F.interpolate(nearest) + conv2d on the CPU."""
+    from hvtest import to_act, from_act, ohwi_T, dev, maxerr
+    from hvgan import ops, lib
+    B, h, w_, Cin, Cout, act = case          # the small tensor is B x Cin x h x w_; the conv runs at 2h x 2w_ and has Cout output channels
+    g = torch.Generator().manual_seed(3 + Cin + Cout)
+    pre = torch.randn(B, Cin, h, w_, generator=g)
+    pre.requires_grad_(True)
+    fn = {'elu': F.elu, 'relu': F.relu, 'none': lambda t: t}[act]
+    low = fn(pre)
+    wt = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).half().float()
+    y = F.conv2d(F.interpolate(low, scale_factor=2, mode='nearest'), wt, None, stride=1, padding=1)
+    gy = torch.randn(y.shape, generator=g).half().float()
+    y.backward(gy)
+    want = pre.grad                                               # d/d(pre-activation of the small tensor)
+    wb = ohwi_T(wt)                                               # [Cin][9][Cout]: the data-gradient table
+    wh = wb.half()
+    wtl = ops.tile_weights(wh, Cin, 9, Cout)
+    ga = to_act(gy, dtype=torch.float16)
+    la = to_act(low.detach(), dtype=torch.float16)
+    dxa = ops.Act.empty(B, h, w_, Cin, dev(), dtype=torch.float16)
+    assert ops.pool2_ok(ga, dxa, 3, 1, 1, 1, 'fp16', wh, wtl)
+    ops.conv2d(ga, wb, dxa, 3, 1, 1, 1, transposed=True, precision='fp16', w_h=wh, w_t=wtl, pool2=True, mul=(la, act) if act != 'none' else None)
+    assert lib.get().size('hv_last_kernel_path') == 7
+    torch.cuda.synchronize()
+    scale = max(1.0, want.abs().max().item())
+    assert maxerr(from_act(dxa), want) <= 4e-3 * scale
+    ops.conv2d(ga, wb, dxa, 3, 1, 1, 1, transposed=True, precision='fp16', w_h=wh, w_t=wtl, pool2=True, accumulate=1, mul=(la, act) if act != 'none' else None)
+    torch.cuda.synchronize()
+    assert maxerr(from_act(dxa), 2 * want) <= 8e-3 * scale
+    # a shape the pooled kernel does not serve is refused, not silently computed at full size
+    with pytest.raises(RuntimeError):
+        ops.conv2d(ga, wb, dxa, 3, 1, 1, 1, transposed=True, precision='fp32', pool2=True)
+
+
 @pytest.mark.parametrize('case', [(2, 7, 7, 32, 1), (2, 18, 21, 64, 3), (3, 31, 31, 512, 1), (2, 33, 17, 256, 4)])
 def test_conv_logits_data_gradient_taps_as_mfma_contraction(case):
     """logits_dgrad_kernel: data gradient of a 4x4 / stride 1 / pad 1 conv with <= 4 output channels (gradient stored with a channel stride
