@@ -118,8 +118,9 @@ extern "C" int hv_weight_tile_f16(const void* w_f16, void* w_tiled, int rows, in
 // read coalesced into LDS and written out tap-major.  (Indexing the threads by the destination and gathering the source -- the first version --
 // read 36 .. 64-byte-strided floats: every XCD's L2 fetched the same lines again, 178 MB of fabric reads per launch for 16 MB of weights.)
 // conv_transpose sources (transposed_src) have no such contiguity and keep the gather.
-__global__ __launch_bounds__(256) void weight_layout_fwd_kernel(const hv_wprep_layer* __restrict__ layers) {
+__global__ __launch_bounds__(256) void weight_layout_fwd_kernel(const hv_wprep_layer* __restrict__ layers, int only_legacy) {
     const hv_wprep_layer L = layers[blockIdx.y];
+    if (only_legacy && !(L.transposed_src || L.taps > 16)) return;      // (taken by weight_layout_fused_kernel)
     __shared__ float sh[4096 + 256];
     const int taps = L.taps, ldt = taps + 1;                                    // LDS rows [ci][taps + 1]: the tap-major read-out is conflict-free
     int CC = 256;
@@ -153,9 +154,9 @@ __global__ __launch_bounds__(256) void weight_layout_fwd_kernel(const hv_wprep_l
 
 // Data-gradient tables: w_bwd[ci][tap][co] = w_fwd[co][tap][ci], a 32 x 32 LDS tile transpose per tap (both sides 128-byte rows); runs after the
 // forward tables of the same call (stream order).
-__global__ __launch_bounds__(256) void weight_layout_bwd_kernel(const hv_wprep_layer* __restrict__ layers) {
+__global__ __launch_bounds__(256) void weight_layout_bwd_kernel(const hv_wprep_layer* __restrict__ layers, int only_legacy) {
     const hv_wprep_layer L = layers[blockIdx.y];
-    if (!L.w_bwd) return;
+    if (!L.w_bwd || (only_legacy && !(L.transposed_src || L.taps > 16))) return;
     __shared__ float sh[32][33];
     const int taps = L.taps, tco = (L.CoutP + 31) / 32, tci = (L.CinB + 31) / 32;
     const long long work = (long long)taps * tco * tci;
@@ -191,12 +192,140 @@ extern "C" int hv_weight_prep(const hv_wprep_layer* d_layers, int n_layers, long
     HV_LAUNCH_CHECK();
     // grid-stride over the layers' work items (the host knows only the largest table, not every layer's shape)
     const int gx = hv_cdiv(max_numel, 2048) < 1 ? 1 : hv_cdiv(max_numel, 2048);
-    hipLaunchKernelGGL(weight_layout_fwd_kernel, dim3(gx, n_layers), dim3(256), 0, (hipStream_t)stream, d_layers);
+    hipLaunchKernelGGL(weight_layout_fwd_kernel, dim3(gx, n_layers), dim3(256), 0, (hipStream_t)stream, d_layers, 0);
     HV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(weight_layout_bwd_kernel, dim3(gx, n_layers), dim3(256), 0, (hipStream_t)stream, d_layers);
+    hipLaunchKernelGGL(weight_layout_bwd_kernel, dim3(gx, n_layers), dim3(256), 0, (hipStream_t)stream, d_layers, 0);
     HV_LAUNCH_CHECK();
     return HV_OK;
 }
+
+// All six tables of a layer from ONE read of its weights (hv_weight_prep2).  The two kernels above cost 23 + 15 us per discriminator and sit between the Adam
+// step and the next forward, i.e. on the step's critical path four times (timing-only run without them: 8.45 -> 8.07 ms): they write element by element,
+// the fragment-ordered tables as scattered 2-byte stores, and the data-gradient pass re-reads the forward table.  Here a work item is a 32 x 32
+// (filter, input channel) tile with all its taps: the source rows (32 ci x taps contiguous floats per filter) go to LDS once, the plain tables leave as
+// 128-byte (fp32) / 64-byte (fp16) runs and a 16 x 32 MFMA fragment of either ordered table as 64 sixteen-byte pieces = 1 KB contiguous.
+// Layers it does not take (conv_transpose sources, more than 16 taps) are left to the kernels above (hv_weight_prep2's any_legacy).
+#define WL_T 32
+__global__ __launch_bounds__(256) void weight_layout_fused_kernel(const hv_wprep_layer* __restrict__ layers) {
+    const hv_wprep_layer L = layers[blockIdx.y];
+    if (L.transposed_src || L.taps > 16) return;
+    extern __shared__ __attribute__((aligned(16))) float wl_sh[];              // [32 filters][32 * ldt + 1]
+    const int taps = L.taps, ldt = taps | 1, RS = WL_T * ldt + 1;
+    const int rows_f = L.CoutF, rows_b = L.w_bwd ? L.CinB : 0;
+    const int nco = (max(L.CoutF, L.w_bwd ? L.CoutP : 0) + WL_T - 1) / WL_T, nci = (max(L.CinP, rows_b) + WL_T - 1) / WL_T;
+    const float sigma = L.sigma[0];
+    const int Tf = L.w_fwd_t ? tile_width(L.CinP) : 0, Tb = (L.w_bwd && L.w_bwd_t) ? tile_width(L.CoutP) : 0;
+    const int tid = threadIdx.x;
+    for (int w = blockIdx.x; w < nco * nci; w += gridDim.x) {
+        const int co0 = (w / nci) * WL_T, ci0 = (w % nci) * WL_T;
+        const int cs = max(0, min(WL_T, L.Cin - ci0));                        // real input channels of the tile
+        __syncthreads();
+        // (every loop below walks (row, tap) with the lane as the contiguous index: no division by the run-time tap count -- the first version, indexed
+        // by a flat element number, spent its time in integer divisions: 68 us against 23 + 15 for the two element-wise kernels)
+        const int lane = tid & 31, sub = tid >> 5;
+        // ---- source -> LDS (zeros where the tile leaves the real weight): lane = input channel, its taps are contiguous in the source
+        for (int r = sub; r < WL_T; r += 8) {
+            const int co = co0 + r;
+            const bool real = co < L.Cout && lane < cs;
+            const float* src = L.w_orig + ((long long)co * L.Cin + ci0 + lane) * taps;
+            float* dst = wl_sh + r * RS + lane * ldt;
+            for (int tap = 0; tap < taps; ++tap) dst[tap] = real ? src[tap] / sigma : 0.f;       // (the division the element-wise kernels do: same bits)
+        }
+        __syncthreads();
+        // ---- forward tables [co][tap][ci]: a warp-wide run of 32 input channels per (co, tap)
+        {
+            const int ci = ci0 + lane;
+            for (int r = sub; r < WL_T; r += 8) {
+                const int co = co0 + r;
+                if (co >= rows_f || ci >= L.CinP) continue;
+                for (int tap = 0; tap < taps; ++tap) {
+                    const float val = wl_sh[r * RS + lane * ldt + tap];
+                    const long long i = ((long long)co * taps + tap) * L.CinP + ci;
+                    L.w_fwd[i] = val;
+                    if (L.w_fwd_h) reinterpret_cast<_Float16*>(L.w_fwd_h)[i] = (_Float16)val;
+                    if (Tf == 16) reinterpret_cast<_Float16*>(L.w_fwd_t)[tiled_index(co, tap, ci, taps, L.CinP, 16)] = (_Float16)val;
+                }
+            }
+        }
+        if (Tf == 32 && ci0 < L.CinP) {       // fragment (16-row block rb, tap): [kq][row][8 channels], pieces of 16 bytes; 64 pieces = threads (rb, kq, row)
+            const int row = tid & 15, kq = (tid >> 4) & 3, half = tid >> 6;          // 4 x 64 threads: (rb, tap parity)
+            const int rb = half & 1;
+            const int cob = co0 + rb * 16;
+            if (cob < (rows_f + 15) / 16 * 16) {
+                for (int tap = half >> 1; tap < taps; tap += 2) {
+                    f16x8 h;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) h[e] = (_Float16)wl_sh[(rb * 16 + row) * RS + (kq * 8 + e) * ldt + tap];
+                    _Float16* base = reinterpret_cast<_Float16*>(L.w_fwd_t) + (long long)(cob >> 4) * 16 * taps * L.CinP + (long long)((tap * L.CinP + ci0) >> 5) * 512;
+                    *reinterpret_cast<f16x8*>(base + (kq * 16 + row) * 8) = h;
+                }
+            }
+        }
+        // ---- data-gradient tables [ci][tap][co]: a run of 32 filters per (ci, tap)
+        if (L.w_bwd) {
+            const int co = co0 + lane;
+            for (int cil = sub; cil < WL_T; cil += 8) {
+                const int ci = ci0 + cil;
+                if (ci >= rows_b || co >= L.CoutP) continue;
+                const bool in = ci < L.CinP && co < L.CoutF;                                  // (the old pass read the forward table: zero beyond it)
+                for (int tap = 0; tap < taps; ++tap) {
+                    const float val = in ? wl_sh[lane * RS + cil * ldt + tap] : 0.f;
+                    const long long i = ((long long)ci * taps + tap) * L.CoutP + co;
+                    L.w_bwd[i] = val;
+                    if (L.w_bwd_h) reinterpret_cast<_Float16*>(L.w_bwd_h)[i] = (_Float16)val;
+                    if (Tb == 16) reinterpret_cast<_Float16*>(L.w_bwd_t)[tiled_index(ci, tap, co, taps, L.CoutP, 16)] = (_Float16)val;
+                }
+            }
+            if (Tb == 32 && co0 < L.CoutP) {
+                const int row = tid & 15, kq = (tid >> 4) & 3, half = tid >> 6;
+                const int rb = half & 1;
+                const int cib = ci0 + rb * 16;
+                if (cib < (rows_b + 15) / 16 * 16) {
+                    const int cil = rb * 16 + row;
+                    const bool in = ci0 + cil < L.CinP;
+                    for (int tap = half >> 1; tap < taps; tap += 2) {
+                        f16x8 h;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) h[e] = (in && co0 + kq * 8 + e < L.CoutF) ? (_Float16)wl_sh[(kq * 8 + e) * RS + cil * ldt + tap] : (_Float16)0.f;
+                        _Float16* base = reinterpret_cast<_Float16*>(L.w_bwd_t) + (long long)(cib >> 4) * 16 * taps * L.CoutP + (long long)((tap * L.CoutP + co0) >> 5) * 512;
+                        *reinterpret_cast<f16x8*>(base + (kq * 16 + row) * 8) = h;
+                    }
+                }
+            }
+        }
+    }
+}
+
+extern "C" int hv_weight_prep2(const hv_wprep_layer* d_layers, int n_layers, long long max_numel, int any_sn, int any_legacy, void* stream) {
+    if (!d_layers || n_layers <= 0 || max_numel <= 0) return HV_ERR_ARG;
+    static const int fused = getenv("HV_WPREP_FUSED") ? atoi(getenv("HV_WPREP_FUSED")) : 1;      // A/B knob
+    if (!fused) return hv_weight_prep(d_layers, n_layers, max_numel, stream);
+    if (any_sn) {      // sigma (and the power iteration); layers without spectral norm keep the 1.0 their sigma slot was created with
+        hipLaunchKernelGGL(weight_prep_kernel, dim3(n_layers), dim3(PREP_THREADS), 0, (hipStream_t)stream, d_layers);
+        HV_LAUNCH_CHECK();
+    }
+    const size_t lds = (size_t)WL_T * (WL_T * 17 + 1) * sizeof(float);
+    static bool raised = false;
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(weight_layout_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (e != hipSuccess) return -1000 - (int)e;
+        raised = true;
+    }
+    // a 32 x 32 tile is 1024 * taps elements of one table: about one workgroup per tile of the largest layer, grid-stride for the rest
+    int gx = (int)hv_cdiv(max_numel, 2 * 1024 * 9);
+    gx = gx < 1 ? 1 : (gx > 512 ? 512 : gx);
+    hipLaunchKernelGGL(weight_layout_fused_kernel, dim3(gx, n_layers), dim3(256), lds, (hipStream_t)stream, d_layers);
+    HV_LAUNCH_CHECK();
+    if (any_legacy) {
+        const int gl = hv_cdiv(max_numel, 2048) < 1 ? 1 : hv_cdiv(max_numel, 2048);
+        hipLaunchKernelGGL(weight_layout_fwd_kernel, dim3(gl, n_layers), dim3(256), 0, (hipStream_t)stream, d_layers, 1);
+        HV_LAUNCH_CHECK();
+        hipLaunchKernelGGL(weight_layout_bwd_kernel, dim3(gl, n_layers), dim3(256), 0, (hipStream_t)stream, d_layers, 1);
+        HV_LAUNCH_CHECK();
+    }
+    return HV_OK;
+}
+
 
 // backward phase 1 (spectral-norm layers only): dot = <dWsn, Wsn> -> sigma[1]
 __global__ __launch_bounds__(PREP_THREADS) void weight_prep_bwd_dot_kernel(const hv_wprep_bwd_layer* __restrict__ layers) {

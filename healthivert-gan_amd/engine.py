@@ -87,6 +87,7 @@ class ParamSet:
             c.w_bwd = store[off:off + b]; off += b
             c.dw = store[off:off + d]; off += d
             c.sigma = store[off:off + 4]; off += 4
+            c.sigma[0] = 1.0            # (layers without spectral norm: hv_weight_prep2 skips the sigma kernel when a net has none)
         self._store = store
         # fp16 copies of the prepared weights (halo-tiled conv kernel, HV_F16 precision)
         hstore = torch.zeros(sum(c.sizes()[0] + c.sizes()[1] + 16 for c in self.convs), dtype=torch.float16, device=device)
@@ -141,7 +142,8 @@ class ParamSet:
 
     def prep(self, device, power_iter):
         self._ensure(device)
-        ops.weight_prep(self.t_prep[bool(power_iter)], max(c.sizes()[0] + c.sizes()[1] for c in self.convs))
+        ops.weight_prep(self.t_prep[bool(power_iter)], max(c.sizes()[0] + c.sizes()[1] for c in self.convs), any_sn=any(c.sn for c in self.convs),
+                        any_legacy=any(c.transposed_src or c.taps > 16 for c in self.convs))
 
     def finish_backward(self, accumulate=False):
         """Kernel-layout weight gradients -> .grad of weight_orig / weight (spectral-norm backward included)."""

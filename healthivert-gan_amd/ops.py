@@ -312,9 +312,9 @@ def tile_weights(w_h, rows, taps, K):
     return out
 
 
-def weight_prep(table, max_numel):
-    _lib.get().call('hv_weight_prep', ctypes.cast(table.ptr(), ctypes.POINTER(_lib.get().hv_wprep_layer)), table.n,
-                    ctypes.c_longlong(max_numel), stream())
+def weight_prep(table, max_numel, any_sn=True, any_legacy=True):
+    _lib.get().call('hv_weight_prep2', ctypes.cast(table.ptr(), ctypes.POINTER(_lib.get().hv_wprep_layer)), table.n,
+                    ctypes.c_longlong(max_numel), int(any_sn), int(any_legacy), stream())
 
 
 def weight_prep_backward(table, max_numel, any_sn):

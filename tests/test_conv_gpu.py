@@ -293,6 +293,44 @@ def test_weight_prep_writes_the_fragment_ordered_tables():
                 assert torch.equal(want, tiled), c.name
 
 
+@pytest.mark.parametrize('sn', [False, True])
+def test_weight_prep_fused_layout_kernel_writes_the_same_six_tables(sn):
+    """hv_weight_prep2 (one read of the weights, 32 x 32 tiles through LDS, whole fragments per store) against hv_weight_prep's element-wise kernels:
+    all six tables of every layer bit for bit -- PatchGAN shapes (1 -> 64 stem, 256 -> 512, 512 -> 1 logits), generator shapes (ragged 33-channel
+    concat input, 5 x 5 stem that stays on the element-wise path), with and without spectral norm."""
+    from hvtest import dev
+    from hvgan import ops, engine, lib
+    import ctypes
+    import torch.nn as nn
+    torch.manual_seed(7)
+    shapes = [(1, 64, 4), (64, 128, 4), (256, 512, 4), (512, 1, 4), (33, 32, 3), (64, 64, 3), (8, 1, 3), (4, 16, 5), (24, 40, 3)]
+    convs = []
+    for i, (cin, cout, k) in enumerate(shapes):
+        m = nn.Conv2d(cin, cout, k).to(dev())
+        u = torch.randn(cout, device=dev()) if sn else None
+        v = torch.randn(cin * k * k, device=dev()) if sn else None
+        convs.append(engine.ConvParams('c%d' % i, m.weight, m.bias, cin, cout, k, u=u, v=v))
+    ps = engine.ParamSet(convs)
+    ps.prep(dev(), power_iter=False)
+    torch.cuda.synchronize()
+    names = ('w_fwd', 'w_bwd', 'w_fwd_h', 'w_bwd_h', 'w_fwd_t', 'w_bwd_t')
+    got = [{n: (getattr(c, n).clone() if getattr(c, n) is not None else None) for n in names} for c in convs]
+    for c in convs:      # scribble over the tables (not the padding of the ordered ones: the element-wise kernels never write it), then the old entry point
+        for n in names[:4]:
+            getattr(c, n).fill_(7.0)
+    L = lib.get()
+    table = ps.t_prep[False]
+    L.call('hv_weight_prep', ctypes.cast(table.ptr(), ctypes.POINTER(L.hv_wprep_layer)), table.n,
+           ctypes.c_longlong(max(c.sizes()[0] + c.sizes()[1] for c in convs)), ops.stream())
+    torch.cuda.synchronize()
+    for c, g in zip(convs, got):
+        for n in names:
+            t = getattr(c, n)
+            assert (t is None) == (g[n] is None)
+            if t is not None:
+                assert torch.equal(t, g[n]), (c.name, n, (t.float() - g[n].float()).abs().max().item())
+
+
 HEAD_CASES = [   # B, H, W, Cin, k, stride, pad, transposed, act
     (16, 31, 31, 512, 4, 1, 1, 0, 'none'),     # PatchGAN logits
     (3, 17, 23, 96, 3, 1, 1, 0, 'sigmoid'),    # 9 taps, one 32-channel step per item, ragged pixel count
