@@ -14,6 +14,8 @@
 // paste moved 1.1 GB per launch for 140 MB of operands, 164 us).  Here a workgroup owns a 128 x 128 tile of C, both operand tiles go global ->
 // registers (fp32, 16 B per lane, converted) -> LDS as fp16 with 80-byte rows (a 16-lane group's 16-byte fragment reads hit every bank once), double
 // buffered with one barrier per 32-deep k-step, and all tiles of one sample run on one XCD (its L2 fetches the sample's operands once).
+// (Measured and not kept, round 3: a 64-deep k-step for fp16 x fp16 -- half the barriers, the second half-step's fragments read behind the first
+// half-step's MFMAs, 144-byte LDS rows: 57.2 -> 56.0 us.  The kernel is not barrier-bound.)
 #include <stdlib.h>
 
 #include "hv_common.h"
