@@ -9,7 +9,7 @@ static int at_grid(long long n, int cap = 16384) { long long b = (n + 255) / 256
 #define AT_LOOP(i, n) for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long long)gridDim.x * blockDim.x)
 
 // ---- downsample + 3x3 patch matrix (+ transposed copy) ------------------------------------------------
-__global__ void ca_down_kernel(const float* __restrict__ f, float* __restrict__ fd, int H, int W, int C, int f_ld, long long n) {
+__global__ void ca_down_kernel(const void* __restrict__ f, int fh, float* __restrict__ fd, int H, int W, int C, int f_ld, long long n) {
     const int h = H / 2, w = W / 2;
     AT_LOOP(i, n) {
         const int c = (int)(i % C);
@@ -17,7 +17,7 @@ __global__ void ca_down_kernel(const float* __restrict__ f, float* __restrict__ 
         const int x = (int)(r % w); r /= w;
         const int y = (int)(r % h);
         const long long b = r / h;
-        fd[i] = f[((b * H + 2 * y) * W + 2 * x) * f_ld + c];
+        fd[i] = hv_ld1(f, ((b * H + 2 * y) * W + 2 * x) * f_ld + c, fh);          // fh: the feature map is stored as fp16
     }
 }
 __global__ void ca_wp_kernel(const float* __restrict__ fd, float* __restrict__ wp, float* __restrict__ wpT, int h, int w, int C, long long n) {
@@ -69,8 +69,8 @@ extern "C" int hv_transpose_batched(const float* src, float* dst, int B, int R, 
 // layouts 4 bytes at a 4-KB stride: 81 / 93 us for 38 / 134 MB).  One workgroup = 64 patch positions x 64 channels of one tap:
 // rows are read (and the [l][tap][c] copy written) 16 bytes per lane along the channels, the [c][tap][l] copy is written along l from
 // the transposed tile.  KS x KS taps, stride ST, pad 1 (3x3 / 1 on the down-sampled map, 4x4 / 2 on the full map).
-template <int KS, int ST, typename OT = float>       // OT = _Float16: both copies written as fp16 (operands of the batched GEMMs only)
-__global__ __launch_bounds__(256) void ca_patch_tile_kernel(const float* __restrict__ src, OT* __restrict__ lt, OT* __restrict__ tl,
+template <int KS, int ST, typename OT = float, typename ST_ = float>       // OT = _Float16: both copies written as fp16 (operands of the batched GEMMs only); ST_: storage of the source map
+__global__ __launch_bounds__(256) void ca_patch_tile_kernel(const ST_* __restrict__ src, OT* __restrict__ lt, OT* __restrict__ tl,
                                                             int Hs, int Ws, int w, int L, int C, int s_ld) {
     __shared__ float tile[64][65];
     constexpr int T = KS * KS;
@@ -83,7 +83,14 @@ __global__ __launch_bounds__(256) void ca_patch_tile_kernel(const float* __restr
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (l < L && c < C) {
             const int y = ST * (l / w) + dy, x = ST * (l % w) + dx;
-            if ((unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws) v = *reinterpret_cast<const float4*>(src + ((b * Hs + y) * Ws + x) * s_ld + c);
+            if ((unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws) {
+                if constexpr (sizeof(ST_) == 2) {
+                    const f16x4 h4 = *reinterpret_cast<const f16x4*>(src + ((b * Hs + y) * Ws + x) * s_ld + c);
+                    v = make_float4((float)h4[0], (float)h4[1], (float)h4[2], (float)h4[3]);
+                } else {
+                    v = *reinterpret_cast<const float4*>(src + ((b * Hs + y) * Ws + x) * s_ld + c);
+                }
+            }
             if (lt) {
                 if constexpr (sizeof(OT) == 2) *reinterpret_cast<f16x4*>(lt + ((b * L + l) * T + tap) * C + c) = (f16x4){(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
                 else *reinterpret_cast<float4*>(lt + ((b * L + l) * T + tap) * C + c) = v;
@@ -105,13 +112,13 @@ static bool ca_tile_ok(const float* src, int C, int s_ld, const float* lt) {
     return enabled && (C & 3) == 0 && (s_ld & 3) == 0 && !((uintptr_t)src & 15) && !((uintptr_t)lt & 15);
 }
 
-extern "C" int hv_ca_patches(const float* f, int B, int H, int W, int C, int f_ld, float* fd, float* wp, float* wpT, float* norm,
+extern "C" int hv_ca_patches(const void* f, int f_f16, int B, int H, int W, int C, int f_ld, float* fd, float* wp, float* wpT, float* norm,
                              float* rnorm, void* stream) {
     if (!f || !fd || !wp || !norm || !rnorm || B <= 0 || H <= 0 || W <= 0 || C <= 0 || ((H | W) & 1) || f_ld < C) return HV_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     const int h = H / 2, w = W / 2;
     long long n = (long long)B * h * w * C;
-    hipLaunchKernelGGL(ca_down_kernel, dim3(at_grid(n)), dim3(256), 0, s, f, fd, H, W, C, f_ld, n);
+    hipLaunchKernelGGL(ca_down_kernel, dim3(at_grid(n)), dim3(256), 0, s, f, f_f16, fd, H, W, C, f_ld, n);
     HV_LAUNCH_CHECK();
     n *= 9;
     if (ca_tile_ok(fd, C, C, wp) && B <= 65535)    // wpT layout: [b][(tap, c)][l] -- as [c][tap][l] it would need c outermost: only wp here, wpT below
@@ -140,11 +147,16 @@ extern "C" int hv_ca_raw_patches(const float* f, int B, int H, int W, int C, int
 }
 
 // the same two patch tables stored as fp16 (operands of hv_bgemm_nt only; the fp32 tables feed the per-sample-filter convolutions of the fp32 mode)
-extern "C" int hv_ca_raw_patches_f16(const float* f, int B, int H, int W, int C, int f_ld, void* raw_h, void* rawT_h, void* stream) {
+extern "C" int hv_ca_raw_patches_f16(const void* f, int f_f16, int B, int H, int W, int C, int f_ld, void* raw_h, void* rawT_h, void* stream) {
     if (!f || (!raw_h && !rawT_h) || B <= 0 || H <= 0 || W <= 0 || C <= 0 || ((H | W) & 1) || f_ld < C) return HV_ERR_ARG;
-    if (!ca_tile_ok(f, C, f_ld, (const float*)raw_h) || B > 65535 || ((uintptr_t)raw_h & 7)) return HV_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((ca_patch_tile_kernel<4, 2, _Float16>), dim3(hv_cdiv((H / 2) * (W / 2), 64), 16 * hv_cdiv(C, 64), B), dim3(256), 0, (hipStream_t)stream,
-                       f, (_Float16*)raw_h, (_Float16*)rawT_h, H, W, W / 2, (H / 2) * (W / 2), C, f_ld);
+    if (!ca_tile_ok((const float*)f, C, f_ld, (const float*)raw_h) || B > 65535 || ((uintptr_t)raw_h & 7)) return HV_ERR_UNSUPPORTED;
+    const dim3 grid(hv_cdiv((H / 2) * (W / 2), 64), 16 * hv_cdiv(C, 64), B);
+    if (f_f16)
+        hipLaunchKernelGGL((ca_patch_tile_kernel<4, 2, _Float16, _Float16>), grid, dim3(256), 0, (hipStream_t)stream, (const _Float16*)f, (_Float16*)raw_h,
+                           (_Float16*)rawT_h, H, W, W / 2, (H / 2) * (W / 2), C, f_ld);
+    else
+    hipLaunchKernelGGL((ca_patch_tile_kernel<4, 2, _Float16>), grid, dim3(256), 0, (hipStream_t)stream,
+                       (const float*)f, (_Float16*)raw_h, (_Float16*)rawT_h, H, W, W / 2, (H / 2) * (W / 2), C, f_ld);
     HV_LAUNCH_CHECK();
     return HV_OK;
 }

@@ -182,7 +182,7 @@ extern "C" int hv_bgemm_nt(const void* A, int a_f16, int lda, long long strideA,
 // fold (col2im) of 4x4 stride-2 pad-1 patches: src[b][p][tap][c] (p over the (H/2) x (W/2) patch grid, tap = r*4 + s) ->
 //   dst[b][y][x][c] (+)= alpha * sum over the taps (r, s) with (y + 1 - r), (x + 1 - s) even and the patch position inside the grid
 // = F.conv_transpose2d(A, raw patches, stride 2, padding 1) after the contraction over the patches, and equally the adjoint of hv_ca_raw_patches.
-__global__ __launch_bounds__(256) void ca_fold_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int W, int C, int dst_ld, float alpha,
+__global__ __launch_bounds__(256) void ca_fold_kernel(const float* __restrict__ src, void* __restrict__ dst, int dsth, int H, int W, int C, int dst_ld, float alpha,
                                                       int accumulate, long long n) {
     const int h = H >> 1, w = W >> 1;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
@@ -204,17 +204,17 @@ __global__ __launch_bounds__(256) void ca_fold_kernel(const float* __restrict__ 
                 s += src[(((b * h + py) * w + px) * 16 + rr * 4 + ss) * C + c];
             }
         }
-        float* d = dst + ((b * H + y) * W + x) * dst_ld + c;
-        *d = accumulate ? *d + alpha * s : alpha * s;
+        const long long o = ((b * H + y) * W + x) * dst_ld + c;
+        hv_st1(dst, o, accumulate ? hv_ld1(dst, o, dsth) + alpha * s : alpha * s, dsth);      // dsth: the destination map is stored as fp16
     }
 }
 
-extern "C" int hv_ca_fold(const float* src, float* dst, int B, int H, int W, int C, int dst_ld, float alpha, int accumulate, void* stream) {
+extern "C" int hv_ca_fold(const float* src, void* dst, int dst_f16, int B, int H, int W, int C, int dst_ld, float alpha, int accumulate, void* stream) {
     if (!src || !dst || B <= 0 || H <= 0 || W <= 0 || C <= 0 || ((H | W) & 1) || dst_ld < C) return HV_ERR_ARG;
     const long long n = (long long)B * H * W * C;
     long long blocks = (n + 255) / 256;
     if (blocks > 65536) blocks = 65536;
-    hipLaunchKernelGGL(ca_fold_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst, H, W, C, dst_ld, alpha, accumulate, n);
+    hipLaunchKernelGGL(ca_fold_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst, dst_f16, H, W, C, dst_ld, alpha, accumulate, n);
     HV_LAUNCH_CHECK();
     return HV_OK;
 }

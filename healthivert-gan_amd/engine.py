@@ -369,6 +369,7 @@ def conv_backward_chain(nodes, book, prec, tmp_full=None, premultiplied_first=Fa
 
 
 # ================================================================================================ contextual attention
+CA_F16_IO = os.environ.get('HV_CA_F16_IO', '1') != '0'   # the attention block's boundary kernels read / write fp16-stored maps themselves (A/B knob)
 CA_GEMM = os.environ.get('HV_CA_GEMM', '1') != '0'     # fp16 mode: the attention block's five contractions as batched NT GEMMs (csrc/bgemm.hip)
 
 
@@ -410,15 +411,16 @@ class AttentionPlan:
         # the attention block keeps fp32 internally (its score matrices feed a x10 soft-max): fp16-stored feature maps are converted
         # at its boundary (two small copies of the 64-channel map)
         out_user = None
-        if f.f16:
+        gemm = CA_GEMM and ops.precision_id(prec) == ops.F16 and (9 * C) % 32 == 0 and L % 32 == 0 and C % 4 == 0
+        self.gemm = gemm
+        # (the GEMM route's boundary kernels read / write fp16-stored maps themselves: same values, no conversion copies)
+        if f.f16 and not (gemm and CA_F16_IO):
             self.f32 = getattr(self, 'f32', None) or Act(torch.zeros(B, H, W, C, dtype=torch.float32, device=f.t.device))
             ops.copy_channels(f, self.f32, mode=0)
             f = self.f32
-        if out.f16:
+        if out.f16 and not (gemm and CA_F16_IO):
             self.out32 = getattr(self, 'out32', None) or Act(torch.zeros(B, H, W, C, dtype=torch.float32, device=f.t.device))
             out_user, out = out, self.out32
-        gemm = CA_GEMM and ops.precision_id(prec) == ops.F16 and (9 * C) % 32 == 0 and L % 32 == 0 and C % 4 == 0
-        self.gemm = gemm
         if gemm:
             # GEMM route: the patch tables that are only GEMM operands are stored as fp16 (half the bytes through the vector memory path, no
             # conversion when staged); wp stays fp32 (norms, the patch gradient's coefficient term), its transpose is written as fp16
@@ -426,11 +428,11 @@ class AttentionPlan:
                 hz = lambda *s: torch.zeros(*s, dtype=torch.float16, device=f.t.device)
                 self.raw_h, self.rawT_h, self.wpT_h = hz(B, L, 16 * C), hz(B, 16 * C, L), hz(B, 9 * C, L)
                 self.O = torch.zeros(B, L, 16 * C, dtype=torch.float32, device=f.t.device)
-            L_.call('hv_ca_patches', ptr(f.t), B, H, W, C, f.ld, ptr(self.fd.t), ptr(self.wp), None, ptr(self.norm), ptr(self.rnorm), stream())
+            L_.call('hv_ca_patches', ptr(f.t), f.f16, B, H, W, C, f.ld, ptr(self.fd.t), ptr(self.wp), None, ptr(self.norm), ptr(self.rnorm), stream())
             L_.call('hv_transpose_batched_f16', ptr(self.wp), ptr(self.wpT_h), B, L, 9 * C, stream())
-            L_.call('hv_ca_raw_patches_f16', ptr(f.t), B, H, W, C, f.ld, ptr(self.raw_h), ptr(self.rawT_h), stream())
+            L_.call('hv_ca_raw_patches_f16', ptr(f.t), f.f16, B, H, W, C, f.ld, ptr(self.raw_h), ptr(self.rawT_h), stream())
         else:
-            L_.call('hv_ca_patches', ptr(f.t), B, H, W, C, f.ld, ptr(self.fd.t), ptr(self.wp), ptr(self.wpT), ptr(self.norm), ptr(self.rnorm), stream())
+            L_.call('hv_ca_patches', ptr(f.t), f.f16, B, H, W, C, f.ld, ptr(self.fd.t), ptr(self.wp), ptr(self.wpT), ptr(self.norm), ptr(self.rnorm), stream())
             L_.call('hv_ca_raw_patches', ptr(f.t), B, H, W, C, f.ld, ptr(self.raw), ptr(self.rawT), stream())
         if per_sample_mask:
             if self.mm_b is None:
@@ -456,7 +458,7 @@ class AttentionPlan:
                     ptr(self.argmax) if want_argmax else None, stream())
         if gemm:    # paste = (A rawT^T) folded: O[p][(c, tap)], then every output pixel sums the 4 taps that reach it
             _bgemm(self.A.t, self.rawT_h, self.O, L, 16 * C, L, B, b_split=C)          # rows of rawT [c][tap] taken as (tap, c): O[p][tap][c]
-            L_.call('hv_ca_fold', ptr(self.O), ptr(out.t), B, H, W, C, out.ld, ctypes.c_float(0.25), 0, stream())
+            L_.call('hv_ca_fold', ptr(self.O), ptr(out.t), out.f16, B, H, W, C, out.ld, ctypes.c_float(0.25), 0, stream())
         else:
             ops.conv2d(self.A, self.rawT, out, 4, 2, 1, 1, transposed=True, alpha=0.25, w_bstride=C * 16 * L, precision=prec)
         if out_user is not None:
@@ -473,24 +475,24 @@ class AttentionPlan:
                            coef=z(17 * B, L), dwp=Act(z(B, self.h, self.w, 9 * C)))
         bw = self.bw
         df_user = None
-        if dout.f16:
+        gemm = getattr(self, 'gemm', False) and ops.precision_id(prec) == ops.F16
+        if dout.f16 and not (gemm and CA_F16_IO):
             self.dout32 = getattr(self, 'dout32', None) or Act(torch.zeros(B, H, W, C, dtype=torch.float32, device=dout.t.device))
             ops.copy_channels(dout, self.dout32, mode=0)
             dout = self.dout32
-        if df.f16:
+        if df.f16:      # (two kernels add into df: it stays fp32 until both are in, one rounding)
             self.df32 = getattr(self, 'df32', None) or Act(torch.zeros(B, H, W, C, dtype=torch.float32, device=dout.t.device))
             df_user, df, df_acc, accumulate = df, self.df32, accumulate, False
         # through the paste: dA and d(raw patches)
-        gemm = getattr(self, 'gemm', False) and ops.precision_id(prec) == ops.F16
         if gemm:
             if 'dOraw_h' not in bw:
                 hz = lambda *s: torch.zeros(*s, dtype=torch.float16, device=dout.t.device)
                 bw['dOraw_h'], bw['dOrawT_h'], bw['AT_h'] = hz(B, L, 16 * C), hz(B, 16 * C, L), hz(B, L, L)
-            L_.call('hv_ca_raw_patches_f16', ptr(dout.t), B, H, W, C, dout.ld, ptr(bw['dOraw_h']), ptr(bw['dOrawT_h']), stream())
+            L_.call('hv_ca_raw_patches_f16', ptr(dout.t), dout.f16, B, H, W, C, dout.ld, ptr(bw['dOraw_h']), ptr(bw['dOrawT_h']), stream())
             _bgemm(bw['dOraw_h'], self.raw_h, bw['dA'].t, L, L, 16 * C, B, alpha=0.25)
             L_.call('hv_transpose_batched_f16', ptr(self.A.t), ptr(bw['AT_h']), B, L, L, stream())
             _bgemm(bw['AT_h'], bw['dOrawT_h'], self.O, L, 16 * C, L, B, b_split=C)      # d(raw patches)[l][tap][c] (the forward's O buffer is free by now)
-            L_.call('hv_ca_fold', ptr(self.O), ptr(df.t), B, H, W, C, df.ld, ctypes.c_float(0.25), int(bool(accumulate)), stream())
+            L_.call('hv_ca_fold', ptr(self.O), ptr(df.t), df.f16, B, H, W, C, df.ld, ctypes.c_float(0.25), int(bool(accumulate)), stream())
         else:
             ops.conv2d(dout, self.raw, bw['dA'], 4, 2, 1, 1, alpha=0.25, w_bstride=L * 16 * C, precision=prec)
             L_.call('hv_transpose_batched', ptr(self.A.t), ptr(bw['AT'].t), B, L, L, stream())

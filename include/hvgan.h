@@ -240,7 +240,7 @@ int hv_gap_fc_sigmoid_backward(const float* dpred, const float* pred, const floa
  * Score matrices are [b][p][l]: p = foreground position, l = background patch (contiguous), L = (H/2)*(W/2). */
 /* x1/2 nearest downsample fd[B][h][w][C]; 3x3 zero-padded patches wp[B][L][9][C] (+ transposed wpT[B][9*C][L]);
  * norm[B][L] = max(||patch||, 1e-4) and rnorm = 1/norm  (:282-294, :341-345). */
-int hv_ca_patches(const float* f, int B, int H, int W, int C, int f_ld, float* fd, float* wp, float* wpT, float* norm,
+int hv_ca_patches(const void* f, int f_f16 /* storage of f: 0 fp32, 1 fp16 */, int B, int H, int W, int C, int f_ld, float* fd, float* wp, float* wpT, float* norm,
                   float* rnorm, void* stream);
 /* 4x4 stride-2 'same' patches of a full-resolution map (:270-277): raw[B][L][16][C] and/or rawT[B][C][16][L]. */
 int hv_ca_raw_patches(const float* f, int B, int H, int W, int C, int f_ld, float* raw, float* rawT, void* stream);
@@ -274,9 +274,9 @@ int hv_transpose_batched(const float* src, float* dst, int B, int R, int C, void
  * F.conv_transpose2d(..., stride=2, padding=1) (models/inpaint_networks.py:379) after the contraction, and the adjoint of hv_ca_raw_patches. */
 int hv_bgemm_nt(const void* A, int a_f16, int lda, long long strideA, const void* B, int b_f16, int ldb, long long strideB, float* C, int ldc,
                 long long strideC, int M, int N, int K, int batch, float alpha, const float* colscale, long long strideS, int b_split, void* stream);
-int hv_ca_fold(const float* src, float* dst, int B, int H, int W, int C, int dst_ld, float alpha, int accumulate, void* stream);
+int hv_ca_fold(const float* src, void* dst, int dst_f16 /* storage of dst */, int B, int H, int W, int C, int dst_ld, float alpha, int accumulate, void* stream);
 /* fp16-stored forms of two operand producers (same layouts as hv_ca_raw_patches / hv_transpose_batched) */
-int hv_ca_raw_patches_f16(const float* f, int B, int H, int W, int C, int f_ld, void* raw_h, void* rawT_h, void* stream);
+int hv_ca_raw_patches_f16(const void* f, int f_f16 /* storage of f */, int B, int H, int W, int C, int f_ld, void* raw_h, void* rawT_h, void* stream);
 int hv_transpose_batched_f16(const float* src, void* dst_h, int B, int R, int C, void* stream);
 /* Gs[b][i][j] = dS[b][j][i]*rnorm[b][i] + dS[b][i][j]*rnorm[b][j];  coef[b][l] = -(sum_p dS[p][l]*S0[p][l])/norm[l]^2.
  * coef must hold 17*B*L floats: the first B*L are the result, the rest is scratch for the row-chunk partial sums. */

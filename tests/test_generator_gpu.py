@@ -345,7 +345,7 @@ def test_fold_of_stride2_patches_is_conv_transpose_tail():
     ref = 0.25 * F.fold(cols, (H, W), kernel_size=4, stride=2, padding=1)          # (B, C, H, W)
     dst = torch.ones(B, H, W, C, device=dev)
     for acc in (0, 1):
-        lib.get().call('hv_ca_fold', lib.ptr(src.to(dev)), lib.ptr(dst), B, H, W, C, C, ctypes.c_float(0.25), acc, lib.stream())
+        lib.get().call('hv_ca_fold', lib.ptr(src.to(dev)), lib.ptr(dst), 0, B, H, W, C, C, ctypes.c_float(0.25), acc, lib.stream())
         torch.cuda.synchronize()
         want = ref.permute(0, 2, 3, 1) * (1 + acc)
         assert (dst.cpu() - want).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item())
