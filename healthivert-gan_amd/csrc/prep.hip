@@ -120,7 +120,7 @@ extern "C" int hv_weight_tile_f16(const void* w_f16, void* w_tiled, int rows, in
 // conv_transpose sources (transposed_src) have no such contiguity and keep the gather.
 __global__ __launch_bounds__(256) void weight_layout_fwd_kernel(const hv_wprep_layer* __restrict__ layers, int only_legacy) {
     const hv_wprep_layer L = layers[blockIdx.y];
-    if (only_legacy && !(L.transposed_src || L.taps > 16)) return;      // (taken by weight_layout_fused_kernel)
+    if (only_legacy && !L.transposed_src) return;      // (taken by weight_layout_fused_kernel)
     __shared__ float sh[4096 + 256];
     const int taps = L.taps, ldt = taps + 1;                                    // LDS rows [ci][taps + 1]: the tap-major read-out is conflict-free
     int CC = 256;
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void weight_layout_fwd_kernel(const hv_wprep_l
 // forward tables of the same call (stream order).
 __global__ __launch_bounds__(256) void weight_layout_bwd_kernel(const hv_wprep_layer* __restrict__ layers, int only_legacy) {
     const hv_wprep_layer L = layers[blockIdx.y];
-    if (!L.w_bwd || (only_legacy && !(L.transposed_src || L.taps > 16))) return;
+    if (!L.w_bwd || (only_legacy && !L.transposed_src)) return;
     __shared__ float sh[32][33];
     const int taps = L.taps, tco = (L.CoutP + 31) / 32, tci = (L.CinB + 31) / 32;
     const long long work = (long long)taps * tco * tci;
@@ -204,32 +204,40 @@ extern "C" int hv_weight_prep(const hv_wprep_layer* d_layers, int n_layers, long
 // the fragment-ordered tables as scattered 2-byte stores, and the data-gradient pass re-reads the forward table.  Here a work item is a 32 x 32
 // (filter, input channel) tile with all its taps: the source rows (32 ci x taps contiguous floats per filter) go to LDS once, the plain tables leave as
 // 128-byte (fp32) / 64-byte (fp16) runs and a 16 x 32 MFMA fragment of either ordered table as 64 sixteen-byte pieces = 1 KB contiguous.
-// Layers it does not take (conv_transpose sources, more than 16 taps) are left to the kernels above (hv_weight_prep2's any_legacy).
+// conv_transpose sources (no contiguous source rows) are left to the kernels above (hv_weight_prep2's any_legacy).
 #define WL_T 32
 __global__ __launch_bounds__(256) void weight_layout_fused_kernel(const hv_wprep_layer* __restrict__ layers) {
     const hv_wprep_layer L = layers[blockIdx.y];
-    if (L.transposed_src || L.taps > 16) return;
-    extern __shared__ __attribute__((aligned(16))) float wl_sh[];              // [32 filters][32 * ldt + 1]
-    const int taps = L.taps, ldt = taps | 1, RS = WL_T * ldt + 1;
+    if (L.transposed_src) return;
+    // a work item = (32 filters x 32 input channels) x a group of up to 4 taps: the largest PatchGAN layer is 128 tiles, with the taps split it is 512 items
+    // (41 us with whole-tap tiles: each thread walked 16 taps x 4 rows three times, on 128 of the 256 CUs)
+    constexpr int TG = 4, LDT = TG + 1, RS = WL_T * LDT + 1;
+    __shared__ float wl_sh[WL_T * RS];                                         // [32 filters][32 channels x 5 + 1]
+    const int taps = L.taps, ntg = (taps + TG - 1) / TG;
     const int rows_f = L.CoutF, rows_b = L.w_bwd ? L.CinB : 0;
     const int nco = (max(L.CoutF, L.w_bwd ? L.CoutP : 0) + WL_T - 1) / WL_T, nci = (max(L.CinP, rows_b) + WL_T - 1) / WL_T;
     const float sigma = L.sigma[0];
     const int Tf = L.w_fwd_t ? tile_width(L.CinP) : 0, Tb = (L.w_bwd && L.w_bwd_t) ? tile_width(L.CoutP) : 0;
-    const int tid = threadIdx.x;
-    for (int w = blockIdx.x; w < nco * nci; w += gridDim.x) {
-        const int co0 = (w / nci) * WL_T, ci0 = (w % nci) * WL_T;
+    const int tid = threadIdx.x, lane = tid & 31, sub = tid >> 5;
+    for (int w = blockIdx.x; w < nco * nci * ntg; w += gridDim.x) {
+        const int tg = w % ntg, tile = w / ntg;
+        const int co0 = (tile / nci) * WL_T, ci0 = (tile % nci) * WL_T;
+        const int t0 = tg * TG, tn = min(TG, taps - t0);                      // this item's taps t0 .. t0 + tn
         const int cs = max(0, min(WL_T, L.Cin - ci0));                        // real input channels of the tile
         __syncthreads();
-        // (every loop below walks (row, tap) with the lane as the contiguous index: no division by the run-time tap count -- the first version, indexed
-        // by a flat element number, spent its time in integer divisions: 68 us against 23 + 15 for the two element-wise kernels)
-        const int lane = tid & 31, sub = tid >> 5;
         // ---- source -> LDS (zeros where the tile leaves the real weight): lane = input channel, its taps are contiguous in the source
         for (int r = sub; r < WL_T; r += 8) {
             const int co = co0 + r;
             const bool real = co < L.Cout && lane < cs;
-            const float* src = L.w_orig + ((long long)co * L.Cin + ci0 + lane) * taps;
-            float* dst = wl_sh + r * RS + lane * ldt;
-            for (int tap = 0; tap < taps; ++tap) dst[tap] = real ? src[tap] / sigma : 0.f;       // (the division the element-wise kernels do: same bits)
+            const float* src = L.w_orig + ((long long)co * L.Cin + ci0 + lane) * taps + t0;
+            float* dst = wl_sh + r * RS + lane * LDT;
+            if (real && tn == TG && !(taps & 3)) {
+                const float4 v = *reinterpret_cast<const float4*>(src);
+                dst[0] = v.x / sigma; dst[1] = v.y / sigma; dst[2] = v.z / sigma; dst[3] = v.w / sigma;       // (the division the element-wise kernels do: same bits)
+            } else {
+#pragma unroll
+                for (int t = 0; t < TG; ++t) dst[t] = (real && t < tn) ? src[t] / sigma : 0.f;
+            }
         }
         __syncthreads();
         // ---- forward tables [co][tap][ci]: a warp-wide run of 32 input channels per (co, tap)
@@ -238,25 +246,24 @@ __global__ __launch_bounds__(256) void weight_layout_fused_kernel(const hv_wprep
             for (int r = sub; r < WL_T; r += 8) {
                 const int co = co0 + r;
                 if (co >= rows_f || ci >= L.CinP) continue;
-                for (int tap = 0; tap < taps; ++tap) {
-                    const float val = wl_sh[r * RS + lane * ldt + tap];
-                    const long long i = ((long long)co * taps + tap) * L.CinP + ci;
+                for (int t = 0; t < tn; ++t) {
+                    const float val = wl_sh[r * RS + lane * LDT + t];
+                    const long long i = ((long long)co * taps + t0 + t) * L.CinP + ci;
                     L.w_fwd[i] = val;
                     if (L.w_fwd_h) reinterpret_cast<_Float16*>(L.w_fwd_h)[i] = (_Float16)val;
-                    if (Tf == 16) reinterpret_cast<_Float16*>(L.w_fwd_t)[tiled_index(co, tap, ci, taps, L.CinP, 16)] = (_Float16)val;
+                    if (Tf == 16) reinterpret_cast<_Float16*>(L.w_fwd_t)[tiled_index(co, t0 + t, ci, taps, L.CinP, 16)] = (_Float16)val;
                 }
             }
         }
-        if (Tf == 32 && ci0 < L.CinP) {       // fragment (16-row block rb, tap): [kq][row][8 channels], pieces of 16 bytes; 64 pieces = threads (rb, kq, row)
-            const int row = tid & 15, kq = (tid >> 4) & 3, half = tid >> 6;          // 4 x 64 threads: (rb, tap parity)
-            const int rb = half & 1;
+        if (Tf == 32 && ci0 < L.CinP) {       // fragment (16-row block rb, tap): [kq][row][8 channels], pieces of 16 bytes; threads = (tap parity, rb, kq, row)
+            const int row = tid & 15, kq = (tid >> 4) & 3, half = tid >> 6, rb = half & 1;
             const int cob = co0 + rb * 16;
             if (cob < (rows_f + 15) / 16 * 16) {
-                for (int tap = half >> 1; tap < taps; tap += 2) {
+                for (int t = half >> 1; t < tn; t += 2) {
                     f16x8 h;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) h[e] = (_Float16)wl_sh[(rb * 16 + row) * RS + (kq * 8 + e) * ldt + tap];
-                    _Float16* base = reinterpret_cast<_Float16*>(L.w_fwd_t) + (long long)(cob >> 4) * 16 * taps * L.CinP + (long long)((tap * L.CinP + ci0) >> 5) * 512;
+                    for (int e = 0; e < 8; ++e) h[e] = (_Float16)wl_sh[(rb * 16 + row) * RS + (kq * 8 + e) * LDT + t];
+                    _Float16* base = reinterpret_cast<_Float16*>(L.w_fwd_t) + (long long)(cob >> 4) * 16 * taps * L.CinP + (long long)(((t0 + t) * L.CinP + ci0) >> 5) * 512;
                     *reinterpret_cast<f16x8*>(base + (kq * 16 + row) * 8) = h;
                 }
             }
@@ -268,26 +275,25 @@ __global__ __launch_bounds__(256) void weight_layout_fused_kernel(const hv_wprep
                 const int ci = ci0 + cil;
                 if (ci >= rows_b || co >= L.CoutP) continue;
                 const bool in = ci < L.CinP && co < L.CoutF;                                  // (the old pass read the forward table: zero beyond it)
-                for (int tap = 0; tap < taps; ++tap) {
-                    const float val = in ? wl_sh[lane * RS + cil * ldt + tap] : 0.f;
-                    const long long i = ((long long)ci * taps + tap) * L.CoutP + co;
+                for (int t = 0; t < tn; ++t) {
+                    const float val = in ? wl_sh[lane * RS + cil * LDT + t] : 0.f;
+                    const long long i = ((long long)ci * taps + t0 + t) * L.CoutP + co;
                     L.w_bwd[i] = val;
                     if (L.w_bwd_h) reinterpret_cast<_Float16*>(L.w_bwd_h)[i] = (_Float16)val;
-                    if (Tb == 16) reinterpret_cast<_Float16*>(L.w_bwd_t)[tiled_index(ci, tap, co, taps, L.CoutP, 16)] = (_Float16)val;
+                    if (Tb == 16) reinterpret_cast<_Float16*>(L.w_bwd_t)[tiled_index(ci, t0 + t, co, taps, L.CoutP, 16)] = (_Float16)val;
                 }
             }
             if (Tb == 32 && co0 < L.CoutP) {
-                const int row = tid & 15, kq = (tid >> 4) & 3, half = tid >> 6;
-                const int rb = half & 1;
+                const int row = tid & 15, kq = (tid >> 4) & 3, half = tid >> 6, rb = half & 1;
                 const int cib = ci0 + rb * 16;
                 if (cib < (rows_b + 15) / 16 * 16) {
                     const int cil = rb * 16 + row;
                     const bool in = ci0 + cil < L.CinP;
-                    for (int tap = half >> 1; tap < taps; tap += 2) {
+                    for (int t = half >> 1; t < tn; t += 2) {
                         f16x8 h;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) h[e] = (in && co0 + kq * 8 + e < L.CoutF) ? (_Float16)wl_sh[(kq * 8 + e) * RS + cil * ldt + tap] : (_Float16)0.f;
-                        _Float16* base = reinterpret_cast<_Float16*>(L.w_bwd_t) + (long long)(cib >> 4) * 16 * taps * L.CoutP + (long long)((tap * L.CoutP + co0) >> 5) * 512;
+                        for (int e = 0; e < 8; ++e) h[e] = (in && co0 + kq * 8 + e < L.CoutF) ? (_Float16)wl_sh[(kq * 8 + e) * RS + cil * LDT + t] : (_Float16)0.f;
+                        _Float16* base = reinterpret_cast<_Float16*>(L.w_bwd_t) + (long long)(cib >> 4) * 16 * taps * L.CoutP + (long long)(((t0 + t) * L.CoutP + co0) >> 5) * 512;
                         *reinterpret_cast<f16x8*>(base + (kq * 16 + row) * 8) = h;
                     }
                 }
@@ -304,17 +310,10 @@ extern "C" int hv_weight_prep2(const hv_wprep_layer* d_layers, int n_layers, lon
         hipLaunchKernelGGL(weight_prep_kernel, dim3(n_layers), dim3(PREP_THREADS), 0, (hipStream_t)stream, d_layers);
         HV_LAUNCH_CHECK();
     }
-    const size_t lds = (size_t)WL_T * (WL_T * 17 + 1) * sizeof(float);
-    static bool raised = false;
-    if (!raised) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(weight_layout_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        if (e != hipSuccess) return -1000 - (int)e;
-        raised = true;
-    }
-    // a 32 x 32 tile is 1024 * taps elements of one table: about one workgroup per tile of the largest layer, grid-stride for the rest
-    int gx = (int)hv_cdiv(max_numel, 2 * 1024 * 9);
-    gx = gx < 1 ? 1 : (gx > 512 ? 512 : gx);
-    hipLaunchKernelGGL(weight_layout_fused_kernel, dim3(gx, n_layers), dim3(256), lds, (hipStream_t)stream, d_layers);
+    // one item = 32 x 32 x 4 elements of a table: about one workgroup per item of the largest layer, grid-stride for the rest
+    int gx = (int)hv_cdiv(max_numel, 2 * 1024 * 4);
+    gx = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
+    hipLaunchKernelGGL(weight_layout_fused_kernel, dim3(gx, n_layers), dim3(256), 0, (hipStream_t)stream, d_layers);
     HV_LAUNCH_CHECK();
     if (any_legacy) {
         const int gl = hv_cdiv(max_numel, 2048) < 1 ? 1 : hv_cdiv(max_numel, 2048);

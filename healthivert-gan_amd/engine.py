@@ -143,7 +143,7 @@ class ParamSet:
     def prep(self, device, power_iter):
         self._ensure(device)
         ops.weight_prep(self.t_prep[bool(power_iter)], max(c.sizes()[0] + c.sizes()[1] for c in self.convs), any_sn=any(c.sn for c in self.convs),
-                        any_legacy=any(c.transposed_src or c.taps > 16 for c in self.convs))
+                        any_legacy=any(c.transposed_src for c in self.convs))
 
     def finish_backward(self, accumulate=False):
         """Kernel-layout weight gradients -> .grad of weight_orig / weight (spectral-norm backward included)."""

@@ -146,7 +146,7 @@ typedef struct {
 int hv_weight_prep(const hv_wprep_layer* d_layers, int n_layers, long long max_numel, void* stream); /* d_layers: DEVICE array; max_numel = largest w_fwd+w_bwd element count of a layer */
 /* The same tables with all six of a layer written from one read of its weights (32 x 32 filter x channel tiles through LDS, whole MFMA fragments per store).
  * any_sn: some layer has sn = 1 (otherwise the sigma kernel is not launched: sigma[0] must already hold 1.0); any_legacy: some layer is a conv_transpose
- * source or has more than 16 taps (those take the element-wise kernels of hv_weight_prep). */
+ * source (those take the element-wise kernels of hv_weight_prep). */
 int hv_weight_prep2(const hv_wprep_layer* d_layers, int n_layers, long long max_numel, int any_sn, int any_legacy, void* stream);
 
 /* MFMA-fragment order of an fp16 filter table w[rows][taps][K] (K = padded input channels; T = 32 when K % 32 == 0, 16 when K % 16 == 0, otherwise
