@@ -500,6 +500,11 @@ static bool wgrad_tr_plan(const hv_wgrad_desc* d, WTrPlan* pl) {
     if (d->Cout < 32 || d->Cin < 16) return false;        // narrower layers: wgrad_halo_kernel / the gather kernel
     pl->BN = d->Cout >= 64 ? 64 : 32;
     pl->BC = d->Cin >= 32 ? 32 : 16;
+    {   // layers with a small dW (the generators' 64 x 64 x 9): every workgroup writes a whole slab of its tile pair, so 32-filter blocks halve the slab bytes
+        // (and double the pixel tiles per workgroup at the same workgroup count)
+        static const int bn32 = getenv("HV_WTR_BN32") ? atoi(getenv("HV_WTR_BN32")) : 1;      // A/B knob (three same-box pairs: 8.85 -> 8.82 ms)
+        if (bn32 && d->stride == 1 && d->Cout == 64 && d->Cin <= 64 && d->Cin >= 32) pl->BN = 32;
+    }
     if (d->stride == 2 && pl->BN == 64) pl->BC = 16;      // the stride-2 patch is 3x larger: its prefetch registers leave room for 16 accumulator tiles
     const int PH = 7 * d->stride + d->KH, PW = 15 * d->stride + d->KW;
     pl->lds = (size_t)128 * wtr_stride(pl->BN, 1) + (size_t)PH * PW * wtr_stride(pl->BC, d->stride);
