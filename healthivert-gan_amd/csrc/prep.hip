@@ -393,6 +393,64 @@ extern "C" int hv_weight_prep_backward(const hv_wprep_bwd_layer* d_layers, int n
     return HV_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ 1-channel heads: loss seed -> gradient carrier
+// g = seed * act'(y) written as channel 0 of an fp16 [pixel][4] carrier (channels 1-3 zero: the carrier is the padded gradient operand of the head's
+// weight / data gradient kernels) + the bias gradient sum(g).  Replaces three passes at the head of the generator backward (fp32 seed -> carrier copy,
+// in-place act' pass whose 1-channel form took 18 us for 2 MB, column sums): four pixels per thread, one 32-byte store.
+__global__ __launch_bounds__(256) void head_seed_kernel(const float* __restrict__ seed, const void* __restrict__ y, int yh, int y_ld, int y_coff,
+                                                        _Float16* __restrict__ carrier, long long npix, int act, float* __restrict__ part) {
+    __shared__ float red[20];
+    const long long p0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    float s = 0.f;
+    if (p0 + 3 < npix) {
+        const float4 sd = *reinterpret_cast<const float4*>(seed + p0);
+        float g[4] = {sd.x, sd.y, sd.z, sd.w};
+        f16x8 lo, hi;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) lo[e] = hi[e] = (_Float16)0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            g[u] *= hv_act_grad_from_out(hv_ld1(y, (p0 + u) * y_ld + y_coff, yh), act);
+            const _Float16 h = (_Float16)g[u];
+            s += (float)h;                                   // the bias gradient sums what the carrier holds (as the in-place pass did)
+            if (u < 2) lo[u * 4] = h; else hi[(u - 2) * 4] = h;
+        }
+        *reinterpret_cast<f16x8*>(carrier + p0 * 4) = lo;
+        *reinterpret_cast<f16x8*>(carrier + p0 * 4 + 8) = hi;
+    } else {
+        for (long long p = p0; p < npix; ++p) {
+            const _Float16 h = (_Float16)(seed[p] * hv_act_grad_from_out(hv_ld1(y, p * y_ld + y_coff, yh), act));
+            s += (float)h;
+            carrier[p * 4] = h; carrier[p * 4 + 1] = carrier[p * 4 + 2] = carrier[p * 4 + 3] = (_Float16)0.f;
+        }
+    }
+    if (part) {
+        s = hv_block_sum(s, red);
+        if (threadIdx.x == 0) part[blockIdx.x] = s;
+    }
+}
+
+__global__ __launch_bounds__(64) void colsum_finalize_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ out, int accumulate);
+
+extern "C" size_t hv_head_seed_workspace_bytes(long long npix) { return (size_t)((npix + 1023) / 1024) * sizeof(float); }
+
+extern "C" int hv_head_seed_backward(const float* seed, const void* y, int y_f16, int y_ld, int y_coff, void* carrier_f16, long long npix, int act, float* dbias,
+                                     int dbias_accumulate, float* workspace, size_t workspace_bytes, void* stream) {
+    if (!seed || !y || !carrier_f16 || npix <= 0 || y_ld < 1 || act < HV_ACT_NONE || act > HV_ACT_CLAMP) return HV_ERR_ARG;
+    if (((uintptr_t)seed | (uintptr_t)carrier_f16) & 15) return HV_ERR_UNSUPPORTED;
+    const int nb = (int)((npix + 1023) / 1024);
+    if (dbias && (!workspace || workspace_bytes < (size_t)nb * sizeof(float))) return HV_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(head_seed_kernel, dim3(nb), dim3(256), 0, s, seed, y, y_f16, y_ld, y_coff, reinterpret_cast<_Float16*>(carrier_f16), npix, act,
+                       dbias ? workspace : nullptr);
+    HV_LAUNCH_CHECK();
+    if (dbias) {
+        hipLaunchKernelGGL(colsum_finalize_kernel, dim3(1), dim3(64), 0, s, workspace, nb, 1, dbias, dbias_accumulate);
+        HV_LAUNCH_CHECK();
+    }
+    return HV_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ activation gradient
 // vector path: C % 4 == 0 and C/4 a power of two <= 256: thread owns one 4-channel group, rows strided.
 template <bool VEC>

@@ -257,7 +257,7 @@ def _wgrad(node, p, xin, gfull, accumulate, prec, dbias=None, dbias_accumulate=F
 
 
 def conv_backward(node, book, prec, dbias_accumulate=False, wgrad_accumulate=False, tmp_full=None, wgrad=True, x_wg=None, premultiplied=False,
-                  mul_x=None):
+                  mul_x=None, dbias_done=False):
     """Backward of one ConvNode: activation gradient (+bias gradient), weight gradient, data gradient.
     x_wg: channel-padded copy of the input for the weight-gradient kernel (1-channel image inputs).
     premultiplied: the gradient buffer of node.y already holds the PRE-activation gradient (its only writer applied act').
@@ -265,7 +265,7 @@ def conv_backward(node, book, prec, dbias_accumulate=False, wgrad_accumulate=Fal
     epilogue, so that layer's backward starts `premultiplied` (conv_backward_chain)."""
     p = node.p
     gy = book.twin(node.y)
-    want_dbias = p.bias is not None and node.use_bias and wgrad
+    want_dbias = p.bias is not None and node.use_bias and wgrad and not dbias_done      # dbias_done: the caller's seed pass already summed it
     # the bias gradient (column sums of the activation gradient) rides in the weight-gradient kernels, which stream g anyway;
     # conv_transpose nodes (roles of x and g swapped there) and unpadded channel counts keep the stand-alone reduction
     fuse_dbias = want_dbias and not node.transposed and FUSE_DBIAS and p.coutP == p.cout

@@ -18,6 +18,9 @@ from ._backend import ops
 from ._backend import lib as _lib_
 ptr, stream = _lib_.ptr, _lib_.stream
 from ._backend import ops as _ops_
+
+import os as _os_
+HEAD_SEED = _os_.environ.get('HV_HEAD_SEED', '1') != '0'      # fused seed pass of the 1-channel heads (A/B knob)
 Act, rup = _ops_.Act, _ops_.rup
 
 _ACTS = ('relu', 'elu', 'lrelu', 'prelu', 'selu', 'tanh', 'sigmoid', 'none')
@@ -432,8 +435,14 @@ class Generator(nn.Module):
     def _head_backward(self, P, node, seed, gname, prec, book, mul_x=None):
         """1-channel head: seed (B,1,H,W) -> padded carrier -> activation/bias gradient -> wgrad + dgrad."""
         carrier = P.g_head[gname]                       # [B,H,W,4], channel 0 live
-        ops.copy_channels(Act(seed.view(P.B, P.H, P.W, 1)), carrier, mode=0)
         book.twins[id(node.y.t)] = carrier.t            # the head's output gradient lives in the carrier
+        pn = node.p
+        if HEAD_SEED and carrier.f16 and seed.dtype == torch.float32 and seed.is_contiguous() and pn.bias is not None and node.use_bias:
+            # seed -> act' -> carrier -> bias gradient in one pass (was: copy, in-place act' pass, column sums)
+            ops.head_seed_backward(seed, node.y, Act(carrier.t, 4, 0), node.act, dbias=pn.bias.grad)
+            E.conv_backward(node, book, prec, premultiplied=True, dbias_done=True, mul_x=mul_x if E.FUSE_ACT else None)
+            return
+        ops.copy_channels(Act(seed.view(P.B, P.H, P.W, 1)), carrier, mode=0)
         E.conv_backward(node, book, prec, mul_x=mul_x if E.FUSE_ACT else None)
 
     def run_backward(self, P, d_coarse_seg, d_fine_seg, d_x_stage1, d_x_stage2, d_pred1, d_pred2):

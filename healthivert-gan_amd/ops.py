@@ -337,6 +337,17 @@ def act_backward(dy, y, act, dbias=None, dbias_accumulate=False):
            ptr(dbias), int(dbias_accumulate), ptr(b), nb, stream())
 
 
+def head_seed_backward(seed, y, carrier, act, dbias=None, dbias_accumulate=False):
+    """1-channel head: carrier[..., 0] = seed * act'(y) (fp16 [B,H,W,4] carrier, channels 1-3 zeroed), dbias (+)= its sum.  seed: fp32 tensor of npix
+    elements; y: Act (the head's output)."""
+    L = _lib.get()
+    npix = carrier.npix
+    need = L.size('hv_head_seed_workspace_bytes', ctypes.c_longlong(npix)) if dbias is not None else 0
+    b, nb = _ws(need, carrier.t.device)
+    L.call('hv_head_seed_backward', ptr(seed), ptr(y.t), y.f16, y.ld, y.coff, ptr(carrier.t), ctypes.c_longlong(npix), ACT[act], ptr(dbias),
+           int(dbias_accumulate), ptr(b), nb, stream())
+
+
 def copy_channels(src, dst, mode=0, accumulate=False):
     """dst (+)= resample(src); H,W of dst rule (mode: 0 same, 1 up x2, 2 down x1/2, 3 adjoint of 1, 4 adjoint of 2)."""
     if 'copy_channels' in _DIAG_SKIP:

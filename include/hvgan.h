@@ -166,6 +166,13 @@ typedef struct {
 } hv_wprep_bwd_layer;
 int hv_weight_prep_backward(const hv_wprep_bwd_layer* d_layers, int n_layers, long long max_numel, int any_sn, void* stream);
 
+/* 1-channel heads (models/inpaint_networks.py:115,230: clamp / sigmoid heads): loss seed -> the head's gradient carrier in one pass.
+ * carrier_f16[p][0] = seed[p] * act'(y[p]) (fp16; channels 1-3 of the [pixel][4] carrier are zeroed), dbias (+)= sum_p of the stored values.
+ * workspace: hv_head_seed_workspace_bytes(npix) bytes when dbias != NULL. */
+size_t hv_head_seed_workspace_bytes(long long npix);
+int hv_head_seed_backward(const float* seed, const void* y, int y_f16, int y_ld, int y_coff, void* carrier_f16, long long npix, int act, float* dbias,
+                          int dbias_accumulate, float* workspace, size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------- activation gradient + bias gradient
  * g[p,c] = dy[p,c] * act'(y[p,c]) in place over dy; dbias[c] (+)= sum_p g[p,c] when dbias != NULL.
  * (autograd of nn.ELU/ReLU/Sigmoid/clamp after the conv, models/inpaint_networks.py:459-474,115,230). */
