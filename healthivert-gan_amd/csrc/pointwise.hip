@@ -502,6 +502,12 @@ __global__ __launch_bounds__(256) void gloss_finalize_kernel(const hv_gloss_desc
     const float lh = (float)(hsum / B);
     d.losses[0] = l1; d.losses[1] = ldice; d.losses[2] = lcd; d.losses[3] = ledge; d.losses[4] = lh;
     d.losses[5] = l1 + ldice + lcd + ledge + lh;
+    if (d.gan_terms && d.loss_G_GAN) {
+        float lg = d.gan_terms[0];
+        for (int k = 1; k < d.n_gan_terms; ++k) lg += d.gan_terms[k];
+        d.loss_G_GAN[0] = lg;
+        if (d.loss_G) d.loss_G[0] = d.losses[5] + lg;
+    }
 }
 __global__ void gloss_seed_kernel(const hv_gloss_desc d, const float* __restrict__ coef, long long n) {
     const int HW = d.H * d.W;
@@ -511,7 +517,8 @@ __global__ void gloss_seed_kernel(const hv_gloss_desc d, const float* __restrict
         const int b = (int)(i / HW);
         const float rb = d.real_B[i];
         const float e1 = d.fake_B[i] - rb, e2 = d.fake_B_coarse[i] - rb;
-        d.d_fake_B[i] = cl1 * (e1 > 0.f ? 1.f : (e1 < 0.f ? -1.f : 0.f));
+        const float s1 = cl1 * (e1 > 0.f ? 1.f : (e1 < 0.f ? -1.f : 0.f));
+        d.d_fake_B[i] = d.add_d_fake_B ? s1 + d.add_d_fake_B[i] : s1;
         d.d_fake_B_coarse[i] = cl1 * (e2 > 0.f ? 1.f : (e2 < 0.f ? -1.f : 0.f));
         const float Af = coef[1 + 4 * b], Tf = coef[2 + 4 * b], Ac = coef[3 + 4 * b], Tc = coef[4 + 4 * b];
         d.d_fine_seg[i] = -15.f * invB * (2.f * d.real_B_mask[i] * Af - Tf) / (Af * Af);

@@ -307,9 +307,6 @@ class Pix2PixModel(BaseModel):
             for k in (1, 2, 3):
                 self._g_step_D(k)
         dxs = self._dxs
-        L.call('hv_affine', ptr(lg), ptr(self._loss_slot(16)), ctypes.c_longlong(1), ctypes.c_float(1.0), ctypes.c_float(0.0), stream())
-        ops.axpy(lg, self._loss_slot(17), 1.0)
-        ops.axpy(lg, self._loss_slot(18), 1.0)
         g = L.hv_gloss_desc()
         seeds = {n: self._buf(n, self.real_B) for n in ('d_fake_B', 'd_fake_B_coarse', 'd_fine_seg', 'd_coarse_seg')}
         dp1, dp2 = self._buf('d_pred1', shape=(B, 1)), self._buf('d_pred2', shape=(B, 1))
@@ -323,6 +320,12 @@ class Pix2PixModel(BaseModel):
             setattr(g, f, ptr(t).value)
         g.lambda_L1 = float(self.opt.lambda_L1)
         g.grad_scale = self.grad_scale
+        # loss_G_GAN = the three discriminators' terms, loss_G, and the discriminator's gradient wrt fake_B added to its seed: folded into the loss
+        # kernels (they were six 1-element / 4-MB launches in a row at the head of the generator backward)
+        self.loss_G = self._loss_slot(14)
+        g.gan_terms, g.n_gan_terms = ptr(self._loss_buf[16:19]).value, 3
+        g.loss_G_GAN, g.loss_G = ptr(lg).value, ptr(self.loss_G).value
+        g.add_d_fake_B = ptr(dxs[1]).value
         g.B, g.H, g.W = B, H, W
         need = L.size('hv_generator_losses_workspace_bytes', B)
         ws, _ = ops._ws(need, self.device, slot=1)
@@ -331,11 +334,7 @@ class Pix2PixModel(BaseModel):
         self.loss_G_GAN = lg
         self.loss_G_maskL1, self.loss_G_Dice, self.loss_coarse_Dice = losses[0], losses[1], losses[2]
         self.loss_edge, self.loss_h = losses[3], losses[4]
-        self.loss_G = self._loss_slot(14)
-        L.call('hv_affine', ptr(self.loss_G), ptr(losses[5:6]), ctypes.c_longlong(1), ctypes.c_float(1.0), ctypes.c_float(0.0), stream())
-        ops.axpy(self.loss_G, lg, 1.0)
         # gradient wrt the composited images -> wrt the raw generator outputs (rows [xu, xb) only)
-        ops.axpy(seeds['d_fake_B'], dxs[1], 1.0)
         d_x2, d_x1 = self._buf('d_x_stage2', self.real_B), self._buf('d_x_stage1', self.real_B)
         L.call('hv_shrm_backward', ptr(seeds['d_fake_B']), ptr(dxs[3]), ptr(self.mask), ptr(self._rows), 0, ptr(d_x2), B, H, W,
                self.half_band, 0, stream())

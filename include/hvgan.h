@@ -337,6 +337,11 @@ typedef struct {
     float* workspace; size_t workspace_bytes;
     float grad_scale;   /* the six gradient seeds are multiplied by this (0 = 1): the gradient (loss) scale of the fp16 storage mode, a power of two
                            removed again from the parameter gradients by the caller (the losses themselves are not scaled) */
+    /* optional bookkeeping folded into the same launches (each was a 1-element kernel at the head of the generator backward):
+       loss_G_GAN = gan_terms[0] + ... + gan_terms[n_gan_terms-1] (in this order), loss_G = losses[5] + loss_G_GAN;
+       add_d_fake_B: d_fake_B[i] += add_d_fake_B[i] (the discriminator's gradient wrt the composited image) */
+    const float* gan_terms; int n_gan_terms; float* loss_G_GAN; float* loss_G;
+    const float* add_d_fake_B;
 } hv_gloss_desc;
 size_t hv_generator_losses_workspace_bytes(int B);
 int hv_generator_losses(const hv_gloss_desc* d, void* stream);
