@@ -420,6 +420,71 @@ extern "C" int hv_gan_loss_ws(const float* z, long long n, int target_is_real, i
     return HV_OK;
 }
 
+// The PatchGAN loss head in two launches: loss, d loss / d logit written STRAIGHT into the logits layer's padded fp16 gradient carrier ([n][4], channels
+// 1-3 zero) and the logits layer's bias gradient (= the sum of the stored values).  The separate passes (fp32 dz -> carrier copy, bias column sums and
+// their finalize) were four more small launches in the chain between a discriminator's forward and its backward, three times per step.
+__global__ __launch_bounds__(256) void gan_loss_head_part_kernel(const float* __restrict__ z, long long n, float t, int mode, float gw, float* __restrict__ dz,
+                                                                 _Float16* __restrict__ carrier, float* __restrict__ part, float* __restrict__ gpart) {
+    __shared__ float red[20];
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    float l = 0.f, gs = 0.f;
+    if (i < n) {
+        const float v = z[i];
+        float g;
+        if (mode == 0) {
+            const float e = expf(-fabsf(v)), r = 1.f / (1.f + e);
+            g = (v >= 0.f ? r : e * r) - t;
+            l = fmaxf(v, 0.f) - v * t + log1pf(e);
+        } else {
+            g = 2.f * (v - t);
+            l = (v - t) * (v - t);
+        }
+        g = gw * g / (float)n;
+        if (dz) dz[i] = g;
+        const _Float16 h = (_Float16)g;
+        *reinterpret_cast<f16x4*>(carrier + i * 4) = (f16x4){h, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+        gs = (float)h;
+    }
+    l = hv_block_sum(l, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = l;
+    if (gpart) {
+        __syncthreads();
+        gs = hv_block_sum(gs, red);
+        if (threadIdx.x == 0) gpart[blockIdx.x] = gs;
+    }
+}
+__global__ __launch_bounds__(256) void gan_loss_head_final_kernel(const float* __restrict__ part, const float* __restrict__ gpart, int nparts, long long n, float lw,
+                                                                  float* loss, int lacc, float* dbias, int bacc) {
+    __shared__ float red[20];
+    float s = 0.f, g = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 256) { s += part[i]; if (gpart) g += gpart[i]; }
+    s = hv_block_sum(s, red);
+    __syncthreads();
+    g = hv_block_sum(g, red);
+    if (threadIdx.x == 0) {
+        if (loss) { const float v = lw * s / (float)n; loss[0] = lacc ? loss[0] + v : v; }
+        if (dbias) dbias[0] = bacc ? dbias[0] + g : g;
+    }
+}
+extern "C" size_t hv_gan_loss_head_workspace_bytes(long long n) { return 2 * (size_t)((n + 255) / 256) * sizeof(float); }
+extern "C" int hv_gan_loss_head(const float* z, long long n, int target_is_real, int mode, float loss_weight, float* loss, int loss_accumulate, float grad_weight,
+                                float* dz, void* carrier_f16, float* dbias, int dbias_accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!z || !carrier_f16 || n <= 0 || mode < 0 || mode > 1) return HV_ERR_ARG;
+    if (!workspace || workspace_bytes < hv_gan_loss_head_workspace_bytes(n) || ((uintptr_t)workspace & 3) || ((uintptr_t)carrier_f16 & 7)) return HV_ERR_WORKSPACE;
+    const int nparts = (int)((n + 255) / 256);
+    float* part = reinterpret_cast<float*>(workspace);
+    float* gpart = dbias ? part + nparts : nullptr;
+    hipLaunchKernelGGL(gan_loss_head_part_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, z, n, target_is_real ? 1.f : 0.f, mode, grad_weight, dz,
+                       reinterpret_cast<_Float16*>(carrier_f16), part, gpart);
+    HV_LAUNCH_CHECK();
+    if (loss || dbias) {
+        hipLaunchKernelGGL(gan_loss_head_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, part, gpart, nparts, n, loss_weight, loss, loss_accumulate, dbias,
+                           dbias_accumulate);
+        HV_LAUNCH_CHECK();
+    }
+    return HV_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ generator losses
 #define GL_CHUNKS 32
 #define GL_NQ 10   // S1,S2,cnt,tpf,spf,sgf,tpc,spc,sgc,E

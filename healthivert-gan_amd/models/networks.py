@@ -144,6 +144,7 @@ class GANLoss(nn.Module):
 
 # ================================================================================================ PatchGAN
 CONV_STATS = os.environ.get('HV_CONV_STATS', '1') != '0'     # A/B knob: BatchNorm statistics from the producing conv's epilogue
+LOSS_HEAD = os.environ.get('HV_LOSS_HEAD', '1') != '0'      # GAN loss kernel writes the logits layer's gradient carrier + bias gradient (A/B knob)
 FUSE_NORM_ACT = os.environ.get('HV_FUSE_NORM_ACT', '1') != '0'     # A/B knob, see _DiscPlan-based run_backward
 
 
@@ -312,7 +313,22 @@ class NLayerDiscriminator(nn.Module):
         P.training, P.groups = training, groups
         return P
 
-    def run_backward(self, P, dlogits, need_dx=False, param_grads=True, accumulate=False):
+    def loss_backward(self, P, target_is_real, mode, loss, grad_weight, need_dx=False, param_grads=True, accumulate=False, loss_weight=1.0, dz=None):
+        """GAN loss on P.logits + backward.  fp16 storage mode: the loss kernel writes d loss / d logit straight into the logits layer's gradient carrier
+        and sums its bias gradient (hv_gan_loss_head) -- the copy, the column-sum pass and its finalize leave the chain between forward and backward."""
+        last = P.layers[-1]
+        if LOSS_HEAD and P.g_logits.f16 and P.g_logits.t.shape[-1] == 4 and P.g_logits.coff == 0:
+            pl = last['p']
+            want_db = param_grads and pl.bias is not None and last['node'].use_bias
+            ops.gan_loss(P.logits, target_is_real, mode, loss=loss, loss_weight=loss_weight, grad_weight=grad_weight, carrier=Act(P.g_logits.t, 4, 0),
+                         dbias=pl.bias.grad if want_db else None, dbias_accumulate=accumulate)
+            return self.run_backward(P, None, need_dx=need_dx, param_grads=param_grads, accumulate=accumulate, logits_ready=True)
+        if dz is None:
+            dz = torch.empty_like(P.logits)
+        ops.gan_loss(P.logits, target_is_real, mode, loss=loss, loss_weight=loss_weight, dz=dz, grad_weight=grad_weight)
+        return self.run_backward(P, dz, need_dx=need_dx, param_grads=param_grads, accumulate=accumulate)
+
+    def run_backward(self, P, dlogits, need_dx=False, param_grads=True, accumulate=False, logits_ready=False):
         """dlogits: (B,1,Ho,Wo) gradient of the loss wrt the logits.  Fills kernel-layout weight gradients and the
         bias / affine .grad (accumulating when `accumulate`); call finish() afterwards.  Returns d loss / d input."""
         prec = ops.precision_id(self.precision)
@@ -320,7 +336,8 @@ class NLayerDiscriminator(nn.Module):
         book.reset()
         B = P.B
         last = P.layers[-1]
-        ops.copy_channels(Act(dlogits.contiguous().view(B, last['y'].H, last['y'].W, 1)), P.g_logits, mode=0)
+        if not logits_ready:      # (loss_backward: the loss kernel already wrote the carrier and the logits layer's bias gradient)
+            ops.copy_channels(Act(dlogits.contiguous().view(B, last['y'].H, last['y'].W, 1)), P.g_logits, mode=0)
         book.twins[id(last['y'].t)] = P.g_logits.t
         # the input view changes every call: its gradient always lives in P.dx
         book.twins.pop(getattr(P, '_in_id', None), None)
@@ -352,7 +369,7 @@ class NLayerDiscriminator(nn.Module):
                                       dbeta=nm.bias.grad if (bn and param_grads) else None, param_accumulate=accumulate,
                                       groups=P.groups)
             # the stem's output has one consumer (layer 1): its LeakyReLU' rides in layer 1's data-gradient epilogue
-            E.conv_backward(node, book, prec, dbias_accumulate=accumulate, wgrad_accumulate=accumulate, wgrad=param_grads,
+            E.conv_backward(node, book, prec, dbias_accumulate=accumulate, wgrad_accumulate=accumulate, wgrad=param_grads, dbias_done=bool(logits_ready and L['last']),
                             mul_x=P.layers[0]['node'].act if (li == 1 and fuse0) else ('lrelu' if (prev_normed and fuse_n) else None))
         if need_dx:
             g = book.twin(P.x_in)

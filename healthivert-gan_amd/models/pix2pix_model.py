@@ -245,9 +245,8 @@ class Pix2PixModel(BaseModel):
         net = getattr(self, 'netD_%d' % k)
         lr = self._loss_slot(2 * k + 1)
         P = net.run_forward(real, training=True, prep=True, stat_order='swapped_first')
-        dz = self._buf('dz%d' % k, P.logits)
-        ops.gan_loss(P.logits, True, self.opt.gan_mode, loss=lr, dz=dz, grad_weight=0.5 * self.grad_scale)
-        net.run_backward(P, dz, need_dx=False, param_grads=True, accumulate=False)
+        net.loss_backward(P, True, self.opt.gan_mode, lr, 0.5 * self.grad_scale, need_dx=False, param_grads=True, accumulate=False,
+                          dz=self._buf('dz%d' % k, P.logits))
         setattr(self, 'loss_D_real_%d' % k, lr)
 
     def _d_fake_second(self, k, fake):
@@ -256,9 +255,8 @@ class Pix2PixModel(BaseModel):
         net = getattr(self, 'netD_%d' % k)
         lf = self._loss_slot(2 * k)
         P = net.run_forward(fake, training=True, prep=False, stat_order='swapped_second')
-        dz = self._buf('dz%d' % k, P.logits)
-        ops.gan_loss(P.logits, False, self.opt.gan_mode, loss=lf, dz=dz, grad_weight=0.5 * self.grad_scale)
-        net.run_backward(P, dz, need_dx=False, param_grads=True, accumulate=True)
+        net.loss_backward(P, False, self.opt.gan_mode, lf, 0.5 * self.grad_scale, need_dx=False, param_grads=True, accumulate=True,
+                          dz=self._buf('dz%d' % k, P.logits))
         net.finish()
         self._unscale(net)
         setattr(self, 'loss_D_fake_%d' % k, lf)
@@ -294,9 +292,11 @@ class Pix2PixModel(BaseModel):
         fake = {1: self.fake_B, 2: self.fake_B_mask_raw, 3: self.fake_B_local}[k]
         P = net.run_forward(fake, training=True, prep=True)
         dz = self._buf('dz%d' % k, P.logits)
-        ops.gan_loss(P.logits, True, self.opt.gan_mode, loss=self._loss_slot(15 + k), loss_weight=1.0 / 6.0, dz=dz, grad_weight=self.grad_scale / 6.0)
         if k != 2:   # D_2 sees a thresholded mask: no gradient path to G (reference :201,:324)
-            self._dxs[k] = net.run_backward(P, dz, need_dx=True, param_grads=False)
+            self._dxs[k] = net.loss_backward(P, True, self.opt.gan_mode, self._loss_slot(15 + k), self.grad_scale / 6.0, need_dx=True, param_grads=False,
+                                             loss_weight=1.0 / 6.0, dz=dz)
+        else:
+            ops.gan_loss(P.logits, True, self.opt.gan_mode, loss=self._loss_slot(15 + k), loss_weight=1.0 / 6.0, dz=dz, grad_weight=self.grad_scale / 6.0)
 
     def backward_G(self, d_done=False):
         L = _lib.get()

@@ -396,10 +396,18 @@ def sobel(img, out=None):
 GAN_LOSS_WS = os.environ.get('HV_GAN_LOSS_WS', '1') != '0'   # A/B knob
 
 
-def gan_loss(z, target_is_real, mode='vanilla', loss=None, loss_weight=1.0, loss_accumulate=False, dz=None, grad_weight=1.0):
+def gan_loss(z, target_is_real, mode='vanilla', loss=None, loss_weight=1.0, loss_accumulate=False, dz=None, grad_weight=1.0, carrier=None, dbias=None,
+             dbias_accumulate=False):
+    """carrier: Act fp16 [.., 4] -- the logits layer's padded gradient operand, written directly (hv_gan_loss_head), with the layer's bias gradient dbias."""
     m = {'vanilla': 0, 'lsgan': 1}[mode]
     L = _lib.get()
     n = z.numel()
+    if carrier is not None:
+        assert carrier.f16 and carrier.ld == 4 and carrier.coff == 0 and carrier.npix == n
+        b, nb = _ws(L.size('hv_gan_loss_head_workspace_bytes', ctypes.c_longlong(n)), z.device, slot=2)
+        L.call('hv_gan_loss_head', ptr(z), ctypes.c_longlong(n), int(bool(target_is_real)), m, ctypes.c_float(loss_weight), ptr(loss), int(loss_accumulate),
+               ctypes.c_float(grad_weight), ptr(dz), ptr(carrier.t), ptr(dbias), int(dbias_accumulate), ptr(b), nb, stream())
+        return
     if n >= 4096 and GAN_LOSS_WS:      # many workgroups + per-stream scratch for their partial sums
         b, nb = _ws(L.size('hv_gan_loss_workspace_bytes', ctypes.c_longlong(n)), z.device, slot=2)
         L.call('hv_gan_loss_ws', ptr(z), ctypes.c_longlong(n), int(bool(target_is_real)), m, ctypes.c_float(loss_weight), ptr(loss),

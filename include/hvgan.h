@@ -322,6 +322,13 @@ size_t hv_gan_loss_workspace_bytes(long long n);
 int hv_gan_loss_ws(const float* z, long long n, int target_is_real, int mode, float loss_weight, float* loss, int loss_accumulate,
                    float grad_weight, float* dz, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The PatchGAN loss head in two launches: hv_gan_loss_ws + d loss / d logit written into the logits layer's padded fp16 gradient carrier
+ * (carrier_f16[i][0]; channels 1-3 of the [n][4] carrier zeroed) + the logits layer's bias gradient dbias[0] (+)= sum of the stored values.
+ * dz (fp32) and loss, dbias are optional.  workspace: hv_gan_loss_head_workspace_bytes(n) bytes. */
+size_t hv_gan_loss_head_workspace_bytes(long long n);
+int hv_gan_loss_head(const float* z, long long n, int target_is_real, int mode, float loss_weight, float* loss, int loss_accumulate, float grad_weight,
+                     float* dz, void* carrier_f16, float* dbias, int dbias_accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Generator losses and their gradient seeds (models/pix2pix_model.py:331-353): writes
  * losses[0..5] = {G_maskL1, G_Dice, coarse_Dice, edge, h, sum of those five} and the seeds
  * d_fake_B (L1 part), d_fake_B_coarse, d_fine_seg, d_coarse_seg, d_pred1 (raw sigmoid output), d_pred2. */
