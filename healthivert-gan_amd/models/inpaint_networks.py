@@ -464,7 +464,9 @@ class Generator(nn.Module):
         self._head_backward(P, M[8], d_fine_seg, 'f18', prec, book)
         gcat17 = book.twin(a['cat17'])
         # x_stage1 also feeds the fine heads (channel c/2 of cat17)
-        d_xs1_total = P.__dict__.setdefault('d_xs1_total', torch.zeros_like(P.x_stage1))
+        if 'd_xs1_total' not in P.__dict__:      # (setdefault(..., torch.zeros_like(...)) built and filled the default on every call: a fill kernel per step)
+            P.d_xs1_total, P.d_cs_total = torch.zeros_like(P.x_stage1), torch.zeros_like(P.coarse_seg)
+        d_xs1_total = P.d_xs1_total
         ops.copy_channels(Act(d_x_stage1.view(B, H, W, 1)), Act(d_xs1_total.view(B, H, W, 1)), mode=0)
         ops.copy_channels(gcat17.slice(c // 2, 1), Act(d_xs1_total.view(B, H, W, 1)), mode=0, accumulate=True)
         # pure links (single producer, single consumer): the consumer's data gradient applies the producer's act'
@@ -494,7 +496,7 @@ class Generator(nn.Module):
             main.wait_stream(side)
             E.conv_backward(pm_rev[-1], book, prec, premultiplied=E.chain_link(pm_rev[-2], pm_rev[-1], prec))
         # coarse_seg enters the fine generator as channel 1 of its input
-        d_cs_total = P.__dict__.setdefault('d_cs_total', torch.zeros_like(P.coarse_seg))
+        d_cs_total = P.d_cs_total
         ops.copy_channels(Act(d_coarse_seg.view(B, H, W, 1)), Act(d_cs_total.view(B, H, W, 1)), mode=0)
         ops.copy_channels(book.twin(P.f_in).slice(1, 1), Act(d_cs_total.view(B, H, W, 1)), mode=0, accumulate=True)
         # ---- coarse
