@@ -21,6 +21,7 @@ struct HaloK {
     const void* mul_src; int mul_ld, mul_coff, mul_act, mul_vec;   // epilogue factor act'(mul_src[..]) or NULL; mul_vec: vector loads are aligned
     int x_half, y_half, mul_half;
     int ep16;  // conv_halo2_kernel: fp16 output tile handed through LDS and stored as 16-byte pieces (whole channel rows per pixel)
+    const void* x1; int x1_half, x1_ld, x1_coff; const float* w1; int w1_row, w1_tap;   // conv_lf_kernel: one extra input channel (hv_conv_desc.x1) or NULL
     int pool2; // conv_lf_kernel: the output tile leaves 2x2 sum-pooled (hv_conv_desc.pool2); Ho / Wo are then the POOLED tensor's size
     int dil;   // conv_halo2_kernel: dilation d > 1 runs as d*d residue sub-grids (pixel step d), each an undilated conv; 1 otherwise
     const _Float16* wt; unsigned wt_bytes;   // the filters in MFMA-fragment order (hv_conv_desc.w_f16_tiled) or NULL; conv_halo2_kernel only

@@ -364,6 +364,7 @@ int hv_conv2d_halo(const hv_conv_desc* d, const void* w_f16, hipStream_t s) {
     k.x_bytes = (unsigned)((size_t)d->B * k.img_stride * xs);
     k.w_bytes = (unsigned)((size_t)d->Cout * d->KH * d->KW * d->Cin * sizeof(_Float16));
     k.Cout = d->Cout; k.w_row = d->KH * d->KW * d->Cin; k.y_ld = d->y_ld; k.y_coff = d->y_coff; k.Ho = d->Ho; k.Wo = d->Wo;
+    k.x1 = d->x1; k.x1_half = d->x1_f16 ? 1 : 0; k.x1_ld = d->x1_ld; k.x1_coff = d->x1_coff; k.w1 = d->w1; k.w1_row = d->w1_row; k.w1_tap = d->w1_tap;
     k.pool2 = d->pool2 ? 1 : 0;
     if (k.pool2) { k.Ho = d->Ho / 2; k.Wo = d->Wo / 2; }      // the stored tensor; the classes below keep the convolution's own grid
     k.alpha = d->alpha; k.act = d->act; k.accumulate = d->accumulate;
@@ -449,7 +450,7 @@ int hv_conv2d_halo(const hv_conv_desc* d, const void* w_f16, hipStream_t s) {
     static const bool halo2 = !(getenv("HV_HALO2") && atoi(getenv("HV_HALO2")) == 0);   // A/B knob
     {   // filters-in-LDS form (3x3 stride-1 layers with whole-chunk channel counts)
         const int rc = hv_convlf_launch(k, d->KH, d->KW, s);
-        if (rc != HV_ERR_UNSUPPORTED || d->pool2) return rc;
+        if (rc != HV_ERR_UNSUPPORTED || d->pool2 || d->x1) return rc;
     }
     if (halo2) {   // weights-in-registers form where an instantiation exists
         const int rc = hv_halo2_launch(k, TW, d->KH, d->KW, maxpatch, s);

@@ -384,6 +384,12 @@ static int conv2d_dispatch(const hv_conv_desc* d, void* stream) {
         return HV_ERR_UNSUPPORTED;
     if (d->H > 16000 || d->W > 16000 || (d->KH - 1) * d->dil > 120 || (d->KW - 1) * d->dil > 120) return HV_ERR_UNSUPPORTED;
 
+    if (d->x1) {         // extra input channel: the filters-in-LDS kernel or nothing (the caller keeps the materialised concat)
+        if (d->precision != HV_F16 || !d->w_f16 || !d->w_f16_tiled || !d->y_f16 || d->transposed || d->dil != 1 || d->stride != 1 || d->KH != 3 || d->KW != 3 || !d->w1 ||
+            d->pool2 || d->stats || d->x1_ld < 1)
+            return HV_ERR_UNSUPPORTED;
+        return hv_conv2d_halo(d, d->w_f16, (hipStream_t)stream);
+    }
     if (d->pool2) {      // pooled data gradient: the filters-in-LDS kernel or nothing (the caller keeps the conv + copy form)
         if (d->precision != HV_F16 || !d->w_f16 || !d->y_f16 || (d->Ho & 1) || (d->Wo & 1) || d->dil != 1 || d->stride != 1 || d->KH != 3 || d->KW != 3 || d->bias ||
             d->act != HV_ACT_NONE || d->in_shift || d->stats)

@@ -33,12 +33,13 @@ struct LfCfg {
     static constexpr int PATCH_HALFS = NPL * PLANE;
     static constexpr int OST_HALFS = TH * TW * LDO;
     static constexpr int TAIL_HALFS = PATCH_HALFS > OST_HALFS ? PATCH_HALFS : OST_HALFS;
-    static constexpr size_t LDS_BYTES = (size_t)(WHALFS + TAIL_HALFS) * 2;
+    static constexpr int X1_FLOATS = PH * PW + CO * 9;       // the extra input channel's patch + its filters (hv_conv_desc.x1)
+    static constexpr size_t LDS_BYTES = (size_t)(WHALFS + TAIL_HALFS) * 2 + (size_t)X1_FLOATS * 4;
     static constexpr int WITEMS = (WHALFS * 2 / 16 + NTHR - 1) / NTHR;           // 16-byte filter items per thread
     static constexpr int PITEMS = (PH * PW * (CIN / 8) + NTHR - 1) / NTHR;       // 16-byte patch items per thread
 };
 
-template <int CIN, int CO, int TH, int WPS>
+template <int CIN, int CO, int TH, int WPS, bool X1 = false>       // X1: the hv_conv_desc.x1 form (its own instantiations: the extra code must not cost the others registers)
 __global__ __launch_bounds__(512, WPS) void conv_lf_kernel(const HaloK p) {
     typedef LfCfg<CIN, CO, TH> G;
     constexpr int T = G::T, NPL = G::NPL, LDP = G::LDP, MT = G::MT, NT = G::NT, PW = G::PW, PH = G::PH, TW = G::TW;
@@ -103,6 +104,24 @@ __global__ __launch_bounds__(512, WPS) void conv_lf_kernel(const HaloK p) {
         }
 #pragma unroll
         for (int i = 0; i < PPI; ++i) preg[kc][i] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, pvo[i], kc * T * 2, 0);
+    }
+    // the extra input channel (scalar branch): its (TH + 2) x 18 patch and the workgroup's CO x 9 filter values, as floats behind the tail region
+    float* x1p = reinterpret_cast<float*>(smem + (size_t)(G::WHALFS + G::TAIL_HALFS) * 2);
+    float* w1s = x1p + PH * PW;
+    // (requested now -- one patch value and up to two filter values per thread -- and parked in LDS behind the MFMA loop: as LDS stores up here the address
+    // arithmetic and the stores sat on top of the filter / patch prefetch registers and spilled)
+    float x1v = 0.f, w1v[2] = {0.f, 0.f};
+    static_assert(!X1 || (PH * PW <= G::NTHR && CO * 9 <= 2 * G::NTHR), "one patch value, two filter values per thread");
+    if constexpr (X1) {
+        if (tid < PH * PW) {
+            const int py = tid / PW, px = tid - py * PW, hi = h0 + py, wi = w0 + px;
+            if ((unsigned)hi < (unsigned)p.Hl && (unsigned)wi < (unsigned)p.Wl) x1v = hv_ld1(p.x1, ((long long)(n_img * p.Hl + hi) * p.Wl + wi) * p.x1_ld + p.x1_coff, p.x1_half);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = tid + u * G::NTHR, co = n_base + e / 9, tp = e % 9;
+            if (e < CO * 9 && co < p.Cout) w1v[u] = p.w1[(long long)co * p.w1_row + tp * p.w1_tap];
+        }
     }
     // scalar tap table
     int toff[9], widx[9];
@@ -202,6 +221,12 @@ __global__ __launch_bounds__(512, WPS) void conv_lf_kernel(const HaloK p) {
             yreg[k] = __builtin_amdgcn_raw_buffer_load_b128(ysrc, ok ? (unsigned)(ooff[k] * 2) : HV_OOB, 0, 0);
         }
     }
+    if constexpr (X1) {
+        if (tid < PH * PW) x1p[tid] = x1v;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (tid + u * G::NTHR < CO * 9) w1s[tid + u * G::NTHR] = w1v[u];
+    }
     __syncthreads();          // every wave is done with the patch: its room becomes the output staging tile
 
     // ---- epilogue: (alpha, +bias, activation) -> fp16 tile in LDS -> 16-byte pieces (act' multiplier / accumulate forms applied there).
@@ -209,6 +234,40 @@ __global__ __launch_bounds__(512, WPS) void conv_lf_kernel(const HaloK p) {
     // other kernels (a scalar switch, range checks and a pointer path per value) is ~25 instructions x 32 values per lane here.
     _Float16* ot = patch;
     constexpr int LDO = G::LDO;
+    if constexpr (X1) {      // acc += the extra channel's 9 taps (before alpha / bias / activation): 9 patch values per pixel row, 9 filter values per channel
+        float cv[MT][9];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int q = (wave * MT + m) * 16 + (lane & 15);
+#pragma unroll
+            for (int t9 = 0; t9 < 9; ++t9) {
+                const uint32_t e = C.taps[t9];
+                cv[m][t9] = x1p[((q >> 4) + (int)(e & 0xff)) * PW + (q & 15) + (int)((e >> 8) & 0xff)];
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            // the 4 x 9 filter values of this lane's four channels of block n in one batch of LDS reads (one (channel, tap) at a time was a chain of
+            // LDS latencies: +20 us on the 256 x 256 layer), then the sums -- each "used" by an empty asm so that the next block's reads are not
+            // fetched ahead of them (all CO x 9 values up front: +108 registers, spills)
+            float w9[4][9];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int t9 = 0; t9 < 9; ++t9) w9[r][t9] = w1s[(n * 16 + (lane >> 4) * 4 + r) * 9 + widx[t9]];      // (an LDS address, not a register index)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    float ex = 0.f;
+#pragma unroll
+                    for (int t9 = 0; t9 < 9; ++t9) ex += cv[m][t9] * w9[r][t9];
+                    float v = acc[n][m][r] + ex;
+                    asm volatile("" : "+v"(v) : : "memory");
+                    acc[n][m][r] = v;
+                }
+        }
+    }
     auto stage = [&](auto actf) __attribute__((always_inline)) {
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -314,7 +373,7 @@ __global__ __launch_bounds__(512, WPS) void conv_lf_kernel(const HaloK p) {
 #endif
 }
 
-template <int CIN, int CO, int TH, int WPS>
+template <int CIN, int CO, int TH, int WPS, bool X1 = false>
 static int launch_lf(HaloK& k, hipStream_t s) {
     typedef LfCfg<CIN, CO, TH> G;
     static_assert(G::LDS_BYTES <= 160 * 1024, "filters + patch exceed the LDS");
@@ -325,7 +384,7 @@ static int launch_lf(HaloK& k, hipStream_t s) {
     C.t0 = 0;
     C.PH = G::PH; C.PW = G::PW;
     kk.w = kk.wt; kk.w_bytes = kk.wt_bytes;
-    auto kern = conv_lf_kernel<CIN, CO, TH, WPS>;
+    auto kern = conv_lf_kernel<CIN, CO, TH, WPS, X1>;
     static bool raised = false;
     if (G::LDS_BYTES > 48 * 1024 && !raised) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -356,6 +415,11 @@ int hv_convlf_launch(HaloK& k, int KH, int KW, hipStream_t s) {
     // <48, 32, 16> / <80, 64, 8> instantiations on 16-channel planes: step 8.76 vs 8.78 ms -- no gain over conv_halo2's ragged 16-channel chunks.)
     const int ci = Cin == 16 ? 0 : Cin == 32 ? 1 : Cin == 64 ? 2 : -1, co = Cout <= 16 ? 0 : Cout <= 32 ? 1 : 2;
     if (ci < 0 || !((mask >> (ci * 3 + co)) & 1)) return HV_ERR_UNSUPPORTED;
+    if (k.x1) {      // extra input channel: the two shapes that have it (32 + 1 -> 32, 64 + 1 -> 64)
+        if (Cin == 32 && Cout == 32) return launch_lf<32, 32, 16, 3, true>(k, s);
+        if (Cin == 64 && Cout == 64) return launch_lf<64, 64, 16, 2, true>(k, s);
+        return HV_ERR_UNSUPPORTED;
+    }
     switch (ci * 3 + co) {
         case 0: return launch_lf<16, 16, 16, 4>(k, s);
         case 1: return launch_lf<16, 32, 16, 4>(k, s);

@@ -268,6 +268,19 @@ __global__ __launch_bounds__(256) void weight_layout_fused_kernel(const hv_wprep
                 }
             }
         }
+        if (L.w_fwd_t2 && ci0 < L.K2) {       // the first K2 channels once more as a fragment-ordered table of their own (hv_conv_desc.x1 layers; K2 % 32 == 0)
+            const int row = tid & 15, kq = (tid >> 4) & 3, half = tid >> 6, rb = half & 1;
+            const int cob = co0 + rb * 16;
+            if (cob < (rows_f + 15) / 16 * 16) {
+                for (int t = half >> 1; t < tn; t += 2) {
+                    f16x8 h;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) h[e] = (_Float16)wl_sh[(rb * 16 + row) * RS + (kq * 8 + e) * LDT + t];
+                    _Float16* base = reinterpret_cast<_Float16*>(L.w_fwd_t2) + (long long)(cob >> 4) * 16 * taps * L.K2 + (long long)(((t0 + t) * L.K2 + ci0) >> 5) * 512;
+                    *reinterpret_cast<f16x8*>(base + (kq * 16 + row) * 8) = h;
+                }
+            }
+        }
         // ---- data-gradient tables [ci][tap][co]: a run of 32 filters per (ci, tap)
         if (L.w_bwd) {
             const int co = co0 + lane;

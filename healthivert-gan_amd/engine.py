@@ -42,6 +42,8 @@ class ConvParams:
         self.transposed_src = transposed_src
         self.w_fwd = self.w_bwd = self.sigma = self.dw = None
         self.w_fwd_t = self.w_bwd_t = None      # fp16 tables in MFMA-fragment order (None: the shape has no tiled form)
+        self.split_k = None                     # K2: also keep the first K2 input channels as a fragment-ordered table of their own (w_fwd_t2: conv2d's x1 layers)
+        self.w_fwd_t2 = None
 
     def sizes(self):
         return (self.cout * self.taps * self.cin_fwd, self.cin_fwd * self.taps * self.coutP, self.coutP * self.taps * self.cin_wg)
@@ -99,12 +101,14 @@ class ParamSet:
         self._hstore = hstore
         # the same fp16 tables in MFMA-fragment order, for the kernels that fetch filter rows straight into MFMA registers (zero-filled once:
         # the prep kernel never writes the padding rows)
-        tsz = [(ops.tiled_elems(c.cout, c.taps, c.cin_fwd), ops.tiled_elems(c.cin_fwd, c.taps, c.coutP)) for c in self.convs]
-        tstore = torch.zeros(sum(a + b for a, b in tsz) + 8, dtype=torch.float16, device=device)
+        tsz = [(ops.tiled_elems(c.cout, c.taps, c.cin_fwd), ops.tiled_elems(c.cin_fwd, c.taps, c.coutP),
+                ops.tiled_elems(c.cout, c.taps, c.split_k) if c.split_k else 0) for c in self.convs]
+        tstore = torch.zeros(sum(a + b + e for a, b, e in tsz) + 8, dtype=torch.float16, device=device)
         off = 0
-        for c, (a, b) in zip(self.convs, tsz):
+        for c, (a, b, e) in zip(self.convs, tsz):
             c.w_fwd_t = tstore[off:off + a] if a else None; off += a
             c.w_bwd_t = tstore[off:off + b] if b else None; off += b
+            c.w_fwd_t2 = tstore[off:off + e] if e else None; off += e
         self._tstore = tstore
         # flat gradients; .grad of every trainable tensor is a view into it
         ps = self.trainable()
@@ -120,7 +124,7 @@ class ParamSet:
                 rows.append(dict(w_orig=c.weight.data, u=c.u if c.sn else None, v=c.v if c.sn else None, sigma=c.sigma,
                                  w_fwd=c.w_fwd, w_bwd=c.w_bwd, w_fwd_h=c.w_fwd_h, w_bwd_h=c.w_bwd_h, w_fwd_t=c.w_fwd_t, w_bwd_t=c.w_bwd_t, Cout=c.cout, Cin=c.cin, taps=c.taps, CinP=c.cin_fwd,
                                  CoutF=c.cout, CoutP=c.coutP, CinB=c.cin_fwd, sn=int(c.sn), power_iter=int(pi and c.sn),
-                                 transposed_src=int(c.transposed_src)))
+                                 transposed_src=int(c.transposed_src), w_fwd_t2=c.w_fwd_t2, K2=int(c.split_k or 0)))
             self.t_prep[pi].update(rows, key, device)
         for acc in (True, False):
             rows = []
@@ -152,7 +156,7 @@ class ParamSet:
 
 class ConvNode:
     """conv (+bias +activation) between two NHWC views; knows how to run forward and backward."""
-    __slots__ = ('p', 'x', 'y', 'k', 's', 'pad', 'd', 'act', 'shift', 'need_dx', 'transposed', 'use_bias', 'dx_c', 'pool_to')
+    __slots__ = ('p', 'x', 'y', 'k', 's', 'pad', 'd', 'act', 'shift', 'need_dx', 'transposed', 'use_bias', 'dx_c', 'pool_to', 'split')
 
     def __init__(self, p, x, y, s=1, pad=0, d=1, act='none', shift=0, need_dx=True, transposed=False, use_bias=True, dx_c=None):
         self.p, self.x, self.y, self.k, self.s, self.pad, self.d = p, x, y, p.k, s, pad, d
@@ -163,9 +167,26 @@ class ConvNode:
         # pool_to = (Act low, activation of low's producer): x is a concat buffer whose first dx_c channels are the nearest x2 up-sampling of `low`;
         # set by the owner of the plan when the pooled data gradient can serve it (conv_backward)
         self.pool_to = None
+        # split = (Act low, Act x1): x is the concat [nearest x2 up-sampling of low (p.split_k channels) | x1 (one channel) | padding]; where the
+        # filters-in-LDS kernel serves the shape the forward reads `low` with the fused up-sampling and adds x1's taps in its epilogue, so the
+        # up-sampled part of x is only materialised for the backward (split_forward() tells)
+        self.split = None
+
+    def split_forward(self, prec):
+        p = self.p
+        if self.split is None or not SPLIT_CONCAT or p.w_fwd_t2 is None or ops.precision_id(prec) != ops.F16 or self.k != 3 or self.s != 1 or self.d != 1:
+            return False
+        low, x1 = self.split
+        return bool(low.f16 and self.y.f16 and low.C == p.split_k and low.ld % 8 == 0 and low.coff % 8 == 0 and self.y.ld % 8 == 0 and p.cout % 8 == 0)
 
     def forward(self, prec, stats=None):
         p = self.p
+        if self.split_forward(prec):
+            low, x1 = self.split
+            ops.conv2d(low, p.w_fwd, self.y, self.k, self.s, self.pad, self.d, bias=p.bias if self.use_bias else None, act=self.act, w_h=p.w_fwd_h,
+                       w_t=p.w_fwd_t2, in_shift=1, precision=prec, cin=p.split_k, cout=p.cout,
+                       x1=(x1, p.w_fwd, p.split_k, p.taps * p.cin_fwd, p.cin_fwd))
+            return
         xin = Act(self.x.t, p.cin_fwd, self.x.coff)
         ops.conv2d(xin, p.w_fwd, self.y, self.k, self.s, self.pad, self.d, bias=p.bias if self.use_bias else None, act=self.act, w_h=p.w_fwd_h, w_t=p.w_fwd_t,
                    in_shift=self.shift, transposed=self.transposed, precision=prec, cout=p.cout, stats=stats)
@@ -198,6 +219,7 @@ def named_stream(name, device, priority=0):
     return st
 
 
+SPLIT_CONCAT = os.environ.get('HV_SPLIT_CONCAT', '1') != '0'   # [up-sampled | 1 channel] concat layers read the small tensor + the channel (A/B knob)
 FUSE_DBIAS = os.environ.get('HV_FUSE_DBIAS', '1') != '0'   # bias gradients computed inside the weight-gradient kernels
 SERIAL = False            # True: no side streams at all (per-kernel timing with HIP events needs the GPU to itself)
 

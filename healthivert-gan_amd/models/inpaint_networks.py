@@ -250,6 +250,8 @@ class _GenPlan:
             N(P['coarse_generator.conv17'], a['c16'], xs1, 1, 1, 1, 'clamp'),
             N(P['coarse_generator.conv18'], a['c16'], cs, 1, 1, 1, 'sigmoid'),
         ]
+        self.c_nodes[12].split = (a['c12'], a['cat20'].slice(4 * c, 1))      # conv20 = [up(c12) | CAM at 128^2]
+        self.c_nodes[15].split = (a['c14'], a['cat19'].slice(2 * c, 1))      # conv19 = [up(c14) | CAM]
         self.c_pool = torch.zeros(B, 4 * c, device=device); self.pred1 = torch.zeros(B, 1, device=device)
         # ---------------- fine
         self.f_in = z(H, W, 4)
@@ -345,6 +347,11 @@ class Generator(nn.Module):
                 for n, m in g.named_children():
                     if isinstance(m, Conv2dBlock):
                         convs['%s.%s' % (gname, n)] = m.params('%s.%s' % (gname, n), cin_fwd=ops.cpad(m.cin))
+            # conv19 / conv20 read [up-sampled feature map | CAM]: their first 2c / 4c input channels also as a filter table of their own, so that the
+            # forward can read the small map with the fused up-sampling and take the CAM channel in its epilogue (ConvNode.split, hv_conv_desc.x1)
+            for n, k2 in (('coarse_generator.conv19', 2 * self.cnum), ('coarse_generator.conv20', 4 * self.cnum)):
+                if n in convs and k2 % 32 == 0 and convs[n].cin == k2 + 1:
+                    convs[n].split_k = k2
             self._pset_convs = convs
             cg, fg = self.coarse_generator, self.fine_generator
             self._pset = E.ParamSet(convs.values(), [cg.fc_height.weight, cg.fc_height.bias, fg.fc_height.weight, fg.fc_height.bias])
@@ -384,11 +391,14 @@ class Generator(nn.Module):
             n.forward(prec)
         ops.gap_fc_sigmoid(a['c10'], cg.fc_height.weight, cg.fc_height.bias, P.c_pool, P.pred1)
         P.c_nodes[10].forward(prec); P.c_nodes[11].forward(prec)
-        ops.copy_channels(a['c12'], a['cat20'].slice(0, 4 * c), mode=1)
+        # (split layers read c12 / c14 themselves: the up-sampled part of the concat buffer is then built by the backward, on its side stream)
+        if not P.c_nodes[12].split_forward(prec):
+            ops.copy_channels(a['c12'], a['cat20'].slice(0, 4 * c), mode=1)
         ops.copy_channels(cam, a['cat20'].slice(4 * c, 1), mode=2)
         for n in P.c_nodes[12:15]:
             n.forward(prec)
-        ops.copy_channels(a['c14'], a['cat19'].slice(0, 2 * c), mode=1)
+        if not P.c_nodes[15].split_forward(prec):
+            ops.copy_channels(a['c14'], a['cat19'].slice(0, 2 * c), mode=1)
         ops.copy_channels(cam, a['cat19'].slice(2 * c, 1), mode=0)
         for n in P.c_nodes[15:]:
             n.forward(prec)
@@ -459,6 +469,11 @@ class Generator(nn.Module):
         d_coarse_seg, d_x_stage1 = zero(d_coarse_seg, P.coarse_seg), zero(d_x_stage1, P.x_stage1)
         d_pred1, d_pred2 = zero(d_pred1, P.pred1), zero(d_pred2, P.pred2)
         M = P.f_nodes_merge
+        # the concat inputs of the split layers (forward: never built) for their weight gradients: up-sampled now, beside the head kernels
+        for node, low, cat, k2 in ((P.c_nodes[15], a['c14'], a['cat19'], 2 * c), (P.c_nodes[12], a['c12'], a['cat20'], 4 * c)):
+            if node.split_forward(prec):
+                with (torch.cuda.stream(book.fork()) if book.can_fork() else contextlib.nullcontext()):
+                    ops.copy_channels(low, cat.slice(0, k2), mode=1)
         # ---- fine: heads
         self._head_backward(P, M[7], d_x_stage2, 'f17', prec, book)
         self._head_backward(P, M[8], d_fine_seg, 'f18', prec, book)

@@ -162,7 +162,7 @@ def conv_out_size(n, k, stride, pad, dil):
 
 def conv2d(x, w, y, k, stride=1, pad=0, dil=1, bias=None, act='none', transposed=False, in_shift=0, alpha=1.0,
            accumulate=0, ch_scale=None, w_bstride=0, ch_scale_bstride=0, precision=None, cin=None, cout=None, w_h=None, mul=None, w_t=None,
-           stats=None, _parts_only=False, pool2=False):
+           stats=None, _parts_only=False, pool2=False, x1=None):
     """y = act(alpha*ch_scale*conv(x, w) + bias)  [* act'(m) with mul = (Act m, activation name): see hv_conv_desc.mul_src].  x,y: Act; w: prepared [CoutF][k*k][CinP] tensor (or [B][...] with
     w_bstride).  cin/cout default to the view widths (x.C consumed, y.C produced).
     stats: float tensor of conv2d_stats_parts(...) * Cout * 2 elements that receives the per-channel partial sums of the stored output
@@ -185,6 +185,11 @@ def conv2d(x, w, y, k, stride=1, pad=0, dil=1, bias=None, act='none', transposed
     d.y = ptr(y.t).value
     d.Ho, d.Wo, d.y_ld, d.y_coff = (y.H << 1 if pool2 else y.H), (y.W << 1 if pool2 else y.W), y.ld, y.coff
     d.pool2 = int(bool(pool2))
+    if x1 is not None:      # (Act of ONE channel at the conv's own resolution, full fp32 forward table, its channel index there, row stride, tap stride)
+        xa, wfull, ch, w1_row, w1_tap = x1
+        assert xa.C == 1 and xa.H == d.H and xa.W == d.W
+        d.x1, d.x1_f16, d.x1_ld, d.x1_coff = ptr(xa.t).value, xa.f16, xa.ld, xa.coff
+        d.w1, d.w1_row, d.w1_tap = ptr(wfull).value + 4 * ch, w1_row, w1_tap
     d.precision = precision_id(precision)
     d.w_f16 = None if w_h is None else ptr(w_h).value
     d.w_f16_tiled = None if (w_t is None or w_h is None) else ptr(w_t).value      # w_h in MFMA-fragment order (tile_weights / hv_weight_prep)

@@ -99,6 +99,14 @@ typedef struct {
                                          epilogue: stats[(part * Cout + c) * 2 + {0: sum, 1: sum of squares}] for part < hv_conv2d_stats_parts(d).
                                          Feeds hv_norm_desc.partials (BatchNorm statistics without a reduction pass over the tensor).  Only the
                                          kernels that hv_conv2d_stats_parts reports (> 0) write it; NULL = not wanted */
+    const void* x1;                   /* optional ONE extra input channel at the convolution's own resolution, added before bias / activation:
+                                         y += sum_taps x1[n][i + dh][j + dw] * w1[co * w1_row + tap * w1_tap] (zero padded like x).  With in_shift = 1 on x this
+                                         is a convolution over the concatenation [nearest x2 up-sampling of x | x1] that is never materialised (the coarse
+                                         generator's conv19 / conv20: models/inpaint_networks.py:97-106); w1 = channel Cin of the full fp32 forward table
+                                         [Cout][taps][CinP] (w1_row = taps * CinP, w1_tap = CinP).  Forward 3x3 stride-1 only, filters-in-LDS kernel only:
+                                         HV_ERR_UNSUPPORTED otherwise */
+    int x1_f16, x1_ld, x1_coff;
+    const float* w1; int w1_row, w1_tap;
     int pool2;                        /* 1: the output is stored 2x2 sum-pooled -- y, mul_src (and the accumulate operand) are (Ho/2) x (Wo/2) tensors and
                                          y[n][i][j][c] (+)= act'(mul_src[n][i][j][c]) * sum of the four fp16-rounded conv outputs at (2i + {0,1}, 2j + {0,1}):
                                          the data gradient of a convolution whose input was the nearest x2 up-sampling of a smaller tensor, without the
@@ -142,6 +150,9 @@ typedef struct {
                                        hv_weight_tiled_elems(CoutF, taps, CinP) / (CinB, taps, CoutP) halfs, zero-filled once by the caller */
     int Cout, Cin, taps, CinP, CoutF, CoutP, CinB;
     int sn, power_iter, transposed_src;
+    void* w_fwd_t2; int K2;   /* optional: the first K2 (32 or 64) input channels of the forward table once more in MFMA-fragment order, as a table of its
+                                 own ([CoutF][taps][K2]: hv_weight_tiled_elems(CoutF, taps, K2) halfs) -- the filters of hv_conv_desc.x1 layers; written by
+                                 hv_weight_prep2 only */
 } hv_wprep_layer;
 int hv_weight_prep(const hv_wprep_layer* d_layers, int n_layers, long long max_numel, void* stream); /* d_layers: DEVICE array; max_numel = largest w_fwd+w_bwd element count of a layer */
 /* The same tables with all six of a layer written from one read of its weights (32 x 32 filter x channel tiles through LDS, whole MFMA fragments per store).

@@ -453,6 +453,46 @@ def test_conv_data_gradient_of_upsampled_input_leaves_pooled(case):
         ops.conv2d(ga, wb, dxa, 3, 1, 1, 1, transposed=True, precision='fp32', pool2=True)
 
 
+@pytest.mark.parametrize('case', [(2, 16, 16, 32, 'elu'), (2, 24, 16, 64, 'elu'), (3, 8, 24, 32, 'none')])
+def test_conv_over_upsampled_map_plus_one_extra_channel_without_the_concat(case):
+    """hv_conv_desc.x1: a 3x3 conv over the concatenation [nearest x2 up-sampling of a K-channel map | one extra channel] that is never built -- the main
+    input is read with the fused up-sampling (in_shift), the extra channel's nine taps are added in the epilogue -- against torch on the materialised
+    concat; the filters of the first K channels come from hv_weight_prep2's split table (w_fwd_t2)."""
+    from hvtest import to_act, from_act, dev, maxerr
+    from hvgan import ops, engine, lib
+    import torch.nn as nn
+    B, h, w_, K, act = case
+    g = torch.Generator().manual_seed(21 + K)
+    low = torch.randn(B, K, h, w_, generator=g).half().float()
+    x1 = torch.randn(B, 1, 2 * h, 2 * w_, generator=g).half().float()
+    m = nn.Conv2d(K + 1, K, 3, padding=1)
+    with torch.no_grad():
+        m.weight.copy_((torch.randn(m.weight.shape, generator=g) / ((K + 1) * 9) ** 0.5))
+        m.bias.copy_(torch.randn(K, generator=g) * 0.1)
+    fn = {'elu': F.elu, 'none': lambda t: t}[act]
+    ref = fn(F.conv2d(torch.cat([F.interpolate(low, scale_factor=2, mode='nearest'), x1], 1), m.weight.half().float(), m.bias, padding=1))
+    m = m.to(dev())
+    cp = engine.ConvParams('c', m.weight, m.bias, K + 1, K, 3, cin_fwd=ops.cpad(K + 1))
+    cp.split_k = K
+    ps = engine.ParamSet([cp])
+    ps.prep(dev(), power_iter=False)
+    cat = ops.Act.empty(B, 2 * h, 2 * w_, K + 1, dev(), ld=ops.cpad(K + 1), dtype=torch.float16, zero=True)
+    ops.copy_channels(to_act(x1, dtype=torch.float16), cat.slice(K, 1), mode=0)
+    node = engine.ConvNode(cp, cat, ops.Act.empty(B, 2 * h, 2 * w_, K, dev(), dtype=torch.float16), 1, 1, 1, act)
+    node.split = (to_act(low, dtype=torch.float16), cat.slice(K, 1))
+    assert node.split_forward('fp16')
+    node.forward('fp16')
+    assert lib.get().size('hv_last_kernel_path') == 7
+    torch.cuda.synchronize()
+    assert maxerr(from_act(node.y), ref) <= 4e-3 * max(1.0, ref.abs().max().item())
+    # the same node through the materialised concat (what the fp32 mode and unsupported shapes do)
+    ops.copy_channels(to_act(low, dtype=torch.float16), cat.slice(0, K), mode=1)
+    node.split = None
+    node.forward('fp16')
+    torch.cuda.synchronize()
+    assert maxerr(from_act(node.y), ref) <= 4e-3 * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize('case', [(2, 7, 7, 32, 1), (2, 18, 21, 64, 3), (3, 31, 31, 512, 1), (2, 33, 17, 256, 4)])
 def test_conv_logits_data_gradient_taps_as_mfma_contraction(case):
     """logits_dgrad_kernel: data gradient of a 4x4 / stride 1 / pad 1 conv with <= 4 output channels (gradient stored with a channel stride
