@@ -110,12 +110,16 @@ __global__ __launch_bounds__(512, WPS) void conv_lf_kernel(const HaloK p) {
     float* w1s = x1p + PH * PW;
     // (requested now -- one patch value and up to two filter values per thread -- and parked in LDS behind the MFMA loop: as LDS stores up here the address
     // arithmetic and the stores sat on top of the filter / patch prefetch registers and spilled)
-    float x1v = 0.f, w1v[2] = {0.f, 0.f};
-    static_assert(!X1 || (PH * PW <= G::NTHR && CO * 9 <= 2 * G::NTHR), "one patch value, two filter values per thread");
+    float x1v[2] = {0.f, 0.f}, w1v[2] = {0.f, 0.f};
+    static_assert(!X1 || (PH * PW <= 2 * G::NTHR && CO * 9 <= 2 * G::NTHR), "two patch values, two filter values per thread");
     if constexpr (X1) {
-        if (tid < PH * PW) {
-            const int py = tid / PW, px = tid - py * PW, hi = h0 + py, wi = w0 + px;
-            if ((unsigned)hi < (unsigned)p.Hl && (unsigned)wi < (unsigned)p.Wl) x1v = hv_ld1(p.x1, ((long long)(n_img * p.Hl + hi) * p.Wl + wi) * p.x1_ld + p.x1_coff, p.x1_half);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = tid + u * G::NTHR;
+            if (e < PH * PW) {
+                const int py = e / PW, px = e - py * PW, hi = h0 + py, wi = w0 + px;
+                if ((unsigned)hi < (unsigned)p.Hl && (unsigned)wi < (unsigned)p.Wl) x1v[u] = hv_ld1(p.x1, ((long long)(n_img * p.Hl + hi) * p.Wl + wi) * p.x1_ld + p.x1_coff, p.x1_half);
+            }
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -222,10 +226,11 @@ __global__ __launch_bounds__(512, WPS) void conv_lf_kernel(const HaloK p) {
         }
     }
     if constexpr (X1) {
-        if (tid < PH * PW) x1p[tid] = x1v;
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < 2; ++u) {
+            if (tid + u * G::NTHR < PH * PW) x1p[tid + u * G::NTHR] = x1v[u];
             if (tid + u * G::NTHR < CO * 9) w1s[tid + u * G::NTHR] = w1v[u];
+        }
     }
     __syncthreads();          // every wave is done with the patch: its room becomes the output staging tile
 
@@ -415,6 +420,8 @@ int hv_convlf_launch(HaloK& k, int KH, int KW, hipStream_t s) {
     // <48, 32, 16> / <80, 64, 8> instantiations on 16-channel planes: step 8.76 vs 8.78 ms -- no gain over conv_halo2's ragged 16-channel chunks.)
     const int ci = Cin == 16 ? 0 : Cin == 32 ? 1 : Cin == 64 ? 2 : -1, co = Cout <= 16 ? 0 : Cout <= 32 ? 1 : 2;
     if (ci < 0 || !((mask >> (ci * 3 + co)) & 1)) return HV_ERR_UNSUPPORTED;
+    // (Measured and not kept, round 3: 32 x 16-pixel tiles for the 256 x 256 layers -- half the filter loads and workgroups per pixel: 30.1 / 21.4 / 37.5 /
+    // 22.7 us against 28.8 / 23.1 / 34.9 / 23.8 us with 16 x 16 tiles, step 8.20 -> 8.23 ms.)
     if (k.x1) {      // extra input channel: the two shapes that have it (32 + 1 -> 32, 64 + 1 -> 64)
         if (Cin == 32 && Cout == 32) return launch_lf<32, 32, 16, 3, true>(k, s);
         if (Cin == 64 && Cout == 64) return launch_lf<64, 64, 16, 2, true>(k, s);
