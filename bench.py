@@ -360,6 +360,28 @@ def main():
         fine2 = model.netG.time_fine
         model.netG.time_fine = None
         model.use_graph = ug
+    # ... and the refinement generator's forward ALONE as the product launches it: one captured hipGraph (both branches on their two streams),
+    # replayed with nothing else on the GPU.  The two event pairs above are taken around eager launches (one Python / ctypes call per kernel:
+    # the host can be the bound); this one is the device time of the ~65 kernels
+    fine_graph = None
+    if rank == 0 and not args.serial and model.use_graph and getattr(model, '_gplan', None) is not None:
+        try:
+            torch.cuda.synchronize()
+            cam_t = model._buf('cam_temp', model.CAM)
+            g = model.netG.fine_forward_graph(model._gplan, model.real_A, model.mask, model.slice_ratio)
+            for _ in range(3):
+                g.replay()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            nrep = 50
+            e0.record()
+            for _ in range(nrep):
+                g.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            fine_graph = e0.elapsed_time(e1) / nrep
+            del g, cam_t
+        except Exception as exc:       # noqa: BLE001 -- a diagnostic leg: the headline numbers do not depend on it
+            sys.stderr.write('bench.py: fine-generator graph replay leg skipped (%s)\n' % str(exc).splitlines()[0])
     if world > 1:      # MAX over ranks, region by region
         t = torch.tensor(region_dt, device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -421,6 +443,10 @@ def main():
             tf2 = GFLOP_FINE_FWD * args.batch * (args.size / 256.0) ** 2 / f2
             out['fine_generator_forward']['two_streams'] = {'ms': round(f2, 3), 'tflops': round(tf2, 1), 'frac_of_mfma_peak': round(tf2 / MFMA_PEAK_TFLOPS[args.precision], 4),
                                                             'timed_in': 'eager steps with the step\'s own streams (the two branches concurrent, discriminator streams busy beside them), mean of %d' % len(fine2)}
+        if fine_graph and 'fine_generator_forward' in out:
+            tfg = GFLOP_FINE_FWD * args.batch * (args.size / 256.0) ** 2 / fine_graph
+            out['fine_generator_forward']['graph_replay'] = {'ms': round(fine_graph, 3), 'tflops': round(tfg, 1), 'frac_of_mfma_peak': round(tfg / MFMA_PEAK_TFLOPS[args.precision], 4),
+                                                             'timed_in': 'the refinement generator\'s training forward alone as one captured hipGraph (two branch streams), mean of 50 back-to-back replays, GPU otherwise idle'}
         ngraphs = len(model._dp_graphs or ()) or len(model._graphs or ())
         out['config']['launch'] = ('hipGraph replay (%d graphs/step)' % ngraphs if model.use_graph else 'eager') + \
                                   (', one stream' if args.serial else ', %d streams' % (5 if world > 1 else 4))

@@ -4,8 +4,11 @@ Mirror of the reference's AlignedDataset.__getitem__ + default collate (data/ali
 arithmetic): the reference loads three float64 NIfTI volumes per item (~100 MB), cuts one slice, quantises it to uint8, re-stacks rows
 around the masked band and converts to tensors on the CPU.  Here a vertebra's volumes are quantised ONCE (`VertebraVolume`, host, numpy),
 uploaded once (`DeviceBatchAssembler`), and a batch is one `hv_assemble_batch` launch that writes the six float32 planes the model's
-`set_input` consumes.  Only the slice draw (np.random, same call sequence as the reference => same slices for the same seed) and the
-8-connected component filter of a drawn slice (scipy.ndimage.label, the reference's own third-party call, cached per slice) stay on the host.
+`set_input` consumes.  The 8-connected component filter the reference applies to every drawn slice (aligned_dataset.py:16-31,:186-188) runs
+on the device too, once per volume over all of its slices (`hv_slice_components_u8`: filtered mask planes + pixel count / first row / last row
+per slice -- everything the draw's acceptance test and the band rows need).  Only the slice draw itself stays on the host (np.random, same call
+sequence as the reference => same slices for the same seed; it reads the per-slice table, no pixels).  `VertebraVolume.slice_info` without a
+table is the host mirror of the filter (scipy.ndimage.label, the reference's own third-party call) that the tests hold the device table against.
 """
 import ctypes
 
@@ -77,9 +80,16 @@ class VertebraVolume:
         self.dirty = set()                                       # slices whose filtered mask differs from what was uploaded
         self._choice = None
 
+    def set_slice_table(self, stats):
+        """stats: [Z][4] ints from hv_slice_components_u8 (count, first row, last row, row sum) -> the per-slice table the draw reads."""
+        for z in range(self.Z):
+            c, r0, r1 = int(stats[z][0]), int(stats[z][1]), int(stats[z][2])
+            self._info[z] = (float(c), r0 if c else -1, r1 if c else -1)
+        self.dirty.clear()
+
     def slice_info(self, z):
         info = self._info.get(z)
-        if info is None:
+        if info is None:      # host mirror of the device filter (stand-alone use / tests)
             before = self._vert[z].copy()
             _remove_small_components(self._vert[z], 50)
             if not np.array_equal(before, self._vert[z]):
@@ -142,12 +152,18 @@ class DeviceBatchAssembler:
             raise ValueError("all volumes of one assembler must share the slice size, got %s" % sorted(shapes))
         (self.H, self.W), = shapes
         self._planes = []         # per volume: uint8 tensor [4][Z][H][W] = ct, vert, normal, cam
+        self._L = L = _lib.get()
         for v in self.volumes:
-            v.prefilter()         # component-filter every slice a draw can reach BEFORE the upload: no blocking plane refresh in the training loop
-            host = torch.from_numpy(np.stack([v.ct, v.vert, v.normal, v.cam]))
-            self._planes.append(host.to(self.device))
-            v.dirty.clear()
-        self._L = _lib.get()
+            planes = torch.from_numpy(np.stack([v.ct, v.vert, v.normal, v.cam])).to(self.device)
+            # component filter of EVERY slice on the device, in place on the resident mask plane, before the first draw: the training loop never
+            # touches pixels on the host and never refreshes a plane
+            need = L.size('hv_slice_components_workspace_bytes', v.Z, v.H, v.W)
+            ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            stats = torch.empty(v.Z, 4, dtype=torch.int32, device=self.device)
+            L.call('hv_slice_components_u8', ptr(planes[1]), v.Z, v.H, v.W, 255, 50, ptr(stats), ptr(planes[1]), ptr(ws),
+                   ctypes.c_size_t(need), stream())
+            v.set_slice_table(stats.cpu().numpy())
+            self._planes.append(planes)
 
     def __len__(self):
         return len(self.volumes)
@@ -160,12 +176,6 @@ class DeviceBatchAssembler:
             ring[self._ring_i] = torch.empty(max(nbytes, 4096), dtype=torch.uint8).pin_memory()
         return ring[self._ring_i]
 
-    def _sync_filtered(self, i):
-        v = self.volumes[i]
-        for z in sorted(v.dirty):     # a drawn slice lost small components: refresh that one plane (H*W bytes)
-            self._planes[i][1, z].copy_(torch.from_numpy(v.vert[z]))
-        v.dirty.clear()
-
     def batch(self, indices):
         L = self._L
         B, H, W = len(indices), self.H, self.W
@@ -174,7 +184,6 @@ class DeviceBatchAssembler:
         for b, i in enumerate(indices):
             v = self.volumes[i]
             z, ratio, x1, x2 = v.draw()
-            self._sync_filtered(i)
             min_x, max_x = band_rows(x1, x2, H, v.maxheight)
             if x1 - min_x < 0 or x2 > max_x or max_x > H or min_x < 0:
                 raise ValueError("could not broadcast: vertebra rows [%d, %d] do not fit the band [%d, %d) of a %d-row slice"

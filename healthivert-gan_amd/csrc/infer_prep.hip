@@ -12,11 +12,16 @@ __device__ __forceinline__ int coherent_load(const int* p) { return __hip_atomic
 // Label equivalence (Hawick et al.): L[p] = index of a pixel of the same component with a smaller-or-equal index; "scan" lowers the root of
 // a pixel's tree to the smallest neighbouring label (atomicMin), "analysis" points every pixel at its root; repeat until a scan changes
 // nothing.  Labels live in global memory (64 K pixels x 4 B exceed the LDS) and are read with device-scope loads: the atomics resolve in L2.
-__global__ __launch_bounds__(1024) void slice_components_kernel(const float* __restrict__ label, int H, int W, float value, int min_size,
-                                                                int* __restrict__ Lall, int* __restrict__ Call, int* __restrict__ stats) {
+// T = float (label maps of the inference driver) or unsigned char (the uint8 mask planes of the batch assembler).  keep != NULL: the filtered
+// mask is written back (value where the pixel's component survived, 0 elsewhere; may be the input plane itself: it is read only by the
+// first loop).
+template <typename T>
+__global__ __launch_bounds__(1024) void slice_components_kernel(const T* __restrict__ label, int H, int W, T value, int min_size,
+                                                                int* __restrict__ Lall, int* __restrict__ Call, int* __restrict__ stats,
+                                                                T* keep) {
     __shared__ int changed, s_cnt, s_min, s_max, s_sum;
     const int HW = H * W, tid = threadIdx.x;
-    const float* lab = label + (long long)blockIdx.x * HW;
+    const T* lab = label + (long long)blockIdx.x * HW;
     int* L = Lall + (long long)blockIdx.x * HW;
     int* C = Call + (long long)blockIdx.x * HW;
     for (int p = tid; p < HW; p += 1024) {
@@ -73,11 +78,13 @@ __global__ __launch_bounds__(1024) void slice_components_kernel(const float* __r
     int cnt = 0, rmin = 1 << 30, rmax = -1, rsum = 0;
     for (int p = tid; p < HW; p += 1024) {
         const int l = coherent_load(L + p);
-        if (l >= 0 && coherent_load(C + l) >= min_size) {
+        const bool kept = l >= 0 && coherent_load(C + l) >= min_size;
+        if (kept) {
             const int r = p / W;
             ++cnt; rsum += r;
             rmin = min(rmin, r); rmax = max(rmax, r);
         }
+        if (keep) keep[(long long)blockIdx.x * HW + p] = kept ? value : (T)0;
     }
     if (cnt) { atomicAdd(&s_cnt, cnt); atomicAdd(&s_sum, rsum); atomicMin(&s_min, rmin); atomicMax(&s_max, rmax); }
     __syncthreads();
@@ -96,7 +103,43 @@ extern "C" int hv_slice_components(const float* label, int S, int H, int W, floa
     if ((long long)H * W > (1 << 24)) return HV_ERR_UNSUPPORTED;     // row sums stay below 2^31
     if (!workspace || workspace_bytes < hv_slice_components_workspace_bytes(S, H, W)) return HV_ERR_WORKSPACE;
     int* L = reinterpret_cast<int*>(workspace);
-    hipLaunchKernelGGL(slice_components_kernel, dim3(S), dim3(1024), 0, (hipStream_t)stream, label, H, W, value, min_size, L, L + (long long)S * H * W, stats);
+    hipLaunchKernelGGL(slice_components_kernel<float>, dim3(S), dim3(1024), 0, (hipStream_t)stream, label, H, W, value, min_size, L,
+                       L + (long long)S * H * W, stats, (float*)nullptr);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+extern "C" int hv_slice_components_u8(const void* plane, int S, int H, int W, int value, int min_size, int* stats, void* filtered,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+    if (!plane || !stats || S <= 0 || H <= 0 || W <= 0 || value <= 0 || value > 255) return HV_ERR_ARG;
+    if ((long long)H * W > (1 << 24)) return HV_ERR_UNSUPPORTED;
+    if (!workspace || workspace_bytes < hv_slice_components_workspace_bytes(S, H, W)) return HV_ERR_WORKSPACE;
+    int* L = reinterpret_cast<int*>(workspace);
+    hipLaunchKernelGGL(slice_components_kernel<unsigned char>, dim3(S), dim3(1024), 0, (hipStream_t)stream, (const unsigned char*)plane, H, W,
+                       (unsigned char)value, min_size, L, L + (long long)S * H * W, stats, (unsigned char*)filtered);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+
+// count[s] = number of elements of slice s equal to `value` (the reference's `np.sum(label[:, :, z] == neighbour) > 200` gate on the ORIGINAL
+// labels, eval_3d_sagittal_twostage.py:208,217): one workgroup per slice, integer sums in a fixed order
+__global__ __launch_bounds__(1024) void slice_count_kernel(const float* __restrict__ label, long long per, float value, int* __restrict__ count) {
+    __shared__ int red[16];
+    const float* lab = label + (long long)blockIdx.x * per;
+    int c = 0;
+    for (long long i = threadIdx.x; i < per; i += 1024) c += lab[i] == value ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int k = 0; k < 16; ++k) t += red[k];
+        count[blockIdx.x] = t;
+    }
+}
+extern "C" int hv_slice_count(const float* label, int S, long long per_slice, float value, int* count, void* stream) {
+    if (!label || !count || S <= 0 || per_slice <= 0 || per_slice > (1ll << 30)) return HV_ERR_ARG;
+    hipLaunchKernelGGL(slice_count_kernel, dim3(S), dim3(1024), 0, (hipStream_t)stream, label, per_slice, value, count);
     HV_LAUNCH_CHECK();
     return HV_OK;
 }

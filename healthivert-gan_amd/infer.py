@@ -187,18 +187,23 @@ def process_volume(model, ct_data, label_data, cam_data, vert_id, device, maxhei
     stage_np = stage.numpy()
     for i, vol in enumerate((label_data, ct_data, cam_data)):
         np.copyto(stage_np[i], vol[:, :, nz0:nz1 + 1], casting='unsafe')
-    lab_hws = stage_np[0]
     hws = stage.to(dev, non_blocking=True)
     vols = torch.empty(3, S, H, W, dtype=torch.float32, device=dev)
     L.call('hv_transpose_batched', ptr(hws), ptr(vols), 3, H * W, S, stream())
     st = {'lab': vols[0], 'ct': vols[1], 'cam': vols[2],
           'ratio': torch.tensor([abs(z - centre) / rng_len * 2 for z in zs], dtype=torch.float64, device=dev)}
-    for nb, cond in ((vert_id - 1, vert_id > 8), (vert_id + 1, vert_id < 24)):
-        if not cond:
-            continue
-        sel = (lab_hws == nb).sum(axis=(0, 1)) > 200          # on the ORIGINAL labels, like the reference (:208,:217)
-        if sel.any():
-            _stage_device(model, st, nb, torch.from_numpy(sel.astype(np.int32)).to(dev), maxheight)
+    # the neighbour stages run on the slices where the neighbour has > 200 pixels on the ORIGINAL labels (reference :208,:217): both counts are
+    # taken on the device before the first stage rewrites the label slices (hv_slice_count), one small read-back decides which stages run
+    nbs = [nb for nb, cond in ((vert_id - 1, vert_id > 8), (vert_id + 1, vert_id < 24)) if cond]
+    if nbs:
+        counts = torch.empty(len(nbs), S, dtype=torch.int32, device=dev)
+        for i, nb in enumerate(nbs):
+            L.call('hv_slice_count', ptr(st['lab']), S, ctypes.c_longlong(H * W), ctypes.c_float(float(nb)), ptr(counts[i]), stream())
+        sel = (counts > 200).int()
+        runs = sel.any(dim=1).cpu()
+        for i, nb in enumerate(nbs):
+            if bool(runs[i]):
+                _stage_device(model, st, nb, sel[i].contiguous(), maxheight)
     valid = _stage_device(model, st, vert_id, None, maxheight)
     res = torch.zeros(2, S, H * W, dtype=torch.float32, device=dev)
     per = ctypes.c_longlong(H * W)

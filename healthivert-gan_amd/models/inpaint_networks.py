@@ -409,6 +409,15 @@ class Generator(nn.Module):
             tf[-1][0].record()
         else:
             tf = None
+        self._fine_forward(P, x, mask, ratio, prec, per_sample_mask)
+        if tf is not None:
+            tf[-1][1].record()
+        return P
+
+    def _fine_forward(self, P, x, mask, ratio, prec, per_sample_mask=False):
+        """FineGenerator.forward (reference models/inpaint_networks.py:169-232) over the plan's buffers: reads x, mask, P.coarse_seg, P.x_stage1."""
+        B, _, H, W = x.shape
+        fg, c, a = self.fine_generator, self.cnum, P.a
         ops.gen_input(x, P.coarse_seg, mask, ratio, P.f_in, 1)
         # the dilated-conv branch and the attention branch only share their input: two streams (two branches of the step graph)
         side = E.branch_stream()
@@ -431,9 +440,18 @@ class Generator(nn.Module):
             n.forward(prec)
         ops.copy_channels(Act(P.x_stage1.view(B, H, W, 1)), a['cat17'].slice(c // 2, 1), mode=0)
         P.f_nodes_merge[7].forward(prec); P.f_nodes_merge[8].forward(prec)
-        if tf is not None:
-            tf[-1][1].record()
-        return P
+
+    def fine_forward_graph(self, P, x, mask, slice_ratio):
+        """bench.py: the refinement generator's training forward alone as ONE captured hipGraph over the buffers of plan P (which a full
+        run_forward has filled: coarse outputs, prepared weight tables) -- both branches on their two streams, as inside the step graphs."""
+        prec = ops.precision_id(self.precision)
+        ratio = slice_ratio.to(device=x.device, dtype=torch.float64).contiguous()
+        x = x.contiguous().float(); mask = mask.contiguous().float()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=E.named_stream('capture', x.device), capture_error_mode='thread_local'):
+            self._fine_forward(P, x, mask, ratio, prec)
+        self._fine_graph_keep = (x, mask, ratio)
+        return g
 
     def _tmp_up(self, P, node):
         key = id(node)

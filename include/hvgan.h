@@ -440,7 +440,13 @@ int hv_assemble_batch(const hv_assemble_item* d_items, int B, int H, int W, floa
  * band [min_x, max_x), ori_ct = the quantised slice, mask = rows [min_x, max_x] -- ToTensor / Normalize applied.  ct / cam: [S][H][W] float32 in
  * [0, 256).  selected (or NULL = all): slices this stage runs on.  valid[s] = vertebra present and selected; slices that are not valid get
  * rows that keep the re-compositing in bounds (x1 = x2 = 0, height = H) and zero planes.
- * hv_select_slices: dst[s] = flag[s] ? src[s] : (keep_unflagged ? dst[s] : 0)  -- slices without the vertebra pass a stage unchanged. */
+ * hv_select_slices: dst[s] = flag[s] ? src[s] : (keep_unflagged ? dst[s] : 0)  -- slices without the vertebra pass a stage unchanged.
+ * hv_slice_components_u8: the same component filter on a uint8 mask plane [S][H][W] (pixels == value, 1..255) -- the loader's
+ * remove_small_connected_components on a drawn slice (data/aligned_dataset.py:16-31,:186-188) for every slice of a resident volume at once;
+ * filtered (NULL, or [S][H][W], may be `plane` itself) receives the mask without the dropped components; stats as above
+ * (count / first row / last row feed the loader's slice acceptance test and band rows, aligned_dataset.py:126-146,:198-226).
+ * hv_slice_count: count[s] = number of elements of slice s ([S][per_slice] floats) equal to value -- the `> 200 pixels of the neighbour on the
+ * original labels` gate of the volume driver (eval_3d_sagittal_twostage.py:208,217). */
 size_t hv_slice_components_workspace_bytes(int S, int H, int W);
 int hv_slice_components(const float* label, int S, int H, int W, float value, int min_size, int* stats, void* workspace,
                         size_t workspace_bytes, void* stream);
@@ -448,6 +454,9 @@ int hv_infer_prepare(const float* ct, const float* cam, const int* stats, const 
                      float* ct_masked, float* ori_ct, float* mask, float* cam_out, long long* x1, long long* x2, long long* height,
                      int* valid, void* stream);
 int hv_select_slices(const int* flag, const float* src, float* dst, int S, long long per_slice, int keep_unflagged, void* stream);
+int hv_slice_components_u8(const void* plane /* uint8 */, int S, int H, int W, int value, int min_size, int* stats, void* filtered /* uint8 */,
+                           void* workspace, size_t workspace_bytes, void* stream);
+int hv_slice_count(const float* label, int S, long long per_slice, float value, int* count, void* stream);
 
 #ifdef __cplusplus
 }

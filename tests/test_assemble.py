@@ -185,3 +185,61 @@ def test_sagittal_and_coronal_feed_at_512_drives_train_steps(monkeypatch):
     losses = model.get_current_losses()
     assert all(np.isfinite(v) for v in losses.values()), losses
     assert model.real_B.shape[-2:] == (512, 512) and sum(model.overflow_steps().values()) == 0
+
+
+@pytest.mark.gpu
+def test_component_filter_of_a_resident_volume_runs_on_the_device():
+    """Row f1's residue: the loader's remove_small_connected_components (data/aligned_dataset.py:16-31) for every slice of a volume at once
+    (hv_slice_components_u8, in place on the uint8 mask plane).  Against scipy.ndimage.label on slices with specks, 8-connected diagonal
+    chains and a spiral: the filtered planes byte for byte, and the per-slice table (count, first row, last row) the draw reads."""
+    import ctypes
+    from test_infer_gpu import _blob_slices
+    import hvgan  # noqa: F401
+    from hvgan import lib
+    from hvgan.lib import ptr, stream
+    from hvgan.batch_assembly import VertebraVolume, DeviceBatchAssembler, _remove_small_components
+    L = lib.get()
+    dev = torch.device('cuda:0')
+    S, H, W = 7, 128, 96
+    blobs = _blob_slices(5, S, H, W, 20.0)                     # [S][H][W] labels, specks below 50 pixels among them
+    plane = ((blobs == 20.0) * 255).astype(np.uint8)
+    exp = np.stack([_remove_small_components((plane[s] > 0).astype(np.float64), 50) for s in range(S)])
+    assert (exp.sum(axis=(1, 2)) < (plane > 0).sum(axis=(1, 2))).any(), 'the case must contain components the filter drops'
+    d = torch.from_numpy(plane).to(dev)
+    need = L.size('hv_slice_components_workspace_bytes', S, H, W)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    stats = torch.full((S, 4), -7, dtype=torch.int32, device=dev)
+    out = torch.full_like(d, 9)
+    L.call('hv_slice_components_u8', ptr(d), S, H, W, 255, 50, ptr(stats), ptr(out), ptr(ws), ctypes.c_size_t(need), stream())
+    assert np.array_equal(out.cpu().numpy(), (exp * 255).astype(np.uint8))
+    L.call('hv_slice_components_u8', ptr(d), S, H, W, 255, 50, ptr(stats), ptr(d), ptr(ws), ctypes.c_size_t(need), stream())      # in place
+    assert torch.equal(d, out)
+    got = stats.cpu().numpy()
+    for s in range(S):
+        rows = np.flatnonzero(exp[s].any(axis=1))
+        assert list(got[s][:3]) == [int(exp[s].sum()), int(rows.min()) if rows.size else -1, int(rows.max()) if rows.size else -1], s
+    # through the assembler: a volume [H][W][Z] whose vertebra 20 carries those shapes -> device table == host mirror for every slice,
+    # resident mask plane == host-filtered plane, and no scipy call after construction
+    label = np.moveaxis(blobs, 0, 2).astype(np.float64)
+    ct = np.random.RandomState(0).randint(0, 255, label.shape).astype(np.float64)
+    cam = np.random.RandomState(1).rand(*label.shape)
+    v_dev, v_host = (VertebraVolume(ct, label, cam, 20, ['21']) for _ in range(2))
+    asm = DeviceBatchAssembler([v_dev], 'cuda:0')
+    for z in range(S):
+        assert v_dev._info[z] == v_host.slice_info(z), z
+    assert np.array_equal(asm._planes[0][1].cpu().numpy(), v_host.vert)
+    import scipy.ndimage
+    real = scipy.ndimage.label
+
+    def refuse(*a, **k):
+        raise AssertionError('the training loop called scipy.ndimage.label')
+    scipy.ndimage.label = refuse
+    try:
+        v_dev.maxheight = H            # accept any vertebra height: this case is about the filter, not the band
+        np.random.seed(3)
+        b = asm.batch([0, 0, 0])
+        torch.cuda.synchronize()
+    finally:
+        scipy.ndimage.label = real
+    for j, z in enumerate(b['slice']):
+        assert np.array_equal((b['A_mask'][j, 0].cpu().numpy() * 255).astype(np.uint8), v_host.vert[z])

@@ -223,6 +223,25 @@ def test_slice_components_match_scipy():
             assert list(got[s]) == [int(v) for v in exp], (S, s, got[s], exp)
 
 
+def test_slice_count_matches_numpy():
+    """hv_slice_count: the `np.sum(label[:, :, z] == neighbour)` of the volume driver (eval_3d_sagittal_twostage.py:208,217), exact integers."""
+    import ctypes
+    import numpy as np
+    import hvgan  # noqa: F401
+    from hvgan import lib
+    from hvgan.lib import ptr, stream
+    L = lib.get()
+    dev = torch.device('cuda:0')
+    rng = np.random.RandomState(4)
+    for S, per in ((51, 256 * 256), (3, 1000), (1, 1)):
+        lab = rng.randint(8, 12, (S, per)).astype(np.float32)
+        lab[0] = 3.0                                                     # a slice without the value
+        d = torch.from_numpy(lab).to(dev)
+        cnt = torch.full((S,), -1, dtype=torch.int32, device=dev)
+        L.call('hv_slice_count', ptr(d), S, ctypes.c_longlong(per), ctypes.c_float(9.0), ptr(cnt), stream())
+        assert np.array_equal(cnt.cpu().numpy(), (lab == 9.0).sum(axis=1).astype(np.int32))
+
+
 def test_infer_prepare_matches_reference_network_inputs():
     """hv_slice_components + hv_infer_prepare on the G10 slices as one batch: the generator's input planes equal what the reference's
     run_model fed its network, bit for bit; rows / height / presence flags too."""
