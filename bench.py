@@ -234,12 +234,13 @@ def inference_record(dev, precision):
     net.to(dev).eval()
     net.precision = precision
     ct, label, cam = synth.make_volume(nz=64, size=256, seed=2)
+    cam255 = cam * 255          # the reference scales the attention map where it loads the file (eval_3d_sagittal_twostage.py:181): input, not path
     for _ in range(2):
-        infer.process_volume(net, ct, label, cam * 255, 20, dev)
+        infer.process_volume(net, ct, label, cam255, 20, dev)
     torch.cuda.synchronize()
     n, t0 = 5, time.perf_counter()
     for _ in range(n):
-        out_ct, out_seg = infer.process_volume(net, ct, label, cam * 255, 20, dev)
+        out_ct, out_seg = infer.process_volume(net, ct, label, cam255, 20, dev)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
     nz = int((out_seg.reshape(-1, out_seg.shape[2]) != 0).any(axis=0).sum())

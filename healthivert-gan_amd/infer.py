@@ -124,13 +124,24 @@ def prepare_slice(cam2d, label2d, ct2d, vert_id, maxheight=40):
 
 
 _PIN = {}
+_POOL = []
 
 
-def _pinned_f32(n):
-    b = _PIN.get('buf')
+def _pinned_f32(n, slot='buf'):
+    b = _PIN.get(slot)
     if b is None or b.numel() < n:
-        b = _PIN['buf'] = torch.empty(n, dtype=torch.float32).pin_memory()
+        b = _PIN[slot] = torch.empty(n, dtype=torch.float32).pin_memory()
     return b[:n]
+
+
+def _parallel(jobs):
+    """Run a few numpy copy / convert jobs side by side (numpy releases the GIL inside them): the float64 <-> float32 slab copies of a
+    volume are three / two independent passes over 3-13 MB each."""
+    if not _POOL:
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL.append(ThreadPoolExecutor(max_workers=3))
+    for f in [_POOL[0].submit(j) for j in jobs]:
+        f.result()
 
 
 def _stage_device(model, st, vert_id, selected, maxheight):
@@ -170,7 +181,13 @@ def process_volume(model, ct_data, label_data, cam_data, vert_id, device, maxhei
     L = _lib.get()
     dev = torch.device(device)
     H, W, Z = label_data.shape
-    zhas = np.flatnonzero((label_data == vert_id).any(axis=(0, 1)))
+    has = [None] * 3                 # z-extent of the vertebra (:186-190): three row bands scanned side by side
+    bands = np.array_split(np.arange(H), 3)
+
+    def scan(i):
+        has[i] = (label_data[bands[i][0]:bands[i][-1] + 1] == vert_id).any(axis=(0, 1)) if len(bands[i]) else np.zeros(Z, dtype=bool)
+    _parallel([lambda i=i: scan(i) for i in range(3)])
+    zhas = np.flatnonzero(has[0] | has[1] | has[2])
     z0, z1 = int(zhas.min()), int(zhas.max())
     rng_len = z1 - z0 + 1
     new_len = int(rng_len * 4 / 5)
@@ -185,8 +202,8 @@ def process_volume(model, ct_data, label_data, cam_data, vert_id, device, maxhei
     # the [H, W, Z] inputs have z fastest: the z-range is cut out as it lies (float32, [H*W][S]) and transposed to slices on the device
     stage = _pinned_f32(3 * H * W * S).view(3, H, W, S)          # one pinned staging buffer: no intermediate copies, asynchronous upload
     stage_np = stage.numpy()
-    for i, vol in enumerate((label_data, ct_data, cam_data)):
-        np.copyto(stage_np[i], vol[:, :, nz0:nz1 + 1], casting='unsafe')
+    _parallel([(lambda i=i, vol=vol: np.copyto(stage_np[i], vol[:, :, nz0:nz1 + 1], casting='unsafe'))
+               for i, vol in enumerate((label_data, ct_data, cam_data))])
     hws = stage.to(dev, non_blocking=True)
     vols = torch.empty(3, S, H, W, dtype=torch.float32, device=dev)
     L.call('hv_transpose_batched', ptr(hws), ptr(vols), 3, H * W, S, stream())
@@ -211,6 +228,12 @@ def process_volume(model, ct_data, label_data, cam_data, vert_id, device, maxhei
     L.call('hv_select_slices', ptr(valid), ptr(st['lab']), ptr(res[1]), S, per, 0, stream())
     res_hws = torch.empty(2, H * W, S, dtype=torch.float32, device=dev)
     L.call('hv_transpose_batched', ptr(res), ptr(res_hws), 2, S, H * W, stream())
-    res_hws = res_hws.cpu().numpy().reshape(2, H, W, S)
-    out_ct[:, :, nz0:nz1 + 1], out_seg[:, :, nz0:nz1 + 1] = res_hws[0], res_hws[1]
+    back = _pinned_f32(2 * H * W * S, 'back').view(2, H * W, S)      # pinned: the download runs at PCIe speed, no staging copy
+    back.copy_(res_hws, non_blocking=True)
+    torch.cuda.current_stream().synchronize()
+    res_np = back.numpy().reshape(2, H, W, S)
+
+    def put(dst, i):
+        dst[:, :, nz0:nz1 + 1] = res_np[i]
+    _parallel([lambda: put(out_ct, 0), lambda: put(out_seg, 1)])
     return out_ct, out_seg
