@@ -270,3 +270,31 @@ def test_tiled_filter_table_size_is_host_arithmetic():
     for rows, taps, K, want in ((512, 16, 256, 512 * 16 * 256), (20, 9, 48, 32 * 9 * 48), (4, 25, 16, 16 * 25 * 16), (64, 9, 36, 0), (1, 16, 512, 16 * 16 * 512),
                                 (0, 9, 32, 0), (8, 0, 32, 0)):
         assert L.size('hv_weight_tiled_elems', rows, taps, K) == want, (rows, taps, K)
+
+
+def test_attention_scores_are_a_box_filter_on_the_pixel_gram_matrix():
+    """the 3x3 patches of contextual attention are both filters and inputs, so the reference's score matrix
+    (models/inpaint_networks.py:327-344: conv2d of the padded map with its own normalised patches) equals rnorm[l] * sum over the 3x3 offsets t of
+    G[l+t][p+t] with G the Gram matrix of the PIXELS (K = C instead of 9C), and the patch norms are the same sums on G's diagonal.  Held against
+    the oracle's own tensors: the identity is what a blocked attention kernel would start from."""
+    import torch.nn.functional as F
+    from oracle import restate as R
+    torch.manual_seed(0)
+    c, h, w = 8, 6, 10
+    L = h * w
+    fd = torch.randn(1, c, h, w)
+    wp = R._patches(fd, 3, 1)
+    norm = torch.sqrt((wp ** 2).sum(dim=(2, 3, 4))).reshape(L)
+    xp = F.unfold(R._same_pad(fd, 3, 1), kernel_size=3, stride=1)
+    S = torch.bmm((wp / torch.clamp(norm, min=1e-4).view(1, L, 1, 1, 1)).reshape(1, L, -1), xp)[0]
+    px = fd[0].reshape(c, L).t()
+    G = (px @ px.t()).view(h, w, h, w)
+    T = torch.zeros(h, w, h, w)
+    for ty in (-1, 0, 1):
+        for tx in (-1, 0, 1):
+            ys = slice(max(0, -ty), h - max(0, ty)); xs = slice(max(0, -tx), w - max(0, tx))
+            yd = slice(max(0, ty), h + min(0, ty)); xd = slice(max(0, tx), w + min(0, tx))
+            T[ys, xs, ys, xs] += G[yd, xd, yd, xd]
+    T = T.view(L, L)
+    assert (S - T / torch.clamp(norm, min=1e-4).view(L, 1)).abs().max().item() <= 1e-4
+    assert (T.diagonal().sqrt() - norm).abs().max().item() <= 1e-4
