@@ -209,7 +209,12 @@ __global__ __launch_bounds__(256) void thin1_fwd_kernel(const NarrowK p) {
 // v_mfma_f32_16x16x16_f16 -- A = filters [16 channels x 16 taps] from registers, B = the image window: lane (pixel, row r) loads the four
 // consecutive input pixels of filter row r -- a wave turns 16 pixels x 64 channels into 4 MFMAs, and the lane's four accumulators are four
 // consecutive channels of one pixel (one 16-byte store).  One workgroup = one output row; a wave takes 16-pixel groups.
+// ST = true (fp16 output, 64 channels, no accumulate form, 16-byte aligned channel rows): a wave's 16 pixels x 64 channels leave through a 2-KB LDS
+// image as whole 16-byte pieces -- one contiguous 2 KB per group instead of sixteen 8-byte-per-lane stores that each touch a quarter of 16 lines.
+template <bool ST>
 __global__ __launch_bounds__(256) void stem1_mfma_kernel(const NarrowK p, const _Float16* __restrict__ wh) {
+    constexpr int LDT = 64 + 8;                       // halfs per staged pixel row (144 B)
+    __shared__ __attribute__((aligned(16))) _Float16 stg[ST ? 4 * 16 * LDT : 8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
     const int MT = p.Cout >> 4;                       // 16-channel tiles (<= 4)
     f16x4 wa[4];
@@ -244,6 +249,13 @@ __global__ __launch_bounds__(256) void stem1_mfma_kernel(const NarrowK p, const 
             const f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x16f16(wa[t], xb, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);   // all lanes: MFMA ignores EXEC
             if (ox >= p.Wo) continue;                  // ragged last group: columns past the row end are computed on zeros and not stored
             float o[4];
+            if constexpr (ST) {
+                f16x4 h;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) h[j] = (_Float16)hv_act(acc[j] * p.alpha + bias[t][j], p.act);
+                *reinterpret_cast<f16x4*>(stg + (wave * 16 + n) * LDT + t * 16 + g * 4) = h;
+                continue;
+            }
             const float4 old4 = p.accumulate ? hv_ld4(p.y, yi + t * 16, p.y_half) : make_float4(0.f, 0.f, 0.f, 0.f);
             const float old[4] = {old4.x, old4.y, old4.z, old4.w};
 #pragma unroll
@@ -254,6 +266,19 @@ __global__ __launch_bounds__(256) void stem1_mfma_kernel(const NarrowK p, const 
                 o[j] = p.accumulate == 1 ? old[j] + v : v;
             }
             hv_st4(p.y, yi + t * 16, make_float4(o[0], o[1], o[2], o[3]), p.y_half);
+        }
+        if constexpr (ST) {
+            // the wave's own 16 x 64 image (written and read by this wave only: no workgroup barrier)
+            __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the LDS stores above have landed
+            __builtin_amdgcn_wave_barrier();
+            _Float16* yb = reinterpret_cast<_Float16*>(p.y);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int q = lane + 64 * k, px = q >> 3, c8 = q & 7;
+                const hv_u32x4 v = *reinterpret_cast<const hv_u32x4*>(stg + (wave * 16 + px) * LDT + c8 * 8);
+                if (ox0 + px < p.Wo) *reinterpret_cast<hv_u32x4*>(yb + ((long long)row * p.Wo + ox0 + px) * p.y_ld + p.y_coff + c8 * 8) = v;
+            }
+            __builtin_amdgcn_wave_barrier();             // the next group's stores come after these reads
         }
     }
 }
@@ -510,8 +535,15 @@ int hv_conv2d_thin_in(const hv_conv_desc* d, hipStream_t s) {
     static const int stem_mfma = getenv("HV_STEM_MFMA") ? atoi(getenv("HV_STEM_MFMA")) : 1;   // A/B knob
     if (stem_mfma && d->precision == HV_F16 && d->w_f16 && (d->Cout & 15) == 0 && !((uintptr_t)d->w_f16 & 7) && (long long)d->B * d->Ho < (1ll << 31)) {
         hv_path_note = 4;
+        static const int stem_st = getenv("HV_STEM_ST") ? atoi(getenv("HV_STEM_ST")) : 1;   // A/B knob
+        if (stem_st && d->y_f16 && d->Cout == 64 && !d->accumulate && !(d->y_ld & 7) && !(d->y_coff & 7) && !((uintptr_t)d->y & 15)) {
+            HV_KNAME("stem1_mfma_kernel<true>");
+            hipLaunchKernelGGL(stem1_mfma_kernel<true>, dim3(d->B * d->Ho), dim3(256), 0, s, k, reinterpret_cast<const _Float16*>(d->w_f16));
+            HV_LAUNCH_CHECK();
+            return HV_OK;
+        }
         HV_KNAME("stem1_mfma_kernel");
-        hipLaunchKernelGGL(stem1_mfma_kernel, dim3(d->B * d->Ho), dim3(256), 0, s, k, reinterpret_cast<const _Float16*>(d->w_f16));
+        hipLaunchKernelGGL(stem1_mfma_kernel<false>, dim3(d->B * d->Ho), dim3(256), 0, s, k, reinterpret_cast<const _Float16*>(d->w_f16));
         HV_LAUNCH_CHECK();
         return HV_OK;
     }

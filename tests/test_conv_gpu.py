@@ -542,10 +542,12 @@ def test_conv_one_channel_stem_mfma(case):
     wf = ohwi(w)
     ya = ops.Act.empty(B, ref.shape[2], ref.shape[3], Cout, dev(), dtype=torch.float16)
     ops.conv2d(to_act(x), wf, ya, 4, s, 1, 1, bias=b.to(dev()), act=act, precision='fp16', w_h=wf.half())
-    assert (lib.get().cdll.hv_last_kernel_name() or b'').decode() == 'stem1_mfma_kernel'
+    # 64 channels, fp16 output: the form whose tiles leave through LDS as 16-byte pieces (ragged row ends in the 70 x 50 case)
+    assert (lib.get().cdll.hv_last_kernel_name() or b'').decode() == ('stem1_mfma_kernel<true>' if Cout == 64 else 'stem1_mfma_kernel')
     torch.cuda.synchronize()
     assert maxerr(from_act(ya), ref) <= 4e-3 * max(1.0, ref.abs().max().item())
     ops.conv2d(to_act(x), wf, ya, 4, s, 1, 1, bias=b.to(dev()), act=act, accumulate=1, precision='fp16', w_h=wf.half())
+    assert (lib.get().cdll.hv_last_kernel_name() or b'').decode() == 'stem1_mfma_kernel'
     torch.cuda.synchronize()
     assert maxerr(from_act(ya), 2 * ref) <= 8e-3 * max(1.0, ref.abs().max().item())
 
