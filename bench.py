@@ -365,7 +365,7 @@ def main():
     # replayed with nothing else on the GPU.  The two event pairs above are taken around eager launches (one Python / ctypes call per kernel:
     # the host can be the bound); this one is the device time of the ~65 kernels
     fine_graph = None
-    if rank == 0 and not args.serial and model.use_graph and getattr(model, '_gplan', None) is not None:
+    if world == 1 and not args.serial and model.use_graph and getattr(model, '_gplan', None) is not None:
         try:
             torch.cuda.synchronize()
             cam_t = model._buf('cam_temp', model.CAM)

@@ -71,7 +71,7 @@ extern "C" int hv_transpose_batched(const float* src, float* dst, int B, int R, 
 // the transposed tile.  KS x KS taps, stride ST, pad 1 (3x3 / 1 on the down-sampled map, 4x4 / 2 on the full map).
 template <int KS, int ST, typename OT = float, typename ST_ = float>       // OT = _Float16: both copies written as fp16 (operands of the batched GEMMs only); ST_: storage of the source map
 __global__ __launch_bounds__(256) void ca_patch_tile_kernel(const ST_* __restrict__ src, OT* __restrict__ lt, OT* __restrict__ tl,
-                                                            int Hs, int Ws, int w, int L, int C, int s_ld) {
+                                                            int Hs, int Ws, int w, int L, int C, int s_ld, _Float16* __restrict__ lt_h) {
     __shared__ float tile[64][65];
     constexpr int T = KS * KS;
     const int t = threadIdx.x, l0 = blockIdx.x * 64, tap = blockIdx.y % T, c0 = (blockIdx.y / T) * 64;
@@ -95,6 +95,8 @@ __global__ __launch_bounds__(256) void ca_patch_tile_kernel(const ST_* __restric
                 if constexpr (sizeof(OT) == 2) *reinterpret_cast<f16x4*>(lt + ((b * L + l) * T + tap) * C + c) = (f16x4){(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
                 else *reinterpret_cast<float4*>(lt + ((b * L + l) * T + tap) * C + c) = v;
             }
+            // the same rows once more as fp16: the operand copy of the batched GEMMs (same rounding as their staging of an fp32 operand)
+            if (lt_h) *reinterpret_cast<f16x4*>(lt_h + ((b * L + l) * T + tap) * C + c) = (f16x4){(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
         }
         tile[ll][(t & 15) * 4 + 0] = v.x; tile[ll][(t & 15) * 4 + 1] = v.y; tile[ll][(t & 15) * 4 + 2] = v.z; tile[ll][(t & 15) * 4 + 3] = v.w;
     }
@@ -112,9 +114,10 @@ static bool ca_tile_ok(const float* src, int C, int s_ld, const float* lt) {
     return enabled && (C & 3) == 0 && (s_ld & 3) == 0 && !((uintptr_t)src & 15) && !((uintptr_t)lt & 15);
 }
 
-extern "C" int hv_ca_patches(const void* f, int f_f16, int B, int H, int W, int C, int f_ld, float* fd, float* wp, float* wpT, float* norm,
-                             float* rnorm, void* stream) {
+static int ca_patches_impl(const void* f, int f_f16, int B, int H, int W, int C, int f_ld, float* fd, float* wp, float* wpT, float* norm,
+                           float* rnorm, _Float16* wp_h, void* stream) {
     if (!f || !fd || !wp || !norm || !rnorm || B <= 0 || H <= 0 || W <= 0 || C <= 0 || ((H | W) & 1) || f_ld < C) return HV_ERR_ARG;
+    if (wp_h && (!(ca_tile_ok(fd, C, C, wp) && B <= 65535) || ((uintptr_t)wp_h & 7))) return HV_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     const int h = H / 2, w = W / 2;
     long long n = (long long)B * h * w * C;
@@ -122,7 +125,7 @@ extern "C" int hv_ca_patches(const void* f, int f_f16, int B, int H, int W, int 
     HV_LAUNCH_CHECK();
     n *= 9;
     if (ca_tile_ok(fd, C, C, wp) && B <= 65535)    // wpT layout: [b][(tap, c)][l] -- as [c][tap][l] it would need c outermost: only wp here, wpT below
-        hipLaunchKernelGGL((ca_patch_tile_kernel<3, 1>), dim3(hv_cdiv(h * w, 64), 9 * hv_cdiv(C, 64), B), dim3(256), 0, s, fd, wp, (float*)nullptr, h, w, w, h * w, C, C);
+        hipLaunchKernelGGL((ca_patch_tile_kernel<3, 1>), dim3(hv_cdiv(h * w, 64), 9 * hv_cdiv(C, 64), B), dim3(256), 0, s, fd, wp, (float*)nullptr, h, w, w, h * w, C, C, wp_h);
     else
         hipLaunchKernelGGL(ca_wp_kernel, dim3(at_grid(n)), dim3(256), 0, s, fd, wp, (float*)nullptr, h, w, C, n);
     HV_LAUNCH_CHECK();
@@ -134,12 +137,21 @@ extern "C" int hv_ca_patches(const void* f, int f_f16, int B, int H, int W, int 
     HV_LAUNCH_CHECK();
     return HV_OK;
 }
+extern "C" int hv_ca_patches(const void* f, int f_f16, int B, int H, int W, int C, int f_ld, float* fd, float* wp, float* wpT, float* norm,
+                             float* rnorm, void* stream) {
+    return ca_patches_impl(f, f_f16, B, H, W, C, f_ld, fd, wp, wpT, norm, rnorm, nullptr, stream);
+}
+extern "C" int hv_ca_patches_h(const void* f, int f_f16, int B, int H, int W, int C, int f_ld, float* fd, float* wp, void* wp_h, float* norm,
+                               float* rnorm, void* stream) {
+    if (!wp_h) return HV_ERR_ARG;
+    return ca_patches_impl(f, f_f16, B, H, W, C, f_ld, fd, wp, nullptr, norm, rnorm, (_Float16*)wp_h, stream);
+}
 extern "C" int hv_ca_raw_patches(const float* f, int B, int H, int W, int C, int f_ld, float* raw, float* rawT, void* stream) {
     if (!f || (!raw && !rawT) || B <= 0 || H <= 0 || W <= 0 || C <= 0 || ((H | W) & 1) || f_ld < C) return HV_ERR_ARG;
     const long long n = (long long)B * C * 16 * (H / 2) * (W / 2);
     if (ca_tile_ok(f, C, f_ld, raw) && B <= 65535)
         hipLaunchKernelGGL((ca_patch_tile_kernel<4, 2>), dim3(hv_cdiv((H / 2) * (W / 2), 64), 16 * hv_cdiv(C, 64), B), dim3(256), 0, (hipStream_t)stream,
-                           f, raw, rawT, H, W, W / 2, (H / 2) * (W / 2), C, f_ld);
+                           f, raw, rawT, H, W, W / 2, (H / 2) * (W / 2), C, f_ld, (_Float16*)nullptr);
     else
         hipLaunchKernelGGL(ca_raw_kernel, dim3(at_grid(n)), dim3(256), 0, (hipStream_t)stream, f, raw, rawT, H, W, C, f_ld, n);
     HV_LAUNCH_CHECK();
@@ -153,10 +165,10 @@ extern "C" int hv_ca_raw_patches_f16(const void* f, int f_f16, int B, int H, int
     const dim3 grid(hv_cdiv((H / 2) * (W / 2), 64), 16 * hv_cdiv(C, 64), B);
     if (f_f16)
         hipLaunchKernelGGL((ca_patch_tile_kernel<4, 2, _Float16, _Float16>), grid, dim3(256), 0, (hipStream_t)stream, (const _Float16*)f, (_Float16*)raw_h,
-                           (_Float16*)rawT_h, H, W, W / 2, (H / 2) * (W / 2), C, f_ld);
+                           (_Float16*)rawT_h, H, W, W / 2, (H / 2) * (W / 2), C, f_ld, (_Float16*)nullptr);
     else
     hipLaunchKernelGGL((ca_patch_tile_kernel<4, 2, _Float16>), grid, dim3(256), 0, (hipStream_t)stream,
-                       (const float*)f, (_Float16*)raw_h, (_Float16*)rawT_h, H, W, W / 2, (H / 2) * (W / 2), C, f_ld);
+                       (const float*)f, (_Float16*)raw_h, (_Float16*)rawT_h, H, W, W / 2, (H / 2) * (W / 2), C, f_ld, (_Float16*)nullptr);
     HV_LAUNCH_CHECK();
     return HV_OK;
 }
@@ -405,14 +417,15 @@ extern "C" int hv_ca_fuse(const float* S, float* out, int B, int h, int w, int a
 }
 
 // ---- masked scaled softmax over l (one 256-thread block per row) -------------------------------------
-__global__ __launch_bounds__(256) void ca_softmax_kernel(const float* __restrict__ S, const float* __restrict__ mm, float* __restrict__ A, int L,
+template <typename AT = float>       // AT = _Float16: the attention matrix stored as fp16 (the GEMM route: its consumers are the batched GEMMs and the soft-max backward)
+__global__ __launch_bounds__(256) void ca_softmax_kernel(const float* __restrict__ S, const float* __restrict__ mm, AT* __restrict__ A, int L,
                                                          float scale, int* __restrict__ argmax, long long mm_bs) {
     __shared__ float red[8];
     __shared__ int redi[8];
     const long long row = blockIdx.x;
     mm += (row / L) * mm_bs;           // per-sample masks (hv_ca_softmax_batched) or one shared mask (stride 0)
     const float* s = S + row * L;
-    float* a = A + row * L;
+    AT* a = A + row * L;
     const int tid = threadIdx.x;
     if (L <= 2048 && (L & 255) == 0) {   // the row fits the workgroup's registers: S is read once instead of three times
         const int ept = L >> 8;
@@ -440,7 +453,7 @@ __global__ __launch_bounds__(256) void ca_softmax_kernel(const float* __restrict
         for (int k = 0; k < 8; ++k)
             if (k < ept) {
                 const float o = v[k] / sum * m[k];
-                a[tid + k * 256] = o;
+                a[tid + k * 256] = (AT)o;
                 if (o > best) { best = o; bi = tid + k * 256; }
             }
         if (argmax) {
@@ -478,7 +491,7 @@ __global__ __launch_bounds__(256) void ca_softmax_kernel(const float* __restrict
     int bi = 0x7fffffff;
     for (int l = tid; l < L; l += 256) {
         const float v = expf(s[l] * mm[l] * scale - mx) / sum * mm[l];
-        a[l] = v;
+        a[l] = (AT)v;
         if (v > best) { best = v; bi = l; }
     }
     if (argmax) {  // first index of the maximum (torch.argmax tie rule on CPU)
@@ -500,14 +513,20 @@ __global__ __launch_bounds__(256) void ca_softmax_kernel(const float* __restrict
 }
 extern "C" int hv_ca_softmax(const float* S, const float* mm, float* A, int B, int L, float scale, int* argmax, void* stream) {
     if (!S || !mm || !A || B <= 0 || L <= 0) return HV_ERR_ARG;
-    hipLaunchKernelGGL(ca_softmax_kernel, dim3(B * L), dim3(256), 0, (hipStream_t)stream, S, mm, A, L, scale, argmax, 0ll);
+    hipLaunchKernelGGL(ca_softmax_kernel<float>, dim3(B * L), dim3(256), 0, (hipStream_t)stream, S, mm, A, L, scale, argmax, 0ll);
     HV_LAUNCH_CHECK();
     return HV_OK;
 }
 extern "C" int hv_ca_softmax_batched(const float* S, const float* mm, long long mm_bstride, float* A, int B, int L, float scale, int* argmax,
                                      void* stream) {
     if (!S || !mm || !A || B <= 0 || L <= 0 || mm_bstride < 0) return HV_ERR_ARG;
-    hipLaunchKernelGGL(ca_softmax_kernel, dim3(B * L), dim3(256), 0, (hipStream_t)stream, S, mm, A, L, scale, argmax, mm_bstride);
+    hipLaunchKernelGGL(ca_softmax_kernel<float>, dim3(B * L), dim3(256), 0, (hipStream_t)stream, S, mm, A, L, scale, argmax, mm_bstride);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+extern "C" int hv_ca_softmax_f16(const float* S, const float* mm, long long mm_bstride, void* A_h, int B, int L, float scale, int* argmax, void* stream) {
+    if (!S || !mm || !A_h || B <= 0 || L <= 0 || mm_bstride < 0) return HV_ERR_ARG;
+    hipLaunchKernelGGL(ca_softmax_kernel<_Float16>, dim3(B * L), dim3(256), 0, (hipStream_t)stream, S, mm, (_Float16*)A_h, L, scale, argmax, mm_bstride);
     HV_LAUNCH_CHECK();
     return HV_OK;
 }
@@ -516,32 +535,39 @@ extern "C" int hv_ca_softmax_batched(const float* S, const float* mm, long long 
 // 4-wave workgroup per CU, and the tile loop (15 four-byte loads, 15 LDS stores, 36 LDS reads per lane and tile) is then fully exposed; the two
 // separate kernels run at 8 workgroups per CU and the extra 128 MB round trip of the fused scores costs less than that.)
 // dS[p][l] = scale*mm[l]*A[p][l]*(dA[p][l] - sum_l' dA[p][l']*A[p][l'])   (A already carries the mask)
-__global__ __launch_bounds__(256) void ca_softmax_bwd_kernel(const float* __restrict__ dA, const float* __restrict__ A, const float* __restrict__ mm,
+template <typename AT = float>
+__global__ __launch_bounds__(256) void ca_softmax_bwd_kernel(const float* __restrict__ dA, const AT* __restrict__ A, const float* __restrict__ mm,
                                                              float* __restrict__ dS, int L, float scale) {
     __shared__ float red[20];
     const long long row = blockIdx.x;
-    const float* a = A + row * L;
+    const AT* a = A + row * L;
     const float* g = dA + row * L;
     float dot = 0.f;
-    for (int l = threadIdx.x; l < L; l += 256) dot += g[l] * a[l];
+    for (int l = threadIdx.x; l < L; l += 256) dot += g[l] * (float)a[l];
     dot = hv_block_sum(dot, red);
-    for (int l = threadIdx.x; l < L; l += 256) dS[row * L + l] = scale * mm[l] * a[l] * (g[l] - dot);
+    for (int l = threadIdx.x; l < L; l += 256) dS[row * L + l] = scale * mm[l] * (float)a[l] * (g[l] - dot);
 }
 extern "C" int hv_ca_softmax_backward(const float* dA, const float* A, const float* mm, float* dS, int B, int L, float scale, void* stream) {
     if (!dA || !A || !mm || !dS || B <= 0 || L <= 0) return HV_ERR_ARG;
-    hipLaunchKernelGGL(ca_softmax_bwd_kernel, dim3(B * L), dim3(256), 0, (hipStream_t)stream, dA, A, mm, dS, L, scale);
+    hipLaunchKernelGGL(ca_softmax_bwd_kernel<float>, dim3(B * L), dim3(256), 0, (hipStream_t)stream, dA, A, mm, dS, L, scale);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+extern "C" int hv_ca_softmax_backward_f16(const float* dA, const void* A_h, const float* mm, float* dS, int B, int L, float scale, void* stream) {
+    if (!dA || !A_h || !mm || !dS || B <= 0 || L <= 0) return HV_ERR_ARG;
+    hipLaunchKernelGGL(ca_softmax_bwd_kernel<_Float16>, dim3(B * L), dim3(256), 0, (hipStream_t)stream, dA, (const _Float16*)A_h, mm, dS, L, scale);
     HV_LAUNCH_CHECK();
     return HV_OK;
 }
 
 // ---- batched transpose (32x32 LDS tiles) ----------------------------------------------------------------
-template <typename OT = float>
-__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, OT* __restrict__ dst, int R, int C) {
+template <typename OT = float, typename IT = float>
+__global__ __launch_bounds__(256) void transpose_kernel(const IT* __restrict__ src, OT* __restrict__ dst, int R, int C) {
     __shared__ float t[32][33];
     const long long b = blockIdx.z;
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int k = ty; k < 32; k += 8)
-        if (r0 + k < R && c0 + tx < C) t[k][tx] = src[(b * R + r0 + k) * C + c0 + tx];
+        if (r0 + k < R && c0 + tx < C) t[k][tx] = (float)src[(b * R + r0 + k) * C + c0 + tx];
     __syncthreads();
     for (int k = ty; k < 32; k += 8)
         if (c0 + k < C && r0 + tx < R) dst[(b * C + c0 + k) * R + r0 + tx] = (OT)t[tx][k];
@@ -555,6 +581,14 @@ extern "C" int hv_transpose_batched(const float* src, float* dst, int B, int R, 
 extern "C" int hv_transpose_batched_f16(const float* src, void* dst_h, int B, int R, int C, void* stream) {      // the transpose stored as fp16
     if (!src || !dst_h || B <= 0 || R <= 0 || C <= 0) return HV_ERR_ARG;
     hipLaunchKernelGGL(transpose_kernel<_Float16>, dim3(hv_cdiv(C, 32), hv_cdiv(R, 32), B), dim3(256), 0, (hipStream_t)stream, src, (_Float16*)dst_h, R, C);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+
+extern "C" int hv_transpose_batched_h2h(const void* src_h, void* dst_h, int B, int R, int C, void* stream) {        // fp16 in, fp16 out (exact)
+    if (!src_h || !dst_h || B <= 0 || R <= 0 || C <= 0) return HV_ERR_ARG;
+    hipLaunchKernelGGL((transpose_kernel<_Float16, _Float16>), dim3(hv_cdiv(C, 32), hv_cdiv(R, 32), B), dim3(256), 0, (hipStream_t)stream, (const _Float16*)src_h,
+                       (_Float16*)dst_h, R, C);
     HV_LAUNCH_CHECK();
     return HV_OK;
 }

@@ -392,6 +392,7 @@ def conv_backward_chain(nodes, book, prec, tmp_full=None, premultiplied_first=Fa
 
 # ================================================================================================ contextual attention
 CA_F16_IO = os.environ.get('HV_CA_F16_IO', '1') != '0'   # the attention block's boundary kernels read / write fp16-stored maps themselves (A/B knob)
+CA_F16_COPIES = os.environ.get('HV_CA_F16_COPIES', '1') != '0'   # GEMM route: fp16 operand copies written by their producers (wp_h, A as fp16 only); A/B knob
 CA_GEMM = os.environ.get('HV_CA_GEMM', '1') != '0'     # fp16 mode: the attention block's five contractions as batched NT GEMMs (csrc/bgemm.hip)
 
 
@@ -446,12 +447,21 @@ class AttentionPlan:
         if gemm:
             # GEMM route: the patch tables that are only GEMM operands are stored as fp16 (half the bytes through the vector memory path, no
             # conversion when staged); wp stays fp32 (norms, the patch gradient's coefficient term), its transpose is written as fp16
+            # Round 3: the copies are written by their PRODUCERS -- wp_h beside wp by the patch kernel, the attention matrix as fp16 only by the
+            # soft-max (HV_CA_F16_COPIES=0: the previous form, fp32 tables converted when a GEMM stages them: same GEMM bits) -- and the transpose of
+            # wp, which only the backward reads, is taken there
             if getattr(self, 'raw_h', None) is None:
                 hz = lambda *s: torch.zeros(*s, dtype=torch.float16, device=f.t.device)
                 self.raw_h, self.rawT_h, self.wpT_h = hz(B, L, 16 * C), hz(B, 16 * C, L), hz(B, 9 * C, L)
                 self.O = torch.zeros(B, L, 16 * C, dtype=torch.float32, device=f.t.device)
-            L_.call('hv_ca_patches', ptr(f.t), f.f16, B, H, W, C, f.ld, ptr(self.fd.t), ptr(self.wp), None, ptr(self.norm), ptr(self.rnorm), stream())
-            L_.call('hv_transpose_batched_f16', ptr(self.wp), ptr(self.wpT_h), B, L, 9 * C, stream())
+                if CA_F16_COPIES:
+                    self.wp_h, self.A_h = hz(B, L, 9 * C), hz(B, L, L)
+            self.f16_copies = CA_F16_COPIES
+            if self.f16_copies:
+                L_.call('hv_ca_patches_h', ptr(f.t), f.f16, B, H, W, C, f.ld, ptr(self.fd.t), ptr(self.wp), ptr(self.wp_h), ptr(self.norm), ptr(self.rnorm), stream())
+            else:
+                L_.call('hv_ca_patches', ptr(f.t), f.f16, B, H, W, C, f.ld, ptr(self.fd.t), ptr(self.wp), None, ptr(self.norm), ptr(self.rnorm), stream())
+                L_.call('hv_transpose_batched_f16', ptr(self.wp), ptr(self.wpT_h), B, L, 9 * C, stream())
             L_.call('hv_ca_raw_patches_f16', ptr(f.t), f.f16, B, H, W, C, f.ld, ptr(self.raw_h), ptr(self.rawT_h), stream())
         else:
             L_.call('hv_ca_patches', ptr(f.t), f.f16, B, H, W, C, f.ld, ptr(self.fd.t), ptr(self.wp), ptr(self.wpT), ptr(self.norm), ptr(self.rnorm), stream())
@@ -463,8 +473,10 @@ class AttentionPlan:
                     self.h, self.w, ptr(self.mm_b), stream())
         else:
             L_.call('hv_ca_mask', ptr(mask_img), self.img_hw[0], self.img_hw[1], self.h, self.w, ptr(self.mm), stream())
+        f16c = gemm and self.f16_copies
         if gemm:    # the 3x3 patches of the (zero-padded) map are both the conv's input columns and its filters: scores = rnorm (.) wp wp^T
-            _bgemm(self.wp, self.wp, self.S0.t, L, L, 9 * C, B, colscale=self.rnorm)
+            wp_op = self.wp_h if f16c else self.wp
+            _bgemm(wp_op, wp_op, self.S0.t, L, L, 9 * C, B, colscale=self.rnorm)
         else:
             ops.conv2d(self.fd, self.wp, self.S0, 3, 1, 1, 1, w_bstride=L * 9 * C, ch_scale=self.rnorm, ch_scale_bstride=L, precision=prec)
         if self.fuse:
@@ -472,14 +484,17 @@ class AttentionPlan:
             s = self.S1
         else:
             s = self.S0
-        if per_sample_mask:
+        if f16c:
+            L_.call('hv_ca_softmax_f16', ptr(s.t), ptr(self.mm_b if per_sample_mask else self.mm), ctypes.c_longlong(L if per_sample_mask else 0),
+                    ptr(self.A_h), B, L, ctypes.c_float(self.scale), ptr(self.argmax) if want_argmax else None, stream())
+        elif per_sample_mask:
             L_.call('hv_ca_softmax_batched', ptr(s.t), ptr(self.mm_b), ctypes.c_longlong(L), ptr(self.A.t), B, L, ctypes.c_float(self.scale),
                     ptr(self.argmax) if want_argmax else None, stream())
         else:
             L_.call('hv_ca_softmax', ptr(s.t), ptr(self.mm), ptr(self.A.t), B, L, ctypes.c_float(self.scale),
                     ptr(self.argmax) if want_argmax else None, stream())
         if gemm:    # paste = (A rawT^T) folded: O[p][(c, tap)], then every output pixel sums the 4 taps that reach it
-            _bgemm(self.A.t, self.rawT_h, self.O, L, 16 * C, L, B, b_split=C)          # rows of rawT [c][tap] taken as (tap, c): O[p][tap][c]
+            _bgemm(self.A_h if f16c else self.A.t, self.rawT_h, self.O, L, 16 * C, L, B, b_split=C)          # rows of rawT [c][tap] taken as (tap, c): O[p][tap][c]
             L_.call('hv_ca_fold', ptr(self.O), ptr(out.t), out.f16, B, H, W, C, out.ld, ctypes.c_float(0.25), 0, stream())
         else:
             ops.conv2d(self.A, self.rawT, out, 4, 2, 1, 1, transposed=True, alpha=0.25, w_bstride=C * 16 * L, precision=prec)
@@ -512,7 +527,10 @@ class AttentionPlan:
                 bw['dOraw_h'], bw['dOrawT_h'], bw['AT_h'] = hz(B, L, 16 * C), hz(B, 16 * C, L), hz(B, L, L)
             L_.call('hv_ca_raw_patches_f16', ptr(dout.t), dout.f16, B, H, W, C, dout.ld, ptr(bw['dOraw_h']), ptr(bw['dOrawT_h']), stream())
             _bgemm(bw['dOraw_h'], self.raw_h, bw['dA'].t, L, L, 16 * C, B, alpha=0.25)
-            L_.call('hv_transpose_batched_f16', ptr(self.A.t), ptr(bw['AT_h']), B, L, L, stream())
+            if self.f16_copies:
+                L_.call('hv_transpose_batched_h2h', ptr(self.A_h), ptr(bw['AT_h']), B, L, L, stream())
+            else:
+                L_.call('hv_transpose_batched_f16', ptr(self.A.t), ptr(bw['AT_h']), B, L, L, stream())
             _bgemm(bw['AT_h'], bw['dOrawT_h'], self.O, L, 16 * C, L, B, b_split=C)      # d(raw patches)[l][tap][c] (the forward's O buffer is free by now)
             L_.call('hv_ca_fold', ptr(self.O), ptr(df.t), df.f16, B, H, W, C, df.ld, ctypes.c_float(0.25), int(bool(accumulate)), stream())
         else:
@@ -522,7 +540,10 @@ class AttentionPlan:
             ops.conv2d(bw['AT'], bw['dOrawT'], df, 4, 2, 1, 1, transposed=True, alpha=0.25, w_bstride=C * 16 * L,
                        accumulate=int(accumulate), precision=prec)
         # through softmax and score fusion
-        L_.call('hv_ca_softmax_backward', ptr(bw['dA'].t), ptr(self.A.t), ptr(self.mm), ptr(bw['dS1'].t), B, L, ctypes.c_float(self.scale), stream())
+        if gemm and self.f16_copies:
+            L_.call('hv_ca_softmax_backward_f16', ptr(bw['dA'].t), ptr(self.A_h), ptr(self.mm), ptr(bw['dS1'].t), B, L, ctypes.c_float(self.scale), stream())
+        else:
+            L_.call('hv_ca_softmax_backward', ptr(bw['dA'].t), ptr(self.A.t), ptr(self.mm), ptr(bw['dS1'].t), B, L, ctypes.c_float(self.scale), stream())
         if self.fuse:
             L_.call('hv_ca_fuse', ptr(bw['dS1'].t), ptr(bw['dS0'].t), B, self.h, self.w, 1, stream())
             ds0 = bw['dS0']
@@ -531,6 +552,8 @@ class AttentionPlan:
         # through the normalised patch matching (patches act as both filters and inputs)
         L_.call('hv_ca_score_backward_prep', ptr(ds0.t), ptr(self.S0.t), ptr(self.norm), ptr(self.rnorm), ptr(bw['Gs'].t), ptr(bw['coef']), B, L, stream())
         if gemm:
+            if self.f16_copies:      # (the transpose of wp has this one reader)
+                L_.call('hv_transpose_batched_f16', ptr(self.wp), ptr(self.wpT_h), B, L, 9 * C, stream())
             _bgemm(bw['Gs'].t, self.wpT_h, bw['dwp'].t, L, 9 * C, L, B)
         else:
             ops.conv2d(bw['Gs'], self.wpT, bw['dwp'], 1, 1, 0, 1, w_bstride=9 * C * L, precision=prec)

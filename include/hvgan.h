@@ -296,6 +296,17 @@ int hv_ca_fold(const float* src, void* dst, int dst_f16 /* storage of dst */, in
 /* fp16-stored forms of two operand producers (same layouts as hv_ca_raw_patches / hv_transpose_batched) */
 int hv_ca_raw_patches_f16(const void* f, int f_f16 /* storage of f */, int B, int H, int W, int C, int f_ld, void* raw_h, void* rawT_h, void* stream);
 int hv_transpose_batched_f16(const float* src, void* dst_h, int B, int R, int C, void* stream);
+/* The GEMM route's fp16 operand copies written by their producers (round 3): hv_ca_patches_h = hv_ca_patches that also stores the [b][l][tap][c] patch
+ * table as fp16 (wp_h: both operands of the score GEMM, same rounding as the GEMM's own staging of an fp32 operand -> same bits);
+ * hv_ca_softmax_f16 = hv_ca_softmax(_batched) with the attention matrix stored as fp16 only (its readers are the paste GEMM, the transpose for the
+ * d(raw patches) GEMM and the soft-max backward; models/inpaint_networks.py:364-381); hv_ca_softmax_backward_f16 reads that matrix;
+ * hv_transpose_batched_h2h: fp16 -> fp16 (exact). */
+int hv_ca_patches_h(const void* f, int f_f16, int B, int H, int W, int C, int f_ld, float* fd, float* wp, void* wp_h, float* norm, float* rnorm,
+                    void* stream);
+int hv_ca_softmax_f16(const float* S, const float* mm, long long mm_bstride /* L: per-sample masks, 0: shared */, void* A_h, int B, int L, float scale,
+                      int* argmax, void* stream);
+int hv_ca_softmax_backward_f16(const float* dA, const void* A_h, const float* mm, float* dS, int B, int L, float scale, void* stream);
+int hv_transpose_batched_h2h(const void* src_h, void* dst_h, int B, int R, int C, void* stream);
 /* Gs[b][i][j] = dS[b][j][i]*rnorm[b][i] + dS[b][i][j]*rnorm[b][j];  coef[b][l] = -(sum_p dS[p][l]*S0[p][l])/norm[l]^2.
  * coef must hold 17*B*L floats: the first B*L are the result, the rest is scratch for the row-chunk partial sums. */
 int hv_ca_score_backward_prep(const float* dS, const float* S0, const float* norm, const float* rnorm, float* Gs, float* coef,
