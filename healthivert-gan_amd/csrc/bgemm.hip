@@ -28,6 +28,7 @@ struct BgemmK {
     int tiles_m, tiles_n, swizzle;
     int b_split;                   // > 0: logical row n = t * b_split + c of B is stored as row c * (N / b_split) + t (see hv_bgemm_nt)
     float alpha;
+    int c_f16;                     // C stored as fp16 (hv_bgemm_nt_h): the product only feeds a fold / a fp16 consumer
 };
 
 // one operand tile's staging: BR rows x 32 k.  fp32 source: 256 threads = 32 rows x 8 float4 per pass, converted when written to LDS;
@@ -129,7 +130,8 @@ __global__ __launch_bounds__(256, 2) void bgemm_nt_kernel(const BgemmK p) {
         if (kt + 1 < nk) lstore(buf ^ 1);
         __syncthreads();
     }
-    float* C = p.C + b * p.sC;
+    float* C = p.C + (p.c_f16 ? 0 : b * p.sC);
+    _Float16* Ch = reinterpret_cast<_Float16*>(p.C) + (p.c_f16 ? b * p.sC : 0);
     const float* cs = p.colscale ? p.colscale + b * p.sS : nullptr;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -141,13 +143,14 @@ __global__ __launch_bounds__(256, 2) void bgemm_nt_kernel(const BgemmK p) {
             if (col >= p.N) continue;                       // N % 4 == 0: a lane's four columns are all inside or all outside
             float4 v = make_float4(acc[n][m][0] * p.alpha, acc[n][m][1] * p.alpha, acc[n][m][2] * p.alpha, acc[n][m][3] * p.alpha);
             if (cs) { const float4 s4 = *reinterpret_cast<const float4*>(cs + col); v.x *= s4.x; v.y *= s4.y; v.z *= s4.z; v.w *= s4.w; }
-            *reinterpret_cast<float4*>(C + (long long)row * p.ldc + col) = v;
+            if (p.c_f16) *reinterpret_cast<f16x4*>(Ch + (long long)row * p.ldc + col) = (f16x4){(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+            else *reinterpret_cast<float4*>(C + (long long)row * p.ldc + col) = v;
         }
     }
 }
 
-extern "C" int hv_bgemm_nt(const void* A, int a_f16, int lda, long long strideA, const void* B, int b_f16, int ldb, long long strideB, float* C, int ldc,
-                           long long strideC, int M, int N, int K, int batch, float alpha, const float* colscale, long long strideS, int b_split, void* stream) {
+static int bgemm_impl(const void* A, int a_f16, int lda, long long strideA, const void* B, int b_f16, int ldb, long long strideB, float* C, int c_f16, int ldc,
+                      long long strideC, int M, int N, int K, int batch, float alpha, const float* colscale, long long strideS, int b_split, void* stream) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || b_split < 0 || (b_split && N % b_split)) return HV_ERR_ARG;
     const int va = a_f16 ? 7 : 3, vb = b_f16 ? 7 : 3;        // 16-byte items: 8 halfs / 4 floats
     if ((K & 31) || (N & 3) || (lda & va) || (ldb & vb) || (ldc & 3) || lda < K || ldb < K || ldc < N) return HV_ERR_UNSUPPORTED;
@@ -157,7 +160,7 @@ extern "C" int hv_bgemm_nt(const void* A, int a_f16, int lda, long long strideA,
     BgemmK k;
     k.A = A; k.B = B; k.C = C; k.colscale = colscale;
     k.sA = strideA; k.sB = strideB; k.sC = strideC; k.sS = strideS;
-    k.lda = lda; k.ldb = ldb; k.ldc = ldc; k.M = M; k.N = N; k.K = K; k.batch = batch; k.alpha = alpha; k.b_split = b_split;
+    k.lda = lda; k.ldb = ldb; k.ldc = ldc; k.M = M; k.N = N; k.K = K; k.batch = batch; k.alpha = alpha; k.b_split = b_split; k.c_f16 = c_f16 ? 1 : 0;
     const int BN = N % 128 == 0 ? 128 : 64;      // N = 576 (the 3x3 patch gradient): nine 64-column tiles instead of a half-empty fifth 128-column one
     k.tiles_m = hv_cdiv(M, 128); k.tiles_n = hv_cdiv(N, BN);
     const long long tiles = (long long)k.tiles_m * k.tiles_n * batch;
@@ -177,6 +180,15 @@ extern "C" int hv_bgemm_nt(const void* A, int a_f16, int lda, long long strideA,
 #undef HV_BG
     HV_LAUNCH_CHECK();
     return HV_OK;
+}
+extern "C" int hv_bgemm_nt(const void* A, int a_f16, int lda, long long strideA, const void* B, int b_f16, int ldb, long long strideB, float* C, int ldc,
+                           long long strideC, int M, int N, int K, int batch, float alpha, const float* colscale, long long strideS, int b_split, void* stream) {
+    return bgemm_impl(A, a_f16, lda, strideA, B, b_f16, ldb, strideB, C, 0, ldc, strideC, M, N, K, batch, alpha, colscale, strideS, b_split, stream);
+}
+extern "C" int hv_bgemm_nt_h(const void* A, int a_f16, int lda, long long strideA, const void* B, int b_f16, int ldb, long long strideB, void* C_h, int ldc,
+                             long long strideC, int M, int N, int K, int batch, float alpha, const float* colscale, long long strideS, int b_split, void* stream) {
+    return bgemm_impl(A, a_f16, lda, strideA, B, b_f16, ldb, strideB, reinterpret_cast<float*>(C_h), 1, ldc, strideC, M, N, K, batch, alpha, colscale, strideS,
+                      b_split, stream);
 }
 
 // fold (col2im) of 4x4 stride-2 pad-1 patches: src[b][p][tap][c] (p over the (H/2) x (W/2) patch grid, tap = r*4 + s) ->
@@ -209,8 +221,106 @@ __global__ __launch_bounds__(256) void ca_fold_kernel(const float* __restrict__ 
     }
 }
 
+// The same on 8-channel pieces (16 bytes of an fp16 source / destination per access), integer index arithmetic, the four taps' loads issued before the
+// first add: the element-wise kernel above pays three 64-bit divisions and four 4-byte loads per output element (24 us for 67 MB at bs 16).  Same
+// summation order per element: with an fp32 source the same bits.
+template <bool SH, bool DH>
+__global__ __launch_bounds__(256) void ca_fold_vec_kernel(const void* __restrict__ src, void* __restrict__ dst, int H, int W, int C, int dst_ld, float alpha,
+                                                          int accumulate, int n) {
+    const int h = H >> 1, w = W >> 1, C8 = C >> 3;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int c = (i % C8) * 8;
+        int r = i / C8;
+        const int x = r % W;
+        r /= W;
+        const int y = r % H, b = r / H;
+        float v[4][8];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int rr = ((y + 1) & 1) + 2 * a, py = (y + 1 - rr) >> 1, ss = ((x + 1) & 1) + 2 * q, px = (x + 1 - ss) >> 1;
+                const bool ok = (unsigned)py < (unsigned)h && (unsigned)px < (unsigned)w;
+                const long long o = ((((long long)b * h + py) * w + px) * 16 + rr * 4 + ss) * C + c;
+                if (SH) {
+                    hv_u32x4 u = {0u, 0u, 0u, 0u};
+                    if (ok) u = *reinterpret_cast<const hv_u32x4*>(reinterpret_cast<const _Float16*>(src) + o);
+                    const f16x8 h8 = __builtin_bit_cast(f16x8, u);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[a * 2 + q][e] = (float)h8[e];
+                } else {
+                    float4 u0 = make_float4(0.f, 0.f, 0.f, 0.f), u1 = u0;
+                    if (ok) { u0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(src) + o); u1 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(src) + o + 4); }
+                    v[a * 2 + q][0] = u0.x; v[a * 2 + q][1] = u0.y; v[a * 2 + q][2] = u0.z; v[a * 2 + q][3] = u0.w;
+                    v[a * 2 + q][4] = u1.x; v[a * 2 + q][5] = u1.y; v[a * 2 + q][6] = u1.z; v[a * 2 + q][7] = u1.w;
+                }
+            }
+        const long long od = (((long long)b * H + y) * W + x) * dst_ld + c;
+        float o8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float s = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) s += v[t][e];      // absent taps are +0: adding them leaves the partial sum's bits (the sum starts at +0 as before)
+            o8[e] = alpha * s;
+        }
+        if (DH) {
+            _Float16* d = reinterpret_cast<_Float16*>(dst) + od;
+            f16x8 h8;
+            if (accumulate) {
+                const f16x8 old = __builtin_bit_cast(f16x8, *reinterpret_cast<const hv_u32x4*>(d));
+#pragma unroll
+                for (int e = 0; e < 8; ++e) h8[e] = (_Float16)((float)old[e] + o8[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) h8[e] = (_Float16)o8[e];
+            }
+            *reinterpret_cast<hv_u32x4*>(d) = __builtin_bit_cast(hv_u32x4, h8);
+        } else {
+            float* d = reinterpret_cast<float*>(dst) + od;
+            float4 a0 = make_float4(o8[0], o8[1], o8[2], o8[3]), a1 = make_float4(o8[4], o8[5], o8[6], o8[7]);
+            if (accumulate) {
+                const float4 p0 = *reinterpret_cast<const float4*>(d), p1 = *reinterpret_cast<const float4*>(d + 4);
+                a0 = make_float4(p0.x + a0.x, p0.y + a0.y, p0.z + a0.z, p0.w + a0.w);
+                a1 = make_float4(p1.x + a1.x, p1.y + a1.y, p1.z + a1.z, p1.w + a1.w);
+            }
+            *reinterpret_cast<float4*>(d) = a0;
+            *reinterpret_cast<float4*>(d + 4) = a1;
+        }
+    }
+}
+static int ca_fold_impl(const void* src, int src_f16, void* dst, int dst_f16, int B, int H, int W, int C, int dst_ld, float alpha, int accumulate, void* stream) {
+    if (!src || !dst || B <= 0 || H <= 0 || W <= 0 || C <= 0 || ((H | W) & 1) || dst_ld < C) return HV_ERR_ARG;
+    const long long n8 = (long long)B * H * W * (C / 8);
+    static const int vec = getenv("HV_CA_FOLD_VEC") ? atoi(getenv("HV_CA_FOLD_VEC")) : 1;      // A/B knob
+    const bool vec_ok = !(C & 7) && !(dst_ld & 7) && !((uintptr_t)src & 15) && !((uintptr_t)dst & 15) && n8 < (1ll << 31);
+    if ((vec || src_f16) && vec_ok) {
+        long long blocks = (n8 + 255) / 256;
+        if (blocks > 65536) blocks = 65536;
+        const dim3 grid((unsigned)blocks);
+        hipStream_t s = (hipStream_t)stream;
+        if (src_f16) {
+            if (dst_f16) hipLaunchKernelGGL((ca_fold_vec_kernel<true, true>), grid, dim3(256), 0, s, src, dst, H, W, C, dst_ld, alpha, accumulate, (int)n8);
+            else hipLaunchKernelGGL((ca_fold_vec_kernel<true, false>), grid, dim3(256), 0, s, src, dst, H, W, C, dst_ld, alpha, accumulate, (int)n8);
+        } else {
+            if (dst_f16) hipLaunchKernelGGL((ca_fold_vec_kernel<false, true>), grid, dim3(256), 0, s, src, dst, H, W, C, dst_ld, alpha, accumulate, (int)n8);
+            else hipLaunchKernelGGL((ca_fold_vec_kernel<false, false>), grid, dim3(256), 0, s, src, dst, H, W, C, dst_ld, alpha, accumulate, (int)n8);
+        }
+        HV_LAUNCH_CHECK();
+        return HV_OK;
+    }
+    if (src_f16) return HV_ERR_UNSUPPORTED;
+    return 1;      // the element-wise kernel below
+}
+extern "C" int hv_ca_fold_h(const void* src_h, void* dst, int dst_f16, int B, int H, int W, int C, int dst_ld, float alpha, int accumulate, void* stream) {
+    return ca_fold_impl(src_h, 1, dst, dst_f16, B, H, W, C, dst_ld, alpha, accumulate, stream);
+}
 extern "C" int hv_ca_fold(const float* src, void* dst, int dst_f16, int B, int H, int W, int C, int dst_ld, float alpha, int accumulate, void* stream) {
     if (!src || !dst || B <= 0 || H <= 0 || W <= 0 || C <= 0 || ((H | W) & 1) || dst_ld < C) return HV_ERR_ARG;
+    {
+        const int rc = ca_fold_impl(src, 0, dst, dst_f16, B, H, W, C, dst_ld, alpha, accumulate, stream);
+        if (rc != 1) return rc;
+    }
     const long long n = (long long)B * H * W * C;
     long long blocks = (n + 255) / 256;
     if (blocks > 65536) blocks = 65536;

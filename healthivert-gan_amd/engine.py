@@ -398,8 +398,8 @@ CA_GEMM = os.environ.get('HV_CA_GEMM', '1') != '0'     # fp16 mode: the attentio
 
 def _bgemm(A, B, C, M, N, K, batch, alpha=1.0, colscale=None, b_split=0):
     """C[b] = alpha * colscale[b] (.) A[b] @ B[b]^T over contiguous per-sample matrices A [batch][M][K], B [batch][N][K] (fp32 or fp16),
-    C [batch][M][N] fp32; b_split: B's rows taken in (outer, inner = b_split) order (hv_bgemm_nt)."""
-    _lib.get().call('hv_bgemm_nt', ptr(A), int(A.dtype == torch.float16), K, ctypes.c_longlong(M * K), ptr(B), int(B.dtype == torch.float16), K,
+    C [batch][M][N] fp32 (or fp16: hv_bgemm_nt_h); b_split: B's rows taken in (outer, inner = b_split) order (hv_bgemm_nt)."""
+    _lib.get().call('hv_bgemm_nt_h' if C.dtype == torch.float16 else 'hv_bgemm_nt', ptr(A), int(A.dtype == torch.float16), K, ctypes.c_longlong(M * K), ptr(B), int(B.dtype == torch.float16), K,
                     ctypes.c_longlong(N * K), ptr(C), N, ctypes.c_longlong(M * N), M, N, K, batch, ctypes.c_float(alpha), ptr(colscale),
                     ctypes.c_longlong(N if colscale is not None else 0), int(b_split), stream())
 
@@ -456,6 +456,7 @@ class AttentionPlan:
                 self.O = torch.zeros(B, L, 16 * C, dtype=torch.float32, device=f.t.device)
                 if CA_F16_COPIES:
                     self.wp_h, self.A_h = hz(B, L, 9 * C), hz(B, L, L)
+                    self.O = hz(B, L, 16 * C)          # the paste product only feeds the fold (whose result is stored as fp16): fp16 too
             self.f16_copies = CA_F16_COPIES
             if self.f16_copies:
                 L_.call('hv_ca_patches_h', ptr(f.t), f.f16, B, H, W, C, f.ld, ptr(self.fd.t), ptr(self.wp), ptr(self.wp_h), ptr(self.norm), ptr(self.rnorm), stream())
@@ -495,7 +496,7 @@ class AttentionPlan:
                     ptr(self.argmax) if want_argmax else None, stream())
         if gemm:    # paste = (A rawT^T) folded: O[p][(c, tap)], then every output pixel sums the 4 taps that reach it
             _bgemm(self.A_h if f16c else self.A.t, self.rawT_h, self.O, L, 16 * C, L, B, b_split=C)          # rows of rawT [c][tap] taken as (tap, c): O[p][tap][c]
-            L_.call('hv_ca_fold', ptr(self.O), ptr(out.t), out.f16, B, H, W, C, out.ld, ctypes.c_float(0.25), 0, stream())
+            L_.call('hv_ca_fold_h' if self.O.dtype == torch.float16 else 'hv_ca_fold', ptr(self.O), ptr(out.t), out.f16, B, H, W, C, out.ld, ctypes.c_float(0.25), 0, stream())
         else:
             ops.conv2d(self.A, self.rawT, out, 4, 2, 1, 1, transposed=True, alpha=0.25, w_bstride=C * 16 * L, precision=prec)
         if out_user is not None:
@@ -532,7 +533,8 @@ class AttentionPlan:
             else:
                 L_.call('hv_transpose_batched_f16', ptr(self.A.t), ptr(bw['AT_h']), B, L, L, stream())
             _bgemm(bw['AT_h'], bw['dOrawT_h'], self.O, L, 16 * C, L, B, b_split=C)      # d(raw patches)[l][tap][c] (the forward's O buffer is free by now)
-            L_.call('hv_ca_fold', ptr(self.O), ptr(df.t), df.f16, B, H, W, C, df.ld, ctypes.c_float(0.25), int(bool(accumulate)), stream())
+            L_.call('hv_ca_fold_h' if self.O.dtype == torch.float16 else 'hv_ca_fold', ptr(self.O), ptr(df.t), df.f16, B, H, W, C, df.ld, ctypes.c_float(0.25),
+                    int(bool(accumulate)), stream())
         else:
             ops.conv2d(dout, self.raw, bw['dA'], 4, 2, 1, 1, alpha=0.25, w_bstride=L * 16 * C, precision=prec)
             L_.call('hv_transpose_batched', ptr(self.A.t), ptr(bw['AT'].t), B, L, L, stream())

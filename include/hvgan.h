@@ -293,6 +293,10 @@ int hv_transpose_batched(const float* src, float* dst, int B, int R, int C, void
 int hv_bgemm_nt(const void* A, int a_f16, int lda, long long strideA, const void* B, int b_f16, int ldb, long long strideB, float* C, int ldc,
                 long long strideC, int M, int N, int K, int batch, float alpha, const float* colscale, long long strideS, int b_split, void* stream);
 int hv_ca_fold(const float* src, void* dst, int dst_f16 /* storage of dst */, int B, int H, int W, int C, int dst_ld, float alpha, int accumulate, void* stream);
+/* the same pair with the product stored as fp16 (it only feeds the fold, whose result is stored as fp16 as well): half the bytes written and read */
+int hv_bgemm_nt_h(const void* A, int a_f16, int lda, long long strideA, const void* B, int b_f16, int ldb, long long strideB, void* C_h, int ldc,
+                  long long strideC, int M, int N, int K, int batch, float alpha, const float* colscale, long long strideS, int b_split, void* stream);
+int hv_ca_fold_h(const void* src_h, void* dst, int dst_f16, int B, int H, int W, int C, int dst_ld, float alpha, int accumulate, void* stream);
 /* fp16-stored forms of two operand producers (same layouts as hv_ca_raw_patches / hv_transpose_batched) */
 int hv_ca_raw_patches_f16(const void* f, int f_f16 /* storage of f */, int B, int H, int W, int C, int f_ld, void* raw_h, void* rawT_h, void* stream);
 int hv_transpose_batched_f16(const float* src, void* dst_h, int B, int R, int C, void* stream);
