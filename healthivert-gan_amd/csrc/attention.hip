@@ -286,12 +286,33 @@ __global__ __launch_bounds__(256) void ca_fuse_p2_kernel(const float* __restrict
 // grid row wraps to the top of the next column; (h-1)*w - 1 + px for the first one), and so are the columns: three 34 x 34 pieces of S (one halo
 // row / column for the row-order shift e) are staged in LDS once and every output is nine LDS reads -- the kernel above reads each source row of S
 // nine times through L2 (250 MB of fabric traffic for 128 MB of operands, 110 us).  Terms are added in the same (d, e) order: the same bits.
-__global__ __launch_bounds__(256) void ca_fuse_tile32_kernel(const float* __restrict__ S, float* __restrict__ out) {
+// Tile order (round 3): the three pieces of a tile are the S blocks (py0 + d - 1, ly0 + d - 1), so each block of S is read by the three tiles of one
+// (circular) tile DIAGONAL ly0 - py0 = const.  In (ly0, py0, sample) launch order those three run on different XCDs at different times and every block
+// came over the fabric three times (PMC: 404 MB per launch for 128 MB of operands -- the kernel ran at the fabric's 7 TB/s).  ca_tile_of() deals whole
+// diagonals to the XCD that the hardware's round-robin gives a workgroup (linear id & 7), consecutive workgroups of an XCD walking along one diagonal:
+// the re-reads hit that XCD's L2.
+__device__ __forceinline__ void ca_tile_of(int id, int xcd_order, int& py0, int& ly0, int& b) {
+    if (xcd_order) {
+        const int xcd = id & 7;
+        int q = id >> 3;
+        const int k = q & 31;
+        q >>= 5;
+        const int delta = (q & 3) * 8 + xcd;
+        b = q >> 2;
+        py0 = k;
+        ly0 = (k + delta) & 31;
+    } else {
+        ly0 = id & 31; py0 = (id >> 5) & 31; b = id >> 10;
+    }
+}
+__global__ __launch_bounds__(256) void ca_fuse_tile32_kernel(const float* __restrict__ S, float* __restrict__ out, int xcd_order) {
     constexpr int W = 32, HH = 32, L = W * HH, TS = 34, LDT = 35;
     __shared__ float T[3][TS * LDT];
-    const float* Sb = S + (long long)blockIdx.z * L * L;
-    float* ob = out + (long long)blockIdx.z * L * L;
-    const int py0 = blockIdx.y, ly0 = blockIdx.x, p0 = py0 * W, l0 = ly0 * W;
+    int py0, ly0, bb;
+    ca_tile_of((int)blockIdx.x, xcd_order, py0, ly0, bb);
+    const float* Sb = S + (long long)bb * L * L;
+    float* ob = out + (long long)bb * L * L;
+    const int p0 = py0 * W, l0 = ly0 * W;
     int pb[3], lb[3];
     pb[0] = py0 >= 1 ? p0 - W : (HH - 1) * W - 1;  pb[1] = p0;  pb[2] = py0 < HH - 1 ? p0 + W : 1;
     lb[0] = ly0 >= 1 ? l0 - W : (HH - 1) * W - 1;  lb[1] = l0;  lb[2] = ly0 < HH - 1 ? l0 + W : 1;
@@ -338,13 +359,15 @@ __global__ __launch_bounds__(256) void ca_fuse_tile32_kernel(const float* __rest
 // The adjoint on the same tiles: out[p][l] = sum_e U[p+e][l+e] with U[q][m] = sum_d S[itr(tr(q)+d)][itr(tr(m)+d)].  The 34 rows q = p0-1 .. p0+32
 // (the two halo rows belong to the neighbouring grid rows, whose wrap cases differ) get their three source rows from a small index table built by
 // the first lanes; columns alike.  Terms are added in the (e, d) order of ca_fuse_p2_kernel<true>: the same bits.
-__global__ __launch_bounds__(256) void ca_fuse_adj_tile32_kernel(const float* __restrict__ S, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void ca_fuse_adj_tile32_kernel(const float* __restrict__ S, float* __restrict__ out, int xcd_order) {
     constexpr int W = 32, HH = 32, L = W * HH, TS = 34, LDT = 35;
     __shared__ float T[3][TS * LDT];
     __shared__ int prow[3][TS], pcol[3][TS];           // source row / column of (d, i), -1 = outside
-    const float* Sb = S + (long long)blockIdx.z * L * L;
-    float* ob = out + (long long)blockIdx.z * L * L;
-    const int p0 = blockIdx.y * W, l0 = blockIdx.x * W;
+    int py0, ly0, bb;
+    ca_tile_of((int)blockIdx.x, xcd_order, py0, ly0, bb);
+    const float* Sb = S + (long long)bb * L * L;
+    float* ob = out + (long long)bb * L * L;
+    const int p0 = py0 * W, l0 = ly0 * W;
     if (threadIdx.x < 2 * 3 * TS) {
         const int which = threadIdx.x / (3 * TS), e = threadIdx.x % (3 * TS), d = e / TS, i = e % TS;
         const int q = (which ? l0 : p0) - 1 + i;
@@ -398,8 +421,9 @@ extern "C" int hv_ca_fuse(const float* S, float* out, int B, int h, int w, int a
     if (at_pow2(h) && at_pow2(w) && (long long)h * w <= 32768) {
         static const int tile32 = getenv("HV_CA_FUSE_TILE") ? atoi(getenv("HV_CA_FUSE_TILE")) : 1;      // A/B knob
         if (tile32 && h == 32 && w == 32 && B <= 65535 && !((uintptr_t)out & 15)) {
-            if (adjoint) hipLaunchKernelGGL(ca_fuse_adj_tile32_kernel, dim3(32, 32, B), dim3(256), 0, (hipStream_t)stream, S, out);
-            else hipLaunchKernelGGL(ca_fuse_tile32_kernel, dim3(32, 32, B), dim3(256), 0, (hipStream_t)stream, S, out);
+            static const int xcd_order = getenv("HV_CA_FUSE_XCD") ? atoi(getenv("HV_CA_FUSE_XCD")) : 1;      // A/B knob (same bits either way)
+            if (adjoint) hipLaunchKernelGGL(ca_fuse_adj_tile32_kernel, dim3(1024 * B), dim3(256), 0, (hipStream_t)stream, S, out, xcd_order);
+            else hipLaunchKernelGGL(ca_fuse_tile32_kernel, dim3(1024 * B), dim3(256), 0, (hipStream_t)stream, S, out, xcd_order);
             HV_LAUNCH_CHECK();
             return HV_OK;
         }
@@ -511,8 +535,115 @@ __global__ __launch_bounds__(256) void ca_softmax_kernel(const float* __restrict
         }
     }
 }
+// One WAVE per row (round 3): a lane keeps NV x 4 consecutive-in-groups elements of its row (16-byte loads, NV of them in flight), the maximum, the sum
+// and the arg-max are wave reductions -- no LDS, no workgroup barrier (the block-per-row kernel above spends three __syncthreads on 4 elements per
+// thread at L = 1024).  Same formulas; the fp32 sum of the exponentials is taken in another order.  L = 256 * NV.
+template <typename AT, int NV>
+__global__ __launch_bounds__(256) void ca_softmax_wave_kernel(const float* __restrict__ S, const float* __restrict__ mm, AT* __restrict__ A, float scale,
+                                                              int* __restrict__ argmax, long long mm_bs, long long rows) {
+    constexpr int L = 256 * NV;
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* mrow = mm + (row / L) * mm_bs;
+    const float* s = S + row * L;
+    float4 v[NV], m[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) { v[k] = *reinterpret_cast<const float4*>(s + k * 256 + lane * 4); m[k] = *reinterpret_cast<const float4*>(mrow + k * 256 + lane * 4); }
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        v[k].x = v[k].x * m[k].x * scale; v[k].y = v[k].y * m[k].y * scale; v[k].z = v[k].z * m[k].z * scale; v[k].w = v[k].w * m[k].w * scale;
+        mx = fmaxf(fmaxf(mx, fmaxf(v[k].x, v[k].y)), fmaxf(v[k].z, v[k].w));
+    }
+    mx = hv_wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        v[k].x = expf(v[k].x - mx); v[k].y = expf(v[k].y - mx); v[k].z = expf(v[k].z - mx); v[k].w = expf(v[k].w - mx);
+        sum += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+    }
+    sum = hv_wave_sum(sum);
+    float best = -1.f;
+    int bi = 0x7fffffff;
+    AT* a = A + row * L;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const float o[4] = {v[k].x / sum * m[k].x, v[k].y / sum * m[k].y, v[k].z / sum * m[k].z, v[k].w / sum * m[k].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (o[e] > best) { best = o[e]; bi = k * 256 + lane * 4 + e; }       // increasing index inside a lane: the first maximum wins
+        if constexpr (sizeof(AT) == 2) *reinterpret_cast<f16x4*>(a + k * 256 + lane * 4) = (f16x4){(_Float16)o[0], (_Float16)o[1], (_Float16)o[2], (_Float16)o[3]};
+        else *reinterpret_cast<float4*>(a + k * 256 + lane * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    if (argmax) {      // first index of the maximum (torch.argmax tie rule on CPU)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (lane == 0) argmax[row] = bi;
+    }
+}
+// dS[p][l] = scale*mm[l]*A[p][l]*(dA[p][l] - sum_l' dA[p][l']*A[p][l']) with one wave per row
+template <typename AT, int NV>
+__global__ __launch_bounds__(256) void ca_softmax_bwd_wave_kernel(const float* __restrict__ dA, const AT* __restrict__ A, const float* __restrict__ mm,
+                                                                  float* __restrict__ dS, float scale, long long rows) {
+    constexpr int L = 256 * NV;
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* g = dA + row * L;
+    const AT* a = A + row * L;
+    float4 gv[NV], av[NV], mv[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        gv[k] = *reinterpret_cast<const float4*>(g + k * 256 + lane * 4);
+        mv[k] = *reinterpret_cast<const float4*>(mm + k * 256 + lane * 4);
+        if constexpr (sizeof(AT) == 2) {
+            const f16x4 h = *reinterpret_cast<const f16x4*>(a + k * 256 + lane * 4);
+            av[k] = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+        } else {
+            av[k] = *reinterpret_cast<const float4*>(a + k * 256 + lane * 4);
+        }
+    }
+    float dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) dot += (gv[k].x * av[k].x + gv[k].y * av[k].y) + (gv[k].z * av[k].z + gv[k].w * av[k].w);
+    dot = hv_wave_sum(dot);
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+        *reinterpret_cast<float4*>(dS + row * L + k * 256 + lane * 4) =
+            make_float4(scale * mv[k].x * av[k].x * (gv[k].x - dot), scale * mv[k].y * av[k].y * (gv[k].y - dot), scale * mv[k].z * av[k].z * (gv[k].z - dot),
+                        scale * mv[k].w * av[k].w * (gv[k].w - dot));
+}
+static const int ca_sm_wave = getenv("HV_CA_SOFTMAX_WAVE") ? atoi(getenv("HV_CA_SOFTMAX_WAVE")) : 1;      // A/B knob
+template <typename AT>
+static bool ca_softmax_wave_launch(const float* S, const float* mm, long long mm_bs, AT* A, int B, int L, float scale, int* argmax, hipStream_t s) {
+    if (!ca_sm_wave || (((uintptr_t)S | (uintptr_t)mm | (uintptr_t)A) & 15) || (mm_bs & 3)) return false;
+    const long long rows = (long long)B * L;
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    if (L == 1024) hipLaunchKernelGGL((ca_softmax_wave_kernel<AT, 4>), grid, dim3(256), 0, s, S, mm, A, scale, argmax, mm_bs, rows);
+    else if (L == 4096) hipLaunchKernelGGL((ca_softmax_wave_kernel<AT, 16>), grid, dim3(256), 0, s, S, mm, A, scale, argmax, mm_bs, rows);
+    else if (L == 256) hipLaunchKernelGGL((ca_softmax_wave_kernel<AT, 1>), grid, dim3(256), 0, s, S, mm, A, scale, argmax, mm_bs, rows);
+    else return false;
+    return true;
+}
+template <typename AT>
+static bool ca_softmax_bwd_wave_launch(const float* dA, const AT* A, const float* mm, float* dS, int B, int L, float scale, hipStream_t s) {
+    if (!ca_sm_wave || (((uintptr_t)dA | (uintptr_t)mm | (uintptr_t)A | (uintptr_t)dS) & 15)) return false;
+    const long long rows = (long long)B * L;
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    if (L == 1024) hipLaunchKernelGGL((ca_softmax_bwd_wave_kernel<AT, 4>), grid, dim3(256), 0, s, dA, A, mm, dS, scale, rows);
+    else if (L == 4096) hipLaunchKernelGGL((ca_softmax_bwd_wave_kernel<AT, 16>), grid, dim3(256), 0, s, dA, A, mm, dS, scale, rows);
+    else if (L == 256) hipLaunchKernelGGL((ca_softmax_bwd_wave_kernel<AT, 1>), grid, dim3(256), 0, s, dA, A, mm, dS, scale, rows);
+    else return false;
+    return true;
+}
 extern "C" int hv_ca_softmax(const float* S, const float* mm, float* A, int B, int L, float scale, int* argmax, void* stream) {
     if (!S || !mm || !A || B <= 0 || L <= 0) return HV_ERR_ARG;
+    if (ca_softmax_wave_launch<float>(S, mm, 0ll, A, B, L, scale, argmax, (hipStream_t)stream)) { HV_LAUNCH_CHECK(); return HV_OK; }
     hipLaunchKernelGGL(ca_softmax_kernel<float>, dim3(B * L), dim3(256), 0, (hipStream_t)stream, S, mm, A, L, scale, argmax, 0ll);
     HV_LAUNCH_CHECK();
     return HV_OK;
@@ -520,12 +651,14 @@ extern "C" int hv_ca_softmax(const float* S, const float* mm, float* A, int B, i
 extern "C" int hv_ca_softmax_batched(const float* S, const float* mm, long long mm_bstride, float* A, int B, int L, float scale, int* argmax,
                                      void* stream) {
     if (!S || !mm || !A || B <= 0 || L <= 0 || mm_bstride < 0) return HV_ERR_ARG;
+    if (ca_softmax_wave_launch<float>(S, mm, mm_bstride, A, B, L, scale, argmax, (hipStream_t)stream)) { HV_LAUNCH_CHECK(); return HV_OK; }
     hipLaunchKernelGGL(ca_softmax_kernel<float>, dim3(B * L), dim3(256), 0, (hipStream_t)stream, S, mm, A, L, scale, argmax, mm_bstride);
     HV_LAUNCH_CHECK();
     return HV_OK;
 }
 extern "C" int hv_ca_softmax_f16(const float* S, const float* mm, long long mm_bstride, void* A_h, int B, int L, float scale, int* argmax, void* stream) {
     if (!S || !mm || !A_h || B <= 0 || L <= 0 || mm_bstride < 0) return HV_ERR_ARG;
+    if (ca_softmax_wave_launch<_Float16>(S, mm, mm_bstride, (_Float16*)A_h, B, L, scale, argmax, (hipStream_t)stream)) { HV_LAUNCH_CHECK(); return HV_OK; }
     hipLaunchKernelGGL(ca_softmax_kernel<_Float16>, dim3(B * L), dim3(256), 0, (hipStream_t)stream, S, mm, (_Float16*)A_h, L, scale, argmax, mm_bstride);
     HV_LAUNCH_CHECK();
     return HV_OK;
@@ -549,12 +682,14 @@ __global__ __launch_bounds__(256) void ca_softmax_bwd_kernel(const float* __rest
 }
 extern "C" int hv_ca_softmax_backward(const float* dA, const float* A, const float* mm, float* dS, int B, int L, float scale, void* stream) {
     if (!dA || !A || !mm || !dS || B <= 0 || L <= 0) return HV_ERR_ARG;
+    if (ca_softmax_bwd_wave_launch<float>(dA, A, mm, dS, B, L, scale, (hipStream_t)stream)) { HV_LAUNCH_CHECK(); return HV_OK; }
     hipLaunchKernelGGL(ca_softmax_bwd_kernel<float>, dim3(B * L), dim3(256), 0, (hipStream_t)stream, dA, A, mm, dS, L, scale);
     HV_LAUNCH_CHECK();
     return HV_OK;
 }
 extern "C" int hv_ca_softmax_backward_f16(const float* dA, const void* A_h, const float* mm, float* dS, int B, int L, float scale, void* stream) {
     if (!dA || !A_h || !mm || !dS || B <= 0 || L <= 0) return HV_ERR_ARG;
+    if (ca_softmax_bwd_wave_launch<_Float16>(dA, (const _Float16*)A_h, mm, dS, B, L, scale, (hipStream_t)stream)) { HV_LAUNCH_CHECK(); return HV_OK; }
     hipLaunchKernelGGL(ca_softmax_bwd_kernel<_Float16>, dim3(B * L), dim3(256), 0, (hipStream_t)stream, dA, (const _Float16*)A_h, mm, dS, L, scale);
     HV_LAUNCH_CHECK();
     return HV_OK;

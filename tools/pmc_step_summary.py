@@ -48,7 +48,13 @@ def norm(names):
             elif ch == '(' and depth == 0:
                 d = d[:i]
                 break
-        out[n] = d.strip()
+        d = d.strip()
+        # conv_lf_kernel's fifth template argument (the hv_conv_desc.x1 form) is not part of the name the C dispatch reports: the plain instantiation
+        # keeps the reported name, the x1 one is listed beside it
+        m = re.match(r'(conv_lf_kernel<\d+, \d+, \d+, \d+), (false|true)>$', d)
+        if m:
+            d = m.group(1) + '>' + (' [x1]' if m.group(2) == 'true' else '')
+        out[n] = d
     return out
 
 
