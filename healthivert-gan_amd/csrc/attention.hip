@@ -730,10 +730,24 @@ extern "C" int hv_transpose_batched_h2h(const void* src_h, void* dst_h, int B, i
 
 // ---- backward of the matching scores -------------------------------------------------------------------
 // Gs[b][i][j] = dS[b][j][i]*rnorm[b][i] + dS[b][i][j]*rnorm[b][j]
-__global__ __launch_bounds__(256) void ca_gs_kernel(const float* __restrict__ dS, const float* __restrict__ rnorm, float* __restrict__ Gs, int L) {
+// xcd_order (L / 32 a multiple of 8): tile (i, j) reads the blocks (j, i) and (i, j) of dS, tile (j, i) the same two -- both are dealt to the XCD
+// (i + j) & 7 (linear workgroup id & 7 is the XCD the hardware's round-robin gives it), where an XCD's 128 tiles of a sample run side by side: every
+// block of dS crosses the fabric once instead of twice (PMC: 126 MB fetched per launch for 64 MB, the kernel ran at 5.7 TB/s of fabric traffic).
+__global__ __launch_bounds__(256) void ca_gs_kernel(const float* __restrict__ dS, const float* __restrict__ rnorm, float* __restrict__ Gs, int L, int xcd_order) {
     __shared__ float t[32][33];
-    const long long b = blockIdx.z;
-    const int j0 = blockIdx.x * 32, i0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    long long b;
+    int it, jt;
+    if (xcd_order) {
+        const int nt = L >> 5, per = nt * (nt >> 3), id = (int)blockIdx.x, xcd = id & 7;
+        int q = id >> 3;
+        b = q / per;
+        q -= (int)b * per;
+        it = q / (nt >> 3);
+        jt = ((xcd - it) & 7) + 8 * (q % (nt >> 3));
+    } else {
+        b = blockIdx.z; jt = blockIdx.x; it = blockIdx.y;
+    }
+    const int j0 = jt * 32, i0 = it * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const float* D = dS + b * (long long)L * L;
     for (int k = ty; k < 32; k += 8) t[k][tx] = D[(long long)(j0 + k) * L + i0 + tx];   // t[jj][ii] = dS[j0+jj][i0+ii]
     __syncthreads();
@@ -781,7 +795,11 @@ extern "C" int hv_ca_score_backward_prep(const float* dS, const float* S0, const
                                          int B, int L, void* stream) {
     if (!dS || !S0 || !norm || !rnorm || !Gs || !coef || B <= 0 || L <= 0 || (L & 31)) return HV_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(ca_gs_kernel, dim3(L / 32, L / 32, B), dim3(256), 0, s, dS, rnorm, Gs, L);
+    static const int gs_xcd = getenv("HV_CA_GS_XCD") ? atoi(getenv("HV_CA_GS_XCD")) : 1;      // A/B knob (same bits either way)
+    if (gs_xcd && (L / 32) % 8 == 0 && (long long)(L / 32) * (L / 32) * B < (1ll << 31))
+        hipLaunchKernelGGL(ca_gs_kernel, dim3((L / 32) * (L / 32) * B), dim3(256), 0, s, dS, rnorm, Gs, L, 1);
+    else
+        hipLaunchKernelGGL(ca_gs_kernel, dim3(L / 32, L / 32, B), dim3(256), 0, s, dS, rnorm, Gs, L, 0);
     HV_LAUNCH_CHECK();
     // row-chunk partials live behind the result: coef holds B*L*(1 + 16) floats (include/hvgan.h)
     float* part = coef + (long long)B * L;
@@ -819,9 +837,56 @@ __global__ void ca_patches_bwd_kernel(const float* __restrict__ dwp, const float
         *d = acc ? *d + v : v;
     }
 }
+// The accumulate form on four channels per thread: only the even positions of the full map receive anything, so the work items are the h x w
+// patch positions (a quarter of the map), the nine taps' 16-byte loads are all issued before the first add, indices are 32-bit.  Same operation
+// order per element as the kernel above: the same bits (that kernel walks the whole map with three 64-bit divisions and 18 four-byte loads per element).
+__global__ __launch_bounds__(256) void ca_patches_bwd_vec_kernel(const float* __restrict__ dwp, const float* __restrict__ wp, const float* __restrict__ coef,
+                                                                 float* __restrict__ df, int H, int W, int C, int df_ld, int n) {
+    const int h = H / 2, w = W / 2, L = h * w, C4 = C >> 2;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int c = (i % C4) * 4;
+        int r = i / C4;
+        const int x = r % w;
+        r /= w;
+        const int y = r % h, b = r / h;
+        float4 dv[9], wv[9];
+        float cf[9];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ly = y - (tap / 3 - 1), lx = x - (tap % 3 - 1);
+            const bool ok = (unsigned)ly < (unsigned)h && (unsigned)lx < (unsigned)w;
+            const int l = ok ? ly * w + lx : 0;
+            const long long o = (((long long)b * L + l) * 9 + tap) * C + c;
+            dv[tap] = ok ? *reinterpret_cast<const float4*>(dwp + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+            wv[tap] = ok ? *reinterpret_cast<const float4*>(wp + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+            cf[tap] = ok ? coef[(long long)b * L + l] : 0.f;
+        }
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ly = y - (tap / 3 - 1), lx = x - (tap % 3 - 1);
+            if ((unsigned)ly < (unsigned)h && (unsigned)lx < (unsigned)w) {
+                v.x += dv[tap].x + cf[tap] * wv[tap].x; v.y += dv[tap].y + cf[tap] * wv[tap].y;
+                v.z += dv[tap].z + cf[tap] * wv[tap].z; v.w += dv[tap].w + cf[tap] * wv[tap].w;
+            }
+        }
+        float4* d = reinterpret_cast<float4*>(df + (((long long)b * H + 2 * y) * W + 2 * x) * df_ld + c);
+        const float4 o4 = *d;
+        *d = make_float4(o4.x + v.x, o4.y + v.y, o4.z + v.z, o4.w + v.w);
+    }
+}
 extern "C" int hv_ca_patches_backward(const float* dwp, const float* wp, const float* coef, float* df, int B, int H, int W, int C, int df_ld,
                                       int accumulate, void* stream) {
     if (!dwp || !wp || !coef || !df || B <= 0 || H <= 0 || W <= 0 || C <= 0 || ((H | W) & 1) || df_ld < C) return HV_ERR_ARG;
+    static const int pb_vec = getenv("HV_CA_PBWD_VEC") ? atoi(getenv("HV_CA_PBWD_VEC")) : 1;      // A/B knob (same bits either way)
+    const long long n4 = (long long)B * (H / 2) * (W / 2) * (C / 4);
+    if (pb_vec && accumulate && !(C & 3) && !(df_ld & 3) && !(((uintptr_t)dwp | (uintptr_t)wp | (uintptr_t)df) & 15) && n4 < (1ll << 31)) {
+        long long blocks = (n4 + 255) / 256;
+        if (blocks > 65536) blocks = 65536;
+        hipLaunchKernelGGL(ca_patches_bwd_vec_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dwp, wp, coef, df, H, W, C, df_ld, (int)n4);
+        HV_LAUNCH_CHECK();
+        return HV_OK;
+    }
     const long long n = (long long)B * H * W * C;
     hipLaunchKernelGGL(ca_patches_bwd_kernel, dim3(at_grid(n)), dim3(256), 0, (hipStream_t)stream, dwp, wp, coef, df, H, W, C, df_ld, accumulate, n);
     HV_LAUNCH_CHECK();
