@@ -420,3 +420,24 @@ def test_score_fusion_tiles_match_the_index_formula(adjoint):
                 rows = itr(np.clip(a, 0, L - 1))
                 add(rows, rows, ok, ok)
     assert np.array_equal(out.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize('B,R,C', [(2, 1024, 576), (3, 72, 40), (1, 64, 8), (2, 33, 50)])
+def test_attention_operand_transposes_are_exact(B, R, C):
+    """hv_transpose_batched_f16 (fp32 -> fp16) and hv_transpose_batched_h2h (fp16 -> fp16): the operand tables of the attention block's batched
+    GEMMs.  64 x 64 tiles with 16-byte accesses when R and C are multiples of 8 (incl. ragged tile edges), the 32 x 32 element kernel otherwise;
+    a conversion and a copy: exact against torch."""
+    import hvgan  # noqa: F401
+    from hvgan import lib
+    from hvgan.lib import ptr, stream
+    L = lib.get()
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(5)
+    src = torch.randn(B, R, C, generator=g).to(dev)
+    dst = torch.full((B, C, R), 7.0, dtype=torch.float16, device=dev)
+    L.call('hv_transpose_batched_f16', ptr(src), ptr(dst), B, R, C, stream())
+    assert torch.equal(dst, src.half().transpose(1, 2).contiguous())
+    src_h = src.half().contiguous()
+    dst2 = torch.full((B, C, R), 7.0, dtype=torch.float16, device=dev)
+    L.call('hv_transpose_batched_h2h', ptr(src_h), ptr(dst2), B, R, C, stream())
+    assert torch.equal(dst2, src_h.transpose(1, 2).contiguous())
