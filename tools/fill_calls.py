@@ -36,7 +36,7 @@ def wrap(mod, name):
     setattr(mod, name, g)
 for n in ('zeros', 'zeros_like', 'full', 'ones', 'full_like', 'ones_like'):
     wrap(torch, n)
-for n in ('zero_', 'fill_'):
+for n in ('zero_', 'fill_', 'copy_', 'clone', 'float', 'half', 'mul_', 'add_', 'sum', 'mean'):      # (copies and stray element-wise ops too)
     wrap(torch.Tensor, n)
 model.optimize_parameters()
 torch.cuda.synchronize()
