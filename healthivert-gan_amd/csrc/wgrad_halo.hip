@@ -290,8 +290,12 @@ static bool wgrad_halo_plan(const hv_wgrad_desc* d, WHaloPlan* pl) {
     pl->lds = stage > red ? stage : red;
     const long long ntiles = (long long)d->B * hv_cdiv(d->Ho, 8) * hv_cdiv(d->Wo, 32);
     const long long pairs = (long long)hv_cdiv(d->Cout, pl->BN) * hv_cdiv(d->Cin, pl->BC);
-    static const int gx_target = getenv("HV_WHALO_GX") ? atoi(getenv("HV_WHALO_GX")) : 256;   // one persistent workgroup per CU
-    // (measured on the 256x256 layers: 53 / 55 / 35 us at 256 workgroups vs 87 / 72 / 48 us at 1024 -- fewer slabs, longer tile pipelines)
+    static const int gx_env = getenv("HV_WHALO_GX") ? atoi(getenv("HV_WHALO_GX")) : 0;
+    // Workgroups per launch.  Round 1 (fp32 storage): one persistent workgroup per CU won on the 256x256 layers (53 / 55 / 35 us at 256 against 87 / 72 / 48 us
+    // at 1024 -- fewer slabs, longer tile pipelines).  Re-measured at the end of round 3 (fp16 storage: half the bytes per tile, the loads of one workgroup no
+    // longer keep a CU's memory pipe busy; tools/ab_env_stats.sh, us at 256 / 512 / 1024): 3x3 16<-16 26.1 / 19.1 / 18.5, 3x3 16<-32 46.3 / 34.2 / 42.9,
+    // 4x4 stem 20.5 / 20.5 / 16.6, 5x5 45.8 / 52.6 / 65.8 -> per filter size
+    const int gx_target = gx_env ? gx_env : (d->KH == 3 ? 512 : d->KH == 4 ? 1024 : 256);
     long long gx = gx_target / pairs;
     if (gx < 32) gx = 32;
     if (gx > ntiles) gx = ntiles;
