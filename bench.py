@@ -450,7 +450,7 @@ def main():
                                                              'timed_in': 'the refinement generator\'s training forward alone as one captured hipGraph (two branch streams), mean of 50 back-to-back replays, GPU otherwise idle'}
         ngraphs = len(model._dp_graphs or ()) or len(model._graphs or ())
         out['config']['launch'] = ('hipGraph replay (%d graphs/step)' % ngraphs if model.use_graph else 'eager') + \
-                                  (', one stream' if args.serial else ', %d streams' % (5 if world > 1 else 4))
+                                  (', one stream' if args.serial else ', %d streams' % (5 if (world > 1 or model.grad_sync.active()) else 4))
         out['losses'] = {k: round(v, 4) for k, v in model.get_current_losses().items()}
         if world == 1 and not args.no_inference and args.size == 256:
             out['inference'] = inference_record(dev, args.precision)

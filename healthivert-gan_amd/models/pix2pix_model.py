@@ -106,7 +106,16 @@ class Pix2PixModel(BaseModel):
         if self.grad_scale <= 0 or (self.grad_scale != 1 and not float(self.grad_scale).is_integer()) or int(self.grad_scale) & (int(self.grad_scale) - 1):
             raise ValueError('HV_GRAD_SCALE must be a power of two')
         self.concurrent_d = _os.environ.get('HV_CONCURRENT_D', '1') != '0'
-        self.batch_d = _os.environ.get('HV_BATCH_D', '0') != '0'   # measured: no gain once the three D streams overlap
+        # fake | real discriminator passes as ONE 2B-sample launch sequence (per-half BatchNorm groups).  Round 2: no gain beside the three-stream overlap;
+        # re-measured at the end of round 3 with the pipelined 4x4 kernels (one round of one workgroup per CU at bs 16): 8.18 -> 8.09 ms in three same-box
+        # pairs, although it gives up the real-image passes' overlap with the generator forward.  Single-process schedule only: the data-parallel schedule
+        # keeps the split real-first form (the generator's all-reduce and Adam step hide behind the next step's real-image passes there).
+        self.batch_d = _os.environ.get('HV_BATCH_D', '1') != '0'
+        # data-parallel step schedule: 'graphs' = the single-process three-graph step with the gradient means between the graphs; 'phases' = twelve
+        # phase graphs with the exchanges hidden behind other phases (see optimize_parameters / _step_data_parallel)
+        self.dp_schedule = _os.environ.get('HV_DP_SCHEDULE', 'graphs')
+        if self.dp_schedule not in ('graphs', 'phases'):
+            raise ValueError("HV_DP_SCHEDULE must be 'graphs' or 'phases'")
         self.real_first = _os.environ.get('HV_REAL_FIRST', '1') != '0'   # D real passes overlap the generator forward
 
     # tensors forward()/backward bind as attributes; they live in per-shape buffers, so the names follow the active batch shape
@@ -442,22 +451,41 @@ class Pix2PixModel(BaseModel):
         for o in self.optimizers:
             o.sync_lr()
         graphable = self.use_graph and ops.timer() is None
-        if self.grad_sync.active():
+        dp = self.grad_sync.active()
+        if dp and self.dp_schedule == 'phases':
             return self._step_data_parallel(graphable)
+        # Data parallelism, 'graphs' schedule (default since the end of round 3): the single-process step as it is -- its three graphs were cut where
+        # the exchanges belong -- with the flat gradients averaged between them: D_1..D_3 after graph A, G after graph B (exchange stream; the main
+        # stream waits for each mean: no overlap with compute, no extra graphs).  Measured on one device in a one-rank RCCL group: the twelve-phase
+        # schedule costs 0.55-0.75 ms per step over this one (8.44 vs 7.7-7.9 ms) before any communication, more than the four all-reduces it hides
+        # are expected to take over xGMI (three of 11 MB, one of 4 MB); HV_DP_SCHEDULE=phases keeps it.
         if graphable and self._graphs is None and self._eager_steps >= self.GRAPH_WARMUP:
             try:
                 self._capture()
             except RuntimeError as e:
                 self._graph_failed(e)
                 graphable = False
-        if graphable and self._graphs is not None:
-            for g in self._graphs:
-                g.replay()
-            return
-        self._phase_a()
-        self._phase_b()
-        self._phase_c()
-        self._eager_steps += 1
+        replay = graphable and self._graphs is not None
+        phases = self._graphs if replay else (self._phase_a, self._phase_b, self._phase_c)
+        run = (lambda ph: ph.replay()) if replay else (lambda ph: ph())
+        run(phases[0])
+        if dp:
+            self._exchange([self.netD_1, self.netD_2, self.netD_3])
+        run(phases[1])
+        if dp:
+            self._exchange([self.netG])
+        run(phases[2])
+        if not replay:
+            self._eager_steps += 1
+
+    def _exchange(self, nets):
+        """Mean over the ranks of the networks' flat gradients (one all-reduce each, issued back to back on the exchange stream); the current stream
+        continues when all of them are done.  Nothing blocks the host."""
+        main = torch.cuda.current_stream(self.device)
+        events = [self.grad_sync.reduce(n.paramset().flat_grad, after=main) for n in nets]
+        for ev in events:
+            if ev is not None:
+                main.wait_event(ev)
 
     # ---------------------------------------------------------------- the data-parallel step (one process per GPU)
     # Phases, the stream each runs on, and what it waits for:
