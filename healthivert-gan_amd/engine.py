@@ -232,7 +232,10 @@ class GradBook:
         self.written = set()
         self.side = None          # side HIP stream for weight gradients (they overlap the data-gradient chain)
         self._side_of = None      # ... of this parent stream
-        self.overlap = os.environ.get('HV_OVERLAP_WGRAD', '1') != '0'
+        # Weight gradients on a side stream beside the data-gradient chain: a gain in rounds 1-2 (20.6 -> 19.1 ms era); re-measured at the end of round 3
+        # (six same-box pairs, tools/ab_step.sh): in line is faster now, 8.25 -> 8.15 ms on average -- every kernel fills the chip, and the per-layer
+        # fork / join edges cost more than the overlap returns.  HV_OVERLAP_WGRAD=1 brings the side stream back.
+        self.overlap = os.environ.get('HV_OVERLAP_WGRAD', '0') != '0'
 
     def can_fork(self):
         return self.overlap and not SERIAL and torch.cuda.current_stream().cuda_stream not in NO_FORK_STREAMS
