@@ -418,7 +418,7 @@ def main():
         pdir = os.path.join(ROOT, 'profiles')
 
         def add_traffic(rec):
-            for fn in ('r03g_traffic_step.json', 'r03f_traffic_step.json', 'r03d_traffic_step.json', 'r03_traffic_step.json', 'r02_traffic_step.json', 'r01_traffic_step.json'):
+            for fn in ('r03i_traffic_step.json', 'r03g_traffic_step.json', 'r03f_traffic_step.json', 'r03d_traffic_step.json', 'r03_traffic_step.json', 'r02_traffic_step.json', 'r01_traffic_step.json'):
                 try:
                     e = json.load(open(os.path.join(pdir, fn)))['kernels'].get(rec['kernel'])
                 except (OSError, ValueError, KeyError):
