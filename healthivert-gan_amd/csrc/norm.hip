@@ -161,8 +161,9 @@ __global__ void norm_fwd_finalize_kernel(const double* __restrict__ part, int G,
             continue;
         }
         double s = 0, q = 0;
-        if (fpart) {
-            for (int k = threadIdx.x; k < nchunk; k += 64) {
+        if (fpart) {      // the producing conv's partials are ordered by (image, tile): group g owns the g-th of G equal ranges
+            const int per = nchunk / G;
+            for (int k = g * per + threadIdx.x; k < (g + 1) * per; k += 64) {
                 const float2 v = *reinterpret_cast<const float2*>(fpart + ((long long)k * C + c) * 2);
                 s += v.x; q += v.y;
             }
@@ -261,7 +262,9 @@ extern "C" int hv_norm_act_forward(const hv_norm_desc* d, void* stream) {
     k.stats = d->stats; k.gamma = d->norm == HV_NORM_BATCH ? d->gamma : nullptr; k.beta = d->beta;
     double* part = (double*)d->workspace;
     // statistics handed over by the producing conv (hv_conv_desc.stats): no reduction pass over x
-    const bool handed = d->partials && d->n_partials > 0 && d->norm == HV_NORM_BATCH && !use_running && pl.G == 1;
+    // (groups > 1: the partials of whole images, in image order -- every group is a contiguous, equal share of them)
+    const bool handed = d->partials && d->n_partials > 0 && d->norm == HV_NORM_BATCH && !use_running && pl.G >= 1 && d->n_partials % pl.G == 0 &&
+                        (d->n_partials / pl.G) % (d->B / pl.G) == 0;
     if (!use_running && !handed) {
         dim3 grid(pl.nchunk, pl.G, pl.slices);
         if (d->f16) {

@@ -298,7 +298,7 @@ class NLayerDiscriminator(nn.Module):
             # BatchNorm statistics out of the conv's own epilogue where its kernel has one (the 4x4 stride-2 layers): the normalisation then
             # skips its reduction pass over z (HV_CONV_STATS=0: always reduce)
             parts = 0
-            if CONV_STATS and self.norm_kind == 'batch' and training and groups <= 1:
+            if CONV_STATS and self.norm_kind == 'batch' and training:      # (groups > 1: the partials are per image tile, in image order: the finalize sums each group's share)
                 if 'parts' not in ent:
                     ent['parts'] = int(ent['node'].stats_parts(prec))
                     ent['partials'] = torch.zeros(max(1, ent['parts']) * ent['p'].cout * 2, dtype=torch.float32, device=x.device)

@@ -206,7 +206,8 @@ typedef struct {
                      part by part (fake | real halves of one discriminator launch == two consecutive calls); 0/1 = one group */
     int f16;      /* storage of x and y (statistics, affine parameters and all arithmetic stay fp32 / fp64) */
     const float* partials; int n_partials;
-                  /* optional (batch norm, training, groups <= 1): the producing conv's hv_conv_desc.stats -- [n_partials][C][2] partial sums of x.
+                  /* optional (batch norm, training): the producing conv's hv_conv_desc.stats -- [n_partials][C][2] partial sums of x, parts of whole
+                     images in image order (groups > 1: group g is the g-th of `groups` equal ranges of them; n_partials must divide accordingly, else x is reduced here).
                      The reduction pass over x is skipped; the partials are folded in double precision in a fixed order.  NULL = reduce x here */
 } hv_norm_desc;
 size_t hv_norm_workspace_bytes(int B, int HW, int C);
