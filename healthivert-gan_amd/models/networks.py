@@ -328,6 +328,26 @@ class NLayerDiscriminator(nn.Module):
         ops.gan_loss(P.logits, target_is_real, mode, loss=loss, loss_weight=loss_weight, dz=dz, grad_weight=grad_weight)
         return self.run_backward(P, dz, need_dx=need_dx, param_grads=param_grads, accumulate=accumulate)
 
+    def loss_backward_halves(self, P, mode, loss_fake, loss_real, grad_weight, dz=None):
+        """The batched fake | real pass (run_forward(..., groups=2) on [fake; real]): GAN loss of each half against its own target + ONE backward.
+        fp16 storage mode: each half's loss kernel writes its part of the logits layer's gradient carrier and adds its bias gradient
+        (hv_gan_loss_head), as loss_backward does for a whole batch."""
+        last = P.layers[-1]
+        B = P.B // 2
+        if LOSS_HEAD and P.g_logits.f16 and P.g_logits.t.shape[-1] == 4 and P.g_logits.coff == 0:
+            pl = last['p']
+            want_db = pl.bias is not None and last['node'].use_bias
+            for half, (real, loss) in enumerate(((False, loss_fake), (True, loss_real))):
+                sl = slice(half * B, (half + 1) * B)
+                ops.gan_loss(P.logits[sl], real, mode, loss=loss, grad_weight=grad_weight, carrier=Act(P.g_logits.t[sl], 4, 0),
+                             dbias=pl.bias.grad if want_db else None, dbias_accumulate=bool(half))
+            return self.run_backward(P, None, need_dx=False, param_grads=True, accumulate=False, logits_ready=True)
+        if dz is None:
+            dz = torch.empty_like(P.logits)
+        ops.gan_loss(P.logits[:B], False, mode, loss=loss_fake, dz=dz[:B], grad_weight=grad_weight)
+        ops.gan_loss(P.logits[B:], True, mode, loss=loss_real, dz=dz[B:], grad_weight=grad_weight)
+        return self.run_backward(P, dz, need_dx=False, param_grads=True, accumulate=False)
+
     def run_backward(self, P, dlogits, need_dx=False, param_grads=True, accumulate=False, logits_ready=False):
         """dlogits: (B,1,Ho,Wo) gradient of the loss wrt the logits.  Fills kernel-layout weight gradients and the
         bias / affine .grad (accumulating when `accumulate`); call finish() afterwards.  Returns d loss / d input."""

@@ -231,10 +231,7 @@ class Pix2PixModel(BaseModel):
             L.call('hv_affine', ptr(x2[:B]), ptr(fake), n, ctypes.c_float(1.0), ctypes.c_float(0.0), stream())
             L.call('hv_affine', ptr(x2[B:]), ptr(real), n, ctypes.c_float(1.0), ctypes.c_float(0.0), stream())
             P = net.run_forward(x2, training=True, prep=True, groups=2)
-            dz = self._buf('dzz%d' % k, P.logits)
-            ops.gan_loss(P.logits[:B], False, mode, loss=lf, dz=dz[:B], grad_weight=0.5 * self.grad_scale)
-            ops.gan_loss(P.logits[B:], True, mode, loss=lr, dz=dz[B:], grad_weight=0.5 * self.grad_scale)
-            net.run_backward(P, dz, need_dx=False, param_grads=True, accumulate=False)
+            net.loss_backward_halves(P, mode, lf, lr, 0.5 * self.grad_scale, dz=self._buf('dzz%d' % k, P.logits))
         else:
             P = net.run_forward(fake, training=True, prep=True)
             dz = self._buf('dz%d' % k, P.logits)
