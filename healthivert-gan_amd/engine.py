@@ -113,7 +113,14 @@ class ParamSet:
         # flat gradients; .grad of every trainable tensor is a view into it
         ps = self.trainable()
         n = sum(p.numel() for p in ps)
-        self.flat_grad = torch.zeros(n, dtype=torch.float32, device=device)
+        # (grad_home: a caller-provided slice of a larger buffer -- the data-parallel step keeps the three discriminators' flat gradients
+        # back to back so that ONE all-reduce averages them all)
+        home = getattr(self, 'grad_home', None)
+        if home is not None and home.numel() == n and home.device == torch.device(device) and home.dtype == torch.float32:
+            self.flat_grad = home
+            self.flat_grad.zero_()
+        else:
+            self.flat_grad = torch.zeros(n, dtype=torch.float32, device=device)
         off = 0
         for p in ps:
             p.grad = self.flat_grad[off:off + p.numel()].view_as(p)

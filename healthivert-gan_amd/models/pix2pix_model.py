@@ -453,6 +453,8 @@ class Pix2PixModel(BaseModel):
         dp = self.grad_sync.active()
         if dp and self.dp_schedule == 'phases':
             return self._step_data_parallel(graphable)
+        if dp and self._eager_steps == 0 and self._graphs is None:
+            self._home_d_grads()
         # Data parallelism, 'graphs' schedule (default since the end of round 3): the single-process step as it is -- its three graphs were cut where
         # the exchanges belong -- with the flat gradients averaged between them: D_1..D_3 after graph A, G after graph B (exchange stream; the main
         # stream waits for each mean: no overlap with compute, no extra graphs).  Measured on one device in a one-rank RCCL group: the twelve-phase
@@ -477,11 +479,34 @@ class Pix2PixModel(BaseModel):
         if not replay:
             self._eager_steps += 1
 
+    def _home_d_grads(self):
+        """Data parallelism: the three discriminators' flat gradient buffers as three consecutive slices of ONE buffer (ParamSet.grad_home, taken up
+        when a set lays out its tables), so that their means are one collective."""
+        if getattr(self, '_d_grad_arena', None) is not None:
+            return
+        sets = [getattr(self, 'netD_%d' % k).paramset() for k in (1, 2, 3)]
+        sizes = [sum(p.numel() for p in ps.trainable()) for ps in sets]
+        rup = lambda n: (n + 63) // 64 * 64          # every slice starts on a 256-byte boundary (the guarded Adam's vector loads); the gaps stay zero
+        self._d_grad_arena = torch.zeros(sum(rup(n) for n in sizes), dtype=torch.float32, device=self.device)
+        off = 0
+        for ps, n in zip(sets, sizes):
+            ps.grad_home = self._d_grad_arena[off:off + n]
+            ps._key = None          # lay the tables out again over the new gradient storage at the next prep
+            for t in list(ps.t_prep.values()) + list(ps.t_bwd.values()):
+                t.key = None        # (their rows hold pointers into the gradient storage)
+            off += rup(n)
+
     def _exchange(self, nets):
-        """Mean over the ranks of the networks' flat gradients (one all-reduce each, issued back to back on the exchange stream); the current stream
-        continues when all of them are done.  Nothing blocks the host."""
+        """Mean over the ranks of the networks' flat gradients (one all-reduce each, issued back to back on the exchange stream -- ONE for all of them
+        when their buffers lie back to back, see _home_d_grads); the current stream continues when all of them are done.  Nothing blocks the host."""
         main = torch.cuda.current_stream(self.device)
-        events = [self.grad_sync.reduce(n.paramset().flat_grad, after=main) for n in nets]
+        flats = [n.paramset().flat_grad for n in nets]
+        arena = getattr(self, '_d_grad_arena', None)
+        if len(flats) == 3 and arena is not None:
+            lo, hi = arena.data_ptr(), arena.data_ptr() + 4 * arena.numel()
+            if all(lo <= f.data_ptr() and f.data_ptr() + 4 * f.numel() <= hi for f in flats) and sum((f.numel() + 63) // 64 * 64 for f in flats) == arena.numel():
+                flats = [arena]          # the three discriminators' buffers (and the zero gaps between them) as one collective
+        events = [self.grad_sync.reduce(f, after=main) for f in flats]
         for ev in events:
             if ev is not None:
                 main.wait_event(ev)
