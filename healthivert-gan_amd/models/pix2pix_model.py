@@ -113,6 +113,9 @@ class Pix2PixModel(BaseModel):
         self.batch_d = _os.environ.get('HV_BATCH_D', '1') != '0'
         # data-parallel step schedule: 'graphs' = the single-process three-graph step with the gradient means between the graphs; 'phases' = twelve
         # phase graphs with the exchanges hidden behind other phases (see optimize_parameters / _step_data_parallel)
+        # single process: the three phases captured as ONE graph (7.81 -> 7.70 ms over four same-box pairs: two graph-launch boundaries less); HV_ONE_GRAPH=0 keeps
+        # the three graphs, and a data-parallel job always does (the gradient means sit between them)
+        self.one_graph = _os.environ.get('HV_ONE_GRAPH', '1') != '0'
         self.dp_schedule = _os.environ.get('HV_DP_SCHEDULE', 'graphs')
         if self.dp_schedule not in ('graphs', 'phases'):
             raise ValueError("HV_DP_SCHEDULE must be 'graphs' or 'phases'")
@@ -467,6 +470,9 @@ class Pix2PixModel(BaseModel):
                 self._graph_failed(e)
                 graphable = False
         replay = graphable and self._graphs is not None
+        if replay and len(self._graphs) == 1:      # the whole step as one graph (single process)
+            self._graphs[0].replay()
+            return
         phases = self._graphs if replay else (self._phase_a, self._phase_b, self._phase_c)
         run = (lambda ph: ph.replay()) if replay else (lambda ph: ph())
         run(phases[0])
@@ -631,7 +637,11 @@ class Pix2PixModel(BaseModel):
             self._capture_stream = engine.named_stream('capture', self.device)
         torch.cuda.synchronize(self.device)
         graphs, pool = [], None
-        for phase in (self._phase_a, self._phase_b, self._phase_c):
+        one = self.one_graph and not self.grad_sync.active()      # (data parallelism needs the cuts: the gradient means sit between the graphs)
+
+        def whole():
+            self._phase_a(); self._phase_b(); self._phase_c()
+        for phase in ((whole,) if one else (self._phase_a, self._phase_b, self._phase_c)):
             g = torch.cuda.CUDAGraph()
             # thread_local: a process-group watchdog thread polling its events must not invalidate the capture
             with torch.cuda.graph(g, pool=pool, stream=self._capture_stream, capture_error_mode='thread_local'):

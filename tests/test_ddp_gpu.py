@@ -196,17 +196,18 @@ def _bench(extra_env, args, launcher=None):
 def test_bench_data_parallel_dress_rehearsal_on_one_device():
     """The driver's multi-GPU bench without a node: (a) the real bench with the data-parallel SCHEDULE (the step's three graphs with RCCL all-reduce
     calls on the exchange stream between them) in a one-rank RCCL group against the plain three-graph step on the same device -- the schedule itself
-    must cost < 5 % (the twelve-phase schedule of HV_DP_SCHEDULE=phases: < 12 %, measured 7-10 %);
+    must cost < 8 % over the single-process one-graph step (the twelve-phase schedule of HV_DP_SCHEDULE=phases: < 15 %, measured 7-10 % over the three-graph step);
     (b) the real bench started as TWO ranks by torch.distributed.run on this one device (gloo transport -- RCCL refuses two ranks on one device):
     the JSON line must report what the collective layer saw (n_gpus, global batch, backend, world size)."""
     plain = _bench({}, ['--steps', '10', '--warmup', '3'])
-    assert plain['n_gpus'] == 1 and plain['comm']['world_size'] == 1 and '3 graphs' in plain['config']['launch'], plain['config']
+    assert plain['n_gpus'] == 1 and plain['comm']['world_size'] == 1 and '1 graphs' in plain['config']['launch'], plain['config']      # (single process: the whole step is one graph)
     assert len(plain['regions_ms_per_step']) == 3 and plain['ms_per_step'] == sorted(plain['regions_ms_per_step'])[1]
     one = _bench({'HV_DDP_FORCE': '1'}, ['--steps', '10', '--warmup', '3'])
     assert one['comm']['backend'] == 'nccl' and one['comm']['world_size'] == 1 and '3 graphs' in one['config']['launch'], (one['comm'], one['config'])
-    assert one['ms_per_step'] <= 1.05 * plain['ms_per_step'], ('data-parallel schedule vs single-rank step', one['ms_per_step'], plain['ms_per_step'])
+    # (measured: +0.14-0.20 ms for the two stream hops and one-rank collectives, +0.11 ms for three graphs instead of the single-process one: ~4 % of 7.7 ms)
+    assert one['ms_per_step'] <= 1.08 * plain['ms_per_step'], ('data-parallel schedule vs single-rank step', one['ms_per_step'], plain['ms_per_step'])
     ph = _bench({'HV_DDP_FORCE': '1', 'HV_DP_SCHEDULE': 'phases'}, ['--steps', '10', '--warmup', '3'])
-    assert '12 graphs' in ph['config']['launch'] and ph['ms_per_step'] <= 1.12 * plain['ms_per_step'], (ph['config'], ph['ms_per_step'], plain['ms_per_step'])
+    assert '12 graphs' in ph['config']['launch'] and ph['ms_per_step'] <= 1.15 * plain['ms_per_step'], (ph['config'], ph['ms_per_step'], plain['ms_per_step'])
     two = _bench({'HV_DDP_BACKEND': 'gloo'}, ['--gpus', '2', '--steps', '4', '--warmup', '3'],
                  launcher=[sys.executable, '-m', 'torch.distributed.run', '--standalone', '--nnodes=1', '--nproc-per-node', '2', '--local-addr', '127.0.0.1'])
     assert two['n_gpus'] == 2 and two['config']['global_batch'] == 32 and two['config']['parallelism'] == 'dp2', two['config']

@@ -122,7 +122,7 @@ def test_g7_eval_forward_bs1_matches_reference_golden():
 
 
 def test_graph_replay_matches_eager_launches(monkeypatch):
-    """The captured hipGraph step (three graphs per step) leaves the same weights, BatchNorm statistics, Adam state and
+    """The captured hipGraph step (one graph per step in a single process; three, cut where the gradient exchanges go, under data parallelism) leaves the same weights, BatchNorm statistics, Adam state and
     losses as launching the ~650 kernels eagerly: 5 steps on changing inputs from one seed, compared bit for bit."""
     monkeypatch.setenv('HV_PRECISION', 'fp16')
     import hvgan
