@@ -187,6 +187,34 @@ def fp32_record(args, dev, local_rank):
             os.environ['HV_PRECISION'] = prev
 
 
+def config5_record(args, dev, local_rank):
+    """BASELINE config #5's single-GPU workload: the same train step at 512x512, bs 16, fp16 mode (attention over 64x64 patches, L = 4096): 3 warm-up
+    (incl. the capture) + 5 timed graph replays."""
+    import torch
+    from hvgan import synth
+    from hvgan.models.pix2pix_model import Pix2PixModel
+    torch.manual_seed(1234)
+    opt = make_opt(args.precision)
+    opt.gpu_ids = [local_rank]
+    m = Pix2PixModel(opt)
+    m.setup(opt)
+    m.strict_graph = True
+    m.set_input(synth.make_batch(16, 512, seed=1234))
+    for _ in range(max(3, m.GRAPH_WARMUP + 1)):
+        m.optimize_parameters()
+    torch.cuda.synchronize()
+    n, t0 = 5, time.perf_counter()
+    for _ in range(n):
+        m.optimize_parameters()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    rec = {'workload': 'the same two-stage train step at 512x512, bs 16, fp16 mode (BASELINE config #5, one GPU)', 'ms_per_step': round(dt * 1e3, 3),
+           'slices_s': round(16 / dt, 1), 'steps': n, 'pixels_per_s': round(16 * 512 * 512 / dt / 1e6, 1)}
+    del m
+    torch.cuda.empty_cache()
+    return rec
+
+
 def device_loader_record(model, args, dev):
     """The real train loop: every step assembles 16 FRESH slices on the device from resident synthetic volumes (batch_assembly.DeviceBatchAssembler,
     SURVEY.md section 8f row f1) and hands them to set_input before optimize_parameters -- the bench's timed region replays one resident batch."""
@@ -314,9 +342,10 @@ def main():
     for _ in range(max(args.warmup, model.GRAPH_WARMUP + 1 if model.use_graph else 1)):
         step()
     barrier()
-    if model.use_graph and not (model._graphs or model._dp_graphs):
+    if model.use_graph and not model._graphs:
         raise SystemExit('bench.py: the step was not captured as hipGraphs')
     prof = profiler.KernelTimer()
+    prof.calibrate()                  # what an event pair reads around NOTHING on this box: taken off every kernel's event duration below
     serial0 = engine.SERIAL
     engine.SERIAL = True              # per-kernel HIP-event timing: one stream, the kernel has the GPU to itself
     prof.enable()                     # untimed eager survey step: time every conv launch, pick the dominant kernel class
@@ -403,7 +432,10 @@ def main():
         'regions_ms_per_step': [round(r / args.steps * 1e3, 3) for r in region_dt],
         # what the collective layer actually saw (an N-GPU record must show N ranks behind RCCL)
         'comm': {'backend': (dist.get_backend() if dist.is_initialized() else None), 'world_size': (dist.get_world_size() if dist.is_initialized() else 1),
-                 'grad_exchange': ('flat all-reduce (mean) per network on a side stream' if world > 1 else 'none (single rank)')},
+                 'grad_exchange': (('flat all-reduce (ncclAvg) per network, captured inside the step graph: D_k\'s forked from D_k\'s stream, G\'s before its Adam step'
+                                    if getattr(model, '_inline_exchange', False) else 'flat all-reduce (mean) between the step\'s three graphs on the exchange stream')
+                                   if model.grad_sync.active() else 'none (single rank)'),
+                 'dp_schedule': (model.dp_schedule if model.grad_sync.active() else None), 'capture_error': getattr(model, 'dp_capture_error', None)},
     }
     if rank == 0:
         out['roofline'] = prof.roofline(args.precision, MFMA_PEAK_TFLOPS[args.precision], name=dom[0] if dom else None)
@@ -417,20 +449,41 @@ def main():
         # passes over a serial bench run; mean per launch of this instantiation)
         pdir = os.path.join(ROOT, 'profiles')
 
+        import glob
+        traffic_files = sorted(glob.glob(os.path.join(pdir, 'r*_traffic_step.json')), reverse=True)      # newest round / tag first
+
         def add_traffic(rec):
-            for fn in ('r03i_traffic_step.json', 'r03g_traffic_step.json', 'r03f_traffic_step.json', 'r03d_traffic_step.json', 'r03_traffic_step.json', 'r02_traffic_step.json', 'r01_traffic_step.json'):
+            for fp in traffic_files:
                 try:
-                    e = json.load(open(os.path.join(pdir, fn)))['kernels'].get(rec['kernel'])
+                    e = json.load(open(fp))['kernels'].get(rec['kernel'])
                 except (OSError, ValueError, KeyError):
                     e = None
                 if e:
                     rec['traffic'] = int(e['traffic_bytes'])
-                    rec['traffic_source'] = 'profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, serial bench run)' % fn
+                    rec['traffic_source'] = 'profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, serial bench run)' % os.path.basename(fp)
                     break
         add_traffic(out['roofline'])
         if out.get('roofline_mfma'):
             add_traffic(out['roofline_mfma'])
-        out['roofline']['timed_in'] = 'eager single-stream re-run of the K steps after the timed region (HIP events on the launch stream)'
+        out['roofline']['timed_in'] = ('eager single-stream re-run of the K steps after the timed region (HIP events on the launch stream); avg_us is net of the '
+                                       'event pair\'s own reading around nothing (event_pair_overhead_us, measured in this run), avg_us_events is the raw reading')
+        # the whole step against both roofs: algorithmic FLOPs of the step and the HBM bytes the committed PMC passes measured per step
+        step_rec = {'achieved_tflops': round(GFLOP_PER_SLICE * args.batch * (args.size / 256.0) ** 2 / ms, 1)}
+        step_rec['frac_mfma'] = round(step_rec['achieved_tflops'] / MFMA_PEAK_TFLOPS[args.precision], 4)
+        for fp in traffic_files:
+            try:
+                doc = json.load(open(fp))
+                tot = doc.get('step_total_bytes')
+                if not tot:      # (files written before round 4: steps of the profiled run = launches of the once-per-step compositing kernel)
+                    once = doc['kernels'].get('post_generator_kernel', {}).get('launches')
+                    tot = int(sum(v['traffic_bytes'] * v['launches'] for v in doc['kernels'].values()) / once) if once else None
+            except (OSError, ValueError, KeyError):
+                tot = None
+            if tot and args.size == 256 and args.batch == 16 and args.precision == 'fp16':
+                step_rec.update(hbm_gb_per_step=round(tot / 1e9, 2), hbm_gbs=round(tot / 1e9 / (ms * 1e-3), 1), frac_hbm=round(tot / 1e9 / (ms * 1e-3) / profiler.HBM_PEAK_GBS, 4),
+                                traffic_source='profiles/%s (sum over every kernel of the step, PMC passes)' % os.path.basename(fp))
+                break
+        out['step_roofline'] = step_rec
         if fine:
             torch.cuda.synchronize()
             fms = sum(s.elapsed_time(e) for s, e in fine) / len(fine)
@@ -448,7 +501,7 @@ def main():
             tfg = GFLOP_FINE_FWD * args.batch * (args.size / 256.0) ** 2 / fine_graph
             out['fine_generator_forward']['graph_replay'] = {'ms': round(fine_graph, 3), 'tflops': round(tfg, 1), 'frac_of_mfma_peak': round(tfg / MFMA_PEAK_TFLOPS[args.precision], 4),
                                                              'timed_in': 'the refinement generator\'s training forward alone as one captured hipGraph (two branch streams), mean of 50 back-to-back replays, GPU otherwise idle'}
-        ngraphs = len(model._dp_graphs or ()) or len(model._graphs or ())
+        ngraphs = len(model._graphs or ())
         out['config']['launch'] = ('hipGraph replay (%d graphs/step)' % ngraphs if model.use_graph else 'eager') + \
                                   (', one stream' if args.serial else ', %d streams' % (5 if (world > 1 or model.grad_sync.active()) else 4))
         out['losses'] = {k: round(v, 4) for k, v in model.get_current_losses().items()}
@@ -457,6 +510,9 @@ def main():
         if world == 1 and not args.no_extra and args.precision == 'fp16':
             out['device_loader'] = device_loader_record(model, args, dev)
             out['fp32'] = fp32_record(args, dev, local_rank)
+            if args.size == 256:
+                out['config5'] = config5_record(args, dev, local_rank)
+                out['config5']['per_pixel_rate_vs_256'] = round(out['config5']['pixels_per_s'] / (value * 256 * 256 / 1e6), 3)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(model, args.size, 1234)
         print(json.dumps(out), flush=True)

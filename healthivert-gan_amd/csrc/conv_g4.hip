@@ -567,24 +567,30 @@ static int g4_tile_rows(int B, int Hc, int Wc, int ny) {
     return (long long)B * hv_cdiv(Hc, 16) * hv_cdiv(Wc, 16) * ny >= 200 ? 16 : 8;
 }
 
-// 4x4, stride 2, pad 1, dilation 1, fp16 NHWC views with 16-byte aligned channel rows, fragment-ordered filters.  HV_ERR_UNSUPPORTED otherwise.
-int hv_conv2d_g4(const hv_conv_desc* d, hipStream_t s) {
+// The ONE eligibility predicate of the pipelined 4x4 kernels: 4x4, stride 2 or 1, pad 1, dilation 1, fp16 NHWC views with 16-byte aligned channel rows,
+// fragment-ordered filters.  hv_conv2d_g4 launches exactly when it holds, and hv_conv2d_g4_stats_floats promises a statistics epilogue only then.
+static bool g4_eligible(const hv_conv_desc* d) {
     static const int on = getenv("HV_CONV_G4") ? atoi(getenv("HV_CONV_G4")) : 3;      // bit 0: forward, bit 1: data gradient
-    if (!(on & (d->transposed ? 2 : 1))) return HV_ERR_UNSUPPORTED;
-    if (d->KH != 4 || d->KW != 4 || (d->stride != 2 && d->stride != 1) || d->pad != 1 || d->dil != 1 || d->in_shift || d->w_bstride || d->ch_scale) return HV_ERR_UNSUPPORTED;
-    if (d->precision != HV_F16 || !d->w_f16_tiled || !d->x_f16 || !d->y_f16 || d->accumulate > 1) return HV_ERR_UNSUPPORTED;
+    if (!(on & (d->transposed ? 2 : 1))) return false;
+    if (d->KH != 4 || d->KW != 4 || (d->stride != 2 && d->stride != 1) || d->pad != 1 || d->dil != 1 || d->in_shift || d->w_bstride || d->ch_scale) return false;
+    if (d->precision != HV_F16 || !d->w_f16_tiled || !d->x_f16 || !d->y_f16 || d->accumulate > 1) return false;
     if (d->stride == 1) {
         static const int s1 = getenv("HV_CONV_G4S1") ? atoi(getenv("HV_CONV_G4S1")) : 3;      // bit 0: forward, bit 1: data gradient
-        if (!(s1 & (d->transposed ? 2 : 1)) || (d->Cout & 127) || (d->Cin & 31)) return HV_ERR_UNSUPPORTED;
+        if (!(s1 & (d->transposed ? 2 : 1)) || (d->Cout & 127) || (d->Cin & 31)) return false;
     }
-    if ((d->Cin & 31) || (d->Cout & 63) || (!d->transposed && (d->Cout & 127))) return HV_ERR_UNSUPPORTED;
+    if ((d->Cin & 31) || (d->Cout & 63) || (!d->transposed && (d->Cout & 127))) return false;
     if ((d->x_ld & 7) || (d->x_coff & 7) || ((uintptr_t)d->x & 15) || (d->y_ld & 7) || (d->y_coff & 7) || ((uintptr_t)d->y & 15) || ((uintptr_t)d->w_f16_tiled & 15))
-        return HV_ERR_UNSUPPORTED;
-    if (d->mul_src && (!d->mul_f16 || (d->mul_ld & 7) || (d->mul_coff & 7) || ((uintptr_t)d->mul_src & 15))) return HV_ERR_UNSUPPORTED;
-    if (d->stride == 2 && !d->transposed && (d->Ho != d->H / 2 || d->Wo != d->W / 2 || (d->H & 1) || (d->W & 1))) return HV_ERR_UNSUPPORTED;
-    if (d->stride == 2 && d->transposed && (d->Ho != 2 * d->H || d->Wo != 2 * d->W)) return HV_ERR_UNSUPPORTED;
-    if (d->stride == 1 && (d->Ho != d->H + (d->transposed ? 1 : -1) || d->Wo != d->W + (d->transposed ? 1 : -1) || d->Ho < 1 || d->Wo < 1)) return HV_ERR_UNSUPPORTED;
-    if ((long long)d->B * d->H * d->W * d->x_ld >= (1ll << 30) || (long long)d->B * d->Ho * d->Wo * d->y_ld >= (1ll << 30)) return HV_ERR_UNSUPPORTED;
+        return false;
+    if (d->mul_src && (!d->mul_f16 || (d->mul_ld & 7) || (d->mul_coff & 7) || ((uintptr_t)d->mul_src & 15))) return false;
+    if (d->stride == 2 && !d->transposed && (d->Ho != d->H / 2 || d->Wo != d->W / 2 || (d->H & 1) || (d->W & 1))) return false;
+    if (d->stride == 2 && d->transposed && (d->Ho != 2 * d->H || d->Wo != 2 * d->W)) return false;
+    if (d->stride == 1 && (d->Ho != d->H + (d->transposed ? 1 : -1) || d->Wo != d->W + (d->transposed ? 1 : -1) || d->Ho < 1 || d->Wo < 1)) return false;
+    if ((long long)d->B * d->H * d->W * d->x_ld >= (1ll << 30) || (long long)d->B * d->Ho * d->Wo * d->y_ld >= (1ll << 30)) return false;
+    return true;
+}
+
+int hv_conv2d_g4(const hv_conv_desc* d, hipStream_t s) {
+    if (!g4_eligible(d)) return HV_ERR_UNSUPPORTED;
     G4K k;
     k.dbg = getenv("HV_G4_DBG") ? atoi(getenv("HV_G4_DBG")) : 0;
     k.x = d->x; k.w = reinterpret_cast<const _Float16*>(d->w_f16_tiled); k.bias = d->bias; k.y = d->y; k.mul_src = d->mul_src;
@@ -616,11 +622,8 @@ int hv_conv2d_g4(const hv_conv_desc* d, hipStream_t s) {
 // kernel has no statistics epilogue (the caller runs its reduction pass)
 size_t hv_conv2d_g4_stats_floats(const hv_conv_desc* d, int* nparts) {
     hv_conv_desc t = *d;
-    if (t.transposed || t.KH != 4 || t.KW != 4 || (t.stride != 2 && t.stride != 1) || t.pad != 1 || t.dil != 1 || t.in_shift || t.w_bstride || t.ch_scale) return 0;
-    if (t.precision != HV_F16 || !t.w_f16_tiled || !t.x_f16 || !t.y_f16 || t.accumulate || (t.Cin & 31) || (t.Cout & 127)) return 0;
-    static const int on = getenv("HV_CONV_G4") ? atoi(getenv("HV_CONV_G4")) : 3;
-    static const int s1 = getenv("HV_CONV_G4S1") ? atoi(getenv("HV_CONV_G4S1")) : 3;
-    if (!(on & 1) || (t.stride == 2 && ((t.H & 1) || (t.W & 1))) || (t.stride == 1 && !(s1 & 1))) return 0;
+    // the forward launches of hv_conv2d_g4 (same predicate: alignment, size limits and the act' operand included) that assign their output
+    if (t.transposed || t.accumulate || !g4_eligible(&t)) return 0;
     const int th = g4_tile_rows(t.B, t.Ho, t.Wo, t.Cout / 128);
     const int parts = t.B * hv_cdiv(t.Ho, th) * hv_cdiv(t.Wo, 16);
     if (nparts) *nparts = parts;

@@ -384,6 +384,9 @@ static int conv2d_dispatch(const hv_conv_desc* d, void* stream) {
         return HV_ERR_UNSUPPORTED;
     if (d->H > 16000 || d->W > 16000 || (d->KH - 1) * d->dil > 120 || (d->KW - 1) * d->dil > 120) return HV_ERR_UNSUPPORTED;
 
+    // statistics epilogue asked for: only a kernel that has one may run (a silent fallback would leave the caller's partial sums unwritten and its
+    // normalisation reading zeros) -- callers size `stats` with hv_conv2d_stats_parts, which is 0 exactly when this refuses
+    if (d->stats && !hv_conv2d_g4_stats_floats(d, nullptr)) return HV_ERR_UNSUPPORTED;
     if (d->x1) {         // extra input channel: the filters-in-LDS kernel or nothing (the caller keeps the materialised concat)
         if (d->precision != HV_F16 || !d->w_f16 || !d->w_f16_tiled || !d->y_f16 || d->transposed || d->dil != 1 || d->stride != 1 || d->KH != 3 || d->KW != 3 || !d->w1 ||
             d->pool2 || d->stats || d->x1_ld < 1)
@@ -499,6 +502,19 @@ static int conv2d_dispatch(const hv_conv_desc* d, void* stream) {
     hv_path_note = 0;
     if (d->precision == HV_F32) return vec_in ? dispatch_conv<float, false>(k, s) : dispatch_conv<float, true>(k, s);
     return vec_in ? dispatch_conv<_Float16, false>(k, s) : dispatch_conv<_Float16, true>(k, s);
+}
+
+// Would hv_conv2d serve this descriptor?  Only the forms WITHOUT a generic fallback can be refused for their shape -- the extra input channel (x1), the
+// pooled data gradient (pool2), a statistics epilogue (stats) -- so callers ask before they drop the materialised alternative (engine.ConvNode.split_forward,
+// ops.pool2_ok).  The answer comes from the dispatch itself run in probe mode (every launch site returns before its launch): no mirror of the checks.
+thread_local int hv_probe_only = 0;
+extern "C" int hv_conv2d_supported(const hv_conv_desc* d) {
+    if (!d) return 0;
+    if (!d->x1 && !d->pool2) return d->stats ? (hv_conv2d_g4_stats_floats(d, nullptr) ? 1 : 0) : 1;
+    hv_probe_only = 1;
+    const int rc = conv2d_dispatch(d, nullptr);
+    hv_probe_only = 0;
+    return rc == HV_OK ? 1 : 0;
 }
 
 // profiling: with hv_set_kernel_timing armed, the two events are recorded here, microseconds apart on the host, right around the launch(es) of

@@ -389,6 +389,7 @@ static int launch_lf(HaloK& k, hipStream_t s) {
     C.t0 = 0;
     C.PH = G::PH; C.PW = G::PW;
     kk.w = kk.wt; kk.w_bytes = kk.wt_bytes;
+    if (hv_probe_only) return HV_OK;          // hv_conv2d_supported: this instantiation would take the descriptor
     auto kern = conv_lf_kernel<CIN, CO, TH, WPS, X1>;
     static bool raised = false;
     if (G::LDS_BYTES > 48 * 1024 && !raised) {
@@ -398,7 +399,7 @@ static int launch_lf(HaloK& k, hipStream_t s) {
     }
     dim3 grid(C.tiles * kk.B * (kk.dil > 1 ? kk.dil * kk.dil : 1), hv_cdiv(kk.Cout, CO));
     hv_path_note = 7;
-    HV_KNAME("conv_lf_kernel<%d, %d, %d, %d>", CIN, CO, TH, WPS);
+    HV_KNAME("conv_lf_kernel<%d, %d, %d, %d, %s>", CIN, CO, TH, WPS, X1 ? "true" : "false");      // (as rocprofv3 prints the instantiation)
     hipLaunchKernelGGL(kern, grid, dim3(G::NTHR), G::LDS_BYTES, s, kk);
     HV_LAUNCH_CHECK();
     return HV_OK;

@@ -16,6 +16,7 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
     } while (0)
 
 extern thread_local int hv_path_note;   // set by the launcher that actually launched (hv_last_kernel_path)
+extern thread_local int hv_probe_only;  // hv_conv2d_supported: the dispatch runs without launching (the launch sites of the forms it asks about return HV_OK early)
 // name of the kernel instantiation the last launcher launched, as rocprofv3 lists it (hv_last_kernel_name)
 extern thread_local char hv_kname[192];
 #define HV_KNAME(...) snprintf(hv_kname, sizeof(hv_kname), __VA_ARGS__)

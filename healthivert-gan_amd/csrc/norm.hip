@@ -253,7 +253,12 @@ extern "C" int hv_norm_act_forward(const hv_norm_desc* d, void* stream) {
     const bool use_running = d->norm == HV_NORM_BATCH && !d->training;
     if (use_running && (!d->running_mean || !d->running_var)) return HV_ERR_ARG;
     const size_t need = (size_t)pl.G * pl.nchunk * 2 * d->C * sizeof(double);
-    if (!use_running && !(d->partials && d->n_partials > 0) && (!d->workspace || d->workspace_bytes < need || ((uintptr_t)d->workspace & 7))) return HV_ERR_WORKSPACE;
+    // statistics handed over by the producing conv (hv_conv_desc.stats): no reduction pass over x
+    // (groups > 1: the partials of whole images, in image order -- every group is a contiguous, equal share of them)
+    const bool handed = d->partials && d->n_partials > 0 && d->norm == HV_NORM_BATCH && !use_running && pl.G >= 1 && d->n_partials % pl.G == 0 &&
+                        (d->n_partials / pl.G) % (d->B / pl.G) == 0;
+    if (d->partials && d->n_partials > 0 && !use_running && !handed) return HV_ERR_ARG;      // partials that do not divide into the groups: never a silent reduction into an unchecked workspace
+    if (!use_running && !handed && (!d->workspace || d->workspace_bytes < need || ((uintptr_t)d->workspace & 7))) return HV_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     NormK k = {};
     k.x = d->x; k.out = d->y; k.x_ld = d->x_ld; k.x_coff = d->x_coff; k.o_ld = d->y_ld; k.o_coff = d->y_coff;
@@ -261,10 +266,6 @@ extern "C" int hv_norm_act_forward(const hv_norm_desc* d, void* stream) {
     k.CB = pl.CB; k.lc = n_log2(vec ? d->C / 4 : d->C);
     k.stats = d->stats; k.gamma = d->norm == HV_NORM_BATCH ? d->gamma : nullptr; k.beta = d->beta;
     double* part = (double*)d->workspace;
-    // statistics handed over by the producing conv (hv_conv_desc.stats): no reduction pass over x
-    // (groups > 1: the partials of whole images, in image order -- every group is a contiguous, equal share of them)
-    const bool handed = d->partials && d->n_partials > 0 && d->norm == HV_NORM_BATCH && !use_running && pl.G >= 1 && d->n_partials % pl.G == 0 &&
-                        (d->n_partials / pl.G) % (d->B / pl.G) == 0;
     if (!use_running && !handed) {
         dim3 grid(pl.nchunk, pl.G, pl.slices);
         if (d->f16) {

@@ -5,10 +5,11 @@ models/networks.py:112-116).  Here every rank runs the whole step on its own 16-
 reference's per-batch quirks stay per-rank) and the four networks' gradients are averaged with one flat
 all-reduce each on a dedicated HIP stream:
 
-* D_k's reduction is issued the moment D_k's backward has been queued on D_k's stream and only D_k's optimiser step
-  waits for it, so it overlaps the other discriminators' passes and their generator-step forwards;
-* the generator's reduction and its Adam step run on the exchange stream BESIDE the next step's real-image
-  discriminator passes (which need neither the generator's weights nor its gradients).
+* D_k's reduction is issued from D_k's own stream the moment D_k's gradients are final and only D_k's optimiser step
+  waits for it, so it overlaps the other discriminators' passes;
+* the generator's reduction sits between its backward and its Adam step;
+* RCCL collectives are stream-ordered, so all four are captured INSIDE the step's hipGraph (`reduce_inline`); a transport that
+  cannot be captured (gloo: tests and rehearsals) gets the step cut into three graphs with the exchanges between them (`reduce`).
 
 `init_from_env()` joins the process group that `python -m torch.distributed.run` describes in the environment, so
 a reference `train.py` needs no edit.  With no process group initialised every call is a no-op.
@@ -65,6 +66,18 @@ class GradSync:
     def active():
         # HV_DDP_FORCE=1: run the exchange even in a one-rank group (RCCL smoke test of the exact call sequence on a single GPU)
         return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get('HV_DDP_FORCE') == '1')
+
+    def capturable(self):
+        """True when the transport's collectives are stream-ordered device work that a hipGraph capture records (RCCL); gloo's run on the host."""
+        return self.active() and dist.get_backend(self.group) == 'nccl' and os.environ.get('HV_DDP_CAPTURE', '1') != '0'
+
+    def reduce_inline(self, flat):
+        """Average `flat` across the ranks IN the calling stream's order: the process group's own stream waits for the calling stream, runs the
+        collective (ncclAvg: the mean is taken inside it), and the calling stream waits for the result -- two event edges, no host block, and under
+        stream capture both edges and the collective become nodes of the graph being captured.  Other streams keep running beside it."""
+        if not flat.is_cuda:
+            raise RuntimeError('reduce_inline: device tensors only')
+        dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
 
     def exchange_stream(self, device):
         if self.stream is None:

@@ -163,7 +163,7 @@ class ParamSet:
 
 class ConvNode:
     """conv (+bias +activation) between two NHWC views; knows how to run forward and backward."""
-    __slots__ = ('p', 'x', 'y', 'k', 's', 'pad', 'd', 'act', 'shift', 'need_dx', 'transposed', 'use_bias', 'dx_c', 'pool_to', 'split')
+    __slots__ = ('p', 'x', 'y', 'k', 's', 'pad', 'd', 'act', 'shift', 'need_dx', 'transposed', 'use_bias', 'dx_c', 'pool_to', 'split', '_split_ok')
 
     def __init__(self, p, x, y, s=1, pad=0, d=1, act='none', shift=0, need_dx=True, transposed=False, use_bias=True, dx_c=None):
         self.p, self.x, self.y, self.k, self.s, self.pad, self.d = p, x, y, p.k, s, pad, d
@@ -178,13 +178,22 @@ class ConvNode:
         # filters-in-LDS kernel serves the shape the forward reads `low` with the fused up-sampling and adds x1's taps in its epilogue, so the
         # up-sampled part of x is only materialised for the backward (split_forward() tells)
         self.split = None
+        self._split_ok = None
 
     def split_forward(self, prec):
+        """True when the forward reads [up-sampled low | x1] without the concat: asked of the C dispatch (hv_conv2d_supported -- the x1 kernel exists
+        for two channel shapes only and follows the HV_CONV_LF knobs), once per node; otherwise the materialised concat is built and read."""
         p = self.p
-        if self.split is None or not SPLIT_CONCAT or p.w_fwd_t2 is None or ops.precision_id(prec) != ops.F16 or self.k != 3 or self.s != 1 or self.d != 1:
+        if self.split is None or not SPLIT_CONCAT or p.w_fwd_t2 is None or ops.precision_id(prec) != ops.F16:
             return False
-        low, x1 = self.split
-        return bool(low.f16 and self.y.f16 and low.C == p.split_k and low.ld % 8 == 0 and low.coff % 8 == 0 and self.y.ld % 8 == 0 and p.cout % 8 == 0)
+        key = (ops.precision_id(prec), p.w_fwd_t2.data_ptr(), self.y.t.data_ptr())
+        if getattr(self, '_split_ok', None) is None or self._split_ok[0] != key:
+            low, x1 = self.split
+            ok = bool(low.f16 and self.y.f16 and low.C == p.split_k) and ops.conv2d_supported(
+                low, p.w_fwd, self.y, self.k, self.s, self.pad, self.d, bias=p.bias if self.use_bias else None, act=self.act, w_h=p.w_fwd_h, w_t=p.w_fwd_t2,
+                in_shift=1, precision=prec, cin=p.split_k, cout=p.cout, x1=(x1, p.w_fwd, p.split_k, p.taps * p.cin_fwd, p.cin_fwd))
+            self._split_ok = (key, ok)
+        return self._split_ok[1]
 
     def forward(self, prec, stats=None):
         p = self.p
@@ -368,7 +377,7 @@ FUSE_ACT = os.environ.get('HV_FUSE_ACT', '1') != '0'   # act' of the producer la
 
 def _pool2_node_ok(node, gfull, gx, prec):
     p = node.p
-    return ops.pool2_ok(gfull, gx, node.k, node.s, node.pad, node.d, prec, p.w_bwd_h, p.w_bwd_t)
+    return ops.pool2_ok(gfull, gx, node.k, node.s, node.pad, node.d, prec, p.w_bwd_h, p.w_bwd_t, w=p.w_bwd)
 
 
 def chain_link(n, nxt, prec=None):

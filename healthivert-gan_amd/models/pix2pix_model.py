@@ -90,8 +90,7 @@ class Pix2PixModel(BaseModel):
         self._in = {}
         self._shapes, self._cur = {}, None      # per batch shape: input buffers, warm-up count, captured graphs
         self._graphs = None
-        self._dp_graphs = None
-        self._dp_replay = True
+        self._inline_exchange = False
         self._eager_steps = 0
         self.use_graph = _os_environ_graph()
         self.grad_sync = ddp.GradSync() if self.isTrain else None
@@ -108,17 +107,21 @@ class Pix2PixModel(BaseModel):
         self.concurrent_d = _os.environ.get('HV_CONCURRENT_D', '1') != '0'
         # fake | real discriminator passes as ONE 2B-sample launch sequence (per-half BatchNorm groups).  Round 2: no gain beside the three-stream overlap;
         # re-measured at the end of round 3 with the pipelined 4x4 kernels (one round of one workgroup per CU at bs 16): 8.18 -> 8.09 ms in three same-box
-        # pairs, although it gives up the real-image passes' overlap with the generator forward.  Single-process schedule only: the data-parallel schedule
-        # keeps the split real-first form (the generator's all-reduce and Adam step hide behind the next step's real-image passes there).
+        # pairs, although it gives up the real-image passes' overlap with the generator forward.  Both the single-process and the data-parallel step take it.
         self.batch_d = _os.environ.get('HV_BATCH_D', '1') != '0'
-        # data-parallel step schedule: 'graphs' = the single-process three-graph step with the gradient means between the graphs; 'phases' = twelve
-        # phase graphs with the exchanges hidden behind other phases (see optimize_parameters / _step_data_parallel)
         # single process: the three phases captured as ONE graph (7.81 -> 7.70 ms over four same-box pairs: two graph-launch boundaries less); HV_ONE_GRAPH=0 keeps
-        # the three graphs, and a data-parallel job always does (the gradient means sit between them)
+        # the three graphs.
         self.one_graph = _os.environ.get('HV_ONE_GRAPH', '1') != '0'
-        self.dp_schedule = _os.environ.get('HV_DP_SCHEDULE', 'graphs')
-        if self.dp_schedule not in ('graphs', 'phases'):
-            raise ValueError("HV_DP_SCHEDULE must be 'graphs' or 'phases'")
+        # data-parallel step schedule (one process per GPU):
+        #   'captured' (default with the RCCL backend): the single-process step AS IT IS, with the gradient means issued INSIDE it -- D_k's all-reduce on
+        #       D_k's own stream the moment its gradients are final (it runs beside the other discriminators' passes; only D_k's Adam step waits for it),
+        #       the generator's between its backward and its Adam step.  RCCL collectives are stream-ordered, so they are captured into the step's ONE
+        #       hipGraph like any kernel: no graph cut, no host in the loop.
+        #   'graphs': the step cut into its three graphs where the exchanges belong, the means issued eagerly between them on the exchange stream (the main
+        #       stream waits for each).  Taken when the transport cannot be captured (gloo: tests / rehearsals on one device) or a capture with collectives fails.
+        self.dp_schedule = _os.environ.get('HV_DP_SCHEDULE', 'captured')
+        if self.dp_schedule not in ('captured', 'graphs'):
+            raise ValueError("HV_DP_SCHEDULE must be 'captured' or 'graphs'")
         self.real_first = _os.environ.get('HV_REAL_FIRST', '1') != '0'   # D real passes overlap the generator forward
 
     # tensors forward()/backward bind as attributes; they live in per-shape buffers, so the names follow the active batch shape
@@ -136,13 +139,13 @@ class Pix2PixModel(BaseModel):
         key = tuple(input['A_mask'].shape)
         st = self._shapes.get(key)
         if st is None:
-            st = self._shapes[key] = {'in': {}, 'graphs': None, 'dp_graphs': None, 'eager': 0}
+            st = self._shapes[key] = {'in': {}, 'graphs': None, 'eager': 0}
         if st is not self._cur:
             if self._cur is not None:
-                self._cur.update(graphs=self._graphs, dp_graphs=self._dp_graphs, eager=self._eager_steps,
+                self._cur.update(graphs=self._graphs, eager=self._eager_steps,
                                  outs={n: getattr(self, n) for n in self._STEP_OUTPUTS if hasattr(self, n)})
             self._cur, self._in = st, st['in']
-            self._graphs, self._dp_graphs, self._eager_steps = st['graphs'], st['dp_graphs'], st['eager']
+            self._graphs, self._eager_steps = st['graphs'], st['eager']
             for n, v in st.get('outs', {}).items():     # a graph replay does not re-run the Python that binds these names
                 setattr(self, n, v)
 
@@ -151,7 +154,7 @@ class Pix2PixModel(BaseModel):
             if b is None or b.shape != t.shape or b.dtype != dtype:
                 b = torch.empty(t.shape, dtype=dtype, device=self.device)
                 self._in[name] = b
-                self._graphs = self._dp_graphs = None        # input addresses changed: captured graphs are stale,
+                self._graphs = None        # input addresses changed: captured graphs are stale,
                 self._eager_steps = 0      # and the new shape needs its own eager warm-up (plans, tables) before a capture
             b.copy_(t, non_blocking=True)
             return b
@@ -392,6 +395,8 @@ class Pix2PixModel(BaseModel):
                     self.set_requires_grad(getattr(self, 'netD_%d' % k), True)
                     getattr(self, 'optimizer_D_%d' % k).zero_grad()
                     bw()
+                if self._inline_exchange:       # D_k's mean over the ranks, forked from D_k's stream: beside the other discriminators' passes
+                    self.grad_sync.reduce_inline(getattr(self, 'netD_%d' % k).paramset().flat_grad)
         self._join_d(main)
 
     def _phase_b(self):
@@ -409,6 +414,8 @@ class Pix2PixModel(BaseModel):
         self.set_requires_grad([self.netD_1, self.netD_2, self.netD_3], False)
         self.optimizer_G.zero_grad()
         self.backward_G(d_done=True)
+        if self._inline_exchange:
+            self.grad_sync.reduce_inline(self.netG.paramset().flat_grad)
 
     def _phase_c(self):
         self._opt_step(self.optimizer_G, self.netG)
@@ -425,6 +432,27 @@ class Pix2PixModel(BaseModel):
         self.sync_tail()
         return {n: getattr(self, 'optimizer_' + n).skipped_steps() for n in ('G', 'D_1', 'D_2', 'D_3')}
 
+    OVERFLOW_WARN_RUN = 3      # consecutive loss reads that each saw new skipped steps before the scale is called too large
+
+    def get_current_losses(self):
+        """The reference's loss dict (base_model.py:136-142).  The losses are read on the host here anyway, so the overflow guard's counters are read
+        with them: a step skipped by the guard is reported on the spot, and skips seen at OVERFLOW_WARN_RUN reads in a row say that HV_GRAD_SCALE is
+        too large for this data (a persistent overflow would otherwise freeze a network's weights behind normal-looking losses)."""
+        out = BaseModel.get_current_losses(self)
+        if self.isTrain and self.grad_scale != 1.0:
+            now = self.overflow_steps()
+            last = getattr(self, '_overflow_seen', None) or dict.fromkeys(now, 0)
+            new = {n: now[n] - last[n] for n in now if now[n] > last[n]}
+            self._overflow_seen = now
+            self._overflow_run = getattr(self, '_overflow_run', 0) + 1 if new else 0
+            if new:
+                import warnings
+                msg = 'fp16 overflow guard skipped optimiser steps since the last loss read: %s (HV_GRAD_SCALE=%g)' % (new, self.grad_scale)
+                if self._overflow_run >= self.OVERFLOW_WARN_RUN:
+                    msg += ' -- %d reads in a row: the gradient scale is too large for this data, restart with HV_GRAD_SCALE=%g' % (self._overflow_run, self.grad_scale / 4)
+                warnings.warn(msg)
+        return out
+
     def _join_d(self, main):
         if self.concurrent_d and not engine.SERIAL:
             for side in self._d_streams:
@@ -439,54 +467,59 @@ class Pix2PixModel(BaseModel):
             raise RuntimeError('hipGraph capture of the train step failed: %s' % str(e).splitlines()[0]) from e
         import warnings
         warnings.warn('hipGraph capture of the train step failed (%s); continuing with eager launches' % str(e).splitlines()[0])
-        self.use_graph, self._graphs, self._dp_graphs = False, None, None
+        self.use_graph, self._graphs = False, None
         torch.cuda.synchronize(self.device)
 
     def optimize_parameters(self):
         """forward; D_1, D_2, D_3 updates; G update (reference :356-382).
 
         The step is device-only (no host reads, learning rate and Adam step count live on the device), so after
-        GRAPH_WARMUP eager steps its phases are captured once as hipGraphs and replayed: ~650 kernel launches per
-        step become a few graph launches, which removes the host launch latency that otherwise leaves the GPU idle
-        between the short kernels of the backward passes.  A multi-GPU job runs the data-parallel schedule
-        (_step_data_parallel); HV_GRAPH=0 or an active kernel timer keeps the eager path."""
+        GRAPH_WARMUP eager steps it is captured once as a hipGraph and replayed: ~490 kernel launches per step become
+        one graph launch, which removes the host launch latency that otherwise leaves the GPU idle between the short
+        kernels of the backward passes.  In a multi-GPU job (one process per GPU) the four networks' flat gradients are
+        averaged over the ranks inside the same step -- see `dp_schedule` in __init__; HV_GRAPH=0 or an active kernel
+        timer keeps the eager path."""
         for o in self.optimizers:
             o.sync_lr()
         graphable = self.use_graph and ops.timer() is None
         dp = self.grad_sync.active()
-        if dp and self.dp_schedule == 'phases':
-            return self._step_data_parallel(graphable)
-        if dp and self._eager_steps == 0 and self._graphs is None:
+        inline = dp and self.dp_schedule == 'captured' and self.grad_sync.capturable()
+        self._inline_exchange = inline
+        cut = dp and not inline            # the means sit BETWEEN the step's graphs (exchange stream, issued eagerly)
+        if cut and self._eager_steps == 0 and self._graphs is None:
             self._home_d_grads()
-        # Data parallelism, 'graphs' schedule (default since the end of round 3): the single-process step as it is -- its three graphs were cut where
-        # the exchanges belong -- with the flat gradients averaged between them: D_1..D_3 after graph A, G after graph B (exchange stream; the main
-        # stream waits for each mean: no overlap with compute, no extra graphs).  Measured on one device in a one-rank RCCL group: the twelve-phase
-        # schedule costs 0.55-0.75 ms per step over this one (8.44 vs 7.7-7.9 ms) before any communication, more than the four all-reduces it hides
-        # are expected to take over xGMI (three of 11 MB, one of 4 MB); HV_DP_SCHEDULE=phases keeps it.
         if graphable and self._graphs is None and self._eager_steps >= self.GRAPH_WARMUP:
             try:
-                self._capture()
+                self._capture(cut)
             except RuntimeError as e:
+                if inline:
+                    # a runtime that refuses to capture the collectives: keep the step, cut it at the exchanges instead (they are then issued eagerly)
+                    import warnings
+                    warnings.warn('hipGraph capture of the step with its RCCL collectives failed (%s); falling back to HV_DP_SCHEDULE=graphs' % str(e).splitlines()[0])
+                    torch.cuda.synchronize(self.device)
+                    self.dp_schedule, self._graphs, self._eager_steps = 'graphs', None, 0
+                    self.dp_capture_error = str(e).splitlines()[0]
+                    return self.optimize_parameters()
                 self._graph_failed(e)
                 graphable = False
         replay = graphable and self._graphs is not None
-        if replay and len(self._graphs) == 1:      # the whole step as one graph (single process)
+        if replay and len(self._graphs) == 1:      # the whole step as one graph
             self._graphs[0].replay()
             return
         phases = self._graphs if replay else (self._phase_a, self._phase_b, self._phase_c)
         run = (lambda ph: ph.replay()) if replay else (lambda ph: ph())
         run(phases[0])
-        if dp:
+        if cut:
             self._exchange([self.netD_1, self.netD_2, self.netD_3])
         run(phases[1])
-        if dp:
+        if cut:
             self._exchange([self.netG])
         run(phases[2])
         if not replay:
             self._eager_steps += 1
 
     def _home_d_grads(self):
-        """Data parallelism: the three discriminators' flat gradient buffers as three consecutive slices of ONE buffer (ParamSet.grad_home, taken up
+        """Cut schedule: the three discriminators' flat gradient buffers as three consecutive slices of ONE buffer (ParamSet.grad_home, taken up
         when a set lays out its tables), so that their means are one collective."""
         if getattr(self, '_d_grad_arena', None) is not None:
             return
@@ -503,8 +536,9 @@ class Pix2PixModel(BaseModel):
             off += rup(n)
 
     def _exchange(self, nets):
-        """Mean over the ranks of the networks' flat gradients (one all-reduce each, issued back to back on the exchange stream -- ONE for all of them
-        when their buffers lie back to back, see _home_d_grads); the current stream continues when all of them are done.  Nothing blocks the host."""
+        """Cut schedule: mean over the ranks of the networks' flat gradients (one all-reduce each, issued back to back on the exchange stream -- ONE
+        for all of them when their buffers lie back to back, see _home_d_grads); the current stream continues when all of them are done.  Nothing
+        blocks the host."""
         main = torch.cuda.current_stream(self.device)
         flats = [n.paramset().flat_grad for n in nets]
         arena = getattr(self, '_d_grad_arena', None)
@@ -517,127 +551,17 @@ class Pix2PixModel(BaseModel):
             if ev is not None:
                 main.wait_event(ev)
 
-    # ---------------------------------------------------------------- the data-parallel step (one process per GPU)
-    # Phases, the stream each runs on, and what it waits for:
-    #   real_k  (S_k)   D_k on the real images, gradients assigned        <- the batch (main)
-    #   gfwd    (main)  generator forward + compositing + Sobel           <- previous step's G Adam (exchange stream)
-    #   fake_k  (S_k)   D_k on the fakes, gradients accumulated, finish   <- gfwd
-    #   [exchange stream: mean of D_k's flat gradient over the ranks      <- fake_k]
-    #   dstep_k (S_k)   Adam D_k, D_k(fake) with the new weights, d/dfake <- D_k's reduction only
-    #   gbwd    (main)  generator losses + backward                       <- dstep_1..3
-    #   [exchange stream: mean of G's flat gradient, then gadam = Adam G  <- gbwd]
-    # so D_k's reduction runs beside the other discriminators' passes / generator-step forwards, and the generator's
-    # reduction + Adam beside the NEXT step's real_k.  Each phase is one hipGraph after the warm-up steps; the RCCL calls are
-    # issued eagerly between the graph launches (never captured), and nothing blocks the host.
-    def _dp_phases(self):
-        def real(k):
-            def f():
-                reals = {1: lambda: self.real_B, 2: lambda: self.real_B_mask, 3: self._real_local_early}
-                self.set_requires_grad(getattr(self, 'netD_%d' % k), True)
-                getattr(self, 'optimizer_D_%d' % k).zero_grad()
-                self._d_real_first(k, reals[k]())
-            return f
-
-        def fake(k):
-            return lambda: self._d_fake_second(k, {1: self.fake_B, 2: self.fake_B_mask_raw, 3: self.fake_B_local}[k])
-
-        def dstep(k):
-            def f():
-                self._opt_step(getattr(self, 'optimizer_D_%d' % k), getattr(self, 'netD_%d' % k))
-                self._g_step_D(k)
-            return f
-
-        def gbwd():
-            self.set_requires_grad([self.netD_1, self.netD_2, self.netD_3], False)
-            self.optimizer_G.zero_grad()
-            self.backward_G(d_done=True)
-        ph = {'gfwd': self.forward, 'gbwd': gbwd, 'gadam': self._phase_c}
-        for k in (1, 2, 3):
-            ph['real%d' % k], ph['fake%d' % k], ph['dstep%d' % k] = real(k), fake(k), dstep(k)
-        return ph
-
-    def _dp_setup(self):
-        if getattr(self, '_d_streams', None) is None:
-            self._d_streams = [engine.named_stream('discriminator-%d' % k, self.device) for k in (1, 2, 3)]
-            engine.NO_FORK_STREAMS.update(st.cuda_stream for st in self._d_streams)
-        if getattr(self, '_dp_ph', None) is None:
-            self._dp_ph = self._dp_phases()
-            self._dp_graphs = None
-        self._dxs = getattr(self, '_dxs', None) or {}
-        comm = self.grad_sync.exchange_stream(self.device)
-        self.netG._tail_stream = comm          # direct users of netG (train.py's evaluate_model) wait for the pending Adam step
-        return comm
-
-    def _dp_run(self, name, st):
-        with torch.cuda.stream(st):
-            g = self._dp_graphs.get(name) if (self._dp_graphs and self._dp_replay) else None
-            if g is not None:
-                g.replay()
-            else:
-                self._dp_ph[name]()
-
     def sync_tail(self):
-        """Order the current stream after the generator's pending all-reduce + Adam step (they run on the exchange stream)."""
-        if self.grad_sync is not None and self.grad_sync.stream is not None:
-            torch.cuda.current_stream(self.device).wait_stream(self.grad_sync.stream)
+        """Nothing of a step runs on after optimize_parameters() returns to the current stream (the twelve-phase schedule of rounds 1-3, whose
+        generator Adam step trailed on the exchange stream, is gone); kept for callers."""
+        return None
 
-    def _step_data_parallel(self, graphable):
-        comm = self._dp_setup()
-        main = torch.cuda.current_stream(self.device)
-        S = self._d_streams
-        serial = engine.SERIAL
-        on = (lambda k: main) if serial else (lambda k: S[k - 1])
-        if graphable and self._dp_graphs is None and self._eager_steps >= self.GRAPH_WARMUP:
-            try:
-                self._capture_data_parallel()
-            except RuntimeError as e:
-                self._graph_failed(e)
-        self._dp_replay = bool(graphable)           # an active kernel timer / HV_GRAPH=0: launch the phases eagerly
-        for k in (1, 2, 3):
-            on(k).wait_stream(main)                 # the batch (set_input copies) and last step's readers of D_k's outputs
-            self._dp_run('real%d' % k, on(k))
-        main.wait_stream(comm)                      # last step's generator Adam
-        self._dp_run('gfwd', main)
-        events = {}
-        for k in (1, 2, 3):
-            on(k).wait_stream(main)
-            self._dp_run('fake%d' % k, on(k))
-            events[k] = self.grad_sync.reduce(getattr(self, 'netD_%d' % k).paramset().flat_grad, after=on(k))
-        for k in (1, 2, 3):
-            if events[k] is not None:
-                on(k).wait_event(events[k])
-            self._dp_run('dstep%d' % k, on(k))
-        for k in (1, 2, 3):
-            main.wait_stream(on(k))
-        self._dp_run('gbwd', main)
-        self.grad_sync.reduce(self.netG.paramset().flat_grad, after=main)
-        self._dp_run('gadam', comm)
-        if serial:
-            main.wait_stream(comm)
-        if not (self._dp_graphs and graphable):
-            self._eager_steps += 1
-
-    def _capture_data_parallel(self):
-        if getattr(self, '_capture_stream', None) is None:
-            self._capture_stream = engine.named_stream('capture', self.device)
-        torch.cuda.synchronize(self.device)
-        graphs = {}
-        for name, fn in self._dp_ph.items():
-            # the discriminator phases are captured on the stream they replay on: per-stream scratch buffers stay disjoint
-            # between phases that run concurrently
-            st = self._d_streams[int(name[-1]) - 1] if name[-1] in '123' else self._capture_stream
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=st, capture_error_mode='thread_local'):
-                fn()
-            graphs[name] = g
-        self._dp_graphs = graphs
-
-    def _capture(self):
+    def _capture(self, cut=False):
         if getattr(self, '_capture_stream', None) is None:
             self._capture_stream = engine.named_stream('capture', self.device)
         torch.cuda.synchronize(self.device)
         graphs, pool = [], None
-        one = self.one_graph and not self.grad_sync.active()      # (data parallelism needs the cuts: the gradient means sit between the graphs)
+        one = self.one_graph and not cut      # (the cut data-parallel schedule issues its gradient means between the graphs)
 
         def whole():
             self._phase_a(); self._phase_b(); self._phase_c()

@@ -162,7 +162,7 @@ def conv_out_size(n, k, stride, pad, dil):
 
 def conv2d(x, w, y, k, stride=1, pad=0, dil=1, bias=None, act='none', transposed=False, in_shift=0, alpha=1.0,
            accumulate=0, ch_scale=None, w_bstride=0, ch_scale_bstride=0, precision=None, cin=None, cout=None, w_h=None, mul=None, w_t=None,
-           stats=None, _parts_only=False, pool2=False, x1=None):
+           stats=None, _parts_only=False, pool2=False, x1=None, _supported_only=False):
     """y = act(alpha*ch_scale*conv(x, w) + bias)  [* act'(m) with mul = (Act m, activation name): see hv_conv_desc.mul_src].  x,y: Act; w: prepared [CoutF][k*k][CinP] tensor (or [B][...] with
     w_bstride).  cin/cout default to the view widths (x.C consumed, y.C produced).
     stats: float tensor of conv2d_stats_parts(...) * Cout * 2 elements that receives the per-channel partial sums of the stored output
@@ -199,6 +199,8 @@ def conv2d(x, w, y, k, stride=1, pad=0, dil=1, bias=None, act='none', transposed
         d.mul_src, d.mul_ld, d.mul_coff, d.mul_act, d.mul_f16 = ptr(m.t).value, m.ld, m.coff, ACT[mact], m.f16
     if _parts_only:
         return L.size('hv_conv2d_stats_parts', ctypes.byref(d))
+    if _supported_only:
+        return bool(L.cdll.hv_conv2d_supported(ctypes.byref(d)))
     if stats is not None:
         d.stats = ptr(stats).value
     if d.Cout == 1:      # single-channel heads / logits: the [pixel][tap] table of conv_head.hip lives in the per-stream scratch
@@ -223,12 +225,26 @@ def conv2d(x, w, y, k, stride=1, pad=0, dil=1, bias=None, act='none', transposed
 POOL2 = os.environ.get('HV_POOL2', '1') != '0'      # A/B knob: data gradients of up-sampled inputs written pooled by the conv itself
 
 
-def pool2_ok(g, y_low, k, stride, pad, dil, precision, w_h, w_t, cout=None):
-    """Can conv2d(..., transposed=True, pool2=True) serve this data gradient?  (mirror of the checks in conv2d_dispatch / hv_convlf_launch)"""
+_SUPPORTED = {}
+
+
+def conv2d_supported(*args, **kw):
+    """Would conv2d(...) with these arguments be served?  (hv_conv2d_supported: the C dispatch itself, run without launching -- the x1 and pool2
+    forms have no generic fallback, so their callers ask before they drop the materialised alternative.)"""
+    return conv2d(*args, _supported_only=True, **kw)
+
+
+def pool2_ok(g, y_low, k, stride, pad, dil, precision, w_h, w_t, cout=None, w=None):
+    """Can conv2d(..., transposed=True, pool2=True) serve this data gradient?  Asked of the C dispatch (hv_conv2d_supported), once per shape."""
+    if not POOL2 or w_h is None or w_t is None or precision_id(precision) != F16 or g.H != 2 * y_low.H or g.W != 2 * y_low.W:
+        return False
     co = y_low.C if cout is None else cout
-    return bool(POOL2 and precision_id(precision) == F16 and w_h is not None and w_t is not None and k == 3 and stride == 1 and pad == 1 and dil == 1
-                and g.f16 and y_low.f16 and g.C in (16, 32, 64) and g.ld % 8 == 0 and g.coff % 8 == 0 and co % 8 == 0 and y_low.ld % 8 == 0
-                and y_low.coff % 8 == 0 and g.H == 2 * y_low.H and g.W == 2 * y_low.W and not (g.C == 16 and co > 32))
+    key = ('pool2', g.B, g.H, g.W, g.C, g.ld, g.coff, g.f16, co, y_low.ld, y_low.coff, y_low.f16, k, stride, pad, dil, ptr(w_t).value & 15)
+    r = _SUPPORTED.get(key)
+    if r is None:
+        r = _SUPPORTED[key] = conv2d_supported(g, w_h if w is None else w, Act(y_low.t, co, y_low.coff), k, stride, pad, dil, transposed=True, pool2=True,
+                                               precision=precision, w_h=w_h, w_t=w_t)
+    return r
 
 
 def conv2d_stats_parts(*args, **kw):

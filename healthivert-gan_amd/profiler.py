@@ -21,6 +21,21 @@ class KernelTimer:
         self.names = {}       # shape key -> kernel instantiation name as rocprofv3 prints it (hv_last_kernel_name)
         self.only = None      # set of shape keys to time, or None = all
         self.active = False
+        self.pair_us = 0.0    # calibrate(): an empty event pair's own reading, subtracted from every launch
+
+    def calibrate(self, n=200):
+        """Median reading of an event pair recorded around NOTHING on the current stream (microseconds): the part of every kernel's event duration
+        that is the events' own (the two barrier packets and the hand-over between them), which rocprofv3's kernel durations do not contain."""
+        torch.cuda.synchronize()
+        pairs = []
+        for _ in range(n):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record(); e.record()
+            pairs.append((s, e))
+        torch.cuda.synchronize()
+        v = sorted(s.elapsed_time(e) * 1e3 for s, e in pairs)
+        self.pair_us = v[len(v) // 2]
+        return self.pair_us
 
     # ---- hook called by ops.conv2d / ops.conv2d_wgrad around each launch
     def wrap(self, key, flops, launch, nbytes=0):
@@ -52,9 +67,9 @@ class KernelTimer:
         agg = {}
         for key, flops, s, e in self.records:
             a = agg.setdefault(key, [0.0, 0, flops])
-            a[0] += s.elapsed_time(e)
+            a[0] += max(s.elapsed_time(e) - self.pair_us * 1e-3, 1e-4)      # net of the event pair's own reading
             a[1] += 1
-        return agg   # shape key -> [total ms, launches, flops per launch]
+        return agg   # shape key -> [total ms (net), launches, flops per launch]
 
     def by_kernel(self):
         """kernel instantiation name -> [total ms, launches, total flops, [shape keys]] (the granularity of a rocprofv3 stats row)."""
@@ -102,7 +117,8 @@ class KernelTimer:
                     'frac': round(gbs / HBM_PEAK_GBS if hbm else tf / peak_tflops, 4)}
         shapes = [shape_row(k) for k in sorted(keys, key=lambda k: -agg[k][0])]
         nbytes = sum(self.bytes.get(k, 0) * agg[k][1] for k in keys)          # algorithmic bytes over all launches of the instantiation
-        out = {'kernel': name, 'launches': n, 'avg_us': round(ms / n * 1e3, 2), 'gflop_per_launch': round(flops / n / 1e9, 3),
+        out = {'kernel': name, 'launches': n, 'avg_us': round(ms / n * 1e3, 2), 'avg_us_events': round(ms / n * 1e3 + self.pair_us, 2),
+               'event_pair_overhead_us': round(self.pair_us, 2), 'gflop_per_launch': round(flops / n / 1e9, 3),
                'algorithmic_mb_per_launch': round(nbytes / n / 1e6, 2), 'shapes': shapes, 'traffic': None}
         # which roofline bounds it: arithmetic intensity against the ridge of the two peaks
         if nbytes and flops / nbytes < ridge:

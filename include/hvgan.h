@@ -116,6 +116,9 @@ typedef struct {
 int hv_conv2d(const hv_conv_desc* d, void* stream);
 size_t hv_conv2d_workspace_bytes(const hv_conv_desc* d);   /* 0 when no kernel for this shape wants scratch */
 size_t hv_conv2d_stats_parts(const hv_conv_desc* d);       /* parts of hv_conv_desc.stats this call would write (0: its kernel has no statistics epilogue) */
+int hv_conv2d_supported(const hv_conv_desc* d);            /* 1 when hv_conv2d would serve d.  Only the forms without a generic fallback can be refused for their
+                                                              shape -- x1, pool2, stats (hv_conv2d then returns HV_ERR_UNSUPPORTED and launches nothing) -- so a caller
+                                                              asks before it drops the materialised alternative.  Runs the dispatch itself without launching */
 
 /* Weight gradient: dw[co][(r,s)][ci] = sum_{n,ho,wo} g[n,ho,wo,co] * x[n, ho*stride-pad+r*dil, ..., ci].
  * (autograd of the convs above; for a transposed conv swap the roles of x and g on the caller side).

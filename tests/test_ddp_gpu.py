@@ -1,6 +1,9 @@
-"""Two data-parallel ranks on one MI355X (gloo transport, device tensors) against the CPU oracle's data-parallel step: every
-parameter gradient equals the MEAN of the two ranks' oracle gradients and the weights stay identical on both ranks -- the
-semantics of SURVEY.md section 8e (per-rank batch quirks, mean of gradients).  Plus the RCCL call sequence in a one-rank group."""
+"""Data-parallel ranks on one MI355X (gloo transport, device tensors) against the CPU oracle's data-parallel step: every
+parameter gradient equals the MEAN of the ranks' oracle gradients and the weights stay identical on all ranks -- the
+semantics of SURVEY.md section 8e (per-rank batch quirks, mean of gradients) -- in the exact-fp32 mode AND in the benchmarked
+fp16 mode (gradient scale -> unscale -> all-reduce -> guarded Adam), with an fp16 overflow seen by ONE rank only, and at BASELINE
+config #3's per-rank shape (bs 16, full-size discriminators).  Plus the RCCL call sequence -- collectives captured inside the
+step's hipGraph -- in a one-rank RCCL group."""
 import os
 import subprocess
 import sys
@@ -15,33 +18,34 @@ pytestmark = pytest.mark.gpu
 RANK = r'''
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))
-rank = int(sys.argv[1]); os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=sys.argv[2], HV_PRECISION='fp32', HV_DP_SCHEDULE=sys.argv[4])
-dist.init_process_group('gloo', rank=rank, world_size=2)
+rank, port, dst, prec, world, bs, ndf, steps = int(sys.argv[1]), sys.argv[2], sys.argv[3], sys.argv[4], int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7]), int(sys.argv[8])
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=port, HV_PRECISION=prec)
+dist.init_process_group('gloo', rank=rank, world_size=world)
 import hvgan
 from hvgan import synth, ddp
 from hvgan.models.pix2pix_model import Pix2PixModel
 from test_step_gpu import make_opt
 torch.manual_seed(11 + 100 * rank)      # DIFFERENT initial weights per rank: the model must broadcast rank 0's
-model = Pix2PixModel(make_opt(ndf=16))
+model = Pix2PixModel(make_opt(ndf=ndf))
 nets = ('G', 'D_1', 'D_2', 'D_3')
 snap = lambda: {n: {k: v.detach().cpu().clone() for k, v in getattr(model, 'net' + n).state_dict().items()} for n in nets}
 out = {'w0': snap()}
-for step in range(4):      # steps 3 and 4 replay the captured hipGraphs with the reductions in between
-    model.set_input(synth.make_batch(2, 256, seed=100 + rank + 10 * step))
+for step in range(steps):      # steps 3 and 4 replay the captured hipGraphs with the reductions between them (gloo cannot be captured)
+    model.set_input(synth.make_batch(bs, 256, seed=100 + rank + 10 * step))
     model.optimize_parameters()
     if step == 0:
         torch.cuda.synchronize()
         out['g1'] = {n: {k: p.grad.detach().cpu().clone() for k, p in getattr(model, 'net' + n).named_parameters()} for n in nets}
         out['w1'] = snap()
         out['l1'] = dict(model.get_current_losses())
+        out['fake_mask'] = model.fake_B_mask_raw.detach().cpu().clone()
 torch.cuda.synchronize()
-if sys.argv[4] == 'phases':
-    assert model._dp_graphs is not None and len(model._dp_graphs) == 12
-else:
-    assert model._graphs is not None and len(model._graphs) == 3 and not model._dp_graphs
-out['w4'] = snap()
-out['l4'] = dict(model.get_current_losses())
-torch.save(out, sys.argv[3] + '/rank%%d.pt' %% rank)
+if steps > 2:
+    assert model._graphs is not None and len(model._graphs) == 3 and model.dp_schedule == 'captured' and not model._inline_exchange
+out['wN'] = snap()
+out['lN'] = dict(model.get_current_losses())
+out['overflow'] = model.overflow_steps()
+torch.save(out, dst + '/rank%%d.pt' %% rank)
 dist.destroy_process_group()
 print('ok', rank)
 '''
@@ -51,32 +55,44 @@ def _rel(a, b):
     return float((a.double() - b.double()).norm() / max(float(b.double().norm()), 1e-12))
 
 
-@pytest.mark.parametrize('schedule', ['graphs', 'phases'])
-def test_two_ranks_equal_the_mean_of_oracle_gradients(tmp_path, schedule):
-    """SURVEY.md section 8e: the N-rank result == one step whose gradients are the MEAN of the N single-rank oracle gradients.
-    Two ranks (gloo transport, device tensors, one MI355X), fp32 parity mode, different batches per rank, four steps (the last two
-    replay the captured graphs -- the single-process step's three with the gradient means between them (default), or the twelve phase
-    graphs of HV_DP_SCHEDULE=phases -- with the exchanges between them):
-      * rank 1's different seed is overridden by the broadcast of rank 0's initial weights;
-      * after step 1 every parameter's .grad on both ranks equals the mean of the two oracle ranks' gradients (<= 2e-3 relative L2,
-        a missing 1/world_size would show as a factor 2) and the losses are each rank's own;
-      * weights stay bit-identical across the ranks through all four steps and follow the oracle's data-parallel weights."""
-    port = str(29600 + os.getpid() % 1000 + (1000 if schedule == 'phases' else 0))
-    procs = [subprocess.Popen([sys.executable, '-c', RANK % (ROOT, ROOT), str(r), port, str(tmp_path), schedule], stdout=subprocess.PIPE,
-                              stderr=subprocess.STDOUT) for r in range(2)]
+def _run_ranks(tmp_path, world, prec, bs, ndf, steps, port_base, script=RANK, extra=()):
+    port = str(port_base + os.getpid() % 1000)
+    procs = [subprocess.Popen([sys.executable, '-c', script % (ROOT, ROOT), str(r), port, str(tmp_path), prec, str(world), str(bs), str(ndf), str(steps)] + list(extra),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     for p in procs:
-        out, _ = p.communicate(timeout=900)
+        out, _ = p.communicate(timeout=1500)
         assert p.returncode == 0 and b'ok' in out, out.decode()[-3000:]
-    a, b = torch.load(tmp_path / 'rank0.pt'), torch.load(tmp_path / 'rank1.pt')
-    for tag in ('w0', 'w1', 'w4'):
-        for n in a[tag]:
-            for k in a[tag][n]:
-                if 'running' in k or 'tracked' in k:
-                    continue      # BatchNorm running statistics are per-rank data statistics (saved from rank 0)
-                assert torch.equal(a[tag][n][k], b[tag][n][k]), (tag, n, k)
-    for n in a['g1']:
-        for k in a['g1'][n]:
-            assert torch.equal(a['g1'][n][k], b['g1'][n][k]), (n, k)
+    return [torch.load(tmp_path / ('rank%d.pt' % r)) for r in range(world)]
+
+
+def _same_weights_everywhere(ranks, tags):
+    a = ranks[0]
+    for b in ranks[1:]:
+        for tag in tags:
+            for n in a[tag]:
+                for k in a[tag][n]:
+                    if 'running' in k or 'tracked' in k:
+                        continue      # BatchNorm running statistics are per-rank data statistics (saved from rank 0)
+                    assert torch.equal(a[tag][n][k], b[tag][n][k]), (tag, n, k)
+        for n in a['g1']:
+            for k in a['g1'][n]:
+                assert torch.equal(a['g1'][n][k], b['g1'][n][k]), (n, k)
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'fp16'])
+def test_two_ranks_equal_the_mean_of_oracle_gradients(tmp_path, precision):
+    """SURVEY.md section 8e: the N-rank result == one step whose gradients are the MEAN of the N single-rank oracle gradients.
+    Two ranks (gloo transport, device tensors, one MI355X), different batches per rank, four steps (the last two replay the step's three
+    captured graphs with the gradient means between them), in the exact-fp32 mode (<= 2e-3 relative L2 per tensor) and in the BENCHMARKED fp16
+    mode (scaled seeds -> unscale -> mean over the ranks -> guarded Adam; the fp16 gates of test_step_gpu: matrices <= 6 %, pixel-sum vectors
+    <= 16 %; D_2, whose input is a thresholded mask that fp16 rounding may flip, is held to the cross-rank identity only):
+      * rank 1's different seed is overridden by the broadcast of rank 0's initial weights;
+      * after step 1 every parameter's .grad on both ranks equals the mean of the two oracle ranks' gradients (a missing 1/world_size would
+        show as a factor 2) and the losses are each rank's own;
+      * weights stay bit-identical across the ranks through all four steps and follow the oracle's data-parallel weights; no step is skipped."""
+    a, b = _run_ranks(tmp_path, 2, precision, 2, 16, 4, 29600 + (1000 if precision == 'fp16' else 0))
+    _same_weights_everywhere([a, b], ('w0', 'w1', 'wN'))
+    assert a['overflow'] == b['overflow'] == {n: 0 for n in ('G', 'D_1', 'D_2', 'D_3')}
     # ---- the oracle's data-parallel steps from the same initial weights
     import hvgan  # noqa: F401
     from hvgan import synth
@@ -85,39 +101,124 @@ def test_two_ranks_equal_the_mean_of_oracle_gradients(tmp_path, schedule):
     names = ('D_1', 'D_2', 'D_3')
     mk = lambda: R.StepState(a['w0']['G'], [a['w0'][n] for n in names], lr=2e-4, beta1=0.5, norm='batch', gan_mode='vanilla', lambda_l1=200.0)
     st = [mk(), mk()]
+    fp32 = precision == 'fp32'
+    gtol, vtol, ltol = (2e-3, 2e-3, 2e-3) if fp32 else (6e-2, 1.6e-1, 6e-3)
     for step in range(4):
         res = R.pix2pix_step_data_parallel(st, [synth.to_model_inputs(synth.make_batch(2, 256, seed=100 + r + 10 * step)) for r in range(2)])
         if step == 0:
             for r, got in ((0, a), (1, b)):
                 for k, v in res[r][0].items():
-                    assert abs(got['l1'][k] - v) <= 2e-3 * max(1.0, abs(v)), ('loss', r, k, got['l1'][k], v)
-            worst = 0.0
+                    assert abs(got['l1'][k] - v) <= ltol * max(1.0, abs(v)), ('loss', r, k, got['l1'][k], v)
             for k in st[0].g_params:
                 e = _rel(a['g1']['G'][k], st[0].g[k].grad)
-                worst = max(worst, e)
-                assert e <= 2e-3, ('G grad', k, e)
+                assert e <= (gtol if a['g1']['G'][k].dim() > 1 else vtol), ('G grad', k, e)
             for d, n in enumerate(names):
+                if not fp32 and n == 'D_2':
+                    continue
                 for k in st[0].d_params[d]:
                     e = _rel(a['g1'][n][k], st[0].d[d][k].grad)
-                    assert e <= 2e-3, (n, k, e)
+                    assert e <= (gtol if a['g1'][n][k].dim() > 1 else vtol), (n, k, e)
             for k in st[0].g_params:      # one Adam step moves every weight by at most lr = 2e-4
                 assert (a['w1']['G'][k] - st[0].g[k].detach()).abs().max() <= 4.1e-4, k
     # after four steps: losses of each rank's last batch and the parameter norms follow the oracle
     for r, got in ((0, a), (1, b)):
         for k, v in res[r][0].items():
-            tol = 5e-2 if k.startswith('D_') or k == 'G_GAN' else 1e-2
-            assert abs(got['l4'][k] - v) <= tol * max(1.0, abs(v)), ('loss4', r, k, got['l4'][k], v)
+            tol = 5e-2 if k.startswith('D_') or k == 'G_GAN' else (1e-2 if fp32 else 2e-2)
+            assert abs(got['lN'][k] - v) <= tol * max(1.0, abs(v)), ('loss4', r, k, got['lN'][k], v)
     for k in st[0].g_params:
         ref = st[0].g[k].detach()
-        assert abs(float(a['w4']['G'][k].norm()) - float(ref.norm())) <= 2e-3 * max(float(ref.norm()), 1e-3), k
+        assert abs(float(a['wN']['G'][k].norm()) - float(ref.norm())) <= (2e-3 if fp32 else 4e-3) * max(float(ref.norm()), 1e-3), k
+
+
+OVERFLOW_RANK = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))
+rank, port, dst = int(sys.argv[1]), sys.argv[2], sys.argv[3]
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=port, HV_PRECISION='fp16')
+dist.init_process_group('gloo', rank=rank, world_size=2)
+import hvgan
+from hvgan import synth
+from hvgan.models.pix2pix_model import Pix2PixModel
+from test_step_gpu import make_opt
+torch.manual_seed(31)
+model = Pix2PixModel(make_opt(ndf=16))
+nets = ('G', 'D_1', 'D_2', 'D_3')
+snap = lambda: {n: torch.cat([p.detach().flatten().cpu().clone() for p in getattr(model, 'net' + n).parameters()]) for n in nets}
+out = {'w0': snap()}
+assert model.grad_scale == 8192.0
+for step in range(4):
+    # step 0: an absurd gradient scale on RANK 1 ONLY -- its scaled activation gradients overflow its fp16 buffers, rank 0's do not
+    model.grad_scale = float(2 ** 40) if (step == 0 and rank == 1) else 8192.0
+    model.set_input(synth.make_batch(2, 256, seed=300 + rank + 10 * step))
+    model.optimize_parameters()
+    torch.cuda.synchronize()
+    out['w%%d' %% (step + 1)] = snap()
+    out['of%%d' %% (step + 1)] = model.overflow_steps()
+    if step == 0:
+        out['finite_own'] = {n: bool(torch.isfinite(getattr(model, 'net' + n).paramset().flat_grad).all().item()) for n in nets}
+out['steps'] = {n: float(getattr(model, 'optimizer_' + n)._step[0].item()) for n in nets}
+torch.save(out, dst + '/rank%%d.pt' %% rank)
+dist.destroy_process_group()
+print('ok', rank)
+'''
+
+
+def test_fp16_overflow_on_one_rank_is_skipped_by_every_rank(tmp_path):
+    """DESIGN.md section 3: the overflow guard reads the flat gradient AFTER the all-reduce, so an inf / nan produced on one rank reaches every
+    rank's copy and 'every rank decides alike'.  Step 1 overflows on rank 1 only (gradient scale 2^40 there): both ranks must skip all four Adam
+    steps (weights bit-identical to the start, counters 1 on both), steps 2-4 (the last two as graph replays) update every network on both
+    ranks, and the weights stay bit-identical ACROSS the ranks throughout."""
+    port = str(31600 + os.getpid() % 1000)
+    procs = [subprocess.Popen([sys.executable, '-c', OVERFLOW_RANK % (ROOT, ROOT), str(r), port, str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    for p in procs:
+        out, _ = p.communicate(timeout=900)
+        assert p.returncode == 0 and b'ok' in out, out.decode()[-3000:]
+    a, b = torch.load(tmp_path / 'rank0.pt'), torch.load(tmp_path / 'rank1.pt')
+    nets = ('G', 'D_1', 'D_2', 'D_3')
+    for n in nets:
+        assert not a['finite_own'][n] and not b['finite_own'][n], ('the reduced gradient must carry the overflow on BOTH ranks', n, a['finite_own'], b['finite_own'])
+        for tag in ('w0', 'w1', 'w2', 'w3', 'w4'):
+            assert torch.equal(a[tag][n], b[tag][n]), (tag, n)
+        assert torch.equal(a['w0'][n], a['w1'][n]), ('skipped step moved the weights', n)
+        assert (a['w2'][n] - a['w1'][n]).abs().max().item() > 1e-5 and torch.isfinite(a['w4'][n]).all(), n
+    for tag in ('of1', 'of2', 'of3', 'of4'):
+        assert a[tag] == b[tag] == {n: 1 for n in nets}, (tag, a[tag], b[tag])
+    assert a['steps'] == b['steps'] == {n: 3.0 for n in nets}, (a['steps'], b['steps'])
+
+
+def test_config3_shape_four_ranks_bs16_equal_the_mean_of_oracle_gradients(tmp_path):
+    """BASELINE config #3 at its per-rank shape (SURVEY.md section 8e: 'N-rank result == average of N single-rank bs = 16 oracle gradients'): FOUR
+    ranks x bs 16, 256 x 256, full-size discriminators (ndf 64), exact-fp32 mode, one step; every parameter gradient on every rank equals the mean
+    of the four oracle ranks' gradients (<= 2e-3 relative L2) and each rank's losses are its own batch's.  (Eight ranks would exceed the GPU box's
+    limit of six processes on the card; the arithmetic -- flat mean over world_size -- does not depend on N.)"""
+    world = 4
+    ranks = _run_ranks(tmp_path, world, 'fp32', 16, 64, 1, 32600)
+    _same_weights_everywhere(ranks, ('w0', 'w1'))
+    import hvgan  # noqa: F401
+    from hvgan import synth
+    from oracle import restate as R
+    torch.set_num_threads(max(1, (os.cpu_count() or 8)))
+    a = ranks[0]
+    names = ('D_1', 'D_2', 'D_3')
+    st = [R.StepState(a['w0']['G'], [a['w0'][n] for n in names], lr=2e-4, beta1=0.5, norm='batch', gan_mode='vanilla', lambda_l1=200.0) for _ in range(world)]
+    res = R.pix2pix_step_data_parallel(st, [synth.to_model_inputs(synth.make_batch(16, 256, seed=100 + r)) for r in range(world)])
+    for r in range(world):
+        for k, v in res[r][0].items():
+            assert abs(ranks[r]['l1'][k] - v) <= 2e-3 * max(1.0, abs(v)), ('loss', r, k, ranks[r]['l1'][k], v)
+    for k in st[0].g_params:
+        e = _rel(a['g1']['G'][k], st[0].g[k].grad)
+        assert e <= 2e-3, ('G grad', k, e)
+    for d, n in enumerate(names):
+        for k in st[0].d_params[d]:
+            e = _rel(a['g1'][n][k], st[0].d[d][k].grad)
+            assert e <= 2e-3, (n, k, e)
 
 
 RCCL_ONE = r'''
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))
-os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=sys.argv[1], HV_PRECISION='fp32', HV_DDP_FORCE=sys.argv[2], HV_DP_SCHEDULE=sys.argv[4])
-if sys.argv[4] == 'phases':
-    os.environ['HV_BATCH_D'] = '0'      # the twelve-phase schedule always takes the split real-first discriminator passes: same summation order for the bit-for-bit comparison
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=sys.argv[1], HV_PRECISION=sys.argv[5], HV_DDP_FORCE=sys.argv[2], HV_DP_SCHEDULE=sys.argv[4])
 torch.cuda.set_device(0)
 if sys.argv[2] == '1':
     dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))     # "nccl" IS RCCL on ROCm
@@ -127,58 +228,48 @@ from hvgan.models.pix2pix_model import Pix2PixModel
 from test_step_gpu import make_opt
 torch.manual_seed(11)
 model = Pix2PixModel(make_opt(ndf=16))
+model.strict_graph = True
 assert ddp.GradSync.active() == (sys.argv[2] == '1')
-for step in range(4):
+for step in range(5):
     model.set_input(synth.make_batch(2, 256, seed=100 + 10 * step))
     model.optimize_parameters()
 torch.cuda.synchronize()
-assert (model._dp_graphs if (sys.argv[2] == '1' and sys.argv[4] == 'phases') else model._graphs) is not None
+assert model._graphs is not None
 if sys.argv[2] == '1':
+    if sys.argv[4] == 'captured':      # the collectives are INSIDE the one step graph
+        assert len(model._graphs) == 1 and model._inline_exchange and getattr(model, 'dp_capture_error', None) is None, (len(model._graphs), getattr(model, 'dp_capture_error', None))
+    else:
+        assert len(model._graphs) == 3 and not model._inline_exchange
     t = torch.tensor([1.5], device='cuda:0', dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX); dist.barrier()
     assert float(t.item()) == 1.5
     dist.destroy_process_group()
-sd = {n: {k: v.detach().cpu() for k, v in getattr(model, 'net' + n).state_dict().items()} for n in ('G', 'D_1')}
+else:
+    assert len(model._graphs) == 1
+sd = {n: {k: v.detach().cpu() for k, v in getattr(model, 'net' + n).state_dict().items()} for n in ('G', 'D_1', 'D_3')}
 torch.save(sd, sys.argv[3])
 print('ok')
 '''
 
 
-@pytest.mark.parametrize('schedule', ['graphs', 'phases'])
-def test_rccl_exchange_path_single_rank(tmp_path, schedule):
-    """The gradient exchange exactly as a multi-GPU job issues it (RCCL all-reduce of the flat gradient buffers on the side stream between the
-    captured step graphs, broadcast, barrier, MAX-reduce of the bench clock) in a one-rank RCCL group: averaging over one rank is the
-    identity, so the weights after four steps must equal those of a run without a process group, bit for bit."""
-    port = str(29700 + os.getpid() % 1000 + (1000 if schedule == 'phases' else 0))
+@pytest.mark.parametrize('schedule,precision', [('captured', 'fp16'), ('captured', 'fp32'), ('graphs', 'fp32')])
+def test_rccl_exchange_path_single_rank(tmp_path, schedule, precision):
+    """The gradient exchange exactly as a multi-GPU job issues it -- RCCL all-reduce (ncclAvg) of the flat gradient buffers CAPTURED INSIDE the step's one
+    hipGraph (D_k's forked from D_k's stream, G's before its Adam step; default), or issued on the exchange stream between the step's three graphs
+    (HV_DP_SCHEDULE=graphs) -- plus broadcast, barrier and the MAX-reduce of the bench clock, in a one-rank RCCL group: averaging over one rank is the
+    identity, so the weights after five steps (three of them graph replays) must equal those of a run without a process group, bit for bit."""
+    port = str(29700 + os.getpid() % 1000 + (1000 if schedule == 'graphs' else 0) + (500 if precision == 'fp16' else 0))
     outs = []
     for force in ('1', '0'):
         dst = str(tmp_path / ('w%s.pt' % force))
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
-        p = subprocess.run([sys.executable, '-c', RCCL_ONE % (ROOT, ROOT), port, force, dst, schedule], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+        p = subprocess.run([sys.executable, '-c', RCCL_ONE % (ROOT, ROOT), port, force, dst, schedule, precision], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                            timeout=600, env=env)
         assert p.returncode == 0 and b'ok' in p.stdout, p.stdout.decode()[-3000:]
         outs.append(torch.load(dst))
     for n in outs[0]:
         for k in outs[0][n]:
             assert torch.equal(outs[0][n][k], outs[1][n][k]), (n, k)
-
-
-def test_bench_two_ranks_rehearsal_over_gloo():
-    """`python bench.py --gpus 2` from a plain shell, the whole flow the driver's scaling run takes -- launcher, process group from the
-    environment, broadcast, the data-parallel step with its twelve phase graphs, survey / timed / roofline legs, MAX-over-ranks clock, one
-    JSON line from rank 0 -- with the gloo transport so that both ranks can share this box's one GPU (RCCL refuses two ranks per device)."""
-    import json
-    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
-    env.update(HV_DDP_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
-    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '3', '--no-cpu-baseline'],
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env)
-    assert p.returncode == 0, p.stderr.decode()[-3000:]
-    lines = [l for l in p.stdout.decode().splitlines() if l.startswith('{')]
-    assert len(lines) == 1, p.stdout.decode()[-2000:]
-    rec = json.loads(lines[0])
-    assert rec['n_gpus'] == 2 and rec['config']['global_batch'] == 32 and rec['config']['parallelism'] == 'dp2'
-    assert rec['config']['launch'].startswith('hipGraph replay (3 graphs/step)')
-    assert rec['roofline'] and rec['roofline']['launches'] > 0 and 'fine_generator_forward' in rec
 
 
 def _bench(extra_env, args, launcher=None):
@@ -193,21 +284,42 @@ def _bench(extra_env, args, launcher=None):
     return json.loads(lines[0])
 
 
+def test_bench_two_ranks_rehearsal_over_gloo():
+    """`python bench.py --gpus 2` from a plain shell, the whole flow the driver's scaling run takes -- launcher, process group from the
+    environment, broadcast, the data-parallel step, survey / timed / roofline legs, MAX-over-ranks clock, one JSON line from rank 0 -- with the
+    gloo transport so that both ranks can share this box's one GPU (RCCL refuses two ranks per device; gloo cannot be captured, so the step is cut
+    into its three graphs with the means between them)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(HV_DDP_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '3', '--no-cpu-baseline'],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1, p.stdout.decode()[-2000:]
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['config']['global_batch'] == 32 and rec['config']['parallelism'] == 'dp2'
+    assert rec['config']['launch'].startswith('hipGraph replay (3 graphs/step)')
+    assert rec['comm']['backend'] == 'gloo' and rec['comm']['world_size'] == 2 and rec['scaling'] == 'weak' and rec['value'] > 0
+    assert rec['roofline'] and rec['roofline']['launches'] > 0 and 'fine_generator_forward' in rec
+
+
 def test_bench_data_parallel_dress_rehearsal_on_one_device():
-    """The driver's multi-GPU bench without a node: (a) the real bench with the data-parallel SCHEDULE (the step's three graphs with RCCL all-reduce
-    calls on the exchange stream between them) in a one-rank RCCL group against the plain three-graph step on the same device -- the schedule itself
-    must cost < 8 % over the single-process one-graph step (the twelve-phase schedule of HV_DP_SCHEDULE=phases: < 15 %, measured 7-10 % over the three-graph step);
-    (b) the real bench started as TWO ranks by torch.distributed.run on this one device (gloo transport -- RCCL refuses two ranks on one device):
-    the JSON line must report what the collective layer saw (n_gpus, global batch, backend, world size)."""
+    """The driver's multi-GPU bench without a node: the real bench with the data-parallel step (RCCL all-reduces captured inside the one step graph) in a
+    one-rank RCCL group, and the same started as TWO ranks by torch.distributed.run on this one device (gloo transport): the JSON line must report
+    what the collective layer saw (n_gpus, global batch, backend, world size, schedule, graphs per step).  The step-time ratio against the
+    single-process step is printed, and asserted only under HV_PERF_ASSERT=1 (wall-clock ratios do not belong in a correctness suite: tools/dp_ratio.sh)."""
     plain = _bench({}, ['--steps', '10', '--warmup', '3'])
     assert plain['n_gpus'] == 1 and plain['comm']['world_size'] == 1 and '1 graphs' in plain['config']['launch'], plain['config']      # (single process: the whole step is one graph)
     assert len(plain['regions_ms_per_step']) == 3 and plain['ms_per_step'] == sorted(plain['regions_ms_per_step'])[1]
     one = _bench({'HV_DDP_FORCE': '1'}, ['--steps', '10', '--warmup', '3'])
-    assert one['comm']['backend'] == 'nccl' and one['comm']['world_size'] == 1 and '3 graphs' in one['config']['launch'], (one['comm'], one['config'])
-    # (measured: +0.14-0.20 ms for the two stream hops and one-rank collectives, +0.11 ms for three graphs instead of the single-process one: ~4 % of 7.7 ms)
-    assert one['ms_per_step'] <= 1.08 * plain['ms_per_step'], ('data-parallel schedule vs single-rank step', one['ms_per_step'], plain['ms_per_step'])
-    ph = _bench({'HV_DDP_FORCE': '1', 'HV_DP_SCHEDULE': 'phases'}, ['--steps', '10', '--warmup', '3'])
-    assert '12 graphs' in ph['config']['launch'] and ph['ms_per_step'] <= 1.15 * plain['ms_per_step'], (ph['config'], ph['ms_per_step'], plain['ms_per_step'])
+    assert one['comm']['backend'] == 'nccl' and one['comm']['world_size'] == 1 and one['comm']['dp_schedule'] == 'captured', one['comm']
+    assert '1 graphs' in one['config']['launch'] and one['comm']['capture_error'] is None, (one['comm'], one['config'])
+    cut = _bench({'HV_DDP_FORCE': '1', 'HV_DP_SCHEDULE': 'graphs'}, ['--steps', '10', '--warmup', '3'])
+    assert '3 graphs' in cut['config']['launch'] and cut['comm']['dp_schedule'] == 'graphs', (cut['comm'], cut['config'])
+    print('data-parallel schedule in a one-rank RCCL group: captured %.3f ms, cut %.3f ms, single process %.3f ms' % (one['ms_per_step'], cut['ms_per_step'], plain['ms_per_step']))
+    if os.environ.get('HV_PERF_ASSERT') == '1':
+        assert one['ms_per_step'] <= 1.03 * plain['ms_per_step'], ('captured data-parallel step vs single-process step', one['ms_per_step'], plain['ms_per_step'])
     two = _bench({'HV_DDP_BACKEND': 'gloo'}, ['--gpus', '2', '--steps', '4', '--warmup', '3'],
                  launcher=[sys.executable, '-m', 'torch.distributed.run', '--standalone', '--nnodes=1', '--nproc-per-node', '2', '--local-addr', '127.0.0.1'])
     assert two['n_gpus'] == 2 and two['config']['global_batch'] == 32 and two['config']['parallelism'] == 'dp2', two['config']

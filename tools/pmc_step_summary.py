@@ -49,11 +49,7 @@ def norm(names):
                 d = d[:i]
                 break
         d = d.strip()
-        # conv_lf_kernel's fifth template argument (the hv_conv_desc.x1 form) is not part of the name the C dispatch reports: the plain instantiation
-        # keeps the reported name, the x1 one is listed beside it
-        m = re.match(r'(conv_lf_kernel<\d+, \d+, \d+, \d+), (false|true)>$', d)
-        if m:
-            d = m.group(1) + '>' + (' [x1]' if m.group(2) == 'true' else '')
+        # (round 4: hv_last_kernel_name() reports all five template arguments of conv_lf_kernel, as rocprofv3 prints them: no folding)
         out[n] = d
     return out
 
@@ -76,10 +72,15 @@ def main():
         w = sum(cs['WRITE_SIZE']) / len(cs['WRITE_SIZE'])
         kernels[name] = {'launches': len(cs['FETCH_SIZE']), 'FETCH_SIZE_KiB_raw': round(f, 1), 'WRITE_SIZE_KiB': round(w, 1),
                          'traffic_bytes': int((2 * f + w) * 1024)}
+    # steps of the profiled run = launches of a kernel that runs exactly once per train step
+    once = [v['launches'] for k, v in kernels.items() if k.startswith('post_generator_kernel')]
+    nsteps = once[0] if once else None
     doc = {'_how': 'tools/pmc_step.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE and, in a second run, --pmc WRITE_SIZE over '
                    '"bench.py --serial --no-graph --steps 2 --warmup 1"; mean per launch of every kernel instantiation over all the '
                    'layer shapes it serves in the step. traffic_bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB (gfx950 FETCH_SIZE correction '
                    'from MI355X_MICROARCH.md, HBM section).',
+           'steps_in_run': nsteps,
+           'step_total_bytes': (int(sum(v['traffic_bytes'] * v['launches'] for v in kernels.values()) / nsteps) if nsteps else None),
            'kernels': dict(sorted(kernels.items(), key=lambda kv: -kv[1]['traffic_bytes'] * kv[1]['launches']))}
     json.dump(doc, open(dst, 'w'), indent=1)
     for k, v in list(doc['kernels'].items())[:25]:
