@@ -272,6 +272,17 @@ def inference_record(dev, precision):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
     nz = int((out_seg.reshape(-1, out_seg.shape[2]) != 0).any(axis=0).sum())
+    # steady state over a stream of volumes (infer.process_volumes: volume n + 1's pinned copy / upload / scan and volume n - 1's download overlap
+    # volume n's stages): 10 volumes, the first two not counted
+    def stream_rate(copy):
+        vols = [(ct, label, cam255, 20)] * 10
+        t, k = None, 0
+        for _ in infer.process_volumes(net, vols, dev, copy=copy):
+            k += 1
+            if k == 2:
+                t = time.perf_counter()
+        return (time.perf_counter() - t) / (len(vols) - 2)
+    dt_pipe, dt_pipe_views = stream_rate(True), stream_rate(False)
     # the bare stage batch: eval forward of the generator on one batch of that many slices (HIP events, inputs resident)
     bb = synth.to_model_inputs(synth.make_batch(max(nz, 1), 256, seed=3))
     a = [bb['real_A'].to(dev), bb['mask'].to(dev), (1 - bb['CAM']).to(dev), bb['slice_ratio'].to(dev)]
@@ -286,6 +297,11 @@ def inference_record(dev, precision):
     ms = e0.elapsed_time(e1) / 5
     return {'workload': 'eval_3d_sagittal_twostage: 256x256x64 synthetic volume, upper -> lower -> target synthesis, each stage one batched launch',
             'ms_per_volume': round(dt * 1e3, 2), 'volumes_per_s': round(1.0 / dt, 2), 'slices_with_output': nz,
+            'pipelined': {'ms_per_volume': round(dt_pipe * 1e3, 2), 'volumes_per_s': round(1.0 / dt_pipe, 2),
+                          'ms_per_volume_pinned_views': round(dt_pipe_views * 1e3, 2),
+                          'what': 'steady state of infer.process_volumes over 10 volumes (first two not counted): one pinned host copy per volume, upload / z-extent scan / '
+                                  'float32 conversion / output volumes on the device, transfers of neighbouring volumes overlapped with the stages; '
+                                  'pinned_views = outputs handed out as views of the pinned download buffers instead of fresh arrays'},
             'slice_stages_per_s': round(3 * nz / dt, 1), 'stage_batch_forward_ms': round(ms, 3),
             'stage_batch_slices_per_s': round(max(nz, 1) / ms * 1e3, 1),
             'stage_batch_tflops': round(GFLOP_G_FWD * max(nz, 1) / ms, 1), 'includes': 'host slicing, PCIe in/out, device preparation, 3 generator stages'}

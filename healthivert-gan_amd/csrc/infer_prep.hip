@@ -221,3 +221,93 @@ extern "C" int hv_select_slices(const int* flag, const float* src, float* dst, i
     HV_LAUNCH_CHECK();
     return HV_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------------------
+// Volume intake / output of the inference driver on the device (reference eval_3d_sagittal_twostage.py:186-197,:208,:217,:236-239): the float64
+// [H][W][Z] volumes (z fastest) are uploaded as they lie -- ONE pinned copy per volume on the host, no scan and no float32 conversion there --
+//   volume_scan_kernel     counts[j][z] = number of voxels of slice z equal to ids[j] (the vertebra's z-extent and the two neighbours' > 200-pixel
+//                          gates in one pass over the label volume; integer sums: exact in any order)
+//   volume_slices_kernel   out[s][p] = (float)vol[p][z0 + s]: cut the z-range, convert (C cast, numpy's astype) and transpose to slices
+//   volume_merge_kernel    out[p][z] = (z in range and flag[z - z0]) ? (double)src[z - z0][p] : 0: the output volume as the reference builds it
+//                          (np.zeros + per-slice assignment), z fastest, float64
+__global__ __launch_bounds__(256) void volume_scan_kernel(const double* __restrict__ label, long long n, int Z, double id0, double id1, double id2,
+                                                          int* __restrict__ counts) {
+    extern __shared__ int hist[];      // [3][Z]
+    for (int i = threadIdx.x; i < 3 * Z; i += 256) hist[i] = 0;
+    __syncthreads();
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const double v = label[i];
+        if (v == 0.0) continue;          // background: no id is 0 (checked on the host side)
+        const int z = (int)(i % Z);
+        if (v == id0) atomicAdd(hist + z, 1);
+        else if (v == id1) atomicAdd(hist + Z + z, 1);
+        else if (v == id2) atomicAdd(hist + 2 * Z + z, 1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * Z; i += 256)
+        if (hist[i]) atomicAdd(counts + i, hist[i]);
+}
+extern "C" int hv_volume_scan(const double* label, long long HW, int Z, double id0, double id1, double id2, int* counts, void* stream) {
+    if (!label || !counts || HW <= 0 || Z <= 0 || Z > 2048) return HV_ERR_ARG;
+    if (id0 == 0.0 || id1 == 0.0 || id2 == 0.0) return HV_ERR_ARG;      // unused ids are passed as a negative number
+    hipError_t e = hipMemsetAsync(counts, 0, (size_t)3 * Z * sizeof(int), (hipStream_t)stream);
+    if (e != hipSuccess) return -1000 - (int)e;
+    const long long n = HW * Z;
+    const int grid = (int)(n / (256 * 16) < 1 ? 1 : (n / (256 * 16) > 2048 ? 2048 : n / (256 * 16)));
+    hipLaunchKernelGGL(volume_scan_kernel, dim3(grid), dim3(256), (size_t)3 * Z * sizeof(int), (hipStream_t)stream, label, n, Z, id0, id1, id2, counts);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+
+// 64 pixels x 32 slices per workgroup through LDS: 256-byte runs of doubles in, 256-byte runs of floats out
+__global__ __launch_bounds__(256) void volume_slices_kernel(const double* __restrict__ vol, long long HW, int Z, int z0, int S, float* __restrict__ out) {
+    __shared__ float t[64][33];
+    const long long p0 = (long long)blockIdx.x * 64;
+    const int s0 = blockIdx.y * 32, zz = threadIdx.x & 31, pr = threadIdx.x >> 5;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const long long p = p0 + pr + 8 * k;
+        t[pr + 8 * k][zz] = (p < HW && s0 + zz < S) ? (float)vol[p * Z + z0 + s0 + zz] : 0.f;
+    }
+    __syncthreads();
+    const int pl = threadIdx.x & 63, sr = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int s = s0 + sr + 4 * k;
+        if (s < S && p0 + pl < HW) out[(long long)s * HW + p0 + pl] = t[pl][sr + 4 * k];
+    }
+}
+extern "C" int hv_volume_slices(const double* vol, long long HW, int Z, int z0, int S, float* out, void* stream) {
+    if (!vol || !out || HW <= 0 || Z <= 0 || z0 < 0 || S <= 0 || z0 + S > Z || HW > (1ll << 31) || S > 32 * 65535) return HV_ERR_ARG;
+    hipLaunchKernelGGL(volume_slices_kernel, dim3((unsigned)hv_cdiv(HW, 64), hv_cdiv(S, 32)), dim3(256), 0, (hipStream_t)stream, vol, HW, Z, z0, S, out);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+
+__global__ __launch_bounds__(256) void volume_merge_kernel(const float* __restrict__ src, const int* __restrict__ flag, long long HW, int Z, int z0, int S,
+                                                           double* __restrict__ out) {
+    __shared__ float t[64][33];
+    const long long p0 = (long long)blockIdx.x * 64;
+    const int zb = blockIdx.y * 32;                 // 32 output slices zb .. zb + 31 of the FULL z range
+    const int pl = threadIdx.x & 63, sr = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int z = zb + sr + 4 * k, s = z - z0;
+        const bool in = z < Z && s >= 0 && s < S && p0 + pl < HW && flag[s] != 0;
+        t[pl][sr + 4 * k] = in ? src[(long long)s * HW + p0 + pl] : 0.f;
+    }
+    __syncthreads();
+    const int zz = threadIdx.x & 31, pr = threadIdx.x >> 5;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const long long p = p0 + pr + 8 * k;
+        if (p < HW && zb + zz < Z) out[p * Z + zb + zz] = (double)t[pr + 8 * k][zz];
+    }
+}
+extern "C" int hv_volume_merge(const float* src, const int* flag, long long HW, int Z, int z0, int S, double* out, void* stream) {
+    if (!src || !flag || !out || HW <= 0 || Z <= 0 || z0 < 0 || S <= 0 || z0 + S > Z || HW > (1ll << 31)) return HV_ERR_ARG;
+    hipLaunchKernelGGL(volume_merge_kernel, dim3((unsigned)hv_cdiv(HW, 64), hv_cdiv(Z, 32)), dim3(256), 0, (hipStream_t)stream, src, flag, HW, Z, z0, S, out);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}

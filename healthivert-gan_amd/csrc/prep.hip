@@ -206,7 +206,7 @@ extern "C" int hv_weight_prep(const hv_wprep_layer* d_layers, int n_layers, long
 // 128-byte (fp32) / 64-byte (fp16) runs and a 16 x 32 MFMA fragment of either ordered table as 64 sixteen-byte pieces = 1 KB contiguous.
 // conv_transpose sources (no contiguous source rows) are left to the kernels above (hv_weight_prep2's any_legacy).
 #define WL_T 32
-__global__ __launch_bounds__(256) void weight_layout_fused_kernel(const hv_wprep_layer* __restrict__ layers) {
+__global__ __launch_bounds__(256) void weight_layout_fused_kernel(const hv_wprep_layer* __restrict__ layers, int diag_lean) {
     const hv_wprep_layer L = layers[blockIdx.y];
     if (L.transposed_src) return;
     // a work item = (32 filters x 32 input channels) x a group of up to 4 taps: the largest PatchGAN layer is 128 tiles, with the taps split it is 512 items
@@ -249,8 +249,10 @@ __global__ __launch_bounds__(256) void weight_layout_fused_kernel(const hv_wprep
                 for (int t = 0; t < tn; ++t) {
                     const float val = wl_sh[r * RS + lane * LDT + t];
                     const long long i = ((long long)co * taps + t0 + t) * L.CinP + ci;
+                    if (!(diag_lean && Tf == 32)) {
                     L.w_fwd[i] = val;
                     if (L.w_fwd_h) reinterpret_cast<_Float16*>(L.w_fwd_h)[i] = (_Float16)val;
+                    }
                     if (Tf == 16) reinterpret_cast<_Float16*>(L.w_fwd_t)[tiled_index(co, t0 + t, ci, taps, L.CinP, 16)] = (_Float16)val;
                 }
             }
@@ -291,8 +293,10 @@ __global__ __launch_bounds__(256) void weight_layout_fused_kernel(const hv_wprep
                 for (int t = 0; t < tn; ++t) {
                     const float val = in ? wl_sh[lane * RS + cil * LDT + t] : 0.f;
                     const long long i = ((long long)ci * taps + t0 + t) * L.CoutP + co;
+                    if (!(diag_lean && Tb == 32)) {
                     L.w_bwd[i] = val;
                     if (L.w_bwd_h) reinterpret_cast<_Float16*>(L.w_bwd_h)[i] = (_Float16)val;
+                    }
                     if (Tb == 16) reinterpret_cast<_Float16*>(L.w_bwd_t)[tiled_index(ci, t0 + t, co, taps, L.CoutP, 16)] = (_Float16)val;
                 }
             }
@@ -326,7 +330,8 @@ extern "C" int hv_weight_prep2(const hv_wprep_layer* d_layers, int n_layers, lon
     // one item = 32 x 32 x 4 elements of a table: about one workgroup per item of the largest layer, grid-stride for the rest
     int gx = (int)hv_cdiv(max_numel, 2 * 1024 * 4);
     gx = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
-    hipLaunchKernelGGL(weight_layout_fused_kernel, dim3(gx, n_layers), dim3(256), 0, (hipStream_t)stream, d_layers);
+    static const int diag_lean = getenv("HV_DIAG_LEAN_TABLES") ? atoi(getenv("HV_DIAG_LEAN_TABLES")) : 0;      // timing-only experiment: fragment-ordered tables only
+    hipLaunchKernelGGL(weight_layout_fused_kernel, dim3(gx, n_layers), dim3(256), 0, (hipStream_t)stream, d_layers, diag_lean);
     HV_LAUNCH_CHECK();
     if (any_legacy) {
         const int gl = hv_cdiv(max_numel, 2048) < 1 ? 1 : hv_cdiv(max_numel, 2048);

@@ -209,7 +209,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(const WTrK p) {
 // lane-linear, so the LDS images cannot carry the odd row strides used above; instead the SOURCE side permutes 16-byte pieces:
 //   G   [128 pixels][128 B]:  piece j of tile pixel (ty, tx) holds channel piece j ^ 2 ((tx >> 1) & 3)
 //   X   stride 1: [PH][24 pixels][64 B], piece j of patch pixel (py, px) holds channel piece j ^ 2 ((px >> 2) & 1)
-//       stride 2: [PH][40 pixels][32 B], patch pixel pp = 40 py + px sits in row pp ^ ((pp >> 3) & 1)
+//       stride 2: [PH][2 column parities][24 pixels][64 B]: the patch row DE-INTERLEAVED by column parity at DMA time (patch column px sits at
+//                 (px & 1, px >> 1)), so a tap's stride-2 pixel walk is a unit-stride walk inside one parity half and the stride-1 image's piece key
+//                 (on the half's own index) serves it unchanged.  Round 4 -- before: [PH][40 pixels][32 B] with 16-channel input blocks (a 64-byte row
+//                 under a 2-pixel step puts a half-wave's eight rows on two bank octets whatever the piece key); the 32-channel block halves the number
+//                 of (filter block, channel block) pairs, i.e. the G tiles' re-reads and the DMA instructions per MFMA
 // (patch rows padded to a multiple of 8 pixels so that the keys depend on px alone; the pad pixels are out-of-range lanes of the DMA = zeros,
 // never read).  Each transposed read's eight pixel rows of a 32-lane half then cover all 64 banks once for every tap and k-step (brute-forced
 // over all (tap, k-step, fragment) address sets).  The per-lane address of a fragment is (lane base) ^ (fragment << 5) + an immediate.
@@ -230,8 +234,8 @@ __device__ __forceinline__ i32x4 wtr_rsrc(const void* base, unsigned bytes) {
 
 template <int KS, int ST>
 struct WTrdCfg {
-    static constexpr int BN = 64, BC = ST == 1 ? 32 : 16, TH = 8, TW = 16, TAPS = KS * KS, SLOTS = (TAPS + 3) / 4;
-    static constexpr int PH = (TH - 1) * ST + KS, PW = (TW - 1) * ST + KS, PWP = ST == 1 ? 24 : 40;
+    static constexpr int BN = 64, BC = 32, TH = 8, TW = 16, TAPS = KS * KS, SLOTS = (TAPS + 3) / 4;
+    static constexpr int PH = (TH - 1) * ST + KS, PW = (TW - 1) * ST + KS, PWP = ST == 1 ? 24 : 48;      // stride 2: two parity halves of 24
     static constexpr int NT = BN / 16, CT = BC / 16, XPR = BC / 8, XROW = BC * 2;
     static constexpr int XI = PH * PWP * XPR, XINS = (XI + 63) / 64, XPT = (XINS + 3) / 4;
     static constexpr int GBUF = TH * TW * 128, XBUF = XINS * 1024, BUFSZ = GBUF + XBUF;
@@ -272,9 +276,9 @@ __global__ __launch_bounds__(512, 1) void wgrad_trd_kernel(const WTrK p) {
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
         const int t = wave + 4 * s, tt = t < TAPS ? t : 0, r = tt / KS, q = tt - r * KS;
-        const int px = tx_l * ST + q;
-        if (ST == 1) xa0[s] = GBUF + (r * PWP + px) * XROW + (((px >> 2) & 1) << 5) + pc * 8;
-        else xa0[s] = GBUF + (((r * PWP + px) ^ (((r & 1) + (px >> 3)) & 1)) * XROW) + pc * 8;
+        // stride 2: patch column 2 tx + q lies in parity half q & 1 at index u = tx + (q >> 1)
+        const int u = ST == 1 ? tx_l + q : tx_l + (q >> 1), half = ST == 1 ? 0 : (q & 1) * 24;
+        xa0[s] = GBUF + (r * PWP + half + u) * XROW + (((u >> 2) & 1) << 5) + pc * 8;
     }
 
     // ---- tile-invariant part of the DMA items: wave w issues G instructions 4w .. 4w+3 and X instructions w, w+4, ...
@@ -289,9 +293,9 @@ __global__ __launch_bounds__(512, 1) void wgrad_trd_kernel(const WTrK p) {
 #pragma unroll
     for (int i = 0; i < XPT; ++i) {
         const int e = (wave + 4 * i) * 64 + lane, row = e / XPR, j = e % XPR;
-        const int pp = ST == 1 ? row : row ^ ((row >> 3) & 1);
-        const int py = pp / PWP, px = pp - py * PWP;
-        const int ci = ci0 + ((ST == 1 ? j ^ (((px >> 2) & 1) << 1) : j) << 3);
+        const int py = row / PWP, rem = row - py * PWP;
+        const int u = ST == 1 ? rem : rem % 24, px = ST == 1 ? rem : 2 * u + rem / 24;      // LDS slot (py, [parity,] u) <- patch pixel (py, px)
+        const int ci = ci0 + ((j ^ (((u >> 2) & 1) << 1)) << 3);
         const bool ok = e < XI && px < PW && ci < p.Cin;
         xrel[i] = ok ? (py * p.Wl + px) * p.x_ld + p.x_coff + ci : NOPE;
         xpp[i] = (py << 8) | px;
@@ -505,34 +509,42 @@ static bool wgrad_tr_plan(const hv_wgrad_desc* d, WTrPlan* pl) {
         static const int bn32 = getenv("HV_WTR_BN32") ? atoi(getenv("HV_WTR_BN32")) : 1;      // A/B knob (three same-box pairs: 8.85 -> 8.82 ms)
         if (bn32 && d->stride == 1 && d->Cout == 64 && d->Cin <= 64 && d->Cin >= 32) pl->BN = 32;
     }
-    if (d->stride == 2 && pl->BN == 64) pl->BC = 16;      // the stride-2 patch is 3x larger: its prefetch registers leave room for 16 accumulator tiles
+    // (Measured and not kept, round 4: 16 x 16 blocks -- 16 block pairs x 32 pixel chunks, 9-KB slab tiles, 4.7 MB of slabs instead of 18.9 -- for the
+    // generators' 32- / 64-channel 3x3 layers: 64 -> 64 @64^2 21.6 -> 29.1 us, 32 -> 32 @128^2 19.4 -> 27.1, 32 -> 32 @256^2 40.2 -> 91.7 at the best of 256 .. 2048
+    // workgroups (kernel + slab fold): one A and one B fragment per MFMA makes the LDS reads the bound; the slab bytes were not.)
+    const bool s2_dma = d->stride == 2 && pl->BN == 64 && !(d->Cin & 31) && d->in_shift == 0;      // the LDS-DMA form takes 32-channel blocks at both strides
+    if (d->stride == 2 && pl->BN == 64 && !s2_dma) pl->BC = 16;      // register-staged form: the stride-2 patch is 3x larger, its prefetch registers leave room for 16 accumulator tiles
     const int PH = 7 * d->stride + d->KH, PW = 15 * d->stride + d->KW;
     pl->lds = (size_t)128 * wtr_stride(pl->BN, 1) + (size_t)PH * PW * wtr_stride(pl->BC, d->stride);
     // the LDS-DMA form: 64-channel output blocks, its fixed input block (32 channels at stride 1, 16 at stride 2), no fused upsampling
     static const int dma_on = getenv("HV_WGRAD_TRD") ? atoi(getenv("HV_WGRAD_TRD")) : 1;   // A/B knob
-    pl->dma = dma_on && pl->BN == 64 && pl->BC == (d->stride == 1 ? 32 : 16) && d->in_shift == 0;
+    pl->dma = dma_on && pl->BN == 64 && pl->BC == 32 && d->in_shift == 0;
     const bool dma_candidate = pl->dma;
     if (pl->dma) {
-        const int PWP = d->stride == 1 ? 24 : 40, XI = PH * PWP * (pl->BC / 8);
+        const int PWP = d->stride == 1 ? 24 : 48, XI = PH * PWP * (pl->BC / 8);
         pl->lds = (size_t)2 * (8 * 16 * 128 + (XI + 63) / 64 * 1024);
     }
     const long long ntiles = (long long)d->B * hv_cdiv(d->Ho, 8) * hv_cdiv(d->Wo, 16);
-    const long long pairs = (long long)hv_cdiv(d->Cout, pl->BN) * hv_cdiv(d->Cin, pl->BC);
     // workgroups wanted per launch (split over pixel chunks): every chunk writes a whole slab of dW, so a layer with a small dW tile count (the
     // generators' 64-channel layers: 2 tiles, 256 slabs of 147 KB = 38 MB for 17 MB of operands) is bound by its slab traffic, not by its MFMAs
     // (step-level A/B, round 3, same box: PatchGAN layers 512 -> 256 workgroups 9.43 -> 9.25 ms (their slabs are 8 MB each); 192: 9.23; the
     // generators' layers 512 / 256: no difference, 128: +0.2 ms)
     static const int want_big = getenv("HV_WGRAD_TR_WGS") ? atoi(getenv("HV_WGRAD_TR_WGS")) : 256;
     static const int want_small = getenv("HV_WGRAD_TR_WGS_SMALL") ? atoi(getenv("HV_WGRAD_TR_WGS_SMALL")) : 512;
-    const int want = pairs <= 4 ? want_small : want_big;
-    long long gx = (want + pairs - 1) / pairs;
-    if (gx > ntiles) gx = ntiles;
-    if (gx < 1) gx = 1;
-    pl->gx = (int)gx;
+    auto chunks = [&]() {
+        const long long pairs = (long long)hv_cdiv(d->Cout, pl->BN) * hv_cdiv(d->Cin, pl->BC);
+        const int want = pairs <= 4 ? want_small : want_big;
+        long long gx = (want + pairs - 1) / pairs;
+        if (gx > ntiles) gx = ntiles;
+        if (gx < 1) gx = 1;
+        pl->gx = (int)gx;
+    };
+    chunks();
     // the DMA form pays a longer prologue (8 waves, hoisted DMA indices): it needs a few tiles per workgroup to win (generator 64 -> 64 at 64 x 64, 2 tiles
     // per workgroup: 22.8 us against 16.1)
-    if (dma_candidate && ntiles < 4 * gx) {
+    if (dma_candidate && ntiles < 4 * pl->gx) {
         pl->dma = false;
+        if (d->stride == 2) { pl->BC = 16; chunks(); }      // (the register-staged form's block at stride 2)
         pl->lds = (size_t)128 * wtr_stride(pl->BN, 1) + (size_t)PH * PW * wtr_stride(pl->BC, d->stride);
     }
     return true;

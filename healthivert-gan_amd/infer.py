@@ -123,20 +123,11 @@ def prepare_slice(cam2d, label2d, ct2d, vert_id, maxheight=40):
     return dict(ct_masked=f(ct_masked, True), ori_ct=f(ct_u8, True), mask=f(mask, False), cam=f(cam, False), x1=x1, x2=x2, height=height)
 
 
-_PIN = {}
 _POOL = []
 
 
-def _pinned_f32(n, slot='buf'):
-    b = _PIN.get(slot)
-    if b is None or b.numel() < n:
-        b = _PIN[slot] = torch.empty(n, dtype=torch.float32).pin_memory()
-    return b[:n]
-
-
 def _parallel(jobs):
-    """Run a few numpy copy / convert jobs side by side (numpy releases the GIL inside them): the float64 <-> float32 slab copies of a
-    volume are three / two independent passes over 3-13 MB each."""
+    """Run a few numpy copy jobs side by side (numpy releases the GIL inside them): the pinned copies of a volume's three float64 arrays."""
     if not _POOL:
         from concurrent.futures import ThreadPoolExecutor
         _POOL.append(ThreadPoolExecutor(max_workers=3))
@@ -170,70 +161,159 @@ def _stage_device(model, st, vert_id, selected, maxheight):
     return valid
 
 
+class VolumePipeline:
+    """process_nii_files' per-volume loop (reference eval_3d_sagittal_twostage.py:186-241) for a STREAM of volumes.
+
+    Per volume the host does ONE thing with the data: it copies the three float64 [H, W, Z] arrays into a pinned buffer (three threads; numpy
+    releases the GIL).  Everything else runs on the device: the upload (copy stream), the z-extent scan and the neighbours' pixel counts
+    (hv_volume_scan, one pass over the label volume), the z-range cut + float32 conversion + transpose to slices (hv_volume_slices), the three
+    chained synthesis stages batched over all slices (`_stage_device`), the float64 output volumes (hv_volume_merge) and their download.  Buffers
+    are double: while the compute stream runs volume n's stages, volume n + 1 is copied to pinned memory (worker thread), uploaded and scanned
+    (copy stream) and volume n - 1's outputs come down (output stream) -- one host wait per volume (its 3 x Z scan counts decide S, the z-range and
+    which neighbour stages run)."""
+
+    def __init__(self, model, device, maxheight=40):
+        from concurrent.futures import ThreadPoolExecutor
+        from . import engine
+        self.model, self.dev, self.maxheight = model, torch.device(device), maxheight
+        self.copy_stream = engine.named_stream('volume-upload', self.dev)
+        self.out_stream = engine.named_stream('volume-download', self.dev)
+        self.slots = [None, None]
+        self.stager = ThreadPoolExecutor(max_workers=1)
+
+    def _slot(self, i, H, W, Z):
+        sl = self.slots[i]
+        if sl is None or sl['shape'] != (H, W, Z):
+            n = H * W * Z
+            sl = self.slots[i] = {
+                'shape': (H, W, Z),
+                'pin_in': torch.empty(3 * n, dtype=torch.float64).pin_memory(), 'dev_in': torch.empty(3 * n, dtype=torch.float64, device=self.dev),
+                'counts': torch.empty(3 * Z, dtype=torch.int32, device=self.dev), 'pin_counts': torch.empty(3 * Z, dtype=torch.int32).pin_memory(),
+                'dev_out': torch.empty(2 * n, dtype=torch.float64, device=self.dev), 'pin_out': torch.empty(2 * n, dtype=torch.float64).pin_memory(),
+                'ev_in': torch.cuda.Event(), 'ev_done': torch.cuda.Event(), 'ev_out': torch.cuda.Event(), 'ev_free': None}
+        return sl
+
+    def _stage_in(self, i, ct_data, label_data, cam_data, vert_id):
+        """Worker thread: the volume's three arrays -> pinned slot i -> device; scan; counts -> pinned.  Returns the slot (its ev_in says when)."""
+        import numpy as np
+        H, W, Z = label_data.shape
+        sl = self._slot(i, H, W, Z)
+        if sl['ev_free'] is not None:
+            sl['ev_free'].synchronize()          # the compute stream has read this slot's previous volume out of dev_in
+        n = H * W * Z
+        pin = sl['pin_in'].numpy().reshape(3, H, W, Z)
+        _parallel([(lambda k=k, vol=vol: np.copyto(pin[k], vol, casting='unsafe')) for k, vol in enumerate((label_data, ct_data, cam_data))])
+        L = _lib.get()
+        nbs = [float(nb) if cond else -1.0 for nb, cond in ((vert_id - 1, vert_id > 8), (vert_id + 1, vert_id < 24))]
+        with torch.cuda.stream(self.copy_stream):
+            sl['dev_in'].copy_(sl['pin_in'], non_blocking=True)
+            L.call('hv_volume_scan', ptr(sl['dev_in']), ctypes.c_longlong(H * W), Z, ctypes.c_double(float(vert_id)), ctypes.c_double(nbs[0]),
+                   ctypes.c_double(nbs[1]), ptr(sl['counts']), stream())
+            sl['pin_counts'].copy_(sl['counts'], non_blocking=True)
+            sl['ev_in'].record(self.copy_stream)
+        sl['vert_id'] = vert_id
+        return sl
+
+    def _compute(self, sl):
+        """Main thread: wait for the slot's scan counts, plan the z-range, queue the stages, the output volumes and their download."""
+        L = _lib.get()
+        H, W, Z = sl['shape']
+        vert_id, dev = sl['vert_id'], self.dev
+        sl['ev_in'].synchronize()                # the only host wait of the volume (the upload + scan ran while the previous volume computed)
+        counts = sl['pin_counts'].numpy().reshape(3, Z)
+        zhas = counts[0].nonzero()[0]
+        main = torch.cuda.current_stream(dev)
+        n = H * W * Z
+        out = sl['dev_out'].view(2, n)
+        sl['empty'] = zhas.size == 0
+        S = 0
+        if not sl['empty']:
+            z0, z1 = int(zhas.min()), int(zhas.max())
+            rng_len = z1 - z0 + 1
+            new_len = int(rng_len * 4 / 5)
+            nz0 = z0 + (rng_len - new_len) // 2
+            nz1 = nz0 + new_len - 1
+            centre = (nz0 + nz1) // 2
+            S = nz1 - nz0 + 1
+        if S <= 0:
+            sl['empty'] = True
+            sl['dev_out'].zero_()
+        else:
+            main.wait_event(sl['ev_in'])
+            vols = torch.empty(3, S, H, W, dtype=torch.float32, device=dev)
+            for k in range(3):
+                L.call('hv_volume_slices', ptr(sl['dev_in'][k * n:(k + 1) * n]), ctypes.c_longlong(H * W), Z, nz0, S, ptr(vols[k]), stream())
+            sl['ev_free'] = torch.cuda.Event()
+            sl['ev_free'].record(main)           # dev_in may take the next volume
+            st = {'lab': vols[0], 'ct': vols[1], 'cam': vols[2],
+                  'ratio': torch.tensor([abs(z - centre) / rng_len * 2 for z in range(nz0, nz1 + 1)], dtype=torch.float64, device=dev)}
+            # the neighbour stages run on the slices where the neighbour has > 200 pixels on the ORIGINAL labels (reference :208,:217): the scan counted
+            # them per z, so the host already knows which stages run and on which slices
+            for j, (nb, cond) in enumerate(((vert_id - 1, vert_id > 8), (vert_id + 1, vert_id < 24))):
+                if cond:
+                    sel = counts[1 + j, nz0:nz1 + 1] > 200
+                    if sel.any():
+                        _stage_device(self.model, st, nb, torch.from_numpy(sel.astype('int32')).to(dev, non_blocking=True), self.maxheight)
+            valid = _stage_device(self.model, st, vert_id, None, self.maxheight)
+            for k, name in enumerate(('ct', 'lab')):
+                L.call('hv_volume_merge', ptr(st[name]), ptr(valid), ctypes.c_longlong(H * W), Z, nz0, S, ptr(out[k]), stream())
+        sl['ev_done'].record(main)
+        with torch.cuda.stream(self.out_stream):
+            self.out_stream.wait_event(sl['ev_done'])
+            sl['pin_out'].copy_(sl['dev_out'], non_blocking=True)
+            sl['ev_out'].record(self.out_stream)
+
+    def _finish(self, sl, copy):
+        import numpy as np
+        H, W, Z = sl['shape']
+        sl['ev_out'].synchronize()
+        res = sl['pin_out'].numpy().reshape(2, H, W, Z)
+        if not copy:
+            return res[0], res[1]
+        outs = [np.empty((H, W, Z), dtype=np.float64), np.empty((H, W, Z), dtype=np.float64)]
+        _parallel([lambda: np.copyto(outs[0], res[0]), lambda: np.copyto(outs[1], res[1])])
+        return outs[0], outs[1]
+
+    def run(self, volumes, copy=True):
+        """volumes: iterable of (ct_data, label_data, cam_data, vert_id) -- float64 [H, W, Z] arrays, ct in 0..255, cam already scaled by 255
+        (reference :181).  Yields (output_ct, output_seg) [H, W, Z] float64 per volume, in order.  copy=False hands out views of the pinned download
+        buffers instead of fresh arrays: valid until the volume after next has been yielded."""
+        it = iter(volumes)
+        nxt = next(it, None)
+        if nxt is None:
+            return
+        fut = self.stager.submit(self._stage_in, 0, *nxt)
+        i, prev = 0, None
+        while fut is not None:
+            sl = fut.result()
+            nxt = next(it, None)
+            fut = self.stager.submit(self._stage_in, (i + 1) & 1, *nxt) if nxt is not None else None
+            if prev is not None and not copy:
+                pass      # (views of prev's pinned buffer were handed out one iteration ago; prev's slot is re-used by the volume after this one)
+            self._compute(sl)
+            if prev is not None:
+                yield self._finish(prev, copy)
+            prev, i = sl, i + 1
+        yield self._finish(prev, copy)
+
+
+_PIPELINES = {}
+
+
+def process_volumes(model, volumes, device, maxheight=40, copy=True):
+    """Generator over (output_ct, output_seg) for an iterable of (ct_data, label_data, cam_data, vert_id): `VolumePipeline.run`."""
+    key = (id(model), str(device), maxheight)
+    pipe = _PIPELINES.get(key)
+    if pipe is None:
+        pipe = _PIPELINES[key] = VolumePipeline(model, device, maxheight)
+    return pipe.run(volumes, copy=copy)
+
+
 def process_volume(model, ct_data, label_data, cam_data, vert_id, device, maxheight=40):
-    """process_nii_files' per-volume loop (reference :186-234) with the three chained syntheses (upper neighbour, lower
-    neighbour, target) each batched over ALL z-slices: 3 generator launches per volume instead of ~130 bs=1 calls, and the slices
-    stay on the device between the stages -- component filter, bounding rows, band re-stacking and quantisation (run_model :46-98) run there
-    too (`_stage_device`).  ct_data in 0..255, label_data = vertebra ids, cam_data already scaled by 255 (reference :181).  Returns
-    (output_ct [H,W,Z], output_seg [H,W,Z]) as float64 numpy arrays (zeros outside the processed z range).
+    """process_nii_files' per-volume body (reference :186-234) with the three chained syntheses (upper neighbour, lower neighbour, target) each
+    batched over ALL z-slices: 3 generator launches per volume instead of ~130 bs=1 calls, the slices staying on the device between the stages --
+    component filter, bounding rows, band re-stacking and quantisation (run_model :46-98) included.  ct_data in 0..255, label_data = vertebra
+    ids, cam_data already scaled by 255 (reference :181).  Returns (output_ct [H,W,Z], output_seg [H,W,Z]) as float64 numpy arrays (zeros outside
+    the processed z range).  One volume through `VolumePipeline`; a loop over volumes should use `process_volumes`, which overlaps their transfers.
     (Where the reference would raise -- a neighbour stage returning None, :212,:221 -- the slice passes through unchanged.)"""
-    import numpy as np
-    L = _lib.get()
-    dev = torch.device(device)
-    H, W, Z = label_data.shape
-    has = [None] * 3                 # z-extent of the vertebra (:186-190): three row bands scanned side by side
-    bands = np.array_split(np.arange(H), 3)
-
-    def scan(i):
-        has[i] = (label_data[bands[i][0]:bands[i][-1] + 1] == vert_id).any(axis=(0, 1)) if len(bands[i]) else np.zeros(Z, dtype=bool)
-    _parallel([lambda i=i: scan(i) for i in range(3)])
-    zhas = np.flatnonzero(has[0] | has[1] | has[2])
-    z0, z1 = int(zhas.min()), int(zhas.max())
-    rng_len = z1 - z0 + 1
-    new_len = int(rng_len * 4 / 5)
-    nz0 = z0 + (rng_len - new_len) // 2
-    nz1 = nz0 + new_len - 1
-    centre = (nz0 + nz1) // 2
-    zs = list(range(nz0, nz1 + 1))
-    S = len(zs)
-    out_ct, out_seg = np.zeros((H, W, Z), dtype=np.float64), np.zeros((H, W, Z), dtype=np.float64)
-    if S == 0:
-        return out_ct, out_seg
-    # the [H, W, Z] inputs have z fastest: the z-range is cut out as it lies (float32, [H*W][S]) and transposed to slices on the device
-    stage = _pinned_f32(3 * H * W * S).view(3, H, W, S)          # one pinned staging buffer: no intermediate copies, asynchronous upload
-    stage_np = stage.numpy()
-    _parallel([(lambda i=i, vol=vol: np.copyto(stage_np[i], vol[:, :, nz0:nz1 + 1], casting='unsafe'))
-               for i, vol in enumerate((label_data, ct_data, cam_data))])
-    hws = stage.to(dev, non_blocking=True)
-    vols = torch.empty(3, S, H, W, dtype=torch.float32, device=dev)
-    L.call('hv_transpose_batched', ptr(hws), ptr(vols), 3, H * W, S, stream())
-    st = {'lab': vols[0], 'ct': vols[1], 'cam': vols[2],
-          'ratio': torch.tensor([abs(z - centre) / rng_len * 2 for z in zs], dtype=torch.float64, device=dev)}
-    # the neighbour stages run on the slices where the neighbour has > 200 pixels on the ORIGINAL labels (reference :208,:217): both counts are
-    # taken on the device before the first stage rewrites the label slices (hv_slice_count), one small read-back decides which stages run
-    nbs = [nb for nb, cond in ((vert_id - 1, vert_id > 8), (vert_id + 1, vert_id < 24)) if cond]
-    if nbs:
-        counts = torch.empty(len(nbs), S, dtype=torch.int32, device=dev)
-        for i, nb in enumerate(nbs):
-            L.call('hv_slice_count', ptr(st['lab']), S, ctypes.c_longlong(H * W), ctypes.c_float(float(nb)), ptr(counts[i]), stream())
-        sel = (counts > 200).int()
-        runs = sel.any(dim=1).cpu()
-        for i, nb in enumerate(nbs):
-            if bool(runs[i]):
-                _stage_device(model, st, nb, sel[i].contiguous(), maxheight)
-    valid = _stage_device(model, st, vert_id, None, maxheight)
-    res = torch.zeros(2, S, H * W, dtype=torch.float32, device=dev)
-    per = ctypes.c_longlong(H * W)
-    L.call('hv_select_slices', ptr(valid), ptr(st['ct']), ptr(res[0]), S, per, 0, stream())
-    L.call('hv_select_slices', ptr(valid), ptr(st['lab']), ptr(res[1]), S, per, 0, stream())
-    res_hws = torch.empty(2, H * W, S, dtype=torch.float32, device=dev)
-    L.call('hv_transpose_batched', ptr(res), ptr(res_hws), 2, S, H * W, stream())
-    back = _pinned_f32(2 * H * W * S, 'back').view(2, H * W, S)      # pinned: the download runs at PCIe speed, no staging copy
-    back.copy_(res_hws, non_blocking=True)
-    torch.cuda.current_stream().synchronize()
-    res_np = back.numpy().reshape(2, H, W, S)
-
-    def put(dst, i):
-        dst[:, :, nz0:nz1 + 1] = res_np[i]
-    _parallel([lambda: put(out_ct, 0), lambda: put(out_seg, 1)])
-    return out_ct, out_seg
+    return next(process_volumes(model, [(ct_data, label_data, cam_data, vert_id)], device, maxheight))

@@ -24,8 +24,9 @@ class KernelTimer:
         self.pair_us = 0.0    # calibrate(): an empty event pair's own reading, subtracted from every launch
 
     def calibrate(self, n=200):
-        """Median reading of an event pair recorded around NOTHING on the current stream (microseconds): the part of every kernel's event duration
-        that is the events' own (the two barrier packets and the hand-over between them), which rocprofv3's kernel durations do not contain."""
+        """Reading of an event pair recorded around NOTHING on the current stream (microseconds; the 5 % quantile of n pairs -- a lower bound of the
+        events' own share, so the net durations stay on the conservative side): the part of every kernel's event duration that is the two barrier
+        packets' own, which rocprofv3's kernel durations do not contain (measured: 3.7 us on a 13.9 us kernel, profiles/r03l)."""
         torch.cuda.synchronize()
         pairs = []
         for _ in range(n):
@@ -34,7 +35,7 @@ class KernelTimer:
             pairs.append((s, e))
         torch.cuda.synchronize()
         v = sorted(s.elapsed_time(e) * 1e3 for s, e in pairs)
-        self.pair_us = v[len(v) // 2]
+        self.pair_us = v[len(v) // 20]
         return self.pair_us
 
     # ---- hook called by ops.conv2d / ops.conv2d_wgrad around each launch

