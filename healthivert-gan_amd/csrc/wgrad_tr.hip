@@ -533,7 +533,9 @@ static bool wgrad_tr_plan(const hv_wgrad_desc* d, WTrPlan* pl) {
     static const int want_small = getenv("HV_WGRAD_TR_WGS_SMALL") ? atoi(getenv("HV_WGRAD_TR_WGS_SMALL")) : 512;
     auto chunks = [&]() {
         const long long pairs = (long long)hv_cdiv(d->Cout, pl->BN) * hv_cdiv(d->Cin, pl->BC);
-        const int want = pairs <= 4 ? want_small : want_big;
+        // (the small-dW rule by BYTES since round 4: with 32-channel blocks at stride 2 the PatchGAN 64 -> 128 layer has 4 pairs too, and 128 slabs of its
+        // 0.5-MB dW would be 67 MB)
+        const int want = (pairs <= 4 && (long long)d->Cout * d->KH * d->KW * d->Cin * 4 <= 256 * 1024) ? want_small : want_big;
         long long gx = (want + pairs - 1) / pairs;
         if (gx > ntiles) gx = ntiles;
         if (gx < 1) gx = 1;

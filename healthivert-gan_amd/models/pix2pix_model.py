@@ -128,6 +128,17 @@ class Pix2PixModel(BaseModel):
     _STEP_OUTPUTS = ('fake_B', 'fake_B_coarse', 'fake_B_local', 'real_B_local', 'fake_B_mask_raw', 'coarse_seg_binary', 'coarse_seg_sigmoid',
                      'fake_B_mask_sigmoid', 'x_stage1', 'fake_B_raw', 'pred1_h', 'pred2_h', 'real_edges', 'fake_edges', '_gplan', '_rows', '_dxs')
 
+    # discriminator k's batched input [fake_k | real_k] (2B samples): the step's producers write straight into its halves
+    _PAIRED = {'real_B': 1, 'real_B_mask': 2}
+
+    def _pair_buffer(self, k, shape):
+        """D_k's 2B-sample input buffer for the current batch shape (lives with the inputs: its upper half IS an input)."""
+        key = 'dcat%d' % k
+        b = self._in.get(key)
+        if b is None or b.shape[1:] != tuple(shape[1:]) or b.shape[0] != 2 * shape[0]:
+            b = self._in[key] = torch.zeros((2 * shape[0],) + tuple(shape[1:]), dtype=torch.float32, device=self.device)
+        return b
+
     # ---------------------------------------------------------------- inputs
     def set_input(self, input):
         """Unpack a batch dict (reference models/pix2pix_model.py:137-175).  The tensors land in persistent device buffers, one set
@@ -152,7 +163,11 @@ class Pix2PixModel(BaseModel):
         def put(name, t, dtype):
             b = self._in.get(name)
             if b is None or b.shape != t.shape or b.dtype != dtype:
-                b = torch.empty(t.shape, dtype=dtype, device=self.device)
+                pair = self._PAIRED.get(name) if (self.isTrain and self.batch_d) else None
+                if pair is not None:      # the real image of D_k is the upper half of D_k's 2B-sample input buffer (fake | real): no copy into it per step
+                    b = self._pair_buffer(pair, t.shape)[t.shape[0]:]
+                else:
+                    b = torch.empty(t.shape, dtype=dtype, device=self.device)
                 self._in[name] = b
                 self._graphs = None        # input addresses changed: captured graphs are stale,
                 self._eager_steps = 0      # and the new shape needs its own eager warm-up (plans, tables) before a capture
@@ -199,8 +214,14 @@ class Pix2PixModel(BaseModel):
         self.x_stage1, self.fake_B_raw = P.x_stage1, P.x_stage2
         d = L.hv_postg_desc()
         outs = {}
+        paired = self.isTrain and self.batch_d and 'dcat1' in self._in
+        halves = {'fake_B': (1, 0), 'fake_B_mask_raw': (2, 0), 'fake_B_local': (3, 0), 'real_B_local': (3, 1)} if paired else {}
         for n in ('fake_B', 'fake_B_coarse', 'fake_B_local', 'real_B_local', 'fake_B_mask_raw', 'coarse_seg_binary'):
-            outs[n] = self._buf(n, self.real_B)
+            if n in halves:      # written by the compositing kernel straight into D_k's [fake | real] input buffer
+                k, hi = halves[n]
+                outs[n] = self._pair_buffer(k, self.real_B.shape)[hi * B:(hi + 1) * B]
+            else:
+                outs[n] = self._buf(n, self.real_B)
             setattr(self, n, outs[n])
         p1h, p2h = self._buf('pred1_h', shape=(1, B)), self._buf('pred2_h', shape=(1, B))
         self._rows = self._buf('rows', shape=(B, 4), dtype=torch.int32)
@@ -232,10 +253,13 @@ class Pix2PixModel(BaseModel):
         lf, lr = self._loss_slot(2 * k), self._loss_slot(2 * k + 1)
         if self.batch_d:
             B = fake.shape[0]
-            x2 = self._buf('dcat%d' % k, shape=(2 * B,) + tuple(fake.shape[1:]))
-            n = ctypes.c_longlong(fake.numel())
-            L.call('hv_affine', ptr(x2[:B]), ptr(fake), n, ctypes.c_float(1.0), ctypes.c_float(0.0), stream())
-            L.call('hv_affine', ptr(x2[B:]), ptr(real), n, ctypes.c_float(1.0), ctypes.c_float(0.0), stream())
+            x2 = self._in.get('dcat%d' % k)
+            if not (x2 is not None and x2.shape[0] == 2 * B and fake.data_ptr() == x2.data_ptr() and real.data_ptr() == x2[B:].data_ptr()):
+                # (callers with tensors of their own: gather the two halves)
+                x2 = self._buf('dcat%d' % k, shape=(2 * B,) + tuple(fake.shape[1:]))
+                n = ctypes.c_longlong(fake.numel())
+                L.call('hv_affine', ptr(x2[:B]), ptr(fake), n, ctypes.c_float(1.0), ctypes.c_float(0.0), stream())
+                L.call('hv_affine', ptr(x2[B:]), ptr(real), n, ctypes.c_float(1.0), ctypes.c_float(0.0), stream())
             P = net.run_forward(x2, training=True, prep=True, groups=2)
             net.loss_backward_halves(P, mode, lf, lr, 0.5 * self.grad_scale, dz=self._buf('dzz%d' % k, P.logits))
         else:
