@@ -533,6 +533,7 @@ static int launch_g4s1(G4K& k, int ny, hipStream_t s) {
     }
     hv_path_note = 8;
     HV_KNAME("conv_g4s1_kernel<%d, %d>", DG, MT);
+    HV_WUSE(4);
     hipLaunchKernelGGL(kern, dim3(k.tiles * k.B, ny), dim3(512), lds, s, k);
     HV_LAUNCH_CHECK();
     return HV_OK;
@@ -555,6 +556,7 @@ static int launch_g4(G4K& k, int ny, hipStream_t s) {
     }
     hv_path_note = 8;
     HV_KNAME("conv_g4_kernel<%d, %d>", MODE, MT);
+    HV_WUSE(4);
     hipLaunchKernelGGL(kern, dim3(k.tiles * k.B, ny), dim3(512), lds, s, k);
     HV_LAUNCH_CHECK();
     return HV_OK;

@@ -294,6 +294,7 @@ static int launch_halo_t(const HaloK& k, int tiles, int maxpatch, hipStream_t s)
                    lds >= (size_t)TH * TW * (BN + 8) * sizeof(_Float16)) ? 1 : 0;
         if (kk.ep16 && kk.mul_src && kk.mul_half && !(kk.mul_ld & 7) && !(kk.mul_coff & 7) && !((uintptr_t)kk.mul_src & 15)) kk.ep16 = 2;
     }
+    HV_WUSE(2);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, kk);
     HV_LAUNCH_CHECK();
     return HV_OK;

@@ -369,6 +369,7 @@ static int launch2(HaloK& k, hipStream_t s, int th0 = 8, int tw0 = TW) {
         if (kk.ep16 && kk.mul_src && kk.mul_half && !(kk.mul_ld & 7) && !(kk.mul_coff & 7) && !((uintptr_t)kk.mul_src & 15)) kk.ep16 = 2;
     }
     if (kk.wt) { kk.w = kk.wt; kk.w_bytes = kk.wt_bytes; }
+    HV_WUSE(kk.wt ? 4 : 2);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, kk);
     HV_LAUNCH_CHECK();
     return HV_OK;

@@ -195,6 +195,7 @@ int hv_conv2d_head(const hv_conv_desc* d, hipStream_t s) {
     if (!d->transposed && ((d->H + 2 * d->pad - d->KH) / d->stride + 1 != d->Ho || (d->W + 2 * d->pad - d->KW) / d->stride + 1 != d->Wo))
         return HV_ERR_ARG;
     HeadK k;
+    HV_WUSE(2);
     k.x = d->x; k.w = reinterpret_cast<const _Float16*>(d->w_f16); k.P = reinterpret_cast<float*>(d->workspace);
     k.M = d->B * d->H * d->W; k.tiles = hv_cdiv(k.M, 16); k.x_ld = d->x_ld; k.x_coff = d->x_coff; k.K = d->Cin; k.ntaps = d->KH * d->KW;
     k.wstride = d->Cin + ((16 - d->Cin % 128) + 128) % 128;   // row stride = 32 B mod 256 B: the 16 taps x 4 groups of a wave's 8-byte reads

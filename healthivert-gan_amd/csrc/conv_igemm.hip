@@ -22,6 +22,8 @@
 #define HV_BK 32
 
 thread_local int hv_path_note = 0;
+thread_local int hv_wtable_used = 0;
+extern "C" int hv_last_weight_tables(void) { return hv_wtable_used; }
 thread_local char hv_kname[192] = "";
 extern "C" const char* hv_last_kernel_name(void) { return hv_kname; }
 extern "C" int hv_last_kernel_path(void) { return hv_path_note; }
@@ -369,6 +371,7 @@ static int dispatch_conv(ConvK& k, hipStream_t s) {
 }
 
 static int conv2d_dispatch(const hv_conv_desc* d, void* stream) {
+    hv_wtable_used = 0;
     if (!d || !d->x || !d->w || !d->y) return HV_ERR_ARG;
     if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->KH <= 0 || d->KW <= 0 ||
         d->stride <= 0 || d->dil <= 0 || d->pad < 0 || d->Ho <= 0 || d->Wo <= 0)
@@ -500,6 +503,7 @@ static int conv2d_dispatch(const hv_conv_desc* d, void* stream) {
                         ((uintptr_t)d->w & 15) == 0 && (d->w_bstride & 3) == 0;
     hipStream_t s = (hipStream_t)stream;
     hv_path_note = 0;
+    HV_WUSE(1);      // the gather kernel reads the fp32 table (and converts)
     if (d->precision == HV_F32) return vec_in ? dispatch_conv<float, false>(k, s) : dispatch_conv<float, true>(k, s);
     return vec_in ? dispatch_conv<_Float16, false>(k, s) : dispatch_conv<_Float16, true>(k, s);
 }

@@ -400,6 +400,7 @@ static int launch_lf(HaloK& k, hipStream_t s) {
     dim3 grid(C.tiles * kk.B * (kk.dil > 1 ? kk.dil * kk.dil : 1), hv_cdiv(kk.Cout, CO));
     hv_path_note = 7;
     HV_KNAME("conv_lf_kernel<%d, %d, %d, %d, %s>", CIN, CO, TH, WPS, X1 ? "true" : "false");      // (as rocprofv3 prints the instantiation)
+    HV_WUSE(X1 ? 4 | 1 : 4);      // (the extra channel's filters come from the fp32 forward table)
     hipLaunchKernelGGL(kern, grid, dim3(G::NTHR), G::LDS_BYTES, s, kk);
     HV_LAUNCH_CHECK();
     return HV_OK;

@@ -431,6 +431,7 @@ int hv_conv2d_stem5(const hv_conv_desc* d, hipStream_t s) {
         return HV_ERR_UNSUPPORTED;
     if ((d->x_ld & 3) || (d->x_coff & 3) || ((uintptr_t)d->x & 15) || ((uintptr_t)d->w_f16 & 7) || (long long)d->B * d->H >= (1ll << 31)) return HV_ERR_UNSUPPORTED;
     Stem5K k;
+    HV_WUSE(2);
     k.x = d->x; k.w = reinterpret_cast<const _Float16*>(d->w_f16); k.y = d->y; k.x_half = d->x_f16 ? 1 : 0;
     k.H = d->H; k.W = d->W; k.x_ld = d->x_ld; k.x_coff = d->x_coff; k.img_stride = d->H * d->W * d->x_ld; k.y_ld = d->y_ld; k.y_coff = d->y_coff;
     k.epi.alpha = d->alpha; k.epi.act = d->act; k.epi.accumulate = d->accumulate; k.epi.Cout = 16; k.epi.bias = d->bias; k.epi.scale = nullptr;
@@ -458,6 +459,7 @@ int hv_conv2d_stem5_dgrad(const hv_conv_desc* d, hipStream_t s) {
         return HV_ERR_UNSUPPORTED;
     if ((d->x_ld & 7) || (d->x_coff & 7) || ((uintptr_t)d->x & 15) || ((uintptr_t)d->w_f16 & 15) || (long long)d->B * hv_cdiv(d->H, 8) > 65535) return HV_ERR_UNSUPPORTED;
     Stem5K k;
+    HV_WUSE(2);
     k.x = d->x; k.w = reinterpret_cast<const _Float16*>(d->w_f16); k.y = d->y; k.x_half = 1;
     k.H = d->H; k.W = d->W; k.x_ld = d->x_ld; k.x_coff = d->x_coff; k.img_stride = d->H * d->W * d->x_ld; k.y_ld = d->y_ld; k.y_coff = d->y_coff;
     k.epi.alpha = d->alpha; k.epi.act = d->act; k.epi.accumulate = d->accumulate; k.epi.Cout = 4; k.epi.bias = nullptr; k.epi.scale = nullptr;
@@ -474,6 +476,7 @@ int hv_conv2d_narrow(const hv_conv_desc* d, hipStream_t s) {
     if (d->w_bstride || d->ch_scale || d->dil != 1 || d->stride > 2) return HV_ERR_UNSUPPORTED;
     NarrowK k;
     const int Hp = d->H >> d->in_shift, Wp = d->W >> d->in_shift;
+    HV_WUSE(1 | 2);      // (fp32 VALU kernels; the MFMA stem reads the fp16 rows)
     k.x = d->x; k.w = d->w; k.bias = d->bias; k.y = d->y; k.x_half = d->x_f16 ? 1 : 0; k.y_half = d->y_f16 ? 1 : 0;
     k.B = d->B; k.H = d->H; k.W = d->W; k.in_shift = d->in_shift; k.Wp = Wp; k.img_stride = Hp * Wp * d->x_ld;
     k.x_ld = d->x_ld; k.x_coff = d->x_coff; k.Cin = d->Cin;
@@ -526,6 +529,7 @@ int hv_conv2d_thin_in(const hv_conv_desc* d, hipStream_t s) {
     if ((d->y_ld & 3) || (d->y_coff & 3) || ((uintptr_t)d->y & 15) || (long long)d->B * d->Ho > 65535) return HV_ERR_UNSUPPORTED;
     NarrowK k;
     const int Hp = d->H >> d->in_shift, Wp = d->W >> d->in_shift;
+    HV_WUSE(1 | 2);      // (fp32 VALU kernels; the MFMA stem reads the fp16 rows)
     k.x = d->x; k.w = d->w; k.bias = d->bias; k.y = d->y; k.x_half = d->x_f16 ? 1 : 0; k.y_half = d->y_f16 ? 1 : 0;
     k.B = d->B; k.H = d->H; k.W = d->W; k.in_shift = d->in_shift; k.Wp = Wp; k.img_stride = Hp * Wp * d->x_ld;
     k.x_ld = d->x_ld; k.x_coff = d->x_coff; k.Cin = d->Cin;

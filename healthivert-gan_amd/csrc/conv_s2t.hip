@@ -223,6 +223,7 @@ static int launch_s2t(S2TK& k, hipStream_t s) {
     dim3 grid(k.tiles * k.B, hv_cdiv(k.Cout, BN));
     hv_path_note = 6;
     HV_KNAME("conv_s2t_kernel<%d, %d, %d, %d>", KS, TH, BN, CK);
+    HV_WUSE(k.wt ? 4 : 2);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, k);
     HV_LAUNCH_CHECK();
     return HV_OK;

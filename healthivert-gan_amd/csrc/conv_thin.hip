@@ -193,6 +193,7 @@ int hv_conv2d_logits_dgrad(const hv_conv_desc* d, hipStream_t s) {
     if (d->mul_src && (!d->mul_f16 || (d->mul_ld & 7) || (d->mul_coff & 7) || ((uintptr_t)d->mul_src & 15))) return HV_ERR_UNSUPPORTED;
     if ((long long)d->B * d->Ho * d->Wo * d->y_ld >= (1ll << 31)) return HV_ERR_UNSUPPORTED;
     ThinK k;
+    HV_WUSE(1 | 2);
     k.g = reinterpret_cast<const _Float16*>(d->x); k.w = d->w; k.y = d->y; k.mul = reinterpret_cast<const _Float16*>(d->mul_src);
     k.B = d->B; k.H = d->Ho; k.W = d->Wo; k.g_ld = d->x_ld; k.g_coff = d->x_coff; k.Cin = d->Cin; k.Cout = d->Cout; k.w_row = 16 * d->Cin;
     k.y_ld = d->y_ld; k.y_coff = d->y_coff; k.mul_ld = d->mul_ld; k.mul_coff = d->mul_coff; k.mul_act = d->mul_act; k.accumulate = d->accumulate; k.pad = d->pad;
@@ -218,6 +219,7 @@ int hv_conv2d_thin_dgrad(const hv_conv_desc* d, hipStream_t s) {
     const long long npix = (long long)d->B * d->H * d->W;
     if (npix * d->x_ld >= (1ll << 30) || npix >= (1ll << 31) - 256) return HV_ERR_UNSUPPORTED;
     ThinK k;
+    HV_WUSE(1 | 2);
     k.g = reinterpret_cast<const _Float16*>(d->x); k.w = d->w; k.y = d->y; k.mul = reinterpret_cast<const _Float16*>(d->mul_src);
     k.B = d->B; k.H = d->H; k.W = d->W; k.g_ld = d->x_ld; k.g_coff = d->x_coff; k.Cin = d->Cin; k.Cout = d->Cout; k.w_row = 9 * d->Cin;
     k.y_ld = d->y_ld; k.y_coff = d->y_coff; k.mul_ld = d->mul_ld; k.mul_coff = d->mul_coff; k.mul_act = d->mul_act; k.accumulate = d->accumulate; k.pad = d->pad;

@@ -16,6 +16,10 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
     } while (0)
 
 extern thread_local int hv_path_note;   // set by the launcher that actually launched (hv_last_kernel_path)
+// which prepared weight tables the convolution launched last read (hv_last_weight_tables): 1 = fp32 (hv_conv_desc.w; also w1), 2 = fp16 plain rows (w_f16),
+// 4 = fp16 in MFMA-fragment order (w_f16_tiled).  A launcher may over-report, never under-report: the layout pass skips what no conv of a layer reads
+extern thread_local int hv_wtable_used;
+#define HV_WUSE(bits) (hv_wtable_used |= (bits))
 extern thread_local int hv_probe_only;  // hv_conv2d_supported: the dispatch runs without launching (the launch sites of the forms it asks about return HV_OK early)
 // name of the kernel instantiation the last launcher launched, as rocprofv3 lists it (hv_last_kernel_name)
 extern thread_local char hv_kname[192];

@@ -206,7 +206,7 @@ extern "C" int hv_weight_prep(const hv_wprep_layer* d_layers, int n_layers, long
 // 128-byte (fp32) / 64-byte (fp16) runs and a 16 x 32 MFMA fragment of either ordered table as 64 sixteen-byte pieces = 1 KB contiguous.
 // conv_transpose sources (no contiguous source rows) are left to the kernels above (hv_weight_prep2's any_legacy).
 #define WL_T 32
-__global__ __launch_bounds__(256) void weight_layout_fused_kernel(const hv_wprep_layer* __restrict__ layers, int diag_lean) {
+__global__ __launch_bounds__(256) void weight_layout_fused_kernel(const hv_wprep_layer* __restrict__ layers) {
     const hv_wprep_layer L = layers[blockIdx.y];
     if (L.transposed_src) return;
     // a work item = (32 filters x 32 input channels) x a group of up to 4 taps: the largest PatchGAN layer is 128 tiles, with the taps split it is 512 items
@@ -214,10 +214,13 @@ __global__ __launch_bounds__(256) void weight_layout_fused_kernel(const hv_wprep
     constexpr int TG = 4, LDT = TG + 1, RS = WL_T * LDT + 1;
     __shared__ float wl_sh[WL_T * RS];                                         // [32 filters][32 channels x 5 + 1]
     const int taps = L.taps, ntg = (taps + TG - 1) / TG;
-    const int rows_f = L.CoutF, rows_b = L.w_bwd ? L.CinB : 0;
-    const int nco = (max(L.CoutF, L.w_bwd ? L.CoutP : 0) + WL_T - 1) / WL_T, nci = (max(L.CinP, rows_b) + WL_T - 1) / WL_T;
+    // every table is optional on its own (round 4): a caller that knows which tables the layer's convolutions read (hv_last_weight_tables) passes NULL for
+    // the others -- in the fp16 mode the big layers read the fragment-ordered tables only, 4 of the 20 bytes per weight this pass used to write
+    const bool has_b = L.w_bwd || L.w_bwd_h || L.w_bwd_t;
+    const int rows_f = L.CoutF, rows_b = has_b ? L.CinB : 0;
+    const int nco = (max(L.CoutF, has_b ? L.CoutP : 0) + WL_T - 1) / WL_T, nci = (max(L.CinP, rows_b) + WL_T - 1) / WL_T;
     const float sigma = L.sigma[0];
-    const int Tf = L.w_fwd_t ? tile_width(L.CinP) : 0, Tb = (L.w_bwd && L.w_bwd_t) ? tile_width(L.CoutP) : 0;
+    const int Tf = L.w_fwd_t ? tile_width(L.CinP) : 0, Tb = L.w_bwd_t ? tile_width(L.CoutP) : 0;
     const int tid = threadIdx.x, lane = tid & 31, sub = tid >> 5;
     for (int w = blockIdx.x; w < nco * nci * ntg; w += gridDim.x) {
         const int tg = w % ntg, tile = w / ntg;
@@ -249,10 +252,8 @@ __global__ __launch_bounds__(256) void weight_layout_fused_kernel(const hv_wprep
                 for (int t = 0; t < tn; ++t) {
                     const float val = wl_sh[r * RS + lane * LDT + t];
                     const long long i = ((long long)co * taps + t0 + t) * L.CinP + ci;
-                    if (!(diag_lean && Tf == 32)) {
-                    L.w_fwd[i] = val;
+                    if (L.w_fwd) L.w_fwd[i] = val;
                     if (L.w_fwd_h) reinterpret_cast<_Float16*>(L.w_fwd_h)[i] = (_Float16)val;
-                    }
                     if (Tf == 16) reinterpret_cast<_Float16*>(L.w_fwd_t)[tiled_index(co, t0 + t, ci, taps, L.CinP, 16)] = (_Float16)val;
                 }
             }
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(256) void weight_layout_fused_kernel(const hv_wprep
             }
         }
         // ---- data-gradient tables [ci][tap][co]: a run of 32 filters per (ci, tap)
-        if (L.w_bwd) {
+        if (has_b) {
             const int co = co0 + lane;
             for (int cil = sub; cil < WL_T; cil += 8) {
                 const int ci = ci0 + cil;
@@ -293,10 +294,8 @@ __global__ __launch_bounds__(256) void weight_layout_fused_kernel(const hv_wprep
                 for (int t = 0; t < tn; ++t) {
                     const float val = in ? wl_sh[lane * RS + cil * LDT + t] : 0.f;
                     const long long i = ((long long)ci * taps + t0 + t) * L.CoutP + co;
-                    if (!(diag_lean && Tb == 32)) {
-                    L.w_bwd[i] = val;
+                    if (L.w_bwd) L.w_bwd[i] = val;
                     if (L.w_bwd_h) reinterpret_cast<_Float16*>(L.w_bwd_h)[i] = (_Float16)val;
-                    }
                     if (Tb == 16) reinterpret_cast<_Float16*>(L.w_bwd_t)[tiled_index(ci, t0 + t, co, taps, L.CoutP, 16)] = (_Float16)val;
                 }
             }
@@ -330,8 +329,7 @@ extern "C" int hv_weight_prep2(const hv_wprep_layer* d_layers, int n_layers, lon
     // one item = 32 x 32 x 4 elements of a table: about one workgroup per item of the largest layer, grid-stride for the rest
     int gx = (int)hv_cdiv(max_numel, 2 * 1024 * 4);
     gx = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
-    static const int diag_lean = getenv("HV_DIAG_LEAN_TABLES") ? atoi(getenv("HV_DIAG_LEAN_TABLES")) : 0;      // timing-only experiment: fragment-ordered tables only
-    hipLaunchKernelGGL(weight_layout_fused_kernel, dim3(gx, n_layers), dim3(256), 0, (hipStream_t)stream, d_layers, diag_lean);
+    hipLaunchKernelGGL(weight_layout_fused_kernel, dim3(gx, n_layers), dim3(256), 0, (hipStream_t)stream, d_layers);
     HV_LAUNCH_CHECK();
     if (any_legacy) {
         const int gl = hv_cdiv(max_numel, 2048) < 1 ? 1 : hv_cdiv(max_numel, 2048);

@@ -42,6 +42,9 @@ class ConvParams:
         self.transposed_src = transposed_src
         self.w_fwd = self.w_bwd = self.sigma = self.dw = None
         self.w_fwd_t = self.w_bwd_t = None      # fp16 tables in MFMA-fragment order (None: the shape has no tiled form)
+        # which prepared tables the layer's forward / data-gradient convolutions have read so far (hv_last_weight_tables bits: 1 fp32, 2 fp16 rows, 4 fp16
+        # fragment order; 0 = not seen yet): ParamSet.prep writes only those inside a lean_tables() context
+        self.use_fwd = self.use_bwd = 0
         self.split_k = None                     # K2: also keep the first K2 input channels as a fragment-ordered table of their own (w_fwd_t2: conv2d's x1 layers)
         self.w_fwd_t2 = None
 
@@ -59,6 +62,7 @@ class ParamSet:
         self.device = None
         self.t_prep = {True: ops.LayerTable('hv_wprep_layer'), False: ops.LayerTable('hv_wprep_layer')}
         self.t_bwd = {True: ops.LayerTable('hv_wprep_bwd_layer'), False: ops.LayerTable('hv_wprep_bwd_layer')}
+        self.t_lean = {True: ops.LayerTable('hv_wprep_layer'), False: ops.LayerTable('hv_wprep_layer')}
         self.flat_grad = None
         self._key = None
 
@@ -126,13 +130,7 @@ class ParamSet:
             p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
             off += p.numel()
         for pi in (True, False):
-            rows = []
-            for c in self.convs:
-                rows.append(dict(w_orig=c.weight.data, u=c.u if c.sn else None, v=c.v if c.sn else None, sigma=c.sigma,
-                                 w_fwd=c.w_fwd, w_bwd=c.w_bwd, w_fwd_h=c.w_fwd_h, w_bwd_h=c.w_bwd_h, w_fwd_t=c.w_fwd_t, w_bwd_t=c.w_bwd_t, Cout=c.cout, Cin=c.cin, taps=c.taps, CinP=c.cin_fwd,
-                                 CoutF=c.cout, CoutP=c.coutP, CinB=c.cin_fwd, sn=int(c.sn), power_iter=int(pi and c.sn),
-                                 transposed_src=int(c.transposed_src), w_fwd_t2=c.w_fwd_t2, K2=int(c.split_k or 0)))
-            self.t_prep[pi].update(rows, key, device)
+            self.t_prep[pi].update(self._prep_rows(pi, False), key, device)
         for acc in (True, False):
             rows = []
             for c in self.convs:
@@ -151,9 +149,34 @@ class ParamSet:
                 p.grad = self.flat_grad[off:off + n].view_as(p)
             off += n
 
+    def _prep_rows(self, pi, lean):
+        rows = []
+        for c in self.convs:
+            # lean: only the tables the layer's convolutions have been seen to read (0 = not seen yet: all of them); conv_transpose sources keep all (their
+            # layout kernels write every table), spectral-norm layers keep the fp32 forward table (hv_weight_prep_backward reads it)
+            mf = mb = 7
+            if lean and not c.transposed_src:
+                mf = (c.use_fwd or 7) | (1 if c.sn else 0)
+                mb = c.use_bwd or 7
+            rows.append(dict(w_orig=c.weight.data, u=c.u if c.sn else None, v=c.v if c.sn else None, sigma=c.sigma,
+                             w_fwd=c.w_fwd if mf & 1 else None, w_bwd=c.w_bwd if mb & 1 else None, w_fwd_h=c.w_fwd_h if mf & 2 else None,
+                             w_bwd_h=c.w_bwd_h if mb & 2 else None, w_fwd_t=c.w_fwd_t if mf & 4 else None, w_bwd_t=c.w_bwd_t if mb & 4 else None,
+                             Cout=c.cout, Cin=c.cin, taps=c.taps, CinP=c.cin_fwd, CoutF=c.cout, CoutP=c.coutP, CinB=c.cin_fwd, sn=int(c.sn),
+                             power_iter=int(pi and c.sn), transposed_src=int(c.transposed_src), w_fwd_t2=c.w_fwd_t2, K2=int(c.split_k or 0)))
+        return rows
+
     def prep(self, device, power_iter):
         self._ensure(device)
-        ops.weight_prep(self.t_prep[bool(power_iter)], max(c.sizes()[0] + c.sizes()[1] for c in self.convs), any_sn=any(c.sn for c in self.convs),
+        pi = bool(power_iter)
+        table = self.t_prep[pi]
+        if LEAN and LEAN_TABLES and ops.precision_id(None) == ops.F16:
+            # inside the train step, after the step has been seen once for this batch shape: the layout pass skips the tables no kernel of the layer reads
+            # (fp16 mode: the big layers read the fragment-ordered tables only -- 4 of 20 bytes per weight)
+            key = (self._key, tuple((c.use_fwd, c.use_bwd) for c in self.convs))
+            table = self.t_lean[pi]
+            if table.key != key:
+                table.update(self._prep_rows(pi, True), key, device)
+        ops.weight_prep(table, max(c.sizes()[0] + c.sizes()[1] for c in self.convs), any_sn=any(c.sn for c in self.convs),
                         any_legacy=any(c.transposed_src for c in self.convs))
 
     def finish_backward(self, accumulate=False):
@@ -201,11 +224,11 @@ class ConvNode:
             low, x1 = self.split
             ops.conv2d(low, p.w_fwd, self.y, self.k, self.s, self.pad, self.d, bias=p.bias if self.use_bias else None, act=self.act, w_h=p.w_fwd_h,
                        w_t=p.w_fwd_t2, in_shift=1, precision=prec, cin=p.split_k, cout=p.cout,
-                       x1=(x1, p.w_fwd, p.split_k, p.taps * p.cin_fwd, p.cin_fwd))
+                       x1=(x1, p.w_fwd, p.split_k, p.taps * p.cin_fwd, p.cin_fwd), wuse=(p, 'use_fwd'))
             return
         xin = Act(self.x.t, p.cin_fwd, self.x.coff)
         ops.conv2d(xin, p.w_fwd, self.y, self.k, self.s, self.pad, self.d, bias=p.bias if self.use_bias else None, act=self.act, w_h=p.w_fwd_h, w_t=p.w_fwd_t,
-                   in_shift=self.shift, transposed=self.transposed, precision=prec, cout=p.cout, stats=stats)
+                   in_shift=self.shift, transposed=self.transposed, precision=prec, cout=p.cout, stats=stats, wuse=(p, 'use_fwd'))
 
     def stats_parts(self, prec):
         """Partial-sum rows this node's forward kernel writes when handed a statistics buffer (0: that kernel has no such epilogue)."""
@@ -233,6 +256,23 @@ def named_stream(name, device, priority=0):
     if st is None:
         st = _named_streams[key] = torch.cuda.Stream(device=dev, priority=priority)
     return st
+
+
+LEAN_TABLES = os.environ.get('HV_LEAN_TABLES', '1') != '0' and os.environ.get('HV_WPREP_FUSED', '1') != '0'   # A/B knob: see ParamSet.prep
+LEAN = False              # set by lean_tables(): the caller vouches that every convolution of its networks has run once for the current shapes
+
+
+@contextlib.contextmanager
+def lean_tables(on=True):
+    """Inside: ParamSet.prep writes only the weight tables the layers' convolutions have been seen to read (ConvParams.use_fwd / use_bwd).  For
+    the train step after its first eager step for a batch shape: the same kernels are dispatched again (dispatch is a function of the shapes),
+    so the unread tables may go stale.  Outside (eval forwards, the nn.Module API, another shape's first step) every table is written."""
+    global LEAN
+    prev, LEAN = LEAN, bool(on)
+    try:
+        yield
+    finally:
+        LEAN = prev
 
 
 SPLIT_CONCAT = os.environ.get('HV_SPLIT_CONCAT', '1') != '0'   # [up-sampled | 1 channel] concat layers read the small tensor + the channel (A/B knob)
@@ -324,7 +364,7 @@ def conv_backward(node, book, prec, dbias_accumulate=False, wgrad_accumulate=Fal
     if node.need_dx and node.transposed:
         gx = book.twin(node.x)
         gx = Act(gx.t, p.cin_fwd, gx.coff)
-        ops.conv2d(gfull, p.w_bwd, gx, node.k, node.s, node.pad, node.d, transposed=False, accumulate=int(book.mark(gx)), precision=prec, w_h=p.w_bwd_h, w_t=p.w_bwd_t)
+        ops.conv2d(gfull, p.w_bwd, gx, node.k, node.s, node.pad, node.d, transposed=False, accumulate=int(book.mark(gx)), precision=prec, w_h=p.w_bwd_h, w_t=p.w_bwd_t, wuse=(p, 'use_bwd'))
     elif node.need_dx:
         gx = book.twin(node.x)
         gx = Act(gx.t, node.dx_c or p.cin_fwd, gx.coff)
@@ -335,20 +375,20 @@ def conv_backward(node, book, prec, dbias_accumulate=False, wgrad_accumulate=Fal
             gl = book.twin(low)
             gl = Act(gl.t, node.dx_c or low.C, gl.coff)
             ops.conv2d(gfull, p.w_bwd, gl, node.k, node.s, node.pad, node.d, transposed=True, pool2=True, accumulate=int(book.mark(gl)), precision=prec,
-                       w_h=p.w_bwd_h, w_t=p.w_bwd_t, mul=(Act(low.t, gl.C, low.coff), low_act) if low_act != 'none' else None)
+                       w_h=p.w_bwd_h, w_t=p.w_bwd_t, mul=(Act(low.t, gl.C, low.coff), low_act) if low_act != 'none' else None, wuse=(p, 'use_bwd'))
         elif node.shift and _pool2_node_ok(node, gfull, gx, prec):
             # fused up-sampling in the forward: the data gradient leaves 2x2 sum-pooled from the conv's own epilogue (no full-resolution gradient in
             # memory, no hv_copy_channels mode 3 pass), times act'(node.x) when the chain asks for it
             ops.conv2d(gfull, p.w_bwd, gx, node.k, node.s, node.pad, node.d, transposed=True, pool2=True, accumulate=int(book.mark(gx)), precision=prec,
-                       w_h=p.w_bwd_h, w_t=p.w_bwd_t, mul=(Act(node.x.t, p.cin_fwd, node.x.coff), mul_x) if mul_x else None)
+                       w_h=p.w_bwd_h, w_t=p.w_bwd_t, mul=(Act(node.x.t, p.cin_fwd, node.x.coff), mul_x) if mul_x else None, wuse=(p, 'use_bwd'))
         elif node.shift:
             assert not mul_x
             full = tmp_full() if callable(tmp_full) else tmp_full      # (the full-resolution buffer is only built where this fallback runs)
-            ops.conv2d(gfull, p.w_bwd, full, node.k, node.s, node.pad, node.d, transposed=True, precision=prec, w_h=p.w_bwd_h, w_t=p.w_bwd_t)
+            ops.conv2d(gfull, p.w_bwd, full, node.k, node.s, node.pad, node.d, transposed=True, precision=prec, w_h=p.w_bwd_h, w_t=p.w_bwd_t, wuse=(p, 'use_bwd'))
             ops.copy_channels(full, gx, mode=3, accumulate=book.mark(gx))
         else:
             ops.conv2d(gfull, p.w_bwd, gx, node.k, node.s, node.pad, node.d, transposed=True, accumulate=int(book.mark(gx)), w_h=p.w_bwd_h, w_t=p.w_bwd_t,
-                       precision=prec, mul=(Act(node.x.t, p.cin_fwd, node.x.coff), mul_x) if mul_x else None)
+                       precision=prec, mul=(Act(node.x.t, p.cin_fwd, node.x.coff), mul_x) if mul_x else None, wuse=(p, 'use_bwd'))
 
 
 BRANCHES = os.environ.get('HV_G_BRANCHES', '1') != '0'   # independent generator branches on two HIP streams / graph branches

@@ -503,6 +503,12 @@ class Pix2PixModel(BaseModel):
         kernels of the backward passes.  In a multi-GPU job (one process per GPU) the four networks' flat gradients are
         averaged over the ranks inside the same step -- see `dp_schedule` in __init__; HV_GRAPH=0 or an active kernel
         timer keeps the eager path."""
+        # after the first eager step for this batch shape every convolution of the four networks has been dispatched once: from then on the weight
+        # layout passes write only the tables those kernels read (engine.lean_tables)
+        with engine.lean_tables(self._eager_steps >= 1):
+            return self._optimize_parameters()
+
+    def _optimize_parameters(self):
         for o in self.optimizers:
             o.sync_lr()
         graphable = self.use_graph and ops.timer() is None

@@ -162,7 +162,7 @@ def conv_out_size(n, k, stride, pad, dil):
 
 def conv2d(x, w, y, k, stride=1, pad=0, dil=1, bias=None, act='none', transposed=False, in_shift=0, alpha=1.0,
            accumulate=0, ch_scale=None, w_bstride=0, ch_scale_bstride=0, precision=None, cin=None, cout=None, w_h=None, mul=None, w_t=None,
-           stats=None, _parts_only=False, pool2=False, x1=None, _supported_only=False):
+           stats=None, _parts_only=False, pool2=False, x1=None, _supported_only=False, wuse=None):
     """y = act(alpha*ch_scale*conv(x, w) + bias)  [* act'(m) with mul = (Act m, activation name): see hv_conv_desc.mul_src].  x,y: Act; w: prepared [CoutF][k*k][CinP] tensor (or [B][...] with
     w_bstride).  cin/cout default to the view widths (x.C consumed, y.C produced).
     stats: float tensor of conv2d_stats_parts(...) * Cout * 2 elements that receives the per-channel partial sums of the stored output
@@ -217,8 +217,10 @@ def conv2d(x, w, y, k, stride=1, pad=0, dil=1, bias=None, act='none', transposed
             ((2 if mul[0].f16 else 4) * y.B * y.H * y.W * d.Cout if mul is not None else 0)
         _TIMER.wrap(('conv', x.B, d.H, d.W, d.Cin, d.Cout, kh, stride, dil, int(transposed)), flops,
                     lambda: L.call('hv_conv2d', ctypes.byref(d), stream()), nbytes)
-        return y
-    L.call('hv_conv2d', ctypes.byref(d), stream())
+    else:
+        L.call('hv_conv2d', ctypes.byref(d), stream())
+    if wuse is not None:      # (owner, attribute): which of the layer's prepared tables this call's kernel read (engine.ParamSet skips the others when it may)
+        setattr(wuse[0], wuse[1], getattr(wuse[0], wuse[1]) | int(L.cdll.hv_last_weight_tables()))
     return y
 
 

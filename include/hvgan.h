@@ -116,6 +116,9 @@ typedef struct {
 int hv_conv2d(const hv_conv_desc* d, void* stream);
 size_t hv_conv2d_workspace_bytes(const hv_conv_desc* d);   /* 0 when no kernel for this shape wants scratch */
 size_t hv_conv2d_stats_parts(const hv_conv_desc* d);       /* parts of hv_conv_desc.stats this call would write (0: its kernel has no statistics epilogue) */
+int hv_last_weight_tables(void);                           /* which prepared tables the hv_conv2d call this thread made last read: 1 = fp32 (w, w1), 2 = fp16 rows
+                                                              (w_f16), 4 = fp16 in MFMA-fragment order (w_f16_tiled); may over-report.  A caller that collects
+                                                              this per layer can pass NULL for the unread tables of hv_wprep_layer (hv_weight_prep2) */
 int hv_conv2d_supported(const hv_conv_desc* d);            /* 1 when hv_conv2d would serve d.  Only the forms without a generic fallback can be refused for their
                                                               shape -- x1, pool2, stats (hv_conv2d then returns HV_ERR_UNSUPPORTED and launches nothing) -- so a caller
                                                               asks before it drops the materialised alternative.  Runs the dispatch itself without launching */
@@ -146,7 +149,7 @@ typedef struct {
     const float* w_orig;  /* [Cout][Cin][KH][KW] (torch layout); for conv_transpose [Cin][Cout][KH][KW] with transposed_src=1 */
     float* u; float* v;   /* [Cout], [Cin*KH*KW]; NULL when sn=0 */
     float* sigma;         /* [4] scratch: [0] = sigma out (1.0 when sn=0), [1] = <dWsn,Wsn> written by the backward */
-    float* w_fwd;         /* [CoutF][taps][CinP]  rows >= Cout and channels >= Cin are zero */
+    float* w_fwd;         /* [CoutF][taps][CinP]  rows >= Cout and channels >= Cin are zero; NULL = not wanted (hv_weight_prep2 only: every table is optional there) */
     float* w_bwd;         /* [CinB][taps][CoutP]  or NULL */
     void* w_fwd_h; void* w_bwd_h;   /* optional fp16 copies of w_fwd / w_bwd (same layouts) or NULL */
     void* w_fwd_t; void* w_bwd_t;   /* optional fp16 copies in MFMA-fragment order (hv_conv_desc.w_f16_tiled; layout at hv_weight_tile_f16) or NULL;
