@@ -22,6 +22,10 @@
 struct G4K {
     const void* x; const _Float16* w; const float* bias; void* y; const void* mul_src;
     float* stats;                              // [tiles_total][Cstat][2] partial sums (or NULL)
+    // data-gradient forms: the sums of the batch normalisation whose output gradient this launch writes (hv_conv_desc.bstats) -- bn_x its raw input (fp16, same
+    // pixels / channels as y), bn_stats its [groups][2][Cout] mean / rstd, bn_ipg images per group; bstats[(part * Cout + c) * 2 + {sum g, sum g * xhat}]
+    const void* bn_x; const float* bn_stats; float* bstats;
+    int bn_x_ld, bn_x_coff, bn_ipg;
     int B, H, W, x_ld, x_coff, Cin;            // operand tensor (forward: x, data gradient: g) and its channel count (the GEMM's K source)
     int Ho, Wo, y_ld, y_coff, Cout;
     int mul_ld, mul_coff, mul_act, act, accumulate;
@@ -174,6 +178,62 @@ __device__ __forceinline__ void g4_epilogue(const G4K& p, f32x4 (&acc)[4][MT], c
 #pragma unroll
     for (int k = 0; k < OITEMS; ++k)
         if (ooff[k] >= 0) *reinterpret_cast<u32x4*>(yb + ooff[k]) = o[k];
+    if (p.bstats) {
+        // Batch-norm backward sums of this tile (the reduction pass norm_reduce_kernel<1> re-read dy and x for): per channel sum g and sum g * xhat, g = the value
+        // just stored, xhat = (x - mean) * rstd of the normalisation's raw input at the same pixel.  A thread's OITEMS pieces share one 8-channel piece
+        // (it & 15): its x pieces are requested now (the multiplier / old-gradient registers are dead), folded like the forward statistics above.
+        const int pc = tid & 15, s = pc >> 3;
+        const int ch0 = cob_s[s] + (pc & 7) * 8;
+        const int grp = n_img / p.bn_ipg;
+        const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.bn_x), 0, 0x7ffffff0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ssrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bn_stats), 0, 0x7ffffff0u, 0x00020000);
+        u32x4 xreg[OITEMS];
+#pragma unroll
+        for (int k = 0; k < OITEMS; ++k) {
+            // the x piece of output piece k: same pixel and channels, the normalisation input's own strides
+            const int q = (tid + k * NTHR) >> 4;
+            int ho = i0 + (q >> 4), wo = j0 + (q & 15);
+            if (MODE == 1) { ho = 2 * ho + (cls_s[s] >> 1); wo = 2 * wo + (cls_s[s] & 1); }
+            const long long opix = (long long)(n_img * p.Ho + ho) * p.Wo + wo;
+            xreg[k] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, ooff[k] >= 0 ? (unsigned)((opix * p.bn_x_ld + p.bn_x_coff + ch0) * 2) : HV_OOB, 0, 0);
+        }
+        f32x4 mr[4];      // mean[8], rstd[8] of this thread's channels in the image's group
+        const unsigned sb = (unsigned)((grp * 2 * p.Cout + ch0) * 4);
+        const bool chok = ch0 < p.Cout;
+        mr[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ssrc, chok ? sb : HV_OOB, 0, 0));
+        mr[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ssrc, chok ? sb + 16u : HV_OOB, 0, 0));
+        mr[2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ssrc, chok ? sb + (unsigned)p.Cout * 4u : HV_OOB, 0, 0));
+        mr[3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ssrc, chok ? sb + (unsigned)p.Cout * 4u + 16u : HV_OOB, 0, 0));
+        float s1[8], s2[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+#pragma unroll
+        for (int k = 0; k < OITEMS; ++k) {
+            if (ooff[k] < 0) continue;
+            const f16x8 v8 = __builtin_bit_cast(f16x8, o[k]), x8 = __builtin_bit_cast(f16x8, xreg[k]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float g = (float)v8[e], xh = ((float)x8[e] - mr[e >> 2][e & 3]) * mr[2 + (e >> 2)][e & 3];
+                s1[e] += g; s2[e] += g * xh;
+            }
+        }
+        __syncthreads();                       // the staging tile has been read into registers by every thread
+        float* red = reinterpret_cast<float*>(smem);       // [32 rows][16 pieces][16]
+        float* mine = red + ((tid >> 4) * 16 + (tid & 15)) * 16;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { mine[e] = s1[e]; mine[8 + e] = s2[e]; }
+        __syncthreads();
+        if (tid < 256) {      // 128 columns (two 64-channel slots) x {sum g, sum g * xhat}
+            const int pq = tid >> 4, e = tid & 15;
+            float sum = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < 32; ++r) sum += red[(r * 16 + pq) * 16 + e];
+            const int sl = pq >> 3, ch = cob_s[sl] + (pq & 7) * 8 + (e & 7);
+            // MODE 1: the four output-parity classes of a tile are four parts (two per workgroup of the class pair); else one part per workgroup
+            const long long part = MODE == 1 ? (long long)blockIdx.x * 4 + cls_s[sl] : (long long)blockIdx.x;
+            if (ch < p.Cout) p.bstats[(part * p.Cout + ch) * 2 + (e >> 3)] = sum;
+        }
+    }
 }
 
 template <int MODE, int MT>
@@ -571,6 +631,7 @@ static int g4_tile_rows(int B, int Hc, int Wc, int ny) {
 
 // The ONE eligibility predicate of the pipelined 4x4 kernels: 4x4, stride 2 or 1, pad 1, dilation 1, fp16 NHWC views with 16-byte aligned channel rows,
 // fragment-ordered filters.  hv_conv2d_g4 launches exactly when it holds, and hv_conv2d_g4_stats_floats promises a statistics epilogue only then.
+size_t hv_conv2d_g4_bstats_parts(const hv_conv_desc* d);
 static bool g4_eligible(const hv_conv_desc* d) {
     static const int on = getenv("HV_CONV_G4") ? atoi(getenv("HV_CONV_G4")) : 3;      // bit 0: forward, bit 1: data gradient
     if (!(on & (d->transposed ? 2 : 1))) return false;
@@ -597,6 +658,12 @@ int hv_conv2d_g4(const hv_conv_desc* d, hipStream_t s) {
     k.dbg = getenv("HV_G4_DBG") ? atoi(getenv("HV_G4_DBG")) : 0;
     k.x = d->x; k.w = reinterpret_cast<const _Float16*>(d->w_f16_tiled); k.bias = d->bias; k.y = d->y; k.mul_src = d->mul_src;
     k.stats = d->transposed ? nullptr : d->stats;
+    k.bn_x = nullptr; k.bn_stats = nullptr; k.bstats = nullptr; k.bn_x_ld = k.bn_x_coff = 0; k.bn_ipg = 1;
+    if (d->bstats) {
+        if (!hv_conv2d_g4_bstats_parts(d)) return HV_ERR_UNSUPPORTED;
+        k.bn_x = d->bn_x; k.bn_stats = d->bn_stats; k.bstats = d->bstats; k.bn_x_ld = d->bn_x_ld; k.bn_x_coff = d->bn_x_coff;
+        k.bn_ipg = d->B / (d->bn_groups > 0 ? d->bn_groups : 1);
+    }
     k.B = d->B; k.H = d->H; k.W = d->W; k.x_ld = d->x_ld; k.x_coff = d->x_coff; k.Cin = d->Cin;
     k.Ho = d->Ho; k.Wo = d->Wo; k.y_ld = d->y_ld; k.y_coff = d->y_coff; k.Cout = d->Cout;
     k.mul_ld = d->mul_ld; k.mul_coff = d->mul_coff; k.mul_act = d->mul_act; k.act = d->act; k.accumulate = d->accumulate; k.alpha = d->alpha;
@@ -618,6 +685,22 @@ int hv_conv2d_g4(const hv_conv_desc* d, hipStream_t s) {
     k.Hc = d->H; k.Wc = d->W;
     const int ny = 2 * (d->Cout / 64);
     return g4_tile_rows(d->B, k.Hc, k.Wc, ny) == 16 ? launch_g4<1, 4>(k, ny, s) : launch_g4<1, 2>(k, ny, s);
+}
+
+// parts of the batch-norm backward sums (hv_conv_desc.bstats) the data-gradient launches of hv_conv2d_g4 write: one per workgroup along x (stride 1) or four
+// (the output-parity classes, stride 2); 0 = no such epilogue for this descriptor
+size_t hv_conv2d_g4_bstats_parts(const hv_conv_desc* d) {
+    if (!d->transposed || d->accumulate || !g4_eligible(d)) return 0;
+    if (!d->bn_x || !d->bn_stats || !d->mul_src || (d->bn_x_ld & 7) || (d->bn_x_coff & 7) || ((uintptr_t)d->bn_x & 15) || ((uintptr_t)d->bn_stats & 15) || (d->Cout & 7)) return 0;
+    const int G = d->bn_groups > 0 ? d->bn_groups : 1;
+    if (d->B % G) return 0;
+    if ((long long)d->B * d->Ho * d->Wo * d->bn_x_ld >= (1ll << 30)) return 0;
+    if (d->stride == 1) {
+        const int th = g4_tile_rows(d->B, d->Ho, d->Wo, d->Cout / 128);
+        return (size_t)d->B * hv_cdiv(d->Ho, th) * hv_cdiv(d->Wo, 16);
+    }
+    const int th = g4_tile_rows(d->B, d->H, d->W, 2 * (d->Cout / 64));
+    return (size_t)d->B * hv_cdiv(d->H, th) * hv_cdiv(d->W, 16) * 4;
 }
 
 // floats of the statistics partials hv_conv2d writes for this descriptor when d->stats is set: [workgroups along x][Cout][2]; 0 = this shape's

@@ -38,6 +38,8 @@ int hv_conv2d_g4(const hv_conv_desc* d, hipStream_t s);                        /
 int hv_conv2d_thin_dgrad(const hv_conv_desc* d, hipStream_t s);                // conv_thin.hip
 int hv_conv2d_logits_dgrad(const hv_conv_desc* d, hipStream_t s);
 size_t hv_conv2d_g4_stats_floats(const hv_conv_desc* d, int* nparts);
+size_t hv_conv2d_g4_bstats_parts(const hv_conv_desc* d);
+size_t hv_conv2d_logits_bstats_parts(const hv_conv_desc* d);                   // conv_thin.hip
 size_t hv_wgrad_halo_workspace_bytes(const hv_wgrad_desc* d);                  // wgrad_halo.hip
 int hv_wgrad_halo(const hv_wgrad_desc* d, int* nslabs, hipStream_t s);
 size_t hv_wgrad_tr_workspace_bytes(const hv_wgrad_desc* d);                    // wgrad_tr.hip
@@ -370,6 +372,13 @@ static int dispatch_conv(ConvK& k, hipStream_t s) {
     return launch_conv<T, 64, 64, 2, 2, ASC>(k, mt, s);
 }
 
+// parts of hv_conv_desc.bstats: the kernels with that epilogue are the PatchGAN data gradients (logits layer, 4x4 stride 1 and stride 2)
+extern "C" size_t hv_conv2d_bstats_parts(const hv_conv_desc* d) {
+    if (!d || !d->transposed || d->precision != HV_F16) return 0;
+    if (d->Cin == 4 && d->KH == 4 && d->stride == 1) return hv_conv2d_logits_bstats_parts(d);
+    return hv_conv2d_g4_bstats_parts(d);
+}
+
 static int conv2d_dispatch(const hv_conv_desc* d, void* stream) {
     hv_wtable_used = 0;
     if (!d || !d->x || !d->w || !d->y) return HV_ERR_ARG;
@@ -390,6 +399,7 @@ static int conv2d_dispatch(const hv_conv_desc* d, void* stream) {
     // statistics epilogue asked for: only a kernel that has one may run (a silent fallback would leave the caller's partial sums unwritten and its
     // normalisation reading zeros) -- callers size `stats` with hv_conv2d_stats_parts, which is 0 exactly when this refuses
     if (d->stats && !hv_conv2d_g4_stats_floats(d, nullptr)) return HV_ERR_UNSUPPORTED;
+    if (d->bstats && !hv_conv2d_bstats_parts(d)) return HV_ERR_UNSUPPORTED;      // (the same for the batch-norm backward sums of a data gradient)
     if (d->x1) {         // extra input channel: the filters-in-LDS kernel or nothing (the caller keeps the materialised concat)
         if (d->precision != HV_F16 || !d->w_f16 || !d->w_f16_tiled || !d->y_f16 || d->transposed || d->dil != 1 || d->stride != 1 || d->KH != 3 || d->KW != 3 || !d->w1 ||
             d->pool2 || d->stats || d->x1_ld < 1)
@@ -514,6 +524,7 @@ static int conv2d_dispatch(const hv_conv_desc* d, void* stream) {
 thread_local int hv_probe_only = 0;
 extern "C" int hv_conv2d_supported(const hv_conv_desc* d) {
     if (!d) return 0;
+    if (d->bstats && !hv_conv2d_bstats_parts(d)) return 0;
     if (!d->x1 && !d->pool2) return d->stats ? (hv_conv2d_g4_stats_floats(d, nullptr) ? 1 : 0) : 1;
     hv_probe_only = 1;
     const int rc = conv2d_dispatch(d, nullptr);

@@ -13,6 +13,9 @@ struct ThinK {
     int y_ld, y_coff, mul_ld, mul_coff, mul_act, accumulate, pad;
     float alpha;
     unsigned g_bytes;
+    // logits_dgrad_kernel only: the batch-norm backward sums of the layer whose output gradient it writes (hv_conv_desc.bstats; at most two groups)
+    const _Float16* bn_x; const float* bn_stats; float* bstats;
+    int bn_x_ld, bn_x_coff, bn_ipg, bn_groups;
 };
 
 template <int CO>        // output channels per lane: 8, 12 or 16
@@ -99,6 +102,22 @@ __global__ __launch_bounds__(256) void logits_dgrad_kernel(const ThinK p, const 
         }
     }
     __syncthreads();
+    // batch-norm backward sums (hv_conv_desc.bstats): a lane's pieces always carry the same 8 channels (piece lane % PPR of the slice), so it keeps
+    // sum g and sum g * xhat of those channels per normalisation group over its whole grid-stride loop; one part per (group, workgroup of the slice)
+    const bool bst = p.bstats != nullptr;       // scalar
+    const int pcl = lane % PPR, chl = cb + pcl * 8;
+    float bmean[2][8], brstd[2][8], bs1[2][8], bs2[2][8];
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            bs1[g2][e] = bs2[g2][e] = 0.f;
+            bmean[g2][e] = 0.f; brstd[g2][e] = 0.f;
+            if (bst && g2 < p.bn_groups) {
+                bmean[g2][e] = p.bn_stats[(long long)g2 * 2 * p.Cout + chl + e];
+                brstd[g2][e] = p.bn_stats[(long long)g2 * 2 * p.Cout + p.Cout + chl + e];
+            }
+        }
     const int Hi = p.H - 1, Wi = p.W - 1;                                // gradient (input) size; p.H, p.W = output size
     const int gpr = (p.W + 15) >> 4;                                     // 16-pixel groups per output row
     const int ngroups = p.B * p.H * gpr;
@@ -118,16 +137,18 @@ __global__ __launch_bounds__(256) void logits_dgrad_kernel(const ThinK p, const 
         }
         // second-stage operands, all in flight before the MFMA section: piece it = lane + 64 j -> pixel q = it / PPR, piece pc = it % PPR
         const long long pix0 = ((long long)b * p.H + y) * p.W + xg * 16;
-        f16x8 m8[NP], y8[NP];
+        f16x8 m8[NP], y8[NP], x8[NP];
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             const int it = lane + 64 * j, q = it / PPR, pc = it % PPR;
-            m8[j] = f16x8{0, 0, 0, 0, 0, 0, 0, 0}; y8[j] = m8[j];
+            m8[j] = f16x8{0, 0, 0, 0, 0, 0, 0, 0}; y8[j] = m8[j]; x8[j] = m8[j];
             if (xg * 16 + q < p.W) {
                 if (p.mul) m8[j] = *reinterpret_cast<const f16x8*>(p.mul + (pix0 + q) * p.mul_ld + p.mul_coff + cb + pc * 8);
                 if (p.accumulate) y8[j] = *reinterpret_cast<const f16x8*>(reinterpret_cast<const _Float16*>(p.y) + (pix0 + q) * p.y_ld + p.y_coff + cb + pc * 8);
+                if (bst) x8[j] = *reinterpret_cast<const f16x8*>(p.bn_x + (pix0 + q) * p.bn_x_ld + p.bn_x_coff + cb + pc * 8);
             }
         }
+        const int bgi = bst ? (b / p.bn_ipg) & 1 : 0;                    // the image's normalisation group (wave-uniform)
         f16x4 bfr[4];
         bool live[4];
 #pragma unroll
@@ -164,8 +185,41 @@ __global__ __launch_bounds__(256) void logits_dgrad_kernel(const ThinK p, const 
                 for (int e = 0; e < 8; ++e) v8[e] = (_Float16)((float)v8[e] + (float)y8[j][e]);
             }
             *reinterpret_cast<f16x8*>(reinterpret_cast<_Float16*>(p.y) + (pix0 + q) * p.y_ld + p.y_coff + cb + pc * 8) = v8;
+            if (bst) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float gv = (float)v8[e];
+                    if (bgi == 0) { bs1[0][e] += gv; bs2[0][e] += gv * (((float)x8[j][e] - bmean[0][e]) * brstd[0][e]); }
+                    else { bs1[1][e] += gv; bs2[1][e] += gv * (((float)x8[j][e] - bmean[1][e]) * brstd[1][e]); }
+                }
+            }
         }
     }
+    if (bst) {      // fold the 256 / PPR lanes that share a piece, group by group, in a fixed order; row = group * (workgroups per slice) + this workgroup
+        __shared__ float red[256 * 16];
+        const int gbw = gridDim.x >> nq_log, wgi = blockIdx.x >> nq_log;
+        for (int g2 = 0; g2 < p.bn_groups; ++g2) {
+            __syncthreads();
+            float* mine2 = red + ((threadIdx.x / PPR) * PPR + pcl) * 16;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { mine2[e] = g2 == 0 ? bs1[0][e] : bs1[1][e]; mine2[8 + e] = g2 == 0 ? bs2[0][e] : bs2[1][e]; }
+            __syncthreads();
+            if (threadIdx.x < PPR * 16) {
+                const int pq = threadIdx.x >> 4, e = threadIdx.x & 15;
+                float sum = 0.f;
+                for (int r = 0; r < 256 / PPR; ++r) sum += red[(r * PPR + pq) * 16 + e];
+                p.bstats[(((long long)g2 * gbw + wgi) * p.Cout + cb + pq * 8 + (e & 7)) * 2 + (e >> 3)] = sum;
+            }
+        }
+    }
+}
+
+// workgroups per channel slice of a launch (= parts per normalisation group of hv_conv_desc.bstats)
+static int logits_gb(int Cout, int groups) {
+    const int NP = Cout == 32 ? 1 : Cout == 64 ? 2 : 4, nq = Cout / (32 * NP);
+    int gb = (groups + 3) / 4;                                           // 4 pixel groups each, at most ~8 workgroups per CU in all
+    if (gb * nq > 2048) gb = 2048 / nq;
+    return gb;
 }
 
 template <int NP>
@@ -173,8 +227,7 @@ static int launch_logits(const ThinK& k, const _Float16* wh, int groups, hipStre
     const int nq = k.Cout / (32 * NP);                                   // a power of two (checked by the caller)
     int nq_log = 0;
     while ((1 << nq_log) < nq) ++nq_log;
-    int gb = (groups + 3) / 4;                                           // workgroups per slice: 4 pixel groups each, at most ~8 workgroups per CU in all
-    if (gb * nq > 2048) gb = 2048 / nq;
+    const int gb = logits_gb(k.Cout, groups);
     HV_KNAME("logits_dgrad_kernel");
     hipLaunchKernelGGL(logits_dgrad_kernel<NP>, dim3(gb * nq), dim3(256), 0, s, k, wh, nq, nq_log);
     HV_LAUNCH_CHECK();
@@ -182,16 +235,30 @@ static int launch_logits(const ThinK& k, const _Float16* wh, int groups, hipStre
 }
 
 // hv_conv2d: transposed, 4x4, stride 1, pad 1, gradient channel stride 4 (<= 4 live channels), Cout % 16 == 0 (<= 512), fp16 views + fp16 filter copy
-int hv_conv2d_logits_dgrad(const hv_conv_desc* d, hipStream_t s) {
+static bool logits_dgrad_eligible(const hv_conv_desc* d) {
     static const int on = getenv("HV_LOGITS_DGRAD") ? atoi(getenv("HV_LOGITS_DGRAD")) : 1;
     if (!on || !d->transposed || d->KH != 4 || d->KW != 4 || d->stride != 1 || d->pad != 1 || d->dil != 1 || d->in_shift || d->w_bstride || d->ch_scale || !d->w_f16)
-        return HV_ERR_UNSUPPORTED;
-    if (d->Cin != 4 || d->x_ld != 4 || (d->x_coff & 3) || !d->x_f16 || !d->y_f16 || d->bias || d->act != HV_ACT_NONE || d->accumulate > 1) return HV_ERR_UNSUPPORTED;
+        return false;
+    if (d->Cin != 4 || d->x_ld != 4 || (d->x_coff & 3) || !d->x_f16 || !d->y_f16 || d->bias || d->act != HV_ACT_NONE || d->accumulate > 1) return false;
     if (d->Cout > 512 || (d->Cout & 31) || (d->Cout & (d->Cout - 1)) || ((uintptr_t)d->w_f16 & 15) || (d->y_ld & 7) || (d->y_coff & 7) || ((uintptr_t)d->y & 15) || ((uintptr_t)d->x & 7) ||
         d->Ho != d->H + 1 || d->Wo != d->W + 1)
-        return HV_ERR_UNSUPPORTED;
-    if (d->mul_src && (!d->mul_f16 || (d->mul_ld & 7) || (d->mul_coff & 7) || ((uintptr_t)d->mul_src & 15))) return HV_ERR_UNSUPPORTED;
-    if ((long long)d->B * d->Ho * d->Wo * d->y_ld >= (1ll << 31)) return HV_ERR_UNSUPPORTED;
+        return false;
+    if (d->mul_src && (!d->mul_f16 || (d->mul_ld & 7) || (d->mul_coff & 7) || ((uintptr_t)d->mul_src & 15))) return false;
+    if ((long long)d->B * d->Ho * d->Wo * d->y_ld >= (1ll << 31)) return false;
+    return true;
+}
+
+// parts of hv_conv_desc.bstats this kernel writes: (normalisation groups, at most two) x (workgroups per channel slice); 0 = not served
+size_t hv_conv2d_logits_bstats_parts(const hv_conv_desc* d) {
+    if (!logits_dgrad_eligible(d) || d->accumulate) return 0;
+    const int G = d->bn_groups > 0 ? d->bn_groups : 1;
+    if (G > 2 || d->B % G || !d->bn_x || !d->bn_stats || (d->bn_x_ld & 7) || (d->bn_x_coff & 7) || ((uintptr_t)d->bn_x & 15)) return 0;
+    if ((long long)d->B * d->Ho * d->Wo * d->bn_x_ld >= (1ll << 31)) return 0;
+    return (size_t)G * logits_gb(d->Cout, d->B * d->Ho * ((d->Wo + 15) / 16));
+}
+
+int hv_conv2d_logits_dgrad(const hv_conv_desc* d, hipStream_t s) {
+    if (!logits_dgrad_eligible(d)) return HV_ERR_UNSUPPORTED;
     ThinK k;
     HV_WUSE(1 | 2);
     k.g = reinterpret_cast<const _Float16*>(d->x); k.w = d->w; k.y = d->y; k.mul = reinterpret_cast<const _Float16*>(d->mul_src);
@@ -199,6 +266,12 @@ int hv_conv2d_logits_dgrad(const hv_conv_desc* d, hipStream_t s) {
     k.y_ld = d->y_ld; k.y_coff = d->y_coff; k.mul_ld = d->mul_ld; k.mul_coff = d->mul_coff; k.mul_act = d->mul_act; k.accumulate = d->accumulate; k.pad = d->pad;
     k.alpha = d->alpha; k.g_bytes = 0;
     const int groups = d->B * d->Ho * ((d->Wo + 15) / 16);
+    k.bn_x = nullptr; k.bn_stats = nullptr; k.bstats = nullptr; k.bn_x_ld = k.bn_x_coff = 0; k.bn_ipg = 1; k.bn_groups = 0;
+    if (d->bstats) {
+        if (!hv_conv2d_logits_bstats_parts(d)) return HV_ERR_UNSUPPORTED;
+        k.bn_x = reinterpret_cast<const _Float16*>(d->bn_x); k.bn_stats = d->bn_stats; k.bstats = d->bstats; k.bn_x_ld = d->bn_x_ld; k.bn_x_coff = d->bn_x_coff;
+        k.bn_groups = d->bn_groups > 0 ? d->bn_groups : 1; k.bn_ipg = d->B / k.bn_groups;
+    }
     const _Float16* wh = reinterpret_cast<const _Float16*>(d->w_f16);
     hv_path_note = 9;
     if (d->Cout == 32) return launch_logits<1>(k, wh, groups, s);

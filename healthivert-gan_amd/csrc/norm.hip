@@ -298,13 +298,22 @@ extern "C" int hv_norm_act_forward(const hv_norm_desc* d, void* stream) {
 }
 
 // sums over chunks -> ab[g][2][C] (floats); dgamma/dbeta over groups
+// fpart != NULL: the sums come from the epilogue of the data gradient that produced dy (hv_conv_desc.bstats: [nchunk][C][2] floats, group g = the g-th of G
+// equal ranges of rows) instead of norm_reduce_kernel<1>
 __global__ void norm_bwd_finalize_kernel(const double* __restrict__ part, int G, int nchunk, int C, float* __restrict__ ab,
-                                         float* dgamma, float* dbeta, int accumulate) {
+                                         float* dgamma, float* dbeta, int accumulate, const float* __restrict__ fpart) {
     const int c = blockIdx.x;   // one wave per channel
     if (c >= C) return;
     double ta = 0, tb = 0;
     for (int g = 0; g < G; ++g) {
         double a = 0, b = 0;
+        if (fpart) {
+            const int per = nchunk / G;
+            for (int k = g * per + threadIdx.x; k < (g + 1) * per; k += 64) {
+                const float2 v = *reinterpret_cast<const float2*>(fpart + ((long long)k * C + c) * 2);
+                a += v.x; b += v.y;
+            }
+        } else
         for (int k = threadIdx.x; k < nchunk; k += 64) {
             a += part[((long long)g * nchunk + k) * 2 * C + c];
             b += part[((long long)g * nchunk + k) * 2 * C + C + c];
@@ -410,17 +419,22 @@ extern "C" int hv_norm_act_backward(const hv_norm_bwd_desc* d, void* stream) {
     k.stats = d->stats; k.gamma = d->norm == HV_NORM_BATCH ? d->gamma : nullptr;
     double* part = (double*)d->workspace;
     float* ab = (float*)((char*)d->workspace + need_part);
-    dim3 grid(pl.nchunk, pl.G, pl.slices);
-    if (d->f16) {
-        if (vec) hipLaunchKernelGGL((norm_reduce_kernel<1, true, true>), grid, dim3(256), 0, s, k, part);
-        else hipLaunchKernelGGL((norm_reduce_kernel<1, false, true>), grid, dim3(256), 0, s, k, part);
-    } else {
-        if (vec) hipLaunchKernelGGL((norm_reduce_kernel<1, true, false>), grid, dim3(256), 0, s, k, part);
-        else hipLaunchKernelGGL((norm_reduce_kernel<1, false, false>), grid, dim3(256), 0, s, k, part);
+    // sums handed over by the data gradient that wrote dy (hv_conv_desc.bstats): no reduction pass over dy and x
+    const bool handed = d->partials && d->n_partials > 0;
+    if (handed && (d->norm != HV_NORM_BATCH || !d->training || need_y || d->n_partials % pl.G)) return HV_ERR_ARG;
+    if (!handed) {
+        dim3 grid(pl.nchunk, pl.G, pl.slices);
+        if (d->f16) {
+            if (vec) hipLaunchKernelGGL((norm_reduce_kernel<1, true, true>), grid, dim3(256), 0, s, k, part);
+            else hipLaunchKernelGGL((norm_reduce_kernel<1, false, true>), grid, dim3(256), 0, s, k, part);
+        } else {
+            if (vec) hipLaunchKernelGGL((norm_reduce_kernel<1, true, false>), grid, dim3(256), 0, s, k, part);
+            else hipLaunchKernelGGL((norm_reduce_kernel<1, false, false>), grid, dim3(256), 0, s, k, part);
+        }
+        HV_LAUNCH_CHECK();
     }
-    HV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(d->C), dim3(64), 0, s, part, pl.G, pl.nchunk, d->C, ab, d->dgamma, d->dbeta,
-                       d->param_accumulate);
+    hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(d->C), dim3(64), 0, s, part, pl.G, handed ? d->n_partials : pl.nchunk, d->C, ab, d->dgamma, d->dbeta,
+                       d->param_accumulate, handed ? d->partials : nullptr);
     HV_LAUNCH_CHECK();
     const int batch_stats = (d->norm == HV_NORM_INSTANCE || d->training) ? 1 : 0;
     const long long n = (long long)pl.R * (vec ? d->C / 4 : d->C);

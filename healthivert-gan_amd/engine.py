@@ -338,12 +338,14 @@ def _wgrad(node, p, xin, gfull, accumulate, prec, dbias=None, dbias_accumulate=F
 
 
 def conv_backward(node, book, prec, dbias_accumulate=False, wgrad_accumulate=False, tmp_full=None, wgrad=True, x_wg=None, premultiplied=False,
-                  mul_x=None, dbias_done=False):
+                  mul_x=None, dbias_done=False, bn=None):
     """Backward of one ConvNode: activation gradient (+bias gradient), weight gradient, data gradient.
     x_wg: channel-padded copy of the input for the weight-gradient kernel (1-channel image inputs).
     premultiplied: the gradient buffer of node.y already holds the PRE-activation gradient (its only writer applied act').
     mul_x: activation name of the layer that produced node.x -- the data gradient is multiplied by act'(node.x) in the conv
-    epilogue, so that layer's backward starts `premultiplied` (conv_backward_chain)."""
+    epilogue, so that layer's backward starts `premultiplied` (conv_backward_chain).
+    bn: (Act raw input of the batch normalisation that produced node.x, its stats, groups, partials) -- the normalisation's backward sums leave
+    this data gradient's epilogue (ops.conv2d bn=; the caller asked conv2d_bstats_parts first)."""
     p = node.p
     gy = book.twin(node.y)
     want_dbias = p.bias is not None and node.use_bias and wgrad and not dbias_done      # dbias_done: the caller's seed pass already summed it
@@ -388,7 +390,7 @@ def conv_backward(node, book, prec, dbias_accumulate=False, wgrad_accumulate=Fal
             ops.copy_channels(full, gx, mode=3, accumulate=book.mark(gx))
         else:
             ops.conv2d(gfull, p.w_bwd, gx, node.k, node.s, node.pad, node.d, transposed=True, accumulate=int(book.mark(gx)), w_h=p.w_bwd_h, w_t=p.w_bwd_t,
-                       precision=prec, mul=(Act(node.x.t, p.cin_fwd, node.x.coff), mul_x) if mul_x else None, wuse=(p, 'use_bwd'))
+                       precision=prec, mul=(Act(node.x.t, p.cin_fwd, node.x.coff), mul_x) if mul_x else None, wuse=(p, 'use_bwd'), bn=bn)
 
 
 BRANCHES = os.environ.get('HV_G_BRANCHES', '1') != '0'   # independent generator branches on two HIP streams / graph branches

@@ -145,6 +145,7 @@ class GANLoss(nn.Module):
 # ================================================================================================ PatchGAN
 CONV_STATS = os.environ.get('HV_CONV_STATS', '1') != '0'     # A/B knob: BatchNorm statistics from the producing conv's epilogue
 LOSS_HEAD = os.environ.get('HV_LOSS_HEAD', '1') != '0'      # GAN loss kernel writes the logits layer's gradient carrier + bias gradient (A/B knob)
+CONV_BSTATS = os.environ.get('HV_CONV_BSTATS', '1') != '0'   # A/B knob: BatchNorm backward sums from the epilogue of the data gradient that writes dy
 FUSE_NORM_ACT = os.environ.get('HV_FUSE_NORM_ACT', '1') != '0'     # A/B knob, see _DiscPlan-based run_backward
 
 
@@ -383,18 +384,46 @@ class NLayerDiscriminator(nn.Module):
                 nm = self.model[L['norm']]
                 gy, gz = book.twin(ent['y']), book.twin(ent['z'])
                 bn = self.norm_kind == 'batch'
+                bparts = ent.get('bparts_used', 0)      # the consumer's data gradient (layer li + 1, a moment ago) summed for this normalisation
                 ops.norm_act_backward(gy, ent['y'], ent['z'], gz, self.norm_kind, P.training, ent['stats'],
                                       gamma=nm.weight if bn else None, act='none' if fuse_n else 'lrelu',
                                       dgamma=nm.weight.grad if (bn and param_grads) else None,
                                       dbeta=nm.bias.grad if (bn and param_grads) else None, param_accumulate=accumulate,
-                                      groups=P.groups)
+                                      groups=P.groups, partials=ent['bpartials'] if bparts else None, n_partials=bparts)
             # the stem's output has one consumer (layer 1): its LeakyReLU' rides in layer 1's data-gradient epilogue
+            mul_x = P.layers[0]['node'].act if (li == 1 and fuse0) else ('lrelu' if (prev_normed and fuse_n) else None)
+            # ... and where layer li - 1 is batch-normalised, the sums of ITS backward (sum g, sum g * xhat over the gradient this launch writes) leave
+            # this data gradient's epilogue: the normalisation's backward then skips its reduction pass over g and z (HV_CONV_BSTATS=0: it reduces)
+            bn_arg = None
+            if prev_normed and fuse_n and mul_x and CONV_BSTATS and self.norm_kind == 'batch' and P.training:
+                pe = P.layers[li - 1]
+                if 'bparts' not in pe:
+                    pe['bparts'] = self._bstats_parts(node, pe, P, book, prec, mul_x)
+                    pe['bpartials'] = torch.zeros(max(1, pe['bparts']) * pe['p'].cout * 2, dtype=torch.float32, device=pe['z'].t.device)
+                if pe['bparts']:
+                    bn_arg = (pe['z'], pe['stats'], P.groups, pe['bpartials'])
+                pe['bparts_used'] = pe['bparts'] if bn_arg else 0
+            elif prev_normed:
+                P.layers[li - 1]['bparts_used'] = 0
             E.conv_backward(node, book, prec, dbias_accumulate=accumulate, wgrad_accumulate=accumulate, wgrad=param_grads, dbias_done=bool(logits_ready and L['last']),
-                            mul_x=P.layers[0]['node'].act if (li == 1 and fuse0) else ('lrelu' if (prev_normed and fuse_n) else None))
+                            mul_x=mul_x, bn=bn_arg)
         if need_dx:
             g = book.twin(P.x_in)
             return g.t.view(B, 1, P.H, P.W)
         return None
+
+    def _bstats_parts(self, node, pe, P, book, prec, mul_x):
+        """Parts of the batch-norm backward sums that node's data gradient (exactly as conv_backward issues it) would write for the normalised layer
+        pe below it; 0 = its kernel has no such epilogue."""
+        p = node.p
+        gy = book.twin(node.y)
+        gfull = Act(gy.t, p.coutP, gy.coff)
+        gx = book.twin(node.x)
+        gx = Act(gx.t, node.dx_c or p.cin_fwd, gx.coff)
+        if (id(gx.t), gx.coff, gx.C) in book.written:       # (an accumulating data gradient is not a whole sum; never the case in this chain)
+            return 0
+        return int(ops.conv2d_bstats_parts(gfull, p.w_bwd, gx, node.k, node.s, node.pad, node.d, transposed=True, accumulate=0, w_h=p.w_bwd_h, w_t=p.w_bwd_t,
+                                           precision=prec, mul=(Act(node.x.t, p.cin_fwd, node.x.coff), mul_x), bn=(pe['z'], pe['stats'], P.groups, None)))
 
     def finish(self):
         for P in self._plans.values():

@@ -162,7 +162,7 @@ def conv_out_size(n, k, stride, pad, dil):
 
 def conv2d(x, w, y, k, stride=1, pad=0, dil=1, bias=None, act='none', transposed=False, in_shift=0, alpha=1.0,
            accumulate=0, ch_scale=None, w_bstride=0, ch_scale_bstride=0, precision=None, cin=None, cout=None, w_h=None, mul=None, w_t=None,
-           stats=None, _parts_only=False, pool2=False, x1=None, _supported_only=False, wuse=None):
+           stats=None, _parts_only=False, pool2=False, x1=None, _supported_only=False, wuse=None, bn=None, _bparts_only=False):
     """y = act(alpha*ch_scale*conv(x, w) + bias)  [* act'(m) with mul = (Act m, activation name): see hv_conv_desc.mul_src].  x,y: Act; w: prepared [CoutF][k*k][CinP] tensor (or [B][...] with
     w_bstride).  cin/cout default to the view widths (x.C consumed, y.C produced).
     stats: float tensor of conv2d_stats_parts(...) * Cout * 2 elements that receives the per-channel partial sums of the stored output
@@ -197,6 +197,15 @@ def conv2d(x, w, y, k, stride=1, pad=0, dil=1, bias=None, act='none', transposed
     if mul is not None:
         m, mact = mul
         d.mul_src, d.mul_ld, d.mul_coff, d.mul_act, d.mul_f16 = ptr(m.t).value, m.ld, m.coff, ACT[mact], m.f16
+    if bn is not None:      # (Act x_raw, stats [G][2][C], groups, partials or None): batch-norm backward sums out of this data gradient's epilogue (hv_conv_desc.bstats)
+        bx, bstat, bgroups, bpart = bn
+        assert bx.f16 == y.f16 and bx.H == y.H and bx.W == y.W and bx.B == y.B
+        d.bn_x, d.bn_x_ld, d.bn_x_coff = ptr(bx.t).value, bx.ld, bx.coff
+        d.bn_stats, d.bn_groups = ptr(bstat).value, int(bgroups)
+        if bpart is not None:
+            d.bstats = ptr(bpart).value
+    if _bparts_only:
+        return L.size('hv_conv2d_bstats_parts', ctypes.byref(d))
     if _parts_only:
         return L.size('hv_conv2d_stats_parts', ctypes.byref(d))
     if _supported_only:
@@ -247,6 +256,11 @@ def pool2_ok(g, y_low, k, stride, pad, dil, precision, w_h, w_t, cout=None, w=No
         r = _SUPPORTED[key] = conv2d_supported(g, w_h if w is None else w, Act(y_low.t, co, y_low.coff), k, stride, pad, dil, transposed=True, pool2=True,
                                                precision=precision, w_h=w_h, w_t=w_t)
     return r
+
+
+def conv2d_bstats_parts(*args, **kw):
+    """Parts of the batch-norm backward sums the conv2d call with these arguments (bn=(x_raw, stats, groups, None)) would write (0: no such epilogue)."""
+    return conv2d(*args, _bparts_only=True, **kw)
 
 
 def conv2d_stats_parts(*args, **kw):
@@ -475,7 +489,7 @@ def norm_act_forward(x, y, norm, training, stats, gamma=None, beta=None, running
 
 
 def norm_act_backward(dy, y, x, dx, norm, training, stats, gamma=None, act='lrelu', post_sigmoid=False, dgamma=None, dbeta=None,
-                      param_accumulate=False, groups=1):
+                      param_accumulate=False, groups=1, partials=None, n_partials=0):
     L = _lib.get()
     d = L.hv_norm_bwd_desc()
     d.dy, d.y, d.x, d.dx = ptr(dy.t).value, ptr(y.t).value, ptr(x.t).value, ptr(dx.t).value
@@ -492,6 +506,8 @@ def norm_act_backward(dy, y, x, dx, norm, training, stats, gamma=None, act='lrel
     d.groups = int(groups)
     assert dy.f16 == y.f16 == x.f16 == dx.f16
     d.f16 = x.f16
+    if partials is not None and n_partials:      # the sums came out of the data gradient that wrote dy (hv_conv_desc.bstats): no reduction pass here
+        d.partials, d.n_partials = ptr(partials).value, int(n_partials)
     need = L.size('hv_norm_workspace_bytes', x.B, x.H * x.W, x.C)
     b, _ = _ws(need, x.t.device)
     d.workspace, d.workspace_bytes = ptr(b).value, b.numel()

@@ -112,8 +112,18 @@ typedef struct {
                                          the data gradient of a convolution whose input was the nearest x2 up-sampling of a smaller tensor, without the
                                          full-resolution gradient in memory (replaces conv + hv_copy_channels mode 3 + the in-place act' pass).  Ho, Wo keep
                                          the convolution's own output size (even).  Served by the filters-in-LDS 3x3 kernel only: HV_ERR_UNSUPPORTED otherwise */
+    const void* bn_x; int bn_x_ld, bn_x_coff;
+    const float* bn_stats; int bn_groups;
+    float* bstats;                    /* optional, data-gradient forms whose output y is the gradient at the OUTPUT of a batch normalisation (its act' applied through
+                                         mul_src): the normalisation's backward sums out of this conv's epilogue.  bn_x = the normalisation's raw input (same pixels /
+                                         channels / storage as y, its own ld / coff), bn_stats = its saved [bn_groups][2][Cout] mean / rstd (hv_norm_desc.stats; the
+                                         batch's images fall into bn_groups equal groups), bstats[(part * Cout + c) * 2 + {0, 1}] = sum g, sum g * xhat over the part's
+                                         pixels (g = the stored value of y, xhat = (bn_x - mean) * rstd), part < hv_conv2d_bstats_parts(d), parts of whole images in
+                                         (group, image) order.  Feeds hv_norm_bwd_desc.partials: hv_norm_act_backward then skips its reduction pass over dy and x.
+                                         hv_conv2d returns HV_ERR_UNSUPPORTED (and launches nothing) when the kernel of this shape has no such epilogue */
 } hv_conv_desc;
 int hv_conv2d(const hv_conv_desc* d, void* stream);
+size_t hv_conv2d_bstats_parts(const hv_conv_desc* d);      /* parts of hv_conv_desc.bstats this call would write (0: its kernel has no such epilogue) */
 size_t hv_conv2d_workspace_bytes(const hv_conv_desc* d);   /* 0 when no kernel for this shape wants scratch */
 size_t hv_conv2d_stats_parts(const hv_conv_desc* d);       /* parts of hv_conv_desc.stats this call would write (0: its kernel has no statistics epilogue) */
 int hv_last_weight_tables(void);                           /* which prepared tables the hv_conv2d call this thread made last read: 1 = fp32 (w, w1), 2 = fp16 rows
@@ -230,6 +240,10 @@ typedef struct {
     float* workspace; size_t workspace_bytes;
     int groups;
     int f16;
+    const float* partials; int n_partials;
+                  /* optional (batch norm, training, act == HV_ACT_NONE): hv_conv_desc.bstats of the data gradient that produced dy -- [n_partials][C][2] sums
+                     (sum dy, sum dy * xhat), parts of whole images in (group, image) order, n_partials a multiple of `groups`.  The reduction pass over dy and x
+                     is skipped.  NULL = reduce here */
 } hv_norm_bwd_desc;
 int hv_norm_act_backward(const hv_norm_bwd_desc* d, void* stream);
 

@@ -441,3 +441,37 @@ def test_attention_operand_transposes_are_exact(B, R, C):
     dst2 = torch.full((B, C, R), 7.0, dtype=torch.float16, device=dev)
     L.call('hv_transpose_batched_h2h', ptr(src_h), ptr(dst2), B, R, C, stream())
     assert torch.equal(dst2, src_h.transpose(1, 2).contiguous())
+
+
+@pytest.mark.parametrize('groups', [1, 2])
+def test_batchnorm_backward_sums_from_the_data_gradient_epilogue(groups, monkeypatch):
+    """fp16 mode, full-size PatchGAN (ndf 64): the batch-norm backward sums (sum g, sum g * xhat per channel and group) come out of the epilogue of the
+    data gradient that writes g -- logits_dgrad_kernel (512 channels), conv_g4s1_kernel (256, stride 1) and conv_g4_kernel<1> (128, stride 2, four
+    parity classes) -- instead of norm_reduce_kernel<1> (hv_conv_desc.bstats -> hv_norm_bwd_desc.partials).  Against the same backward with the
+    reduction pass (HV_CONV_BSTATS=0): every parameter gradient and the input gradient agree to summation-order accuracy, for one statistics group and
+    for the fake | real halves of a batched pass (two groups); a 72 x 56 map: partial tiles in both kernels."""
+    monkeypatch.setenv('HV_PRECISION', 'fp16')
+    from hvgan.models import networks
+    from hvgan import ops
+    dev = torch.device('cuda:0')
+    torch.manual_seed(3)
+    net = networks.define_D(1, 64, 'basic', 3, 'batch', 'normal', 0.02, []).cuda()
+    net.precision = 'fp16'
+    net.train()
+    x = torch.randn(4, 1, 72, 56, device=dev)
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(networks, 'CONV_BSTATS', on)
+        P = net.run_forward(x, training=True, groups=groups)
+        dz = torch.randn(P.logits.shape, generator=torch.Generator().manual_seed(5)).to(dev) * 64.0
+        dx = net.run_backward(P, dz, need_dx=True, param_grads=True)
+        net.finish()
+        torch.cuda.synchronize()
+        used = [ent.get('bparts_used', 0) for ent in P.layers[1:-1]]
+        assert all(u > 0 for u in used) if on else not any(used), (on, used)
+        res[on] = ({k: p.grad.detach().clone() for k, p in net.named_parameters()}, dx.detach().clone())
+    for k in res[True][0]:
+        a, b = res[True][0][k], res[False][0][k]
+        assert torch.isfinite(a).all() and b.abs().max().item() > 0, k
+        assert (a - b).norm().item() <= 2e-3 * b.norm().item(), (k, (a - b).norm().item(), b.norm().item())
+    assert (res[True][1] - res[False][1]).norm().item() <= 2e-3 * res[False][1].norm().item()
