@@ -1,0 +1,240 @@
+// Contextual attention, matching scores and their gradient on the PIXEL Gram matrix (reference models/inpaint_networks.py:327-344 + autograd).
+//
+// The reference convolves the (zero-padded) downsampled map fd with its own normalised 3x3 patches: S0[p][l] = rnorm[l] * <patch_l, patch_p>, a
+// K = 9 C contraction per score (19.3 GFLOP per step at bs 16; patch tables wp / wp_h / wpT of 57-75 MB written and re-read per forward / backward).
+// The patches are both filters and inputs, so with the pixel Gram matrix G[a][b] = <fd[a], fd[b]> (K = C)
+//     T[p][l]  = sum over the 3x3 offsets t of G[p + t][l + t]      (terms with p + t or l + t outside the map dropped)
+//     S0[p][l] = rnorm[l] * T[p][l],      norm[l]^2 = sum_t |fd[l + t]|^2                      (tests/test_host_cpu.py: identity against the oracle)
+// and, for the gradient, with Gs[i][j] = dS0[j][i] rnorm[i] + dS0[i][j] rnorm[j] (hv_ca_score_backward_prep) and E = the same box filter applied to Gs,
+//     d fd[a] = sum_b E[a][b] fd[b] + (sum_t coef[a - t]) fd[a]
+// -- the L x 9C gradient GEMM, the transpose of wp and the col2im pass collapse into one K = L product with N = C.
+// Blocks are grid rows: p in row py, l in row ly is a w x w block whose box filter needs the three Gram blocks (py + ty, ly + ty) on its diagonal;
+// the x shifts stay inside the block (a shifted pixel outside [0, w) is outside the map).  w = 32 or 64, C = 64, fp16 operands, fp32 accumulation.
+#include "hv_common.h"
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// ---- downsample (nearest, even positions) -> fd_h [B][L][C] fp16, fdT_h [B][C][L] fp16, q[B][L] = |fd|^2 (fp32) ----------------------------------------
+template <int C>
+__global__ __launch_bounds__(256) void ca_gram_down_kernel(const _Float16* __restrict__ f, int H, int W, int f_ld, _Float16* __restrict__ fd_h,
+                                                           _Float16* __restrict__ fdT_h, float* __restrict__ q) {
+    constexpr int PC = C / 8;                       // 16-byte pieces per pixel
+    __shared__ _Float16 t[C][64 + 8];               // [channel][pixel of the row segment]
+    const int h = H / 2, w = W / 2, L = h * w;
+    const int segs = (w + 63) / 64;
+    const int seg = blockIdx.x % segs, y = (blockIdx.x / segs) % h, b = blockIdx.x / (segs * h);
+    const int x0 = seg * 64, nx = min(64, w - x0);
+    for (int it = threadIdx.x; it < nx * PC; it += 256) {
+        const int xl = it / PC, pc = it - xl * PC, x = x0 + xl;
+        const f16x8 v = *reinterpret_cast<const f16x8*>(f + (((long long)b * H + 2 * y) * W + 2 * x) * f_ld + pc * 8);
+        const long long l = (long long)y * w + x;
+        *reinterpret_cast<f16x8*>(fd_h + ((long long)b * L + l) * C + pc * 8) = v;
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float a = (float)v[e]; s += a * a; t[pc * 8 + e][xl] = v[e]; }
+        // the PC lanes of a pixel are consecutive lanes of one wave (256 % PC == 0, PC a power of two)
+#pragma unroll
+        for (int o = 1; o < PC; o <<= 1) s += __shfl_xor(s, o, 64);
+        if (pc == 0) q[(long long)b * L + l] = s;
+    }
+    __syncthreads();
+    for (int it = threadIdx.x; it < C * (nx / 8); it += 256) {       // rows of 8 pixels = 16 bytes (w is a multiple of 8)
+        const int c = it / (nx / 8), x8 = (it - c * (nx / 8)) * 8;
+        *reinterpret_cast<f16x8*>(fdT_h + ((long long)b * C + c) * L + (long long)y * w + x0 + x8) = *reinterpret_cast<const f16x8*>(&t[c][x8]);
+    }
+}
+
+extern "C" int hv_ca_gram_down(const void* f, int f_f16, int B, int H, int W, int C, int f_ld, void* fd_h, void* fdT_h, float* q, void* stream) {
+    if (!f || !fd_h || !fdT_h || !q || B <= 0 || H <= 0 || W <= 0 || ((H | W) & 1)) return HV_ERR_ARG;
+    if (!f_f16 || C != 64 || (f_ld & 7) || ((uintptr_t)f & 15) || ((W / 2) & 7)) return HV_ERR_UNSUPPORTED;
+    const int h = H / 2, w = W / 2;
+    hipLaunchKernelGGL(ca_gram_down_kernel<64>, dim3(B * h * ((w + 63) / 64)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const _Float16*>(f), H, W, f_ld,
+                       reinterpret_cast<_Float16*>(fd_h), reinterpret_cast<_Float16*>(fdT_h), q);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+
+// the w x w box filter on three diagonal blocks held in LDS: out[r][c] = sum over the valid blocks tyi and tx in {-1, 0, 1} of Gt[tyi][r + tx][c + tx]
+template <int BW>
+__device__ __forceinline__ float gram_box(const float (*Gt)[BW][BW + 1], const bool (&bv)[3], int r, int c) {
+    float acc = 0.f;
+#pragma unroll
+    for (int tyi = 0; tyi < 3; ++tyi) {
+        if (!bv[tyi]) continue;       // scalar
+#pragma unroll
+        for (int tx = -1; tx <= 1; ++tx)
+            if ((unsigned)(r + tx) < (unsigned)BW && (unsigned)(c + tx) < (unsigned)BW) acc += Gt[tyi][r + tx][c + tx];
+    }
+    return acc;
+}
+
+// ---- scores: one workgroup per (sample, grid row py of p, grid row ly of l) ------------------------------------------------------------------------------
+template <int BW>
+__global__ __launch_bounds__(256) void ca_gram_scores_kernel(const _Float16* __restrict__ fd_h, const float* __restrict__ q, int h, float* __restrict__ S0,
+                                                             float* __restrict__ norm, float* __restrict__ rnorm) {
+    constexpr int C = 64, NT = BW / 16, TPW = NT * NT / 4;      // MFMA tiles per wave
+    __shared__ float Gt[3][BW][BW + 1];
+    const int w = BW, L = h * w;
+    int id = blockIdx.x;
+    const int ly = id % h; id /= h;
+    const int py = id % h;
+    const long long b = id / h;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const _Float16* fb = fd_h + b * (long long)L * C;
+    bool bv[3];
+#pragma unroll
+    for (int tyi = 0; tyi < 3; ++tyi) bv[tyi] = (unsigned)(py + tyi - 1) < (unsigned)h && (unsigned)(ly + tyi - 1) < (unsigned)h;
+#pragma unroll
+    for (int tyi = 0; tyi < 3; ++tyi) {
+        if (!bv[tyi]) continue;
+        const _Float16* prow = fb + (long long)(py + tyi - 1) * w * C;
+        const _Float16* lrow = fb + (long long)(ly + tyi - 1) * w * C;
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) {
+            const int tile = wave * TPW + u, mi = tile / NT, ni = tile - mi * NT;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < C / 32; ++ks) {
+                const f16x8 a = *reinterpret_cast<const f16x8*>(prow + (mi * 16 + (lane & 15)) * C + ks * 32 + 8 * (lane >> 4));
+                const f16x8 bb = *reinterpret_cast<const f16x8*>(lrow + (ni * 16 + (lane & 15)) * C + ks * 32 + 8 * (lane >> 4));
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bb, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Gt[tyi][mi * 16 + 4 * (lane >> 4) + r][ni * 16 + (lane & 15)] = acc[r];
+        }
+    }
+    __syncthreads();
+    const float* qb = q + b * L;
+    float* Sb = S0 + b * (long long)L * L;
+    for (int it = threadIdx.x; it < BW * BW / 4; it += 256) {
+        const int r = it / (BW / 4), c0 = (it - r * (BW / 4)) * 4;
+        float o[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + u;
+            float n2 = 0.f;                     // |patch_l|^2 = the 3x3 box of the pixels' squared norms
+#pragma unroll
+            for (int ty = -1; ty <= 1; ++ty)
+#pragma unroll
+                for (int tx = -1; tx <= 1; ++tx)
+                    if ((unsigned)(ly + ty) < (unsigned)h && (unsigned)(c + tx) < (unsigned)w) n2 += qb[(ly + ty) * w + c + tx];
+            const float nv = fmaxf(sqrtf(n2), 1e-4f);
+            o[u] = gram_box<BW>(Gt, bv, r, c) * (1.f / nv);
+            if (py == 0 && r == 0) { norm[b * L + ly * w + c] = nv; rnorm[b * L + ly * w + c] = 1.f / nv; }
+        }
+        *reinterpret_cast<float4*>(Sb + (long long)(py * w + r) * L + ly * w + c0) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+extern "C" int hv_ca_gram_scores(const void* fd_h, const float* q, int B, int h, int w, int C, float* S0, float* norm, float* rnorm, void* stream) {
+    if (!fd_h || !q || !S0 || !norm || !rnorm || B <= 0 || h <= 0 || w <= 0) return HV_ERR_ARG;
+    if (C != 64 || (w != 32 && w != 64) || ((uintptr_t)fd_h & 15) || ((uintptr_t)S0 & 15) || (long long)B * h * h >= (1ll << 31)) return HV_ERR_UNSUPPORTED;
+    const dim3 grid((unsigned)(B * h * h));
+    if (w == 32) hipLaunchKernelGGL(ca_gram_scores_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const _Float16*>(fd_h), q, h, S0, norm, rnorm);
+    else hipLaunchKernelGGL(ca_gram_scores_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const _Float16*>(fd_h), q, h, S0, norm, rnorm);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+
+// ---- gradient: one workgroup per (sample, grid row ay); d fd[row ay] = sum over by of E(ay, by) fd[row by]  (+ the norm term), added to the even positions of df
+template <int BW>
+__global__ __launch_bounds__(256) void ca_gram_backward_kernel(const float* __restrict__ Gs, const _Float16* __restrict__ fd_h, const _Float16* __restrict__ fdT_h,
+                                                               const float* __restrict__ coef, int h, float* __restrict__ df, int df_ld) {
+    constexpr int C = 64, MT = BW / 16, NTL = C / 16, TPW = MT * NTL / 4, LDE = BW + 8;
+    constexpr int NV = 3 * BW * BW / 4 / 256;            // float4 items of the three Gs blocks per thread
+    __shared__ float Gt[3][BW][BW + 1];
+    __shared__ __attribute__((aligned(16))) _Float16 Eh[BW][LDE];
+    const int w = BW, L = h * w, H = 2 * h, W = 2 * w;
+    const int ay = blockIdx.x % h;
+    const long long b = blockIdx.x / h;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* Gb = Gs + b * (long long)L * L;
+    const _Float16* fTb = fdT_h + b * (long long)C * L;
+    f32x4 acc[TPW];
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float4 pre[NV];
+    auto fetch = [&](int by) __attribute__((always_inline)) {       // the three diagonal blocks (ay + ty, by + ty) of Gs, zeros where a block leaves the map
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int it = threadIdx.x + k * 256, tyi = it / (BW * BW / 4), rem = it - tyi * (BW * BW / 4), r = rem / (BW / 4), c4 = (rem - r * (BW / 4)) * 4;
+            const int ra = ay + tyi - 1, rb = by + tyi - 1;
+            pre[k] = ((unsigned)ra < (unsigned)h && (unsigned)rb < (unsigned)h)
+                         ? *reinterpret_cast<const float4*>(Gb + (long long)(ra * w + r) * L + rb * w + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    fetch(0);
+    const bool all3[3] = {true, true, true};
+    for (int by = 0; by < h; ++by) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int it = threadIdx.x + k * 256, tyi = it / (BW * BW / 4), rem = it - tyi * (BW * BW / 4), r = rem / (BW / 4), c4 = (rem - r * (BW / 4)) * 4;
+            Gt[tyi][r][c4] = pre[k].x; Gt[tyi][r][c4 + 1] = pre[k].y; Gt[tyi][r][c4 + 2] = pre[k].z; Gt[tyi][r][c4 + 3] = pre[k].w;
+        }
+        // this row block's B operands (fd of grid row by, pixel-contiguous: the transposed table), requested before the barrier
+        f16x8 bf[TPW][BW / 32];
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) {
+            const int ni = (wave * TPW + u) % NTL;
+#pragma unroll
+            for (int ks = 0; ks < BW / 32; ++ks)
+                bf[u][ks] = *reinterpret_cast<const f16x8*>(fTb + (long long)(ni * 16 + (lane & 15)) * L + by * w + ks * 32 + 8 * (lane >> 4));
+        }
+        __syncthreads();
+        if (by + 1 < h) fetch(by + 1);        // the next blocks fly behind the box filter and the MFMAs
+        for (int it = threadIdx.x; it < BW * BW / 4; it += 256) {
+            const int r = it / (BW / 4), c0 = (it - r * (BW / 4)) * 4;
+            f16x4 e4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) e4[u] = (_Float16)gram_box<BW>(Gt, all3, r, c0 + u);      // (blocks outside the map were fetched as zeros)
+            *reinterpret_cast<f16x4*>(&Eh[r][c0]) = e4;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) {
+            const int mi = (wave * TPW + u) / NTL;
+#pragma unroll
+            for (int ks = 0; ks < BW / 32; ++ks) {
+                const f16x8 a = *reinterpret_cast<const f16x8*>(&Eh[mi * 16 + (lane & 15)][ks * 32 + 8 * (lane >> 4)]);
+                acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bf[u][ks], acc[u], 0, 0, 0);
+            }
+        }
+        __syncthreads();          // Eh and Gt are rewritten by the next round
+    }
+    // epilogue: + (sum of coef over the 3x3 neighbourhood) * fd[a]; the even positions of the full-resolution gradient map receive the sum
+    const float* cb = coef + b * L;
+    const _Float16* fb = fd_h + b * (long long)L * C;
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+        const int tile = wave * TPW + u, mi = tile / NTL, ni = tile - mi * NTL;
+        const int ch = ni * 16 + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ax = mi * 16 + 4 * (lane >> 4) + r;
+            float cs = 0.f;
+#pragma unroll
+            for (int ty = -1; ty <= 1; ++ty)
+#pragma unroll
+                for (int tx = -1; tx <= 1; ++tx)
+                    if ((unsigned)(ay - ty) < (unsigned)h && (unsigned)(ax - tx) < (unsigned)w) cs += cb[(ay - ty) * w + ax - tx];
+            const float v = acc[u][r] + cs * (float)fb[(long long)(ay * w + ax) * C + ch];
+            float* d = df + (((long long)b * H + 2 * ay) * W + 2 * ax) * df_ld + ch;
+            *d += v;
+        }
+    }
+}
+
+extern "C" int hv_ca_gram_backward(const float* Gs, const void* fd_h, const void* fdT_h, const float* coef, int B, int h, int w, int C, float* df, int df_ld,
+                                   void* stream) {
+    if (!Gs || !fd_h || !fdT_h || !coef || !df || B <= 0 || h <= 0 || w <= 0 || df_ld < C) return HV_ERR_ARG;
+    if (C != 64 || (w != 32 && w != 64) || ((uintptr_t)Gs & 15) || ((uintptr_t)fdT_h & 15) || (long long)B * h >= (1ll << 31)) return HV_ERR_UNSUPPORTED;
+    const dim3 grid((unsigned)(B * h));
+    if (w == 32)
+        hipLaunchKernelGGL(ca_gram_backward_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, Gs, reinterpret_cast<const _Float16*>(fd_h),
+                           reinterpret_cast<const _Float16*>(fdT_h), coef, h, df, df_ld);
+    else
+        hipLaunchKernelGGL(ca_gram_backward_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, Gs, reinterpret_cast<const _Float16*>(fd_h),
+                           reinterpret_cast<const _Float16*>(fdT_h), coef, h, df, df_ld);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}

@@ -454,6 +454,7 @@ def conv_backward_chain(nodes, book, prec, tmp_full=None, premultiplied_first=Fa
 # ================================================================================================ contextual attention
 CA_F16_IO = os.environ.get('HV_CA_F16_IO', '1') != '0'   # the attention block's boundary kernels read / write fp16-stored maps themselves (A/B knob)
 CA_F16_COPIES = os.environ.get('HV_CA_F16_COPIES', '1') != '0'   # GEMM route: fp16 operand copies written by their producers (wp_h, A as fp16 only); A/B knob
+CA_GRAM = os.environ.get('HV_CA_GRAM', '1') != '0'     # GEMM route: matching scores and their gradient on the pixel Gram matrix (csrc/attention_gram.hip); A/B knob
 CA_GEMM = os.environ.get('HV_CA_GEMM', '1') != '0'     # fp16 mode: the attention block's five contractions as batched NT GEMMs (csrc/bgemm.hip)
 
 
@@ -519,7 +520,15 @@ class AttentionPlan:
                     self.wp_h, self.A_h = hz(B, L, 9 * C), hz(B, L, L)
                     self.O = hz(B, L, 16 * C)          # the paste product only feeds the fold (whose result is stored as fp16): fp16 too
             self.f16_copies = CA_F16_COPIES
-            if self.f16_copies:
+            # scores on the pixel Gram matrix (K = C, no patch tables) where the kernels serve the shape
+            self.gram = bool(CA_GRAM and self.f16_copies and f.f16 and C == 64 and self.w in (32, 64) and f.ld % 8 == 0 and f.coff == 0)
+            if self.gram:
+                if getattr(self, 'fd_h', None) is None:
+                    self.fd_h = torch.zeros(B, L, C, dtype=torch.float16, device=f.t.device)
+                    self.fdT_h = torch.zeros(B, C, L, dtype=torch.float16, device=f.t.device)
+                    self.q = torch.zeros(B, L, dtype=torch.float32, device=f.t.device)
+                L_.call('hv_ca_gram_down', ptr(f.t), f.f16, B, H, W, C, f.ld, ptr(self.fd_h), ptr(self.fdT_h), ptr(self.q), stream())
+            elif self.f16_copies:
                 L_.call('hv_ca_patches_h', ptr(f.t), f.f16, B, H, W, C, f.ld, ptr(self.fd.t), ptr(self.wp), ptr(self.wp_h), ptr(self.norm), ptr(self.rnorm), stream())
             else:
                 L_.call('hv_ca_patches', ptr(f.t), f.f16, B, H, W, C, f.ld, ptr(self.fd.t), ptr(self.wp), None, ptr(self.norm), ptr(self.rnorm), stream())
@@ -536,7 +545,9 @@ class AttentionPlan:
         else:
             L_.call('hv_ca_mask', ptr(mask_img), self.img_hw[0], self.img_hw[1], self.h, self.w, ptr(self.mm), stream())
         f16c = gemm and self.f16_copies
-        if gemm:    # the 3x3 patches of the (zero-padded) map are both the conv's input columns and its filters: scores = rnorm (.) wp wp^T
+        if gemm and self.gram:
+            L_.call('hv_ca_gram_scores', ptr(self.fd_h), ptr(self.q), B, self.h, self.w, C, ptr(self.S0.t), ptr(self.norm), ptr(self.rnorm), stream())
+        elif gemm:    # the 3x3 patches of the (zero-padded) map are both the conv's input columns and its filters: scores = rnorm (.) wp wp^T
             wp_op = self.wp_h if f16c else self.wp
             _bgemm(wp_op, wp_op, self.S0.t, L, L, 9 * C, B, colscale=self.rnorm)
         else:
@@ -614,12 +625,16 @@ class AttentionPlan:
             ds0 = bw['dS1']
         # through the normalised patch matching (patches act as both filters and inputs)
         L_.call('hv_ca_score_backward_prep', ptr(ds0.t), ptr(self.S0.t), ptr(self.norm), ptr(self.rnorm), ptr(bw['Gs'].t), ptr(bw['coef']), B, L, stream())
-        if gemm:
-            if self.f16_copies:      # (the transpose of wp has this one reader)
-                L_.call('hv_transpose_batched_f16', ptr(self.wp), ptr(self.wpT_h), B, L, 9 * C, stream())
-            _bgemm(bw['Gs'].t, self.wpT_h, bw['dwp'].t, L, 9 * C, L, B)
+        if gemm and getattr(self, 'gram', False):
+            # d fd = box(Gs) fd + (3x3 sum of coef) fd, added to the even positions of df: one K = L product instead of the L x 9C GEMM + col2im
+            L_.call('hv_ca_gram_backward', ptr(bw['Gs'].t), ptr(self.fd_h), ptr(self.fdT_h), ptr(bw['coef']), B, self.h, self.w, C, ptr(df.t), df.ld, stream())
         else:
-            ops.conv2d(bw['Gs'], self.wpT, bw['dwp'], 1, 1, 0, 1, w_bstride=9 * C * L, precision=prec)
-        L_.call('hv_ca_patches_backward', ptr(bw['dwp'].t), ptr(self.wp), ptr(bw['coef']), ptr(df.t), B, H, W, C, df.ld, 1, stream())
+            if gemm:
+                if self.f16_copies:      # (the transpose of wp has this one reader)
+                    L_.call('hv_transpose_batched_f16', ptr(self.wp), ptr(self.wpT_h), B, L, 9 * C, stream())
+                _bgemm(bw['Gs'].t, self.wpT_h, bw['dwp'].t, L, 9 * C, L, B)
+            else:
+                ops.conv2d(bw['Gs'], self.wpT, bw['dwp'], 1, 1, 0, 1, w_bstride=9 * C * L, precision=prec)
+            L_.call('hv_ca_patches_backward', ptr(bw['dwp'].t), ptr(self.wp), ptr(bw['coef']), ptr(df.t), B, H, W, C, df.ld, 1, stream())
         if df_user is not None:
             ops.copy_channels(df, df_user, mode=0, accumulate=bool(df_acc))

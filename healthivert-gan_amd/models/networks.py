@@ -397,12 +397,15 @@ class NLayerDiscriminator(nn.Module):
             bn_arg = None
             if prev_normed and fuse_n and mul_x and CONV_BSTATS and self.norm_kind == 'batch' and P.training:
                 pe = P.layers[li - 1]
-                if 'bparts' not in pe:
-                    pe['bparts'] = self._bstats_parts(node, pe, P, book, prec, mul_x)
-                    pe['bpartials'] = torch.zeros(max(1, pe['bparts']) * pe['p'].cout * 2, dtype=torch.float32, device=pe['z'].t.device)
-                if pe['bparts']:
+                bp = pe.setdefault('bparts', {})      # by statistics groups: a plan serves the batched fake | real pass (two groups) and a plain pass of the same size
+                if P.groups not in bp:
+                    bp[P.groups] = self._bstats_parts(node, pe, P, book, prec, mul_x)
+                    # (a buffer per group count: captured graphs of both uses keep their own addresses)
+                    pe.setdefault('bpartials_by', {})[P.groups] = torch.zeros(max(1, bp[P.groups]) * pe['p'].cout * 2, dtype=torch.float32, device=pe['z'].t.device)
+                if bp[P.groups]:
+                    pe['bpartials'] = pe['bpartials_by'][P.groups]
                     bn_arg = (pe['z'], pe['stats'], P.groups, pe['bpartials'])
-                pe['bparts_used'] = pe['bparts'] if bn_arg else 0
+                pe['bparts_used'] = bp[P.groups] if bn_arg else 0
             elif prev_normed:
                 P.layers[li - 1]['bparts_used'] = 0
             E.conv_backward(node, book, prec, dbias_accumulate=accumulate, wgrad_accumulate=accumulate, wgrad=param_grads, dbias_done=bool(logits_ready and L['last']),

@@ -340,6 +340,18 @@ int hv_ca_score_backward_prep(const float* dS, const float* S0, const float* nor
 int hv_ca_patches_backward(const float* dwp, const float* wp, const float* coef, float* df, int B, int H, int W, int C,
                            int df_ld, int accumulate, void* stream);
 
+/* The matching scores and their gradient on the PIXEL Gram matrix (csrc/attention_gram.hip; fp16 mode, C = 64, attention map width 32 or 64): the 3x3
+ * patches are both filters and inputs of models/inpaint_networks.py:327-344, so S0[p][l] = rnorm[l] * sum over the 3x3 offsets t of <fd[p + t], fd[l + t]>
+ * (K = C instead of 9 C; no patch tables), and d fd = box(Gs) fd + (3x3 sum of coef) fd with Gs / coef from hv_ca_score_backward_prep.
+ * hv_ca_gram_down: nearest 1/2 downsampling of the fp16 map f [B][H][W][f_ld] -> fd_h [B][L][C], fdT_h [B][C][L] (fp16), q [B][L] = |fd|^2.
+ * hv_ca_gram_scores: S0 [B][L][L] (row p, column l), norm / rnorm [B][L] (= hv_ca_patches' outputs).
+ * hv_ca_gram_backward: df[b][2y][2x][c] += the gradient wrt fd (replaces the L x 9C gradient GEMM + hv_ca_patches_backward).
+ * HV_ERR_UNSUPPORTED for other shapes (the caller keeps the patch-table route). */
+int hv_ca_gram_down(const void* f, int f_f16, int B, int H, int W, int C, int f_ld, void* fd_h, void* fdT_h, float* q, void* stream);
+int hv_ca_gram_scores(const void* fd_h, const float* q, int B, int h, int w, int C, float* S0, float* norm, float* rnorm, void* stream);
+int hv_ca_gram_backward(const float* Gs, const void* fd_h, const void* fdT_h, const float* coef, int B, int h, int w, int C, float* df, int df_ld,
+                        void* stream);
+
 /* ---------------------------------------------------------------- step-level fused operators (Pix2PixModel)
  * Sobel edge magnitude (models/edge_operator.py:29-49). */
 int hv_sobel(const float* img, float* out, int B, int H, int W, void* stream);

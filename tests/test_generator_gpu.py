@@ -475,3 +475,45 @@ def test_batchnorm_backward_sums_from_the_data_gradient_epilogue(groups, monkeyp
         assert torch.isfinite(a).all() and b.abs().max().item() > 0, k
         assert (a - b).norm().item() <= 2e-3 * b.norm().item(), (k, (a - b).norm().item(), b.norm().item())
     assert (res[True][1] - res[False][1]).norm().item() <= 2e-3 * res[False][1].norm().item()
+    # the same plan (same input size) with the other group count -- the batched fake | real pass and a plain pass of equal size share a plan in the train step
+    monkeypatch.setattr(networks, 'CONV_BSTATS', True)
+    P = net.run_forward(x, training=True, groups=3 - groups)
+    dx2 = net.run_backward(P, torch.ones_like(P.logits), need_dx=True, param_grads=True)
+    net.finish()
+    torch.cuda.synchronize()
+    assert all(ent.get('bparts_used', 0) > 0 for ent in P.layers[1:-1]) and torch.isfinite(dx2).all()
+
+
+@pytest.mark.parametrize('size', [64, 128])
+def test_attention_scores_on_the_pixel_gram_matrix_match_the_patch_table_route(size, monkeypatch):
+    """fp16 mode, 64-channel map (the fine generator's attention input at 256 x 256 / 512 x 512 images: a 32- / 64-wide attention map): the matching scores
+    and their gradient computed on the pixel Gram matrix (hv_ca_gram_scores: K = C per score, no patch tables; hv_ca_gram_backward: d fd = box(Gs) fd + the
+    norm term) against the same block with the K = 9C patch GEMMs -- both round the same operands to fp16, only the summation order differs: scores,
+    norms, output and the input gradient; the kernels taken are checked."""
+    from hvgan import engine, ops
+    monkeypatch.setenv('HV_PRECISION', 'fp16')
+    dev = torch.device('cuda:0')
+    B, C, H = 2, 64, size
+    gen = torch.Generator().manual_seed(17)
+    f = torch.randn(B, H, H, C, generator=gen).to(dev).half()
+    mask = torch.zeros(B, 1, 4 * H, 4 * H, device=dev)
+    mask[:, :, 4 * H // 3:4 * H // 3 + 40, :] = 1
+    dout = (torch.randn(B, H, H, C, generator=gen) * 0.05).to(dev).half()
+    res = {}
+    for gram in (True, False):
+        monkeypatch.setattr(engine, 'CA_GRAM', gram)
+        plan = engine.AttentionPlan(B, H, H, C, dev, (4 * H, 4 * H))
+        out = ops.Act(torch.zeros(B, H, H, C, dtype=torch.float16, device=dev))
+        plan.forward(ops.Act(f), mask, out, 'fp16')
+        assert plan.gemm and plan.gram == gram
+        df = ops.Act(torch.zeros(B, H, H, C, dtype=torch.float16, device=dev))
+        plan.backward(ops.Act(dout), df, False, 'fp16')
+        torch.cuda.synchronize()
+        res[gram] = dict(S0=plan.S0.t.float().cpu(), norm=plan.norm.cpu(), out=out.t.float().cpu(), df=df.t.float().cpu())
+    a, b = res[True], res[False]
+    assert (a['norm'] - b['norm']).abs().max().item() <= 1e-4 * b['norm'].abs().max().item()
+    s = b['S0'].abs().max().item()
+    assert s > 1.0 and (a['S0'] - b['S0']).abs().max().item() <= 2e-3 * s, ((a['S0'] - b['S0']).abs().max().item(), s)
+    assert (a['out'] - b['out']).abs().max().item() <= 2e-2 * max(1.0, b['out'].abs().max().item())
+    rel = (a['df'] - b['df']).norm().item() / b['df'].norm().item()
+    assert b['df'].abs().max().item() > 0 and rel <= 2e-2, rel
