@@ -54,84 +54,90 @@ extern "C" int hv_ca_gram_down(const void* f, int f_f16, int B, int H, int W, in
     return HV_OK;
 }
 
-// the w x w box filter on three diagonal blocks held in LDS: out[r][c] = sum over the valid blocks tyi and tx in {-1, 0, 1} of Gt[tyi][r + tx][c + tx]
+// The 3x3 box filter on the diagonal is separable: T = box_x(sum over ty of the three diagonal blocks).  The ty sum is taken where the blocks are produced
+// (in the MFMA accumulators of the scores kernel, in the loading registers of the gradient kernel), so one w x w block sits in LDS and an output is three
+// reads along its diagonal: out[r][c] = G[r - 1][c - 1] + G[r][c] + G[r + 1][c + 1] (terms outside [0, w) dropped: they are outside the map)
 template <int BW>
-__device__ __forceinline__ float gram_box(const float (*Gt)[BW][BW + 1], const bool (&bv)[3], int r, int c) {
-    float acc = 0.f;
-#pragma unroll
-    for (int tyi = 0; tyi < 3; ++tyi) {
-        if (!bv[tyi]) continue;       // scalar
-#pragma unroll
-        for (int tx = -1; tx <= 1; ++tx)
-            if ((unsigned)(r + tx) < (unsigned)BW && (unsigned)(c + tx) < (unsigned)BW) acc += Gt[tyi][r + tx][c + tx];
-    }
+__device__ __forceinline__ float gram_box(const float (*G)[BW + 1], int r, int c) {
+    float acc = G[r][c];
+    if (r >= 1 && c >= 1) acc += G[r - 1][c - 1];
+    if (r + 1 < BW && c + 1 < BW) acc += G[r + 1][c + 1];
     return acc;
 }
 
-// ---- scores: one workgroup per (sample, grid row py of p, grid row ly of l) ------------------------------------------------------------------------------
+// norm[l] = max(sqrt(3x3 box of the pixels' squared norms), 1e-4), rnorm = 1 / norm  (= hv_ca_patches' outputs)
+__global__ __launch_bounds__(256) void ca_gram_norm_kernel(const float* __restrict__ q, int h, int w, long long n, float* __restrict__ norm, float* __restrict__ rnorm) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int L = h * w, l = (int)(i % L), y = l / w, x = l - y * w;
+    const float* qb = q + (i - l);
+    float n2 = 0.f;
+#pragma unroll
+    for (int ty = -1; ty <= 1; ++ty)
+#pragma unroll
+        for (int tx = -1; tx <= 1; ++tx)
+            if ((unsigned)(y + ty) < (unsigned)h && (unsigned)(x + tx) < (unsigned)w) n2 += qb[(y + ty) * w + x + tx];
+    const float nv = fmaxf(sqrtf(n2), 1e-4f);
+    norm[i] = nv;
+    rnorm[i] = 1.f / nv;
+}
+
+// ---- scores: one workgroup per (sample, grid row py of p, group of LG grid rows of l); the block's three Gram products are summed in the accumulators
 template <int BW>
-__global__ __launch_bounds__(256) void ca_gram_scores_kernel(const _Float16* __restrict__ fd_h, const float* __restrict__ q, int h, float* __restrict__ S0,
-                                                             float* __restrict__ norm, float* __restrict__ rnorm) {
+__global__ __launch_bounds__(256) void ca_gram_scores_kernel(const _Float16* __restrict__ fd_h, const float* __restrict__ rnorm, int h, int lg, float* __restrict__ S0) {
     constexpr int C = 64, NT = BW / 16, TPW = NT * NT / 4;      // MFMA tiles per wave
-    __shared__ float Gt[3][BW][BW + 1];
-    const int w = BW, L = h * w;
+    __shared__ float Gt[2][BW][BW + 1];
+    const int w = BW, L = h * w, ngr = (h + lg - 1) / lg;
     int id = blockIdx.x;
-    const int ly = id % h; id /= h;
+    const int lgi = id % ngr; id /= ngr;
     const int py = id % h;
     const long long b = id / h;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const _Float16* fb = fd_h + b * (long long)L * C;
-    bool bv[3];
-#pragma unroll
-    for (int tyi = 0; tyi < 3; ++tyi) bv[tyi] = (unsigned)(py + tyi - 1) < (unsigned)h && (unsigned)(ly + tyi - 1) < (unsigned)h;
-#pragma unroll
-    for (int tyi = 0; tyi < 3; ++tyi) {
-        if (!bv[tyi]) continue;
-        const _Float16* prow = fb + (long long)(py + tyi - 1) * w * C;
-        const _Float16* lrow = fb + (long long)(ly + tyi - 1) * w * C;
+    const float* rb = rnorm + b * L;
+    float* Sb = S0 + b * (long long)L * L;
+    const int ly1 = min(h, (lgi + 1) * lg);
+    int buf = 0;
+    for (int ly = lgi * lg; ly < ly1; ++ly, buf ^= 1) {
 #pragma unroll
         for (int u = 0; u < TPW; ++u) {
             const int tile = wave * TPW + u, mi = tile / NT, ni = tile - mi * NT;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < C / 32; ++ks) {
-                const f16x8 a = *reinterpret_cast<const f16x8*>(prow + (mi * 16 + (lane & 15)) * C + ks * 32 + 8 * (lane >> 4));
-                const f16x8 bb = *reinterpret_cast<const f16x8*>(lrow + (ni * 16 + (lane & 15)) * C + ks * 32 + 8 * (lane >> 4));
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bb, acc, 0, 0, 0);
+            for (int ty = -1; ty <= 1; ++ty) {
+                if ((unsigned)(py + ty) >= (unsigned)h || (unsigned)(ly + ty) >= (unsigned)h) continue;      // scalar: the block is outside the map
+                const _Float16* prow = fb + ((long long)(py + ty) * w + mi * 16 + (lane & 15)) * C + 8 * (lane >> 4);
+                const _Float16* lrow = fb + ((long long)(ly + ty) * w + ni * 16 + (lane & 15)) * C + 8 * (lane >> 4);
+#pragma unroll
+                for (int ks = 0; ks < C / 32; ++ks)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const f16x8*>(prow + ks * 32), *reinterpret_cast<const f16x8*>(lrow + ks * 32), acc, 0, 0, 0);
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Gt[tyi][mi * 16 + 4 * (lane >> 4) + r][ni * 16 + (lane & 15)] = acc[r];
+            for (int r = 0; r < 4; ++r) Gt[buf][mi * 16 + 4 * (lane >> 4) + r][ni * 16 + (lane & 15)] = acc[r];
         }
-    }
-    __syncthreads();
-    const float* qb = q + b * L;
-    float* Sb = S0 + b * (long long)L * L;
-    for (int it = threadIdx.x; it < BW * BW / 4; it += 256) {
-        const int r = it / (BW / 4), c0 = (it - r * (BW / 4)) * 4;
-        float o[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int c = c0 + u;
-            float n2 = 0.f;                     // |patch_l|^2 = the 3x3 box of the pixels' squared norms
-#pragma unroll
-            for (int ty = -1; ty <= 1; ++ty)
-#pragma unroll
-                for (int tx = -1; tx <= 1; ++tx)
-                    if ((unsigned)(ly + ty) < (unsigned)h && (unsigned)(c + tx) < (unsigned)w) n2 += qb[(ly + ty) * w + c + tx];
-            const float nv = fmaxf(sqrtf(n2), 1e-4f);
-            o[u] = gram_box<BW>(Gt, bv, r, c) * (1.f / nv);
-            if (py == 0 && r == 0) { norm[b * L + ly * w + c] = nv; rnorm[b * L + ly * w + c] = 1.f / nv; }
+        __syncthreads();      // (two buffers: the next round's stores go to the other one, and the round after that is behind the next barrier)
+        for (int it = threadIdx.x; it < BW * BW / 4; it += 256) {
+            const int r = it / (BW / 4), c0 = (it - r * (BW / 4)) * 4;
+            const float4 rn = *reinterpret_cast<const float4*>(rb + ly * w + c0);
+            *reinterpret_cast<float4*>(Sb + (long long)(py * w + r) * L + ly * w + c0) =
+                make_float4(gram_box<BW>(Gt[buf], r, c0) * rn.x, gram_box<BW>(Gt[buf], r, c0 + 1) * rn.y, gram_box<BW>(Gt[buf], r, c0 + 2) * rn.z,
+                            gram_box<BW>(Gt[buf], r, c0 + 3) * rn.w);
         }
-        *reinterpret_cast<float4*>(Sb + (long long)(py * w + r) * L + ly * w + c0) = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
 
 extern "C" int hv_ca_gram_scores(const void* fd_h, const float* q, int B, int h, int w, int C, float* S0, float* norm, float* rnorm, void* stream) {
     if (!fd_h || !q || !S0 || !norm || !rnorm || B <= 0 || h <= 0 || w <= 0) return HV_ERR_ARG;
-    if (C != 64 || (w != 32 && w != 64) || ((uintptr_t)fd_h & 15) || ((uintptr_t)S0 & 15) || (long long)B * h * h >= (1ll << 31)) return HV_ERR_UNSUPPORTED;
-    const dim3 grid((unsigned)(B * h * h));
-    if (w == 32) hipLaunchKernelGGL(ca_gram_scores_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const _Float16*>(fd_h), q, h, S0, norm, rnorm);
-    else hipLaunchKernelGGL(ca_gram_scores_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const _Float16*>(fd_h), q, h, S0, norm, rnorm);
+    if (C != 64 || (w != 32 && w != 64) || ((uintptr_t)fd_h & 15) || ((uintptr_t)S0 & 15) || ((uintptr_t)rnorm & 15) || (long long)B * h * h >= (1ll << 31)) return HV_ERR_UNSUPPORTED;
+    const long long n = (long long)B * h * w;
+    hipLaunchKernelGGL(ca_gram_norm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, q, h, w, n, norm, rnorm);
+    HV_LAUNCH_CHECK();
+    static const int lg_env = getenv("HV_CA_GRAM_LG") ? atoi(getenv("HV_CA_GRAM_LG")) : 0;      // tuning knob: grid rows of l per workgroup
+    int lg = lg_env > 0 ? lg_env : 8;
+    while (lg > 1 && (long long)B * h * ((h + lg - 1) / lg) < 1024) lg >>= 1;      // keep >= 4 workgroups per CU in flight
+    const dim3 grid((unsigned)(B * h * ((h + lg - 1) / lg)));
+    if (w == 32) hipLaunchKernelGGL(ca_gram_scores_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const _Float16*>(fd_h), rnorm, h, lg, S0);
+    else hipLaunchKernelGGL(ca_gram_scores_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const _Float16*>(fd_h), rnorm, h, lg, S0);
     HV_LAUNCH_CHECK();
     return HV_OK;
 }
@@ -141,8 +147,8 @@ template <int BW>
 __global__ __launch_bounds__(256) void ca_gram_backward_kernel(const float* __restrict__ Gs, const _Float16* __restrict__ fd_h, const _Float16* __restrict__ fdT_h,
                                                                const float* __restrict__ coef, int h, float* __restrict__ df, int df_ld) {
     constexpr int C = 64, MT = BW / 16, NTL = C / 16, TPW = MT * NTL / 4, LDE = BW + 8;
-    constexpr int NV = 3 * BW * BW / 4 / 256;            // float4 items of the three Gs blocks per thread
-    __shared__ float Gt[3][BW][BW + 1];
+    constexpr int NV = BW * BW / 4 / 256;                // float4 items of ONE block per thread; the three diagonal blocks are summed item by item as they arrive
+    __shared__ float Gt[BW][BW + 1];
     __shared__ __attribute__((aligned(16))) _Float16 Eh[BW][LDE];
     const int w = BW, L = h * w, H = 2 * h, W = 2 * w;
     const int ay = blockIdx.x % h;
@@ -153,23 +159,26 @@ __global__ __launch_bounds__(256) void ca_gram_backward_kernel(const float* __re
     f32x4 acc[TPW];
 #pragma unroll
     for (int u = 0; u < TPW; ++u) acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float4 pre[NV];
+    float4 pre[3][NV];
     auto fetch = [&](int by) __attribute__((always_inline)) {       // the three diagonal blocks (ay + ty, by + ty) of Gs, zeros where a block leaves the map
 #pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            const int it = threadIdx.x + k * 256, tyi = it / (BW * BW / 4), rem = it - tyi * (BW * BW / 4), r = rem / (BW / 4), c4 = (rem - r * (BW / 4)) * 4;
+        for (int tyi = 0; tyi < 3; ++tyi) {
             const int ra = ay + tyi - 1, rb = by + tyi - 1;
-            pre[k] = ((unsigned)ra < (unsigned)h && (unsigned)rb < (unsigned)h)
-                         ? *reinterpret_cast<const float4*>(Gb + (long long)(ra * w + r) * L + rb * w + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool ok = (unsigned)ra < (unsigned)h && (unsigned)rb < (unsigned)h;       // scalar
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const int it = threadIdx.x + k * 256, r = it / (BW / 4), c4 = (it - r * (BW / 4)) * 4;
+                pre[tyi][k] = ok ? *reinterpret_cast<const float4*>(Gb + (long long)(ra * w + r) * L + rb * w + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
     };
     fetch(0);
-    const bool all3[3] = {true, true, true};
     for (int by = 0; by < h; ++by) {
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
-            const int it = threadIdx.x + k * 256, tyi = it / (BW * BW / 4), rem = it - tyi * (BW * BW / 4), r = rem / (BW / 4), c4 = (rem - r * (BW / 4)) * 4;
-            Gt[tyi][r][c4] = pre[k].x; Gt[tyi][r][c4 + 1] = pre[k].y; Gt[tyi][r][c4 + 2] = pre[k].z; Gt[tyi][r][c4 + 3] = pre[k].w;
+            const int it = threadIdx.x + k * 256, r = it / (BW / 4), c4 = (it - r * (BW / 4)) * 4;
+            Gt[r][c4] = (pre[0][k].x + pre[1][k].x) + pre[2][k].x; Gt[r][c4 + 1] = (pre[0][k].y + pre[1][k].y) + pre[2][k].y;
+            Gt[r][c4 + 2] = (pre[0][k].z + pre[1][k].z) + pre[2][k].z; Gt[r][c4 + 3] = (pre[0][k].w + pre[1][k].w) + pre[2][k].w;
         }
         // this row block's B operands (fd of grid row by, pixel-contiguous: the transposed table), requested before the barrier
         f16x8 bf[TPW][BW / 32];
@@ -186,7 +195,7 @@ __global__ __launch_bounds__(256) void ca_gram_backward_kernel(const float* __re
             const int r = it / (BW / 4), c0 = (it - r * (BW / 4)) * 4;
             f16x4 e4;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) e4[u] = (_Float16)gram_box<BW>(Gt, all3, r, c0 + u);      // (blocks outside the map were fetched as zeros)
+            for (int u = 0; u < 4; ++u) e4[u] = (_Float16)gram_box<BW>(Gt, r, c0 + u);
             *reinterpret_cast<f16x4*>(&Eh[r][c0]) = e4;
         }
         __syncthreads();

@@ -186,7 +186,6 @@ __device__ __forceinline__ void g4_epilogue(const G4K& p, f32x4 (&acc)[4][MT], c
         const int ch0 = cob_s[s] + (pc & 7) * 8;
         const int grp = n_img / p.bn_ipg;
         const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.bn_x), 0, 0x7ffffff0u, 0x00020000);
-        const __amdgpu_buffer_rsrc_t ssrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bn_stats), 0, 0x7ffffff0u, 0x00020000);
         u32x4 xreg[OITEMS];
 #pragma unroll
         for (int k = 0; k < OITEMS; ++k) {
@@ -197,13 +196,6 @@ __device__ __forceinline__ void g4_epilogue(const G4K& p, f32x4 (&acc)[4][MT], c
             const long long opix = (long long)(n_img * p.Ho + ho) * p.Wo + wo;
             xreg[k] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, ooff[k] >= 0 ? (unsigned)((opix * p.bn_x_ld + p.bn_x_coff + ch0) * 2) : HV_OOB, 0, 0);
         }
-        f32x4 mr[4];      // mean[8], rstd[8] of this thread's channels in the image's group
-        const unsigned sb = (unsigned)((grp * 2 * p.Cout + ch0) * 4);
-        const bool chok = ch0 < p.Cout;
-        mr[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ssrc, chok ? sb : HV_OOB, 0, 0));
-        mr[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ssrc, chok ? sb + 16u : HV_OOB, 0, 0));
-        mr[2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ssrc, chok ? sb + (unsigned)p.Cout * 4u : HV_OOB, 0, 0));
-        mr[3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ssrc, chok ? sb + (unsigned)p.Cout * 4u + 16u : HV_OOB, 0, 0));
         float s1[8], s2[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
@@ -212,9 +204,9 @@ __device__ __forceinline__ void g4_epilogue(const G4K& p, f32x4 (&acc)[4][MT], c
             if (ooff[k] < 0) continue;
             const f16x8 v8 = __builtin_bit_cast(f16x8, o[k]), x8 = __builtin_bit_cast(f16x8, xreg[k]);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float g = (float)v8[e], xh = ((float)x8[e] - mr[e >> 2][e & 3]) * mr[2 + (e >> 2)][e & 3];
-                s1[e] += g; s2[e] += g * xh;
+            for (int e = 0; e < 8; ++e) {      // sum g and sum g * x: the mean / rstd of xhat = (x - mean) * rstd enter once, when the tile's sums are folded
+                const float g = (float)v8[e];
+                s1[e] += g; s2[e] += g * (float)x8[e];
             }
         }
         __syncthreads();                       // the staging tile has been read into registers by every thread
@@ -223,15 +215,20 @@ __device__ __forceinline__ void g4_epilogue(const G4K& p, f32x4 (&acc)[4][MT], c
 #pragma unroll
         for (int e = 0; e < 8; ++e) { mine[e] = s1[e]; mine[8 + e] = s2[e]; }
         __syncthreads();
-        if (tid < 256) {      // 128 columns (two 64-channel slots) x {sum g, sum g * xhat}
-            const int pq = tid >> 4, e = tid & 15;
-            float sum = 0.f;
+        if (tid < 128) {      // one thread per column (two 64-channel slots): sum g, and sum g * xhat = rstd * (sum g x - mean * sum g)
+            const int pq = tid >> 3, e = tid & 7;
+            float sg = 0.f, sgx = 0.f;
 #pragma unroll 8
-            for (int r = 0; r < 32; ++r) sum += red[(r * 16 + pq) * 16 + e];
-            const int sl = pq >> 3, ch = cob_s[sl] + (pq & 7) * 8 + (e & 7);
+            for (int r = 0; r < 32; ++r) { sg += red[(r * 16 + pq) * 16 + e]; sgx += red[(r * 16 + pq) * 16 + 8 + e]; }
+            const int sl = pq >> 3, ch = cob_s[sl] + (pq & 7) * 8 + e;
             // MODE 1: the four output-parity classes of a tile are four parts (two per workgroup of the class pair); else one part per workgroup
             const long long part = MODE == 1 ? (long long)blockIdx.x * 4 + cls_s[sl] : (long long)blockIdx.x;
-            if (ch < p.Cout) p.bstats[(part * p.Cout + ch) * 2 + (e >> 3)] = sum;
+            if (ch < p.Cout) {
+                const float mean = p.bn_stats[(long long)grp * 2 * p.Cout + ch], rstd = p.bn_stats[(long long)grp * 2 * p.Cout + p.Cout + ch];
+                float* o2 = p.bstats + (part * p.Cout + ch) * 2;
+                o2[0] = sg;
+                o2[1] = rstd * (sgx - mean * sg);
+            }
         }
     }
 }

@@ -103,21 +103,15 @@ __global__ __launch_bounds__(256) void logits_dgrad_kernel(const ThinK p, const 
     }
     __syncthreads();
     // batch-norm backward sums (hv_conv_desc.bstats): a lane's pieces always carry the same 8 channels (piece lane % PPR of the slice), so it keeps
-    // sum g and sum g * xhat of those channels per normalisation group over its whole grid-stride loop; one part per (group, workgroup of the slice)
+    // sum g and sum g * x of those channels per normalisation group over its whole grid-stride loop (two multiply-adds per element; the mean / rstd of
+    // xhat = (x - mean) * rstd enter once, when the lanes' sums are folded); one part per (group, workgroup of the slice)
     const bool bst = p.bstats != nullptr;       // scalar
-    const int pcl = lane % PPR, chl = cb + pcl * 8;
-    float bmean[2][8], brstd[2][8], bs1[2][8], bs2[2][8];
+    const int pcl = lane % PPR;
+    float bs1[2][8], bs2[2][8];
 #pragma unroll
     for (int g2 = 0; g2 < 2; ++g2)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            bs1[g2][e] = bs2[g2][e] = 0.f;
-            bmean[g2][e] = 0.f; brstd[g2][e] = 0.f;
-            if (bst && g2 < p.bn_groups) {
-                bmean[g2][e] = p.bn_stats[(long long)g2 * 2 * p.Cout + chl + e];
-                brstd[g2][e] = p.bn_stats[(long long)g2 * 2 * p.Cout + p.Cout + chl + e];
-            }
-        }
+        for (int e = 0; e < 8; ++e) bs1[g2][e] = bs2[g2][e] = 0.f;
     const int Hi = p.H - 1, Wi = p.W - 1;                                // gradient (input) size; p.H, p.W = output size
     const int gpr = (p.W + 15) >> 4;                                     // 16-pixel groups per output row
     const int ngroups = p.B * p.H * gpr;
@@ -188,15 +182,18 @@ __global__ __launch_bounds__(256) void logits_dgrad_kernel(const ThinK p, const 
             if (bst) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float gv = (float)v8[e];
-                    if (bgi == 0) { bs1[0][e] += gv; bs2[0][e] += gv * (((float)x8[j][e] - bmean[0][e]) * brstd[0][e]); }
-                    else { bs1[1][e] += gv; bs2[1][e] += gv * (((float)x8[j][e] - bmean[1][e]) * brstd[1][e]); }
+                    const float gv = (float)v8[e], gx = gv * (float)x8[j][e];
+                    if (bgi == 0) { bs1[0][e] += gv; bs2[0][e] += gx; }
+                    else { bs1[1][e] += gv; bs2[1][e] += gx; }
                 }
             }
         }
     }
     if (bst) {      // fold the 256 / PPR lanes that share a piece, group by group, in a fixed order; row = group * (workgroups per slice) + this workgroup
-        __shared__ float red[256 * 16];
+        // the fold buffer: 256 x 16 floats.  With 128-channel slices the filter copy `wl` has exactly that size and nobody reads it any more
+        __shared__ float red_small[NP == 4 ? 1 : 256 * 16];
+        float* red = NP == 4 ? reinterpret_cast<float*>(wl) : red_small;
+        static_assert(NP != 4 || sizeof(wl) >= 256 * 16 * sizeof(float), "fold buffer aliases the filter copy");
         const int gbw = gridDim.x >> nq_log, wgi = blockIdx.x >> nq_log;
         for (int g2 = 0; g2 < p.bn_groups; ++g2) {
             __syncthreads();
@@ -204,11 +201,15 @@ __global__ __launch_bounds__(256) void logits_dgrad_kernel(const ThinK p, const 
 #pragma unroll
             for (int e = 0; e < 8; ++e) { mine2[e] = g2 == 0 ? bs1[0][e] : bs1[1][e]; mine2[8 + e] = g2 == 0 ? bs2[0][e] : bs2[1][e]; }
             __syncthreads();
-            if (threadIdx.x < PPR * 16) {
-                const int pq = threadIdx.x >> 4, e = threadIdx.x & 15;
-                float sum = 0.f;
-                for (int r = 0; r < 256 / PPR; ++r) sum += red[(r * PPR + pq) * 16 + e];
-                p.bstats[(((long long)g2 * gbw + wgi) * p.Cout + cb + pq * 8 + (e & 7)) * 2 + (e >> 3)] = sum;
+            if (threadIdx.x < PPR * 8) {      // one thread per channel of the slice: sum g, and sum g * xhat = rstd * (sum g x - mean * sum g)
+                const int pq = threadIdx.x >> 3, e = threadIdx.x & 7;
+                float sg = 0.f, sgx = 0.f;
+                for (int r = 0; r < 256 / PPR; ++r) { sg += red[(r * PPR + pq) * 16 + e]; sgx += red[(r * PPR + pq) * 16 + 8 + e]; }
+                const int ch = cb + pq * 8 + e;
+                const float mean = p.bn_stats[(long long)g2 * 2 * p.Cout + ch], rstd = p.bn_stats[(long long)g2 * 2 * p.Cout + p.Cout + ch];
+                float* o = p.bstats + (((long long)g2 * gbw + wgi) * p.Cout + ch) * 2;
+                o[0] = sg;
+                o[1] = rstd * (sgx - mean * sg);
             }
         }
     }

@@ -30,6 +30,9 @@ struct WTrK {
     int Hl, Wl, in_shift, Wp, img_stride, x_ld, x_coff, Cin;
     int Ho, Wo, g_ld, g_coff, Cout, pad;
     int tiles_x, tiles_per_img, ntiles;
+    int dil, tiles_per_sub;      // dilation d > 1 (3x3, stride 1, pad d): the layer as d*d undilated convolutions on the residue sub-grids (Ho/d x Wo/d pixels, step d);
+                                 // tiles_per_img = d*d * tiles_per_sub, Ho / Wo / Hl / Wl are the SUB-grid extents and Hf / Wf the full ones
+    int Hf, Wf;
     long long slab;              // floats per slab = Cout * KS*KS * Cin
     unsigned x_bytes, g_bytes;   // buffer descriptor ranges
     float* bias_out;             // per-workgroup column sums of g (bias gradient), [gridDim.x][Cout], or NULL
@@ -90,7 +93,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(const WTrK p) {
     const __amdgpu_buffer_rsrc_t gsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.g), 0, p.g_bytes, 0x00020000);
     u32x4 rg[GPT], rx[XPT];
     auto prefetch = [&](int tile) __attribute__((always_inline)) {
-        const int n_img = tile / p.tiles_per_img, tr = tile - n_img * p.tiles_per_img;
+        const int n_img = tile / p.tiles_per_img;
+        int tr = tile - n_img * p.tiles_per_img;
+        // dilation d: tile of residue sub-grid (ry, rx); sub-grid pixel (y, x) is real pixel (ry + d y, rx + d x) of both tensors (d = 1: ry = rx = 0)
+        const int d = p.dil, sub = tr / p.tiles_per_sub;
+        tr -= sub * p.tiles_per_sub;
+        const int ry = sub / d, rxo = sub - ry * d;
         const int oy0 = (tr / p.tiles_x) * TH, ox0 = (tr % p.tiles_x) * TW;
 #pragma unroll
         for (int i = 0; i < GPT; ++i) {
@@ -98,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(const WTrK p) {
             const int c8 = e % (BN / 8), pix = e / (BN / 8), ty = pix / TW, tx = pix - ty * TW;
             const int oy = oy0 + ty, ox = ox0 + tx, co = co0 + c8 * 8;
             const bool ok = e < GI && oy < p.Ho && ox < p.Wo && co < p.Cout;
-            rg[i] = __builtin_amdgcn_raw_buffer_load_b128(gsrc, ok ? (unsigned)(((n_img * p.Ho + oy) * p.Wo + ox) * p.g_ld + p.g_coff + co) * 2u : 0x80000000u, 0, 0);
+            rg[i] = __builtin_amdgcn_raw_buffer_load_b128(gsrc, ok ? (unsigned)(((n_img * p.Hf + ry + d * oy) * p.Wf + rxo + d * ox) * p.g_ld + p.g_coff + co) * 2u : 0x80000000u, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < XPT; ++i) {
@@ -107,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(const WTrK p) {
             const int hi = oy0 * ST - p.pad + py, wi = ox0 * ST - p.pad + px, ci = ci0 + c8 * 8;
             const bool ok = e < XI && (unsigned)hi < (unsigned)p.Hl && (unsigned)wi < (unsigned)p.Wl && ci < p.Cin;
             rx[i] = __builtin_amdgcn_raw_buffer_load_b128(
-                xsrc, ok ? (unsigned)(n_img * p.img_stride + ((hi >> p.in_shift) * p.Wp + (wi >> p.in_shift)) * p.x_ld + p.x_coff + ci) * 2u : 0x80000000u, 0, 0);
+                xsrc, ok ? (unsigned)(n_img * p.img_stride + (((ry + d * hi) >> p.in_shift) * p.Wp + ((rxo + d * wi) >> p.in_shift)) * p.x_ld + p.x_coff + ci) * 2u : 0x80000000u, 0, 0);
         }
     };
     auto flush = [&]() __attribute__((always_inline)) {
@@ -492,13 +500,21 @@ __global__ __launch_bounds__(512, 1) void wgrad_trd_kernel(const WTrK p) {
 #endif
 }
 
-struct WTrPlan { int BN, BC, gx; size_t lds; bool dma; };
+struct WTrPlan { int BN, BC, gx, dil; size_t lds; bool dma; };
 
 static bool wgrad_tr_plan(const hv_wgrad_desc* d, WTrPlan* pl) {
     static const int enabled = getenv("HV_WGRAD_TR") ? atoi(getenv("HV_WGRAD_TR")) : 1;   // A/B knob
-    if (!enabled || d->precision != HV_F16 || !d->x_f16 || !d->g_f16 || d->dil != 1 || d->KH != d->KW) return false;
+    if (!enabled || d->precision != HV_F16 || !d->x_f16 || !d->g_f16 || d->KH != d->KW) return false;
     if (!((d->KH == 3 || d->KH == 4) && (d->stride == 1 || d->stride == 2))) return false;
-    if (d->Ho != (d->H + 2 * d->pad - d->KH) / d->stride + 1 || d->Wo != (d->W + 2 * d->pad - d->KW) / d->stride + 1) return false;
+    pl->dil = 1;
+    if (d->dil != 1) {
+        // dilated same-size 3x3 layers (the generators' d = 2, 4, 8): d*d undilated weight gradients on the residue sub-grids, summed in the same accumulators
+        // (round 4; they ran in the gather kernel at 24.5 us).  d = 16 leaves 4 x 4-pixel sub-grids in 8 x 16 tiles: stays there
+        static const int dilated = getenv("HV_WGRAD_TR_DIL") ? atoi(getenv("HV_WGRAD_TR_DIL")) : 1;      // A/B knob
+        if (!dilated || (d->dil != 2 && d->dil != 4 && d->dil != 8) || d->KH != 3 || d->stride != 1 || d->pad != d->dil || d->in_shift) return false;
+        if (d->H % d->dil || d->W % d->dil || d->Ho != d->H || d->Wo != d->W) return false;
+        pl->dil = d->dil;
+    } else if (d->Ho != (d->H + 2 * d->pad - d->KH) / d->stride + 1 || d->Wo != (d->W + 2 * d->pad - d->KW) / d->stride + 1) return false;
     // 16-byte staging items: 8-channel groups must be whole and aligned in both tensors
     if ((d->Cin & 7) || (d->Cout & 7) || (d->x_ld & 7) || (d->x_coff & 7) || (d->g_ld & 7) || (d->g_coff & 7)) return false;
     if (d->Cout < 32 || d->Cin < 16) return false;        // narrower layers: wgrad_halo_kernel / the gather kernel
@@ -518,13 +534,13 @@ static bool wgrad_tr_plan(const hv_wgrad_desc* d, WTrPlan* pl) {
     pl->lds = (size_t)128 * wtr_stride(pl->BN, 1) + (size_t)PH * PW * wtr_stride(pl->BC, d->stride);
     // the LDS-DMA form: 64-channel output blocks, its fixed input block (32 channels at stride 1, 16 at stride 2), no fused upsampling
     static const int dma_on = getenv("HV_WGRAD_TRD") ? atoi(getenv("HV_WGRAD_TRD")) : 1;   // A/B knob
-    pl->dma = dma_on && pl->BN == 64 && pl->BC == 32 && d->in_shift == 0;
+    pl->dma = dma_on && pl->BN == 64 && pl->BC == 32 && d->in_shift == 0 && pl->dil == 1;
     const bool dma_candidate = pl->dma;
     if (pl->dma) {
         const int PWP = d->stride == 1 ? 24 : 48, XI = PH * PWP * (pl->BC / 8);
         pl->lds = (size_t)2 * (8 * 16 * 128 + (XI + 63) / 64 * 1024);
     }
-    const long long ntiles = (long long)d->B * hv_cdiv(d->Ho, 8) * hv_cdiv(d->Wo, 16);
+    const long long ntiles = (long long)d->B * pl->dil * pl->dil * hv_cdiv(d->Ho / pl->dil, 8) * hv_cdiv(d->Wo / pl->dil, 16);
     // workgroups wanted per launch (split over pixel chunks): every chunk writes a whole slab of dW, so a layer with a small dW tile count (the
     // generators' 64-channel layers: 2 tiles, 256 slabs of 147 KB = 38 MB for 17 MB of operands) is bound by its slab traffic, not by its MFMAs
     // (step-level A/B, round 3, same box: PatchGAN layers 512 -> 256 workgroups 9.43 -> 9.25 ms (their slabs are 8 MB each); 192: 9.23; the
@@ -604,10 +620,12 @@ int hv_wgrad_tr(const hv_wgrad_desc* d, int* nslabs, hipStream_t s) {
     if (!d->workspace || d->workspace_bytes < need) return HV_ERR_WORKSPACE;
     WTrK k;
     k.x = reinterpret_cast<const _Float16*>(d->x); k.g = reinterpret_cast<const _Float16*>(d->g); k.slabs = d->workspace;
-    k.Hl = d->H; k.Wl = d->W; k.in_shift = d->in_shift; k.Wp = d->W >> d->in_shift;
+    const int dl = pl.dil;
+    k.Hl = d->H / dl; k.Wl = d->W / dl; k.in_shift = d->in_shift; k.Wp = d->W >> d->in_shift;
     k.img_stride = (d->H >> d->in_shift) * k.Wp * d->x_ld; k.x_ld = d->x_ld; k.x_coff = d->x_coff; k.Cin = d->Cin;
-    k.Ho = d->Ho; k.Wo = d->Wo; k.g_ld = d->g_ld; k.g_coff = d->g_coff; k.Cout = d->Cout; k.pad = d->pad;
-    k.tiles_x = hv_cdiv(d->Wo, 16); k.tiles_per_img = k.tiles_x * hv_cdiv(d->Ho, 8); k.ntiles = k.tiles_per_img * d->B;
+    k.Ho = d->Ho / dl; k.Wo = d->Wo / dl; k.Hf = d->Ho; k.Wf = d->Wo; k.g_ld = d->g_ld; k.g_coff = d->g_coff; k.Cout = d->Cout; k.pad = dl > 1 ? 1 : d->pad;
+    k.dil = dl;
+    k.tiles_x = hv_cdiv(k.Wo, 16); k.tiles_per_sub = k.tiles_x * hv_cdiv(k.Ho, 8); k.tiles_per_img = k.tiles_per_sub * dl * dl; k.ntiles = k.tiles_per_img * d->B;
     k.slab = (long long)d->Cout * d->KH * d->KW * d->Cin;
     k.bias_out = d->dbias ? d->workspace + (long long)pl.gx * k.slab : nullptr;
     k.dbg = 0;

@@ -672,6 +672,34 @@ def test_wgrad_transposed_lds_read_kernel(case):
     assert maxerr(db.cpu(), 2 * gsum) <= 2e-3 * max(1.0, g.abs().sum(dim=(0, 2, 3)).max().item())
 
 
+@pytest.mark.parametrize('dil,B,H,W,Cin,Cout', [(2, 2, 32, 32, 64, 64), (4, 2, 32, 48, 64, 64), (8, 3, 64, 64, 64, 64), (2, 2, 20, 12, 32, 64), (16, 2, 64, 64, 64, 64)])
+def test_wgrad_dilated_3x3_through_the_transposed_read_kernel(dil, B, H, W, Cin, Cout):
+    """Weight gradients of the generators' dilated same-size 3x3 layers (d = 2, 4, 8): wgrad_tr_kernel walks the d*d residue sub-grids as undilated layers
+    with pixel step d and sums them in the same accumulators (round 4; they ran in the gather kernel).  Against torch CPU fp32, with the bias gradient and
+    the accumulate form; d = 16 (4 x 4-pixel sub-grids) stays in the gather kernel."""
+    from hvtest import to_act, dev, maxerr
+    from hvgan import ops, lib
+    g_ = torch.Generator().manual_seed(40 + dil)
+    x = torch.randn(B, Cin, H, W, generator=g_)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g_) / (Cin * 9) ** 0.5).requires_grad_(True)
+    y = F.conv2d(x, w, None, stride=1, padding=dil, dilation=dil)
+    g = torch.randn(y.shape, generator=g_)
+    y.backward(g)
+    xa, ga = to_act(x, dtype=torch.float16), to_act(g, dtype=torch.float16)
+    dw = torch.empty(Cout, 9, Cin, device=dev())
+    db = torch.full((Cout,), 3.0, device=dev())
+    ops.conv2d_wgrad(xa, ga, dw, 3, 1, dil, dil, precision='fp16', dbias=db)
+    assert lib.get().size('hv_last_kernel_path') == (12 if dil <= 8 else 10)
+    torch.cuda.synchronize()
+    scale = max(1.0, w.grad.abs().max().item())
+    assert maxerr(dw.cpu().reshape(Cout, 3, 3, Cin).permute(0, 3, 1, 2), w.grad) <= 6e-3 * scale
+    gsum = g.half().float().sum(dim=(0, 2, 3))
+    assert maxerr(db.cpu(), gsum) <= 1e-3 * max(1.0, g.abs().sum(dim=(0, 2, 3)).max().item())
+    ops.conv2d_wgrad(xa, ga, dw, 3, 1, dil, dil, precision='fp16', accumulate=True, dbias=db, dbias_accumulate=True)
+    torch.cuda.synchronize()
+    assert maxerr(dw.cpu().reshape(Cout, 3, 3, Cin).permute(0, 3, 1, 2), 2 * w.grad) <= 1.2e-2 * scale
+
+
 S2T_CASES = [   # B, H (conv input = gradient output size), W, Cin, Cout (of the forward conv), k
     (2, 64, 64, 64, 128, 4),       # PatchGAN 64 -> 128 (data gradient 128 -> 64 at 64 x 64)
     (2, 32, 32, 128, 256, 4),
