@@ -82,10 +82,13 @@ __global__ __launch_bounds__(256) void ca_gram_norm_kernel(const float* __restri
     rnorm[i] = 1.f / nv;
 }
 
-// ---- scores: one workgroup per (sample, grid row py of p, group of LG grid rows of l); the block's three Gram products are summed in the accumulators
+// ---- scores: one workgroup per (sample, grid row py of p, group of LG grid rows of l); the block's three Gram products are summed in the accumulators.
+// Every operand fragment of a round is requested before its first MFMA (branch-free: a row outside the map is an out-of-range buffer offset = zeros), the p
+// side's fragments once for the whole group -- the first version fetched per ty inside scalar branches, three dependent L2 round trips per block: 162 us.
+#define GRAM_OOB 0x80000000u
 template <int BW>
 __global__ __launch_bounds__(256) void ca_gram_scores_kernel(const _Float16* __restrict__ fd_h, const float* __restrict__ rnorm, int h, int lg, float* __restrict__ S0) {
-    constexpr int C = 64, NT = BW / 16, TPW = NT * NT / 4;      // MFMA tiles per wave
+    constexpr int C = 64, NT = BW / 16, TPW = NT * NT / 4, KS = C / 32;      // MFMA tiles per wave (they share one tile row mi)
     __shared__ float Gt[2][BW][BW + 1];
     const int w = BW, L = h * w, ngr = (h + lg - 1) / lg;
     int id = blockIdx.x;
@@ -93,27 +96,39 @@ __global__ __launch_bounds__(256) void ca_gram_scores_kernel(const _Float16* __r
     const int py = id % h;
     const long long b = id / h;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const _Float16* fb = fd_h + b * (long long)L * C;
+    const __amdgpu_buffer_rsrc_t fsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(fd_h + b * (long long)L * C), 0, (unsigned)(L * C * 2), 0x00020000);
     const float* rb = rnorm + b * L;
     float* Sb = S0 + b * (long long)L * L;
+    const int mi = (wave * TPW) / NT, ni0 = (wave * TPW) % NT;
+    const unsigned lane_off = (unsigned)(((lane & 15) * C + 8 * (lane >> 4)) * 2);
+    auto frag = [&](int row, int t16, int ks) __attribute__((always_inline)) {      // 16 pixels t16 of grid row `row`, channels 32 ks + 8 (lane >> 4) ..
+        const unsigned off = (unsigned)row < (unsigned)h ? (unsigned)((row * w + t16 * 16) * C + ks * 32) * 2u + lane_off : GRAM_OOB;
+        return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(fsrc, off, 0, 0));
+    };
+    f16x8 afr[3][KS];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) afr[t][ks] = frag(py + t - 1, mi, ks);
     const int ly1 = min(h, (lgi + 1) * lg);
     int buf = 0;
     for (int ly = lgi * lg; ly < ly1; ++ly, buf ^= 1) {
+        f16x8 bfr[TPW][3][KS];
+#pragma unroll
+        for (int u = 0; u < TPW; ++u)
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) bfr[u][t][ks] = frag(ly + t - 1, ni0 + u, ks);
 #pragma unroll
         for (int u = 0; u < TPW; ++u) {
-            const int tile = wave * TPW + u, mi = tile / NT, ni = tile - mi * NT;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ty = -1; ty <= 1; ++ty) {
-                if ((unsigned)(py + ty) >= (unsigned)h || (unsigned)(ly + ty) >= (unsigned)h) continue;      // scalar: the block is outside the map
-                const _Float16* prow = fb + ((long long)(py + ty) * w + mi * 16 + (lane & 15)) * C + 8 * (lane >> 4);
-                const _Float16* lrow = fb + ((long long)(ly + ty) * w + ni * 16 + (lane & 15)) * C + 8 * (lane >> 4);
+            for (int t = 0; t < 3; ++t)      // (a block outside the map contributes zeros: one of its operands is)
 #pragma unroll
-                for (int ks = 0; ks < C / 32; ++ks)
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const f16x8*>(prow + ks * 32), *reinterpret_cast<const f16x8*>(lrow + ks * 32), acc, 0, 0, 0);
-            }
+                for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[t][ks], bfr[u][t][ks], acc, 0, 0, 0);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Gt[buf][mi * 16 + 4 * (lane >> 4) + r][ni * 16 + (lane & 15)] = acc[r];
+            for (int r = 0; r < 4; ++r) Gt[buf][mi * 16 + 4 * (lane >> 4) + r][(ni0 + u) * 16 + (lane & 15)] = acc[r];
         }
         __syncthreads();      // (two buffers: the next round's stores go to the other one, and the round after that is behind the next barrier)
         for (int it = threadIdx.x; it < BW * BW / 4; it += 256) {
@@ -142,13 +157,14 @@ extern "C" int hv_ca_gram_scores(const void* fd_h, const float* q, int B, int h,
     return HV_OK;
 }
 
-// ---- gradient: one workgroup per (sample, grid row ay); d fd[row ay] = sum over by of E(ay, by) fd[row by]  (+ the norm term), added to the even positions of df
-template <int BW>
+// ---- gradient: one workgroup per (sample, grid row ay); d fd[row ay] = sum over by of E(ay, by) fd[row by]  (+ the norm term), added to the even positions of df.
+// NBY grid rows by per round (one K = NBY * w product per round: half the barriers per block at NBY = 2).
+template <int BW, int NBY>
 __global__ __launch_bounds__(256) void ca_gram_backward_kernel(const float* __restrict__ Gs, const _Float16* __restrict__ fd_h, const _Float16* __restrict__ fdT_h,
                                                                const float* __restrict__ coef, int h, float* __restrict__ df, int df_ld) {
-    constexpr int C = 64, MT = BW / 16, NTL = C / 16, TPW = MT * NTL / 4, LDE = BW + 8;
+    constexpr int C = 64, MT = BW / 16, NTL = C / 16, TPW = MT * NTL / 4, KW = NBY * BW, LDE = KW + 8;
     constexpr int NV = BW * BW / 4 / 256;                // float4 items of ONE block per thread; the three diagonal blocks are summed item by item as they arrive
-    __shared__ float Gt[BW][BW + 1];
+    __shared__ float Gt[NBY][BW][BW + 1];
     __shared__ __attribute__((aligned(16))) _Float16 Eh[BW][LDE];
     const int w = BW, L = h * w, H = 2 * h, W = 2 * w;
     const int ay = blockIdx.x % h;
@@ -159,51 +175,57 @@ __global__ __launch_bounds__(256) void ca_gram_backward_kernel(const float* __re
     f32x4 acc[TPW];
 #pragma unroll
     for (int u = 0; u < TPW; ++u) acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float4 pre[3][NV];
-    auto fetch = [&](int by) __attribute__((always_inline)) {       // the three diagonal blocks (ay + ty, by + ty) of Gs, zeros where a block leaves the map
+    float4 pre[NBY][3][NV];
+    auto fetch = [&](int by0) __attribute__((always_inline)) {       // the three diagonal blocks (ay + ty, by + ty) of Gs per by, zeros where a block leaves the map
 #pragma unroll
-        for (int tyi = 0; tyi < 3; ++tyi) {
-            const int ra = ay + tyi - 1, rb = by + tyi - 1;
-            const bool ok = (unsigned)ra < (unsigned)h && (unsigned)rb < (unsigned)h;       // scalar
+        for (int j = 0; j < NBY; ++j)
+#pragma unroll
+            for (int tyi = 0; tyi < 3; ++tyi) {
+                const int ra = ay + tyi - 1, rb = by0 + j + tyi - 1;
+                const bool ok = (unsigned)ra < (unsigned)h && (unsigned)rb < (unsigned)h;       // scalar
+#pragma unroll
+                for (int k = 0; k < NV; ++k) {
+                    const int it = threadIdx.x + k * 256, r = it / (BW / 4), c4 = (it - r * (BW / 4)) * 4;
+                    pre[j][tyi][k] = ok ? *reinterpret_cast<const float4*>(Gb + (long long)(ra * w + r) * L + rb * w + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+    };
+    fetch(0);
+    for (int by0 = 0; by0 < h; by0 += NBY) {
+#pragma unroll
+        for (int j = 0; j < NBY; ++j)
 #pragma unroll
             for (int k = 0; k < NV; ++k) {
                 const int it = threadIdx.x + k * 256, r = it / (BW / 4), c4 = (it - r * (BW / 4)) * 4;
-                pre[tyi][k] = ok ? *reinterpret_cast<const float4*>(Gb + (long long)(ra * w + r) * L + rb * w + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                Gt[j][r][c4] = (pre[j][0][k].x + pre[j][1][k].x) + pre[j][2][k].x; Gt[j][r][c4 + 1] = (pre[j][0][k].y + pre[j][1][k].y) + pre[j][2][k].y;
+                Gt[j][r][c4 + 2] = (pre[j][0][k].z + pre[j][1][k].z) + pre[j][2][k].z; Gt[j][r][c4 + 3] = (pre[j][0][k].w + pre[j][1][k].w) + pre[j][2][k].w;
             }
-        }
-    };
-    fetch(0);
-    for (int by = 0; by < h; ++by) {
-#pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            const int it = threadIdx.x + k * 256, r = it / (BW / 4), c4 = (it - r * (BW / 4)) * 4;
-            Gt[r][c4] = (pre[0][k].x + pre[1][k].x) + pre[2][k].x; Gt[r][c4 + 1] = (pre[0][k].y + pre[1][k].y) + pre[2][k].y;
-            Gt[r][c4 + 2] = (pre[0][k].z + pre[1][k].z) + pre[2][k].z; Gt[r][c4 + 3] = (pre[0][k].w + pre[1][k].w) + pre[2][k].w;
-        }
-        // this row block's B operands (fd of grid row by, pixel-contiguous: the transposed table), requested before the barrier
-        f16x8 bf[TPW][BW / 32];
+        // this round's B operands (fd of grid rows by0 .., pixel-contiguous: the transposed table), requested before the barrier
+        f16x8 bf[TPW][KW / 32];
 #pragma unroll
         for (int u = 0; u < TPW; ++u) {
             const int ni = (wave * TPW + u) % NTL;
 #pragma unroll
-            for (int ks = 0; ks < BW / 32; ++ks)
-                bf[u][ks] = *reinterpret_cast<const f16x8*>(fTb + (long long)(ni * 16 + (lane & 15)) * L + by * w + ks * 32 + 8 * (lane >> 4));
+            for (int ks = 0; ks < KW / 32; ++ks)
+                bf[u][ks] = *reinterpret_cast<const f16x8*>(fTb + (long long)(ni * 16 + (lane & 15)) * L + by0 * w + ks * 32 + 8 * (lane >> 4));
         }
         __syncthreads();
-        if (by + 1 < h) fetch(by + 1);        // the next blocks fly behind the box filter and the MFMAs
-        for (int it = threadIdx.x; it < BW * BW / 4; it += 256) {
-            const int r = it / (BW / 4), c0 = (it - r * (BW / 4)) * 4;
-            f16x4 e4;
+        if (by0 + NBY < h) fetch(by0 + NBY);        // the next blocks fly behind the box filter and the MFMAs
 #pragma unroll
-            for (int u = 0; u < 4; ++u) e4[u] = (_Float16)gram_box<BW>(Gt, r, c0 + u);
-            *reinterpret_cast<f16x4*>(&Eh[r][c0]) = e4;
-        }
+        for (int j = 0; j < NBY; ++j)
+            for (int it = threadIdx.x; it < BW * BW / 4; it += 256) {
+                const int r = it / (BW / 4), c0 = (it - r * (BW / 4)) * 4;
+                f16x4 e4;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) e4[u] = (_Float16)gram_box<BW>(Gt[j], r, c0 + u);
+                *reinterpret_cast<f16x4*>(&Eh[r][j * BW + c0]) = e4;
+            }
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < TPW; ++u) {
             const int mi = (wave * TPW + u) / NTL;
 #pragma unroll
-            for (int ks = 0; ks < BW / 32; ++ks) {
+            for (int ks = 0; ks < KW / 32; ++ks) {
                 const f16x8 a = *reinterpret_cast<const f16x8*>(&Eh[mi * 16 + (lane & 15)][ks * 32 + 8 * (lane >> 4)]);
                 acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bf[u][ks], acc[u], 0, 0, 0);
             }
@@ -238,11 +260,15 @@ extern "C" int hv_ca_gram_backward(const float* Gs, const void* fd_h, const void
     if (!Gs || !fd_h || !fdT_h || !coef || !df || B <= 0 || h <= 0 || w <= 0 || df_ld < C) return HV_ERR_ARG;
     if (C != 64 || (w != 32 && w != 64) || ((uintptr_t)Gs & 15) || ((uintptr_t)fdT_h & 15) || (long long)B * h >= (1ll << 31)) return HV_ERR_UNSUPPORTED;
     const dim3 grid((unsigned)(B * h));
-    if (w == 32)
-        hipLaunchKernelGGL(ca_gram_backward_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, Gs, reinterpret_cast<const _Float16*>(fd_h),
+    static const int nby = getenv("HV_CA_GRAM_NBY") ? atoi(getenv("HV_CA_GRAM_NBY")) : 2;      // A/B knob
+    if (w == 32 && nby == 2 && !(h & 1))
+        hipLaunchKernelGGL((ca_gram_backward_kernel<32, 2>), grid, dim3(256), 0, (hipStream_t)stream, Gs, reinterpret_cast<const _Float16*>(fd_h),
+                           reinterpret_cast<const _Float16*>(fdT_h), coef, h, df, df_ld);
+    else if (w == 32)
+        hipLaunchKernelGGL((ca_gram_backward_kernel<32, 1>), grid, dim3(256), 0, (hipStream_t)stream, Gs, reinterpret_cast<const _Float16*>(fd_h),
                            reinterpret_cast<const _Float16*>(fdT_h), coef, h, df, df_ld);
     else
-        hipLaunchKernelGGL(ca_gram_backward_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, Gs, reinterpret_cast<const _Float16*>(fd_h),
+        hipLaunchKernelGGL((ca_gram_backward_kernel<64, 1>), grid, dim3(256), 0, (hipStream_t)stream, Gs, reinterpret_cast<const _Float16*>(fd_h),
                            reinterpret_cast<const _Float16*>(fdT_h), coef, h, df, df_ld);
     HV_LAUNCH_CHECK();
     return HV_OK;
