@@ -86,10 +86,13 @@ __global__ __launch_bounds__(256) void ca_gram_norm_kernel(const float* __restri
 // Every operand fragment of a round is requested before its first MFMA (branch-free: a row outside the map is an out-of-range buffer offset = zeros), the p
 // side's fragments once for the whole group -- the first version fetched per ty inside scalar branches, three dependent L2 round trips per block: 162 us.
 #define GRAM_OOB 0x80000000u
-template <int BW>
-__global__ __launch_bounds__(256) void ca_gram_scores_kernel(const _Float16* __restrict__ fd_h, const float* __restrict__ rnorm, int h, int lg, float* __restrict__ S0) {
-    constexpr int C = 64, NT = BW / 16, TPW = NT * NT / 4, KS = C / 32;      // MFMA tiles per wave (they share one tile row mi)
-    __shared__ float Gt[2][BW][BW + 1];
+// NLB grid rows of l per round: a row of S0 then leaves as NLB * w * 4 bytes contiguous per store instruction (128-byte segments 4 KB apart held the kernel at
+// 1.2 TB/s: 52-62 us whatever the round structure)
+template <int BW, int NLB>
+__global__ __launch_bounds__(256) void ca_gram_scores_kernel(const _Float16* __restrict__ fd_h, const float* __restrict__ rnorm, int h, int lg, float* __restrict__ S0, int diag) {
+    constexpr int C = 64, NT = BW / 16, KS = C / 32, SW = NLB * BW;      // SW: strip width (columns per round)
+    constexpr int TILES = NT * NT * NLB, TPW = TILES / 4;                  // MFMA tiles per wave and round: tile t -> (block j, mi, ni)
+    __shared__ float Gt[2][NLB][BW][BW + 1];
     const int w = BW, L = h * w, ngr = (h + lg - 1) / lg;
     int id = blockIdx.x;
     const int lgi = id % ngr; id /= ngr;
@@ -99,44 +102,78 @@ __global__ __launch_bounds__(256) void ca_gram_scores_kernel(const _Float16* __r
     const __amdgpu_buffer_rsrc_t fsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(fd_h + b * (long long)L * C), 0, (unsigned)(L * C * 2), 0x00020000);
     const float* rb = rnorm + b * L;
     float* Sb = S0 + b * (long long)L * L;
-    const int mi = (wave * TPW) / NT, ni0 = (wave * TPW) % NT;
     const unsigned lane_off = (unsigned)(((lane & 15) * C + 8 * (lane >> 4)) * 2);
     auto frag = [&](int row, int t16, int ks) __attribute__((always_inline)) {      // 16 pixels t16 of grid row `row`, channels 32 ks + 8 (lane >> 4) ..
         const unsigned off = (unsigned)row < (unsigned)h ? (unsigned)((row * w + t16 * 16) * C + ks * 32) * 2u + lane_off : GRAM_OOB;
         return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(fsrc, off, 0, 0));
     };
-    f16x8 afr[3][KS];
+    // wave -> its TPW tiles.  NLB == 4: wave j owns block j of the round (all NT x NT tiles); NLB == 1: a wave owns one tile row mi (NT tiles).  Either way the
+    // wave's tiles span `NMI` tile rows and `NNI` tile columns of ONE block: its p-side fragments (3 x NMI x KS) are fetched once for the whole row group,
+    // the l-side fragments (3 x NNI x KS) once per round -- with a fetch per tile the kernel moved 786 MB of fragments through L2 (14 TB/s: 54 us)
+    constexpr int NMI = NLB == 4 ? NT : 1, NNI = TPW / NMI;
+    static_assert(TPW == NMI * NNI && (NLB == 4 ? TPW == NT * NT : NNI == NT), "tile ownership");
+    const int jw = NLB == 4 ? wave : 0, mi0 = NLB == 4 ? 0 : wave % NT;
+    f16x8 afr[3][NMI][KS];
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int ty = 0; ty < 3; ++ty)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) afr[t][ks] = frag(py + t - 1, mi, ks);
-    const int ly1 = min(h, (lgi + 1) * lg);
+        for (int m = 0; m < NMI; ++m)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) afr[ty][m][ks] = frag(py + ty - 1, mi0 + m, ks);
+    // rounds: wave jw walks CONSECUTIVE grid rows ly = lw0, lw0 + 1, .. (NLB == 4: the four waves own four runs of lg / 4 rows; NLB == 1: all waves the same
+    // run), so two of a block's three l-side rows are the previous round's: one row of fragments (NNI x KS loads) is fetched per round and the other two
+    // rotate through registers -- a third of the l-side traffic again (fragments per tile: 54 us; per wave and round: 37 us)
+    const int ly0 = lgi * lg, ly1 = min(h, (lgi + 1) * lg);
+    const int rounds = NLB == 4 ? lg / 4 : lg, lw0 = ly0 + jw * rounds;
+    f16x8 brow[4][NNI][KS];      // rows ly - 1, ly, ly + 1 of the round + the next round's new row, requested a round ahead
+    auto load_row = [&](int slot, int row) __attribute__((always_inline)) {
+#pragma unroll
+        for (int n = 0; n < NNI; ++n)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) brow[slot][n][ks] = frag(row, n, ks);
+    };
+    load_row(0, lw0 - 1);
+    load_row(1, lw0);
+    load_row(2, lw0 + 1);
     int buf = 0;
-    for (int ly = lgi * lg; ly < ly1; ++ly, buf ^= 1) {
-        f16x8 bfr[TPW][3][KS];
+    for (int rd = 0; rd < rounds; ++rd, buf ^= 1) {
+        const int ly = lw0 + rd;                 // this wave's grid row of l in this round
+        load_row(3, rd + 1 < rounds ? ly + 2 : -1);
+        if (!(diag & 2)) {
 #pragma unroll
-        for (int u = 0; u < TPW; ++u)
+            for (int m = 0; m < NMI; ++m)
 #pragma unroll
-            for (int t = 0; t < 3; ++t)
+                for (int n = 0; n < NNI; ++n) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) bfr[u][t][ks] = frag(ly + t - 1, ni0 + u, ks);
+                    for (int ty = 0; ty < 3; ++ty)      // (a block outside the map contributes zeros: one of its operands is)
 #pragma unroll
-        for (int u = 0; u < TPW; ++u) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[ty][m][ks], brow[ty][n][ks], acc, 0, 0, 0);
 #pragma unroll
-            for (int t = 0; t < 3; ++t)      // (a block outside the map contributes zeros: one of its operands is)
+                    for (int r = 0; r < 4; ++r) Gt[buf][jw][(mi0 + m) * 16 + 4 * (lane >> 4) + r][n * 16 + (lane & 15)] = acc[r];
+                }
+        }
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[t][ks], bfr[u][t][ks], acc, 0, 0, 0);
+        for (int n = 0; n < NNI; ++n)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Gt[buf][mi * 16 + 4 * (lane >> 4) + r][(ni0 + u) * 16 + (lane & 15)] = acc[r];
+            for (int ks = 0; ks < KS; ++ks) { brow[0][n][ks] = brow[1][n][ks]; brow[1][n][ks] = brow[2][n][ks]; brow[2][n][ks] = brow[3][n][ks]; }
+        // items of the box / store pass: (row r, block j, 4 columns): block j's columns start at grid row lyj = ly0 + j * rounds + rd
+        constexpr int NIT = BW * SW / 4 / 256;
+        float4 rn[NIT];
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int it = threadIdx.x + k * 256, c = (it % (SW / 4)) * 4, j = c / BW, lyj = ly0 + (NLB == 4 ? j * rounds : 0) + rd;
+            rn[k] = lyj < ly1 ? *reinterpret_cast<const float4*>(rb + lyj * w + (c - j * BW)) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __syncthreads();      // (two buffers: the next round's stores go to the other one, and the round after that is behind the next barrier)
-        for (int it = threadIdx.x; it < BW * BW / 4; it += 256) {
-            const int r = it / (BW / 4), c0 = (it - r * (BW / 4)) * 4;
-            const float4 rn = *reinterpret_cast<const float4*>(rb + ly * w + c0);
-            *reinterpret_cast<float4*>(Sb + (long long)(py * w + r) * L + ly * w + c0) =
-                make_float4(gram_box<BW>(Gt[buf], r, c0) * rn.x, gram_box<BW>(Gt[buf], r, c0 + 1) * rn.y, gram_box<BW>(Gt[buf], r, c0 + 2) * rn.z,
-                            gram_box<BW>(Gt[buf], r, c0 + 3) * rn.w);
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int it = threadIdx.x + k * 256, r = it / (SW / 4), c = (it - r * (SW / 4)) * 4, j = c / BW, c0 = c - j * BW;
+            const int lyj = ly0 + (NLB == 4 ? j * rounds : 0) + rd;
+            if (lyj < ly1 && !(diag & 1))
+                *reinterpret_cast<float4*>(Sb + (long long)(py * w + r) * L + lyj * w + c0) =
+                    make_float4(gram_box<BW>(Gt[buf][j], r, c0) * rn[k].x, gram_box<BW>(Gt[buf][j], r, c0 + 1) * rn[k].y, gram_box<BW>(Gt[buf][j], r, c0 + 2) * rn[k].z,
+                                gram_box<BW>(Gt[buf][j], r, c0 + 3) * rn[k].w);
         }
     }
 }
@@ -148,11 +185,13 @@ extern "C" int hv_ca_gram_scores(const void* fd_h, const float* q, int B, int h,
     hipLaunchKernelGGL(ca_gram_norm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, q, h, w, n, norm, rnorm);
     HV_LAUNCH_CHECK();
     static const int lg_env = getenv("HV_CA_GRAM_LG") ? atoi(getenv("HV_CA_GRAM_LG")) : 0;      // tuning knob: grid rows of l per workgroup
-    int lg = lg_env > 0 ? lg_env : 8;
-    while (lg > 1 && (long long)B * h * ((h + lg - 1) / lg) < 1024) lg >>= 1;      // keep >= 4 workgroups per CU in flight
+    static const int diag = getenv("HV_GRAM_DIAG") ? atoi(getenv("HV_GRAM_DIAG")) : 0;      // timing-only: 1 no stores, 2 no operand loads / MFMAs
+    int lg = lg_env > 0 ? lg_env : 16;
+    while (lg > 4 && (long long)B * h * ((h + lg - 1) / lg) < 1024) lg >>= 1;      // keep >= 4 workgroups per CU in flight
+    lg = (lg + 3) / 4 * 4;
     const dim3 grid((unsigned)(B * h * ((h + lg - 1) / lg)));
-    if (w == 32) hipLaunchKernelGGL(ca_gram_scores_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const _Float16*>(fd_h), rnorm, h, lg, S0);
-    else hipLaunchKernelGGL(ca_gram_scores_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const _Float16*>(fd_h), rnorm, h, lg, S0);
+    if (w == 32) hipLaunchKernelGGL((ca_gram_scores_kernel<32, 4>), grid, dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const _Float16*>(fd_h), rnorm, h, lg, S0, diag);
+    else hipLaunchKernelGGL((ca_gram_scores_kernel<64, 1>), grid, dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const _Float16*>(fd_h), rnorm, h, lg, S0, diag);
     HV_LAUNCH_CHECK();
     return HV_OK;
 }
