@@ -1,5 +1,7 @@
 """Generator / ContextualAttention / discriminator on the HIP path (fp32 mode) against the golden vectors the
 reference produced, at the north-star tolerance |d| <= 1e-3 (activations) -- observed errors are ~1e-5."""
+import os
+
 import pytest
 import torch
 
@@ -517,3 +519,64 @@ def test_attention_scores_on_the_pixel_gram_matrix_match_the_patch_table_route(s
     assert (a['out'] - b['out']).abs().max().item() <= 2e-2 * max(1.0, b['out'].abs().max().item())
     rel = (a['df'] - b['df']).norm().item() / b['df'].norm().item()
     assert b['df'].abs().max().item() > 0 and rel <= 2e-2, rel
+
+
+def test_generator_with_other_widths_takes_the_materialised_concat(monkeypatch):
+    """ngf = 32 in the fp16 mode: the [up-sampled | CAM channel] concat layers have 128 / 64 + 1 input channels, for which the extra-channel form of the
+    filters-in-LDS kernel does not exist.  ConvNode.split_forward asks the C dispatch (hv_conv2d_supported) instead of mirroring its checks, so these
+    layers read the materialised concat and the forward / backward run (round 3: RuntimeError 'unsupported'); attention with 128 channels keeps the
+    patch-table route.  Outputs against the exact-fp32 mode on the same weights."""
+    from hvgan.models.inpaint_networks import Generator
+    from hvgan import synth
+    dev = torch.device('cuda:0')
+    b = synth.to_model_inputs(synth.make_batch(2, 256, seed=3))
+    args = [b['real_A'].to(dev), b['mask'].to(dev), (1 - b['CAM']).to(dev), b['slice_ratio'].to(dev)]
+    outs = {}
+    for prec in ('fp16', 'fp32'):
+        monkeypatch.setenv('HV_PRECISION', prec)
+        torch.manual_seed(5)
+        net = Generator({'input_dim': 1, 'ngf': 32}, True).cuda().train()
+        net.precision = prec
+        P = net.run_forward(*args, training=True)
+        if prec == 'fp16':
+            z = lambda t: torch.full_like(t, 1e-3)
+            net.run_backward(P, z(P.coarse_seg), z(P.fine_seg), z(P.x_stage1), z(P.x_stage2), torch.zeros(2, 1, device=dev), torch.zeros(2, 1, device=dev))
+            assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
+        torch.cuda.synchronize()
+        outs[prec] = [t.detach().float().cpu().clone() for t in (P.coarse_seg, P.fine_seg, P.x_stage1, P.x_stage2)]
+    for a, r in zip(outs['fp16'], outs['fp32']):
+        assert torch.isfinite(a).all() and (a - r).abs().max().item() <= 2e-2, (a - r).abs().max().item()
+
+
+def test_train_step_with_the_filters_in_lds_kernel_switched_off():
+    """HV_CONV_LF=0 (a documented A/B knob, read once by the C side: own process): every 3x3 layer falls back to conv_halo2 -- incl. the concat layers, whose
+    extra-channel form and pooled data gradient only the switched-off kernel serves: the Python side asks hv_conv2d_supported / pool2_ok of the dispatch
+    and materialises the concat / the full-resolution gradient again.  Two train steps run and give the default build's losses."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = r'''
+import json, os, sys, torch
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))
+os.environ['HV_PRECISION'] = 'fp16'
+import hvgan
+from hvgan import synth
+from hvgan.models.pix2pix_model import Pix2PixModel
+from test_step_gpu import make_opt
+torch.manual_seed(1234)
+m = Pix2PixModel(make_opt())
+for s in range(2):
+    m.set_input(synth.make_batch(2, 256, seed=1234 + s))
+    m.optimize_parameters()
+torch.cuda.synchronize()
+print('LOSSES ' + json.dumps({k: float(v) for k, v in m.get_current_losses().items()}))
+''' % (ROOT, ROOT)
+    res = {}
+    for lf in ('1', '0'):
+        p = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, HV_CONV_LF=lf), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        assert p.returncode == 0, p.stdout.decode()[-3000:]
+        res[lf] = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith('LOSSES ')][-1][7:])
+    for k, v in res['1'].items():
+        tol = 2e-2 if k in ('edge', 'D_real_2', 'D_fake_2') else 6e-3
+        assert abs(res['0'][k] - v) <= tol * max(1.0, abs(v)), (k, res['0'][k], v)
