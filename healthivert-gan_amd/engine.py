@@ -45,11 +45,22 @@ class ConvParams:
         # which prepared tables the layer's forward / data-gradient convolutions have read so far (hv_last_weight_tables bits: 1 fp32, 2 fp16 rows, 4 fp16
         # fragment order; 0 = not seen yet): ParamSet.prep writes only those inside a lean_tables() context
         self.use_fwd = self.use_bwd = 0
+        self.slabs, self.owner = {}, None
         self.split_k = None                     # K2: also keep the first K2 input channels as a fragment-ordered table of their own (w_fwd_t2: conv2d's x1 layers)
         self.w_fwd_t2 = None
 
     def sizes(self):
         return (self.cout * self.taps * self.cin_fwd, self.cin_fwd * self.taps * self.coutP, self.coutP * self.taps * self.cin_wg)
+
+    # ---- deferred slab folds (ops.conv2d_wgrad defer=): the layer's split-K slabs live in a buffer of its own until the network's ONE fold launch
+    def slab_buffer(self, nbytes, device):
+        b = self.slabs.get(nbytes)       # (by size: the layer may be called with several batch shapes, each captured in its own graphs)
+        if b is None:
+            b = self.slabs[nbytes] = torch.empty(int(nbytes) + 64, dtype=torch.uint8, device=device)
+        return b
+
+    def defer_fold(self, rec):
+        self.owner.pending_folds.append(rec)
 
 
 class ParamSet:
@@ -63,6 +74,11 @@ class ParamSet:
         self.t_prep = {True: ops.LayerTable('hv_wprep_layer'), False: ops.LayerTable('hv_wprep_layer')}
         self.t_bwd = {True: ops.LayerTable('hv_wprep_bwd_layer'), False: ops.LayerTable('hv_wprep_bwd_layer')}
         self.t_lean = {True: ops.LayerTable('hv_wprep_layer'), False: ops.LayerTable('hv_wprep_layer')}
+        # deferred slab folds of the current backward (ops.conv2d_wgrad defer=) and the device tables of fold lists seen so far (a list is a function of the
+        # shapes: one table per batch shape / pass, built during the eager steps and found again by its key under graph capture)
+        self.pending_folds, self.t_folds = [], {}
+        for c in self.convs:
+            c.owner = self
         self.flat_grad = None
         self._key = None
 
@@ -179,8 +195,22 @@ class ParamSet:
         ops.weight_prep(table, max(c.sizes()[0] + c.sizes()[1] for c in self.convs), any_sn=any(c.sn for c in self.convs),
                         any_legacy=any(c.transposed_src for c in self.convs))
 
+    def fold_pending(self):
+        """The recorded slab folds of this network as ONE launch (hv_wgrad_fold_batched)."""
+        if not self.pending_folds:
+            return
+        recs, self.pending_folds = self.pending_folds, []
+        key = tuple(tuple(sorted(r.items())) for r in recs)
+        t = self.t_folds.get(key)
+        if t is None:
+            t = self.t_folds[key] = ops.LayerTable('hv_wgrad_fold')
+            t.update(recs, key, self.device)
+        _lib.get().call('hv_wgrad_fold_batched', ctypes.cast(t.ptr(), ctypes.POINTER(_lib.get().hv_wgrad_fold)), t.n,
+                        ctypes.c_longlong(max(r['numel'] for r in recs)), stream())
+
     def finish_backward(self, accumulate=False):
         """Kernel-layout weight gradients -> .grad of weight_orig / weight (spectral-norm backward included)."""
+        self.fold_pending()
         ops.weight_prep_backward(self.t_bwd[bool(accumulate)], max(c.cout * c.cin * c.taps for c in self.convs), any(c.sn for c in self.convs))
 
 
@@ -327,14 +357,22 @@ class GradBook:
         return acc
 
 
+DEFER_FOLDS = os.environ.get('HV_DEFER_FOLDS', '1') != '0'   # A/B knob: one slab-fold launch per network instead of one per weight gradient
+
+
 def _wgrad(node, p, xin, gfull, accumulate, prec, dbias=None, dbias_accumulate=False):
+    # the slab fold of this weight gradient is deferred to the network's one fold launch (ParamSet.finish_backward) -- unless it accumulates onto an
+    # earlier result of the same backward (the split real / fake discriminator passes): those are folded first, and this one in place
+    defer = p if (DEFER_FOLDS and p.owner is not None and not accumulate and not dbias_accumulate) else None
+    if defer is None and p.owner is not None:
+        p.owner.fold_pending()
     if node.transposed:
         # y = conv_transpose(x): the weight gradient is that of a strided conv with the roles of x and g swapped;
         # the result is laid out [cin][taps][coutP] (hv_weight_prep_backward knows, transposed_src)
-        ops.conv2d_wgrad(gfull, xin, p.dw, node.k, node.s, node.pad, node.d, accumulate=accumulate, precision=prec)
+        ops.conv2d_wgrad(gfull, xin, p.dw, node.k, node.s, node.pad, node.d, accumulate=accumulate, precision=prec, defer=defer)
     else:
         ops.conv2d_wgrad(xin, gfull, p.dw, node.k, node.s, node.pad, node.d, in_shift=node.shift, accumulate=accumulate, precision=prec,
-                         dbias=dbias, dbias_accumulate=dbias_accumulate)
+                         dbias=dbias, dbias_accumulate=dbias_accumulate, defer=defer)
 
 
 def conv_backward(node, book, prec, dbias_accumulate=False, wgrad_accumulate=False, tmp_full=None, wgrad=True, x_wg=None, premultiplied=False,

@@ -269,9 +269,12 @@ def conv2d_stats_parts(*args, **kw):
 
 
 def conv2d_wgrad(x, g, dw, k, stride=1, pad=0, dil=1, in_shift=0, accumulate=False, precision=None, cin=None, cout=None, dbias=None,
-                 dbias_accumulate=False):
+                 dbias_accumulate=False, defer=None):
     """dw[Cout][k*k][Cin] = sum_pixels g (x) x.  x: conv input view, g: gradient wrt the conv output.
-    dbias: optional [Cout] tensor that receives sum_pixels g (the bias gradient), computed by the same kernels."""
+    dbias: optional [Cout] tensor that receives sum_pixels g (the bias gradient), computed by the same kernels.
+    defer: an object with `.slab_buffer(nbytes, device)` and `.defer_fold(record)` (engine.ConvParams / ParamSet): the split-K slabs stay in the
+    layer's own buffer and their fold is recorded instead of launched -- one hv_wgrad_fold_batched per network in front of its weight-gradient
+    finalisation (engine.ParamSet.finish_backward)."""
     L = _lib.get()
     d = L.hv_wgrad_desc()
     kh, kw = (k, k) if isinstance(k, int) else k
@@ -289,7 +292,13 @@ def conv2d_wgrad(x, g, dw, k, stride=1, pad=0, dil=1, in_shift=0, accumulate=Fal
     d.x_f16, d.g_f16 = x.f16, g.f16
     d.workspace, d.workspace_bytes = None, 0
     need = L.size('hv_conv2d_wgrad_workspace_bytes', ctypes.byref(d))
-    if need:
+    fold = None
+    if need and defer is not None:
+        b = defer.slab_buffer(need, x.t.device)
+        d.workspace, d.workspace_bytes = ptr(b).value, b.numel()
+        fold = L.hv_wgrad_fold()
+        d.pending = ctypes.pointer(fold)
+    elif need:
         b, _ = _ws(need, x.t.device)
         d.workspace, d.workspace_bytes = ptr(b).value, b.numel()
     if _TIMER is not None:
@@ -297,8 +306,11 @@ def conv2d_wgrad(x, g, dw, k, stride=1, pad=0, dil=1, in_shift=0, accumulate=Fal
         nbytes = (2 if x.f16 else 4) * x.B * x.H * x.W * d.Cin + (2 if g.f16 else 4) * g.B * g.H * g.W * d.Cout + 4 * d.Cout * kh * kw * d.Cin   # x and g read once, dW written once
         _TIMER.wrap(('wgrad', x.B, d.H, d.W, d.Cin, d.Cout, kh, stride, dil, 0), flops,
                     lambda: L.call('hv_conv2d_wgrad', ctypes.byref(d), stream()), nbytes)
-        return dw
-    L.call('hv_conv2d_wgrad', ctypes.byref(d), stream())
+    else:
+        L.call('hv_conv2d_wgrad', ctypes.byref(d), stream())
+    if fold is not None and fold.nslabs > 0:
+        defer.defer_fold(dict(slabs=fold.slabs, dw=fold.dw, numel=fold.numel, nslabs=fold.nslabs, accumulate=fold.accumulate, bias_slabs=fold.bias_slabs,
+                              dbias=fold.dbias, Cout=fold.Cout, dbias_accumulate=fold.dbias_accumulate))
     return dw
 
 

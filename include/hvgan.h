@@ -133,6 +133,13 @@ int hv_conv2d_supported(const hv_conv_desc* d);            /* 1 when hv_conv2d w
                                                               shape -- x1, pool2, stats (hv_conv2d then returns HV_ERR_UNSUPPORTED and launches nothing) -- so a caller
                                                               asks before it drops the materialised alternative.  Runs the dispatch itself without launching */
 
+/* One deferred slab fold: dw[i] (+)= sum_k slabs[k * numel + i] in the fixed order k = 0 .. nslabs - 1 grouped by four, dbias likewise from bias_slabs
+ * [nslabs][Cout].  nslabs == 0: the call wrote dw directly (nothing to fold). */
+typedef struct {
+    const float* slabs; float* dw; long long numel; int nslabs; int accumulate;
+    const float* bias_slabs; float* dbias; int Cout; int dbias_accumulate;
+} hv_wgrad_fold;
+
 /* Weight gradient: dw[co][(r,s)][ci] = sum_{n,ho,wo} g[n,ho,wo,co] * x[n, ho*stride-pad+r*dil, ..., ci].
  * (autograd of the convs above; for a transposed conv swap the roles of x and g on the caller side).
  * Split over pixel chunks; partial slabs go to `workspace` and are summed in a fixed order (deterministic). */
@@ -146,7 +153,11 @@ typedef struct {
     int x_f16, g_f16;                     /* storage of x / g as in hv_conv_desc (both 0 or both 1) */
     float* dbias; int dbias_accumulate;   /* optional: dbias[co] (+)= sum over pixels of g[.., co] (bias gradient of the same conv), folded
                                              into the kernel that already streams g; NULL = not computed */
+    hv_wgrad_fold* pending;               /* optional (HOST pointer): the split-K slabs are LEFT in `workspace` -- which then has to stay untouched until
+                                             hv_wgrad_fold_batched has run -- and *pending describes their fold; the call launches no slab reduction.  A whole
+                                             network's folds are then ONE launch in front of hv_weight_prep_backward.  NULL = fold here */
 } hv_wgrad_desc;
+int hv_wgrad_fold_batched(const hv_wgrad_fold* d_folds /* device array */, int n, long long max_numel, void* stream);
 size_t hv_conv2d_wgrad_workspace_bytes(const hv_wgrad_desc* d);
 int hv_conv2d_wgrad(const hv_wgrad_desc* d, void* stream);
 

@@ -580,3 +580,44 @@ print('LOSSES ' + json.dumps({k: float(v) for k, v in m.get_current_losses().ite
     for k, v in res['1'].items():
         tol = 2e-2 if k in ('edge', 'D_real_2', 'D_fake_2') else 6e-3
         assert abs(res['0'][k] - v) <= tol * max(1.0, abs(v)), (k, res['0'][k], v)
+
+
+@pytest.mark.parametrize('precision', ['fp16', 'fp32'])
+def test_deferred_slab_folds_equal_the_per_layer_folds(precision, monkeypatch):
+    """hv_wgrad_desc.pending: every weight gradient of a backward leaves its split-K slabs in the layer's own buffer and the network's folds run as ONE
+    hv_wgrad_fold_batched launch in front of the gradient finalisation (engine.ParamSet.fold_pending) instead of one wgrad_reduce_kernel per layer.
+    Same sums in another fixed order: generator and discriminator parameter gradients agree to fp32 rounding with the per-layer folds, and an accumulating
+    second backward (the split real / fake discriminator passes) still adds up."""
+    monkeypatch.setenv('HV_PRECISION', precision)
+    from hvgan import engine, synth
+    from hvgan.models import networks
+    from hvgan.models.inpaint_networks import Generator
+    dev = torch.device('cuda:0')
+    b = synth.to_model_inputs(synth.make_batch(2, 256, seed=3))
+    args = [b['real_A'].to(dev), b['mask'].to(dev), (1 - b['CAM']).to(dev), b['slice_ratio'].to(dev)]
+    x = torch.randn(2, 1, 256, 256, generator=torch.Generator().manual_seed(1)).to(dev)
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(engine, 'DEFER_FOLDS', on)
+        torch.manual_seed(5)
+        net = Generator({'input_dim': 1, 'ngf': 16}, True).cuda().train()
+        net.precision = precision
+        P = net.run_forward(*args, training=True)
+        z = lambda t: torch.full_like(t, 1e-2)
+        net.run_backward(P, z(P.coarse_seg), z(P.fine_seg), z(P.x_stage1), z(P.x_stage2), torch.full((2, 1), 1e-2, device=dev), torch.full((2, 1), 1e-2, device=dev))
+        torch.manual_seed(6)
+        dnet = networks.define_D(1, 64, 'basic', 3, 'batch', 'normal', 0.02, []).cuda().train()
+        dnet.precision = precision
+        for acc in (False, True):       # second pass accumulates (split real / fake form)
+            Pd = dnet.run_forward(x if not acc else -x, training=True)
+            dnet.run_backward(Pd, torch.ones_like(Pd.logits), need_dx=False, param_grads=True, accumulate=acc)
+        dnet.finish()
+        torch.cuda.synchronize()
+        assert not net.paramset().pending_folds and not dnet.paramset().pending_folds
+        assert bool(net.paramset().t_folds) == on
+        res[on] = {('G', k): p.grad.detach().clone() for k, p in net.named_parameters()}
+        res[on].update({('D', k): p.grad.detach().clone() for k, p in dnet.named_parameters()})
+    for k, a in res[True].items():
+        r = res[False][k]
+        assert torch.isfinite(a).all() and r.abs().max().item() > 0, k
+        assert (a - r).norm().item() <= 1e-5 * r.norm().item(), (k, (a - r).norm().item(), r.norm().item())
