@@ -8,8 +8,13 @@ all-reduce each on a dedicated HIP stream:
 * D_k's reduction is issued from D_k's own stream the moment D_k's gradients are final and only D_k's optimiser step
   waits for it, so it overlaps the other discriminators' passes;
 * the generator's reduction sits between its backward and its Adam step;
-* RCCL collectives are stream-ordered, so all four are captured INSIDE the step's hipGraph (`reduce_inline`); a transport that
-  cannot be captured (gloo: tests and rehearsals) gets the step cut into three graphs with the exchanges between them (`reduce`).
+* default schedule (`HV_DP_SCHEDULE=graphs`): the step is cut into its three hipGraphs where the exchanges belong and the means are issued between
+  them through torch.distributed on an exchange stream (`reduce`) -- mainstream PyTorch usage only;
+* `HV_DP_SCHEDULE=captured`: the collectives INSIDE the step's one hipGraph.  torch's ProcessGroupNCCL cannot be used for that on this stack (its
+  watchdog thread queries the work's end event, which was recorded in a capturing stream: `hipErrorCapturedEvent`, the process aborts -- seen in the
+  one-rank rehearsal), so the captured schedule talks to RCCL directly: `RcclComm` below opens a communicator of its own (ncclGetUniqueId on rank 0,
+  broadcast through the process group, ncclCommInitRank) and `reduce_inline` is a plain `ncclAllReduce(..., ncclAvg, comm, stream)` on the CALLING
+  stream -- a kernel node of the graph being captured, no other thread involved.
 
 `init_from_env()` joins the process group that `python -m torch.distributed.run` describes in the environment, so
 a reference `train.py` needs no edit.  With no process group initialised every call is a no-op.
@@ -57,10 +62,46 @@ def rank():
     return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
 
 
+class RcclComm:
+    """A communicator opened on librccl directly (ctypes): ncclAllReduce on a stream of the caller's choice, capturable into a hipGraph.  The library is
+    the one torch itself loaded (torch/lib/librccl.so), the rendezvous goes through the existing process group (any backend)."""
+    NCCL_FLOAT, NCCL_AVG = 7, 4        # rccl.h: ncclFloat32, ncclAvg
+
+    class _UniqueId(ctypes.Structure):
+        _fields_ = [('internal', ctypes.c_byte * 128)]
+
+    def __init__(self, group=None):
+        path = os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')
+        self.lib = ctypes.CDLL(path if os.path.exists(path) else 'librccl.so')
+        self.lib.ncclGetErrorString.restype = ctypes.c_char_p
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        uid = self._UniqueId()
+        if rank == 0:
+            self._check(self.lib.ncclGetUniqueId(ctypes.byref(uid)), 'ncclGetUniqueId')
+        box = [bytes(uid.internal)]
+        dist.broadcast_object_list(box, src=0, group=group)
+        ctypes.memmove(ctypes.byref(uid), box[0], 128)
+        self.comm = ctypes.c_void_p()
+        self.lib.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, self._UniqueId, ctypes.c_int]
+        self._check(self.lib.ncclCommInitRank(ctypes.byref(self.comm), world, uid, rank), 'ncclCommInitRank')
+        self.lib.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        self.world = world
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError('%s failed: %s' % (what, (self.lib.ncclGetErrorString(rc) or b'?').decode()))
+
+    def all_reduce_mean(self, flat):
+        """flat (fp32, device) <- mean over the ranks, in place, on the current stream."""
+        self._check(self.lib.ncclAllReduce(flat.data_ptr(), flat.data_ptr(), flat.numel(), self.NCCL_FLOAT, self.NCCL_AVG, self.comm,
+                                           torch.cuda.current_stream(flat.device).cuda_stream), 'ncclAllReduce')
+
+
 class GradSync:
     def __init__(self, group=None):
         self.group = group
         self.stream = None
+        self.rccl = None
 
     @staticmethod
     def active():
@@ -69,15 +110,19 @@ class GradSync:
 
     def capturable(self):
         """True when the transport's collectives are stream-ordered device work that a hipGraph capture records (RCCL); gloo's run on the host."""
-        return self.active() and dist.get_backend(self.group) == 'nccl' and os.environ.get('HV_DDP_CAPTURE', '1') != '0'
+        return self.active() and dist.get_backend(self.group) == 'nccl'
 
     def reduce_inline(self, flat):
-        """Average `flat` across the ranks IN the calling stream's order: the process group's own stream waits for the calling stream, runs the
-        collective (ncclAvg: the mean is taken inside it), and the calling stream waits for the result -- two event edges, no host block, and under
-        stream capture both edges and the collective become nodes of the graph being captured.  Other streams keep running beside it."""
-        if not flat.is_cuda:
-            raise RuntimeError('reduce_inline: device tensors only')
-        dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
+        """Average `flat` across the ranks IN the calling stream's order: one ncclAllReduce (ncclAvg: the mean is taken inside it) on the current
+        stream through a communicator of our own (RcclComm; opened at the first call, i.e. during the eager warm-up steps).  Under stream capture it is
+        a node of the graph being captured; other streams keep running beside it."""
+        if not flat.is_cuda or flat.dtype != torch.float32:
+            raise RuntimeError('reduce_inline: fp32 device tensors only')
+        if self.rccl is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('reduce_inline: the RCCL communicator must be opened before the capture (run an eager step first)')
+            self.rccl = RcclComm(self.group)
+        self.rccl.all_reduce_mean(flat)
 
     def exchange_stream(self, device):
         if self.stream is None:

@@ -113,13 +113,14 @@ class Pix2PixModel(BaseModel):
         # the three graphs.
         self.one_graph = _os.environ.get('HV_ONE_GRAPH', '1') != '0'
         # data-parallel step schedule (one process per GPU):
-        #   'captured' (default with the RCCL backend): the single-process step AS IT IS, with the gradient means issued INSIDE it -- D_k's all-reduce on
-        #       D_k's own stream the moment its gradients are final (it runs beside the other discriminators' passes; only D_k's Adam step waits for it),
-        #       the generator's between its backward and its Adam step.  RCCL collectives are stream-ordered, so they are captured into the step's ONE
-        #       hipGraph like any kernel: no graph cut, no host in the loop.
-        #   'graphs': the step cut into its three graphs where the exchanges belong, the means issued eagerly between them on the exchange stream (the main
-        #       stream waits for each).  Taken when the transport cannot be captured (gloo: tests / rehearsals on one device) or a capture with collectives fails.
-        self.dp_schedule = _os.environ.get('HV_DP_SCHEDULE', 'captured')
+        #   'graphs' (default): the step cut into its three graphs where the exchanges belong, the means issued eagerly between them through
+        #       torch.distributed on the exchange stream (the main stream waits for each): mainstream PyTorch usage only, works with every backend.
+        #   'captured' (RCCL only): the single-process step AS IT IS, with the gradient means issued INSIDE it -- D_k's all-reduce on D_k's own stream the moment
+        #       its gradients are final (beside the other discriminators' passes; only D_k's Adam step waits for it), the generator's between its backward
+        #       and its Adam step -- as direct ncclAllReduce calls (ddp.RcclComm) that are captured into the step's ONE hipGraph like any kernel: no graph
+        #       cut, no host in the loop.  Opt-in: it could be exercised in a one-rank RCCL group only (one GPU per box), and torch's own
+        #       ProcessGroupNCCL cannot serve it on this stack (its watchdog aborts on events recorded in a capturing stream).
+        self.dp_schedule = _os.environ.get('HV_DP_SCHEDULE', 'graphs')
         if self.dp_schedule not in ('captured', 'graphs'):
             raise ValueError("HV_DP_SCHEDULE must be 'captured' or 'graphs'")
         self.real_first = _os.environ.get('HV_REAL_FIRST', '1') != '0'   # D real passes overlap the generator forward

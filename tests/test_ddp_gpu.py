@@ -42,7 +42,7 @@ for step in range(steps):      # steps 3 and 4 replay the captured hipGraphs wit
         out['fake_mask'] = model.fake_B_mask_raw.detach().cpu().clone()
 torch.cuda.synchronize()
 if steps > 2:
-    assert model._graphs is not None and len(model._graphs) == 3 and model.dp_schedule == 'captured' and not model._inline_exchange
+    assert model._graphs is not None and len(model._graphs) == 3 and model.dp_schedule == 'graphs' and not model._inline_exchange
 out['wN'] = snap()
 out['lN'] = dict(model.get_current_losses())
 out['overflow'] = model.overflow_steps()
@@ -276,9 +276,9 @@ print('ok')
 
 @pytest.mark.parametrize('schedule,precision', [('captured', 'fp16'), ('captured', 'fp32'), ('graphs', 'fp32')])
 def test_rccl_exchange_path_single_rank(tmp_path, schedule, precision):
-    """The gradient exchange exactly as a multi-GPU job issues it -- RCCL all-reduce (ncclAvg) of the flat gradient buffers CAPTURED INSIDE the step's one
-    hipGraph (D_k's forked from D_k's stream, G's before its Adam step; default), or issued on the exchange stream between the step's three graphs
-    (HV_DP_SCHEDULE=graphs) -- plus broadcast, barrier and the MAX-reduce of the bench clock, in a one-rank RCCL group: averaging over one rank is the
+    """The gradient exchange exactly as a multi-GPU job issues it -- RCCL all-reduce (ncclAvg) of the flat gradient buffers on the exchange stream between the
+    step's three graphs (default), or as direct ncclAllReduce calls CAPTURED INSIDE the step's one hipGraph (HV_DP_SCHEDULE=captured: D_k's on D_k's
+    stream, G's before its Adam step; a communicator of our own, ddp.RcclComm) -- plus broadcast, barrier and the MAX-reduce of the bench clock, in a one-rank RCCL group: averaging over one rank is the
     identity, so the weights after five steps (three of them graph replays) must equal those of a run without a process group, bit for bit."""
     port = str(29700 + os.getpid() % 1000 + (1000 if schedule == 'graphs' else 0) + (500 if precision == 'fp16' else 0))
     outs = []
@@ -327,21 +327,22 @@ def test_bench_two_ranks_rehearsal_over_gloo():
 
 
 def test_bench_data_parallel_dress_rehearsal_on_one_device():
-    """The driver's multi-GPU bench without a node: the real bench with the data-parallel step (RCCL all-reduces captured inside the one step graph) in a
-    one-rank RCCL group, and the same started as TWO ranks by torch.distributed.run on this one device (gloo transport): the JSON line must report
+    """The driver's multi-GPU bench without a node: the real bench with the data-parallel step in a one-rank RCCL group -- the default cut schedule (three
+    graphs, the means between them through torch.distributed) and the captured one (direct ncclAllReduce calls inside the one step graph) --, and the
+    same started as TWO ranks by torch.distributed.run on this one device (gloo transport): the JSON line must report
     what the collective layer saw (n_gpus, global batch, backend, world size, schedule, graphs per step).  The step-time ratio against the
     single-process step is printed, and asserted only under HV_PERF_ASSERT=1 (wall-clock ratios do not belong in a correctness suite: tools/dp_ratio.sh)."""
     plain = _bench({}, ['--steps', '10', '--warmup', '3'])
     assert plain['n_gpus'] == 1 and plain['comm']['world_size'] == 1 and '1 graphs' in plain['config']['launch'], plain['config']      # (single process: the whole step is one graph)
     assert len(plain['regions_ms_per_step']) == 3 and plain['ms_per_step'] == sorted(plain['regions_ms_per_step'])[1]
     one = _bench({'HV_DDP_FORCE': '1'}, ['--steps', '10', '--warmup', '3'])
-    assert one['comm']['backend'] == 'nccl' and one['comm']['world_size'] == 1 and one['comm']['dp_schedule'] == 'captured', one['comm']
-    assert '1 graphs' in one['config']['launch'] and one['comm']['capture_error'] is None, (one['comm'], one['config'])
-    cut = _bench({'HV_DDP_FORCE': '1', 'HV_DP_SCHEDULE': 'graphs'}, ['--steps', '10', '--warmup', '3'])
-    assert '3 graphs' in cut['config']['launch'] and cut['comm']['dp_schedule'] == 'graphs', (cut['comm'], cut['config'])
-    print('data-parallel schedule in a one-rank RCCL group: captured %.3f ms, cut %.3f ms, single process %.3f ms' % (one['ms_per_step'], cut['ms_per_step'], plain['ms_per_step']))
+    assert one['comm']['backend'] == 'nccl' and one['comm']['world_size'] == 1 and one['comm']['dp_schedule'] == 'graphs', one['comm']
+    assert '3 graphs' in one['config']['launch'], (one['comm'], one['config'])
+    cap = _bench({'HV_DDP_FORCE': '1', 'HV_DP_SCHEDULE': 'captured'}, ['--steps', '10', '--warmup', '3'])
+    assert '1 graphs' in cap['config']['launch'] and cap['comm']['dp_schedule'] == 'captured' and cap['comm']['capture_error'] is None, (cap['comm'], cap['config'])
+    print('data-parallel schedule in a one-rank RCCL group: cut (default) %.3f ms, captured %.3f ms, single process %.3f ms' % (one['ms_per_step'], cap['ms_per_step'], plain['ms_per_step']))
     if os.environ.get('HV_PERF_ASSERT') == '1':
-        assert one['ms_per_step'] <= 1.03 * plain['ms_per_step'], ('captured data-parallel step vs single-process step', one['ms_per_step'], plain['ms_per_step'])
+        assert cap['ms_per_step'] <= 1.03 * plain['ms_per_step'], ('captured data-parallel step vs single-process step', cap['ms_per_step'], plain['ms_per_step'])
     two = _bench({'HV_DDP_BACKEND': 'gloo'}, ['--gpus', '2', '--steps', '4', '--warmup', '3'],
                  launcher=[sys.executable, '-m', 'torch.distributed.run', '--standalone', '--nnodes=1', '--nproc-per-node', '2', '--local-addr', '127.0.0.1'])
     assert two['n_gpus'] == 2 and two['config']['global_batch'] == 32 and two['config']['parallelism'] == 'dp2', two['config']
