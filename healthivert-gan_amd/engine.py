@@ -357,7 +357,11 @@ class GradBook:
         return acc
 
 
-DEFER_FOLDS = os.environ.get('HV_DEFER_FOLDS', '1') != '0'   # A/B knob: one slab-fold launch per network instead of one per weight gradient
+# One slab-fold launch per network instead of one per weight gradient (hv_wgrad_desc.pending / hv_wgrad_fold_batched).  Built in round 4 because the 62
+# wgrad_reduce launches per step looked like pure overhead; measured (three same-box pairs): 7.595 / 7.664 / 7.619 ms with the per-layer folds against
+# 7.667 / 7.676 / 7.659 ms deferred -- the per-layer fold reads slabs that are still in L2 / the Infinity Cache, the batched one reads 0.7 GB per step back
+# from HBM at the end of the backward, on the critical path.  Off by default; HV_DEFER_FOLDS=1 switches it on.
+DEFER_FOLDS = os.environ.get('HV_DEFER_FOLDS', '0') != '0'
 
 
 def _wgrad(node, p, xin, gfull, accumulate, prec, dbias=None, dbias_accumulate=False):
