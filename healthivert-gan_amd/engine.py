@@ -322,6 +322,10 @@ class GradBook:
         # (six same-box pairs, tools/ab_step.sh): in line is faster now, 8.25 -> 8.15 ms on average -- every kernel fills the chip, and the per-layer
         # fork / join edges cost more than the overlap returns.  HV_OVERLAP_WGRAD=1 brings the side stream back.
         self.overlap = os.environ.get('HV_OVERLAP_WGRAD', '0') != '0'
+        # block deferral (round 4): while `defer_wgrad` is set, conv_backward queues its weight gradient here instead of launching it; the owner of the
+        # plan launches the whole block later on ONE side stream (one fork, one join) beside an independent part of the backward
+        self.defer_wgrad = False
+        self.deferred = []
 
     def can_fork(self):
         return self.overlap and not SERIAL and torch.cuda.current_stream().cuda_stream not in NO_FORK_STREAMS
@@ -402,9 +406,13 @@ def conv_backward(node, book, prec, dbias_accumulate=False, wgrad_accumulate=Fal
         xin = Act(xs.t, p.cin_wg, xs.coff)
         # the weight gradient only feeds the optimiser: queue it on the side stream so that it overlaps the data-gradient
         # chain (joined by GradBook.join() before the gradients are finalised / the activations are overwritten)
-        ctx = torch.cuda.stream(book.fork()) if book.can_fork() else contextlib.nullcontext()
-        with ctx:
-            _wgrad(node, p, xin, gfull, wgrad_accumulate, prec, dbias=p.bias.grad if fuse_dbias else None, dbias_accumulate=dbias_accumulate)
+        if book.defer_wgrad:      # (its operands -- the layer's input and the finished gradient of its output -- stay as they are until the next backward)
+            book.deferred.append(lambda node=node, p=p, xin=xin, gfull=gfull, acc=wgrad_accumulate, db=p.bias.grad if fuse_dbias else None, dba=dbias_accumulate:
+                                 _wgrad(node, p, xin, gfull, acc, prec, dbias=db, dbias_accumulate=dba))
+        else:
+            ctx = torch.cuda.stream(book.fork()) if book.can_fork() else contextlib.nullcontext()
+            with ctx:
+                _wgrad(node, p, xin, gfull, wgrad_accumulate, prec, dbias=p.bias.grad if fuse_dbias else None, dbias_accumulate=dbias_accumulate)
     if node.need_dx and node.transposed:
         gx = book.twin(node.x)
         gx = Act(gx.t, p.cin_fwd, gx.coff)

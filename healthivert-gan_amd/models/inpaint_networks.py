@@ -315,6 +315,9 @@ class _GenPlan:
         self.g_head = {n: z(H, W, 1) for n in ('c17', 'c18', 'f17', 'f18')}
 
 
+G_WGRAD_BLOCK = _os_.environ.get('HV_G_WGRAD_BLOCK', '1') != '0'     # A/B knob: see Generator.run_backward
+
+
 class Generator(nn.Module):
     def __init__(self, config, use_cuda):
         super().__init__()
@@ -492,6 +495,11 @@ class Generator(nn.Module):
             if node.split_forward(prec):
                 with (torch.cuda.stream(book.fork()) if book.can_fork() else contextlib.nullcontext()):
                     ops.copy_channels(low, cat.slice(0, k2), mode=1)
+        # the refinement generator's weight gradients as ONE block on a side stream beside the coarse generator's whole backward (round 4, HV_G_WGRAD_BLOCK):
+        # they only feed the optimiser, and the coarse backward -- a chain of small launches that leave most of a CU's registers and LDS free -- does not
+        # depend on them.  One fork and one join (the per-layer forks of HV_OVERLAP_WGRAD cost more than they returned).
+        wg_block = G_WGRAD_BLOCK and not E.SERIAL and not book.can_fork() and torch.cuda.current_stream().cuda_stream not in E.NO_FORK_STREAMS
+        book.defer_wgrad = bool(wg_block)
         # ---- fine: heads
         self._head_backward(P, M[7], d_x_stage2, 'f17', prec, book)
         self._head_backward(P, M[8], d_fine_seg, 'f18', prec, book)
@@ -532,6 +540,15 @@ class Generator(nn.Module):
         d_cs_total = P.d_cs_total
         ops.copy_channels(Act(d_coarse_seg.view(B, H, W, 1)), Act(d_cs_total.view(B, H, W, 1)), mode=0)
         ops.copy_channels(book.twin(P.f_in).slice(1, 1), Act(d_cs_total.view(B, H, W, 1)), mode=0, accumulate=True)
+        wg_side = None
+        if wg_block:
+            book.defer_wgrad = False
+            wg_side = E.named_stream('generator-wgrad-block', d_cs_total.device)
+            wg_side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(wg_side):
+                for launch in book.deferred:
+                    launch()
+            book.deferred = []
         # ---- coarse
         C = P.c_nodes
         # both heads read c16 (output of conv16, ELU): each applies elu'(c16) to its share of the gradient
@@ -561,6 +578,8 @@ class Generator(nn.Module):
                                     cg.fc_height.weight.grad, cg.fc_height.bias.grad, mul=(a['c10'], C[9].act) if pre10 else None)
         E.conv_backward_chain(list(reversed(C[:10])), book, prec, premultiplied_first=pre10)
         book.join()     # side-stream weight gradients
+        if wg_side is not None:
+            torch.cuda.current_stream().wait_stream(wg_side)
         self.paramset().finish_backward(accumulate=False)
         self.paramset().attach_grads()
 
