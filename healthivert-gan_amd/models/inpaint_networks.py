@@ -497,9 +497,19 @@ class Generator(nn.Module):
                     ops.copy_channels(low, cat.slice(0, k2), mode=1)
         # the refinement generator's weight gradients as ONE block on a side stream beside the coarse generator's whole backward (round 4, HV_G_WGRAD_BLOCK):
         # they only feed the optimiser, and the coarse backward -- a chain of small launches that leave most of a CU's registers and LDS free -- does not
-        # depend on them.  One fork and one join (the per-layer forks of HV_OVERLAP_WGRAD cost more than they returned).
+        # depend on them.  One fork and one join (the per-layer forks of HV_OVERLAP_WGRAD cost more than they returned).  Measured against it, three
+        # same-box pairs each: a first block launched before the two branches (three streams busy there) +0.13 ms; the coarse generator's own weight
+        # gradients in two more blocks +0.14 ms -- both removed.
         wg_block = G_WGRAD_BLOCK and not E.SERIAL and not book.can_fork() and torch.cuda.current_stream().cuda_stream not in E.NO_FORK_STREAMS
         book.defer_wgrad = bool(wg_block)
+        wg_side = E.named_stream('generator-wgrad-block', d_x_stage2.device) if wg_block else None
+
+        def launch_block():
+            wg_side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(wg_side):
+                for launch in book.deferred:
+                    launch()
+            book.deferred = []
         # ---- fine: heads
         self._head_backward(P, M[7], d_x_stage2, 'f17', prec, book)
         self._head_backward(P, M[8], d_fine_seg, 'f18', prec, book)
@@ -540,15 +550,9 @@ class Generator(nn.Module):
         d_cs_total = P.d_cs_total
         ops.copy_channels(Act(d_coarse_seg.view(B, H, W, 1)), Act(d_cs_total.view(B, H, W, 1)), mode=0)
         ops.copy_channels(book.twin(P.f_in).slice(1, 1), Act(d_cs_total.view(B, H, W, 1)), mode=0, accumulate=True)
-        wg_side = None
         if wg_block:
             book.defer_wgrad = False
-            wg_side = E.named_stream('generator-wgrad-block', d_cs_total.device)
-            wg_side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(wg_side):
-                for launch in book.deferred:
-                    launch()
-            book.deferred = []
+            launch_block()
         # ---- coarse
         C = P.c_nodes
         # both heads read c16 (output of conv16, ELU): each applies elu'(c16) to its share of the gradient
