@@ -378,6 +378,364 @@ __global__ __launch_bounds__(512, WPS) void conv_lf_kernel(const HaloK p) {
 #endif
 }
 
+typedef __attribute__((address_space(3))) void* lf_lds_ptr;
+// LDS-DMA: 16 bytes per lane, global -> LDS at dst + 16 * lane (device-only body: see conv_g4.hip)
+__device__ __forceinline__ void lf_dma16(__amdgpu_buffer_rsrc_t r, lf_lds_ptr dst, unsigned voff, int soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 16, voff, soff, 0, 0);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------------------
+// The same convolution for grids of more than one round of workgroups (the 128 x 128 and 256 x 256 layers: 4 .. 16 tiles per CU).  conv_lf_kernel pays its
+// prologue, its filter fetch (73 KB of the 136 KB a 64 -> 64 workgroup reads) and a launch-to-launch bubble once per TILE; here a workgroup stays, keeps
+// its filters in LDS and walks tiles blockIdx.x, + gridDim.x, ...: the next tile's patch is requested (into the registers the current patch has just left
+// for LDS) before the MFMAs of the current one, so it lands behind the MFMA loop and the epilogue; the filters go global -> LDS by LDS-DMA (their LDS image is the
+// tiled table's own byte order: no staging registers).  32-channel planes only (CIN 32 / 64).  Same arithmetic, same order: bit-identical output.
+template <int CIN, int CO, int TH, int WPS, bool X1 = false>
+__global__ __launch_bounds__(512, WPS) void conv_lfp_kernel(const HaloK p, const int total) {
+    typedef LfCfg<CIN, CO, TH> G;
+    constexpr int T = G::T, NPL = G::NPL, LDP = G::LDP, MT = G::MT, NT = G::NT, PW = G::PW, PH = G::PH, TW = G::TW;
+    typedef typename HFrag<T>::V V;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    _Float16* wl = reinterpret_cast<_Float16*>(smem);
+    _Float16* patch = wl + G::WHALFS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const HaloCls& C = p.cls[0];
+    const int n_base = blockIdx.y * CO;
+    struct Tile { int ry, rx, n_img, i0, j0; };
+    auto decode = [&](int t) __attribute__((always_inline)) {
+        Tile tl; tl.ry = 0; tl.rx = 0;
+        if (p.dil > 1) {
+            const int per = C.tiles * p.B, rid = t / per;
+            t -= rid * per;
+            tl.ry = rid / p.dil; tl.rx = rid - tl.ry * p.dil;
+        }
+        tl.n_img = t / C.tiles;
+        t -= tl.n_img * C.tiles;
+        const int tile_y = t / C.tiles_x, tile_x = t - tile_y * C.tiles_x;
+        tl.i0 = tile_y * TH; tl.j0 = tile_x * TW;
+        return tl;
+    };
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.w), 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
+    constexpr int FB = 16 * T * 2, IPF = FB / 16;
+    constexpr int PPI = (PH * PW * (T / 8) + G::NTHR - 1) / G::NTHR;
+    static_assert(T == 32, "1-KB filter fragments");
+    constexpr int NFRAG = (CO / 16) * 9;
+    u32x4 preg[NPL][PPI];
+    int plo[PPI], ppy[PPI], ppx[PPI];
+#pragma unroll
+    for (int i = 0; i < PPI; ++i) {
+        const int e = tid + i * G::NTHR;
+        const int c8 = e % (T / 8), pix = e / (T / 8);
+        ppy[i] = pix / PW; ppx[i] = pix - ppy[i] * PW;
+        plo[i] = pix < PH * PW ? pix * LDP + c8 * 8 : -1;
+    }
+    // byte offsets of this thread's patch items for a tile (HV_OOB: outside the image -> zeros)
+    auto patch_offsets = [&](const Tile& tl, unsigned (&pvo)[PPI]) __attribute__((always_inline)) {
+        const int h0 = tl.i0 + p.boff + C.dh_min, w0 = tl.j0 + p.boff + C.dw_min;
+        const unsigned xbase = (unsigned)(tl.n_img * p.img_stride + p.x_coff) * 2u;
+#pragma unroll
+        for (int i = 0; i < PPI; ++i) {
+            const int hi = h0 + ppy[i], wi = w0 + ppx[i];
+            const int c8 = (tid + i * G::NTHR) % (T / 8);
+            pvo[i] = (plo[i] >= 0 && (unsigned)hi < (unsigned)p.Hl && (unsigned)wi < (unsigned)p.Wl)
+                         ? xbase + (unsigned)((((tl.ry + hi * p.dil) >> p.in_shift) * p.Wp + ((tl.rx + wi * p.dil) >> p.in_shift)) * p.x_ld + c8 * 8) * 2u : HV_OOB;
+        }
+    };
+    float* x1p = reinterpret_cast<float*>(smem + (size_t)(G::WHALFS + G::TAIL_HALFS) * 2);
+    float* w1s = x1p + PH * PW;
+    float x1v[2] = {0.f, 0.f}, w1v[2] = {0.f, 0.f};
+    auto x1_loads = [&](const Tile& tl) __attribute__((always_inline)) {
+        const int h0 = tl.i0 + p.boff + C.dh_min, w0 = tl.j0 + p.boff + C.dw_min;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = tid + u * G::NTHR;
+            x1v[u] = 0.f;
+            if (e < PH * PW) {
+                const int py = e / PW, px = e - py * PW, hi = h0 + py, wi = w0 + px;
+                if ((unsigned)hi < (unsigned)p.Hl && (unsigned)wi < (unsigned)p.Wl) x1v[u] = hv_ld1(p.x1, ((long long)(tl.n_img * p.Hl + hi) * p.Wl + wi) * p.x1_ld + p.x1_coff, p.x1_half);
+            }
+        }
+    };
+    int tcur = (int)blockIdx.x;
+    Tile cur = decode(tcur);
+    {
+        unsigned pvo[PPI];
+        patch_offsets(cur, pvo);
+        const unsigned wbase = (unsigned)(n_base / 16) * (unsigned)(16 * 9 * CIN * 2);
+#pragma unroll
+        for (int kc = 0; kc < NPL; ++kc) {
+            // plane kc of the filters (fragment f of the plane = 1 KB = one wave's DMA), then of the first patch: loads return in order, so the wait for the
+            // patch plane in front of its LDS stores covers the filter plane as well
+#pragma unroll
+            for (int i = 0; i < (NFRAG + G::NW - 1) / G::NW; ++i) {
+                const int f = wave + G::NW * i;
+                if (f < NFRAG) lf_dma16(wsrc, (lf_lds_ptr)(reinterpret_cast<char*>(wl) + (f * NPL + kc) * FB), (unsigned)lane * 16u, (int)wbase + (f * NPL + kc) * FB);
+            }
+#pragma unroll
+            for (int i = 0; i < PPI; ++i) preg[kc][i] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, pvo[i], kc * T * 2, 0);
+        }
+    }
+    static_assert(!X1 || (PH * PW <= 2 * G::NTHR && CO * 9 <= 2 * G::NTHR), "two patch values, two filter values per thread");
+    if constexpr (X1) {
+        x1_loads(cur);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = tid + u * G::NTHR, co = n_base + e / 9, tp = e % 9;
+            if (e < CO * 9 && co < p.Cout) w1v[u] = p.w1[(long long)co * p.w1_row + tp * p.w1_tap];
+            if (e < CO * 9) w1s[e] = w1v[u];      // (tile-invariant: parked once; x1p changes with the tile)
+        }
+    }
+    int toff[9], widx[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        const uint32_t e = C.taps[q];
+        toff[q] = ((int)(e & 0xff) * PW + (int)((e >> 8) & 0xff)) * LDP;
+        widx[q] = (int)(e >> 16);
+    }
+    const __amdgpu_buffer_rsrc_t bsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.bias ? (unsigned)p.Cout * 4u : 0u, 0x00020000);
+    f32x4 bias_r[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+        bias_r[n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bsrc, (unsigned)(n_base + n * 16 + (lane >> 4) * 4) * 4u, 0, 0));
+    const int poff = (wave * MT * PW + (lane & 15)) * LDP + (lane >> 4) * (T / 4);
+    const int aoff = lane * (T / 4);
+    constexpr int PIECES = CO / 8;
+    constexpr int OITEMS = TH * TW * PIECES / G::NTHR;
+    static_assert(TH * TW * PIECES % G::NTHR == 0, "output pieces per thread");
+    constexpr int PPIX = (TH / 2) * (TW / 2), PITEMS = (PPIX * PIECES + G::NTHR - 1) / G::NTHR;
+    constexpr int LDO = G::LDO;
+    const __amdgpu_buffer_rsrc_t msrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.mul_src), 0, p.mul_src ? 0x7ffffff0u : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ysrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.accumulate ? 0x7ffffff0u : 0u, 0x00020000);
+    constexpr bool EPI = !X1;              // act' multiplier / accumulate forms (data gradients): never together with the extra input channel
+    const bool pooled = p.pool2 != 0;      // scalar
+    _Float16* yb = reinterpret_cast<_Float16*>(p.y);
+    _Float16* ot = patch;
+    bool more;
+
+    auto pass = [&]() __attribute__((always_inline)) {      // one tile
+        const int tn = tcur + (int)gridDim.x;
+        more = tn < total;
+        const Tile nxt = decode(more ? tn : tcur);
+        unsigned pvn[PPI];
+        patch_offsets(nxt, pvn);
+        if (!more) {
+#pragma unroll
+            for (int i = 0; i < PPI; ++i) pvn[i] = HV_OOB;
+        }
+        f32x4 acc[NT][MT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        V a[2][NT], b[2][MT];
+#pragma unroll
+        for (int kc = 0; kc < NPL; ++kc) {
+#pragma unroll
+            for (int i = 0; i < PPI; ++i)
+                if (plo[i] >= 0) *reinterpret_cast<u32x4*>(patch + kc * G::PLANE + plo[i]) = preg[kc][i];
+            // the next tile's plane, into the registers this one has just left
+#pragma unroll
+            for (int i = 0; i < PPI; ++i) preg[kc][i] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, pvn[i], kc * T * 2, 0);
+            __syncthreads();
+            auto frags = [&](int q, int buf) __attribute__((always_inline)) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n) a[buf][n] = *reinterpret_cast<const V*>(wl + ((n * 9 + widx[q]) * NPL + kc) * (16 * T) + aoff);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) b[buf][m] = *reinterpret_cast<const V*>(patch + kc * G::PLANE + poff + m * PW * LDP + toff[q]);
+            };
+            frags(0, 0);
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                if (q + 1 < 9) frags(q + 1, (q + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) acc[n][m] = HFrag<T>::mma(a[q & 1][n], b[q & 1][m], acc[n][m]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        const int i0 = cur.i0, j0 = cur.j0, n_img = cur.n_img, ry = cur.ry, rx = cur.rx;
+        u32x4 mreg[OITEMS], yreg[OITEMS];
+        long long ooff[OITEMS];
+        if (!pooled) {
+#pragma unroll
+            for (int k = 0; k < OITEMS; ++k) {
+                const int it = tid + k * G::NTHR;
+                const int q = it / PIECES, pc = it - q * PIECES;
+                const int i = i0 + (q >> 4), j = j0 + (q & 15), ch = n_base + pc * 8;
+                const bool ok = i < C.Hc && j < C.Wc && ch < p.Cout;
+                const int ho = C.ph + ry + i * p.ostep, wo = C.pw + rx + j * p.ostep;
+                const long long opix = (long long)(n_img * p.Ho + ho) * p.Wo + wo;
+                ooff[k] = ok ? opix * p.y_ld + p.y_coff + ch : -1;
+                if constexpr (EPI) {
+                    mreg[k] = __builtin_amdgcn_raw_buffer_load_b128(msrc, ok ? (unsigned)((opix * p.mul_ld + p.mul_coff + ch) * 2) : HV_OOB, 0, 0);
+                    yreg[k] = __builtin_amdgcn_raw_buffer_load_b128(ysrc, ok ? (unsigned)(ooff[k] * 2) : HV_OOB, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = PITEMS; k < OITEMS; ++k) { ooff[k] = -1; if constexpr (EPI) mreg[k] = yreg[k] = (u32x4){0u, 0u, 0u, 0u}; }
+#pragma unroll
+            for (int k = 0; k < PITEMS; ++k) {
+                const int it = tid + k * G::NTHR;
+                const int q = it / PIECES, pc = it - q * PIECES;
+                const int il = (i0 >> 1) + q / (TW / 2), jl = (j0 >> 1) + q % (TW / 2), ch = n_base + pc * 8;
+                const bool ok = q < PPIX && il < p.Ho && jl < p.Wo && ch < p.Cout;
+                const long long opix = (long long)(n_img * p.Ho + il) * p.Wo + jl;
+                ooff[k] = ok ? opix * p.y_ld + p.y_coff + ch : -1;
+                if constexpr (EPI) {
+                    mreg[k] = __builtin_amdgcn_raw_buffer_load_b128(msrc, ok ? (unsigned)((opix * p.mul_ld + p.mul_coff + ch) * 2) : HV_OOB, 0, 0);
+                    yreg[k] = __builtin_amdgcn_raw_buffer_load_b128(ysrc, ok ? (unsigned)(ooff[k] * 2) : HV_OOB, 0, 0);
+                }
+            }
+        }
+        if constexpr (X1) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (tid + u * G::NTHR < PH * PW) x1p[tid + u * G::NTHR] = x1v[u];
+            }
+            if (more) x1_loads(nxt);
+        }
+        __syncthreads();          // every wave is done with the patch: its room becomes the output staging tile
+        if constexpr (X1) {
+            float cv[MT][9];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int q = (wave * MT + m) * 16 + (lane & 15);
+#pragma unroll
+                for (int t9 = 0; t9 < 9; ++t9) {
+                    const uint32_t e = C.taps[t9];
+                    cv[m][t9] = x1p[((q >> 4) + (int)(e & 0xff)) * PW + (q & 15) + (int)((e >> 8) & 0xff)];
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                float w9[4][9];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int t9 = 0; t9 < 9; ++t9) w9[r][t9] = w1s[(n * 16 + (lane >> 4) * 4 + r) * 9 + widx[t9]];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        float ex = 0.f;
+#pragma unroll
+                        for (int t9 = 0; t9 < 9; ++t9) ex += cv[m][t9] * w9[r][t9];
+                        float v = acc[n][m][r] + ex;
+                        asm volatile("" : "+v"(v) : : "memory");
+                        acc[n][m][r] = v;
+                    }
+            }
+        }
+        auto stage = [&](auto actf) __attribute__((always_inline)) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int q = (wave * MT + m) * 16 + (lane & 15);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    f16x4v h;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h[r] = (_Float16)actf(acc[n][m][r] * p.alpha + bias_r[n][r]);
+                    *reinterpret_cast<f16x4v*>(ot + q * LDO + n * 16 + (lane >> 4) * 4) = h;
+                }
+            }
+        };
+        switch (p.act) {
+            case HV_ACT_ELU:
+                stage([](float v) { const float e = __builtin_amdgcn_exp2f(v * 1.44269504f) - 1.f, sm = v + 0.5f * v * v; return v > 0.f ? v : (v > -0.00390625f ? sm : e); });
+                break;
+            case HV_ACT_RELU: stage([](float v) { return v > 0.f ? v : 0.f; }); break;
+            case HV_ACT_LRELU: stage([](float v) { return v > 0.f ? v : 0.2f * v; }); break;
+            case HV_ACT_SIGMOID: stage([](float v) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-v * 1.44269504f)); }); break;
+            case HV_ACT_CLAMP: stage([](float v) { return fminf(fmaxf(v, -1.f), 1.f); }); break;
+            default: stage([](float v) { return v; }); break;
+        }
+        __syncthreads();
+        u32x4 o[OITEMS];
+        if (!pooled) {
+#pragma unroll
+            for (int k = 0; k < OITEMS; ++k) {
+                const int it = tid + k * G::NTHR;
+                const int q = it / PIECES, pc = it - q * PIECES;
+                o[k] = *reinterpret_cast<const u32x4*>(ot + q * LDO + pc * 8);
+            }
+        } else {
+#pragma unroll
+            for (int k = PITEMS; k < OITEMS; ++k) o[k] = (u32x4){0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int k = 0; k < PITEMS; ++k) {
+                const int it = tid + k * G::NTHR;
+                const int q = it / PIECES, pc = it - q * PIECES;
+                const int r2 = 2 * (q / (TW / 2)), c2 = 2 * (q % (TW / 2));
+                float sum[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sum[e] = 0.f;
+                if (q < PPIX) {
+#pragma unroll
+                    for (int dd = 0; dd < 4; ++dd) {
+                        const int rr = r2 + (dd >> 1), cc = c2 + (dd & 1);
+                        if (i0 + rr < C.Hc && j0 + cc < C.Wc) {
+                            const f16x8 v8 = *reinterpret_cast<const f16x8*>(ot + (rr * TW + cc) * LDO + pc * 8);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) sum[e] += (float)v8[e];
+                        }
+                    }
+                }
+                f16x8 h8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) h8[e] = (_Float16)sum[e];
+                o[k] = __builtin_bit_cast(u32x4, h8);
+            }
+        }
+        if (more) __syncthreads();      // the staging tile has been read: the next pass may put its patch there
+        if (EPI && p.mul_src) {
+            auto mulf = [&](auto gradf) __attribute__((always_inline)) {
+#pragma unroll
+                for (int k = 0; k < OITEMS; ++k) {
+                    const f16x8 m8 = __builtin_bit_cast(f16x8, mreg[k]);
+                    f16x8 v8 = __builtin_bit_cast(f16x8, o[k]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v8[e] = (_Float16)((float)v8[e] * gradf((float)m8[e]));
+                    o[k] = __builtin_bit_cast(u32x4, v8);
+                }
+            };
+            switch (p.mul_act) {
+                case HV_ACT_ELU: mulf([](float y) { return y > 0.f ? 1.f : y + 1.f; }); break;
+                case HV_ACT_RELU: mulf([](float y) { return y > 0.f ? 1.f : 0.f; }); break;
+                case HV_ACT_LRELU: mulf([](float y) { return y > 0.f ? 1.f : 0.2f; }); break;
+                case HV_ACT_SIGMOID: mulf([](float y) { return y * (1.f - y); }); break;
+                case HV_ACT_CLAMP: mulf([](float y) { return (y > -1.f && y < 1.f) ? 1.f : 0.f; }); break;
+                default: break;
+            }
+        }
+        if (EPI && p.accumulate) {
+#pragma unroll
+            for (int k = 0; k < OITEMS; ++k) {
+                const f16x8 y8 = __builtin_bit_cast(f16x8, yreg[k]);
+                f16x8 v8 = __builtin_bit_cast(f16x8, o[k]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v8[e] = (_Float16)((float)v8[e] + (float)y8[e]);
+                o[k] = __builtin_bit_cast(u32x4, v8);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < OITEMS; ++k)
+            if (ooff[k] >= 0) *reinterpret_cast<u32x4*>(yb + ooff[k]) = o[k];
+        cur = nxt;
+        tcur = tn;
+    };
+    // the filters arrive by DMA, which the compiler's own wait counting does not tie to the LDS reads below: everything requested so far (filters, first patch,
+    // bias) has landed before the first pass (one full wait per workgroup, not per tile)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    do pass(); while (more);
+}
+
+
 template <int CIN, int CO, int TH, int WPS, bool X1 = false>
 static int launch_lf(HaloK& k, hipStream_t s) {
     typedef LfCfg<CIN, CO, TH> G;
@@ -397,10 +755,35 @@ static int launch_lf(HaloK& k, hipStream_t s) {
         if (e != hipSuccess) return -1000 - (int)e;
         raised = true;
     }
-    dim3 grid(C.tiles * kk.B * (kk.dil > 1 ? kk.dil * kk.dil : 1), hv_cdiv(kk.Cout, CO));
+    const int total = C.tiles * kk.B * (kk.dil > 1 ? kk.dil * kk.dil : 1);
+    dim3 grid(total, hv_cdiv(kk.Cout, CO));
     hv_path_note = 7;
-    HV_KNAME("conv_lf_kernel<%d, %d, %d, %d, %s>", CIN, CO, TH, WPS, X1 ? "true" : "false");      // (as rocprofv3 prints the instantiation)
     HV_WUSE(X1 ? 4 | 1 : 4);      // (the extra channel's filters come from the fp32 forward table)
+    // more than one round of workgroups where only ONE workgroup fits a CU (64 input channels: 80 .. 136 KB of LDS; the extra-channel forms: registers): the
+    // resident form (conv_lfp_kernel), one workgroup per CU walking its share of the tiles.  Back-to-back launches, bs 16: 64 -> 64 @128x128 40.7 -> 34.3 us,
+    // 64 -> 32 27.1 -> 21.6 us; with two workgroups per CU (32 input channels) the second workgroup already hides the first one's loads and the resident form
+    // gains nothing (32 -> 32 @128x128 14.1 vs 14.3 us, 32 -> 64 with the registers of one workgroup per CU 22.7 -> 25.2 us): those stay as they are.
+    static const int persist = getenv("HV_LF_PERSIST") ? atoi(getenv("HV_LF_PERSIST")) : 1;
+    constexpr int per_cu = (int)((160 * 1024) / G::LDS_BYTES) < WPS / 2 ? (int)((160 * 1024) / G::LDS_BYTES) : WPS / 2;
+    if constexpr (G::T == 32 && per_cu <= 1) {
+        constexpr int slots = 256;      // MI355X: 256 CUs
+        if (persist && grid.y == 1 && total > slots && !(X1 && (kk.mul_src || kk.accumulate))) {      // (the extra channel is a forward form: no act' / accumulate there)
+            constexpr int WPSP = 2;     // (the next patch stays in registers across the whole pass)
+            auto kp = conv_lfp_kernel<CIN, CO, TH, WPSP, X1>;
+            static bool raised_p = false;
+            if (G::LDS_BYTES > 48 * 1024 && !raised_p) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) return -1000 - (int)e;
+                raised_p = true;
+            }
+            grid.x = slots;
+            HV_KNAME("conv_lfp_kernel<%d, %d, %d, %d, %s>", CIN, CO, TH, WPSP, X1 ? "true" : "false");
+            hipLaunchKernelGGL(kp, grid, dim3(G::NTHR), G::LDS_BYTES, s, kk, total);
+            HV_LAUNCH_CHECK();
+            return HV_OK;
+        }
+    }
+    HV_KNAME("conv_lf_kernel<%d, %d, %d, %d, %s>", CIN, CO, TH, WPS, X1 ? "true" : "false");      // (as rocprofv3 prints the instantiation)
     hipLaunchKernelGGL(kern, grid, dim3(G::NTHR), G::LDS_BYTES, s, kk);
     HV_LAUNCH_CHECK();
     return HV_OK;

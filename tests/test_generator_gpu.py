@@ -582,6 +582,50 @@ print('LOSSES ' + json.dumps({k: float(v) for k, v in m.get_current_losses().ite
         assert abs(res['0'][k] - v) <= tol * max(1.0, abs(v)), (k, res['0'][k], v)
 
 
+def test_resident_filters_in_lds_kernel_is_bit_identical_to_the_per_tile_one():
+    """conv_lfp_kernel (one workgroup per CU walking several tiles, filters by LDS-DMA, next patch prefetched; taken by the 64-input-channel and the
+    extra-channel 3x3 layers when their grid is more than one round: 128 x 128 and 256 x 256 at bs 16) does the same arithmetic in the same order as
+    conv_lf_kernel: one bs-16 generator forward + backward with HV_LF_PERSIST=1 / 0 (read once by the C side: own processes) gives bit-identical outputs and
+    parameter gradients, and the resident kernel really ran in the first process."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = r'''
+import hashlib, os, sys, torch
+sys.path.insert(0, %r)
+os.environ['HV_PRECISION'] = 'fp16'
+import hvgan
+from hvgan import synth, profiler, engine
+from hvgan.models.inpaint_networks import Generator
+torch.manual_seed(7)
+dev = torch.device('cuda:0')
+b = synth.to_model_inputs(synth.make_batch(16, 256, seed=11))
+args = [b['real_A'].to(dev), b['mask'].to(dev), (1 - b['CAM']).to(dev), b['slice_ratio'].to(dev)]
+G = Generator({'input_dim': 1, 'ngf': 16}, True).to(dev)
+engine.SERIAL = True
+prof = profiler.KernelTimer(); prof.enable()
+P = G.run_forward(*args, training=True)
+g = torch.Generator().manual_seed(3)
+seeds = [torch.randn(t.shape, generator=g).to(dev) * 1e-2 for t in (P.coarse_seg, P.fine_seg, P.x_stage1, P.x_stage2)]
+G.run_backward(P, seeds[0], seeds[1], seeds[2], seeds[3], None, None)
+torch.cuda.synchronize()
+names = sorted(set(prof.names.values())); prof.disable()
+h = hashlib.sha256()
+for t in [P.coarse_seg, P.fine_seg, P.x_stage1, P.x_stage2] + [q.grad for q in G.parameters() if q.grad is not None]:
+    h.update(t.detach().float().cpu().numpy().tobytes())
+print('HASH ' + h.hexdigest())
+print('LFP ' + str(sum('conv_lfp_kernel' in n for n in names)))
+''' % (ROOT,)
+    res = {}
+    for pz in ('1', '0'):
+        p = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, HV_LF_PERSIST=pz), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        assert p.returncode == 0, p.stdout.decode()[-3000:]
+        out = p.stdout.decode().splitlines()
+        res[pz] = ([l for l in out if l.startswith('HASH ')][-1], int([l for l in out if l.startswith('LFP ')][-1][4:]))
+    assert res['1'][1] >= 3 and res['0'][1] == 0, res
+    assert res['1'][0] == res['0'][0], res
+
+
 @pytest.mark.parametrize('precision', ['fp16', 'fp32'])
 def test_deferred_slab_folds_equal_the_per_layer_folds(precision, monkeypatch):
     """hv_wgrad_desc.pending: every weight gradient of a backward leaves its split-K slabs in the layer's own buffer and the network's folds run as ONE

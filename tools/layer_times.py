@@ -16,12 +16,12 @@ model.set_input(synth.make_batch(16, 256, seed=1234))
 for _ in range(2):
     model.optimize_parameters()
 torch.cuda.synchronize()
-prof = profiler.KernelTimer(); prof.enable()
+prof = profiler.KernelTimer(); prof.calibrate(); prof.enable()
 model.optimize_parameters()
 agg = prof.summary(); prof.disable()
 tot = sum(v[0] for v in agg.values())
 print('conv+wgrad total ms', round(tot, 3))
-for key, (ms, n, fl) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:28]:
+for key, (ms, n, fl) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:int(os.environ.get("ROWS", "28"))]:
     print('%7.3f ms  n=%2d  avg %7.1f us  %6.1f TF  %s' % (ms, n, ms / n * 1e3, fl / (ms / n * 1e-3) / 1e12, profiler.describe(key, prof.paths.get(key))))
 kinds = {}
 for key, (ms, n, fl) in agg.items():
