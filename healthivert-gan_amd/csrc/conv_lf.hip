@@ -614,22 +614,26 @@ __global__ __launch_bounds__(512, WPS) void conv_lfp_kernel(const HaloK p, const
             }
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
-                float w9[4][9];
+                // two channels' filter values per batch of LDS reads (conv_lf_kernel takes four: the next patch's registers are live here)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                for (int rh = 0; rh < 2; ++rh) {
+                    float w9[2][9];
 #pragma unroll
-                    for (int t9 = 0; t9 < 9; ++t9) w9[r][t9] = w1s[(n * 16 + (lane >> 4) * 4 + r) * 9 + widx[t9]];
+                    for (int r = 0; r < 2; ++r)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                        for (int t9 = 0; t9 < 9; ++t9) w9[r][t9] = w1s[(n * 16 + (lane >> 4) * 4 + rh * 2 + r) * 9 + widx[t9]];
 #pragma unroll
-                    for (int m = 0; m < MT; ++m) {
-                        float ex = 0.f;
+                    for (int r = 0; r < 2; ++r)
 #pragma unroll
-                        for (int t9 = 0; t9 < 9; ++t9) ex += cv[m][t9] * w9[r][t9];
-                        float v = acc[n][m][r] + ex;
-                        asm volatile("" : "+v"(v) : : "memory");
-                        acc[n][m][r] = v;
-                    }
+                        for (int m = 0; m < MT; ++m) {
+                            float ex = 0.f;
+#pragma unroll
+                            for (int t9 = 0; t9 < 9; ++t9) ex += cv[m][t9] * w9[r][t9];
+                            float v = acc[n][m][rh * 2 + r] + ex;
+                            asm volatile("" : "+v"(v) : : "memory");
+                            acc[n][m][rh * 2 + r] = v;
+                        }
+                }
             }
         }
         auto stage = [&](auto actf) __attribute__((always_inline)) {
