@@ -24,6 +24,9 @@ from .edge_operator import Sobel
 from .inpaint_networks import Generator
 
 
+_THROUGH_AB = __import__('os').environ.get('HV_THROUGH_AB', '1') != '0'     # A/B knob: see Pix2PixModel._capture
+
+
 def _os_environ_graph():
     import os
     return os.environ.get('HV_GRAPH', '1') != '0'
@@ -124,6 +127,7 @@ class Pix2PixModel(BaseModel):
         if self.dp_schedule not in ('captured', 'graphs'):
             raise ValueError("HV_DP_SCHEDULE must be 'captured' or 'graphs'")
         self.real_first = _os.environ.get('HV_REAL_FIRST', '1') != '0'   # D real passes overlap the generator forward
+        self._through_ab = False
 
     # tensors forward()/backward bind as attributes; they live in per-shape buffers, so the names follow the active batch shape
     _STEP_OUTPUTS = ('fake_B', 'fake_B_coarse', 'fake_B_local', 'real_B_local', 'fake_B_mask_raw', 'coarse_seg_binary', 'coarse_seg_sigmoid',
@@ -422,7 +426,8 @@ class Pix2PixModel(BaseModel):
                     bw()
                 if self._inline_exchange:       # D_k's mean over the ranks, forked from D_k's stream: beside the other discriminators' passes
                     self.grad_sync.reduce_inline(getattr(self, 'netD_%d' % k).paramset().flat_grad)
-        self._join_d(main)
+        if not self._through_ab:
+            self._join_d(main)
 
     def _phase_b(self):
         """D_k optimiser step, D_k forward on the fakes with the updated weights (its own stream), generator losses and
@@ -430,7 +435,7 @@ class Pix2PixModel(BaseModel):
         main = torch.cuda.current_stream(self.device)
         for k in (1, 2, 3):
             side = self._d_streams[k - 1] if (self.concurrent_d and not engine.SERIAL) else main
-            if side is not main:
+            if side is not main and not self._through_ab:
                 side.wait_stream(main)
             with torch.cuda.stream(side):
                 self._opt_step(getattr(self, 'optimizer_D_%d' % k), getattr(self, 'netD_%d' % k))
@@ -595,7 +600,14 @@ class Pix2PixModel(BaseModel):
         one = self.one_graph and not cut      # (the cut data-parallel schedule issues its gradient means between the graphs)
 
         def whole():
-            self._phase_a(); self._phase_b(); self._phase_c()
+            # one graph: D_k goes from its backward straight on to its Adam step and its pass for the generator on its own stream -- no join of the three
+            # discriminator streams between the phases (that join only exists for the cut schedule's exchange): a discriminator that is done early
+            # (D_3 reads the 128 x 128 crop) does not wait for the others
+            self._through_ab = self.concurrent_d and not engine.SERIAL and _THROUGH_AB
+            try:
+                self._phase_a(); self._phase_b(); self._phase_c()
+            finally:
+                self._through_ab = False
         for phase in ((whole,) if one else (self._phase_a, self._phase_b, self._phase_c)):
             g = torch.cuda.CUDAGraph()
             # thread_local: a process-group watchdog thread polling its events must not invalidate the capture
