@@ -517,7 +517,9 @@ static bool wgrad_tr_plan(const hv_wgrad_desc* d, WTrPlan* pl) {
     } else if (d->Ho != (d->H + 2 * d->pad - d->KH) / d->stride + 1 || d->Wo != (d->W + 2 * d->pad - d->KW) / d->stride + 1) return false;
     // 16-byte staging items: 8-channel groups must be whole and aligned in both tensors
     if ((d->Cin & 7) || (d->Cout & 7) || (d->x_ld & 7) || (d->x_coff & 7) || (d->g_ld & 7) || (d->g_coff & 7)) return false;
-    if (d->Cout < 32 || d->Cin < 16) return false;        // narrower layers: wgrad_halo_kernel / the gather kernel
+    // narrower layers: wgrad_halo_kernel / the gather kernel -- except the 16 -> 16 stride-2 layers, which the gather kernel served at 24.3 us (bs 16, 256 x 256):
+    // as half-empty 32-filter blocks here 14.8 us (round 4; at stride 1 the 16-filter layers are as fast in wgrad_halo_kernel)
+    if (d->Cout < (d->stride == 2 ? 16 : 32) || d->Cin < 16) return false;
     pl->BN = d->Cout >= 64 ? 64 : 32;
     pl->BC = d->Cin >= 32 ? 32 : 16;
     {   // layers with a small dW (the generators' 64 x 64 x 9): every workgroup writes a whole slab of its tile pair, so 32-filter blocks halve the slab bytes

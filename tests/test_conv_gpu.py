@@ -635,11 +635,12 @@ WTR_CASES = [   # B, H, W, Cin, Cout, k, stride, pad
     (2, 32, 32, 72, 64, 3, 1, 1),         # the 65 (+7 pad) channel concat input of conv20
     (2, 32, 32, 32, 64, 3, 2, 1),         # 3x3 stride-2 downsampling layers
     (2, 64, 48, 16, 32, 3, 2, 1),
+    (2, 64, 48, 16, 16, 3, 2, 1),         # 16 filters at stride 2: a half-empty 32-filter block
     (12, 128, 96, 64, 128, 4, 2, 1),      # enough pixel tiles per workgroup for the LDS-DMA form (wgrad_trd_kernel), stride 2 (32-channel blocks on the parity de-interleaved image) ...
     (12, 40, 56, 128, 256, 4, 2, 1),
     (4, 33, 47, 256, 296, 4, 1, 1),       # ... and stride 1 with ragged tiles and a partial 64-channel output block
 ]
-WTR_DMA = {0, 11, 12, 13}                 # indices of the cases the plan gives to the LDS-DMA form
+WTR_DMA = {0, 12, 13, 14}                 # indices of the cases the plan gives to the LDS-DMA form
 
 
 @pytest.mark.parametrize('case', WTR_CASES)
