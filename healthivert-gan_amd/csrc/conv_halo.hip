@@ -340,7 +340,7 @@ int hv_conv2d_halo(const hv_conv_desc* d, const void* w_f16, hipStream_t s) {
     const int Hf = d->H, Wf = d->W, Hof = d->Ho, Wof = d->Wo;
     if (dil != 1) {
         static const int dilated = getenv("HV_HALO_DILATED") ? atoi(getenv("HV_HALO_DILATED")) : 1;      // A/B knob
-        if (!dilated || (dil != 2 && dil != 4 && dil != 8) || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != dil || d->in_shift) return HV_ERR_UNSUPPORTED;
+        if (!dilated || (dil != 2 && dil != 4 && dil != 8 && dil != 16) || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != dil || d->in_shift) return HV_ERR_UNSUPPORTED;
         if (d->H % dil || d->W % dil || d->Ho != d->H || d->Wo != d->W || (d->Cin & 31) || d->Cout > 64 || d->Cout <= 32) return HV_ERR_UNSUPPORTED;
         dd = *d;
         dd.H /= dil; dd.W /= dil; dd.Ho /= dil; dd.Wo /= dil; dd.pad = 1; dd.dil = 1;
@@ -442,10 +442,14 @@ int hv_conv2d_halo(const hv_conv_desc* d, const void* w_f16, hipStream_t s) {
         k.Wp = Wf; k.img_stride = Hf * Wf * d->x_ld; k.Ho = Hof; k.Wo = Wof; k.ostep = dil;
         if ((long long)d->B * k.img_stride >= (1ll << 29)) return HV_ERR_UNSUPPORTED;
         k.x_bytes = (unsigned)((size_t)d->B * k.img_stride * xs);
-        if (dil <= 4) {
-            const int rc = hv_convlf_launch(k, d->KH, d->KW, s);
-            if (rc != HV_ERR_UNSUPPORTED) return rc;
+        {   // filters-in-LDS form: residue sub-grids of at least a tile, or whole residue classes packed into a tile (conv_lfd_kernel)
+            static const int lf8 = getenv("HV_LF_DIL8") ? atoi(getenv("HV_LF_DIL8")) : 1;      // A/B knob: 0 = round 3's rule (d <= 4 only)
+            if (dil <= 4 || lf8) {
+                const int rc = hv_convlf_launch(k, d->KH, d->KW, s);
+                if (rc != HV_ERR_UNSUPPORTED) return rc;
+            }
         }
+        if (dil > 8) return HV_ERR_UNSUPPORTED;      // (d = 16 elsewhere: the gather kernel, as before)
         return hv_halo2_launch(k, TW, d->KH, d->KW, maxpatch, s);      // (conv_halo_kernel has no pixel step)
     }
     static const bool halo2 = !(getenv("HV_HALO2") && atoi(getenv("HV_HALO2")) == 0);   // A/B knob

@@ -18,7 +18,8 @@
 
 #include "conv_halo.h"
 
-template <int CIN, int CO, int TH>
+// SGE < 16: the tile is (16 / SGE)^2 whole residue sub-grids of a dilated layer, each SGE x SGE pixels (see conv_lfd_kernel)
+template <int CIN, int CO, int TH, int SGE = 16>
 struct LfCfg {
     static constexpr int T = (CIN % 32 == 0) ? 32 : 16;      // channels per plane = per MFMA step (the tiled filter table's fragment width)
     static constexpr int NPL = CIN / T;                      // channel planes of the patch
@@ -26,7 +27,7 @@ struct LfCfg {
     static constexpr int TW = 16, NW = 8, NTHR = NW * 64;
     static constexpr int MT = TH / NW;                       // pixel rows (16-pixel MFMA groups) per wave
     static constexpr int NT = CO / 16;
-    static constexpr int PH = TH + 2, PW = TW + 2;
+    static constexpr int PH = TH + TH / SGE + 1, PW = TW + TW / SGE + 1;      // one ring cell between / around the sub-grids (SGE = 16: the plain 18 x 18 patch)
     static constexpr int PLANE = PH * PW * LDP;              // halfs
     static constexpr int WHALFS = CO * 9 * CIN;              // filter halfs of the workgroup
     static constexpr int LDO = CO + 8;                       // output staging: halfs per pixel row
@@ -39,9 +40,12 @@ struct LfCfg {
     static constexpr int PITEMS = (PH * PW * (CIN / 8) + NTHR - 1) / NTHR;       // 16-byte patch items per thread
 };
 
-template <int CIN, int CO, int TH, int WPS, bool X1 = false>       // X1: the hv_conv_desc.x1 form (its own instantiations: the extra code must not cost the others registers)
-__global__ __launch_bounds__(512, WPS) void conv_lf_kernel(const HaloK p) {
-    typedef LfCfg<CIN, CO, TH> G;
+template <int CIN, int CO, int TH, bool X1, int SGE>
+__device__ __forceinline__ void conv_lf_body(const HaloK& p) {
+    typedef LfCfg<CIN, CO, TH, SGE> G;
+    constexpr bool PK = SGE < 16;                 // packed residue sub-grids (conv_lfd_kernel)
+    constexpr int NSG = 16 / SGE;
+    static_assert(!(PK && X1) && (!PK || TH == 16), "packed sub-grids: plain 16 x 16 tiles");
     constexpr int T = G::T, NPL = G::NPL, LDP = G::LDP, MT = G::MT, NT = G::NT, PW = G::PW, PH = G::PH, TW = G::TW;
     typedef typename HFrag<T>::V V;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -59,7 +63,7 @@ __global__ __launch_bounds__(512, WPS) void conv_lf_kernel(const HaloK p) {
     const HaloCls& C = p.cls[0];
     int t = (int)blockIdx.x;
     int ry = 0, rx = 0;
-    if (p.dil > 1) {
+    if (!PK && p.dil > 1) {
         const int per = C.tiles * p.B, rid = t / per;
         t -= rid * per;
         ry = rid / p.dil; rx = rid - ry * p.dil;
@@ -67,7 +71,8 @@ __global__ __launch_bounds__(512, WPS) void conv_lf_kernel(const HaloK p) {
     const int n_img = t / C.tiles;
     t -= n_img * C.tiles;
     const int tile_y = t / C.tiles_x, tile_x = t - tile_y * C.tiles_x;
-    const int i0 = tile_y * TH, j0 = tile_x * TW;
+    if (PK) { ry = tile_y * NSG; rx = tile_x * NSG; }      // the tile = the NSG x NSG residue classes (ry + gy, rx + gx), whole
+    const int i0 = PK ? 0 : tile_y * TH, j0 = PK ? 0 : tile_x * TW;
     const int n_base = blockIdx.y * CO;
     const int h0 = i0 + p.boff + C.dh_min, w0 = j0 + p.boff + C.dw_min;
 
@@ -92,6 +97,13 @@ __global__ __launch_bounds__(512, WPS) void conv_lf_kernel(const HaloK p) {
         const int hi = h0 + py, wi = w0 + px;
         const bool in = pix < PH * PW;
         plo[i] = in ? pix * LDP + c8 * 8 : -1;
+        if (PK) {
+            // cell (py, px): ring / separator cells (every (SGE + 1)-th) are zeros -- a sub-grid IS its whole residue class, so its neighbours at local
+            // -1 / SGE lie outside the image; the others are pixel (wy - 1, wx - 1) of sub-grid (by, bx)
+            const int by = py / (SGE + 1), wy = py - by * (SGE + 1), bx = px / (SGE + 1), wx = px - bx * (SGE + 1);
+            pvo[i] = (in && wy != 0 && wx != 0)
+                         ? xbase + (unsigned)(((ry + by + (wy - 1) * p.dil) * p.Wp + rx + bx + (wx - 1) * p.dil) * p.x_ld + c8 * 8) * 2u : HV_OOB;
+        } else
         pvo[i] = (in && (unsigned)hi < (unsigned)p.Hl && (unsigned)wi < (unsigned)p.Wl)
                      ? xbase + (unsigned)((((ry + hi * p.dil) >> p.in_shift) * p.Wp + ((rx + wi * p.dil) >> p.in_shift)) * p.x_ld + c8 * 8) * 2u : HV_OOB;
     }
@@ -148,7 +160,12 @@ __global__ __launch_bounds__(512, WPS) void conv_lf_kernel(const HaloK p) {
     for (int n = 0; n < NT; ++n)
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int poff = (wave * MT * PW + (lane & 15)) * LDP + (lane >> 4) * (T / 4);
+    int poffm[MT];      // tile row r, column c -> patch cell (r + r / SGE, c + c / SGE) (+ the tap): SGE = 16 is the plain r * PW + c
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int r = wave * MT + m, c = lane & 15;
+        poffm[m] = ((r + r / SGE) * PW + c + c / SGE) * LDP + (lane >> 4) * (T / 4);
+    }
     const int aoff = lane * (T / 4);
     // per plane: its filters and patch rows -> LDS, one barrier, then a software pipeline over its 9 taps (the fragments of tap q + 1 are requested
     // before the MFMAs of tap q)
@@ -169,7 +186,7 @@ __global__ __launch_bounds__(512, WPS) void conv_lf_kernel(const HaloK p) {
 #pragma unroll
             for (int n = 0; n < NT; ++n) a[buf][n] = *reinterpret_cast<const V*>(wl + ((n * 9 + widx[q]) * NPL + kc) * (16 * T) + aoff);
 #pragma unroll
-            for (int m = 0; m < MT; ++m) b[buf][m] = *reinterpret_cast<const V*>(patch + kc * G::PLANE + poff + m * PW * LDP + toff[q]);
+            for (int m = 0; m < MT; ++m) b[buf][m] = *reinterpret_cast<const V*>(patch + kc * G::PLANE + poffm[m] + toff[q]);
         };
         frags(0, 0);
 #pragma unroll
@@ -203,8 +220,10 @@ __global__ __launch_bounds__(512, WPS) void conv_lf_kernel(const HaloK p) {
             const int it = tid + k * G::NTHR;
             const int q = it / PIECES, pc = it - q * PIECES;
             const int i = i0 + (q >> 4), j = j0 + (q & 15), ch = n_base + pc * 8;
-            const bool ok = i < C.Hc && j < C.Wc && ch < p.Cout;
-            const int ho = C.ph + ry + i * p.ostep, wo = C.pw + rx + j * p.ostep;
+            const bool ok = (PK || (i < C.Hc && j < C.Wc)) && ch < p.Cout;
+            // packed: tile pixel (r, c) = pixel (r % SGE, c % SGE) of sub-grid (r / SGE, c / SGE)
+            const int ho = PK ? C.ph + ry + i / SGE + (i % SGE) * p.ostep : C.ph + ry + i * p.ostep;
+            const int wo = PK ? C.pw + rx + j / SGE + (j % SGE) * p.ostep : C.pw + rx + j * p.ostep;
             const long long opix = (long long)(n_img * p.Ho + ho) * p.Wo + wo;
             ooff[k] = ok ? opix * p.y_ld + p.y_coff + ch : -1;
             mreg[k] = __builtin_amdgcn_raw_buffer_load_b128(msrc, ok ? (unsigned)((opix * p.mul_ld + p.mul_coff + ch) * 2) : HV_OOB, 0, 0);
@@ -376,6 +395,21 @@ __global__ __launch_bounds__(512, WPS) void conv_lf_kernel(const HaloK p) {
         for (int i = 0; i < 6; ++i) d[i] = st[i];
     }
 #endif
+}
+
+template <int CIN, int CO, int TH, int WPS, bool X1 = false>       // X1: the hv_conv_desc.x1 form (its own instantiations: the extra code must not cost the others registers)
+__global__ __launch_bounds__(512, WPS) void conv_lf_kernel(const HaloK p) {
+    conv_lf_body<CIN, CO, TH, X1, 16>(p);
+}
+
+// Dilated layers whose residue sub-grids are SMALLER than a tile (64 x 64 maps: d = 8 -> 8 x 8, d = 16 -> 4 x 4 pixels): the residue scheme above would leave a
+// 16 x 16 tile 25 % / 6 % full, so conv_halo2_kernel (d = 8, 22 us) and the gather kernel (d = 16, 30 us) served them against 10.5 us for the undilated layer.
+// Here a tile is (16 / SGE)^2 WHOLE sub-grids -- the residue classes (ry .. ry + 16 / SGE, rx .. rx + 16 / SGE) -- side by side in the LDS patch with one ring of
+// zeros around each (a sub-grid that is its whole residue class has no neighbours inside the image), so every pixel of the tile is an output, every input pixel is
+// read once (no halo), and the MFMA loop is the plain layer's with another row / column map.  Same arithmetic per output as the residue scheme.
+template <int CIN, int CO, int WPS, int SGE>
+__global__ __launch_bounds__(512, WPS) void conv_lfd_kernel(const HaloK p) {
+    conv_lf_body<CIN, CO, 16, false, SGE>(p);
 }
 
 typedef __attribute__((address_space(3))) void* lf_lds_ptr;
@@ -793,6 +827,35 @@ static int launch_lf(HaloK& k, hipStream_t s) {
     return HV_OK;
 }
 
+template <int CIN, int CO, int WPS, int SGE>
+static int launch_lfd(HaloK& k, hipStream_t s) {
+    typedef LfCfg<CIN, CO, 16, SGE> G;
+    static_assert(G::LDS_BYTES <= 160 * 1024, "filters + patch exceed the LDS");
+    constexpr int NSG = 16 / SGE;
+    HaloK kk = k;
+    HaloCls& C = kk.cls[0];
+    C.tiles_x = kk.dil / NSG;
+    C.tiles = C.tiles_x * C.tiles_x;
+    C.t0 = 0;
+    C.PH = G::PH; C.PW = G::PW;
+    kk.w = kk.wt; kk.w_bytes = kk.wt_bytes;
+    if (hv_probe_only) return HV_OK;
+    auto kern = conv_lfd_kernel<CIN, CO, WPS, SGE>;
+    static bool raised = false;
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return -1000 - (int)e;
+        raised = true;
+    }
+    dim3 grid(C.tiles * kk.B, hv_cdiv(kk.Cout, CO));
+    hv_path_note = 7;
+    HV_WUSE(4);
+    HV_KNAME("conv_lfd_kernel<%d, %d, %d, %d>", CIN, CO, WPS, SGE);
+    hipLaunchKernelGGL(kern, grid, dim3(G::NTHR), G::LDS_BYTES, s, kk);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+
 // 3x3 stride-1 layers (forward, or the data gradient = the same convolution with the transposed filter table) whose input and output are fp16
 // NHWC views with 16-byte aligned channel rows.  Returns HV_ERR_UNSUPPORTED for everything else (the caller goes on to conv_halo2_kernel).
 int hv_convlf_launch(HaloK& k, int KH, int KW, hipStream_t s) {
@@ -809,6 +872,18 @@ int hv_convlf_launch(HaloK& k, int KH, int KW, hipStream_t s) {
     // <48, 32, 16> / <80, 64, 8> instantiations on 16-channel planes: step 8.76 vs 8.78 ms -- no gain over conv_halo2's ragged 16-channel chunks.)
     const int ci = Cin == 16 ? 0 : Cin == 32 ? 1 : Cin == 64 ? 2 : -1, co = Cout <= 16 ? 0 : Cout <= 32 ? 1 : 2;
     if (ci < 0 || !((mask >> (ci * 3 + co)) & 1)) return HV_ERR_UNSUPPORTED;
+    if (k.dil > 1 && (k.Hl < 16 || k.Wl < 16)) {
+        // residue sub-grids smaller than a tile: the packed form, where the sub-grid is the whole residue class (sub-grid edge x dilation = the map) -- the
+        // generators' d = 8 / d = 16 layers on 64 x 64 maps.  Other small sub-grids: d <= 4 as partly filled tiles below (as before), d >= 8 on to
+        // conv_halo2_kernel / the gather kernel
+        static const int packed = getenv("HV_LF_PACKED") ? atoi(getenv("HV_LF_PACKED")) : 1;      // A/B knob
+        const HaloCls& C = k.cls[0];
+        const bool fits = packed && !k.x1 && !k.pool2 && !k.in_shift && k.Hl == k.Wl && k.boff + C.dh_min == -1 && k.boff + C.dw_min == -1 && C.Hc == k.Hl && C.Wc == k.Wl &&
+                          Cin == 64 && Cout == 64;
+        if (fits && k.Hl == 8 && k.dil % 2 == 0) return launch_lfd<64, 64, 2, 8>(k, s);
+        if (fits && k.Hl == 4 && k.dil % 4 == 0) return launch_lfd<64, 64, 2, 4>(k, s);
+        if (k.dil > 4) return HV_ERR_UNSUPPORTED;
+    }
     // (Measured and not kept, round 3: 32 x 16-pixel tiles for the 256 x 256 layers -- half the filter loads and workgroups per pixel: 30.1 / 21.4 / 37.5 /
     // 22.7 us against 28.8 / 23.1 / 34.9 / 23.8 us with 16 x 16 tiles, step 8.20 -> 8.23 ms.)
     if (k.x1) {      // extra input channel: the two shapes that have it (32 + 1 -> 32, 64 + 1 -> 64)

@@ -208,11 +208,13 @@ def test_conv_halo_tiled_fp16_forward_and_dgrad(case):
     assert err <= 6e-3 * max(1.0, want.abs().max().item()), err
 
 
-@pytest.mark.parametrize('dil,H,W', [(2, 32, 32), (4, 32, 48), (8, 64, 64), (2, 20, 12)])
+@pytest.mark.parametrize('dil,H,W', [(2, 32, 32), (4, 32, 48), (8, 64, 64), (2, 20, 12), (16, 64, 64), (16, 128, 128), (8, 128, 128), (8, 64, 32)])
 def test_conv_dilated_3x3_as_residue_subgrids(dil, H, W):
     """Dilated same-size 3x3 layers (the generators' d = 2, 4, 8 blocks): conv_halo2_kernel runs the d*d residue classes as undilated
     convolutions on sub-grids with pixel step d -- forward (bias + ELU) and data gradient (with the act' factor) against torch CPU fp32,
-    plain and fragment-ordered filters bit-identical, and the kernel actually taken (path 3)."""
+    plain and fragment-ordered filters bit-identical, and the kernel actually taken (path 3).  With the fragment-ordered table the filters-in-LDS
+    kernels take the layer (path 7): sub-grids of at least a tile as residue classes, the generators' 8 x 8 (d = 8) and 4 x 4 (d = 16) sub-grids of a
+    64 x 64 map packed whole into one tile (conv_lfd_kernel) -- same bits as conv_halo2_kernel; d = 16 without the table stays in the gather kernel."""
     from hvtest import to_act, from_act, ohwi, ohwi_T, dev, maxerr
     from hvgan import ops, lib
     B, Cin, Cout, k = 2, 64, 64, 3
@@ -225,12 +227,20 @@ def test_conv_dilated_3x3_as_residue_subgrids(dil, H, W):
     wf = ohwi(w)
     ya, yt = (ops.Act.empty(B, H, W, Cout, dev(), dtype=torch.float16) for _ in range(2))
     ops.conv2d(to_act(x.detach(), dtype=torch.float16), wf, ya, k, 1, dil, dil, bias=b.to(dev()), act='elu', precision='fp16', w_h=wf.half())
-    assert lib.get().size('hv_last_kernel_path') == 3
+    halo2 = dil <= 8
+    assert (lib.get().size('hv_last_kernel_path') == 3) == halo2
     ops.conv2d(to_act(x.detach(), dtype=torch.float16), wf, yt, k, 1, dil, dil, bias=b.to(dev()), act='elu', precision='fp16', w_h=wf.half(),
                w_t=ops.tile_weights(wf.half(), Cout, k * k, Cin))
+    packed = H == W and H // dil in (4, 8)          # whole residue classes in one tile
+    lf = packed or min(H, W) // dil >= 16 or dil <= 4
+    assert lib.get().size('hv_last_kernel_path') == (7 if lf else 3)
+    if packed:
+        assert b'conv_lfd_kernel' in lib.get().cdll.hv_last_kernel_name()
     torch.cuda.synchronize()
     assert maxerr(from_act(ya), ref.detach()) <= 4e-3 * max(1.0, ref.abs().max().item())
-    assert torch.equal(ya.t, yt.t)
+    assert maxerr(from_act(yt), ref.detach()) <= 4e-3 * max(1.0, ref.abs().max().item())
+    if halo2:
+        assert torch.equal(ya.t, yt.t)
     gy = torch.randn(y0.shape, generator=g)
     y0.backward(gy)
     m = torch.randn(B, Cin, H, W, generator=g)
@@ -239,10 +249,22 @@ def test_conv_dilated_3x3_as_residue_subgrids(dil, H, W):
     dxa = ops.Act.empty(B, H, W, Cin, dev(), dtype=torch.float16)
     ops.conv2d(to_act(gy, dtype=torch.float16), wb, dxa, k, 1, dil, dil, transposed=True, precision='fp16', w_h=wb.half(),
                mul=(to_act(m, dtype=torch.float16), 'elu'))
-    assert lib.get().size('hv_last_kernel_path') == 3
+    assert (lib.get().size('hv_last_kernel_path') == 3) == halo2
+    dxt = ops.Act.empty(B, H, W, Cin, dev(), dtype=torch.float16)
+    ops.conv2d(to_act(gy, dtype=torch.float16), wb, dxt, k, 1, dil, dil, transposed=True, precision='fp16', w_h=wb.half(),
+               w_t=ops.tile_weights(wb.half(), Cin, k * k, Cout), mul=(to_act(m, dtype=torch.float16), 'elu'))
+    assert lib.get().size('hv_last_kernel_path') == (7 if lf else 3)
     torch.cuda.synchronize()
     want = x.grad * fac
     assert maxerr(from_act(dxa), want) <= 4e-3 * max(1.0, want.abs().max().item())
+    assert maxerr(from_act(dxt), want) <= 4e-3 * max(1.0, want.abs().max().item())
+    if halo2:
+        assert torch.equal(dxa.t, dxt.t)
+    # accumulate form on the packed tiles
+    ops.conv2d(to_act(gy, dtype=torch.float16), wb, dxt, k, 1, dil, dil, transposed=True, precision='fp16', w_h=wb.half(),
+               w_t=ops.tile_weights(wb.half(), Cin, k * k, Cout), mul=(to_act(m, dtype=torch.float16), 'elu'), accumulate=1)
+    torch.cuda.synchronize()
+    assert maxerr(from_act(dxt), 2 * want) <= 8e-3 * max(1.0, want.abs().max().item())
 
 
 @pytest.mark.parametrize('rows,taps,K', [(512, 16, 256), (20, 9, 48), (4, 25, 16), (64, 9, 36), (1, 16, 512)])
