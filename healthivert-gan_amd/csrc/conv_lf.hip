@@ -19,15 +19,20 @@
 #include "conv_halo.h"
 
 // SGE < 16: the tile is (16 / SGE)^2 whole residue sub-grids of a dilated layer, each SGE x SGE pixels (see conv_lfd_kernel)
-template <int CIN, int CO, int TH, int SGE = 16>
+// ST = 2: stride-2 layers (conv_lf2_kernel): the patch is (2 TH + 1) x 33 input pixels, tile pixel (r, c) reads cell (2 r + dy, 2 c + dx)
+template <int CIN, int CO, int TH, int SGE = 16, int ST = 1>
 struct LfCfg {
     static constexpr int T = (CIN % 32 == 0) ? 32 : 16;      // channels per plane = per MFMA step (the tiled filter table's fragment width)
     static constexpr int NPL = CIN / T;                      // channel planes of the patch
-    static constexpr int LDP = T + (T == 32 ? 16 : 8);       // halfs per patch pixel row: 96 B / 48 B
+    // halfs per patch pixel row: 96 B / 48 B; stride 2 with 32-channel planes: 80 B -- the lanes of a fragment read are TWO cells apart, and 160 B steps walk
+    // eight distinct 16-byte bank groups where 192 B steps walk four
+    static constexpr int LDP = (ST == 2 && T == 32) ? 40 : T + (T == 32 ? 16 : 8);
     static constexpr int TW = 16, NW = 8, NTHR = NW * 64;
     static constexpr int MT = TH / NW;                       // pixel rows (16-pixel MFMA groups) per wave
     static constexpr int NT = CO / 16;
-    static constexpr int PH = TH + TH / SGE + 1, PW = TW + TW / SGE + 1;      // one ring cell between / around the sub-grids (SGE = 16: the plain 18 x 18 patch)
+    static constexpr int PH = ST == 2 ? 2 * TH + 1 : TH + TH / SGE + 1;       // one ring cell between / around the sub-grids (SGE = 16: the plain 18 x 18 patch)
+    static constexpr int PW = ST == 2 ? 2 * TW + 1 : TW + TW / SGE + 1;
+    static_assert(ST == 1 || SGE == 16, "stride 2: plain tiles");
     static constexpr int PLANE = PH * PW * LDP;              // halfs
     static constexpr int WHALFS = CO * 9 * CIN;              // filter halfs of the workgroup
     static constexpr int LDO = CO + 8;                       // output staging: halfs per pixel row
@@ -40,9 +45,10 @@ struct LfCfg {
     static constexpr int PITEMS = (PH * PW * (CIN / 8) + NTHR - 1) / NTHR;       // 16-byte patch items per thread
 };
 
-template <int CIN, int CO, int TH, bool X1, int SGE>
+template <int CIN, int CO, int TH, bool X1, int SGE, int ST = 1>
 __device__ __forceinline__ void conv_lf_body(const HaloK& p) {
-    typedef LfCfg<CIN, CO, TH, SGE> G;
+    typedef LfCfg<CIN, CO, TH, SGE, ST> G;
+    static_assert(ST == 1 || !X1, "stride 2: no extra-channel form");
     constexpr bool PK = SGE < 16;                 // packed residue sub-grids (conv_lfd_kernel)
     constexpr int NSG = 16 / SGE;
     static_assert(!(PK && X1) && (!PK || TH == 16), "packed sub-grids: plain 16 x 16 tiles");
@@ -74,7 +80,7 @@ __device__ __forceinline__ void conv_lf_body(const HaloK& p) {
     if (PK) { ry = tile_y * NSG; rx = tile_x * NSG; }      // the tile = the NSG x NSG residue classes (ry + gy, rx + gx), whole
     const int i0 = PK ? 0 : tile_y * TH, j0 = PK ? 0 : tile_x * TW;
     const int n_base = blockIdx.y * CO;
-    const int h0 = i0 + p.boff + C.dh_min, w0 = j0 + p.boff + C.dw_min;
+    const int h0 = i0 * ST + p.boff + C.dh_min, w0 = j0 * ST + p.boff + C.dw_min;
 
     const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.w), 0, p.w_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
@@ -164,7 +170,7 @@ __device__ __forceinline__ void conv_lf_body(const HaloK& p) {
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int r = wave * MT + m, c = lane & 15;
-        poffm[m] = ((r + r / SGE) * PW + c + c / SGE) * LDP + (lane >> 4) * (T / 4);
+        poffm[m] = ST == 2 ? (2 * r * PW + 2 * c) * LDP + (lane >> 4) * (T / 4) : ((r + r / SGE) * PW + c + c / SGE) * LDP + (lane >> 4) * (T / 4);
     }
     const int aoff = lane * (T / 4);
     // per plane: its filters and patch rows -> LDS, one barrier, then a software pipeline over its 9 taps (the fragments of tap q + 1 are requested
@@ -410,6 +416,13 @@ __global__ __launch_bounds__(512, WPS) void conv_lf_kernel(const HaloK p) {
 template <int CIN, int CO, int WPS, int SGE>
 __global__ __launch_bounds__(512, WPS) void conv_lfd_kernel(const HaloK p) {
     conv_lf_body<CIN, CO, 16, false, SGE>(p);
+}
+
+// 3x3 stride-2 layers (the generators' down-sampling convolutions, forward): the same workgroup over a 33 x 33-pixel patch.  They ran in conv_halo_kernel
+// (filters re-fetched per 8 x 16 tile, 1.2 - 2 TB/s of their bytes).
+template <int CIN, int CO, int WPS>
+__global__ __launch_bounds__(512, WPS) void conv_lf2_kernel(const HaloK p) {
+    conv_lf_body<CIN, CO, 16, false, 16, 2>(p);
 }
 
 typedef __attribute__((address_space(3))) void* lf_lds_ptr;
@@ -856,11 +869,40 @@ static int launch_lfd(HaloK& k, hipStream_t s) {
     return HV_OK;
 }
 
+template <int CIN, int CO, int WPS>
+static int launch_lf2(HaloK& k, hipStream_t s) {
+    typedef LfCfg<CIN, CO, 16, 16, 2> G;
+    static_assert(G::LDS_BYTES <= 160 * 1024, "filters + patch exceed the LDS");
+    HaloK kk = k;
+    HaloCls& C = kk.cls[0];
+    C.tiles_x = hv_cdiv(C.Wc, G::TW);
+    C.tiles = C.tiles_x * hv_cdiv(C.Hc, 16);
+    C.t0 = 0;
+    C.PH = G::PH; C.PW = G::PW;
+    kk.w = kk.wt; kk.w_bytes = kk.wt_bytes;
+    if (hv_probe_only) return HV_OK;
+    auto kern = conv_lf2_kernel<CIN, CO, WPS>;
+    static bool raised = false;
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return -1000 - (int)e;
+        raised = true;
+    }
+    dim3 grid(C.tiles * kk.B, hv_cdiv(kk.Cout, CO));
+    hv_path_note = 7;
+    HV_WUSE(4);
+    HV_KNAME("conv_lf2_kernel<%d, %d, %d>", CIN, CO, WPS);
+    hipLaunchKernelGGL(kern, grid, dim3(G::NTHR), G::LDS_BYTES, s, kk);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+
 // 3x3 stride-1 layers (forward, or the data gradient = the same convolution with the transposed filter table) whose input and output are fp16
 // NHWC views with 16-byte aligned channel rows.  Returns HV_ERR_UNSUPPORTED for everything else (the caller goes on to conv_halo2_kernel).
 int hv_convlf_launch(HaloK& k, int KH, int KW, hipStream_t s) {
     static const int on = getenv("HV_CONV_LF") ? atoi(getenv("HV_CONV_LF")) : 1;
-    if (!on || KH != 3 || KW != 3 || k.ncls != 1 || k.bstep != 1 || k.cls[0].ntaps != 9) return HV_ERR_UNSUPPORTED;
+    static const int s2on = getenv("HV_LF_S2") ? atoi(getenv("HV_LF_S2")) : 1;      // A/B knob: stride-2 forward layers (conv_lf2_kernel)
+    if (!on || KH != 3 || KW != 3 || k.ncls != 1 || (k.bstep != 1 && !(k.bstep == 2 && s2on)) || k.cls[0].ntaps != 9) return HV_ERR_UNSUPPORTED;
     if (!k.wt || ((uintptr_t)k.wt & 15) || !k.x_half || !k.y_half || k.accumulate > 1) return HV_ERR_UNSUPPORTED;
     if ((k.x_ld & 7) || (k.x_coff & 7) || ((uintptr_t)k.x & 15) || (k.Cout & 7) || (k.y_ld & 7) || (k.y_coff & 7) || ((uintptr_t)k.y & 15)) return HV_ERR_UNSUPPORTED;
     if (k.mul_src && (!k.mul_half || (k.mul_ld & 7) || (k.mul_coff & 7) || ((uintptr_t)k.mul_src & 15))) return HV_ERR_UNSUPPORTED;
@@ -872,6 +914,16 @@ int hv_convlf_launch(HaloK& k, int KH, int KW, hipStream_t s) {
     // <48, 32, 16> / <80, 64, 8> instantiations on 16-channel planes: step 8.76 vs 8.78 ms -- no gain over conv_halo2's ragged 16-channel chunks.)
     const int ci = Cin == 16 ? 0 : Cin == 32 ? 1 : Cin == 64 ? 2 : -1, co = Cout <= 16 ? 0 : Cout <= 32 ? 1 : 2;
     if (ci < 0 || !((mask >> (ci * 3 + co)) & 1)) return HV_ERR_UNSUPPORTED;
+    if (k.bstep == 2) {      // stride-2 forward (a stride-2 data gradient has four tap classes: never here)
+        if (k.dil != 1 || k.x1 || k.pool2 || k.in_shift || k.mul_src) return HV_ERR_UNSUPPORTED;
+        switch (ci * 3 + co) {
+            case 0: return launch_lf2<16, 16, 4>(k, s);
+            case 1: return launch_lf2<16, 32, 4>(k, s);
+            case 4: return launch_lf2<32, 32, 2>(k, s);
+            case 5: return launch_lf2<32, 64, 2>(k, s);
+            default: return HV_ERR_UNSUPPORTED;
+        }
+    }
     if (k.dil > 1 && (k.Hl < 16 || k.Wl < 16)) {
         // residue sub-grids smaller than a tile: the packed form, where the sub-grid is the whole residue class (sub-grid edge x dilation = the map) -- the
         // generators' d = 8 / d = 16 layers on 64 x 64 maps.  Other small sub-grids: d <= 4 as partly filled tiles below (as before), d >= 8 on to

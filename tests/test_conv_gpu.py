@@ -267,6 +267,30 @@ def test_conv_dilated_3x3_as_residue_subgrids(dil, H, W):
     assert maxerr(from_act(dxt), 2 * want) <= 8e-3 * max(1.0, want.abs().max().item())
 
 
+@pytest.mark.parametrize('B,H,W,Cin,Cout', [(2, 64, 64, 16, 16), (2, 64, 48, 16, 32), (3, 70, 50, 32, 64), (2, 33, 47, 32, 32), (16, 128, 128, 32, 64)])
+def test_conv_3x3_stride2_filters_in_lds(B, H, W, Cin, Cout):
+    """conv_lf2_kernel: the generators' 3x3 stride-2 down-sampling layers (forward) with the filter bank and a 33 x 33-pixel patch in LDS -- against torch CPU
+    fp32 (bias + ELU), bit-identical to conv_halo_kernel (the route without the fragment-ordered table), odd map sizes incl., and the kernel actually taken."""
+    from hvtest import to_act, from_act, ohwi, dev, maxerr
+    from hvgan import ops, lib
+    g = torch.Generator().manual_seed(5 + Cin + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    ref = F.elu(F.conv2d(x, w, b, stride=2, padding=1))
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    wf = ohwi(w)
+    ya, yt = (ops.Act.empty(B, Ho, Wo, Cout, dev(), dtype=torch.float16) for _ in range(2))
+    xa = to_act(x, dtype=torch.float16)
+    ops.conv2d(xa, wf, ya, 3, 2, 1, 1, bias=b.to(dev()), act='elu', precision='fp16', w_h=wf.half())
+    assert lib.get().size('hv_last_kernel_path') == 2
+    ops.conv2d(xa, wf, yt, 3, 2, 1, 1, bias=b.to(dev()), act='elu', precision='fp16', w_h=wf.half(), w_t=ops.tile_weights(wf.half(), Cout, 9, Cin))
+    assert lib.get().size('hv_last_kernel_path') == 7 and b'conv_lf2_kernel' in lib.get().cdll.hv_last_kernel_name()
+    torch.cuda.synchronize()
+    assert maxerr(from_act(yt), ref) <= 4e-3 * max(1.0, ref.abs().max().item())
+    assert torch.equal(ya.t, yt.t)
+
+
 @pytest.mark.parametrize('rows,taps,K', [(512, 16, 256), (20, 9, 48), (4, 25, 16), (64, 9, 36), (1, 16, 512)])
 def test_weight_table_in_mfma_fragment_order(rows, taps, K):
     """hv_weight_tile_f16 / hv_weight_tiled_elems against the index formula documented in include/hvgan.h (rows padded to 16 with zeros;
