@@ -816,7 +816,9 @@ static int launch_lf(HaloK& k, hipStream_t s) {
     // gains nothing (32 -> 32 @128x128 14.1 vs 14.3 us, 32 -> 64 with the registers of one workgroup per CU 22.7 -> 25.2 us): those stay as they are.
     static const int persist = getenv("HV_LF_PERSIST") ? atoi(getenv("HV_LF_PERSIST")) : 1;
     constexpr int per_cu = (int)((160 * 1024) / G::LDS_BYTES) < WPS / 2 ? (int)((160 * 1024) / G::LDS_BYTES) : WPS / 2;
-    if constexpr (G::T == 32 && per_cu <= 1) {
+    // (in the step: 64 -> 64 + 1 @128x128 52.7 -> 44.0 us, 64 -> 32 24.2 -> 19.9, 64 -> 64 data gradient 34.3 -> 26.9; the 32 + 1 -> 32 layer @256x256, one workgroup per CU
+    // by registers only, 64.6 -> 75.3 us: 64 input channels only)
+    if constexpr (CIN == 64 && per_cu <= 1) {
         constexpr int slots = 256;      // MI355X: 256 CUs
         if (persist && grid.y == 1 && total > slots && !(X1 && (kk.mul_src || kk.accumulate))) {      // (single-round grids, measured: 11.4 vs 11.7 us -- stay)      // (the extra channel is a forward form: no act' / accumulate there)
             constexpr int WPSP = 2;     // (the next patch stays in registers across the whole pass)
