@@ -596,6 +596,15 @@ class Pix2PixModel(BaseModel):
         if getattr(self, '_capture_stream', None) is None:
             self._capture_stream = engine.named_stream('capture', self.device)
         torch.cuda.synchronize(self.device)
+        if self.grad_sync.active() and self.grad_sync.capturable():
+            # torch's ProcessGroupNCCL retires finished collectives from its watchdog thread (a poll every 100 ms) by querying their events.  On this stack a
+            # query that lands while ANY stream of the process is capturing can fail with hipErrorCapturedEvent ("operation not permitted on an event last
+            # recorded in a capturing stream" -- torch draws its collective stream from the same pool of 32 streams per device as the step's streams), and
+            # the watchdog then aborts the process: seen once in ~20 runs of the one-rank RCCL test, a few ms after the warm-up steps' collectives (weight
+            # broadcast, the communicator's id exchange, the cut schedule's means).  The device is idle here: give the watchdog time for three polls so
+            # that nothing is left for it to query during the capture.  Once per batch shape.
+            import time
+            time.sleep(0.35)
         graphs, pool = [], None
         one = self.one_graph and not cut      # (the cut data-parallel schedule issues its gradient means between the graphs)
 
