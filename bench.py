@@ -448,10 +448,15 @@ def main():
         'regions_ms_per_step': [round(r / args.steps * 1e3, 3) for r in region_dt],
         # what the collective layer actually saw (an N-GPU record must show N ranks behind RCCL)
         'comm': {'backend': (dist.get_backend() if dist.is_initialized() else None), 'world_size': (dist.get_world_size() if dist.is_initialized() else 1),
-                 'grad_exchange': (('flat all-reduce (ncclAvg) per network, captured inside the step graph: D_k\'s forked from D_k\'s stream, G\'s before its Adam step'
+                 'grad_exchange': (('flat all-reduce (ncclAvg) per network in the order D_1, D_2, D_3, G on ONE exchange branch captured inside the step graph: D_k\'s beside the other discriminators\' passes, G\'s before its Adam step'
                                     if getattr(model, '_inline_exchange', False) else 'flat all-reduce (mean) between the step\'s three graphs on the exchange stream')
                                    if model.grad_sync.active() else 'none (single rank)'),
-                 'dp_schedule': (model.dp_schedule if model.grad_sync.active() else None), 'capture_error': getattr(model, 'dp_capture_error', None)},
+                 'transport': (('RCCL through our own communicator (ddp.RcclComm)' if model.grad_sync.capturable() else 'torch.distributed (%s)' % dist.get_backend())
+                               if model.grad_sync.active() else None),
+                 'dp_schedule': (model.dp_schedule if model.grad_sync.active() else None), 'capture_error': getattr(model, 'dp_capture_error', None),
+                 # both schedules run on this job's first batch before the warm-up: per schedule the slowest rank's ms/step, whether every rank ended with
+                 # the same weights (exact checksum), the error text if it failed; `chosen` is what the timed region ran
+                 'preflight': getattr(model, 'dp_preflight_record', None)},
     }
     if rank == 0:
         out['roofline'] = prof.roofline(args.precision, MFMA_PEAK_TFLOPS[args.precision], name=dom[0] if dom else None)

@@ -5,16 +5,19 @@ models/networks.py:112-116).  Here every rank runs the whole step on its own 16-
 reference's per-batch quirks stay per-rank) and the four networks' gradients are averaged with one flat
 all-reduce each on a dedicated HIP stream:
 
-* D_k's reduction is issued from D_k's own stream the moment D_k's gradients are final and only D_k's optimiser step
-  waits for it, so it overlaps the other discriminators' passes;
-* the generator's reduction sits between its backward and its Adam step;
-* default schedule (`HV_DP_SCHEDULE=graphs`): the step is cut into its three hipGraphs where the exchanges belong and the means are issued between
-  them through torch.distributed on an exchange stream (`reduce`) -- mainstream PyTorch usage only;
-* `HV_DP_SCHEDULE=captured`: the collectives INSIDE the step's one hipGraph.  torch's ProcessGroupNCCL cannot be used for that on this stack (its
-  watchdog thread queries the work's end event, which was recorded in a capturing stream: `hipErrorCapturedEvent`, the process aborts -- seen in the
-  one-rank rehearsal), so the captured schedule talks to RCCL directly: `RcclComm` below opens a communicator of its own (ncclGetUniqueId on rank 0,
-  broadcast through the process group, ncclCommInitRank) and `reduce_inline` is a plain `ncclAllReduce(..., ncclAvg, comm, stream)` on the CALLING
-  stream -- a kernel node of the graph being captured, no other thread involved.
+* every collective of the step goes to ONE communicator on ONE stream (the exchange stream) in the fixed order D_1, D_2, D_3, G -- the same order
+  on every rank by construction (RCCL requires it);
+* `HV_DP_SCHEDULE=captured`: the collectives INSIDE the step's one hipGraph, as one exchange BRANCH of it (`reduce_branch`): the branch waits for
+  D_k's stream where D_k's gradients are final, runs `ncclAllReduce(..., ncclAvg)`, and only D_k's optimiser step waits for it -- the other
+  discriminators' passes run beside it; the generator's reduction sits between its backward and its Adam step on the same branch;
+* `HV_DP_SCHEDULE=graphs`: the step cut into its three hipGraphs where the exchanges belong, the same collectives issued eagerly between them
+  (`reduce`) -- the fallback when a runtime refuses to capture RCCL kernels, and the only schedule for gloo (tests, rehearsals);
+* with an RCCL process group BOTH schedules talk to RCCL directly through `RcclComm` below -- a communicator of our own (ncclGetUniqueId on rank 0,
+  broadcast through the process group, ncclCommInitRank) on torch's own librccl.so.  torch's ProcessGroupNCCL is used for the rendezvous, the weight
+  broadcast and the bench clock only: its watchdog thread polls the end events of its collectives, and a poll that lands while a stream of the
+  process is capturing aborts the process on this stack (`hipErrorCapturedEvent`), so nothing of the step is issued through it;
+* which schedule a multi-GPU job takes is decided by a preflight on the job's own first batch (`Pix2PixModel.dp_preflight`): both are run, their
+  results compared across the ranks, the faster correct one is kept.
 
 `init_from_env()` joins the process group that `python -m torch.distributed.run` describes in the environment, so
 a reference `train.py` needs no edit.  With no process group initialised every call is a no-op.
@@ -85,7 +88,21 @@ class RcclComm:
         self.lib.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, self._UniqueId, ctypes.c_int]
         self._check(self.lib.ncclCommInitRank(ctypes.byref(self.comm), world, uid, rank), 'ncclCommInitRank')
         self.lib.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        self.lib.ncclCommDestroy.argtypes = [ctypes.c_void_p]
         self.world = world
+        import atexit
+        atexit.register(self.close)
+
+    def close(self):
+        """ncclCommDestroy (idempotent; registered with atexit so that teardown does not leave a live communicator behind).  The device is drained
+        first: a collective still in flight on another stream would otherwise be destroyed under its kernel."""
+        comm, self.comm = self.comm, None
+        if comm is not None and comm.value:
+            try:
+                torch.cuda.synchronize()
+                self.lib.ncclCommDestroy(comm)
+            except Exception:      # noqa: BLE001 -- interpreter teardown: the runtime may already be gone
+                pass
 
     def _check(self, rc, what):
         if rc != 0:
@@ -93,6 +110,8 @@ class RcclComm:
 
     def all_reduce_mean(self, flat):
         """flat (fp32, device) <- mean over the ranks, in place, on the current stream."""
+        if self.comm is None:
+            raise RuntimeError('RcclComm: the communicator has been closed')
         self._check(self.lib.ncclAllReduce(flat.data_ptr(), flat.data_ptr(), flat.numel(), self.NCCL_FLOAT, self.NCCL_AVG, self.comm,
                                            torch.cuda.current_stream(flat.device).cuda_stream), 'ncclAllReduce')
 
@@ -110,19 +129,21 @@ class GradSync:
 
     def capturable(self):
         """True when the transport's collectives are stream-ordered device work that a hipGraph capture records (RCCL); gloo's run on the host."""
-        return self.active() and dist.get_backend(self.group) == 'nccl'
+        return self.active() and 'nccl' in str(dist.get_backend(self.group))
 
-    def reduce_inline(self, flat):
-        """Average `flat` across the ranks IN the calling stream's order: one ncclAllReduce (ncclAvg: the mean is taken inside it) on the current
-        stream through a communicator of our own (RcclComm; opened at the first call, i.e. during the eager warm-up steps).  Under stream capture it is
-        a node of the graph being captured; other streams keep running beside it."""
-        if not flat.is_cuda or flat.dtype != torch.float32:
-            raise RuntimeError('reduce_inline: fp32 device tensors only')
-        if self.rccl is None:
+    def open(self):
+        """Open the RCCL communicator (RCCL process groups only; a collective over the process group: every rank calls it at the same point -- the
+        first step's exchange -- and never under stream capture)."""
+        if self.rccl is None and self.capturable():
             if torch.cuda.is_current_stream_capturing():
-                raise RuntimeError('reduce_inline: the RCCL communicator must be opened before the capture (run an eager step first)')
+                raise RuntimeError('GradSync: the RCCL communicator must be opened before the capture (run an eager step first)')
             self.rccl = RcclComm(self.group)
-        self.rccl.all_reduce_mean(flat)
+        return self.rccl
+
+    def close(self):
+        if self.rccl is not None:
+            self.rccl.close()
+            self.rccl = None
 
     def exchange_stream(self, device):
         if self.stream is None:
@@ -132,8 +153,28 @@ class GradSync:
             self.stream = engine.named_stream('exchange', device, priority=int(os.environ.get('HV_DDP_COMM_PRIO', '0')))
         return self.stream
 
+    def reduce_branch(self, flat, producer=None):
+        """Captured schedule: average `flat` across the ranks on the EXCHANGE stream -- the one stream every collective of the step is issued on, in
+        the order of the calls (D_1, D_2, D_3, G: the same on every rank by construction) -- ordered after everything queued on `producer` (default:
+        the current stream), which then waits for the result.  One ncclAllReduce (ncclAvg) through our own communicator; under stream capture it is a
+        node of the exchange branch of the graph being captured, and the other streams keep running beside it."""
+        if not flat.is_cuda or flat.dtype != torch.float32:
+            raise RuntimeError('reduce_branch: fp32 device tensors only')
+        comm = self.open()
+        if comm is None:
+            raise RuntimeError('reduce_branch: needs an RCCL process group')
+        producer = producer if producer is not None else torch.cuda.current_stream(flat.device)
+        st = self.exchange_stream(flat.device)
+        if st.cuda_stream == producer.cuda_stream:
+            comm.all_reduce_mean(flat)
+            return
+        st.wait_stream(producer)
+        with torch.cuda.stream(st):
+            comm.all_reduce_mean(flat)
+        producer.wait_stream(st)
+
     def reduce(self, flat, after=None):
-        """Average `flat` (a network's flat gradient buffer) across ranks on the exchange stream, ordered after everything queued
+        """Cut schedule: average `flat` (a network's flat gradient buffer) across ranks on the exchange stream, ordered after everything queued
         on stream `after` (default: the current stream).  Returns an event that is complete when `flat` holds the mean (None
         for CPU tensors, which are reduced synchronously); the consumer's stream waits for it -- nothing blocks the host."""
         if not self.active():
@@ -147,15 +188,16 @@ class GradSync:
         st = self.exchange_stream(flat.device)
         st.wait_stream(after if after is not None else torch.cuda.current_stream(flat.device))
         with torch.cuda.stream(st):
-            if dist.get_backend(self.group) == 'nccl':
-                # RCCL averages inside the collective (ncclAvg): no pre-scale pass over the buffer
-                work = dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+            if self.capturable():
+                # RCCL averages inside the collective (ncclAvg): no pre-scale pass over the buffer; through our own communicator, so that no
+                # ProcessGroupNCCL work item (and no watchdog poll of its events) exists around the step's graph captures
+                self.open().all_reduce_mean(flat)
             else:
                 # gloo has no AVG: pre-scale (1/ws) with the library's own pointwise kernel, then SUM -- the mean of the ranks' gradients
                 _lib.get().call('hv_affine', _lib.ptr(flat), _lib.ptr(flat), ctypes.c_longlong(flat.numel()), ctypes.c_float(1.0 / ws),
                                 ctypes.c_float(0.0), _lib.stream())
                 work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            work.wait()        # RCCL: the exchange stream waits for the collective's stream (no host block); gloo: host wait
+                work.wait()        # gloo: host wait
             ev = torch.cuda.Event()
             ev.record(st)
         return ev

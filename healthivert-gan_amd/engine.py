@@ -73,7 +73,11 @@ class ParamSet:
         self.device = None
         self.t_prep = {True: ops.LayerTable('hv_wprep_layer'), False: ops.LayerTable('hv_wprep_layer')}
         self.t_bwd = {True: ops.LayerTable('hv_wprep_bwd_layer'), False: ops.LayerTable('hv_wprep_bwd_layer')}
-        self.t_lean = {True: ops.LayerTable('hv_wprep_layer'), False: ops.LayerTable('hv_wprep_layer')}
+        # lean tables by (parameter storage, power iteration, the layers' table-use bits): a captured step graph keeps the DEVICE address of the table it was
+        # captured with, and the use bits can still grow afterwards (another batch shape's first eager step, an eval forward at another size), so a table
+        # is never rebuilt in place or freed -- a new bit pattern gets a new table and the old graphs keep theirs (a superset of bits stays correct for them:
+        # the layout pass then merely writes a table they do not read)
+        self.t_lean = {}
         # deferred slab folds of the current backward (ops.conv2d_wgrad defer=) and the device tables of fold lists seen so far (a list is a function of the
         # shapes: one table per batch shape / pass, built during the eager steps and found again by its key under graph capture)
         self.pending_folds, self.t_folds = [], {}
@@ -188,9 +192,10 @@ class ParamSet:
         if LEAN and LEAN_TABLES and ops.precision_id(None) == ops.F16:
             # inside the train step, after the step has been seen once for this batch shape: the layout pass skips the tables no kernel of the layer reads
             # (fp16 mode: the big layers read the fragment-ordered tables only -- 4 of 20 bytes per weight)
-            key = (self._key, tuple((c.use_fwd, c.use_bwd) for c in self.convs))
-            table = self.t_lean[pi]
-            if table.key != key:
+            key = (self._key, pi, tuple((c.use_fwd, c.use_bwd) for c in self.convs))
+            table = self.t_lean.get(key)
+            if table is None:
+                table = self.t_lean[key] = ops.LayerTable('hv_wprep_layer')
                 table.update(self._prep_rows(pi, True), key, device)
         ops.weight_prep(table, max(c.sizes()[0] + c.sizes()[1] for c in self.convs), any_sn=any(c.sn for c in self.convs),
                         any_legacy=any(c.transposed_src for c in self.convs))
@@ -318,17 +323,10 @@ class GradBook:
         self.written = set()
         self.side = None          # side HIP stream for weight gradients (they overlap the data-gradient chain)
         self._side_of = None      # ... of this parent stream
-        # Weight gradients on a side stream beside the data-gradient chain: a gain in rounds 1-2 (20.6 -> 19.1 ms era); re-measured at the end of round 3
-        # (six same-box pairs, tools/ab_step.sh): in line is faster now, 8.25 -> 8.15 ms on average -- every kernel fills the chip, and the per-layer
-        # fork / join edges cost more than the overlap returns.  HV_OVERLAP_WGRAD=1 brings the side stream back.
-        self.overlap = os.environ.get('HV_OVERLAP_WGRAD', '0') != '0'
         # block deferral (round 4): while `defer_wgrad` is set, conv_backward queues its weight gradient here instead of launching it; the owner of the
         # plan launches the whole block later on ONE side stream (one fork, one join) beside an independent part of the backward
         self.defer_wgrad = False
         self.deferred = []
-
-    def can_fork(self):
-        return self.overlap and not SERIAL and torch.cuda.current_stream().cuda_stream not in NO_FORK_STREAMS
 
     def fork(self):
         """Side stream, ordered after everything queued so far on the current stream."""
@@ -393,6 +391,9 @@ def conv_backward(node, book, prec, dbias_accumulate=False, wgrad_accumulate=Fal
     bn: (Act raw input of the batch normalisation that produced node.x, its stats, groups, partials) -- the normalisation's backward sums leave
     this data gradient's epilogue (ops.conv2d bn=; the caller asked conv2d_bstats_parts first)."""
     p = node.p
+    # the batch-norm sums ride in the plain data gradient only: a caller that set them up for a transposed / pooled / shifted node would skip its reduction
+    # pass and read partials nobody wrote
+    assert bn is None or (node.need_dx and not node.transposed and node.pool_to is None and not node.shift), 'conv_backward: bn= needs the plain data-gradient branch'
     gy = book.twin(node.y)
     want_dbias = p.bias is not None and node.use_bias and wgrad and not dbias_done      # dbias_done: the caller's seed pass already summed it
     # the bias gradient (column sums of the activation gradient) rides in the weight-gradient kernels, which stream g anyway;
@@ -410,9 +411,9 @@ def conv_backward(node, book, prec, dbias_accumulate=False, wgrad_accumulate=Fal
             book.deferred.append(lambda node=node, p=p, xin=xin, gfull=gfull, acc=wgrad_accumulate, db=p.bias.grad if fuse_dbias else None, dba=dbias_accumulate:
                                  _wgrad(node, p, xin, gfull, acc, prec, dbias=db, dbias_accumulate=dba))
         else:
-            ctx = torch.cuda.stream(book.fork()) if book.can_fork() else contextlib.nullcontext()
-            with ctx:
-                _wgrad(node, p, xin, gfull, wgrad_accumulate, prec, dbias=p.bias.grad if fuse_dbias else None, dbias_accumulate=dbias_accumulate)
+            # (in line: per-layer forks to a side stream lost their A/B twice -- 8.25 -> 8.15 ms at the end of round 3, 7.36 -> 7.6-7.8 ms in round 4 -- and are gone;
+            # the refinement generator's weight gradients go to a side stream as ONE block, see defer_wgrad)
+            _wgrad(node, p, xin, gfull, wgrad_accumulate, prec, dbias=p.bias.grad if fuse_dbias else None, dbias_accumulate=dbias_accumulate)
     if node.need_dx and node.transposed:
         gx = book.twin(node.x)
         gx = Act(gx.t, p.cin_fwd, gx.coff)

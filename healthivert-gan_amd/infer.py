@@ -277,7 +277,9 @@ class VolumePipeline:
     def run(self, volumes, copy=True):
         """volumes: iterable of (ct_data, label_data, cam_data, vert_id) -- float64 [H, W, Z] arrays, ct in 0..255, cam already scaled by 255
         (reference :181).  Yields (output_ct, output_seg) [H, W, Z] float64 per volume, in order.  copy=False hands out views of the pinned download
-        buffers instead of fresh arrays: valid until the volume after next has been yielded."""
+        buffers instead of fresh arrays: a view is valid only until the generator is advanced again -- the NEXT `next()` call queues the download of the
+        volume after next into the same pinned slot (two slots), before the following result is yielded.  Consume (or copy) each result before asking
+        for the next one."""
         it = iter(volumes)
         nxt = next(it, None)
         if nxt is None:
@@ -288,8 +290,6 @@ class VolumePipeline:
             sl = fut.result()
             nxt = next(it, None)
             fut = self.stager.submit(self._stage_in, (i + 1) & 1, *nxt) if nxt is not None else None
-            if prev is not None and not copy:
-                pass      # (views of prev's pinned buffer were handed out one iteration ago; prev's slot is re-used by the volume after this one)
             self._compute(sl)
             if prev is not None:
                 yield self._finish(prev, copy)

@@ -493,14 +493,13 @@ class Generator(nn.Module):
         # the concat inputs of the split layers (forward: never built) for their weight gradients: up-sampled now, beside the head kernels
         for node, low, cat, k2 in ((P.c_nodes[15], a['c14'], a['cat19'], 2 * c), (P.c_nodes[12], a['c12'], a['cat20'], 4 * c)):
             if node.split_forward(prec):
-                with (torch.cuda.stream(book.fork()) if book.can_fork() else contextlib.nullcontext()):
-                    ops.copy_channels(low, cat.slice(0, k2), mode=1)
+                ops.copy_channels(low, cat.slice(0, k2), mode=1)
         # the refinement generator's weight gradients as ONE block on a side stream beside the coarse generator's whole backward (round 4, HV_G_WGRAD_BLOCK):
         # they only feed the optimiser, and the coarse backward -- a chain of small launches that leave most of a CU's registers and LDS free -- does not
-        # depend on them.  One fork and one join (the per-layer forks of HV_OVERLAP_WGRAD cost more than they returned).  Measured against it, three
+        # depend on them.  One fork and one join (per-layer forks cost more than they returned and are gone).  Measured against it, three
         # same-box pairs each: a first block launched before the two branches (three streams busy there) +0.13 ms; the coarse generator's own weight
         # gradients in two more blocks +0.14 ms -- both removed.
-        wg_block = G_WGRAD_BLOCK and not E.SERIAL and not book.can_fork() and torch.cuda.current_stream().cuda_stream not in E.NO_FORK_STREAMS
+        wg_block = G_WGRAD_BLOCK and not E.SERIAL and torch.cuda.current_stream().cuda_stream not in E.NO_FORK_STREAMS
         book.defer_wgrad = bool(wg_block)
         wg_side = E.named_stream('generator-wgrad-block', d_x_stage2.device) if wg_block else None
 

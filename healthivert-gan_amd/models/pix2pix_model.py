@@ -24,7 +24,6 @@ from .edge_operator import Sobel
 from .inpaint_networks import Generator
 
 
-_THROUGH_AB = __import__('os').environ.get('HV_THROUGH_AB', '1') != '0'     # A/B knob: see Pix2PixModel._capture
 
 
 def _os_environ_graph():
@@ -112,20 +111,26 @@ class Pix2PixModel(BaseModel):
         # re-measured at the end of round 3 with the pipelined 4x4 kernels (one round of one workgroup per CU at bs 16): 8.18 -> 8.09 ms in three same-box
         # pairs, although it gives up the real-image passes' overlap with the generator forward.  Both the single-process and the data-parallel step take it.
         self.batch_d = _os.environ.get('HV_BATCH_D', '1') != '0'
-        # single process: the three phases captured as ONE graph (7.81 -> 7.70 ms over four same-box pairs: two graph-launch boundaries less); HV_ONE_GRAPH=0 keeps
-        # the three graphs.
-        self.one_graph = _os.environ.get('HV_ONE_GRAPH', '1') != '0'
-        # data-parallel step schedule (one process per GPU):
-        #   'graphs' (default): the step cut into its three graphs where the exchanges belong, the means issued eagerly between them through
-        #       torch.distributed on the exchange stream (the main stream waits for each): mainstream PyTorch usage only, works with every backend.
-        #   'captured' (RCCL only): the single-process step AS IT IS, with the gradient means issued INSIDE it -- D_k's all-reduce on D_k's own stream the moment
-        #       its gradients are final (beside the other discriminators' passes; only D_k's Adam step waits for it), the generator's between its backward
-        #       and its Adam step -- as direct ncclAllReduce calls (ddp.RcclComm) that are captured into the step's ONE hipGraph like any kernel: no graph
-        #       cut, no host in the loop.  Opt-in: it could be exercised in a one-rank RCCL group only (one GPU per box), and torch's own
-        #       ProcessGroupNCCL cannot serve it on this stack (its watchdog aborts on events recorded in a capturing stream).
-        self.dp_schedule = _os.environ.get('HV_DP_SCHEDULE', 'graphs')
-        if self.dp_schedule not in ('captured', 'graphs'):
-            raise ValueError("HV_DP_SCHEDULE must be 'captured' or 'graphs'")
+        # the three phases are captured as ONE graph (7.81 -> 7.70 ms over four same-box pairs: two graph-launch boundaries less) -- except under the cut
+        # data-parallel schedule, which issues its collectives between the graphs
+        # data-parallel step schedule (one process per GPU); every collective of the step goes to one communicator on one stream in the order D_1, D_2, D_3, G:
+        #   'captured' (RCCL only): the single-process step AS IT IS, with the gradient means INSIDE its one hipGraph as an exchange branch -- the branch waits for
+        #       D_k's stream where D_k's gradients are final, averages them (ncclAllReduce, ncclAvg, ddp.RcclComm) beside the other discriminators' passes, and
+        #       only D_k's Adam step waits for it; the generator's mean sits between its backward and its Adam step on the same branch: no graph cut, no
+        #       host in the loop.
+        #   'graphs': the step cut into its three graphs where the exchanges belong, the same collectives issued eagerly between them on the exchange stream
+        #       (the main stream waits for each).  The fallback for runtimes that refuse to capture RCCL kernels, and the only schedule for gloo.
+        #   'auto' (default): gloo -> 'graphs'; RCCL -> dp_preflight() runs BOTH on the job's first batch, checks that every rank ends with the same
+        #       weights, keeps the faster correct one and puts the weights back (the preflight steps are not training steps).
+        self.dp_schedule = _os.environ.get('HV_DP_SCHEDULE', 'auto')
+        if self.dp_schedule == 'phases':      # (the twelve-phase schedule of rounds 1-3 is gone; old launch scripts keep working)
+            import warnings
+            warnings.warn("HV_DP_SCHEDULE=phases is deprecated: taking 'graphs'", DeprecationWarning)
+            self.dp_schedule = 'graphs'
+        if self.dp_schedule not in ('auto', 'captured', 'graphs'):
+            raise ValueError("HV_DP_SCHEDULE must be 'auto', 'captured' or 'graphs'")
+        self.dp_preflight_record = None
+        self._in_preflight = False
         self.real_first = _os.environ.get('HV_REAL_FIRST', '1') != '0'   # D real passes overlap the generator forward
         self._through_ab = False
 
@@ -399,6 +404,10 @@ class Pix2PixModel(BaseModel):
             self._d_streams = [engine.named_stream('discriminator-%d' % k, self.device) for k in (1, 2, 3)]
             engine.NO_FORK_STREAMS.update(st.cuda_stream for st in self._d_streams)
         self._dxs = {}
+        if self._inline_exchange:
+            # the exchange branch leaves the MAIN stream here, before the discriminator streams do (a first-level fork of the capture; the edges it
+            # exchanges with the discriminator streams later are joins between branches that already exist)
+            self.grad_sync.exchange_stream(self.device).wait_stream(main)
         split = self.real_first and not self.batch_d
         def on(k):
             side = self._d_streams[k - 1] if (self.concurrent_d and not engine.SERIAL) else main
@@ -424,8 +433,8 @@ class Pix2PixModel(BaseModel):
                     self.set_requires_grad(getattr(self, 'netD_%d' % k), True)
                     getattr(self, 'optimizer_D_%d' % k).zero_grad()
                     bw()
-                if self._inline_exchange:       # D_k's mean over the ranks, forked from D_k's stream: beside the other discriminators' passes
-                    self.grad_sync.reduce_inline(getattr(self, 'netD_%d' % k).paramset().flat_grad)
+                if self._inline_exchange:       # D_k's mean over the ranks on the exchange branch: beside the other discriminators' passes
+                    self.grad_sync.reduce_branch(getattr(self, 'netD_%d' % k).paramset().flat_grad)
         if not self._through_ab:
             self._join_d(main)
 
@@ -445,7 +454,7 @@ class Pix2PixModel(BaseModel):
         self.optimizer_G.zero_grad()
         self.backward_G(d_done=True)
         if self._inline_exchange:
-            self.grad_sync.reduce_inline(self.netG.paramset().flat_grad)
+            self.grad_sync.reduce_branch(self.netG.paramset().flat_grad)
 
     def _phase_c(self):
         self._opt_step(self.optimizer_G, self.netG)
@@ -511,8 +520,143 @@ class Pix2PixModel(BaseModel):
         timer keeps the eager path."""
         # after the first eager step for this batch shape every convolution of the four networks has been dispatched once: from then on the weight
         # layout passes write only the tables those kernels read (engine.lean_tables)
+        if self.isTrain and self.dp_schedule == 'auto':
+            self._resolve_dp_schedule()
         with engine.lean_tables(self._eager_steps >= 1):
             return self._optimize_parameters()
+
+    # ---------------------------------------------------------------- data-parallel schedule: preflight
+    def _resolve_dp_schedule(self):
+        """'auto' -> a schedule, once, at the first step: single process or gloo -> 'graphs' (gloo cannot be captured); RCCL -> dp_preflight()."""
+        if not self.grad_sync.active() or not self.grad_sync.capturable():
+            self.dp_schedule = 'graphs'
+            return
+        import os
+        if os.environ.get('HV_DP_PREFLIGHT', '1') == '0':
+            self.dp_schedule = 'captured'
+            return
+        self.dp_preflight()
+
+    def _dp_state(self):
+        """Every tensor a train step changes besides the activations: the four networks' parameters and buffers (BatchNorm running statistics,
+        spectral-norm vectors), the optimisers' moments / step counts / overflow counters, the loss slots."""
+        ts = []
+        for n in ('G', 'D_1', 'D_2', 'D_3'):
+            net = getattr(self, 'net' + n)
+            ts += [p.data for p in net.parameters()] + list(net.buffers())
+        for o in self.optimizers:
+            o._ensure_state()
+            ts += [o._m, o._v, o._step]
+        ts.append(self._loss_buf)
+        return ts
+
+    def _dp_weight_checksum(self):
+        """Order-independent, exact checksum of all four networks' weights: the int64 sum of their fp32 bit patterns."""
+        tot = torch.zeros((), dtype=torch.int64, device=self.device)
+        for n in ('G', 'D_1', 'D_2', 'D_3'):
+            for p in getattr(self, 'net' + n).parameters():
+                tot += p.data.view(torch.int32).to(torch.int64).sum()
+        return tot
+
+    def dp_preflight(self, timed_steps=5):
+        """Pick the data-parallel schedule on THIS job, on the batch set_input() just delivered, before the first training step.
+
+        Both schedules ('captured': the exchange branch inside the step's one hipGraph; 'graphs': the step cut at the exchanges) are run from the
+        same weights: GRAPH_WARMUP eager steps, the capture, two replays, then `timed_steps` replays between barriers.  After each the ranks compare
+        (a) that the schedule ran on every rank, (b) an exact checksum of all weights (MIN == MAX over the ranks: the collectives delivered the same
+        mean to every rank, in the same order), (c) the slowest rank's time.  The faster schedule that passed is kept -- with its captured graphs --
+        and every tensor the steps touched (weights, running statistics, Adam state) is put back: preflight steps are not training steps.
+        A schedule that raises, diverges across the ranks or is refused by the runtime is recorded and dropped; if none is left the job stops with
+        the recorded text.  A rank that never comes back from a collective cannot be recovered in-process: a timer (HV_DP_PREFLIGHT_TIMEOUT_S,
+        default 300 s) then ends THIS process with the text on stderr and exit code 3 instead of hanging the launcher (never a re-exec: the
+        process has touched the GPU; a retry is a fresh job)."""
+        import os
+        import sys
+        import threading
+        import time
+        import torch.distributed as dist
+        world = dist.get_world_size()
+        rec = {'world_size': world, 'timed_steps': timed_steps, 'schedules': {}, 'chosen': None}
+        self.dp_preflight_record = rec
+        limit = float(os.environ.get('HV_DP_PREFLIGHT_TIMEOUT_S', '300'))
+        where = {'at': 'start'}
+
+        def expired():
+            sys.stderr.write('healthivert-gan_amd: data-parallel preflight did not finish within %.0f s (rank %d, in %s): a rank is stuck in a collective; '
+                             'giving up (exit 3).  Record so far: %r\n' % (limit, dist.get_rank(), where['at'], rec))
+            sys.stderr.flush()
+            os._exit(3)
+        timer = threading.Timer(limit, expired)
+        timer.daemon = True
+        timer.start()
+        self._home_d_grads()
+        for net in (self.netG, self.netD_1, self.netD_2, self.netD_3):      # (gradient storage and tables in place before the snapshot)
+            net.paramset()._ensure(self.device)
+        state = self._dp_state()
+        snap = [t.clone() for t in state]
+        kept = {}
+        self._in_preflight = True
+        try:
+            for sched in ('captured', 'graphs'):
+                where['at'] = sched
+                r = {'ok': False, 'error': None, 'ms_per_step': None, 'weights_identical_across_ranks': None}
+                rec['schedules'][sched] = r
+                self.dp_schedule, self._graphs, self._eager_steps = sched, None, 0
+                self.dp_capture_error = None
+                ok, dt = 1.0, float('inf')
+                try:
+                    with engine.lean_tables(False):
+                        self._optimize_parameters()
+                    for _ in range(self.GRAPH_WARMUP + 2):
+                        with engine.lean_tables(True):
+                            self._optimize_parameters()
+                    if self.use_graph and self._graphs is None:
+                        raise RuntimeError('the step was not captured')
+                    torch.cuda.synchronize(self.device)
+                    dist.barrier()
+                    torch.cuda.synchronize(self.device)
+                    t0 = time.perf_counter()
+                    for _ in range(timed_steps):
+                        with engine.lean_tables(True):
+                            self._optimize_parameters()
+                    torch.cuda.synchronize(self.device)
+                    dt = (time.perf_counter() - t0) / timed_steps
+                except Exception as e:      # noqa: BLE001 -- recorded; the other schedule may still serve
+                    ok, r['error'] = 0.0, '%s: %s' % (type(e).__name__, (str(e).splitlines() or ['?'])[0])
+                    torch.cuda.synchronize(self.device)
+                # ---- what the other ranks saw (these small collectives run in every case, so that a failure on one rank cannot strand the others)
+                agg = torch.tensor([ok, -dt if ok else 0.0], dtype=torch.float64, device=self.device)
+                dist.all_reduce(agg, op=dist.ReduceOp.MIN)
+                ck = self._dp_weight_checksum()
+                ck2 = torch.stack([ck, -ck])
+                dist.all_reduce(ck2, op=dist.ReduceOp.MIN)
+                torch.cuda.synchronize(self.device)
+                all_ok = float(agg[0].item()) == 1.0
+                same = int(ck2[0].item()) == -int(ck2[1].item())
+                r['weights_identical_across_ranks'] = same
+                if all_ok:
+                    r['ms_per_step'] = round(-float(agg[1].item()) * 1e3, 3)
+                elif r['error'] is None:
+                    r['error'] = 'failed on another rank'
+                r['ok'] = bool(all_ok and same)
+                if r['ok']:
+                    kept[sched] = (self._graphs, self._eager_steps)
+                for t, c in zip(state, snap):      # the same starting point for the next schedule, and for training
+                    t.copy_(c)
+                torch.cuda.synchronize(self.device)
+        finally:
+            self._in_preflight = False
+            timer.cancel()
+        good = [k for k in ('captured', 'graphs') if rec['schedules'][k]['ok']]
+        if not good:
+            raise RuntimeError('data-parallel preflight: no schedule ran correctly on %d rank(s): %r' % (world, rec['schedules']))
+        best = min(good, key=lambda k: rec['schedules'][k]['ms_per_step'])
+        rec['chosen'] = best
+        self.dp_schedule = best
+        self._graphs, self._eager_steps = kept[best]
+        self.dp_capture_error = rec['schedules']['captured']['error'] if best != 'captured' else None
+        if dist.get_rank() == 0:
+            print('data-parallel preflight (%d rank(s)): %s -> %s' % (world, {k: (v['ms_per_step'], v['error']) for k, v in rec['schedules'].items()}, best), flush=True)
 
     def _optimize_parameters(self):
         for o in self.optimizers:
@@ -522,12 +666,14 @@ class Pix2PixModel(BaseModel):
         inline = dp and self.dp_schedule == 'captured' and self.grad_sync.capturable()
         self._inline_exchange = inline
         cut = dp and not inline            # the means sit BETWEEN the step's graphs (exchange stream, issued eagerly)
-        if cut and self._eager_steps == 0 and self._graphs is None:
-            self._home_d_grads()
+        if dp and self._eager_steps == 0 and self._graphs is None:
+            self._home_d_grads()      # (both schedules: a preflight runs them over the same gradient storage, and captured graphs keep its addresses)
         if graphable and self._graphs is None and self._eager_steps >= self.GRAPH_WARMUP:
             try:
                 self._capture(cut)
             except RuntimeError as e:
+                if inline and self._in_preflight:
+                    raise
                 if inline:
                     # a runtime that refuses to capture the collectives: keep the step, cut it at the exchanges instead (they are then issued eagerly)
                     import warnings
@@ -603,16 +749,17 @@ class Pix2PixModel(BaseModel):
             # the watchdog then aborts the process: seen once in ~20 runs of the one-rank RCCL test, a few ms after the warm-up steps' collectives (weight
             # broadcast, the communicator's id exchange, the cut schedule's means).  The device is idle here: give the watchdog time for three polls so
             # that nothing is left for it to query during the capture.  Once per batch shape.
+            import os
             import time
-            time.sleep(0.35)
+            time.sleep(float(os.environ.get('HV_DP_CAPTURE_SETTLE_MS', '350')) * 1e-3)
         graphs, pool = [], None
-        one = self.one_graph and not cut      # (the cut data-parallel schedule issues its gradient means between the graphs)
+        one = not cut      # (the cut data-parallel schedule issues its gradient means between the graphs)
 
         def whole():
             # one graph: D_k goes from its backward straight on to its Adam step and its pass for the generator on its own stream -- no join of the three
             # discriminator streams between the phases (that join only exists for the cut schedule's exchange): a discriminator that is done early
             # (D_3 reads the 128 x 128 crop) does not wait for the others
-            self._through_ab = self.concurrent_d and not engine.SERIAL and _THROUGH_AB
+            self._through_ab = self.concurrent_d and not engine.SERIAL
             try:
                 self._phase_a(); self._phase_b(); self._phase_c()
             finally:

@@ -41,6 +41,18 @@ class FusedAdam(torch.optim.Optimizer):
             self._max = max(p.numel() for p in ps)
         return ps
 
+    def _ensure_state(self):
+        """Moments, step count and learning rate on the device before the first step (Pix2PixModel.dp_preflight snapshots them)."""
+        ps = [p for g in self.param_groups for p in g['params']]
+        dev = ps[0].device
+        if self._m is None or self._m.device != dev:
+            n = sum(p.numel() for p in ps)
+            self._m = torch.zeros(n, dtype=torch.float32, device=dev)
+            self._v = torch.zeros(n, dtype=torch.float32, device=dev)
+            if self._lr is None or self._lr.device != dev:
+                self._lr = None
+        self.sync_lr()
+
     def sync_lr(self):
         """Copy the scheduler's learning rate to the device scalar the kernel reads (outside any graph capture)."""
         lr = float(self.param_groups[0]['lr'])

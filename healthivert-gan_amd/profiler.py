@@ -113,7 +113,7 @@ class KernelTimer:
             avg_s = agg[k][0] / agg[k][1] * 1e-3
             tf, gbs = agg[k][2] / avg_s / 1e12, self.bytes.get(k, 0) / avg_s / 1e9
             hbm = bool(self.bytes.get(k)) and agg[k][2] / self.bytes[k] < ridge        # this shape's own bound
-            return {'shape': describe(k, self.paths.get(k)), 'launches': agg[k][1], 'avg_us': round(avg_s * 1e6, 2), 'tflops': round(tf, 1),
+            return {'shape': describe(k, self.paths.get(k), self.names.get(k)), 'launches': agg[k][1], 'avg_us': round(avg_s * 1e6, 2), 'tflops': round(tf, 1),
                     'algorithmic_gbs': round(gbs, 1), 'bound': 'hbm' if hbm else 'mfma',
                     'frac': round(gbs / HBM_PEAK_GBS if hbm else tf / peak_tflops, 4)}
         shapes = [shape_row(k) for k in sorted(keys, key=lambda k: -agg[k][0])]
@@ -134,11 +134,17 @@ class KernelTimer:
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
-KERNEL_NAMES = {0: 'conv_igemm_kernel', 1: 'narrow_fwd_kernel', 2: 'conv_halo_kernel', 3: 'conv_halo2_kernel', 4: 'thin1_fwd_kernel', 5: 'head_gemm_kernel', 6: 'conv_s2t_kernel', 10: 'wgrad_kernel',
-                11: 'wgrad_halo_kernel', 12: 'wgrad_tr_kernel'}
+# hv_last_kernel_path codes (the `hv_path_note = N` of each launcher in csrc/): the kernel FAMILY; the exact instantiation comes from hv_last_kernel_name
+KERNEL_NAMES = {0: 'conv_igemm_kernel', 1: 'narrow_fwd_kernel', 2: 'conv_halo_kernel', 3: 'conv_halo2_kernel', 4: 'thin1_fwd_kernel', 5: 'head_gemm_kernel', 6: 'conv_s2t_kernel',
+                7: 'conv_lf_kernel', 8: 'conv_g4_kernel', 9: 'thin_dgrad_kernel', 10: 'wgrad_kernel', 11: 'wgrad_halo_kernel', 12: 'wgrad_tr_kernel', 13: 'wgrad_trd_kernel'}
 
 
-def describe(key, path=None):
+def describe(key, path=None, kname=None):
+    """One shape row's label: the kernel that RAN for it -- the instantiation name the launcher reported (as rocprofv3 prints it) when there is one, else
+    the family of its path code -- and the layer's shape."""
     kind, B, H, W, cin, cout, k, s, d, tr = key
-    name = KERNEL_NAMES.get(path, {'conv': 'conv_igemm_kernel', 'wgrad': 'wgrad_kernel'}[kind])
+    name = kname or KERNEL_NAMES.get(path, {'conv': 'conv_igemm_kernel', 'wgrad': 'wgrad_kernel'}[kind])
+    if name.startswith('void '):
+        name = name[5:]
+    name = name.split('(')[0]
     return '%s %s B%d %dx%d Cin%d->Cout%d k%d s%d d%d' % (name, 'transposed' if tr else 'forward', B, H, W, cin, cout, k, s, d)

@@ -138,6 +138,30 @@ def g3_discriminator(nets, out):
              sd_after={k: v for k, v in sd3.items() if 'running' in k or 'tracked' in k}, y_eval=ye)
 
 
+def g3n_discriminator_n_layers(nets, out):
+    """G3n: define_D(1, 8, 'n_layers', n_layers_D, norm) @64^2 for n_layers_D in {2, 4} (models/networks.py:198-199): the depths 'basic' does not build --
+    forward, loss, every gradient, BN running statistics after 3 calls, eval forward."""
+    for nl, norm in ((2, 'batch'), (4, 'batch'), (4, 'instance')):
+        torch.manual_seed(303 + nl)
+        net = nets.define_D(1, 8, 'n_layers', nl, norm, 'normal', 0.02, [])
+        sd0 = np_sd(net.state_dict())
+        g = torch.Generator().manual_seed(5 + nl)
+        xs = [torch.rand(2, 1, 64, 64, generator=g) * 2 - 1 for _ in range(3)]
+        net.train()
+        x0 = xs[0].clone().requires_grad_(True)
+        y0 = net(x0)
+        loss = torch.nn.BCEWithLogitsLoss()(y0, torch.ones_like(y0))
+        loss.backward()
+        grads = {k: p.grad.numpy().copy() for k, p in net.named_parameters()}
+        ys = [y0.detach()] + [net(x).detach() for x in xs[1:]]
+        sd3 = np_sd(net.state_dict())
+        net.eval()
+        ye = net(xs[0]).detach()
+        save(out, 'g3n_disc_n%d_%s' % (nl, norm), sd=sd0, x={str(i): x for i, x in enumerate(xs)},
+             y={str(i): y for i, y in enumerate(ys)}, loss=loss.detach(), grads=grads, grad_x=x0.grad,
+             sd_after={k: v for k, v in sd3.items() if 'running' in k or 'tracked' in k}, y_eval=ye)
+
+
 def g4_small_ops(edge, nets, p2p, out):
     """G4: Sobel, diceCoeff, GANLoss on hand-built inputs."""
     g = torch.Generator().manual_seed(9)
@@ -262,7 +286,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--ref', default='/root/reference')
     ap.add_argument('--out', default=os.path.join(ROOT, 'tests', 'golden'))
-    ap.add_argument('--only', default='', help='comma-separated subset of g1,g2,g3,g4,g5,g6,g6b,g7')
+    ap.add_argument('--only', default='', help='comma-separated subset of g1,g2,g3,g3n,g4,g5,g6,g6b,g7')
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     sys.path.insert(0, ROOT)
@@ -274,6 +298,7 @@ def main():
     if want('g1'): g1_generator(inp, args.out)
     if want('g2'): g2_attention(inp, args.out)
     if want('g3'): g3_discriminator(nets, args.out)
+    if want('g3n'): g3n_discriminator_n_layers(nets, args.out)
     if want('g4'): g4_small_ops(edge, nets, p2p, args.out)
     if want('g6'): g6_unet(unet, args.out)
     if want('g6b'): g6b_unet_dropout(unet, args.out)

@@ -258,10 +258,17 @@ for step in range(5):
 torch.cuda.synchronize()
 assert model._graphs is not None
 if sys.argv[2] == '1':
-    if sys.argv[4] == 'captured':      # the collectives are INSIDE the one step graph
+    if sys.argv[4] == 'auto':          # the preflight ran both schedules, both correct, kept one, and put the weights back (checked by the caller: bit-identity)
+        rec = model.dp_preflight_record
+        assert rec and rec['chosen'] == model.dp_schedule and model.dp_schedule in ('captured', 'graphs'), rec
+        assert all(r['ok'] and r['weights_identical_across_ranks'] and r['error'] is None and r['ms_per_step'] > 0 for r in rec['schedules'].values()), rec
+        assert len(model._graphs) == (1 if model.dp_schedule == 'captured' else 3)
+    elif sys.argv[4] == 'captured':      # the collectives are INSIDE the one step graph
         assert len(model._graphs) == 1 and model._inline_exchange and getattr(model, 'dp_capture_error', None) is None, (len(model._graphs), getattr(model, 'dp_capture_error', None))
     else:
         assert len(model._graphs) == 3 and not model._inline_exchange
+    assert model.grad_sync.rccl is not None      # both schedules talk to RCCL through our own communicator
+    model.grad_sync.close()
     t = torch.tensor([1.5], device='cuda:0', dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX); dist.barrier()
     assert float(t.item()) == 1.5
@@ -274,13 +281,15 @@ print('ok')
 '''
 
 
-@pytest.mark.parametrize('schedule,precision', [('captured', 'fp16'), ('captured', 'fp32'), ('graphs', 'fp32')])
+@pytest.mark.parametrize('schedule,precision', [('captured', 'fp16'), ('captured', 'fp32'), ('graphs', 'fp32'), ('auto', 'fp16')])
 def test_rccl_exchange_path_single_rank(tmp_path, schedule, precision):
-    """The gradient exchange exactly as a multi-GPU job issues it -- RCCL all-reduce (ncclAvg) of the flat gradient buffers on the exchange stream between the
-    step's three graphs (default), or as direct ncclAllReduce calls CAPTURED INSIDE the step's one hipGraph (HV_DP_SCHEDULE=captured: D_k's on D_k's
-    stream, G's before its Adam step; a communicator of our own, ddp.RcclComm) -- plus broadcast, barrier and the MAX-reduce of the bench clock, in a one-rank RCCL group: averaging over one rank is the
-    identity, so the weights after five steps (three of them graph replays) must equal those of a run without a process group, bit for bit."""
-    port = str(29700 + os.getpid() % 1000 + (1000 if schedule == 'graphs' else 0) + (500 if precision == 'fp16' else 0))
+    """The gradient exchange exactly as a multi-GPU job issues it -- ncclAllReduce (ncclAvg) of the flat gradient buffers through a communicator of our own
+    (ddp.RcclComm) on the exchange stream, in the order D_1, D_2, D_3, G: between the step's three graphs (HV_DP_SCHEDULE=graphs), or as ONE exchange branch
+    CAPTURED INSIDE the step's one hipGraph (captured: D_k's mean beside the other discriminators' passes, G's before its Adam step) -- plus broadcast, barrier and
+    the MAX-reduce of the bench clock, in a one-rank RCCL group: averaging over one rank is the identity, so the weights after five steps must equal those of a
+    run without a process group, bit for bit.  'auto' (the default of a multi-GPU job) first runs the PREFLIGHT -- both schedules, 2 x 10 steps, cross-rank
+    checks -- which must leave the weights, running statistics and Adam state exactly as it found them: the same bit-identity after the five steps."""
+    port = str(29700 + os.getpid() % 1000 + {'graphs': 1000, 'auto': 2000}.get(schedule, 0) + (500 if precision == 'fp16' else 0))
     outs = []
     for force in ('1', '0'):
         dst = str(tmp_path / ('w%s.pt' % force))
@@ -335,9 +344,14 @@ def test_bench_data_parallel_dress_rehearsal_on_one_device():
     plain = _bench({}, ['--steps', '10', '--warmup', '3'])
     assert plain['n_gpus'] == 1 and plain['comm']['world_size'] == 1 and '1 graphs' in plain['config']['launch'], plain['config']      # (single process: the whole step is one graph)
     assert len(plain['regions_ms_per_step']) == 3 and plain['ms_per_step'] == sorted(plain['regions_ms_per_step'])[1]
-    one = _bench({'HV_DDP_FORCE': '1'}, ['--steps', '10', '--warmup', '3'])
+    one = _bench({'HV_DDP_FORCE': '1', 'HV_DP_SCHEDULE': 'graphs'}, ['--steps', '10', '--warmup', '3'])
     assert one['comm']['backend'] == 'nccl' and one['comm']['world_size'] == 1 and one['comm']['dp_schedule'] == 'graphs', one['comm']
     assert '3 graphs' in one['config']['launch'], (one['comm'], one['config'])
+    # what the driver's `bench.py --gpus N` takes (no schedule given): the preflight picks, and the line says what it saw
+    auto = _bench({'HV_DDP_FORCE': '1'}, ['--steps', '10', '--warmup', '3'])
+    pf = auto['comm']['preflight']
+    assert pf and pf['chosen'] == auto['comm']['dp_schedule'] and all(r['ok'] for r in pf['schedules'].values()), auto['comm']
+    print('preflight in a one-rank RCCL group: %s' % {k: v['ms_per_step'] for k, v in pf['schedules'].items()}, '->', pf['chosen'])
     cap = _bench({'HV_DDP_FORCE': '1', 'HV_DP_SCHEDULE': 'captured'}, ['--steps', '10', '--warmup', '3'])
     assert '1 graphs' in cap['config']['launch'] and cap['comm']['dp_schedule'] == 'captured' and cap['comm']['capture_error'] is None, (cap['comm'], cap['config'])
     print('data-parallel schedule in a one-rank RCCL group: cut (default) %.3f ms, captured %.3f ms, single process %.3f ms' % (one['ms_per_step'], cap['ms_per_step'], plain['ms_per_step']))

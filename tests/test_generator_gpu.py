@@ -105,12 +105,16 @@ def test_g2_contextual_attention_batch0_mask_quirk():
     assert _err(f.grad, g['grad_f']) <= TOL * max(1.0, g['grad_f'].abs().max().item())
 
 
-@pytest.mark.parametrize('norm', ['batch', 'instance'])
-def test_g3_discriminator(norm):
+@pytest.mark.parametrize('fixture,netD,n_layers,norm', [('g3_disc_batch', 'basic', 3, 'batch'), ('g3_disc_instance', 'basic', 3, 'instance'),
+                                                        ('g3n_disc_n2_batch', 'n_layers', 2, 'batch'), ('g3n_disc_n4_batch', 'n_layers', 4, 'batch'),
+                                                        ('g3n_disc_n4_instance', 'n_layers', 4, 'instance')])
+def test_g3_discriminator(fixture, netD, n_layers, norm):
+    """PatchGAN forward / loss / every gradient / running statistics after three calls / eval forward against the reference's own outputs: 'basic' (G3) and
+    define_D('n_layers', n_layers_D in {2, 4}) (G3n; reference models/networks.py:198-199 -- the depths 'basic' does not build)."""
     from hvgan.models import networks
-    g = load_golden('g3_disc_%s' % norm)
+    g = load_golden(fixture)
     dev = torch.device('cuda:0')
-    net = networks.define_D(1, 8, 'basic', 3, norm, 'normal', 0.02, [])
+    net = networks.define_D(1, 8, netD, n_layers, norm, 'normal', 0.02, [])
     net.load_state_dict(g['sd'])
     net.cuda()
     net.precision = 'fp32'

@@ -55,8 +55,10 @@ def test_g2_attention_batch0_mask_quirk_and_grad():
 
 
 def test_g3_discriminator():
-    for norm in ('batch', 'instance'):
-        g = load_golden('g3_disc_%s' % norm)
+    """'basic' (three layers) and, G3n, define_D('n_layers', n_layers_D in {2, 4}) (reference models/networks.py:198-199)."""
+    for name, norm in (('g3_disc_batch', 'batch'), ('g3_disc_instance', 'instance'), ('g3n_disc_n2_batch', 'batch'), ('g3n_disc_n4_batch', 'batch'),
+                       ('g3n_disc_n4_instance', 'instance')):
+        g = load_golden(name)
         sd = {k: v.clone() for k, v in g['sd'].items()}
         params = [k for k in sd if k.endswith('.weight') or k.endswith('.bias')]
         for k in params:

@@ -20,9 +20,8 @@ def run_case(case):
     torch.manual_seed(0)
     if case == 'phase_a_serial':
         os.environ['HV_CONCURRENT_D'] = '0'
-        os.environ['HV_OVERLAP_WGRAD'] = '0'
     if case == 'phase_a_dstreams':
-        os.environ['HV_OVERLAP_WGRAD'] = '0'
+        pass
     if case == 'phase_a_wgrad':
         os.environ['HV_CONCURRENT_D'] = '0'
     model = Pix2PixModel(make_opt())
