@@ -121,6 +121,7 @@ class GradSync:
         self.group = group
         self.stream = None
         self.rccl = None
+        self._chain = {}
 
     @staticmethod
     def active():
@@ -154,24 +155,40 @@ class GradSync:
         return self.stream
 
     def reduce_branch(self, flat, producer=None):
-        """Captured schedule: average `flat` across the ranks on the EXCHANGE stream -- the one stream every collective of the step is issued on, in
-        the order of the calls (D_1, D_2, D_3, G: the same on every rank by construction) -- ordered after everything queued on `producer` (default:
-        the current stream), which then waits for the result.  One ncclAllReduce (ncclAvg) through our own communicator; under stream capture it is a
-        node of the exchange branch of the graph being captured, and the other streams keep running beside it."""
+        """Captured schedule: average `flat` across the ranks, as ONE chain of collectives over the whole step -- every ncclAllReduce of the step is ordered
+        behind the previous one by an explicit edge, in the order of the calls (D_1, D_2, D_3, G: the same on every rank by construction; RCCL requires
+        it) -- ordered after everything queued on `producer` (default: the current stream), which continues when the mean is there.  Under stream capture
+        the collectives are kernel nodes of the graph being captured, and the other streams keep running beside them.
+        Two forms (HV_DP_BRANCH): 'chain' (default) issues the collective on the PRODUCER's stream behind an event recorded after the previous collective
+        (D_k's mean beside the other discriminators' passes; the only extra edges are joins between branches that exist anyway); 'stream' issues all of
+        them on the exchange stream (a branch of its own: hipStreamEndCapture of ROCm 7.0 / 7.2 crashes on that topology, kept for newer runtimes)."""
         if not flat.is_cuda or flat.dtype != torch.float32:
             raise RuntimeError('reduce_branch: fp32 device tensors only')
         comm = self.open()
         if comm is None:
             raise RuntimeError('reduce_branch: needs an RCCL process group')
         producer = producer if producer is not None else torch.cuda.current_stream(flat.device)
-        st = self.exchange_stream(flat.device)
-        if st.cuda_stream == producer.cuda_stream:
-            comm.all_reduce_mean(flat)
+        if os.environ.get('HV_DP_BRANCH', 'chain') == 'stream':
+            st = self.exchange_stream(flat.device)
+            st.wait_stream(producer)
+            with torch.cuda.stream(st):
+                comm.all_reduce_mean(flat)
+            producer.wait_stream(st)
             return
-        st.wait_stream(producer)
-        with torch.cuda.stream(st):
+        capturing = torch.cuda.is_current_stream_capturing()
+        prev = self._chain.get(capturing)
+        if prev is not None and prev[0] != producer.cuda_stream:
+            producer.wait_event(prev[1])
+        with torch.cuda.stream(producer):
             comm.all_reduce_mean(flat)
-        producer.wait_stream(st)
+            ev = torch.cuda.Event()
+            ev.record(producer)
+        self._chain[capturing] = (producer.cuda_stream, ev)
+
+    def chain_reset(self):
+        """Start of a step (or of a capture): the first collective has no predecessor inside it (an event recorded outside a capture must not be waited
+        for inside it, and the previous step's collectives are ordered before this step's by the streams themselves)."""
+        self._chain = {}
 
     def reduce(self, flat, after=None):
         """Cut schedule: average `flat` (a network's flat gradient buffer) across ranks on the exchange stream, ordered after everything queued

@@ -405,9 +405,10 @@ class Pix2PixModel(BaseModel):
             engine.NO_FORK_STREAMS.update(st.cuda_stream for st in self._d_streams)
         self._dxs = {}
         if self._inline_exchange:
-            # the exchange branch leaves the MAIN stream here, before the discriminator streams do (a first-level fork of the capture; the edges it
-            # exchanges with the discriminator streams later are joins between branches that already exist)
-            self.grad_sync.exchange_stream(self.device).wait_stream(main)
+            self.grad_sync.chain_reset()      # the step's collectives form one chain D_1 -> D_2 -> D_3 -> G (ddp.GradSync.reduce_branch)
+            if __import__('os').environ.get('HV_DP_BRANCH', 'chain') == 'stream':
+                # the exchange branch leaves the MAIN stream here, before the discriminator streams do (a first-level fork of the capture)
+                self.grad_sync.exchange_stream(self.device).wait_stream(main)
         split = self.real_first and not self.batch_d
         def on(k):
             side = self._d_streams[k - 1] if (self.concurrent_d and not engine.SERIAL) else main
