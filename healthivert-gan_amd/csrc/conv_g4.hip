@@ -34,7 +34,6 @@ struct G4K {
     int Hc, Wc;                                // extent of that grid
     unsigned x_bytes, w_bytes, w_rb;           // w_rb: bytes of one 16-row block of the filter table
     int dbg;                                   // diagnostic builds (G4_STAMPS): bit 0 no loads / LDS writes in the loop, bit 1 no barriers, bit 2 no MFMAs, bit 3 no fragment reads
-    int ncb, ntiles, cb_inner;                 // half-width kernels (conv_g4h_kernel): 64-column blocks per tile, tiles of the launch (images included), block order
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -58,18 +57,16 @@ __device__ __forceinline__ void g4_load_bias(const G4K& p, int cob, int lane, f3
 // Shared epilogue of the pipelined-GEMM kernels: the workgroup's TH x 16 pixels x 128 columns (two 64-column slots) -> (alpha, +bias, activation) ->
 // fp16 tile in LDS -> 16-byte pieces with the act' multiplier / accumulate forms; optional per-channel statistics of the stored tile.
 // MODE 1 (stride-2 data gradient): slot s is the output-parity class cls_s[s] -- pixel (i, j) of the tile lands at (2 i + py, 2 j + px).
-// S = 64-column slots of the workgroup: 2 = eight waves x 128 columns (wave -> (row group wave >> 1, slot wave & 1)), 1 = four waves x 64 columns (the
-// half-width kernels, two workgroups per CU); part_x = the workgroup's tile index (image included): the row of the statistics partials it writes.
-template <int MODE, int MT, int S = 2>
+template <int MODE, int MT>
 __device__ __forceinline__ void g4_epilogue(const G4K& p, f32x4 (&acc)[4][MT], char* smem, const int (&cls_s)[2], const int (&cob_s)[2], int n_img, int i0,
-                                            int j0, const f32x4 (&bias_r)[4], int part_x) {
-    constexpr int TW = 16, TH = 4 * MT, NTHR = 256 * S, LDO = 64 * S + 8, PP = 8 * S, PSH = S == 2 ? 4 : 3;      // PP: 16-byte pieces per pixel row of the tile
+                                            int j0, const f32x4 (&bias_r)[4]) {
+    constexpr int TW = 16, TH = 4 * MT, NTHR = 512, LDO = 128 + 8;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = S == 2 ? wave >> 1 : wave, wn = S == 2 ? wave & 1 : 0;
+    const int wm = wave >> 1, wn = wave & 1;
     _Float16* As = reinterpret_cast<_Float16*>(smem);
     // ---- epilogue: this thread's output pieces (act' multiplier, old gradient) requested first, then (alpha, +bias, activation) -> fp16 tile in
     // LDS -> 16-byte pieces
-    constexpr int OITEMS = TH * TW * PP / NTHR;
+    constexpr int OITEMS = TH * TW * 16 / NTHR;
     const __amdgpu_buffer_rsrc_t msrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.mul_src), 0, p.mul_src ? 0x7ffffff0u : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t ysrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.accumulate ? 0x7ffffff0u : 0u, 0x00020000);
     u32x4 mreg[OITEMS], yreg[OITEMS];
@@ -77,7 +74,7 @@ __device__ __forceinline__ void g4_epilogue(const G4K& p, f32x4 (&acc)[4][MT], c
 #pragma unroll
     for (int k = 0; k < OITEMS; ++k) {
         const int it = tid + k * NTHR;
-        const int q = it >> PSH, pc = it & (PP - 1), s = pc >> 3;
+        const int q = it >> 4, pc = it & 15, s = pc >> 3;
         const int i = i0 + (q >> 4), j = j0 + (q & 15);
         const int ch = cob_s[s] + (pc & 7) * 8;
         const bool ok = i < p.Hc && j < p.Wc && ch < p.Cout;
@@ -118,7 +115,7 @@ __device__ __forceinline__ void g4_epilogue(const G4K& p, f32x4 (&acc)[4][MT], c
 #pragma unroll
     for (int k = 0; k < OITEMS; ++k) {
         const int it = tid + k * NTHR;
-        o[k] = *reinterpret_cast<const u32x4*>(ot + (it >> PSH) * LDO + (it & (PP - 1)) * 8);
+        o[k] = *reinterpret_cast<const u32x4*>(ot + (it >> 4) * LDO + (it & 15) * 8);
     }
     if (MODE != 1 && p.stats) {
         // BatchNorm statistics of this tile: thread (q-lane, piece) sums its OITEMS pixels' 8 channels (piece = it & 15 is the same for all of a
@@ -134,18 +131,18 @@ __device__ __forceinline__ void g4_epilogue(const G4K& p, f32x4 (&acc)[4][MT], c
             for (int e = 0; e < 8; ++e) { const float v = (float)v8[e]; s1[e] += v; s2[e] += v * v; }
         }
         __syncthreads();                       // the staging tile has been read into registers by every thread
-        float* red = reinterpret_cast<float*>(smem);       // [32 rows][PP pieces][16]
-        float* mine = red + tid * 16;                      // (row tid / PP, piece tid % PP)
+        float* red = reinterpret_cast<float*>(smem);       // [32 rows][16 pieces][16]
+        float* mine = red + ((tid >> 4) * 16 + (tid & 15)) * 16;
 #pragma unroll
         for (int e = 0; e < 8; ++e) { mine[e] = s1[e]; mine[8 + e] = s2[e]; }
         __syncthreads();
-        if (tid < 16 * PP) {      // 64 S channels x {sum, sum of squares}
+        if (tid < 256) {      // 128 channels x {sum, sum of squares}
             const int pc = tid >> 4, e = tid & 15;
             float s = 0.f;
 #pragma unroll 8
-            for (int r = 0; r < 32; ++r) s += red[(r * PP + pc) * 16 + e];
-            const int ch = cob_s[pc >> 3] + (pc & 7) * 8 + (e & 7);
-            if (ch < p.Cout) p.stats[((long long)part_x * p.Cout + ch) * 2 + (e >> 3)] = s;
+            for (int r = 0; r < 32; ++r) s += red[(r * 16 + pc) * 16 + e];
+            const int ch = (int)blockIdx.y * 128 + pc * 8 + (e & 7);
+            if (ch < p.Cout) p.stats[((long long)blockIdx.x * p.Cout + ch) * 2 + (e >> 3)] = s;
         }
     }
     if (p.mul_src) {
@@ -185,7 +182,7 @@ __device__ __forceinline__ void g4_epilogue(const G4K& p, f32x4 (&acc)[4][MT], c
         // Batch-norm backward sums of this tile (the reduction pass norm_reduce_kernel<1> re-read dy and x for): per channel sum g and sum g * xhat, g = the value
         // just stored, xhat = (x - mean) * rstd of the normalisation's raw input at the same pixel.  A thread's OITEMS pieces share one 8-channel piece
         // (it & 15): its x pieces are requested now (the multiplier / old-gradient registers are dead), folded like the forward statistics above.
-        const int pc = tid & (PP - 1), s = pc >> 3;
+        const int pc = tid & 15, s = pc >> 3;
         const int ch0 = cob_s[s] + (pc & 7) * 8;
         const int grp = n_img / p.bn_ipg;
         const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.bn_x), 0, 0x7ffffff0u, 0x00020000);
@@ -193,7 +190,7 @@ __device__ __forceinline__ void g4_epilogue(const G4K& p, f32x4 (&acc)[4][MT], c
 #pragma unroll
         for (int k = 0; k < OITEMS; ++k) {
             // the x piece of output piece k: same pixel and channels, the normalisation input's own strides
-            const int q = (tid + k * NTHR) >> PSH;
+            const int q = (tid + k * NTHR) >> 4;
             int ho = i0 + (q >> 4), wo = j0 + (q & 15);
             if (MODE == 1) { ho = 2 * ho + (cls_s[s] >> 1); wo = 2 * wo + (cls_s[s] & 1); }
             const long long opix = (long long)(n_img * p.Ho + ho) * p.Wo + wo;
@@ -213,19 +210,19 @@ __device__ __forceinline__ void g4_epilogue(const G4K& p, f32x4 (&acc)[4][MT], c
             }
         }
         __syncthreads();                       // the staging tile has been read into registers by every thread
-        float* red = reinterpret_cast<float*>(smem);       // [32 rows][PP pieces][16]
-        float* mine = red + tid * 16;
+        float* red = reinterpret_cast<float*>(smem);       // [32 rows][16 pieces][16]
+        float* mine = red + ((tid >> 4) * 16 + (tid & 15)) * 16;
 #pragma unroll
         for (int e = 0; e < 8; ++e) { mine[e] = s1[e]; mine[8 + e] = s2[e]; }
         __syncthreads();
-        if (tid < 64 * S) {      // one thread per column (S 64-channel slots): sum g, and sum g * xhat = rstd * (sum g x - mean * sum g)
+        if (tid < 128) {      // one thread per column (two 64-channel slots): sum g, and sum g * xhat = rstd * (sum g x - mean * sum g)
             const int pq = tid >> 3, e = tid & 7;
             float sg = 0.f, sgx = 0.f;
 #pragma unroll 8
-            for (int r = 0; r < 32; ++r) { sg += red[(r * PP + pq) * 16 + e]; sgx += red[(r * PP + pq) * 16 + 8 + e]; }
+            for (int r = 0; r < 32; ++r) { sg += red[(r * 16 + pq) * 16 + e]; sgx += red[(r * 16 + pq) * 16 + 8 + e]; }
             const int sl = pq >> 3, ch = cob_s[sl] + (pq & 7) * 8 + e;
-            // MODE 1: the four output-parity classes of a tile are four parts; else one part per tile
-            const long long part = MODE == 1 ? (long long)part_x * 4 + cls_s[sl] : (long long)part_x;
+            // MODE 1: the four output-parity classes of a tile are four parts (two per workgroup of the class pair); else one part per workgroup
+            const long long part = MODE == 1 ? (long long)blockIdx.x * 4 + cls_s[sl] : (long long)blockIdx.x;
             if (ch < p.Cout) {
                 const float mean = p.bn_stats[(long long)grp * 2 * p.Cout + ch], rstd = p.bn_stats[(long long)grp * 2 * p.Cout + p.Cout + ch];
                 float* o2 = p.bstats + (part * p.Cout + ch) * 2;
@@ -425,7 +422,7 @@ __global__ __launch_bounds__(512, 2) void conv_g4_kernel(const G4K p) {
     __syncthreads();
     G4_STAMP(3);
 
-    g4_epilogue<MODE, MT>(p, acc, smem, cls_s, cob_s, n_img, i0, j0, bias_r, (int)blockIdx.x);
+    g4_epilogue<MODE, MT>(p, acc, smem, cls_s, cob_s, n_img, i0, j0, bias_r);
 #ifdef G4_STAMPS
     __builtin_amdgcn_s_waitcnt(0);
     G4_STAMP(5);
@@ -573,252 +570,7 @@ __global__ __launch_bounds__(512, 2) void conv_g4s1_kernel(const G4K p) {
         sub(kc, std::integral_constant<int, 3>(), ab); ab = ab == 2 ? 0 : ab + 1;
     }
     __syncthreads();
-    g4_epilogue<0, MT>(p, acc, smem, cls_s, cob_s, n_img, i0, j0, bias_r, (int)blockIdx.x);
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------------------------------------
-// Half-width form of the three kernels above (round 5): a workgroup of FOUR waves owns TH x 16 pixels x 64 GEMM columns and keeps <= 74 KB of LDS, so
-// that TWO workgroups share a CU (one wave of each per SIMD).  The eight-wave kernels hold 146-153 KB: one workgroup per CU whose eight waves all meet
-// at one barrier per 64 MFMAs and run prologue, main loop and epilogue in lock step over the whole chip (PMC, round 4: MFMA pipes busy 58 / 34 / 29 % of the
-// SIMD cycles).  Here a SIMD's two waves belong to different workgroups -- also of different launches on the three discriminator streams -- and each
-// fills the other's barrier waits, DMA waits and epilogue.
-//   KIND 0: 4x4 stride-2 forward (space-to-depth view, as conv_g4_kernel<0>);  KIND 1: its data gradient, ONE (parity class, 64-channel) slot per
-//   workgroup;  KIND 2 / 3: 4x4 stride-1 forward / data gradient (as conv_g4s1_kernel).
-//   A stage = (32-channel chunk, TWO taps): its 8 KB filter slice (4 row blocks x 2 taps) arrives by LDS-DMA into a ring of three; the patch of a chunk
-//   arrives once for all its stages (2 at stride 2, 8 at stride 1) into one of two buffers.  A wave computes (TH/4 rows x 16 pixels) x 64 columns: per tap
-//   4 A + MT B fragment reads for 4 MT MFMAs, the same ratio as the eight-wave kernels.  The accumulation order per output element (chunks, then taps, in the
-//   old kernels' order) is unchanged: results are bit-identical to conv_g4_kernel / conv_g4s1_kernel.
-template <int KIND, int MT>
-__global__ __launch_bounds__(256, 2) void conv_g4h_kernel(const G4K p) {
-    constexpr bool S1 = KIND >= 2;
-    constexpr int DG = KIND == 3 ? 1 : 0;
-    constexpr int TW = 16, TH = 4 * MT;
-    constexpr int PH = S1 ? TH + 3 : TH + 1 + (KIND == 1 ? 1 : 0), PW = S1 ? 20 : 17 + (KIND == 1 ? 1 : 0);
-    constexpr int NBP = (PH * PW + 15) / 16, BPW = (NBP + 3) / 4;            // 1-KB pieces of the patch, ... per wave
-    constexpr int ASTG = 8 * 512, BBUF = NBP * 512;                           // halfs
-    constexpr int SPC = S1 ? 8 : 2;                                           // stages per chunk
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    _Float16* As = reinterpret_cast<_Float16*>(smem);                         // [3][ASTG]
-    _Float16* Bs = As + 3 * ASTG;                                             // [2][BBUF] + one spare KB
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // workgroup -> (tile incl. image, column block): column blocks of one tile are `cb_stride` workgroups apart (1: neighbours, they share the patch in
-    // L2; ntiles: a whole pass over the image per column block, the filters stay in L2)
-    int t, cb;
-    {
-        const int id = (int)blockIdx.x;
-        if (p.cb_inner) { t = id / p.ncb; cb = id - t * p.ncb; } else { cb = id / p.ntiles; t = id - cb * p.ntiles; }
-    }
-    const int part_x = t;
-    const int n_img = t / p.tiles;
-    t -= n_img * p.tiles;
-    const int tile_y = t / p.tiles_x, tile_x = t - tile_y * p.tiles_x;
-    const int i0 = tile_y * TH, j0 = tile_x * TW;
-    const int Cin = p.Cin, KC = Cin >> 5;
-    const int NCH = KIND == 0 ? 4 * KC : KC, NS = NCH * SPC;
-    int cls = 0, cob = cb * 64;
-    if (KIND == 1) { const int nco = p.Cout >> 6; cls = cb / nco; cob = (cb - cls * nco) * 64; }
-    const int py = cls >> 1, px = cls & 1;
-    const int cls_s[2] = {cls, cls}, cob_s[2] = {cob, cob};
-    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.w), 0, p.w_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
-    f32x4 bias_r[4];
-    g4_load_bias(p, cob, lane, bias_r);
-
-    // ---- this lane's part of the wave's patch pieces (chunk-independent): piece j = wave + 4 i covers pixels 16 j .. 16 j + 15, lane -> (pixel, slot)
-    int pbase[BPW], pval[BPW];
-    const int xbase = (n_img * p.H * p.W * p.x_ld + p.x_coff) * 2;
-#pragma unroll
-    for (int i = 0; i < BPW; ++i) {
-        const int pix = (wave + 4 * i) * 16 + (lane >> 2);
-        const int c8 = (lane & 3) ^ (((pix >> 2) & 1) << 1);                  // the channel piece this LDS slot holds
-        const int pr = pix / PW, pc = pix - pr * PW;
-        const bool in = wave + 4 * i < NBP && pr < PH && (!S1 || pc < PW - 1);
-        if (KIND == 0) {
-            const int r0 = 2 * (i0 + pr) - 1, c0 = 2 * (j0 + pc) - 1;
-            pbase[i] = xbase + ((r0 * p.W + c0) * p.x_ld + c8 * 8) * 2;
-            int v = 0;
-#pragma unroll
-            for (int dd = 0; dd < 4; ++dd)
-                if (in && (unsigned)(r0 + (dd >> 1)) < (unsigned)p.H && (unsigned)(c0 + (dd & 1)) < (unsigned)p.W) v |= 1 << dd;
-            pval[i] = v;
-        } else {
-            // stride 1: forward reads x[i - 1 + kh], the data gradient g[i + 1 - kh] = g[i - 2 + (3 - kh)]
-            constexpr int ORG = S1 ? (DG ? 2 : 1) : 1;
-            const int r0 = i0 - ORG + pr, c0 = j0 - ORG + pc;
-            pbase[i] = xbase + ((r0 * p.W + c0) * p.x_ld + c8 * 8) * 2;
-            pval[i] = (in && (unsigned)r0 < (unsigned)p.H && (unsigned)c0 < (unsigned)p.W) ? 15 : 0;
-        }
-    }
-    // every wave issues the same number of LDS-DMA instructions per stage (2 filter fragments [+ BPW patch pieces]; a piece index beyond the patch is sent
-    // with every lane out of range and lands in the spare KB), so that the counted vmcnt below means the same thing in every wave
-    auto issueA = [&](int c, int sub, int ab) __attribute__((always_inline)) {
-        int dy = 0, dx = 0, kc = c;
-        if (KIND == 0) { dy = c / (2 * KC); const int rem = c - dy * 2 * KC; dx = rem / KC; kc = rem - dx * KC; }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int f = wave + 4 * i, rbw = f >> 1, j = f & 1;
-            int tap;
-            if (KIND == 0) tap = (2 * sub + dy) * 4 + 2 * j + dx;                          // tt = 2 sub + j: (th, tw) = (sub, j)
-            else if (KIND == 1) tap = (1 - py + 2 * sub) * 4 + (1 - px + 2 * j);
-            else tap = (sub >> 1) * 4 + 2 * (sub & 1) + j;                                  // (kh, kw) = (sub >> 1, 2 (sub & 1) + j)
-            lds_dma16(wsrc, (lds_ptr)(As + ab * ASTG + f * 512), (unsigned)lane * 16u, ((cob >> 4) + rbw) * (int)p.w_rb + (tap * Cin + kc * 32) * 32);
-        }
-    };
-    auto issueB = [&](int c, int bb) __attribute__((always_inline)) {
-        int dy = 0, dx = 0, kc = c;
-        if (KIND == 0) { dy = c / (2 * KC); const int rem = c - dy * 2 * KC; dx = rem / KC; kc = rem - dx * KC; }
-        const int coff = KIND == 0 ? ((dy * p.W + dx) * p.x_ld + kc * 32) * 2 : kc * 64;
-        const int vb = KIND == 0 ? dy * 2 + dx : 0;
-#pragma unroll
-        for (int i = 0; i < BPW; ++i) {
-            _Float16* dst = wave + 4 * i < NBP ? Bs + bb * BBUF + (wave + 4 * i) * 512 : Bs + 2 * BBUF;      // (the spare KB behind the two buffers)
-            lds_dma16(xsrc, (lds_ptr)dst, ((pval[i] >> vb) & 1) ? (unsigned)(pbase[i] + coff) : HV_OOB, 0);
-        }
-    };
-    // B-fragment addresses (halfs) of this lane.  Stride 2: one per (tap of the 2 x 2 set, pixel row m) -- the slot permutation depends on the pixel, i.e. on
-    // the tap.  Stride 1: without the filter row's shift, for even and odd row shifts (20 pixels per row = 5 groups of 4: a row shift flips the permutation
-    // with its parity); the shift itself is an immediate (the stage index is unrolled)
-    constexpr int NBO = S1 ? 8 : 4;
-    int bo[NBO][MT];
-#pragma unroll
-    for (int q = 0; q < NBO; ++q)
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            if (S1) {
-                const int kw = q & 3, par = q >> 2;
-                const int pix = (wave * MT + m) * PW + (lane & 15) + (DG ? 3 - kw : kw);
-                const int s0 = ((pix >> 2) & 1) ^ par;
-                bo[q][m] = pix * 32 + (((lane >> 4) ^ (s0 << 1)) << 3);
-            } else {
-                int dh, dw;
-                if (KIND == 0) { dh = q >> 1; dw = q & 1; } else { dh = py - (q >> 1) + 1; dw = px - (q & 1) + 1; }
-                const int pix = (wave * MT + m + dh) * PW + (lane & 15) + dw;
-                bo[q][m] = pix * 32 + (((lane >> 4) ^ (((pix >> 2) & 1) << 1)) << 3);
-            }
-        }
-    f32x4 acc[4][MT];
-#pragma unroll
-    for (int n = 0; n < 4; ++n)
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f16x8 a[2][4], bf[2][MT];
-    // fragments of tap j of the stage whose index inside its chunk is SUB (compile time), from filter slot ab and patch buffer bb
-    auto frags = [&](auto SUB, int j, int ab, int bb, int buf) __attribute__((always_inline)) {
-        constexpr int sub = decltype(SUB)::value;
-        const _Float16* Ab = As + ab * ASTG + lane * 8;
-#pragma unroll
-        for (int n = 0; n < 4; ++n) a[buf][n] = *reinterpret_cast<const f16x8*>(Ab + (n * 2 + j) * 512);
-        if (S1) {
-            constexpr int kh = sub >> 1, rs = DG ? 3 - kh : kh;
-            const int kw = 2 * (sub & 1) + j;
-            const _Float16* Bb = Bs + bb * BBUF + rs * PW * 32;
-#pragma unroll
-            for (int m = 0; m < MT; ++m) bf[buf][m] = *reinterpret_cast<const f16x8*>(Bb + bo[(rs & 1) * 4 + kw][m]);
-        } else {
-            const _Float16* Bb = Bs + bb * BBUF;
-#pragma unroll
-            for (int m = 0; m < MT; ++m) bf[buf][m] = *reinterpret_cast<const f16x8*>(Bb + bo[2 * sub + j][m]);
-        }
-    };
-    auto mfmas = [&](int buf) __attribute__((always_inline)) {
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int n = 0; n < 4; ++n) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[buf][n], bf[buf][m], acc[n][m], 0, 0, 0);
-    };
-    auto interleave = [&]() __attribute__((always_inline)) {      // one fragment read per two MFMAs (a burst of reads from every wave stalls all MFMA issue)
-#pragma unroll
-        for (int i = 0; i < 4 + MT; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, (4 * MT) / (4 + MT), 0);
-        }
-    };
-    // Stage s = c SPC + sub computes on filter slot s % 3 while the DMA of stages s + 1 and s + 2 is in flight; the patch of chunk c + 1 goes out with the
-    // filters of its first stage.  The barrier sits between the two taps: by then the wave holds all its fragments of stage s (lgkmcnt(0)) and has
-    // waited for its OWN pieces of stage s + 1, so behind the barrier stage s + 1 is complete in LDS and slot s % 3 is free; the first fragments of stage
-    // s + 1 are read behind the second tap's MFMAs.
-    auto stage = [&](int c, auto SUB, int ab) __attribute__((always_inline)) {
-        constexpr int sub = decltype(SUB)::value;
-        const int s_ = c * SPC + sub;
-        constexpr int sub2 = (sub + 2) % SPC;
-        const int c2 = c + (sub + 2 >= SPC ? 1 : 0);
-        const int ab2 = ab == 0 ? 2 : ab - 1;                                 // (s + 2) % 3
-        const bool more = s_ + 2 < NS;
-        if (more) {
-            if (sub == SPC - 2) issueB(c + 1, (c + 1) & 1);
-            issueA(c2, sub2, ab2);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        frags(SUB, 1, ab, c & 1, 1);
-        mfmas(0);
-        interleave();
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) {
-            if (sub == SPC - 2) __builtin_amdgcn_s_waitcnt(0x0070 | ((2 + BPW) & 15) | (((2 + BPW) >> 4) << 14));
-            else __builtin_amdgcn_s_waitcnt(0x0070 | 2);
-        } else {
-            __builtin_amdgcn_s_waitcnt(0x0070);
-        }
-        __builtin_amdgcn_s_barrier();
-        if (s_ + 1 < NS) {
-            constexpr int sub1 = (sub + 1) % SPC;
-            frags(std::integral_constant<int, sub1>(), 0, ab == 2 ? 0 : ab + 1, (c + (sub + 1 >= SPC ? 1 : 0)) & 1, 0);
-        }
-        mfmas(1);
-        interleave();
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    // prologue: the patch of chunk 0, stages 0 and 1 in flight; wait for stage 0's (the two newest instructions -- stage 1's filters -- may stay in flight)
-    issueB(0, 0);
-    issueA(0, 0, 0);
-    issueA(SPC > 1 ? 0 : 1, 1 % SPC, 1);
-    __builtin_amdgcn_s_waitcnt(0x0F70 | 2);
-    __builtin_amdgcn_s_barrier();
-    frags(std::integral_constant<int, 0>(), 0, 0, 0, 0);
-    int ab = 0;
-    for (int c = 0; c < NCH; ++c) {
-        stage(c, std::integral_constant<int, 0>(), ab); ab = ab == 2 ? 0 : ab + 1;
-        stage(c, std::integral_constant<int, 1>(), ab); ab = ab == 2 ? 0 : ab + 1;
-        if (SPC == 8) {
-            stage(c, std::integral_constant<int, 2 % SPC>(), ab); ab = ab == 2 ? 0 : ab + 1;
-            stage(c, std::integral_constant<int, 3 % SPC>(), ab); ab = ab == 2 ? 0 : ab + 1;
-            stage(c, std::integral_constant<int, 4 % SPC>(), ab); ab = ab == 2 ? 0 : ab + 1;
-            stage(c, std::integral_constant<int, 5 % SPC>(), ab); ab = ab == 2 ? 0 : ab + 1;
-            stage(c, std::integral_constant<int, 6 % SPC>(), ab); ab = ab == 2 ? 0 : ab + 1;
-            stage(c, std::integral_constant<int, 7 % SPC>(), ab); ab = ab == 2 ? 0 : ab + 1;
-        }
-    }
-    __syncthreads();
-    g4_epilogue<KIND == 1 ? 1 : 0, MT, 1>(p, acc, smem, cls_s, cob_s, n_img, i0, j0, bias_r, part_x);
-}
-
-template <int KIND, int MT>
-static int launch_g4h(G4K& k, int ncb, hipStream_t s) {
-    constexpr bool S1 = KIND >= 2;
-    constexpr int TH = 4 * MT, PH = S1 ? TH + 3 : TH + 1 + (KIND == 1 ? 1 : 0), PW = S1 ? 20 : 17 + (KIND == 1 ? 1 : 0), NBP = (PH * PW + 15) / 16;
-    constexpr size_t lds_loop = (size_t)(3 * 8 * 512 + (2 * NBP + 1) * 512) * 2, lds_out = (size_t)TH * 16 * 72 * 2, lds_red = 32 * 8 * 16 * 4;
-    constexpr size_t lds = lds_loop > lds_out ? (lds_loop > lds_red ? lds_loop : lds_red) : (lds_out > lds_red ? lds_out : lds_red);
-    static_assert(lds <= 80 * 1024, "two workgroups per CU");
-    k.tiles_x = hv_cdiv(k.Wc, 16);
-    k.tiles = k.tiles_x * hv_cdiv(k.Hc, TH);
-    k.ntiles = k.tiles * k.B;
-    k.ncb = ncb;
-    static const int inner = getenv("HV_G4H_CB_INNER") ? atoi(getenv("HV_G4H_CB_INNER")) : 0;
-    k.cb_inner = inner;
-    auto kern = conv_g4h_kernel<KIND, MT>;
-    static bool raised = false;
-    if (!raised) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        if (e != hipSuccess) return -1000 - (int)e;
-        raised = true;
-    }
-    hv_path_note = 8;
-    HV_KNAME("conv_g4h_kernel<%d, %d>", KIND, MT);
-    HV_WUSE(4);
-    hipLaunchKernelGGL(kern, dim3(k.ntiles * ncb), dim3(256), lds, s, k);
-    HV_LAUNCH_CHECK();
-    return HV_OK;
+    g4_epilogue<0, MT>(p, acc, smem, cls_s, cob_s, n_img, i0, j0, bias_r);
 }
 
 template <int DG, int MT>
@@ -873,29 +625,6 @@ static int g4_tile_rows(int B, int Hc, int Wc, int ny) {
     if (force == 2 || force == 4) return 4 * force;
     return (long long)B * hv_cdiv(Hc, 16) * hv_cdiv(Wc, 16) * ny >= 200 ? 16 : 8;
 }
-// HV_G4H: which launches take the half-width kernels (conv_g4h_kernel, two workgroups per CU): bit 0 stride-2 forward, bit 1 stride-2 data gradient, bit 2
-// stride-1 forward, bit 3 stride-1 data gradient
-static int g4h_mask() {
-    static const int m = getenv("HV_G4H") ? atoi(getenv("HV_G4H")) : 15;
-    return m;
-}
-// tile rows of the half-width kernels: 16-row tiles when they still give every CU its two workgroups (512 slots), else 8-row tiles
-static int g4h_tile_rows(int B, int Hc, int Wc, int ncb) {
-    static const int force = getenv("HV_G4H_MT") ? atoi(getenv("HV_G4H_MT")) : 0;
-    if (force == 2 || force == 4) return 4 * force;
-    static const int want = getenv("HV_G4H_WGS") ? atoi(getenv("HV_G4H_WGS")) : 400;
-    return (long long)B * hv_cdiv(Hc, 16) * hv_cdiv(Wc, 16) * ncb >= want ? 16 : 8;
-}
-// (kernel kind 0..3 of conv_g4h_kernel for an eligible descriptor, 64-column blocks per tile, low-resolution grid extent) -> tile rows; 0 = eight-wave kernels
-static int g4_plan_half(const hv_conv_desc* d, int* kind, int* ncb, int* Hc, int* Wc) {
-    const int k = d->stride == 1 ? (d->transposed ? 3 : 2) : (d->transposed ? 1 : 0);
-    if (!((g4h_mask() >> k) & 1)) return 0;
-    *kind = k;
-    *ncb = (k == 1 ? 4 : 1) * (d->Cout / 64);
-    *Hc = k == 1 ? d->H : d->Ho;
-    *Wc = k == 1 ? d->W : d->Wo;
-    return g4h_tile_rows(d->B, *Hc, *Wc, *ncb);
-}
 
 // The ONE eligibility predicate of the pipelined 4x4 kernels: 4x4, stride 2 or 1, pad 1, dilation 1, fp16 NHWC views with 16-byte aligned channel rows,
 // fragment-ordered filters.  hv_conv2d_g4 launches exactly when it holds, and hv_conv2d_g4_stats_floats promises a statistics epilogue only then.
@@ -924,7 +653,6 @@ int hv_conv2d_g4(const hv_conv_desc* d, hipStream_t s) {
     if (!g4_eligible(d)) return HV_ERR_UNSUPPORTED;
     G4K k;
     k.dbg = getenv("HV_G4_DBG") ? atoi(getenv("HV_G4_DBG")) : 0;
-    k.ncb = k.ntiles = k.cb_inner = 0;
     k.x = d->x; k.w = reinterpret_cast<const _Float16*>(d->w_f16_tiled); k.bias = d->bias; k.y = d->y; k.mul_src = d->mul_src;
     k.stats = d->transposed ? nullptr : d->stats;
     k.bn_x = nullptr; k.bn_stats = nullptr; k.bstats = nullptr; k.bn_x_ld = k.bn_x_coff = 0; k.bn_ipg = 1;
@@ -939,23 +667,6 @@ int hv_conv2d_g4(const hv_conv_desc* d, hipStream_t s) {
     k.x_bytes = (unsigned)((size_t)d->B * d->H * d->W * d->x_ld * 2);
     k.w_rb = (unsigned)(16 * 16 * d->Cin * 2);
     k.w_bytes = (unsigned)((size_t)hv_cdiv(d->Cout, 16) * k.w_rb);
-    {
-        int kind = 0, ncb = 0, Hc = 0, Wc = 0;
-        const int th = g4_plan_half(d, &kind, &ncb, &Hc, &Wc);
-        if (th) {
-            k.Hc = Hc; k.Wc = Wc;
-            switch (kind * 2 + (th == 16 ? 1 : 0)) {
-                case 0: return launch_g4h<0, 2>(k, ncb, s);
-                case 1: return launch_g4h<0, 4>(k, ncb, s);
-                case 2: return launch_g4h<1, 2>(k, ncb, s);
-                case 3: return launch_g4h<1, 4>(k, ncb, s);
-                case 4: return launch_g4h<2, 2>(k, ncb, s);
-                case 5: return launch_g4h<2, 4>(k, ncb, s);
-                case 6: return launch_g4h<3, 2>(k, ncb, s);
-                default: return launch_g4h<3, 4>(k, ncb, s);
-            }
-        }
-    }
     if (d->stride == 1) {
         k.Hc = d->Ho; k.Wc = d->Wo;
         const int ny = d->Cout / 128;
@@ -981,11 +692,6 @@ size_t hv_conv2d_g4_bstats_parts(const hv_conv_desc* d) {
     const int G = d->bn_groups > 0 ? d->bn_groups : 1;
     if (d->B % G) return 0;
     if ((long long)d->B * d->Ho * d->Wo * d->bn_x_ld >= (1ll << 30)) return 0;
-    {
-        int kind = 0, ncb = 0, Hc = 0, Wc = 0;
-        const int th = g4_plan_half(d, &kind, &ncb, &Hc, &Wc);
-        if (th) return (size_t)d->B * hv_cdiv(Hc, th) * hv_cdiv(Wc, 16) * (kind == 1 ? 4 : 1);
-    }
     if (d->stride == 1) {
         const int th = g4_tile_rows(d->B, d->Ho, d->Wo, d->Cout / 128);
         return (size_t)d->B * hv_cdiv(d->Ho, th) * hv_cdiv(d->Wo, 16);
@@ -1000,9 +706,7 @@ size_t hv_conv2d_g4_stats_floats(const hv_conv_desc* d, int* nparts) {
     hv_conv_desc t = *d;
     // the forward launches of hv_conv2d_g4 (same predicate: alignment, size limits and the act' operand included) that assign their output
     if (t.transposed || t.accumulate || !g4_eligible(&t)) return 0;
-    int kind = 0, ncb = 0, Hc = 0, Wc = 0;
-    const int thh = g4_plan_half(&t, &kind, &ncb, &Hc, &Wc);
-    const int th = thh ? thh : g4_tile_rows(t.B, t.Ho, t.Wo, t.Cout / 128);
+    const int th = g4_tile_rows(t.B, t.Ho, t.Wo, t.Cout / 128);
     const int parts = t.B * hv_cdiv(t.Ho, th) * hv_cdiv(t.Wo, 16);
     if (nparts) *nparts = parts;
     return (size_t)parts * t.Cout * 2;
