@@ -18,6 +18,8 @@
 // half-step's MFMAs, 144-byte LDS rows: 57.2 -> 56.0 us.  The kernel is not barrier-bound.)
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "hv_common.h"
 
 struct BgemmK {
@@ -149,6 +151,149 @@ __global__ __launch_bounds__(256, 2) void bgemm_nt_kernel(const BgemmK p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// The fp16 x fp16 products (the attention block's A V, dA and d raw at 1024^3 per sample) on an LDS-DMA ring (round 5).  bgemm_nt_kernel above moves
+// 16 KB of operands global -> registers -> LDS per 64 MFMAs of a 128 x 128 tile: at full MFMA rate that is 64 B per CU cycle, twice what a CU takes in from
+// L2, and it ran at 0.60-0.64 PFLOP/s.  Here a workgroup of eight waves owns a 256 x 256 tile of C (one round of 256 workgroups at 1024^2 x 16 samples;
+// 32 KB of operands per 256 MFMAs = 32 B per CU cycle), a stage is 32 deep in k (one MFMA k-step), both operand tiles arrive by LDS-DMA (buffer_load ... lds,
+// 1 KB per wave instruction, no staging registers) into a ring of four 32-KB stages issued three stages ahead (the operands stream from the Infinity Cache /
+// HBM; with two 64-deep stages and one stage of lead: 48.2 us against 40.7), one barrier per stage of 32 MFMAs per wave.  The DMA writes lane-linear
+// 1-KB pieces = 16 rows x 64 B, so rows cannot be padded: slot s of row r holds its 16-byte k piece s ^ 2 ((r >> 2) & 1) (the permutation goes on the SOURCE
+// address, as for the patch rows of conv_g4_kernel): the four lane groups of a fragment's ds_read_b128 then hit every bank once.  A wave computes 128 (m) x
+// 64 (n): per k-step 8 A + 4 B fragment reads for 32 MFMAs; the fragments are double-buffered over half k-steps (16 MFMAs).  Measured (tools/bench_bgemm.py,
+// rotating operands): 1024^3 x 16 61.1 -> 42.9 us = 0.80 PFLOP/s, 4096 x 4096 x 1024 x 16 975 -> 746 us; same bits (same k order).
+typedef __attribute__((address_space(3))) void* bg_lds_ptr;
+__device__ __forceinline__ void bg_dma16(__amdgpu_buffer_rsrc_t r, bg_lds_ptr dst, unsigned voff, int soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 16, voff, soff, 0, 0);
+#endif
+}
+
+__global__ __launch_bounds__(512, 2) void bgemm_dma_kernel(const BgemmK p) {
+    constexpr int BM = 256, BN = 256;
+    constexpr int STAGE = 32 * 1024, RING = 4;                                // bytes per stage: [operand 2][16 pieces][1 KB]; stages in LDS
+    extern __shared__ __attribute__((aligned(16))) char smem[];               // [RING][STAGE]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;                                  // wave tile: rows wm * 128 .., columns wn * 64 ..
+    const int per = p.tiles_m * p.tiles_n;
+    int id = blockIdx.x, b, t;
+    if (p.swizzle) {
+        const int xcd = id & 7, slot = id >> 3;
+        b = (slot / per) * 8 + xcd;
+        t = slot % per;
+    } else {
+        b = id / per;
+        t = id % per;
+    }
+    const int m_base = (t / p.tiles_n) * BM, n_base = (t % p.tiles_n) * BN;
+    const _Float16* Ab = reinterpret_cast<const _Float16*>(p.A) + b * p.sA;
+    const _Float16* Bb = reinterpret_cast<const _Float16*>(p.B) + b * p.sB;
+    const __amdgpu_buffer_rsrc_t asrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(Ab), 0, (unsigned)((size_t)p.M * p.lda * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t bsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(Bb), 0, (unsigned)((size_t)p.N * p.ldb * 2), 0x00020000);
+    // ---- this lane's part of the wave's 4 DMA pieces per stage (stage-independent): piece idx = wave * 4 + i -> (operand idx >> 4, 16-row block idx & 15);
+    // lane -> (row lane >> 2, slot lane & 3)
+    unsigned doff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = wave * 4 + i, op = idx >> 4, j = idx & 15;
+        const int r = lane >> 2, c8 = (lane & 3) ^ (((r >> 2) & 1) << 1);
+        int row = (op ? n_base : m_base) + j * 16 + r;
+        const int rows = op ? p.N : p.M, ld = op ? p.ldb : p.lda;
+        const bool ok = row < rows;
+        if (op && p.b_split) row = (row % p.b_split) * (p.N / p.b_split) + row / p.b_split;
+        doff[i] = ok ? (unsigned)((row * ld + c8 * 8) * 2) : 0x80000000u;
+    }
+    auto issue = [&](int s) __attribute__((always_inline)) {
+        char* dst = smem + (s & (RING - 1)) * STAGE + wave * 4 * 1024;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bg_dma16(wave >= 4 ? bsrc : asrc, (bg_lds_ptr)(dst + i * 1024), doff[i], s * 64);
+    };
+    // fragment piece of this lane inside a 16-row block: row lane & 15, k piece lane >> 4 at its permuted slot
+    const int fo = (lane & 15) * 64 + ((((lane >> 4) ^ ((((lane & 15) >> 2) & 1) << 1))) << 4);
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int m = 0; m < 8; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f16x8 fb[2][4], fa[2][4];
+    auto ldB = [&](const char* base, int q) __attribute__((always_inline)) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) fb[q][n] = *reinterpret_cast<const f16x8*>(base + (16 + wn * 4 + n) * 1024 + fo);
+    };
+    auto ldA = [&](const char* base, int h, int q) __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) fa[q][m] = *reinterpret_cast<const f16x8*>(base + (wm * 8 + h * 4 + m) * 1024 + fo);
+    };
+    auto mfmas = [&](int qb, int qa, int h) __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[n][h * 4 + m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[qb][n], fa[qa][m], acc[n][h * 4 + m], 0, 0, 0);
+    };
+    auto mix = [&](int reads) __attribute__((always_inline)) {      // the next half-step's fragment reads dealt among this half-step's 16 MFMAs
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (i < reads) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        }
+    };
+    // Stage s (32 deep in k: one MFMA k-step, 32 MFMAs per wave in two halves) computes on buffer s % 4 while the DMA of stages s + 1 .. s + 3 is in flight
+    // (issued three stages ahead: the operands stream from the Infinity Cache / HBM, not from L2).  The barrier sits in front of the second half: the wave holds
+    // all its fragments of stage s and has waited for its OWN pieces of stage s + 1 (counted vmcnt: the 8 newer instructions stay in flight).
+    const int NS = p.K >> 5;
+    issue(0);
+    if (NS > 1) issue(1);
+    if (NS > 2) issue(2);
+    if (NS > 2) __builtin_amdgcn_s_waitcnt(0x0F70 | 8); else if (NS > 1) __builtin_amdgcn_s_waitcnt(0x0F70 | 4); else __builtin_amdgcn_s_waitcnt(0x0F70);
+    __builtin_amdgcn_s_barrier();
+    ldB(smem, 0);
+    ldA(smem, 0, 0);
+    auto stage = [&](int s, auto PAR) __attribute__((always_inline)) {      // PAR: s & 1 at compile time (the B fragments' register set)
+        constexpr int q = decltype(PAR)::value;
+        const char* cur = smem + (s & (RING - 1)) * STAGE;
+        const char* nxt = smem + ((s + 1) & (RING - 1)) * STAGE;
+        // the DMA of stage s + 3 (buffer (s - 1) % 4: every wave left it at the barrier of stage s - 1).  (Measured and not kept: waves 4-7 issuing theirs behind
+        // the first half's MFMAs, and the four instructions dealt among those MFMAs by the scheduler: 42.6 / 42.8 against 42.9 us.  PMC: the 262 144 DMA
+        // instructions of a launch hold their waves for ~150 cycles each = a quarter of all wave cycles wherever they sit; MFMA pipes busy 38 %.)
+        if (s + 3 < NS) issue(s + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        ldA(cur, 1, 1);
+        mfmas(q, 0, 0);
+        mix(4);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 3 < NS) __builtin_amdgcn_s_waitcnt(0x0070 | 8);            // lgkmcnt(0); stages s + 2, s + 3 may stay in flight
+        else if (s + 2 < NS) __builtin_amdgcn_s_waitcnt(0x0070 | 4);
+        else __builtin_amdgcn_s_waitcnt(0x0070);
+        __builtin_amdgcn_s_barrier();
+        if (s + 1 < NS) { ldB(nxt, q ^ 1); ldA(nxt, 0, 0); }
+        mfmas(q, 1, 1);
+        mix(8);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int s = 0; s < NS; s += 2) {
+        stage(s, std::integral_constant<int, 0>());
+        if (s + 1 < NS) stage(s + 1, std::integral_constant<int, 1>());
+    }
+    float* C = p.C + (p.c_f16 ? 0 : b * p.sC);
+    _Float16* Ch = reinterpret_cast<_Float16*>(p.C) + (p.c_f16 ? b * p.sC : 0);
+    const float* cs = p.colscale ? p.colscale + b * p.sS : nullptr;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int row = m_base + wm * 128 + m * 16 + (lane & 15);
+        if (row >= p.M) continue;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int col = n_base + wn * 64 + n * 16 + (lane >> 4) * 4;
+            if (col >= p.N) continue;                       // N % 4 == 0: a lane's four columns are all inside or all outside
+            float4 v = make_float4(acc[n][m][0] * p.alpha, acc[n][m][1] * p.alpha, acc[n][m][2] * p.alpha, acc[n][m][3] * p.alpha);
+            if (cs) { const float4 s4 = *reinterpret_cast<const float4*>(cs + col); v.x *= s4.x; v.y *= s4.y; v.z *= s4.z; v.w *= s4.w; }
+            if (p.c_f16) *reinterpret_cast<f16x4*>(Ch + (long long)row * p.ldc + col) = (f16x4){(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+            else *reinterpret_cast<float4*>(C + (long long)row * p.ldc + col) = v;
+        }
+    }
+}
+
 static int bgemm_impl(const void* A, int a_f16, int lda, long long strideA, const void* B, int b_f16, int ldb, long long strideB, float* C, int c_f16, int ldc,
                       long long strideC, int M, int N, int K, int batch, float alpha, const float* colscale, long long strideS, int b_split, void* stream) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || b_split < 0 || (b_split && N % b_split)) return HV_ERR_ARG;
@@ -161,14 +306,32 @@ static int bgemm_impl(const void* A, int a_f16, int lda, long long strideA, cons
     k.A = A; k.B = B; k.C = C; k.colscale = colscale;
     k.sA = strideA; k.sB = strideB; k.sC = strideC; k.sS = strideS;
     k.lda = lda; k.ldb = ldb; k.ldc = ldc; k.M = M; k.N = N; k.K = K; k.batch = batch; k.alpha = alpha; k.b_split = b_split; k.c_f16 = c_f16 ? 1 : 0;
+    static const int xcd = getenv("HV_XCD") ? atoi(getenv("HV_XCD")) : 1;
+    hipStream_t s = (hipStream_t)stream;
+    {   // fp16 x fp16 with whole 64-deep stages and enough 256 x 256 tiles to go round: the LDS-DMA form
+        static const int dma = getenv("HV_BGEMM_DMA") ? atoi(getenv("HV_BGEMM_DMA")) : 1;      // A/B knob
+        const long long t256 = (long long)hv_cdiv(M, 256) * hv_cdiv(N, 256) * batch;
+        if (dma && a_f16 && b_f16 && !(K & 63) && M >= 256 && N >= 256 && t256 >= 128 && t256 < (1ll << 31) && (size_t)M * lda * 2 < (1ull << 31) &&
+            (size_t)N * ldb * 2 < (1ull << 31)) {
+            k.tiles_m = hv_cdiv(M, 256); k.tiles_n = hv_cdiv(N, 256);
+            k.swizzle = (xcd && batch % 8 == 0) ? 1 : 0;
+            static bool raised = false;
+            if (!raised) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bgemm_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+                if (e != hipSuccess) return -1000 - (int)e;
+                raised = true;
+            }
+            hipLaunchKernelGGL(bgemm_dma_kernel, dim3((unsigned)t256), dim3(512), 128 * 1024, s, k);
+            HV_LAUNCH_CHECK();
+            return HV_OK;
+        }
+    }
     const int BN = N % 128 == 0 ? 128 : 64;      // N = 576 (the 3x3 patch gradient): nine 64-column tiles instead of a half-empty fifth 128-column one
     k.tiles_m = hv_cdiv(M, 128); k.tiles_n = hv_cdiv(N, BN);
     const long long tiles = (long long)k.tiles_m * k.tiles_n * batch;
     if (tiles >= (1ll << 31)) return HV_ERR_UNSUPPORTED;
-    static const int xcd = getenv("HV_XCD") ? atoi(getenv("HV_XCD")) : 1;
     k.swizzle = (xcd && batch % 8 == 0) ? 1 : 0;
     const dim3 grid((unsigned)tiles);
-    hipStream_t s = (hipStream_t)stream;
 #define HV_BG(BN_)                                                                                                       \
     do {                                                                                                                 \
         if (a_f16) hipLaunchKernelGGL((bgemm_nt_kernel<128, BN_, true, true>), grid, dim3(256), 0, s, k);                \

@@ -303,10 +303,14 @@ def test_module_api_backward_in_fp16_storage_mode_scales_its_gradients():
 
 
 @pytest.mark.parametrize('M,N,K,batch,scaled,split', [(1024, 1024, 576, 8, True, 0), (1024, 576, 1024, 3, False, 0), (200, 68, 64, 2, True, 0),
-                                                      (128, 128, 32, 16, False, 0), (256, 1024, 128, 8, False, 64)])
+                                                      (128, 128, 32, 16, False, 0), (256, 1024, 128, 8, False, 64),
+                                                      # the fp16 x fp16 products of these take the LDS-DMA kernel (>= 128 tiles of 256 x 256, K % 64 == 0):
+                                                      (1024, 576, 1024, 16, True, 0), (512, 1024, 128, 16, False, 64), (1024, 1024, 64, 12, False, 0),
+                                                      (1000, 520, 192, 16, True, 0)])
 def test_batched_nt_gemm_against_torch(M, N, K, batch, scaled, split):
     """hv_bgemm_nt (the fp16 mode's attention contractions): operands rounded to fp16, fp32 accumulation -- against torch on the same rounded
-    operands in fp64; ragged tile edges, the column scale, the XCD batch swizzle (batch % 8 == 0) and the plain mapping."""
+    operands in fp64; ragged tile edges, the column scale, the XCD batch swizzle (batch % 8 == 0) and the plain mapping.  The fp16 x fp16 form of the
+    large shapes runs in bgemm_dma_kernel (256 x 256 tiles on an LDS-DMA ring) and must give the bits of the register-staged kernel (same k order)."""
     import ctypes
     from hvgan import lib
     dev = torch.device('cuda:0')
