@@ -877,62 +877,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
-// One launch for the slab folds of a whole network (hv_wgrad_desc.pending): grid (chunks, folds); 256 threads = 64 element quads x 4 slab groups, a lane
-// walks the slabs k = group, group + 4, .. with four loads in flight and the four groups are folded through LDS in a fixed order (deterministic).
-__global__ __launch_bounds__(256) void wgrad_fold_batched_kernel(const hv_wgrad_fold* __restrict__ folds) {
-    const hv_wgrad_fold F = folds[blockIdx.y];
-    if (F.nslabs <= 0) return;
-    __shared__ float4 sh[4][64];
-    const int q = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const long long n4 = F.numel >> 2, nb4 = F.dbias ? (F.Cout + 3) >> 2 : 0;
-    for (long long c = (long long)blockIdx.x * 64; c < n4 + nb4; c += (long long)gridDim.x * 64) {
-        const long long i4 = c + q;
-        const bool bias = i4 >= n4, live = i4 < n4 + nb4;
-        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
-        if (live && !bias) {
-            const float4* src = reinterpret_cast<const float4*>(F.slabs) + i4;
-            int k = grp;
-            for (; k + 4 < F.nslabs; k += 8) {
-                const float4 v0 = src[(long long)k * n4], v1 = src[(long long)(k + 4) * n4];
-                a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w; a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
-            }
-            if (k < F.nslabs) { const float4 v0 = src[(long long)k * n4]; a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w; }
-        } else if (live) {
-            const long long j = (i4 - n4) * 4;
-            for (int k = grp; k < F.nslabs; k += 4)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (j + e < F.Cout) (&a0.x)[e] += F.bias_slabs[(long long)k * F.Cout + j + e];
-        }
-        sh[grp][q] = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
-        __syncthreads();
-        if (grp == 0 && live) {
-            const float4 s0 = sh[0][q], s1 = sh[1][q], s2 = sh[2][q], s3 = sh[3][q];
-            float4 t = make_float4((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z), (s0.w + s1.w) + (s2.w + s3.w));
-            if (!bias) {
-                float4* d = reinterpret_cast<float4*>(F.dw) + i4;
-                if (F.accumulate) { const float4 o = *d; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
-                *d = t;
-            } else {
-                const long long j = (i4 - n4) * 4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (j + e < F.Cout) F.dbias[j + e] = F.dbias_accumulate ? F.dbias[j + e] + (&t.x)[e] : (&t.x)[e];
-            }
-        }
-        __syncthreads();
-    }
-}
-extern "C" int hv_wgrad_fold_batched(const hv_wgrad_fold* d_folds, int n, long long max_numel, void* stream) {
-    if (!d_folds || n <= 0 || max_numel <= 0) return HV_ERR_ARG;
-    long long gx = (max_numel / 4 + 63) / 64;
-    if (gx > 256) gx = 256;          // (the largest fold sets the chunk count; the others stride or idle)
-    if (gx < 1) gx = 1;
-    hipLaunchKernelGGL(wgrad_fold_batched_kernel, dim3((unsigned)gx, n), dim3(256), 0, (hipStream_t)stream, d_folds);
-    HV_LAUNCH_CHECK();
-    return HV_OK;
-}
-// the fold of this call: now, or recorded for hv_wgrad_fold_batched (hv_wgrad_desc.pending)
+thread_local HvFold hv_carry = {};
+thread_local int hv_carry_taken = 0;
+// the fold of this call: now, or recorded for the caller to hand to the NEXT weight gradient (hv_wgrad_desc.pending -> hv_wgrad_desc.carry) / hv_wgrad_fold_now
 static int launch_wgrad_reduce(const float* slabs, float* dw, long long n, int splits, int accumulate, const float* bslabs, float* dbias, int nb,
                                 int bias_accumulate, hipStream_t s);
 static int wgrad_fold_or_defer(const hv_wgrad_desc* d, const float* slabs, long long n, int splits, const float* bslabs, hipStream_t s) {
@@ -944,6 +891,12 @@ static int wgrad_fold_or_defer(const hv_wgrad_desc* d, const float* slabs, long 
     }
     if (d->pending) d->pending->nslabs = 0;      // (folded here after all)
     return launch_wgrad_reduce(slabs, d->dw, n, splits, d->accumulate, bslabs, d->dbias, d->Cout, d->dbias_accumulate, s);
+}
+extern "C" int hv_wgrad_fold_now(const hv_wgrad_fold* f, void* stream) {
+    if (!f) return HV_ERR_ARG;
+    if (f->nslabs <= 0) return HV_OK;
+    if (!f->slabs || !f->dw || f->numel <= 0 || (f->numel & 3)) return HV_ERR_ARG;
+    return launch_wgrad_reduce(f->slabs, f->dw, f->numel, f->nslabs, f->accumulate, f->bias_slabs, f->dbias, f->Cout, f->dbias_accumulate, (hipStream_t)stream);
 }
 static int launch_wgrad_reduce(const float* slabs, float* dw, long long n, int splits, int accumulate, const float* bslabs, float* dbias, int nb,
                                 int bias_accumulate, hipStream_t s) {
@@ -1040,9 +993,36 @@ static int launch_wgrad(const WgradK& k, const WgradPlan& pl, hipStream_t s) {
     return HV_OK;
 }
 
+static int wgrad_dispatch(const hv_wgrad_desc* d, void* stream);
 extern "C" int hv_conv2d_wgrad(const hv_wgrad_desc* d, void* stream) {
     int rc = wgrad_validate(d);
     if (rc != HV_OK) return rc;
+    // the carried fold (hv_wgrad_desc.carry): offered to the launcher of this call's main kernel; one that cannot take it along leaves it to a launch of its own, first
+    hv_carry.splits = 0;
+    hv_carry_taken = 0;
+    const hv_wgrad_fold* c = d->carry;
+    if (c && c->nslabs > 0) {
+        if (!c->slabs || !c->dw || c->numel <= 0 || (c->numel & 3)) return HV_ERR_ARG;
+        static const int carry_on = getenv("HV_FOLD_CARRY") ? atoi(getenv("HV_FOLD_CARRY")) : 1;      // A/B knob (0: every carried fold as its own launch)
+        const bool overlap = (c->slabs == d->workspace);      // (a caller that did not alternate its slab buffers: the fold must be done before this call writes)
+        if (carry_on && !overlap && c->dw != d->dw) {
+            hv_carry = HvFold{c->slabs, c->dw, c->numel, c->nslabs, c->accumulate, c->dbias ? c->bias_slabs : nullptr, c->dbias, c->Cout, c->dbias_accumulate};
+        } else {
+            rc = hv_wgrad_fold_now(c, stream);
+            if (rc != HV_OK) return rc;
+            c = nullptr;
+        }
+    } else c = nullptr;
+    rc = wgrad_dispatch(d, stream);
+    const bool taken = hv_carry_taken != 0;
+    hv_carry.splits = 0;
+    hv_carry_taken = 0;
+    if (rc != HV_OK) return rc;
+    if (c && !taken) return hv_wgrad_fold_now(c, stream);      // (behind this call's kernel: the two folds touch different dW)
+    return HV_OK;
+}
+static int wgrad_dispatch(const hv_wgrad_desc* d, void* stream) {
+    int rc;
     const long long nW = (long long)d->Cout * d->KH * d->KW * d->Cin;
     {   // single-output-channel VALU path (conv_narrow.hip), then the halo-tiled fast path (wgrad_halo.hip: 3x3 / 5x5, stride 1, fp16)
         int nslabs = 0;

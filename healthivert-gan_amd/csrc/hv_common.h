@@ -216,3 +216,78 @@ __device__ __forceinline__ f32x4 hv_conv_value4(const HvEpi& e, const f32x4& a, 
 // byte-wise element address of a tensor whose element size is 2 (half != 0) or 4 bytes
 __device__ __forceinline__ void* hv_eptr(void* base, long long elem, int half) { return reinterpret_cast<char*>(base) + elem * (half ? 2 : 4); }
 __device__ __forceinline__ const void* hv_eptr(const void* base, long long elem, int half) { return reinterpret_cast<const char*>(base) + elem * (half ? 2 : 4); }
+
+// ---- carried slab folds (hv_wgrad_desc.carry): the fold of the PREVIOUS weight gradient's split-K slabs runs as extra workgroups of this weight gradient's
+// launch (blockIdx.x >= the main grid's x extent, for every (y, z)) instead of a launch of its own between the two -- a dependent ~5-us node less per layer
+// on the backward's chains.  Same arithmetic as wgrad_reduce_kernel<G> (conv_igemm.hip), G by slab count: bit-identical sums.
+struct HvFold {
+    const float* slabs; float* dw; long long n; int splits, accumulate;
+    const float* bslabs; float* dbias; int nb, bias_accumulate;
+};
+template <int G>
+__device__ __forceinline__ void hv_fold_blocks_g(const HvFold& F, int fb, int nfb, float4* sh /* >= 256 float4 of LDS */) {
+    constexpr int Q = 256 / G;
+    const int tid = threadIdx.x;
+    const bool worker = tid < 256;                       // (512-thread kernels: the upper half only keeps the barriers company)
+    const int e = tid % Q, grp = (tid & 255) / Q;
+    const long long wblocks = (F.n / 4 + Q - 1) / Q;
+    const long long total = wblocks + (F.dbias ? (F.nb + Q - 1) / Q : 0);
+    auto add = [](float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
+    for (long long blk = fb; blk < total; blk += nfb) {
+        const bool bias_block = blk >= wblocks;          // block-uniform
+        const long long i = bias_block ? (blk - wblocks) * Q + e : (blk * Q + e) * 4;
+        const bool live = worker && i < (bias_block ? (long long)F.nb : F.n);
+        float4 acc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live) {
+            int k = grp;
+            if (bias_block) {
+                for (; k + 3 * G < F.splits; k += 4 * G)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc[u].x += F.bslabs[(long long)(k + u * G) * F.nb + i];
+                for (; k < F.splits; k += G) acc[0].x += F.bslabs[(long long)k * F.nb + i];
+            } else {
+                for (; k + 3 * G < F.splits; k += 4 * G)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) add(acc[u], *reinterpret_cast<const float4*>(F.slabs + (long long)(k + u * G) * F.n + i));
+                for (; k < F.splits; k += G) add(acc[0], *reinterpret_cast<const float4*>(F.slabs + (long long)k * F.n + i));
+            }
+        }
+        add(acc[0], acc[1]); add(acc[2], acc[3]); add(acc[0], acc[2]);
+        if (worker) sh[grp * Q + e] = acc[0];
+        __syncthreads();
+#pragma unroll
+        for (int h = G / 2; h >= 1; h >>= 1) {
+            if (worker && grp < h) add(sh[grp * Q + e], sh[(grp + h) * Q + e]);
+            __syncthreads();
+        }
+        if (worker && grp == 0 && live) {
+            float4 t = sh[e];
+            if (bias_block) F.dbias[i] = F.bias_accumulate ? F.dbias[i] + t.x : t.x;
+            else {
+                if (F.accumulate) add(t, *reinterpret_cast<const float4*>(F.dw + i));
+                *reinterpret_cast<float4*>(F.dw + i) = t;
+            }
+        }
+        __syncthreads();
+    }
+}
+__device__ __forceinline__ void hv_fold_blocks(const HvFold& F, int fb, int nfb, void* lds) {
+    float4* sh = reinterpret_cast<float4*>(lds);
+    if (F.splits <= 16) hv_fold_blocks_g<4>(F, fb, nfb, sh);
+    else if (F.splits <= 64) hv_fold_blocks_g<16>(F, fb, nfb, sh);
+    else hv_fold_blocks_g<32>(F, fb, nfb, sh);
+}
+// host side: the carried fold of the weight-gradient call being dispatched (hv_wgrad_desc.carry; splits == 0: none) and whether a launcher took it along
+extern thread_local HvFold hv_carry;
+extern thread_local int hv_carry_taken;
+// x-blocks to append per (y, z) plane of a grid with `planes` planes for the carried fold (0: nothing carried)
+static inline int hv_carry_blocks(int planes) {
+    if (hv_carry.splits <= 0) return 0;
+    const int Q = 256 / (hv_carry.splits <= 16 ? 4 : hv_carry.splits <= 64 ? 16 : 32);
+    long long total = (hv_carry.n / 4 + Q - 1) / Q + (hv_carry.dbias ? (hv_carry.nb + Q - 1) / Q : 0);
+    if (total > 192) total = 192;                        // (fold blocks beside the main grid: the rest strides)
+    if (planes < 1) planes = 1;
+    return (int)((total + planes - 1) / planes);
+}

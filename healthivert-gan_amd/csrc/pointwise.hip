@@ -485,6 +485,58 @@ extern "C" int hv_gan_loss_head(const float* z, long long n, int target_is_real,
     return HV_OK;
 }
 
+// both ranges in one workgroup of 1 024 threads: a lane walks its elements of a range in a fixed order, the block sums are folded in a fixed order (deterministic)
+__global__ __launch_bounds__(1024) void gan_loss_head_pair_kernel(const float* __restrict__ z0, int n0, float t0, float* loss0, _Float16* __restrict__ c0,
+                                                                  const float* __restrict__ z1, int n1, float t1, float* loss1, _Float16* __restrict__ c1, int mode,
+                                                                  float lw, int lacc, float gw, float* dbias, int bacc) {
+    __shared__ float red[20];
+    float gtot = 0.f;
+    for (int r = 0; r < 2; ++r) {
+        const float* z = r ? z1 : z0;
+        const int n = r ? n1 : n0;
+        const float t = r ? t1 : t0;
+        _Float16* carrier = r ? c1 : c0;
+        float* loss = r ? loss1 : loss0;
+        if (n <= 0) continue;      // (block-uniform)
+        float l = 0.f, gs = 0.f;
+        for (int i = threadIdx.x; i < n; i += 1024) {
+            const float v = z[i];
+            float g;
+            if (mode == 0) {
+                const float e = expf(-fabsf(v)), q = 1.f / (1.f + e);
+                g = (v >= 0.f ? q : e * q) - t;
+                l += fmaxf(v, 0.f) - v * t + log1pf(e);
+            } else {
+                g = 2.f * (v - t);
+                l += (v - t) * (v - t);
+            }
+            g = gw * g / (float)n;
+            const _Float16 h = (_Float16)g;
+            *reinterpret_cast<f16x4*>(carrier + (long long)i * 4) = (f16x4){h, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+            gs += (float)h;
+        }
+        l = hv_block_sum(l, red);
+        __syncthreads();
+        gs = hv_block_sum(gs, red);
+        __syncthreads();
+        if (threadIdx.x == 0 && loss) { const float v = lw * l / (float)n; loss[0] = lacc ? loss[0] + v : v; }
+        gtot = r && n0 > 0 ? gtot + gs : gs;
+    }
+    if (threadIdx.x == 0 && dbias) dbias[0] = bacc ? dbias[0] + gtot : gtot;
+}
+extern "C" int hv_gan_loss_head_pair(const float* z0, long long n0, int real0, float* loss0, void* carrier0_f16, const float* z1, long long n1, int real1, float* loss1,
+                                     void* carrier1_f16, int mode, float loss_weight, int loss_accumulate, float grad_weight, float* dbias, int dbias_accumulate,
+                                     void* stream) {
+    if (!z0 || !carrier0_f16 || n0 <= 0 || n1 < 0 || (n1 > 0 && (!z1 || !carrier1_f16)) || mode < 0 || mode > 1) return HV_ERR_ARG;
+    if (((uintptr_t)carrier0_f16 | (uintptr_t)carrier1_f16) & 7) return HV_ERR_ARG;
+    if (n0 + n1 > 65536) return HV_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(gan_loss_head_pair_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, z0, (int)n0, real0 ? 1.f : 0.f, loss0,
+                       reinterpret_cast<_Float16*>(carrier0_f16), z1, (int)n1, real1 ? 1.f : 0.f, loss1, reinterpret_cast<_Float16*>(carrier1_f16), mode, loss_weight,
+                       loss_accumulate, grad_weight, dbias, dbias_accumulate);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ generator losses
 #define GL_CHUNKS 32
 #define GL_NQ 10   // S1,S2,cnt,tpf,spf,sgf,tpc,spc,sgc,E

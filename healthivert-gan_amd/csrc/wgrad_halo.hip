@@ -22,6 +22,8 @@ struct WHaloK {
     long long slab;   // floats per slab = Cout * KS*KS * Cin
     unsigned x_bytes, g_bytes;   // buffer descriptor ranges
     float* bias_out;             // per-workgroup column sums of g (bias gradient), [gridDim.x][Cout], or NULL
+    int gx;                      // x extent of the main grid (pixel chunks = slabs); blocks beyond it run the carried fold
+    HvFold fold;                 // the previous weight gradient's slab fold, carried along (hv_wgrad_desc.carry; splits == 0: none)
 };
 
 __device__ __forceinline__ uint32_t hv_pack2(float a, float b) {
@@ -56,6 +58,11 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const WHaloK p) {
 
     // the wave index steers MFMA-only branches: it must be a scalar (MFMA ignores EXEC, so an exec-masked "skipped" block
     // whose skip branch the compiler elides would still accumulate)
+    if ((int)blockIdx.x >= p.gx) {      // (block-uniform) the carried fold's workgroups
+        const int fx = (int)gridDim.x - p.gx;
+        hv_fold_blocks(p.fold, ((int)blockIdx.x - p.gx) + fx * ((int)blockIdx.y + (int)gridDim.y * (int)blockIdx.z), fx * (int)gridDim.y * (int)gridDim.z, smem);
+        return;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int co0 = blockIdx.y * BN, ci0 = blockIdx.z * BC;
     // taps are dealt round-robin to the four waves (tap t belongs to wave t & 3, accumulator slot t >> 2): a wave keeps
@@ -143,11 +150,11 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const WHaloK p) {
     };
 
     if ((int)blockIdx.x < p.ntiles) prefetch(blockIdx.x);
-    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += p.gx) {
         __syncthreads();   // previous tile's MFMA reads are done
         flush();
         __syncthreads();
-        if (tile + (int)gridDim.x < p.ntiles) prefetch(tile + gridDim.x);   // next tile's loads fly behind this tile's MFMAs
+        if (tile + p.gx < p.ntiles) prefetch(tile + p.gx);   // next tile's loads fly behind this tile's MFMAs
         if (TS) {
             // ---- MFMA: every wave walks all rows for its own taps
     #pragma unroll 1
@@ -319,10 +326,15 @@ static int launch_wh(const WHaloK& k, const WHaloPlan& pl, const hv_wgrad_desc* 
         lds_limit = 150 * 1024;
     }
     dim3 grid(pl.gx, hv_cdiv(d->Cout, BN), hv_cdiv(d->Cin, BC));
+    WHaloK kk = k;      // the previous weight gradient's fold rides along as extra x-blocks (needs 4 KB of the launch's LDS)
+    kk.gx = pl.gx;
+    kk.fold.splits = 0;
+    const int fx = pl.lds >= 4096 ? hv_carry_blocks((int)(grid.y * grid.z)) : 0;
+    if (fx > 0) { kk.fold = hv_carry; hv_carry_taken = 1; grid.x += fx; }
     hv_path_note = 11;
     HV_KNAME("wgrad_halo_kernel<%d, %d, %d, %s>", KS, BN, BC, TS ? "true" : "false");
     HV_TIMING_BEGIN(s);
-    hipLaunchKernelGGL(kern, grid, dim3(256), pl.lds, s, k);
+    hipLaunchKernelGGL(kern, grid, dim3(256), pl.lds, s, kk);
     HV_TIMING_END(s);
     HV_LAUNCH_CHECK();
     return HV_OK;

@@ -37,6 +37,8 @@ struct WTrK {
     unsigned x_bytes, g_bytes;   // buffer descriptor ranges
     float* bias_out;             // per-workgroup column sums of g (bias gradient), [gridDim.x][Cout], or NULL
     int dbg;                     // diagnostic builds (WT_STAMPS), timing only: bit 0 no DMA after the first tile, bit 1 no MFMAs, bit 2 no fragment reads
+    int gx;                      // x extent of the main grid (pixel chunks = slabs); wgrad_tr_kernel: blocks beyond it run the carried fold
+    HvFold fold;                 // the previous weight gradient's slab fold, carried along (hv_wgrad_desc.carry; splits == 0: none)
 };
 
 __device__ __forceinline__ f16x4 tr_read(const _Float16* lds_addr) {
@@ -64,6 +66,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(const WTrK p) {
     char* Gs = smem;                               // [TH*TW][SG]
     char* Xs = smem + TH * TW * SG;                // [PH*PW][SX]
 
+    if ((int)blockIdx.x >= p.gx) {      // (block-uniform) the carried fold's workgroups
+        const int fx = (int)gridDim.x - p.gx;
+        hv_fold_blocks(p.fold, ((int)blockIdx.x - p.gx) + fx * ((int)blockIdx.y + (int)gridDim.y * (int)blockIdx.z), fx * (int)gridDim.y * (int)gridDim.z, smem);
+        return;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int co0 = blockIdx.y * BN, ci0 = blockIdx.z * BC;
     const int grp = lane >> 4, sub = lane & 15, qr = sub >> 2, pc = sub & 3;
@@ -133,11 +140,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(const WTrK p) {
     const f16x8 ones = {1, 1, 1, 1, 1, 1, 1, 1};
 
     if ((int)blockIdx.x < p.ntiles) prefetch(blockIdx.x);
-    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += p.gx) {
         __syncthreads();   // previous tile's reads are done
         flush();
         __syncthreads();
-        if (tile + (int)gridDim.x < p.ntiles) prefetch(tile + gridDim.x);   // next tile's loads fly behind this tile's MFMAs
+        if (tile + p.gx < p.ntiles) prefetch(tile + p.gx);   // next tile's loads fly behind this tile's MFMAs
         // software pipeline over the (k-step, tap slot) pairs of the tile: the transposed LDS reads of the next pair are issued before the MFMAs of
         // the current one (with the reads right in front of their MFMAs a wave alternated ~130 cycles of LDS latency with 128 cycles of MFMAs; at
         // one workgroup per CU nothing else filled the gaps)
@@ -586,10 +593,15 @@ static int launch_wtr(const WTrK& k, const WTrPlan& pl, const hv_wgrad_desc* d, 
         lds_limit = 150 * 1024;
     }
     dim3 grid(pl.gx, hv_cdiv(d->Cout, BN), hv_cdiv(d->Cin, BC));
+    // the previous weight gradient's fold rides along as extra x-blocks of every (y, z) plane (this kernel leaves LDS and registers for a third workgroup per CU)
+    WTrK kk = k;
+    kk.fold.splits = 0;
+    const int fx = hv_carry_blocks((int)(grid.y * grid.z));
+    if (fx > 0) { kk.fold = hv_carry; hv_carry_taken = 1; grid.x += fx; }
     hv_path_note = 12;
     HV_KNAME("wgrad_tr_kernel<%d, %d, %d, %d>", KS, ST, BN, BC);
     HV_TIMING_BEGIN(s);
-    hipLaunchKernelGGL(kern, grid, dim3(256), pl.lds, s, k);
+    hipLaunchKernelGGL(kern, grid, dim3(256), pl.lds, s, kk);
     HV_TIMING_END(s);
     HV_LAUNCH_CHECK();
     return HV_OK;
@@ -631,6 +643,8 @@ int hv_wgrad_tr(const hv_wgrad_desc* d, int* nslabs, hipStream_t s) {
     k.slab = (long long)d->Cout * d->KH * d->KW * d->Cin;
     k.bias_out = d->dbias ? d->workspace + (long long)pl.gx * k.slab : nullptr;
     k.dbg = 0;
+    k.gx = pl.gx;
+    k.fold.splits = 0;
 #ifdef WT_STAMPS
     if (getenv("HV_WTR_DBG")) k.dbg = atoi(getenv("HV_WTR_DBG"));
 #endif

@@ -45,22 +45,12 @@ class ConvParams:
         # which prepared tables the layer's forward / data-gradient convolutions have read so far (hv_last_weight_tables bits: 1 fp32, 2 fp16 rows, 4 fp16
         # fragment order; 0 = not seen yet): ParamSet.prep writes only those inside a lean_tables() context
         self.use_fwd = self.use_bwd = 0
-        self.slabs, self.owner = {}, None
+        self.owner = None
         self.split_k = None                     # K2: also keep the first K2 input channels as a fragment-ordered table of their own (w_fwd_t2: conv2d's x1 layers)
         self.w_fwd_t2 = None
 
     def sizes(self):
         return (self.cout * self.taps * self.cin_fwd, self.cin_fwd * self.taps * self.coutP, self.coutP * self.taps * self.cin_wg)
-
-    # ---- deferred slab folds (ops.conv2d_wgrad defer=): the layer's split-K slabs live in a buffer of its own until the network's ONE fold launch
-    def slab_buffer(self, nbytes, device):
-        b = self.slabs.get(nbytes)       # (by size: the layer may be called with several batch shapes, each captured in its own graphs)
-        if b is None:
-            b = self.slabs[nbytes] = torch.empty(int(nbytes) + 64, dtype=torch.uint8, device=device)
-        return b
-
-    def defer_fold(self, rec):
-        self.owner.pending_folds.append(rec)
 
 
 class ParamSet:
@@ -78,13 +68,17 @@ class ParamSet:
         # is never rebuilt in place or freed -- a new bit pattern gets a new table and the old graphs keep theirs (a superset of bits stays correct for them:
         # the layout pass then merely writes a table they do not read)
         self.t_lean = {}
-        # deferred slab folds of the current backward (ops.conv2d_wgrad defer=) and the device tables of fold lists seen so far (a list is a function of the
-        # shapes: one table per batch shape / pass, built during the eager steps and found again by its key under graph capture)
-        self.pending_folds, self.t_folds = [], {}
+        # the slab-fold chains of this network's weight gradients, one per stream they are issued on (ops.FoldChain)
+        self.fold_chains = {}
         for c in self.convs:
             c.owner = self
         self.flat_grad = None
         self._key = None
+        # which weights the prepared tables belong to: `version` counts the changes of the parameters that this code knows of (optimiser steps, state-dict
+        # loads, new storage), `prepared` = (version, table set) of the last prep launch.  prep(only_if_stale=True) skips the launch when both still match --
+        # the discriminators' tables written for the generator's part of step t are the ones the discriminator update of step t + 1 reads
+        self.version = 0
+        self.prepared = None
 
     def trainable(self):
         seen, out = set(), []
@@ -104,6 +98,7 @@ class ParamSet:
         if key == self._key and self.device == device:
             return
         self._key, self.device = key, device
+        self.version += 1
         tot = sum(sum(c.sizes()) + 4 for c in self.convs)
         store = torch.zeros(tot, dtype=torch.float32, device=device)
         off = 0
@@ -185,10 +180,21 @@ class ParamSet:
                              power_iter=int(pi and c.sn), transposed_src=int(c.transposed_src), w_fwd_t2=c.w_fwd_t2, K2=int(c.split_k or 0)))
         return rows
 
-    def prep(self, device, power_iter):
+    def weights_changed(self):
+        """The parameters were written by something other than this ParamSet's own launches (an optimiser step, load_state_dict, user code): the next
+        prep(only_if_stale=True) must run."""
+        self.version += 1
+
+    def prep(self, device, power_iter, only_if_stale=False):
         self._ensure(device)
         pi = bool(power_iter)
         table = self.t_prep[pi]
+        tset = 'full'
+        if LEAN and LEAN_TABLES and ops.precision_id(None) == ops.F16:
+            tset = tuple((c.use_fwd, c.use_bwd) for c in self.convs)
+        if only_if_stale and not pi and PREP_SKIP and self.prepared is not None and self.prepared[0] == self.version and self.prepared[1] in ('full', tset):
+            return      # the tables in memory were written from these very weights (and cover the tables asked for)
+        self.prepared = (self.version, tset)
         if LEAN and LEAN_TABLES and ops.precision_id(None) == ops.F16:
             # inside the train step, after the step has been seen once for this batch shape: the layout pass skips the tables no kernel of the layer reads
             # (fp16 mode: the big layers read the fragment-ordered tables only -- 4 of 20 bytes per weight)
@@ -200,22 +206,26 @@ class ParamSet:
         ops.weight_prep(table, max(c.sizes()[0] + c.sizes()[1] for c in self.convs), any_sn=any(c.sn for c in self.convs),
                         any_legacy=any(c.transposed_src for c in self.convs))
 
-    def fold_pending(self):
-        """The recorded slab folds of this network as ONE launch (hv_wgrad_fold_batched)."""
-        if not self.pending_folds:
-            return
-        recs, self.pending_folds = self.pending_folds, []
-        key = tuple(tuple(sorted(r.items())) for r in recs)
-        t = self.t_folds.get(key)
-        if t is None:
-            t = self.t_folds[key] = ops.LayerTable('hv_wgrad_fold')
-            t.update(recs, key, self.device)
-        _lib.get().call('hv_wgrad_fold_batched', ctypes.cast(t.ptr(), ctypes.POINTER(_lib.get().hv_wgrad_fold)), t.n,
-                        ctypes.c_longlong(max(r['numel'] for r in recs)), stream())
+    def fold_chain(self):
+        """The FoldChain of the current stream (weight gradients of this network issued there carry each other's slab folds)."""
+        h = torch.cuda.current_stream().cuda_stream
+        c = self.fold_chains.get(h)
+        if c is None:
+            c = self.fold_chains[h] = ops.FoldChain(h)
+        return c
+
+    def flush_folds(self):
+        """The current stream's last recorded fold as a launch of its own; chains of other streams must have been flushed there before the join."""
+        h = torch.cuda.current_stream().cuda_stream
+        for k, c in self.fold_chains.items():
+            if k == h:
+                c.flush()
+            else:
+                assert c.pending is None, 'a weight-gradient fold chain of another stream was not flushed before finish_backward()'
 
     def finish_backward(self, accumulate=False):
         """Kernel-layout weight gradients -> .grad of weight_orig / weight (spectral-norm backward included)."""
-        self.fold_pending()
+        self.flush_folds()
         ops.weight_prep_backward(self.t_bwd[bool(accumulate)], max(c.cout * c.cin * c.taps for c in self.convs), any(c.sn for c in self.convs))
 
 
@@ -293,6 +303,7 @@ def named_stream(name, device, priority=0):
     return st
 
 
+PREP_SKIP = os.environ.get('HV_PREP_SKIP', '1') != '0'      # A/B knob: ParamSet.prep(only_if_stale=True) may skip (see there)
 LEAN_TABLES = os.environ.get('HV_LEAN_TABLES', '1') != '0' and os.environ.get('HV_WPREP_FUSED', '1') != '0'   # A/B knob: see ParamSet.prep
 LEAN = False              # set by lean_tables(): the caller vouches that every convolution of its networks has run once for the current shapes
 
@@ -359,26 +370,17 @@ class GradBook:
         return acc
 
 
-# One slab-fold launch per network instead of one per weight gradient (hv_wgrad_desc.pending / hv_wgrad_fold_batched).  Built in round 4 because the 62
-# wgrad_reduce launches per step looked like pure overhead; measured (three same-box pairs): 7.595 / 7.664 / 7.619 ms with the per-layer folds against
-# 7.667 / 7.676 / 7.659 ms deferred -- the per-layer fold reads slabs that are still in L2 / the Infinity Cache, the batched one reads 0.7 GB per step back
-# from HBM at the end of the backward, on the critical path.  Off by default; HV_DEFER_FOLDS=1 switches it on.
-DEFER_FOLDS = os.environ.get('HV_DEFER_FOLDS', '0') != '0'
-
-
 def _wgrad(node, p, xin, gfull, accumulate, prec, dbias=None, dbias_accumulate=False):
-    # the slab fold of this weight gradient is deferred to the network's one fold launch (ParamSet.finish_backward) -- unless it accumulates onto an
-    # earlier result of the same backward (the split real / fake discriminator passes): those are folded first, and this one in place
-    defer = p if (DEFER_FOLDS and p.owner is not None and not accumulate and not dbias_accumulate) else None
-    if defer is None and p.owner is not None:
-        p.owner.fold_pending()
+    # the split-K slab fold of this weight gradient rides in the NEXT weight gradient of the network on this stream (ops.FoldChain; the last one is
+    # launched by ParamSet.finish_backward / the owner of a side stream) -- round 4's 62 fold launches per step were each a dependent 5-us node
+    chain = p.owner.fold_chain() if p.owner is not None else None
     if node.transposed:
         # y = conv_transpose(x): the weight gradient is that of a strided conv with the roles of x and g swapped;
         # the result is laid out [cin][taps][coutP] (hv_weight_prep_backward knows, transposed_src)
-        ops.conv2d_wgrad(gfull, xin, p.dw, node.k, node.s, node.pad, node.d, accumulate=accumulate, precision=prec, defer=defer)
+        ops.conv2d_wgrad(gfull, xin, p.dw, node.k, node.s, node.pad, node.d, accumulate=accumulate, precision=prec, chain=chain)
     else:
         ops.conv2d_wgrad(xin, gfull, p.dw, node.k, node.s, node.pad, node.d, in_shift=node.shift, accumulate=accumulate, precision=prec,
-                         dbias=dbias, dbias_accumulate=dbias_accumulate, defer=defer)
+                         dbias=dbias, dbias_accumulate=dbias_accumulate, chain=chain)
 
 
 def conv_backward(node, book, prec, dbias_accumulate=False, wgrad_accumulate=False, tmp_full=None, wgrad=True, x_wg=None, premultiplied=False,

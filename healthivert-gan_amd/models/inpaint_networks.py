@@ -316,6 +316,7 @@ class _GenPlan:
 
 
 G_WGRAD_BLOCK = _os_.environ.get('HV_G_WGRAD_BLOCK', '1') != '0'     # A/B knob: see Generator.run_backward
+G_WGRAD_STREAMS = max(1, int(_os_.environ.get('HV_G_WGRAD_STREAMS', '1')))      # A/B knob: see Generator.run_backward
 
 
 class Generator(nn.Module):
@@ -502,12 +503,21 @@ class Generator(nn.Module):
         wg_block = G_WGRAD_BLOCK and not E.SERIAL and torch.cuda.current_stream().cuda_stream not in E.NO_FORK_STREAMS
         book.defer_wgrad = bool(wg_block)
         wg_side = E.named_stream('generator-wgrad-block', d_x_stage2.device) if wg_block else None
+        # HV_G_WGRAD_STREAMS = n > 1: the block's launches dealt round-robin to n side streams, each a first-level fork of the current stream (the generators'
+        # 3x3 weight gradients are bound by their split-K slab bytes: with fewer workgroups per launch -- HV_WGRAD_TR_WGS_SMALL -- several of them side by
+        # side would fill the chip with a fraction of the slabs)
+        wg_sides = [wg_side] + [E.named_stream('generator-wgrad-block-%d' % i, d_x_stage2.device) for i in range(1, G_WGRAD_STREAMS)] if wg_block else []
 
         def launch_block():
-            wg_side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(wg_side):
-                for launch in book.deferred:
+            cur = torch.cuda.current_stream()
+            for st in wg_sides:
+                st.wait_stream(cur)
+            for i, launch in enumerate(book.deferred):
+                with torch.cuda.stream(wg_sides[i % len(wg_sides)]):
                     launch()
+            for st in wg_sides:      # each side stream's last slab fold, on that stream (before the join)
+                with torch.cuda.stream(st):
+                    self.paramset().fold_chain().flush()
             book.deferred = []
         # ---- fine: heads
         self._head_backward(P, M[7], d_x_stage2, 'f17', prec, book)
@@ -541,6 +551,8 @@ class Generator(nn.Module):
             gp6 = book.twin(a['p6'])
             P.attn.backward(book.twin(a['ca']), gp6, book.mark(gp6), prec)
             E.conv_backward_chain(pm_rev if side is None else pm_rev[:-1], book, prec, stop_before=None if side is None else pm_rev[-1])
+            if side is not None:
+                self.paramset().fold_chain().flush()      # (weight gradients issued in line on the branch stream: their last slab fold, before the join)
         E.conv_backward_chain(list(reversed(P.f_nodes_conv)), book, prec, premultiplied_first=True)
         if side is not None:
             main.wait_stream(side)
@@ -581,8 +593,8 @@ class Generator(nn.Module):
                                     cg.fc_height.weight.grad, cg.fc_height.bias.grad, mul=(a['c10'], C[9].act) if pre10 else None)
         E.conv_backward_chain(list(reversed(C[:10])), book, prec, premultiplied_first=pre10)
         book.join()     # side-stream weight gradients
-        if wg_side is not None:
-            torch.cuda.current_stream().wait_stream(wg_side)
+        for st in wg_sides:
+            torch.cuda.current_stream().wait_stream(st)
         self.paramset().finish_backward(accumulate=False)
         self.paramset().attach_grads()
 

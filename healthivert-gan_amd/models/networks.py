@@ -247,6 +247,12 @@ class NLayerDiscriminator(nn.Module):
             self._pset = E.ParamSet(convs, extra)
         return self._pset
 
+    def load_state_dict(self, *args, **kwargs):
+        r = super().load_state_dict(*args, **kwargs)
+        if self._pset is not None:
+            self._pset.weights_changed()      # (copied into the same storage: the prepared weight tables are stale)
+        return r
+
     def _plan(self, B, H, W, device, slot=0):
         """slot 0 is the explicit executor's plan (Pix2PixModel's fused step); the nn.Module API takes one plan per forward whose
         autograd graph is still alive (slot 1, 2, ...): `pred_fake = D(fake); pred_real = D(real); loss.backward()` -- the
@@ -282,8 +288,8 @@ class NLayerDiscriminator(nn.Module):
         B, _, H, W = x.shape
         P = self._plan(B, H, W, x.device, slot)
         P.book.join()   # weight gradients of the previous backward still read this plan's activations on the side stream
-        if prep:
-            self.paramset().prep(x.device, power_iter=False)
+        if prep:      # prep='if_stale': skipped when the tables in memory were written from the current weights (the train step: engine.ParamSet.prep)
+            self.paramset().prep(x.device, power_iter=False, only_if_stale=(prep == 'if_stale'))
         xin = Act(x.view(B, H, W, 1))
         P.x_in = xin
         for li, ent in enumerate(P.layers):
@@ -321,8 +327,10 @@ class NLayerDiscriminator(nn.Module):
         if LOSS_HEAD and P.g_logits.f16 and P.g_logits.t.shape[-1] == 4 and P.g_logits.coff == 0:
             pl = last['p']
             want_db = param_grads and pl.bias is not None and last['node'].use_bias
-            ops.gan_loss(P.logits, target_is_real, mode, loss=loss, loss_weight=loss_weight, grad_weight=grad_weight, carrier=Act(P.g_logits.t, 4, 0),
-                         dbias=pl.bias.grad if want_db else None, dbias_accumulate=accumulate)
+            if not ops.gan_loss_pair(P.logits, target_is_real, loss, Act(P.g_logits.t, 4, 0), mode=mode, loss_weight=loss_weight, grad_weight=grad_weight,
+                                     dbias=pl.bias.grad if want_db else None, dbias_accumulate=accumulate):
+                ops.gan_loss(P.logits, target_is_real, mode, loss=loss, loss_weight=loss_weight, grad_weight=grad_weight, carrier=Act(P.g_logits.t, 4, 0),
+                             dbias=pl.bias.grad if want_db else None, dbias_accumulate=accumulate)
             return self.run_backward(P, None, need_dx=need_dx, param_grads=param_grads, accumulate=accumulate, logits_ready=True)
         if dz is None:
             dz = torch.empty_like(P.logits)
@@ -338,10 +346,13 @@ class NLayerDiscriminator(nn.Module):
         if LOSS_HEAD and P.g_logits.f16 and P.g_logits.t.shape[-1] == 4 and P.g_logits.coff == 0:
             pl = last['p']
             want_db = pl.bias is not None and last['node'].use_bias
-            for half, (real, loss) in enumerate(((False, loss_fake), (True, loss_real))):
-                sl = slice(half * B, (half + 1) * B)
-                ops.gan_loss(P.logits[sl], real, mode, loss=loss, grad_weight=grad_weight, carrier=Act(P.g_logits.t[sl], 4, 0),
-                             dbias=pl.bias.grad if want_db else None, dbias_accumulate=bool(half))
+            # both halves in one single-workgroup launch where they fit (four tiny dependent launches between forward and backward -> one)
+            if not ops.gan_loss_pair(P.logits[:B], False, loss_fake, Act(P.g_logits.t[:B], 4, 0), P.logits[B:], True, loss_real, Act(P.g_logits.t[B:], 4, 0),
+                                     mode=mode, grad_weight=grad_weight, dbias=pl.bias.grad if want_db else None):
+                for half, (real, loss) in enumerate(((False, loss_fake), (True, loss_real))):
+                    sl = slice(half * B, (half + 1) * B)
+                    ops.gan_loss(P.logits[sl], real, mode, loss=loss, grad_weight=grad_weight, carrier=Act(P.g_logits.t[sl], 4, 0),
+                                 dbias=pl.bias.grad if want_db else None, dbias_accumulate=bool(half))
             return self.run_backward(P, None, need_dx=False, param_grads=True, accumulate=False, logits_ready=True)
         if dz is None:
             dz = torch.empty_like(P.logits)

@@ -270,10 +270,10 @@ class Pix2PixModel(BaseModel):
                 n = ctypes.c_longlong(fake.numel())
                 L.call('hv_affine', ptr(x2[:B]), ptr(fake), n, ctypes.c_float(1.0), ctypes.c_float(0.0), stream())
                 L.call('hv_affine', ptr(x2[B:]), ptr(real), n, ctypes.c_float(1.0), ctypes.c_float(0.0), stream())
-            P = net.run_forward(x2, training=True, prep=True, groups=2)
+            P = net.run_forward(x2, training=True, prep='if_stale', groups=2)      # (step t + 1 finds the tables step t's generator part laid out after D_k's Adam step)
             net.loss_backward_halves(P, mode, lf, lr, 0.5 * self.grad_scale, dz=self._buf('dzz%d' % k, P.logits))
         else:
-            P = net.run_forward(fake, training=True, prep=True)
+            P = net.run_forward(fake, training=True, prep='if_stale')
             dz = self._buf('dz%d' % k, P.logits)
             ops.gan_loss(P.logits, False, mode, loss=lf, dz=dz, grad_weight=0.5 * self.grad_scale)
             net.run_backward(P, dz, need_dx=False, param_grads=True, accumulate=False)
@@ -290,7 +290,7 @@ class Pix2PixModel(BaseModel):
         the generator forward.  Gradients are assigned; BatchNorm running statistics use the swapped-order momentum."""
         net = getattr(self, 'netD_%d' % k)
         lr = self._loss_slot(2 * k + 1)
-        P = net.run_forward(real, training=True, prep=True, stat_order='swapped_first')
+        P = net.run_forward(real, training=True, prep='if_stale', stat_order='swapped_first')
         net.loss_backward(P, True, self.opt.gan_mode, lr, 0.5 * self.grad_scale, need_dx=False, param_grads=True, accumulate=False,
                           dz=self._buf('dz%d' % k, P.logits))
         setattr(self, 'loss_D_real_%d' % k, lr)
@@ -342,7 +342,12 @@ class Pix2PixModel(BaseModel):
             self._dxs[k] = net.loss_backward(P, True, self.opt.gan_mode, self._loss_slot(15 + k), self.grad_scale / 6.0, need_dx=True, param_grads=False,
                                              loss_weight=1.0 / 6.0, dz=dz)
         else:
-            ops.gan_loss(P.logits, True, self.opt.gan_mode, loss=self._loss_slot(15 + k), loss_weight=1.0 / 6.0, dz=dz, grad_weight=self.grad_scale / 6.0)
+            # (only the loss value is wanted; in the fp16 mode the single-launch head serves it -- its gradient goes to the plan's carrier, which nothing reads)
+            g = P.g_logits
+            if not (networks.LOSS_HEAD and g.f16 and g.t.shape[-1] == 4 and g.coff == 0 and
+                    ops.gan_loss_pair(P.logits, True, self._loss_slot(15 + k), ops.Act(g.t, 4, 0), mode=self.opt.gan_mode, loss_weight=1.0 / 6.0,
+                                      grad_weight=self.grad_scale / 6.0)):
+                ops.gan_loss(P.logits, True, self.opt.gan_mode, loss=self._loss_slot(15 + k), loss_weight=1.0 / 6.0, dz=dz, grad_weight=self.grad_scale / 6.0)
 
     def backward_G(self, d_done=False):
         L = _lib.get()
@@ -466,6 +471,7 @@ class Pix2PixModel(BaseModel):
         unchanged; under data parallelism the check runs on the reduced gradient, so every rank takes the same decision) and counted
         (overflow_steps()).  The scale itself is static (HV_GRAD_SCALE, a power of two; head room in DESIGN.md section 3)."""
         optimizer.step(sync_lr=False, guard_flat=net.paramset().flat_grad if self.grad_scale != 1.0 else None)
+        net.paramset().weights_changed()
 
     def overflow_steps(self):
         """{network: optimiser steps skipped by the overflow guard so far} (a host read)."""
@@ -644,6 +650,10 @@ class Pix2PixModel(BaseModel):
                     kept[sched] = (self._graphs, self._eager_steps)
                 for t, c in zip(state, snap):      # the same starting point for the next schedule, and for training
                     t.copy_(c)
+                for k in (1, 2, 3):      # the discriminators' prepared tables belong to the weights just overwritten, and the captured steps (rightly) no longer lay
+                    ps = getattr(self, 'netD_%d' % k).paramset()      # them out before the discriminator update: once, here, from the restored weights
+                    ps.weights_changed()
+                    ps.prep(self.device, False)
                 torch.cuda.synchronize(self.device)
         finally:
             self._in_preflight = False

@@ -268,13 +268,31 @@ def conv2d_stats_parts(*args, **kw):
     return conv2d(*args, _parts_only=True, **kw)
 
 
+class FoldChain:
+    """The split-K slab folds of consecutive weight gradients on ONE stream: a call leaves its slabs in one of two alternating scratch buffers and records
+    their fold (hv_wgrad_desc.pending); the next call takes the record along (hv_wgrad_desc.carry: the fold runs as extra workgroups of its kernel where
+    that kernel has room, else as a launch of its own); flush() launches the last one.  The owner flushes before anything reads the weight gradients."""
+    __slots__ = ('pending', 'slot', 'stream')
+
+    def __init__(self, stream_handle):
+        self.pending, self.slot, self.stream = None, 0, stream_handle
+
+    def flush(self):
+        if self.pending is not None:
+            assert torch.cuda.current_stream().cuda_stream == self.stream, 'FoldChain.flush() on another stream than its weight gradients'
+            f, self.pending = self.pending, None
+            _lib.get().call('hv_wgrad_fold_now', ctypes.byref(f), stream())
+
+
+FOLD_CHAIN = os.environ.get('HV_FOLD_CHAIN', '1') != '0'      # A/B knob: 0 = every weight gradient folds its slabs in a launch of its own right away
+
+
 def conv2d_wgrad(x, g, dw, k, stride=1, pad=0, dil=1, in_shift=0, accumulate=False, precision=None, cin=None, cout=None, dbias=None,
-                 dbias_accumulate=False, defer=None):
+                 dbias_accumulate=False, chain=None):
     """dw[Cout][k*k][Cin] = sum_pixels g (x) x.  x: conv input view, g: gradient wrt the conv output.
     dbias: optional [Cout] tensor that receives sum_pixels g (the bias gradient), computed by the same kernels.
-    defer: an object with `.slab_buffer(nbytes, device)` and `.defer_fold(record)` (engine.ConvParams / ParamSet): the split-K slabs stay in the
-    layer's own buffer and their fold is recorded instead of launched -- one hv_wgrad_fold_batched per network in front of its weight-gradient
-    finalisation (engine.ParamSet.finish_backward)."""
+    chain: a FoldChain of the current stream -- this call's slab fold is recorded on it (and done inside the next call of the chain or by chain.flush())
+    and the chain's previous fold is carried along."""
     L = _lib.get()
     d = L.hv_wgrad_desc()
     kh, kw = (k, k) if isinstance(k, int) else k
@@ -291,13 +309,20 @@ def conv2d_wgrad(x, g, dw, k, stride=1, pad=0, dil=1, in_shift=0, accumulate=Fal
     d.dbias_accumulate = int(dbias_accumulate)
     d.x_f16, d.g_f16 = x.f16, g.f16
     d.workspace, d.workspace_bytes = None, 0
+    if chain is not None and not FOLD_CHAIN:
+        chain = None
     need = L.size('hv_conv2d_wgrad_workspace_bytes', ctypes.byref(d))
     fold = None
-    if need and defer is not None:
-        b = defer.slab_buffer(need, x.t.device)
-        d.workspace, d.workspace_bytes = ptr(b).value, b.numel()
-        fold = L.hv_wgrad_fold()
-        d.pending = ctypes.pointer(fold)
+    if chain is not None:
+        assert torch.cuda.current_stream(x.t.device).cuda_stream == chain.stream, 'a FoldChain belongs to one stream'
+        if chain.pending is not None:
+            d.carry = ctypes.pointer(chain.pending)
+        if need:
+            b, _ = _ws(need, x.t.device, slot=('fold-chain', chain.slot))      # (the carried fold reads the OTHER buffer)
+            chain.slot ^= 1
+            d.workspace, d.workspace_bytes = ptr(b).value, b.numel()
+            fold = L.hv_wgrad_fold()
+            d.pending = ctypes.pointer(fold)
     elif need:
         b, _ = _ws(need, x.t.device)
         d.workspace, d.workspace_bytes = ptr(b).value, b.numel()
@@ -308,9 +333,8 @@ def conv2d_wgrad(x, g, dw, k, stride=1, pad=0, dil=1, in_shift=0, accumulate=Fal
                     lambda: L.call('hv_conv2d_wgrad', ctypes.byref(d), stream()), nbytes)
     else:
         L.call('hv_conv2d_wgrad', ctypes.byref(d), stream())
-    if fold is not None and fold.nslabs > 0:
-        defer.defer_fold(dict(slabs=fold.slabs, dw=fold.dw, numel=fold.numel, nslabs=fold.nslabs, accumulate=fold.accumulate, bias_slabs=fold.bias_slabs,
-                              dbias=fold.dbias, Cout=fold.Cout, dbias_accumulate=fold.dbias_accumulate))
+    if chain is not None:      # the carried fold is done (inside this call's kernel or beside it); this call's own is the chain's pending one now
+        chain.pending = fold if (fold is not None and fold.nslabs > 0) else None
     return dw
 
 
@@ -464,6 +488,24 @@ def gan_loss(z, target_is_real, mode='vanilla', loss=None, loss_weight=1.0, loss
         return
     L.call('hv_gan_loss', ptr(z), ctypes.c_longlong(n), int(bool(target_is_real)), m, ctypes.c_float(loss_weight),
            ptr(loss), int(loss_accumulate), ctypes.c_float(grad_weight), ptr(dz), stream())
+
+
+GAN_LOSS_PAIR = os.environ.get('HV_GAN_LOSS_PAIR', '1') != '0'   # A/B knob
+
+
+def gan_loss_pair(z0, real0, loss0, carrier0, z1=None, real1=True, loss1=None, carrier1=None, mode='vanilla', loss_weight=1.0, loss_accumulate=False,
+                  grad_weight=1.0, dbias=None, dbias_accumulate=False):
+    """The PatchGAN loss head of one or two logit ranges (the fake | real halves of a batched discriminator pass) in ONE single-workgroup launch
+    (hv_gan_loss_head_pair).  Returns False when the ranges are too large for it (the caller then takes gan_loss per range)."""
+    n0, n1 = z0.numel(), (0 if z1 is None else z1.numel())
+    if not GAN_LOSS_PAIR or n0 + n1 > 65536:
+        return False
+    for c, n in ((carrier0, n0), (carrier1, n1)):
+        assert c is None or (c.f16 and c.ld == 4 and c.coff == 0 and c.npix == n)
+    _lib.get().call('hv_gan_loss_head_pair', ptr(z0), ctypes.c_longlong(n0), int(bool(real0)), ptr(loss0), ptr(carrier0.t), ptr(z1), ctypes.c_longlong(n1),
+                    int(bool(real1)), ptr(loss1), None if carrier1 is None else ptr(carrier1.t), {'vanilla': 0, 'lsgan': 1}[mode], ctypes.c_float(loss_weight),
+                    int(loss_accumulate), ctypes.c_float(grad_weight), ptr(dbias), int(dbias_accumulate), stream())
+    return True
 
 
 def adam_step(table, max_numel, lr_dev, beta1, beta2, eps, step_dev, guard_flat=None):

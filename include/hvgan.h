@@ -133,7 +133,7 @@ int hv_conv2d_supported(const hv_conv_desc* d);            /* 1 when hv_conv2d w
                                                               shape -- x1, pool2, stats (hv_conv2d then returns HV_ERR_UNSUPPORTED and launches nothing) -- so a caller
                                                               asks before it drops the materialised alternative.  Runs the dispatch itself without launching */
 
-/* One deferred slab fold: dw[i] (+)= sum_k slabs[k * numel + i] in the fixed order k = 0 .. nslabs - 1 grouped by four, dbias likewise from bias_slabs
+/* One slab fold: dw[i] (+)= sum_k slabs[k * numel + i] in a fixed order (groups by slab count, then a tree: deterministic), dbias likewise from bias_slabs
  * [nslabs][Cout].  nslabs == 0: the call wrote dw directly (nothing to fold). */
 typedef struct {
     const float* slabs; float* dw; long long numel; int nslabs; int accumulate;
@@ -153,11 +153,15 @@ typedef struct {
     int x_f16, g_f16;                     /* storage of x / g as in hv_conv_desc (both 0 or both 1) */
     float* dbias; int dbias_accumulate;   /* optional: dbias[co] (+)= sum over pixels of g[.., co] (bias gradient of the same conv), folded
                                              into the kernel that already streams g; NULL = not computed */
-    hv_wgrad_fold* pending;               /* optional (HOST pointer): the split-K slabs are LEFT in `workspace` -- which then has to stay untouched until
-                                             hv_wgrad_fold_batched has run -- and *pending describes their fold; the call launches no slab reduction.  A whole
-                                             network's folds are then ONE launch in front of hv_weight_prep_backward.  NULL = fold here */
+    hv_wgrad_fold* pending;               /* optional (HOST pointer): the split-K slabs are LEFT in `workspace` -- which then has to stay untouched until their
+                                             fold has run -- and *pending describes that fold; the call launches no slab reduction.  The caller hands the record to
+                                             the NEXT weight gradient of the same stream as `carry` (or to hv_wgrad_fold_now).  NULL = fold here */
+    const hv_wgrad_fold* carry;           /* optional (HOST pointer): the PREVIOUS weight gradient's recorded fold (another dw, another workspace): it runs as extra
+                                             workgroups of this call's main kernel where that kernel leaves room for them (the generators' 3x3 / 5x5 layers),
+                                             else as a launch of its own; either way it is done when this call's work is.  Same sums bit for bit as a fold
+                                             launched on its own.  One dependent ~5-us launch less per layer of a backward chain */
 } hv_wgrad_desc;
-int hv_wgrad_fold_batched(const hv_wgrad_fold* d_folds /* device array */, int n, long long max_numel, void* stream);
+int hv_wgrad_fold_now(const hv_wgrad_fold* fold /* host */, void* stream);     /* the fold of a `pending` record as a launch of its own (the last of a chain) */
 size_t hv_conv2d_wgrad_workspace_bytes(const hv_wgrad_desc* d);
 int hv_conv2d_wgrad(const hv_wgrad_desc* d, void* stream);
 
@@ -398,6 +402,13 @@ int hv_gan_loss_ws(const float* z, long long n, int target_is_real, int mode, fl
 size_t hv_gan_loss_head_workspace_bytes(long long n);
 int hv_gan_loss_head(const float* z, long long n, int target_is_real, int mode, float loss_weight, float* loss, int loss_accumulate, float grad_weight,
                      float* dz, void* carrier_f16, float* dbias, int dbias_accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The same head for up to TWO logit ranges in ONE launch of one workgroup (the fake | real halves of a batched discriminator pass, models/pix2pix_model.py:272-283:
+ * criterionGAN(pred_fake, False), criterionGAN(pred_real, True); or one range with n1 = 0): per range its own target and loss slot, the carrier written in place,
+ * dbias[0] (+)= the sum of both ranges' stored gradients (range 0 first).  Each range's mean is over its own n.  Four tiny dependent launches between a
+ * discriminator's forward and backward become one.  n0 + n1 <= 65 536, else HV_ERR_UNSUPPORTED (callers then use hv_gan_loss_head per range). */
+int hv_gan_loss_head_pair(const float* z0, long long n0, int real0, float* loss0, void* carrier0_f16, const float* z1, long long n1, int real1, float* loss1,
+                          void* carrier1_f16, int mode, float loss_weight, int loss_accumulate, float grad_weight, float* dbias, int dbias_accumulate, void* stream);
 
 /* Generator losses and their gradient seeds (models/pix2pix_model.py:331-353): writes
  * losses[0..5] = {G_maskL1, G_Dice, coarse_Dice, edge, h, sum of those five} and the seeds
