@@ -493,18 +493,33 @@ def gan_loss(z, target_is_real, mode='vanilla', loss=None, loss_weight=1.0, loss
 GAN_LOSS_PAIR = os.environ.get('HV_GAN_LOSS_PAIR', '1') != '0'   # A/B knob
 
 
+_TICKETS = {}
+
+
+def _ticket(device):
+    """One zero-initialised counter per (device, stream) for the kernels whose last workgroup folds their partial results (they leave it at zero)."""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    t = _TICKETS.get(key)
+    if t is None:
+        t = _TICKETS[key] = torch.zeros(16, dtype=torch.int32, device=device)
+    return t
+
+
 def gan_loss_pair(z0, real0, loss0, carrier0, z1=None, real1=True, loss1=None, carrier1=None, mode='vanilla', loss_weight=1.0, loss_accumulate=False,
                   grad_weight=1.0, dbias=None, dbias_accumulate=False):
-    """The PatchGAN loss head of one or two logit ranges (the fake | real halves of a batched discriminator pass) in ONE single-workgroup launch
-    (hv_gan_loss_head_pair).  Returns False when the ranges are too large for it (the caller then takes gan_loss per range)."""
-    n0, n1 = z0.numel(), (0 if z1 is None else z1.numel())
-    if not GAN_LOSS_PAIR or n0 + n1 > 65536:
+    """The PatchGAN loss head of one or two logit ranges (the fake | real halves of a batched discriminator pass) in ONE launch (hv_gan_loss_head_pair: the
+    last workgroup folds the block sums).  Returns False when switched off (the caller then takes gan_loss per range)."""
+    if not GAN_LOSS_PAIR:
         return False
+    n0, n1 = z0.numel(), (0 if z1 is None else z1.numel())
     for c, n in ((carrier0, n0), (carrier1, n1)):
         assert c is None or (c.f16 and c.ld == 4 and c.coff == 0 and c.npix == n)
-    _lib.get().call('hv_gan_loss_head_pair', ptr(z0), ctypes.c_longlong(n0), int(bool(real0)), ptr(loss0), ptr(carrier0.t), ptr(z1), ctypes.c_longlong(n1),
-                    int(bool(real1)), ptr(loss1), None if carrier1 is None else ptr(carrier1.t), {'vanilla': 0, 'lsgan': 1}[mode], ctypes.c_float(loss_weight),
-                    int(loss_accumulate), ctypes.c_float(grad_weight), ptr(dbias), int(dbias_accumulate), stream())
+    L = _lib.get()
+    b, nb = _ws(L.size('hv_gan_loss_head_pair_workspace_bytes', ctypes.c_longlong(n0), ctypes.c_longlong(n1)), z0.device, slot=2)
+    L.call('hv_gan_loss_head_pair', ptr(z0), ctypes.c_longlong(n0), int(bool(real0)), ptr(loss0), ptr(carrier0.t), ptr(z1), ctypes.c_longlong(n1),
+           int(bool(real1)), ptr(loss1), None if carrier1 is None else ptr(carrier1.t), {'vanilla': 0, 'lsgan': 1}[mode], ctypes.c_float(loss_weight),
+           int(loss_accumulate), ctypes.c_float(grad_weight), ptr(dbias), int(dbias_accumulate), ptr(b), nb,
+           ptr(_ticket(z0.device)), stream())
     return True
 
 

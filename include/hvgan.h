@@ -403,12 +403,16 @@ size_t hv_gan_loss_head_workspace_bytes(long long n);
 int hv_gan_loss_head(const float* z, long long n, int target_is_real, int mode, float loss_weight, float* loss, int loss_accumulate, float grad_weight,
                      float* dz, void* carrier_f16, float* dbias, int dbias_accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
-/* The same head for up to TWO logit ranges in ONE launch of one workgroup (the fake | real halves of a batched discriminator pass, models/pix2pix_model.py:272-283:
+/* The same head for up to TWO logit ranges in ONE launch (the fake | real halves of a batched discriminator pass, models/pix2pix_model.py:272-283:
  * criterionGAN(pred_fake, False), criterionGAN(pred_real, True); or one range with n1 = 0): per range its own target and loss slot, the carrier written in place,
- * dbias[0] (+)= the sum of both ranges' stored gradients (range 0 first).  Each range's mean is over its own n.  Four tiny dependent launches between a
- * discriminator's forward and backward become one.  n0 + n1 <= 65 536, else HV_ERR_UNSUPPORTED (callers then use hv_gan_loss_head per range). */
+ * dbias[0] (+)= the sum of both ranges' stored gradients (range 0 first).  Each range's mean is over its own n.  The workgroup that finishes last folds the block
+ * sums in block order (deterministic): four tiny dependent launches between a discriminator's forward and backward become one.
+ * workspace: hv_gan_loss_head_pair_workspace_bytes(n0, n1) bytes of scratch; ticket: ONE zero-initialised unsigned that stays with the call site (the kernel
+ * leaves it at zero; launches that share it must be ordered on one stream). */
+size_t hv_gan_loss_head_pair_workspace_bytes(long long n0, long long n1);
 int hv_gan_loss_head_pair(const float* z0, long long n0, int real0, float* loss0, void* carrier0_f16, const float* z1, long long n1, int real1, float* loss1,
-                          void* carrier1_f16, int mode, float loss_weight, int loss_accumulate, float grad_weight, float* dbias, int dbias_accumulate, void* stream);
+                          void* carrier1_f16, int mode, float loss_weight, int loss_accumulate, float grad_weight, float* dbias, int dbias_accumulate,
+                          void* workspace, size_t workspace_bytes, unsigned* ticket, void* stream);
 
 /* Generator losses and their gradient seeds (models/pix2pix_model.py:331-353): writes
  * losses[0..5] = {G_maskL1, G_Dice, coarse_Dice, edge, h, sum of those five} and the seeds
