@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 GFLOP_PER_SLICE = 195.9          # SURVEY.md section 8d / BASELINE.md section 2: whole train step, per slice
 GFLOP_FINE_FWD = 10.23           # FineGenerator forward per slice, the north-star's MFMA gate
 GFLOP_G_FWD = 17.56              # whole Generator forward per slice
+MB_FINE_FWD = 48.9               # FineGenerator forward per slice: compulsory bytes of its convolutions at fp16 storage, unfused
 MFMA_PEAK_TFLOPS = {'fp16': 2500.0, 'fp32': 157.3}   # MI355X dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -511,6 +512,8 @@ def main():
             tf = GFLOP_FINE_FWD * args.batch * (args.size / 256.0) ** 2 / fms
             out['fine_generator_forward'] = {'ms': round(fms, 3), 'gflop': round(GFLOP_FINE_FWD * args.batch * (args.size / 256.0) ** 2, 1),
                                              'tflops': round(tf, 1), 'frac_of_mfma_peak': round(tf / MFMA_PEAK_TFLOPS[args.precision], 4),
+                                             'algorithmic_mb': round(MB_FINE_FWD * args.batch * (args.size / 256.0) ** 2 * (1 if args.precision == 'fp16' else 2), 1),
+                                             'frac_of_hbm_peak': round(MB_FINE_FWD * args.batch * (args.size / 256.0) ** 2 * (1 if args.precision == 'fp16' else 2) / 1e3 / fms / profiler.HBM_PEAK_GBS * 1e3, 4),
                                              'timed_in': 'the same eager single-stream steps: HIP events around FineGenerator (training forward, '
                                                          'both branches + contextual attention in line), mean of %d' % len(fine)}
         if fine2:
@@ -521,6 +524,7 @@ def main():
         if fine_graph and 'fine_generator_forward' in out:
             tfg = GFLOP_FINE_FWD * args.batch * (args.size / 256.0) ** 2 / fine_graph
             out['fine_generator_forward']['graph_replay'] = {'ms': round(fine_graph, 3), 'tflops': round(tfg, 1), 'frac_of_mfma_peak': round(tfg / MFMA_PEAK_TFLOPS[args.precision], 4),
+                                                             'frac_of_hbm_peak': round(MB_FINE_FWD * args.batch * (args.size / 256.0) ** 2 / 1e3 / fine_graph / profiler.HBM_PEAK_GBS * 1e3, 4),
                                                              'timed_in': 'the refinement generator\'s training forward alone as one captured hipGraph (two branch streams), mean of 50 back-to-back replays, GPU otherwise idle'}
         ngraphs = len(model._graphs or ())
         out['config']['launch'] = ('hipGraph replay (%d graphs/step)' % ngraphs if model.use_graph else 'eager') + \

@@ -495,6 +495,45 @@ def test_batchnorm_backward_sums_from_the_data_gradient_epilogue(groups, monkeyp
 
 
 @pytest.mark.parametrize('size', [64, 128])
+def test_attention_on_the_gram_route_against_the_cpu_oracle(size, monkeypatch):
+    """The benchmarked attention route (fp16 mode: Gram-matrix scores, LDS-DMA batched GEMMs, fp16 attention matrix) against the ORACLE -- oracle.restate.
+    contextual_attention, the CPU restatement pinned by fixture G2 -- at the shapes the fixture cannot reach: a 64-channel map of 64 x 64 (w = 32: the 256 x 256
+    configuration) and 128 x 128 (w = 64, L = 4096: BASELINE config #5's slice size), two samples with DIFFERENT masks (sample 0's mask rules, reference
+    models/inpaint_networks.py:314), output and input gradient.  fp16-mode gates of the G2 test."""
+    from hvgan import engine, ops
+    from oracle import restate as R
+    monkeypatch.setenv('HV_PRECISION', 'fp16')
+    dev = torch.device('cuda:0')
+    B, C, H = 2, 64, size
+    gen = torch.Generator().manual_seed(23)
+    f = (torch.randn(B, C, H, H, generator=gen) * 0.5).half().float()          # (operands exactly representable in fp16: both sides see the same values)
+    mask = torch.zeros(B, 1, 4 * H, 4 * H)
+    mask[0, :, 4 * H // 3:4 * H // 3 + 40, :] = 1
+    mask[1, :, :, 4 * H // 2:4 * H // 2 + 64] = 1
+    coef = (torch.randn(B, C, H, H, generator=gen) * 0.05).half().float()
+    # ---- oracle (CPU, fp32)
+    torch.set_num_threads(max(1, min(32, (os.cpu_count() or 8))))
+    fr = f.clone().requires_grad_(True)
+    yr = R.contextual_attention(fr, fr, mask)
+    (yr * coef).sum().backward()
+    # ---- device
+    plan = engine.AttentionPlan(B, H, H, C, dev, (4 * H, 4 * H))
+    fa = ops.Act(f.permute(0, 2, 3, 1).contiguous().to(dev).half())
+    out = ops.Act(torch.zeros(B, H, H, C, dtype=torch.float16, device=dev))
+    plan.forward(fa, mask.to(dev), out, 'fp16')
+    assert plan.gemm and plan.gram
+    df = ops.Act(torch.zeros(B, H, H, C, dtype=torch.float16, device=dev))
+    plan.backward(ops.Act(coef.permute(0, 2, 3, 1).contiguous().to(dev).half()), df, False, 'fp16')
+    torch.cuda.synchronize()
+    y = out.t.float().cpu().permute(0, 3, 1, 2)
+    g = df.t.float().cpu().permute(0, 3, 1, 2)
+    ys, gs = max(1.0, yr.abs().max().item()), max(1e-6, fr.grad.abs().max().item())
+    assert _err(y, yr.detach()) <= 2e-2 * ys, (_err(y, yr.detach()), ys)
+    rel = (g - fr.grad).norm().item() / fr.grad.norm().item()
+    assert fr.grad.abs().max().item() > 0 and _err(g, fr.grad) <= 4e-2 * gs and rel <= 4e-2, (_err(g, fr.grad), gs, rel)
+
+
+@pytest.mark.parametrize('size', [64, 128])
 def test_attention_scores_on_the_pixel_gram_matrix_match_the_patch_table_route(size, monkeypatch):
     """fp16 mode, 64-channel map (the fine generator's attention input at 256 x 256 / 512 x 512 images: a 32- / 64-wide attention map): the matching scores
     and their gradient computed on the pixel Gram matrix (hv_ca_gram_scores: K = C per score, no patch tables; hv_ca_gram_backward: d fd = box(Gs) fd + the
