@@ -1,19 +1,17 @@
-"""What does one dependent kernel node cost inside a replayed hipGraph on this runtime?  Chains of N tiny kernels (hv_affine over 1 K floats: ~2 us of work)
-captured (a) on one stream, (b) ping-ponging between two streams (every node joins across streams), (c) as two independent chains on two streams.
-    python tools/graph_node_latency.py [N=200]"""
+"""What does a kernel node cost inside a replayed hipGraph on this runtime, and what do parallel branches cost?  N kernels per branch (hv_affine over n floats),
+1 / 2 / 3 independent branches forked from the capture stream and joined at the end; ideal = the time of ONE branch when the kernels are small enough to
+run side by side.     python tools/graph_node_latency.py [N=100]"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import hvgan  # noqa: F401
 from hvgan import lib
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 dev = torch.device('cuda:0')
-x = torch.zeros(1024, device=dev)
-y = torch.zeros(1024, device=dev)
 L = lib.get()
 def k(t):
     L.call('hv_affine', lib.ptr(t), lib.ptr(t), ctypes.c_longlong(t.numel()), ctypes.c_float(1.0), ctypes.c_float(0.0), lib.stream())
-def timeit(g, reps=20):
+def timeit(g, reps=10):
     g.replay(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -21,44 +19,58 @@ def timeit(g, reps=20):
         g.replay()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
-k(x); torch.cuda.synchronize()
 cap = torch.cuda.Stream()
-side = torch.cuda.Stream()
-g1 = torch.cuda.CUDAGraph()
-with torch.cuda.graph(g1, stream=cap):
-    for _ in range(N):
-        k(x)
-t1 = timeit(g1)
-g2 = torch.cuda.CUDAGraph()
-with torch.cuda.graph(g2, stream=cap):
-    cur = torch.cuda.current_stream()
-    for i in range(N):
-        if i & 1:
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                k(x)
-            cur.wait_stream(side)
-        else:
-            k(x)
-t2 = timeit(g2)
-g3 = torch.cuda.CUDAGraph()
-with torch.cuda.graph(g3, stream=cap):
-    cur = torch.cuda.current_stream()
-    side.wait_stream(cur)
-    with torch.cuda.stream(side):
-        for _ in range(N):
-            k(y)
-    for _ in range(N):
-        k(x)
-    cur.wait_stream(side)
-t3 = timeit(g3)
-# eager chain for comparison
-torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(N):
-    k(x)
-e1.record(); torch.cuda.synchronize()
-te = e0.elapsed_time(e1) * 1e3
-print('graph replay, %d tiny dependent kernels: one stream %.2f us/node; alternating two streams %.2f us/node; two independent chains of %d: %.2f us per node pair; eager one stream %.2f us/launch'
-      % (N, t1 / N, t2 / N, N, t3 / N, te / N))
+sides = [torch.cuda.Stream() for _ in range(3)]
+for n in (1024, 1 << 20, 1 << 23):
+    bufs = [torch.zeros(n, device=dev) for _ in range(3)]
+    k(bufs[0]); torch.cuda.synchronize()
+    res = []
+    for nb in (1, 2, 3):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=cap):
+            cur = torch.cuda.current_stream()
+            for b in range(1, nb):
+                sides[b].wait_stream(cur)
+                with torch.cuda.stream(sides[b]):
+                    for _ in range(N):
+                        k(bufs[b])
+            for _ in range(N):
+                k(bufs[0])
+            for b in range(1, nb):
+                cur.wait_stream(sides[b])
+        res.append(timeit(g))
+    print('n = %8d floats, %d kernels per branch: 1 branch %.1f us (%.2f per kernel), 2 branches %.1f us (%.2fx), 3 branches %.1f us (%.2fx)'
+          % (n, N, res[0], res[0] / N, res[1], res[1] / res[0], res[2], res[2] / res[0]))
+
+# ---- the alternative to branches inside one graph: one chain graph per stream, launched side by side
+for n in (1024, 1 << 20, 1 << 23):
+    bufs = [torch.zeros(n, device=dev) for _ in range(3)]
+    graphs = []
+    for b in range(3):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=sides[b]):
+            for _ in range(N):
+                k(bufs[b])
+        graphs.append(g)
+    def run(nb):
+        main = torch.cuda.current_stream()
+        ev = torch.cuda.Event(); ev.record(main)
+        evs = []
+        for b in range(nb):
+            sides[b].wait_event(ev)
+            with torch.cuda.stream(sides[b]):
+                graphs[b].replay()
+                e = torch.cuda.Event(); e.record(sides[b]); evs.append(e)
+        for e in evs:
+            main.wait_event(e)
+    res = []
+    for nb in (1, 2, 3):
+        run(nb); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            run(nb)
+        e1.record(); torch.cuda.synchronize()
+        res.append(e0.elapsed_time(e1) / 10 * 1e3)
+    print('n = %8d floats, one chain graph of %d kernels per stream: 1 stream %.1f us, 2 streams %.1f us (%.2fx), 3 streams %.1f us (%.2fx)'
+          % (n, N, res[0], res[1], res[1] / res[0], res[2], res[2] / res[0]))
