@@ -449,8 +449,9 @@ def main():
         'regions_ms_per_step': [round(r / args.steps * 1e3, 3) for r in region_dt],
         # what the collective layer actually saw (an N-GPU record must show N ranks behind RCCL)
         'comm': {'backend': (dist.get_backend() if dist.is_initialized() else None), 'world_size': (dist.get_world_size() if dist.is_initialized() else 1),
-                 'grad_exchange': (('flat all-reduce (ncclAvg) per network in the order D_1, D_2, D_3, G on ONE exchange branch captured inside the step graph: D_k\'s beside the other discriminators\' passes, G\'s before its Adam step'
-                                    if getattr(model, '_inline_exchange', False) else 'flat all-reduce (mean) between the step\'s three graphs on the exchange stream')
+                 'grad_exchange': (({'captured': 'two ncclAllReduce (ncclAvg) captured inside the step graph on its main branch: the three discriminators\' gradient arena where their streams join, G\'s before its Adam step',
+                                     'overlapped': 'flat all-reduce (ncclAvg) per network captured inside the step graph, chained D_1 -> D_2 -> D_3 -> G by events: D_k\'s beside the other discriminators\' passes, G\'s before its Adam step'}
+                                    .get(model.dp_schedule, '?') if getattr(model, '_inline_exchange', False) else 'flat all-reduce (mean) between the step\'s three graphs on the exchange stream')
                                    if model.grad_sync.active() else 'none (single rank)'),
                  'transport': (('RCCL through our own communicator (ddp.RcclComm)' if model.grad_sync.capturable() else 'torch.distributed (%s)' % dist.get_backend())
                                if model.grad_sync.active() else None),

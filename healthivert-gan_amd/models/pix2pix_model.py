@@ -114,21 +114,23 @@ class Pix2PixModel(BaseModel):
         # the three phases are captured as ONE graph (7.81 -> 7.70 ms over four same-box pairs: two graph-launch boundaries less) -- except under the cut
         # data-parallel schedule, which issues its collectives between the graphs
         # data-parallel step schedule (one process per GPU); every collective of the step goes to one communicator on one stream in the order D_1, D_2, D_3, G:
-        #   'captured' (RCCL only): the single-process step AS IT IS, with the gradient means INSIDE its one hipGraph as an exchange branch -- the branch waits for
-        #       D_k's stream where D_k's gradients are final, averages them (ncclAllReduce, ncclAvg, ddp.RcclComm) beside the other discriminators' passes, and
-        #       only D_k's Adam step waits for it; the generator's mean sits between its backward and its Adam step on the same branch: no graph cut, no
-        #       host in the loop.
+        #   'captured' (RCCL only): the step as ONE hipGraph with the two collectives inside it, both on the main branch (ncclAllReduce, ncclAvg, ddp.RcclComm): the
+        #       three discriminators' gradients -- one arena -- where their streams join, the generator's between its backward and its Adam step.  No graph
+        #       cut, no host in the loop, no edge between branches, the order D, G on every rank by construction.
         #   'graphs': the step cut into its three graphs where the exchanges belong, the same collectives issued eagerly between them on the exchange stream
         #       (the main stream waits for each).  The fallback for runtimes that refuse to capture RCCL kernels, and the only schedule for gloo.
-        #   'auto' (default): gloo -> 'graphs'; RCCL -> dp_preflight() runs BOTH on the job's first batch, checks that every rank ends with the same
-        #       weights, keeps the faster correct one and puts the weights back (the preflight steps are not training steps).
+        #   'overlapped' (RCCL only): 'captured' with one collective per discriminator, issued the moment D_k's gradients are final and chained D_1 -> D_2 ->
+        #       D_3 -> G by events (ddp.GradSync.reduce_branch): D_k's mean runs beside the other discriminators' passes, at the price of edges between the
+        #       graph's branches (this runtime executes branch-crossing edges poorly: +0.3 ms in a one-rank group where 'captured' costs nothing).
+        #   'auto' (default): gloo -> 'graphs'; RCCL -> dp_preflight() runs ALL on the job's first batch, checks that every rank ends with the same
+        #       weights, keeps the fastest correct one and puts the weights back (the preflight steps are not training steps).
         self.dp_schedule = _os.environ.get('HV_DP_SCHEDULE', 'auto')
         if self.dp_schedule == 'phases':      # (the twelve-phase schedule of rounds 1-3 is gone; old launch scripts keep working)
             import warnings
             warnings.warn("HV_DP_SCHEDULE=phases is deprecated: taking 'graphs'", DeprecationWarning)
             self.dp_schedule = 'graphs'
-        if self.dp_schedule not in ('auto', 'captured', 'graphs'):
-            raise ValueError("HV_DP_SCHEDULE must be 'auto', 'captured' or 'graphs'")
+        if self.dp_schedule not in ('auto', 'captured', 'overlapped', 'graphs'):
+            raise ValueError("HV_DP_SCHEDULE must be 'auto', 'captured', 'overlapped' or 'graphs'")
         self.dp_preflight_record = None
         self._in_preflight = False
         self.real_first = _os.environ.get('HV_REAL_FIRST', '1') != '0'   # D real passes overlap the generator forward
@@ -439,10 +441,14 @@ class Pix2PixModel(BaseModel):
                     self.set_requires_grad(getattr(self, 'netD_%d' % k), True)
                     getattr(self, 'optimizer_D_%d' % k).zero_grad()
                     bw()
-                if self._inline_exchange:       # D_k's mean over the ranks on the exchange branch: beside the other discriminators' passes
+                if self._inline_exchange and self.dp_schedule == 'overlapped':       # D_k's mean over the ranks, beside the other discriminators' passes
                     self.grad_sync.reduce_branch(getattr(self, 'netD_%d' % k).paramset().flat_grad)
         if not self._through_ab:
             self._join_d(main)
+        if self._inline_exchange and self.dp_schedule != 'overlapped':      # 'captured': the three discriminators' gradients as ONE collective where their streams join
+            arena = getattr(self, '_d_grad_arena', None)
+            for f in ([arena] if arena is not None else [getattr(self, 'netD_%d' % k).paramset().flat_grad for k in (1, 2, 3)]):
+                self.grad_sync.reduce_branch(f)
 
     def _phase_b(self):
         """D_k optimiser step, D_k forward on the fakes with the updated weights (its own stream), generator losses and
@@ -604,7 +610,7 @@ class Pix2PixModel(BaseModel):
         kept = {}
         self._in_preflight = True
         try:
-            for sched in ('captured', 'graphs'):
+            for sched in ('graphs', 'captured', 'overlapped'):      # (the plain one first: its captured graphs are kept whatever the later trials do)
                 where['at'] = sched
                 r = {'ok': False, 'error': None, 'ms_per_step': None, 'weights_identical_across_ranks': None}
                 rec['schedules'][sched] = r
@@ -658,14 +664,17 @@ class Pix2PixModel(BaseModel):
         finally:
             self._in_preflight = False
             timer.cancel()
-        good = [k for k in ('captured', 'graphs') if rec['schedules'][k]['ok']]
+        good = [k for k in ('graphs', 'captured', 'overlapped') if rec['schedules'][k]['ok']]
         if not good:
             raise RuntimeError('data-parallel preflight: no schedule ran correctly on %d rank(s): %r' % (world, rec['schedules']))
         best = min(good, key=lambda k: rec['schedules'][k]['ms_per_step'])
+        for pref in ('captured', 'overlapped'):      # (within a percent of the fastest: no graph cut / the collectives beside compute)
+            if pref in good and rec['schedules'][pref]['ms_per_step'] <= 1.01 * rec['schedules'][best]['ms_per_step']:
+                best = pref
         rec['chosen'] = best
         self.dp_schedule = best
         self._graphs, self._eager_steps = kept[best]
-        self.dp_capture_error = rec['schedules']['captured']['error'] if best != 'captured' else None
+        self.dp_capture_error = next((rec['schedules'][k]['error'] for k in ('captured', 'overlapped') if rec['schedules'][k]['error']), None)
         if dist.get_rank() == 0:
             print('data-parallel preflight (%d rank(s)): %s -> %s' % (world, {k: (v['ms_per_step'], v['error']) for k, v in rec['schedules'].items()}, best), flush=True)
 
@@ -674,7 +683,7 @@ class Pix2PixModel(BaseModel):
             o.sync_lr()
         graphable = self.use_graph and ops.timer() is None
         dp = self.grad_sync.active()
-        inline = dp and self.dp_schedule == 'captured' and self.grad_sync.capturable()
+        inline = dp and self.dp_schedule in ('captured', 'overlapped') and self.grad_sync.capturable()
         self._inline_exchange = inline
         cut = dp and not inline            # the means sit BETWEEN the step's graphs (exchange stream, issued eagerly)
         if dp and self._eager_steps == 0 and self._graphs is None:
@@ -770,7 +779,7 @@ class Pix2PixModel(BaseModel):
             # one graph: D_k goes from its backward straight on to its Adam step and its pass for the generator on its own stream -- no join of the three
             # discriminator streams between the phases (that join only exists for the cut schedule's exchange): a discriminator that is done early
             # (D_3 reads the 128 x 128 crop) does not wait for the others
-            self._through_ab = self.concurrent_d and not engine.SERIAL
+            self._through_ab = self.concurrent_d and not engine.SERIAL and not (self._inline_exchange and self.dp_schedule == 'captured')
             try:
                 self._phase_a(); self._phase_b(); self._phase_c()
             finally:

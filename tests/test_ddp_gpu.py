@@ -260,10 +260,10 @@ assert model._graphs is not None
 if sys.argv[2] == '1':
     if sys.argv[4] == 'auto':          # the preflight ran both schedules, both correct, kept one, and put the weights back (checked by the caller: bit-identity)
         rec = model.dp_preflight_record
-        assert rec and rec['chosen'] == model.dp_schedule and model.dp_schedule in ('captured', 'graphs'), rec
+        assert rec and rec['chosen'] == model.dp_schedule and model.dp_schedule in ('captured', 'overlapped', 'graphs') and len(rec['schedules']) == 3, rec
         assert all(r['ok'] and r['weights_identical_across_ranks'] and r['error'] is None and r['ms_per_step'] > 0 for r in rec['schedules'].values()), rec
-        assert len(model._graphs) == (1 if model.dp_schedule == 'captured' else 3)
-    elif sys.argv[4] == 'captured':      # the collectives are INSIDE the one step graph
+        assert len(model._graphs) == (3 if model.dp_schedule == 'graphs' else 1)
+    elif sys.argv[4] in ('captured', 'overlapped'):      # the collectives are INSIDE the one step graph
         assert len(model._graphs) == 1 and model._inline_exchange and getattr(model, 'dp_capture_error', None) is None, (len(model._graphs), getattr(model, 'dp_capture_error', None))
     else:
         assert len(model._graphs) == 3 and not model._inline_exchange
@@ -281,15 +281,16 @@ print('ok')
 '''
 
 
-@pytest.mark.parametrize('schedule,precision', [('captured', 'fp16'), ('captured', 'fp32'), ('graphs', 'fp32'), ('auto', 'fp16')])
+@pytest.mark.parametrize('schedule,precision', [('captured', 'fp16'), ('captured', 'fp32'), ('overlapped', 'fp16'), ('graphs', 'fp32'), ('auto', 'fp16')])
 def test_rccl_exchange_path_single_rank(tmp_path, schedule, precision):
     """The gradient exchange exactly as a multi-GPU job issues it -- ncclAllReduce (ncclAvg) of the flat gradient buffers through a communicator of our own
-    (ddp.RcclComm) on the exchange stream, in the order D_1, D_2, D_3, G: between the step's three graphs (HV_DP_SCHEDULE=graphs), or as ONE exchange branch
-    CAPTURED INSIDE the step's one hipGraph (captured: D_k's mean beside the other discriminators' passes, G's before its Adam step) -- plus broadcast, barrier and
+    (ddp.RcclComm): between the step's three graphs (HV_DP_SCHEDULE=graphs), CAPTURED INSIDE the step's one hipGraph on its main branch (captured: the three
+    discriminators' arena where their streams join, G's before its Adam step), or captured per discriminator and chained D_1 -> D_2 -> D_3 -> G by events
+    (overlapped: D_k's mean beside the other discriminators' passes) -- plus broadcast, barrier and
     the MAX-reduce of the bench clock, in a one-rank RCCL group: averaging over one rank is the identity, so the weights after five steps must equal those of a
     run without a process group, bit for bit.  'auto' (the default of a multi-GPU job) first runs the PREFLIGHT -- both schedules, 2 x 10 steps, cross-rank
     checks -- which must leave the weights, running statistics and Adam state exactly as it found them: the same bit-identity after the five steps."""
-    port = str(29700 + os.getpid() % 1000 + {'graphs': 1000, 'auto': 2000}.get(schedule, 0) + (500 if precision == 'fp16' else 0))
+    port = str(29700 + os.getpid() % 1000 + {'graphs': 1000, 'auto': 2000, 'overlapped': 3000}.get(schedule, 0) + (500 if precision == 'fp16' else 0))
     outs = []
     for force in ('1', '0'):
         dst = str(tmp_path / ('w%s.pt' % force))
