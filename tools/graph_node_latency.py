@@ -74,3 +74,29 @@ for n in (1024, 1 << 20, 1 << 23):
         res.append(e0.elapsed_time(e1) / 10 * 1e3)
     print('n = %8d floats, one chain graph of %d kernels per stream: 1 stream %.1f us, 2 streams %.1f us (%.2fx), 3 streams %.1f us (%.2fx)'
           % (n, N, res[0], res[1], res[1] / res[0], res[2], res[2] / res[0]))
+
+# ---- is a branchy region executed level by level?  branch A: 100 tiny kernels; branch B: ONE long kernel (hv_affine over 64 M floats, ~400 us)
+big = torch.zeros(1 << 26, device=dev)
+small = torch.zeros(1024, device=dev)
+k(big); torch.cuda.synchronize()
+cap_stream = torch.cuda.Stream()
+def only_a():
+    for _ in range(N): k(small)
+def only_b():
+    k(big)
+def both(first_long):
+    cur = torch.cuda.current_stream()
+    sides[1].wait_stream(cur)
+    with torch.cuda.stream(sides[1]):
+        if first_long: k(big)
+        else:
+            for _ in range(N): k(small)
+    if first_long:
+        for _ in range(N): k(small)
+    else: k(big)
+    cur.wait_stream(sides[1])
+for name, fn in (('100 tiny alone', only_a), ('1 long alone', only_b), ('long on the side branch, tiny on the main branch', lambda: both(True)), ('tiny on the side branch, long on the main branch', lambda: both(False))):
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=cap_stream):
+        fn()
+    print('%-52s %.1f us' % (name, timeit(g)))
