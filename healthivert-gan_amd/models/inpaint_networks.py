@@ -317,6 +317,7 @@ class _GenPlan:
 
 G_WGRAD_BLOCK = _os_.environ.get('HV_G_WGRAD_BLOCK', '1') != '0'     # A/B knob: see Generator.run_backward
 G_WGRAD_STREAMS = max(1, int(_os_.environ.get('HV_G_WGRAD_STREAMS', '1')))      # A/B knob: see Generator.run_backward
+G_WGRAD_COARSE = int(_os_.environ.get('HV_G_WGRAD_COARSE', '2'))      # A/B knob: see Generator.run_backward
 
 
 class Generator(nn.Module):
@@ -562,7 +563,7 @@ class Generator(nn.Module):
         ops.copy_channels(Act(d_coarse_seg.view(B, H, W, 1)), Act(d_cs_total.view(B, H, W, 1)), mode=0)
         ops.copy_channels(book.twin(P.f_in).slice(1, 1), Act(d_cs_total.view(B, H, W, 1)), mode=0, accumulate=True)
         if wg_block:
-            book.defer_wgrad = False
+            book.defer_wgrad = G_WGRAD_COARSE > 0      # (the first coarse layers' weight gradients join the side streams' queue behind this block: see below)
             launch_block()
         # ---- coarse
         C = P.c_nodes
@@ -582,12 +583,25 @@ class Generator(nn.Module):
         if not p19:
             g14 = book.twin(a['c14'])
             ops.copy_channels(book.twin(a['cat19']).slice(0, 2 * c), g14, mode=3, accumulate=book.mark(g14))
+        # HV_G_WGRAD_COARSE (round 5): the coarse generator's first backward layers -- its heads and the 256 x 256 / 128 x 128 decoder, the most expensive weight
+        # gradients of the chain -- hand their weight gradients to the side stream too (ONE more fork: it queues them behind the refinement generator's
+        # block), so that the main stream walks these layers with data gradients only; the rest of the coarse backward keeps its weight gradients in line
+        # (everything on the side stream made the block outlast the chain: +0.14 ms, round 4)
+        if wg_block and G_WGRAD_COARSE == 1:
+            book.defer_wgrad = False
+            launch_block()
         p20 = pooled(C[12], a['c12'])
         E.conv_backward_chain([C[14], C[13], C[12]], book, prec, premultiplied_first=p19)
         if not p20:
             g12 = book.twin(a['c12'])
             ops.copy_channels(book.twin(a['cat20']).slice(0, 4 * c), g12, mode=3, accumulate=book.mark(g12))
+        if wg_block and G_WGRAD_COARSE == 2:
+            book.defer_wgrad = False
+            launch_block()
         E.conv_backward_chain([C[11], C[10]], book, prec, premultiplied_first=p20, stop_before=C[9])
+        if wg_block and G_WGRAD_COARSE >= 3:
+            book.defer_wgrad = False
+            launch_block()
         pre10 = E.chain_link(C[10], C[9], prec)      # c10 feeds conv11 and the height head: both apply elu'(c10)
         ops.gap_fc_sigmoid_backward(d_pred1, P.pred1, P.c_pool, cg.fc_height.weight, book.twin(a['c10']),
                                     cg.fc_height.weight.grad, cg.fc_height.bias.grad, mul=(a['c10'], C[9].act) if pre10 else None)

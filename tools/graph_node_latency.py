@@ -100,3 +100,22 @@ for name, fn in (('100 tiny alone', only_a), ('1 long alone', only_b), ('long on
     with torch.cuda.graph(g, stream=cap_stream):
         fn()
     print('%-52s %.1f us' % (name, timeit(g)))
+
+# ---- does a fork-join region tax the nodes outside it?  chain of 50 | fork: 2 branches x 25 | join | chain of 50  (150 nodes on the critical path)
+def mixed():
+    cur = torch.cuda.current_stream()
+    for _ in range(50): k(small)
+    sides[1].wait_stream(cur)
+    with torch.cuda.stream(sides[1]):
+        for _ in range(25): k(bufs[1])
+    for _ in range(25): k(small)
+    cur.wait_stream(sides[1])
+    for _ in range(50): k(small)
+def chain125():
+    for _ in range(125): k(small)
+bufs = [torch.zeros(1024, device=dev) for _ in range(3)]
+for name, fn in (('chain of 125 tiny', chain125), ('50 chain | 2 x 25 in a fork-join | 50 chain', mixed)):
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=cap_stream):
+        fn()
+    print('%-52s %.1f us' % (name, timeit(g)))
