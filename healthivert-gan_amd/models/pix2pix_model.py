@@ -540,15 +540,16 @@ class Pix2PixModel(BaseModel):
 
     # ---------------------------------------------------------------- data-parallel schedule: preflight
     def _resolve_dp_schedule(self):
-        """'auto' -> a schedule, once, at the first step: single process or gloo -> 'graphs' (gloo cannot be captured); RCCL -> dp_preflight()."""
-        if not self.grad_sync.active() or not self.grad_sync.capturable():
+        """'auto' -> a schedule, once, at the first step: single process -> nothing to choose; otherwise dp_preflight() over the schedules the transport can
+        run (gloo cannot be captured: 'graphs' only -- the preflight then still proves that every rank ends with the same weights and records the time)."""
+        if not self.grad_sync.active():
             self.dp_schedule = 'graphs'
             return
         import os
         if os.environ.get('HV_DP_PREFLIGHT', '1') == '0':
-            self.dp_schedule = 'captured'
+            self.dp_schedule = 'captured' if self.grad_sync.capturable() else 'graphs'
             return
-        self.dp_preflight()
+        self.dp_preflight(schedules=('graphs', 'captured', 'overlapped') if self.grad_sync.capturable() else ('graphs',))
 
     def _dp_state(self):
         """Every tensor a train step changes besides the activations: the four networks' parameters and buffers (BatchNorm running statistics,
@@ -571,7 +572,7 @@ class Pix2PixModel(BaseModel):
                 tot += p.data.view(torch.int32).to(torch.int64).sum()
         return tot
 
-    def dp_preflight(self, timed_steps=5):
+    def dp_preflight(self, timed_steps=5, schedules=('graphs', 'captured', 'overlapped')):
         """Pick the data-parallel schedule on THIS job, on the batch set_input() just delivered, before the first training step.
 
         Both schedules ('captured': the exchange branch inside the step's one hipGraph; 'graphs': the step cut at the exchanges) are run from the
@@ -610,7 +611,7 @@ class Pix2PixModel(BaseModel):
         kept = {}
         self._in_preflight = True
         try:
-            for sched in ('graphs', 'captured', 'overlapped'):      # (the plain one first: its captured graphs are kept whatever the later trials do)
+            for sched in schedules:      # (the plain one first: its captured graphs are kept whatever the later trials do)
                 where['at'] = sched
                 r = {'ok': False, 'error': None, 'ms_per_step': None, 'weights_identical_across_ranks': None}
                 rec['schedules'][sched] = r
@@ -664,7 +665,7 @@ class Pix2PixModel(BaseModel):
         finally:
             self._in_preflight = False
             timer.cancel()
-        good = [k for k in ('graphs', 'captured', 'overlapped') if rec['schedules'][k]['ok']]
+        good = [k for k in schedules if rec['schedules'][k]['ok']]
         if not good:
             raise RuntimeError('data-parallel preflight: no schedule ran correctly on %d rank(s): %r' % (world, rec['schedules']))
         best = min(good, key=lambda k: rec['schedules'][k]['ms_per_step'])
@@ -674,7 +675,7 @@ class Pix2PixModel(BaseModel):
         rec['chosen'] = best
         self.dp_schedule = best
         self._graphs, self._eager_steps = kept[best]
-        self.dp_capture_error = next((rec['schedules'][k]['error'] for k in ('captured', 'overlapped') if rec['schedules'][k]['error']), None)
+        self.dp_capture_error = next((rec['schedules'][k]['error'] for k in ('captured', 'overlapped') if k in rec['schedules'] and rec['schedules'][k]['error']), None)
         if dist.get_rank() == 0:
             print('data-parallel preflight (%d rank(s)): %s -> %s' % (world, {k: (v['ms_per_step'], v['error']) for k, v in rec['schedules'].items()}, best), flush=True)
 

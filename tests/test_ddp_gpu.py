@@ -156,7 +156,8 @@ OVERFLOW_RANK = r'''
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))
 rank, port, dst = int(sys.argv[1]), sys.argv[2], sys.argv[3]
-os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=port, HV_PRECISION='fp16')
+# (no schedule preflight here: it would capture the step's graphs at step 0, with rank 1's absurd gradient scale baked in as a kernel argument)
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=port, HV_PRECISION='fp16', HV_DP_PREFLIGHT='0')
 dist.init_process_group('gloo', rank=rank, world_size=2)
 import hvgan
 from hvgan import synth
@@ -333,6 +334,8 @@ def test_bench_two_ranks_rehearsal_over_gloo():
     assert rec['n_gpus'] == 2 and rec['config']['global_batch'] == 32 and rec['config']['parallelism'] == 'dp2'
     assert rec['config']['launch'].startswith('hipGraph replay (3 graphs/step)')
     assert rec['comm']['backend'] == 'gloo' and rec['comm']['world_size'] == 2 and rec['scaling'] == 'weak' and rec['value'] > 0
+    pf = rec['comm']['preflight']      # (gloo: one schedule to try; the preflight still proves cross-rank weight identity and puts the weights back)
+    assert pf and pf['chosen'] == 'graphs' and pf['schedules']['graphs']['ok'] and pf['schedules']['graphs']['weights_identical_across_ranks'], rec['comm']
     assert rec['roofline'] and rec['roofline']['launches'] > 0 and 'fine_generator_forward' in rec
 
 
