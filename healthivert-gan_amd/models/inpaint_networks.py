@@ -316,7 +316,6 @@ class _GenPlan:
 
 
 G_WGRAD_BLOCK = _os_.environ.get('HV_G_WGRAD_BLOCK', '1') != '0'     # A/B knob: see Generator.run_backward
-G_WGRAD_STREAMS = max(1, int(_os_.environ.get('HV_G_WGRAD_STREAMS', '1')))      # A/B knob: see Generator.run_backward
 G_WGRAD_COARSE = int(_os_.environ.get('HV_G_WGRAD_COARSE', '2'))      # A/B knob: see Generator.run_backward
 
 
@@ -492,10 +491,17 @@ class Generator(nn.Module):
         d_coarse_seg, d_x_stage1 = zero(d_coarse_seg, P.coarse_seg), zero(d_x_stage1, P.x_stage1)
         d_pred1, d_pred2 = zero(d_pred1, P.pred1), zero(d_pred2, P.pred2)
         M = P.f_nodes_merge
-        # the concat inputs of the split layers (forward: never built) for their weight gradients: up-sampled now, beside the head kernels
-        for node, low, cat, k2 in ((P.c_nodes[15], a['c14'], a['cat19'], 2 * c), (P.c_nodes[12], a['c12'], a['cat20'], 4 * c)):
+        # the concat inputs of the split layers (forward: never built) for their weight gradients: up-sampled now, beside the head kernels -- or, where the
+        # layer's weight gradient goes to the side stream (HV_G_WGRAD_COARSE), on that stream right in front of it: 35 + 20 us of copies (67 + 33 MB written)
+        # off the head of the backward's critical path
+        late_copies = []
+        wg_block_now = G_WGRAD_BLOCK and not E.SERIAL and torch.cuda.current_stream().cuda_stream not in E.NO_FORK_STREAMS
+        for grp, (node, low, cat, k2) in enumerate(((P.c_nodes[15], a['c14'], a['cat19'], 2 * c), (P.c_nodes[12], a['c12'], a['cat20'], 4 * c)), start=1):
             if node.split_forward(prec):
-                ops.copy_channels(low, cat.slice(0, k2), mode=1)
+                if wg_block_now and G_WGRAD_COARSE >= grp:
+                    late_copies.append(lambda low=low, cat=cat, k2=k2: ops.copy_channels(low, cat.slice(0, k2), mode=1))
+                else:
+                    ops.copy_channels(low, cat.slice(0, k2), mode=1)
         # the refinement generator's weight gradients as ONE block on a side stream beside the coarse generator's whole backward (round 4, HV_G_WGRAD_BLOCK):
         # they only feed the optimiser, and the coarse backward -- a chain of small launches that leave most of a CU's registers and LDS free -- does not
         # depend on them.  One fork and one join (per-layer forks cost more than they returned and are gone).  Measured against it, three
@@ -504,21 +510,13 @@ class Generator(nn.Module):
         wg_block = G_WGRAD_BLOCK and not E.SERIAL and torch.cuda.current_stream().cuda_stream not in E.NO_FORK_STREAMS
         book.defer_wgrad = bool(wg_block)
         wg_side = E.named_stream('generator-wgrad-block', d_x_stage2.device) if wg_block else None
-        # HV_G_WGRAD_STREAMS = n > 1: the block's launches dealt round-robin to n side streams, each a first-level fork of the current stream (the generators'
-        # 3x3 weight gradients are bound by their split-K slab bytes: with fewer workgroups per launch -- HV_WGRAD_TR_WGS_SMALL -- several of them side by
-        # side would fill the chip with a fraction of the slabs)
-        wg_sides = [wg_side] + [E.named_stream('generator-wgrad-block-%d' % i, d_x_stage2.device) for i in range(1, G_WGRAD_STREAMS)] if wg_block else []
-
         def launch_block():
-            cur = torch.cuda.current_stream()
-            for st in wg_sides:
-                st.wait_stream(cur)
-            for i, launch in enumerate(book.deferred):
-                with torch.cuda.stream(wg_sides[i % len(wg_sides)]):
+            # (several side streams with the launches dealt round-robin, HV_G_WGRAD_STREAMS 2 / 3, measured slower in round 5: 6.94 -> 6.98-7.36 ms)
+            wg_side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(wg_side):
+                for launch in book.deferred:
                     launch()
-            for st in wg_sides:      # each side stream's last slab fold, on that stream (before the join)
-                with torch.cuda.stream(st):
-                    self.paramset().fold_chain().flush()
+                self.paramset().fold_chain().flush()      # the side stream's last slab fold, on that stream (before the join)
             book.deferred = []
         # ---- fine: heads
         self._head_backward(P, M[7], d_x_stage2, 'f17', prec, book)
@@ -565,6 +563,7 @@ class Generator(nn.Module):
         if wg_block:
             book.defer_wgrad = G_WGRAD_COARSE > 0      # (the first coarse layers' weight gradients join the side streams' queue behind this block: see below)
             launch_block()
+            book.deferred.extend(late_copies)          # (in front of the coarse weight gradients that read them, on their stream)
         # ---- coarse
         C = P.c_nodes
         # both heads read c16 (output of conv16, ELU): each applies elu'(c16) to its share of the gradient
@@ -607,8 +606,8 @@ class Generator(nn.Module):
                                     cg.fc_height.weight.grad, cg.fc_height.bias.grad, mul=(a['c10'], C[9].act) if pre10 else None)
         E.conv_backward_chain(list(reversed(C[:10])), book, prec, premultiplied_first=pre10)
         book.join()     # side-stream weight gradients
-        for st in wg_sides:
-            torch.cuda.current_stream().wait_stream(st)
+        if wg_side is not None:
+            torch.cuda.current_stream().wait_stream(wg_side)
         self.paramset().finish_backward(accumulate=False)
         self.paramset().attach_grads()
 
