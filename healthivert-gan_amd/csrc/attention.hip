@@ -855,6 +855,146 @@ extern "C" int hv_ca_score_backward_prep(const float* dS, const float* S0, const
     return HV_OK;
 }
 
+// The adjoint of the score fusion and the two reductions above in one pass (attention map 32 x 32): Gs needs the tile (it, jt) of dS0 AND its mirror
+// (jt, it), so a workgroup owns the PAIR -- it builds both tiles exactly as ca_fuse_adj_tile32_kernel does (same term order, same bits), keeps them in
+// LDS, writes the two Gs tiles (term order of ca_gs_kernel: same bits) and the column sums of dS0 * S0 of both tiles as partials part[b][row block][l]
+// (32 row blocks; ca_coef_final_kernel<32> folds them in block order -- a different summation order from the 16 row chunks above, same tolerance).
+// dS0 never reaches HBM (64 MB written, 2 x 64 + 64 MB read back by the two consumers).  Tile pairs are dealt by circular diagonal delta = jt - it
+// (0 .. 16; -delta is the mirror) to the XCD the round-robin gives the workgroup, as ca_tile_of() does: delta = 8 * group + XCD, group 0 .. 2, the
+// ids whose delta exceeds 16 (and the second half of delta = 16, which mirrors the first) leave at once; every XCD gets two diagonals' worth of work.
+__device__ __forceinline__ void ca_adj_tile32(const float* __restrict__ Sb, int p0, int l0, float* T, int (*prow)[34], int (*pcol)[34], float (&o)[4]) {
+    constexpr int W = 32, HH = 32, L = W * HH, TS = 34, LDT = 35;
+    if (threadIdx.x < 2 * 3 * TS) {
+        const int which = threadIdx.x / (3 * TS), e = threadIdx.x % (3 * TS), d = e / TS, i = e % TS;
+        const int q = (which ? l0 : p0) - 1 + i;
+        int src = -1;
+        if ((unsigned)q < (unsigned)L) {
+            const int a = (q & (W - 1)) * HH + (q >> 5) + (d - 1);
+            if ((unsigned)a < (unsigned)L) src = (a & (HH - 1)) * W + (a >> 5);
+        }
+        (which ? pcol : prow)[d][i] = src;
+    }
+    __syncthreads();
+    {
+        constexpr int NIT = (TS * TS + 255) / 256;
+        float v[3][NIT];
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int e = threadIdx.x + it * 256, i = e / TS, j = e - i * TS;
+                const int pr = e < TS * TS ? prow[d][i] : -1, lc = e < TS * TS ? pcol[d][j] : -1;
+                v[d][it] = (pr >= 0 && lc >= 0) ? Sb[(long long)pr * L + lc] : 0.f;
+            }
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int e = threadIdx.x + it * 256, i = e / TS, j = e - i * TS;
+                if (e < TS * TS) T[d * TS * LDT + i * LDT + j] = v[d][it];
+            }
+    }
+    __syncthreads();
+    const int r = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * 4;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int c = c0 + u;
+        float acc = 0.f;
+#pragma unroll
+        for (int e = 0; e < 3; ++e)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) acc += T[d * TS * LDT + (r + e) * LDT + c + e];
+        o[u] = acc;
+    }
+}
+__global__ __launch_bounds__(256) void ca_fuse_adj_prep32_kernel(const float* __restrict__ dS1, const float* __restrict__ S0, const float* __restrict__ rnorm,
+                                                                 float* __restrict__ Gs, float* __restrict__ part) {
+    constexpr int L = 1024, TS = 34, LDT = 35, LP = 33;
+    __shared__ float T[3 * TS * LDT];                  // the three source pieces of a tile; afterwards the two 32 x 33 product tiles
+    __shared__ float tA[32 * LP], tB[32 * LP];         // dS0 tiles (it, jt) and (jt, it)
+    __shared__ int prow[3][TS], pcol[3][TS];
+    const int id = (int)blockIdx.x, xcd = id & 7;
+    int q = id >> 3;
+    const int k = q & 31;
+    q >>= 5;
+    const int delta = (q % 3) * 8 + xcd, bb = q / 3;
+    if (delta > 16 || (delta == 16 && k >= 16)) return;
+    const bool self = delta == 0;
+    const int it = k, jt = (k + delta) & 31, i0 = it * 32, j0 = jt * 32;
+    const float* Db = dS1 + (long long)bb * L * L;
+    const float* Sb = S0 + (long long)bb * L * L;
+    const float* rn = rnorm + (long long)bb * L;
+    float* Gb = Gs + (long long)bb * L * L;
+    const int r = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * 4;
+    float oA[4], oB[4] = {0.f, 0.f, 0.f, 0.f};
+    const float4 sA = *reinterpret_cast<const float4*>(Sb + (long long)(i0 + r) * L + j0 + c0);
+    float4 sB = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!self) sB = *reinterpret_cast<const float4*>(Sb + (long long)(j0 + r) * L + i0 + c0);
+    ca_adj_tile32(Db, i0, j0, T, prow, pcol, oA);
+    if (!self) {
+        __syncthreads();                               // T and the index tables are rebuilt
+        ca_adj_tile32(Db, j0, i0, T, prow, pcol, oB);
+    }
+    __syncthreads();
+    float* PA = T;
+    float* PB = T + 32 * LP;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        tA[r * LP + c0 + u] = oA[u];
+        tB[r * LP + c0 + u] = oB[u];
+    }
+    PA[r * LP + c0 + 0] = oA[0] * sA.x;  PA[r * LP + c0 + 1] = oA[1] * sA.y;  PA[r * LP + c0 + 2] = oA[2] * sA.z;  PA[r * LP + c0 + 3] = oA[3] * sA.w;
+    PB[r * LP + c0 + 0] = oB[0] * sB.x;  PB[r * LP + c0 + 1] = oB[1] * sB.y;  PB[r * LP + c0 + 2] = oB[2] * sB.z;  PB[r * LP + c0 + 3] = oB[3] * sB.w;
+    __syncthreads();
+    const float* tM = self ? tA : tB;                  // the mirror tile
+    {   // Gs(it, jt)[r][c] = dS0[j0 + c][i0 + r] * rnorm[i0 + r] + dS0[i0 + r][j0 + c] * rnorm[j0 + c]
+        const float ri = rn[i0 + r];
+        const float4 rj = *reinterpret_cast<const float4*>(rn + j0 + c0);
+        *reinterpret_cast<float4*>(Gb + (long long)(i0 + r) * L + j0 + c0) =
+            make_float4(tM[(c0 + 0) * LP + r] * ri + oA[0] * rj.x, tM[(c0 + 1) * LP + r] * ri + oA[1] * rj.y,
+                        tM[(c0 + 2) * LP + r] * ri + oA[2] * rj.z, tM[(c0 + 3) * LP + r] * ri + oA[3] * rj.w);
+    }
+    if (!self) {   // Gs(jt, it)[r][c] = dS0[i0 + c][j0 + r] * rnorm[j0 + r] + dS0[j0 + r][i0 + c] * rnorm[i0 + c]
+        const float rj = rn[j0 + r];
+        const float4 ri = *reinterpret_cast<const float4*>(rn + i0 + c0);
+        *reinterpret_cast<float4*>(Gb + (long long)(j0 + r) * L + i0 + c0) =
+            make_float4(tA[(c0 + 0) * LP + r] * rj + oB[0] * ri.x, tA[(c0 + 1) * LP + r] * rj + oB[1] * ri.y,
+                        tA[(c0 + 2) * LP + r] * rj + oB[2] * ri.z, tA[(c0 + 3) * LP + r] * rj + oB[3] * ri.w);
+    }
+    if (threadIdx.x < (self ? 32 : 64)) {              // column sums of dS0 * S0, rows in order
+        const int half = threadIdx.x >> 5, c = threadIdx.x & 31;
+        const float* P = half ? PB : PA;
+        float s = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < 32; ++rr) s += P[rr * LP + c];
+        part[((long long)bb * 32 + (half ? jt : it)) * L + (half ? i0 : j0) + c] = s;
+    }
+}
+template <int NCH>
+__global__ void ca_coef_final_n_kernel(const float* __restrict__ part, const float* __restrict__ norm, float* __restrict__ coef, int L) {
+    const long long b = blockIdx.y;
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= L) return;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) s += part[(b * NCH + c) * L + l];
+    const float nv = norm[b * L + l];
+    coef[b * L + l] = nv > 1e-4f ? -s / (nv * nv) : 0.f;
+}
+extern "C" int hv_ca_fuse_backward_prep(const float* dS1, const float* S0, const float* norm, const float* rnorm, float* Gs, float* coef, int B, int h, int w,
+                                        void* stream) {
+    if (!dS1 || !S0 || !norm || !rnorm || !Gs || !coef || dS1 == Gs || B <= 0) return HV_ERR_ARG;
+    if (h != 32 || w != 32 || B > 65535 || (((uintptr_t)S0 | (uintptr_t)Gs | (uintptr_t)rnorm) & 15)) return HV_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const int L = 1024;
+    float* part = coef + (long long)B * L;             // 32 row-block partials behind the result: coef holds 33 * B * L floats
+    hipLaunchKernelGGL(ca_fuse_adj_prep32_kernel, dim3(768 * B), dim3(256), 0, s, dS1, S0, rnorm, Gs, part);
+    HV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ca_coef_final_n_kernel<32>, dim3(hv_cdiv(L, 128), B), dim3(128), 0, s, part, norm, coef, L);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+
 // ---- col2im of the patch-matrix gradient, scattered to the even positions of the full map ------------
 __global__ void ca_patches_bwd_kernel(const float* __restrict__ dwp, const float* __restrict__ wp, const float* __restrict__ coef,
                                       float* __restrict__ df, int H, int W, int C, int df_ld, int acc, long long n) {

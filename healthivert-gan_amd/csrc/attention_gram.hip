@@ -197,17 +197,28 @@ extern "C" int hv_ca_gram_scores(const void* fd_h, const float* q, int B, int h,
 }
 
 // ---- gradient: one workgroup per (sample, grid row ay); d fd[row ay] = sum over by of E(ay, by) fd[row by]  (+ the norm term), added to the even positions of df.
-// NBY grid rows by per round (one K = NBY * w product per round: half the barriers per block at NBY = 2).
+// NBY grid rows by per round (one K = NBY * w product per round: half the barriers per block at NBY = 2; NBY = 4, and Gs stored as 4-KB blocks instead of
+// 128-byte rows 4 KB apart, measured the same step time in round 5 -- the kernel runs beside the weight-gradient stream and is not what the step waits for).
 template <int BW, int NBY>
 __global__ __launch_bounds__(256) void ca_gram_backward_kernel(const float* __restrict__ Gs, const _Float16* __restrict__ fd_h, const _Float16* __restrict__ fdT_h,
-                                                               const float* __restrict__ coef, int h, float* __restrict__ df, int df_ld) {
+                                                               const float* __restrict__ coef, int h, float* __restrict__ df, int df_ld, int xcd_rows) {
     constexpr int C = 64, MT = BW / 16, NTL = C / 16, TPW = MT * NTL / 4, KW = NBY * BW, LDE = KW + 8;
     constexpr int NV = BW * BW / 4 / 256;                // float4 items of ONE block per thread; the three diagonal blocks are summed item by item as they arrive
     __shared__ float Gt[NBY][BW][BW + 1];
     __shared__ __attribute__((aligned(16))) _Float16 Eh[BW][LDE];
     const int w = BW, L = h * w, H = 2 * h, W = 2 * w;
-    const int ay = blockIdx.x % h;
-    const long long b = blockIdx.x / h;
+    // xcd_rows (h a multiple of 8): the workgroups of grid rows ay - 1, ay, ay + 1 read the same blocks of Gs; an XCD (linear id & 7) gets h / 8 consecutive
+    // grid rows of every sample, so a block crosses the fabric 1 + 2 / (h / 8) times instead of three
+    int ay;
+    long long b;
+    if (xcd_rows) {
+        const int per = h >> 3, q = (int)blockIdx.x >> 3;
+        ay = ((int)blockIdx.x & 7) * per + q % per;
+        b = q / per;
+    } else {
+        ay = blockIdx.x % h;
+        b = blockIdx.x / h;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* Gb = Gs + b * (long long)L * L;
     const _Float16* fTb = fdT_h + b * (long long)C * L;
@@ -300,15 +311,17 @@ extern "C" int hv_ca_gram_backward(const float* Gs, const void* fd_h, const void
     if (C != 64 || (w != 32 && w != 64) || ((uintptr_t)Gs & 15) || ((uintptr_t)fdT_h & 15) || (long long)B * h >= (1ll << 31)) return HV_ERR_UNSUPPORTED;
     const dim3 grid((unsigned)(B * h));
     static const int nby = getenv("HV_CA_GRAM_NBY") ? atoi(getenv("HV_CA_GRAM_NBY")) : 2;      // A/B knob
+    static const int xcd_env = getenv("HV_CA_GRAM_BWD_XCD") ? atoi(getenv("HV_CA_GRAM_BWD_XCD")) : 1;      // A/B knob (same bits either way)
+    const int xcd_rows = xcd_env && !(h & 7);
     if (w == 32 && nby == 2 && !(h & 1))
         hipLaunchKernelGGL((ca_gram_backward_kernel<32, 2>), grid, dim3(256), 0, (hipStream_t)stream, Gs, reinterpret_cast<const _Float16*>(fd_h),
-                           reinterpret_cast<const _Float16*>(fdT_h), coef, h, df, df_ld);
+                           reinterpret_cast<const _Float16*>(fdT_h), coef, h, df, df_ld, xcd_rows);
     else if (w == 32)
         hipLaunchKernelGGL((ca_gram_backward_kernel<32, 1>), grid, dim3(256), 0, (hipStream_t)stream, Gs, reinterpret_cast<const _Float16*>(fd_h),
-                           reinterpret_cast<const _Float16*>(fdT_h), coef, h, df, df_ld);
+                           reinterpret_cast<const _Float16*>(fdT_h), coef, h, df, df_ld, xcd_rows);
     else
         hipLaunchKernelGGL((ca_gram_backward_kernel<64, 1>), grid, dim3(256), 0, (hipStream_t)stream, Gs, reinterpret_cast<const _Float16*>(fd_h),
-                           reinterpret_cast<const _Float16*>(fdT_h), coef, h, df, df_ld);
+                           reinterpret_cast<const _Float16*>(fdT_h), coef, h, df, df_ld, xcd_rows);
     HV_LAUNCH_CHECK();
     return HV_OK;
 }

@@ -505,6 +505,7 @@ def conv_backward_chain(nodes, book, prec, tmp_full=None, premultiplied_first=Fa
 
 
 # ================================================================================================ contextual attention
+CA_FUSE_PREP = os.environ.get('HV_CA_FUSE_PREP', '1') != '0'   # score-fusion adjoint + Gs + coef in one kernel at 32 x 32 (A/B knob)
 CA_F16_IO = os.environ.get('HV_CA_F16_IO', '1') != '0'   # the attention block's boundary kernels read / write fp16-stored maps themselves (A/B knob)
 CA_F16_COPIES = os.environ.get('HV_CA_F16_COPIES', '1') != '0'   # GEMM route: fp16 operand copies written by their producers (wp_h, A as fp16 only); A/B knob
 CA_GRAM = os.environ.get('HV_CA_GRAM', '1') != '0'     # GEMM route: matching scores and their gradient on the pixel Gram matrix (csrc/attention_gram.hip); A/B knob
@@ -635,7 +636,7 @@ class AttentionPlan:
             z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dout.t.device)
             self.bw = dict(dA=Act(z(B, self.h, self.w, L)), AT=Act(z(B, self.h, self.w, L)), dOrawT=z(B, C, 16 * L),
                            dS1=Act(z(B, self.h, self.w, L)), dS0=Act(z(B, self.h, self.w, L)), Gs=Act(z(B, self.h, self.w, L)),
-                           coef=z(17 * B, L), dwp=Act(z(B, self.h, self.w, 9 * C)))
+                           coef=z(33 * B, L), dwp=Act(z(B, self.h, self.w, 9 * C)))
         bw = self.bw
         df_user = None
         gemm = getattr(self, 'gemm', False) and ops.precision_id(prec) == ops.F16
@@ -671,14 +672,19 @@ class AttentionPlan:
             L_.call('hv_ca_softmax_backward_f16', ptr(bw['dA'].t), ptr(self.A_h), ptr(self.mm), ptr(bw['dS1'].t), B, L, ctypes.c_float(self.scale), stream())
         else:
             L_.call('hv_ca_softmax_backward', ptr(bw['dA'].t), ptr(self.A.t), ptr(self.mm), ptr(bw['dS1'].t), B, L, ctypes.c_float(self.scale), stream())
-        if self.fuse:
-            L_.call('hv_ca_fuse', ptr(bw['dS1'].t), ptr(bw['dS0'].t), B, self.h, self.w, 1, stream())
-            ds0 = bw['dS0']
+        # ... and through the normalised patch matching (patches act as both filters and inputs)
+        use_gram = gemm and getattr(self, 'gram', False)
+        if self.fuse and self.h == 32 and self.w == 32 and CA_FUSE_PREP:      # one pass, the plain scores' gradient stays on chip
+            L_.call('hv_ca_fuse_backward_prep', ptr(bw['dS1'].t), ptr(self.S0.t), ptr(self.norm), ptr(self.rnorm), ptr(bw['Gs'].t), ptr(bw['coef']),
+                    B, self.h, self.w, stream())
         else:
-            ds0 = bw['dS1']
-        # through the normalised patch matching (patches act as both filters and inputs)
-        L_.call('hv_ca_score_backward_prep', ptr(ds0.t), ptr(self.S0.t), ptr(self.norm), ptr(self.rnorm), ptr(bw['Gs'].t), ptr(bw['coef']), B, L, stream())
-        if gemm and getattr(self, 'gram', False):
+            if self.fuse:
+                L_.call('hv_ca_fuse', ptr(bw['dS1'].t), ptr(bw['dS0'].t), B, self.h, self.w, 1, stream())
+                ds0 = bw['dS0']
+            else:
+                ds0 = bw['dS1']
+            L_.call('hv_ca_score_backward_prep', ptr(ds0.t), ptr(self.S0.t), ptr(self.norm), ptr(self.rnorm), ptr(bw['Gs'].t), ptr(bw['coef']), B, L, stream())
+        if use_gram:
             # d fd = box(Gs) fd + (3x3 sum of coef) fd, added to the even positions of df: one K = L product instead of the L x 9C GEMM + col2im
             L_.call('hv_ca_gram_backward', ptr(bw['Gs'].t), ptr(self.fd_h), ptr(self.fdT_h), ptr(bw['coef']), B, self.h, self.w, C, ptr(df.t), df.ld, stream())
         else:

@@ -351,6 +351,11 @@ int hv_transpose_batched_h2h(const void* src_h, void* dst_h, int B, int R, int C
  * coef must hold 17*B*L floats: the first B*L are the result, the rest is scratch for the row-chunk partial sums. */
 int hv_ca_score_backward_prep(const float* dS, const float* S0, const float* norm, const float* rnorm, float* Gs, float* coef,
                               int B, int L, void* stream);
+/* hv_ca_fuse(adjoint) + hv_ca_score_backward_prep in one pass for the 32 x 32 attention map (csrc/attention.hip ca_fuse_adj_prep32_kernel): dS1 is the gradient
+ * of the FUSED scores; the gradient of the plain scores stays on chip.  Gs has the bits of the two-call route, coef its value in a different summation order
+ * (32 row blocks).  coef must hold 33*B*L floats.  HV_ERR_UNSUPPORTED unless h = w = 32 (the caller keeps the two calls for other maps). */
+int hv_ca_fuse_backward_prep(const float* dS1, const float* S0, const float* norm, const float* rnorm, float* Gs, float* coef, int B, int h, int w,
+                             void* stream);
 /* col2im of (dwp + coef*wp) back to the even positions of the full-resolution map (adjoint of hv_ca_patches). */
 int hv_ca_patches_backward(const float* dwp, const float* wp, const float* coef, float* df, int B, int H, int W, int C,
                            int df_ld, int accumulate, void* stream);

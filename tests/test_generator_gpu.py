@@ -432,6 +432,41 @@ def test_score_fusion_tiles_match_the_index_formula(adjoint):
     assert np.array_equal(out.cpu().numpy(), ref)
 
 
+def test_score_fusion_adjoint_with_gs_and_coef_in_one_pass_matches_the_two_calls():
+    """hv_ca_fuse_backward_prep (32 x 32 map: every workgroup owns a tile of dS0 and its mirror, dS0 never stored) against hv_ca_fuse(adjoint) followed by
+    hv_ca_score_backward_prep: Gs bit for bit (same term order), coef to fp32 rounding (32 row blocks instead of 16 row chunks) and against the fp64 sum."""
+    from hvgan import lib
+    from hvgan.lib import ptr, stream
+    B, h, w = 3, 32, 32
+    L = h * w
+    g = torch.Generator().manual_seed(77)
+    dS1 = torch.randn(B, L, L, generator=g).cuda()
+    S0 = torch.randn(B, L, L, generator=g).cuda()
+    norm = (torch.rand(B, L, generator=g) + 0.5).cuda()
+    norm[1, 17] = 5e-5                                       # a clamped norm: coef 0 there
+    rnorm = (1.0 / norm.clamp_min(1e-4)).contiguous()
+    Lc = lib.get()
+    dS0 = torch.empty_like(dS1)
+    Gs_ref = torch.empty_like(dS1)
+    coef_ref = torch.zeros(17 * B, L, device='cuda')
+    Lc.call('hv_ca_fuse', ptr(dS1), ptr(dS0), B, h, w, 1, stream())
+    Lc.call('hv_ca_score_backward_prep', ptr(dS0), ptr(S0), ptr(norm), ptr(rnorm), ptr(Gs_ref), ptr(coef_ref), B, L, stream())
+    Gs = torch.full_like(dS1, float('nan'))
+    coef = torch.full((33 * B, L), float('nan'), device='cuda')
+    Lc.call('hv_ca_fuse_backward_prep', ptr(dS1), ptr(S0), ptr(norm), ptr(rnorm), ptr(Gs), ptr(coef), B, h, w, stream())
+    torch.cuda.synchronize()
+    assert torch.equal(Gs, Gs_ref)
+    c, cr = coef[:B].cpu(), coef_ref[:B].cpu()
+    exact = -(dS0.double() * S0.double()).sum(1).cpu() / (norm.double().cpu() ** 2)
+    exact[norm.cpu() <= 1e-4] = 0
+    scale = exact.abs().max().item()
+    assert c[1, 17] == 0
+    assert (c.double() - exact).abs().max().item() <= 2e-6 * scale
+    assert (c - cr).abs().max().item() <= 4e-6 * scale
+    with pytest.raises(RuntimeError):                        # other maps keep the two calls
+        Lc.call('hv_ca_fuse_backward_prep', ptr(dS1), ptr(S0), ptr(norm), ptr(rnorm), ptr(Gs), ptr(coef), 1, 16, 64, stream())
+
+
 @pytest.mark.parametrize('B,R,C', [(2, 1024, 576), (3, 72, 40), (1, 64, 8), (2, 33, 50)])
 def test_attention_operand_transposes_are_exact(B, R, C):
     """hv_transpose_batched_f16 (fp32 -> fp16) and hv_transpose_batched_h2h (fp16 -> fp16): the operand tables of the attention block's batched
