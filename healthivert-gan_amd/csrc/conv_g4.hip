@@ -375,6 +375,7 @@ __global__ __launch_bounds__(512, 2) void conv_g4_kernel(const G4K p) {
     // the last tap's MFMAs instead of at the head of the next chunk with every wave of the workgroup waiting for LDS at once.
     auto chunk = [&](int c, int b) __attribute__((always_inline)) {
         const int bn = b == 2 ? 0 : b + 1;
+        // (the pieces of chunk c + 2 one per tap instead of all here -- what conv_g4s1_kernel gains 0-15 % from -- measured 0.95-1.03x on these shapes: not kept)
 #ifdef G4_STAMPS
         if (c + 2 < NCH && !(p.dbg & 1)) issue(c + 2, b == 0 ? 2 : b - 1);
 #else
@@ -439,16 +440,21 @@ __global__ __launch_bounds__(512, 2) void conv_g4_kernel(const G4K p) {
 // a ring of three buffers, the (TH + 3) x 20-pixel patch of a 32-channel chunk arrives ONCE for its four filter rows (two buffers).  conv_halo2_kernel
 // fetched 1 MB of filters per 128-pixel x 64/128-channel tile straight into registers (537 MB of L2 -> CU traffic per launch, 2x the tensors'
 // HBM bytes); a 256-pixel x 128-channel tile halves that and both operands come from LDS.
-template <int DG, int MT>
+template <int DG, int MT, bool SPREAD>
 __global__ __launch_bounds__(512, 2) void conv_g4s1_kernel(const G4K p) {
     constexpr int TW = 16, TH = 4 * MT, PH = TH + 3, PW = 20;                // patch rows of 20 pixels (19 used): a row shift moves the swizzle phase by its parity only
     constexpr int NBP = (PH * PW + 15) / 16, BPW = (NBP + 7) / 8;
+    static_assert(BPW <= 4, "one patch piece per tap");
     constexpr int ABUF = 32 * 512, BBUF = NBP * 512;                          // halfs
     extern __shared__ __attribute__((aligned(16))) char smem[];
     _Float16* As = reinterpret_cast<_Float16*>(smem);                         // [3][ABUF]
     _Float16* Bs = As + 3 * ABUF;                                             // [2][BBUF] + one spare KB
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
+#ifdef G4_STAMPS     // diagnostic build only (tools/g4_stamps.py): phase times of one workgroup, written over the first bytes of y
+    unsigned long long st[8];
+    st[0] = __builtin_amdgcn_s_memrealtime();
+#endif
     int t = (int)blockIdx.x;
     const int n_img = t / p.tiles;
     t -= n_img * p.tiles;
@@ -480,6 +486,17 @@ __global__ __launch_bounds__(512, 2) void conv_g4s1_kernel(const G4K p) {
             const int rb = (cob_s[rbw >> 2] >> 4) + (rbw & 3);
             lds_dma16(wsrc, (lds_ptr)(As + ab * ABUF + f * 512), (unsigned)lane * 16u, rb * (int)p.w_rb + ((kh * 4 + kw) * Cin + kc * 32) * 32);
         }
+    };
+    // SPREAD: one piece at a time, in front of each tap's MFMAs (below); `live` = false sends the piece out of range (zeros into a free buffer), so that the
+    // instruction count a wave's vmcnt waits rely on is the same for every sub-chunk
+    auto issueA1 = [&](int kc, int kh, int ab, int i, bool live) __attribute__((always_inline)) {
+        const int f = wave + 8 * i, rbw = f >> 2, kw = f & 3;
+        const int rb = (cob_s[rbw >> 2] >> 4) + (rbw & 3);
+        lds_dma16(wsrc, (lds_ptr)(As + ab * ABUF + f * 512), live ? (unsigned)lane * 16u : HV_OOB, rb * (int)p.w_rb + ((kh * 4 + kw) * Cin + kc * 32) * 32);
+    };
+    auto issueB1 = [&](int kc, int bb, int i, bool live) __attribute__((always_inline)) {
+        _Float16* dst = wave + 8 * i < NBP ? Bs + bb * BBUF + (wave + 8 * i) * 512 : Bs + 2 * BBUF;
+        lds_dma16(xsrc, (lds_ptr)dst, live ? pvo[i] : HV_OOB, kc * 64);
     };
     auto issueB = [&](int kc, int bb) __attribute__((always_inline)) {
 #pragma unroll
@@ -517,7 +534,8 @@ __global__ __launch_bounds__(512, 2) void conv_g4s1_kernel(const G4K p) {
         constexpr int kh2 = (kh + 2) & 3;
         const int kc2 = kc + (kh >= 2 ? 1 : 0);
         const int ab2 = ab == 0 ? 2 : ab - 1;                                 // (s + 2) % 3
-        if (s_ + 2 < NS) {
+        const bool live = s_ + 2 < NS;
+        if (!SPREAD && live) {
             issueA(kc2, kh2, ab2);
             if (kh == 2) issueB(kc + 1, (kc + 1) & 1);
         }
@@ -533,6 +551,11 @@ __global__ __launch_bounds__(512, 2) void conv_g4s1_kernel(const G4K p) {
 #pragma unroll
         for (int kw = 0; kw < 4; ++kw) {
             __builtin_amdgcn_sched_barrier(0);
+            if (SPREAD) {      // eight waves issuing their 4 (+ BPW) pieces at once stall in the issue: the texture path takes one wave-instruction at a time
+                issueA1(kc2, kh2, ab2, kw, live);
+                if (kh == 2 && kw < BPW) issueB1(kc + 1, (kc + 1) & 1, kw, live);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if (kw + 1 < 4) frags(kw + 1, (kw + 1) & 1);
 #pragma unroll
             for (int m = 0; m < MT; ++m)
@@ -548,7 +571,7 @@ __global__ __launch_bounds__(512, 2) void conv_g4s1_kernel(const G4K p) {
             __builtin_amdgcn_sched_barrier(0);
         }
         // newest DMA instructions of this wave that may stay in flight: those of sub-chunk s + 2 (issued above)
-        if (s_ + 2 < NS) {
+        if (SPREAD || live) {
             if (kh == 2) __builtin_amdgcn_s_waitcnt(0x0070 | ((4 + BPW) & 15));
             else __builtin_amdgcn_s_waitcnt(0x0070 | 4);
         } else {
@@ -562,6 +585,9 @@ __global__ __launch_bounds__(512, 2) void conv_g4s1_kernel(const G4K p) {
     issueA(0, 1, 1);
     __builtin_amdgcn_s_waitcnt(0x0F70 | 4);
     __builtin_amdgcn_s_barrier();
+#ifdef G4_STAMPS
+    st[1] = __builtin_amdgcn_s_memrealtime();
+#endif
     int ab = 0;
     for (int kc = 0; kc < KC; ++kc) {
         sub(kc, std::integral_constant<int, 0>(), ab); ab = ab == 2 ? 0 : ab + 1;
@@ -569,8 +595,21 @@ __global__ __launch_bounds__(512, 2) void conv_g4s1_kernel(const G4K p) {
         sub(kc, std::integral_constant<int, 2>(), ab); ab = ab == 2 ? 0 : ab + 1;
         sub(kc, std::integral_constant<int, 3>(), ab); ab = ab == 2 ? 0 : ab + 1;
     }
+    if (SPREAD) __builtin_amdgcn_s_waitcnt(0x0F70);      // the last sub-chunks' out-of-range pieces (zeros) land before the epilogue reuses the buffers
     __syncthreads();
+#ifdef G4_STAMPS
+    st[2] = __builtin_amdgcn_s_memrealtime();
+#endif
     g4_epilogue<0, MT>(p, acc, smem, cls_s, cob_s, n_img, i0, j0, bias_r);
+#ifdef G4_STAMPS
+    st[3] = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0);
+    st[4] = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0) {
+        unsigned long long* d = reinterpret_cast<unsigned long long*>(p.y);
+        for (int i = 0; i < 5; ++i) d[i] = st[i];
+    }
+#endif
 }
 
 template <int DG, int MT>
@@ -581,7 +620,8 @@ static int launch_g4s1(G4K& k, int ny, hipStream_t s) {
     static_assert(lds <= 160 * 1024, "LDS");
     k.tiles_x = hv_cdiv(k.Wc, 16);
     k.tiles = k.tiles_x * hv_cdiv(k.Hc, TH);
-    auto kern = conv_g4s1_kernel<DG, MT>;
+    static const int spread = getenv("HV_G4S1_SPREAD") ? atoi(getenv("HV_G4S1_SPREAD")) : 1;      // A/B knob (same bits): LDS-DMA pieces issued tap by tap
+    auto kern = spread ? conv_g4s1_kernel<DG, MT, true> : conv_g4s1_kernel<DG, MT, false>;
     static bool raised = false;
     if (!raised) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
