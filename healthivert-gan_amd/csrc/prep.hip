@@ -633,24 +633,38 @@ __global__ __launch_bounds__(256) void adam_kernel(const hv_adam_tensor* __restr
 }
 
 // ---- guarded form (fp16 storage mode: the gradients carry a loss scale and may have overflowed to inf / nan in an fp16 gradient buffer)
-// state[0] = step count, [1] = "this gradient is not finite" (set by the check, consumed by the tick), [2] = skipped steps so far, [3] = skip THIS step
-__global__ __launch_bounds__(256) void grad_finite_check_kernel(const float* __restrict__ g, long long n, float* __restrict__ state) {
+// state[0] = step count, [1] = "this gradient is not finite" (set by the check, consumed by the tick), [2] = skipped steps so far, [3] = skip THIS step,
+// [4] = ticket of the check kernel's workgroups (an unsigned; back at zero when the launch ends)
+// One pass over the flat gradient: the loss scale taken out (mul, a power of two: exact; 1 = leave the values alone), the finite test on the way, and the
+// LAST workgroup to arrive (agent-scope release -> ticket -> acquire, as gan_loss_head_pair_kernel) does what used to be a one-thread launch between the check
+// and the update: count the step or the skip, publish "skip this step", clear the flag.
+__global__ __launch_bounds__(256) void grad_unscale_check_kernel(float* __restrict__ g, long long n, float mul, float* __restrict__ state) {
     bool bad = false;
+    const bool scale = mul != 1.f;
     for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * 1024) {
         if (i + 3 < n) {
-            const float4 v = *reinterpret_cast<const float4*>(g + i);
+            float4 v = *reinterpret_cast<const float4*>(g + i);
             bad |= !(fabsf(v.x) <= 3.0e38f) | !(fabsf(v.y) <= 3.0e38f) | !(fabsf(v.z) <= 3.0e38f) | !(fabsf(v.w) <= 3.0e38f);      // false for inf AND nan
+            if (scale) { v.x *= mul; v.y *= mul; v.z *= mul; v.w *= mul; *reinterpret_cast<float4*>(g + i) = v; }
         } else {
-            for (long long j = i; j < n; ++j) bad |= !(fabsf(g[j]) <= 3.0e38f);
+            for (long long j = i; j < n; ++j) { bad |= !(fabsf(g[j]) <= 3.0e38f); if (scale) g[j] *= mul; }
         }
     }
-    if (__any(bad) && (threadIdx.x & 63) == 0) state[1] = 1.f;      // every writer stores the same value
-}
-__global__ void adam_guard_tick_kernel(float* state) {
-    const bool bad = state[1] != 0.f;
-    if (bad) state[2] += 1.f; else state[0] += 1.f;
-    state[3] = bad ? 1.f : 0.f;
-    state[1] = 0.f;
+    if (__any(bad) && (threadIdx.x & 63) == 0) __hip_atomic_store(state + 1, 1.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // every writer stores the same value
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned* ticket = reinterpret_cast<unsigned*>(state + 4);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == gridDim.x - 1) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const bool any_bad = __hip_atomic_load(state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.f;
+            if (any_bad) state[2] += 1.f; else state[0] += 1.f;
+            state[3] = any_bad ? 1.f : 0.f;
+            state[1] = 0.f;
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 __global__ __launch_bounds__(256) void adam_guarded_kernel(const hv_adam_tensor* __restrict__ ts, const float* __restrict__ lr_p, float beta1,
                                                            float beta2, float eps, const float* __restrict__ state) {
@@ -676,12 +690,11 @@ __global__ __launch_bounds__(256) void adam_guarded_kernel(const hv_adam_tensor*
     }
 }
 extern "C" int hv_adam_step_guarded(const hv_adam_tensor* d_tensors, int n_tensors, long long max_numel, const float* d_lr, float beta1,
-                                    float beta2, float eps, float* d_state, const float* flat_grad, long long n_grad, void* stream) {
-    if (!d_tensors || n_tensors <= 0 || max_numel <= 0 || !d_lr || !d_state || !flat_grad || n_grad <= 0 || ((uintptr_t)flat_grad & 15)) return HV_ERR_ARG;
+                                    float beta2, float eps, float* d_state, float* flat_grad, long long n_grad, float grad_mul, void* stream) {
+    if (!d_tensors || n_tensors <= 0 || max_numel <= 0 || !d_lr || !d_state || !flat_grad || n_grad <= 0 || ((uintptr_t)flat_grad & 15) || !(grad_mul > 0.f))
+        return HV_ERR_ARG;
     const int blocks = (int)(n_grad / 4096 + 1 < 512 ? n_grad / 4096 + 1 : 512);
-    hipLaunchKernelGGL(grad_finite_check_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, flat_grad, n_grad, d_state);
-    HV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(adam_guard_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, d_state);
+    hipLaunchKernelGGL(grad_unscale_check_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, flat_grad, n_grad, grad_mul, d_state);
     HV_LAUNCH_CHECK();
     dim3 grid(hv_cdiv(max_numel, 1024), n_tensors);
     hipLaunchKernelGGL(adam_guarded_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_tensors, d_lr, beta1, beta2, eps, d_state);

@@ -283,7 +283,6 @@ class Pix2PixModel(BaseModel):
             ops.gan_loss(P.logits, True, mode, loss=lr, dz=dz, grad_weight=0.5 * self.grad_scale)
             net.run_backward(P, dz, need_dx=False, param_grads=True, accumulate=True)
         net.finish()
-        self._unscale(net)
         setattr(self, 'loss_D_fake_%d' % k, lf)
         setattr(self, 'loss_D_real_%d' % k, lr)
 
@@ -306,7 +305,6 @@ class Pix2PixModel(BaseModel):
         net.loss_backward(P, False, self.opt.gan_mode, lf, 0.5 * self.grad_scale, need_dx=False, param_grads=True, accumulate=True,
                           dz=self._buf('dz%d' % k, P.logits))
         net.finish()
-        self._unscale(net)
         setattr(self, 'loss_D_fake_%d' % k, lf)
 
     def _real_local_early(self):
@@ -393,13 +391,6 @@ class Pix2PixModel(BaseModel):
                self.half_band, 0, stream())
         L.call('hv_shrm_backward', ptr(seeds['d_fake_B_coarse']), None, None, ptr(self._rows), 1, ptr(d_x1), B, H, W, self.half_band, 0, stream())
         self.netG.run_backward(self._gplan, seeds['d_coarse_seg'], seeds['d_fine_seg'], d_x1, d_x2, dp1, dp2)
-        self._unscale(self.netG)
-
-    def _unscale(self, net):
-        """Take the gradient scale out of a network's parameter gradients (one pass over its flat gradient buffer; exact: 1/S is a power of two)."""
-        if self.grad_scale != 1.0:
-            flat = net.paramset().flat_grad
-            _lib.get().call('hv_affine', ptr(flat), ptr(flat), ctypes.c_longlong(flat.numel()), ctypes.c_float(1.0 / self.grad_scale), ctypes.c_float(0.0), stream())
 
     # ---------------------------------------------------------------- the step, in three device-only phases
     def _phase_a(self):
@@ -476,7 +467,7 @@ class Pix2PixModel(BaseModel):
         buffer (inf / nan), which then reach every parameter gradient of the network -- such a step is skipped (weights, moments, step count
         unchanged; under data parallelism the check runs on the reduced gradient, so every rank takes the same decision) and counted
         (overflow_steps()).  The scale itself is static (HV_GRAD_SCALE, a power of two; head room in DESIGN.md section 3)."""
-        optimizer.step(sync_lr=False, guard_flat=net.paramset().flat_grad if self.grad_scale != 1.0 else None)
+        optimizer.step(sync_lr=False, guard_flat=net.paramset().flat_grad if self.grad_scale != 1.0 else None, grad_mul=1.0 / self.grad_scale)
         net.paramset().weights_changed()
 
     def overflow_steps(self):

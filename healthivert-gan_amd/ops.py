@@ -523,12 +523,12 @@ def gan_loss_pair(z0, real0, loss0, carrier0, z1=None, real1=True, loss1=None, c
     return True
 
 
-def adam_step(table, max_numel, lr_dev, beta1, beta2, eps, step_dev, guard_flat=None):
+def adam_step(table, max_numel, lr_dev, beta1, beta2, eps, step_dev, guard_flat=None, grad_mul=1.0):
     L = _lib.get()
-    if guard_flat is not None:      # step_dev: 4 floats (hv_adam_step_guarded)
+    if guard_flat is not None:      # step_dev: 8 floats (hv_adam_step_guarded)
         L.call('hv_adam_step_guarded', ctypes.cast(table.ptr(), ctypes.POINTER(L.hv_adam_tensor)), table.n, ctypes.c_longlong(max_numel),
                ptr(lr_dev), ctypes.c_float(beta1), ctypes.c_float(beta2), ctypes.c_float(eps), ptr(step_dev), ptr(guard_flat),
-               ctypes.c_longlong(guard_flat.numel()), stream())
+               ctypes.c_longlong(guard_flat.numel()), ctypes.c_float(grad_mul), stream())
         return
     L.call('hv_adam_step', ctypes.cast(table.ptr(), ctypes.POINTER(L.hv_adam_tensor)), table.n, ctypes.c_longlong(max_numel),
            ptr(lr_dev), ctypes.c_float(beta1), ctypes.c_float(beta2), ctypes.c_float(eps), ptr(step_dev), stream())

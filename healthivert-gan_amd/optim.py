@@ -58,7 +58,7 @@ class FusedAdam(torch.optim.Optimizer):
         lr = float(self.param_groups[0]['lr'])
         if self._lr is None:
             dev = self.param_groups[0]['params'][0].device
-            self._step = torch.zeros(4, dtype=torch.float32, device=dev)      # [0] step count; [1..3]: the overflow guard's state (hv_adam_step_guarded)
+            self._step = torch.zeros(8, dtype=torch.float32, device=dev)      # [0] step count; [1..4]: the overflow guard's state (hv_adam_step_guarded)
             self._lr = torch.zeros(1, dtype=torch.float32, device=dev)
             self._lr_host = None
         if lr != self._lr_host:
@@ -66,14 +66,15 @@ class FusedAdam(torch.optim.Optimizer):
             self._lr_host = lr
 
     @torch.no_grad()
-    def step(self, closure=None, sync_lr=True, guard_flat=None):
+    def step(self, closure=None, sync_lr=True, guard_flat=None, grad_mul=1.0):
         """guard_flat: the flat gradient buffer behind the parameters' .grad views (fp16 storage mode): the update is skipped on the device when it
-        holds an inf / nan (scaled gradients that overflowed an fp16 gradient buffer); skipped_steps() counts those."""
+        holds an inf / nan (scaled gradients that overflowed an fp16 gradient buffer); skipped_steps() counts those.  grad_mul: the factor that takes the
+        loss scale out of the gradients (1 / scale), applied by the same pass that checks them."""
         self._ensure()
         if sync_lr:
             self.sync_lr()
         g = self.param_groups[0]
-        ops.adam_step(self._table, self._max, self._lr, g['betas'][0], g['betas'][1], g['eps'], self._step, guard_flat=guard_flat)
+        ops.adam_step(self._table, self._max, self._lr, g['betas'][0], g['betas'][1], g['eps'], self._step, guard_flat=guard_flat, grad_mul=grad_mul)
 
     def skipped_steps(self):
         """Steps the overflow guard skipped so far (a host read: call it between steps, not inside them)."""

@@ -455,11 +455,12 @@ typedef struct { float* p; const float* g; float* m; float* v; long long n; } hv
 int hv_adam_step(const hv_adam_tensor* d_tensors, int n_tensors, long long max_numel, const float* d_lr, float beta1,
                  float beta2, float eps, float* d_step, void* stream);
 /* The same behind an overflow guard (fp16 storage mode: scaled gradients may have overflowed to inf / nan in an fp16 gradient buffer):
- * flat_grad[n_grad] -- the network's flat gradient buffer, after any all-reduce -- is checked first; if it holds a non-finite value the whole step is
- * skipped (weights, moments and step count unchanged) and d_state[2] counts it.  d_state: 4 floats {step count, scratch, skipped steps, scratch},
- * zero-initialised by the caller.  Device-side only (no host read): safe inside a captured graph. */
+ * flat_grad[n_grad] -- the network's flat gradient buffer, after any all-reduce -- is checked first and multiplied by grad_mul on the way (1 / the loss
+ * scale, a power of two; 1 = left alone); if it holds a non-finite value the whole step is skipped (weights, moments and step count unchanged) and
+ * d_state[2] counts it.  d_state: 8 floats {step count, scratch, skipped steps, scratch, ticket, -, -, -}, zero-initialised by the caller.  Two launches
+ * (check + update); device-side only (no host read): safe inside a captured graph. */
 int hv_adam_step_guarded(const hv_adam_tensor* d_tensors, int n_tensors, long long max_numel, const float* d_lr, float beta1,
-                         float beta2, float eps, float* d_state, const float* flat_grad, long long n_grad, void* stream);
+                         float beta2, float eps, float* d_state, float* flat_grad, long long n_grad, float grad_mul, void* stream);
 
 /* misc */
 int hv_threshold(const float* x, float* y, long long n, float thr, float value, void* stream); /* y = x > thr ? value : 0 (torch.where(seg > 0.5, ...)) */
