@@ -970,6 +970,8 @@ __global__ __launch_bounds__(256) void ca_fuse_adj_prep32_kernel(const float* __
         part[((long long)bb * 32 + (half ? jt : it)) * L + (half ? i0 : j0) + c] = s;
     }
 }
+// (Measured and not kept: every sample's last workgroup folding the 32 partials itself instead of the launch below -- 8 448 ticket atomics on 16 addresses
+// serialise at the memory side: the kernel went from ~85 to 124 us, with agent-scope release fences per workgroup to +0.4 ms per step; hv_common.h.)
 template <int NCH>
 __global__ void ca_coef_final_n_kernel(const float* __restrict__ part, const float* __restrict__ norm, float* __restrict__ coef, int L) {
     const long long b = blockIdx.y;

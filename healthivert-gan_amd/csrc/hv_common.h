@@ -217,6 +217,26 @@ __device__ __forceinline__ f32x4 hv_conv_value4(const HvEpi& e, const f32x4& a, 
 __device__ __forceinline__ void* hv_eptr(void* base, long long elem, int half) { return reinterpret_cast<char*>(base) + elem * (half ? 2 : 4); }
 __device__ __forceinline__ const void* hv_eptr(const void* base, long long elem, int half) { return reinterpret_cast<const char*>(base) + elem * (half ? 2 : 4); }
 
+// ---- "the last workgroup to arrive folds the partial results" -- for kernels of a FEW HUNDRED workgroups at most, and without agent-scope release fences.
+// On this multi-XCD part a release fence is a write-back of the XCD's whole L2 (buffer_wbl2 sc1): with thousands of workgroups each issuing one beside tens of
+// MB of ordinary stores the fences cost far more than the launch they save (round 5: the attention backward's coef fold +0.4 ms per step, the heads' bias sums
+// +0.16 ms).  Agent-scope ATOMIC stores are written through to the device's coherence point themselves (sc1), so the partial results go out with hv_publish(),
+// the writer waits for its stores (vmcnt counts stores on gfx9) and takes a ticket; the ONE last arriver calls hv_acquire_once() (one invalidate per kernel) and
+// reads the partial results with ordinary loads (hv_collect(), an agent-scope atomic load, for single values: hipcc issues those one round trip at a time,
+// 1 024 of them took 15 us).  What stays is the ticket itself: the atomics of all workgroups on one address serialise at the memory side, ~15 ns each -- 1 024
+// workgroups: 8 -> 22 us for head_seed_kernel, 8 448 on 16 addresses: 85 -> 124 us for the attention kernel, both slower than the 5-us launch they replaced
+// and removed again; at 113-256 workgroups (loss head, gradient check) the pattern pays.  Only values stored with hv_publish() are covered; what the last
+// arriver writes is read by LATER kernels.
+__device__ __forceinline__ void hv_publish(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float hv_collect(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void hv_acquire_once() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+__device__ __forceinline__ void hv_stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ bool hv_take_ticket_is_last(unsigned* ticket, unsigned n) {
+    return __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n - 1u;
+}
+__device__ __forceinline__ void hv_ticket_reset(unsigned* ticket) { __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+
 // ---- carried slab folds (hv_wgrad_desc.carry): the fold of the PREVIOUS weight gradient's split-K slabs runs as extra workgroups of this weight gradient's
 // launch (blockIdx.x >= the main grid's x extent, for every (y, z)) instead of a launch of its own between the two -- a dependent ~5-us node less per layer
 // on the backward's chains.  Same arithmetic as wgrad_reduce_kernel<G> (conv_igemm.hip), G by slab count: bit-identical sums.

@@ -522,21 +522,15 @@ __global__ __launch_bounds__(256) void gan_loss_head_pair_kernel(const float* __
     l = hv_block_sum(l, red);
     __syncthreads();
     gs = hv_block_sum(gs, red);
-    if (threadIdx.x == 0) { part[2 * blockIdx.x] = l; part[2 * blockIdx.x + 1] = gs; }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last = tk == (unsigned)(nb - 1);
-        if (last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+    if (threadIdx.x == 0) {      // (hv_common.h: publish / ticket / collect without agent-scope fences)
+        hv_publish(part + 2 * blockIdx.x, l);
+        hv_publish(part + 2 * blockIdx.x + 1, gs);
+        hv_stores_done();
+        last = hv_take_ticket_is_last(ticket, (unsigned)nb);
     }
     __syncthreads();
     if (!last) return;
+    hv_acquire_once();
     // the last arriver: per range, the partials in block order (lane k takes blocks k, k + 256, ..; block sum in hv_block_sum's fixed order)
     float gtot = 0.f;
     for (int rr = 0; rr < 2; ++rr) {
@@ -554,7 +548,7 @@ __global__ __launch_bounds__(256) void gan_loss_head_pair_kernel(const float* __
     }
     if (threadIdx.x == 0) {
         if (dbias) dbias[0] = bacc ? dbias[0] + gtot : gtot;
-        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (the next launch of the stream starts behind this kernel)
+        hv_ticket_reset(ticket);      // (the next launch of the stream starts behind this kernel)
     }
 }
 extern "C" size_t hv_gan_loss_head_pair_workspace_bytes(long long n0, long long n1) { return 2 * (size_t)((n0 + 255) / 256 + (n1 + 255) / 256) * sizeof(float) + 64; }

@@ -444,6 +444,8 @@ __global__ __launch_bounds__(256) void head_seed_kernel(const float* __restrict_
         s = hv_block_sum(s, red);
         if (threadIdx.x == 0) part[blockIdx.x] = s;
     }
+    // (Measured and not kept: the last of the 1 024 workgroups folding the block sums itself -- the ticket atomics on one address serialise: 8 -> 22 us for
+    // the 6-us launch it saves; hv_common.h.)
 }
 
 __global__ __launch_bounds__(64) void colsum_finalize_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ out, int accumulate);
@@ -636,7 +638,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const hv_adam_tensor* __restr
 // state[0] = step count, [1] = "this gradient is not finite" (set by the check, consumed by the tick), [2] = skipped steps so far, [3] = skip THIS step,
 // [4] = ticket of the check kernel's workgroups (an unsigned; back at zero when the launch ends)
 // One pass over the flat gradient: the loss scale taken out (mul, a power of two: exact; 1 = leave the values alone), the finite test on the way, and the
-// LAST workgroup to arrive (agent-scope release -> ticket -> acquire, as gan_loss_head_pair_kernel) does what used to be a one-thread launch between the check
+// LAST workgroup to arrive (publish -> ticket -> collect, hv_common.h) does what used to be a one-thread launch between the check
 // and the update: count the step or the skip, publish "skip this step", clear the flag.
 __global__ __launch_bounds__(256) void grad_unscale_check_kernel(float* __restrict__ g, long long n, float mul, float* __restrict__ state) {
     bool bad = false;
@@ -650,19 +652,16 @@ __global__ __launch_bounds__(256) void grad_unscale_check_kernel(float* __restri
             for (long long j = i; j < n; ++j) { bad |= !(fabsf(g[j]) <= 3.0e38f); if (scale) g[j] *= mul; }
         }
     }
-    if (__any(bad) && (threadIdx.x & 63) == 0) __hip_atomic_store(state + 1, 1.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // every writer stores the same value
+    if (__any(bad) && (threadIdx.x & 63) == 0) { hv_publish(state + 1, 1.f); hv_stores_done(); }      // every writer stores the same value
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0) {      // (hv_common.h: publish / ticket / collect without agent-scope fences -- a release fence here would also write back the gradients)
         unsigned* ticket = reinterpret_cast<unsigned*>(state + 4);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t == gridDim.x - 1) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            const bool any_bad = __hip_atomic_load(state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.f;
+        if (hv_take_ticket_is_last(ticket, gridDim.x)) {
+            const bool any_bad = hv_collect(state + 1) != 0.f;
             if (any_bad) state[2] += 1.f; else state[0] += 1.f;
             state[3] = any_bad ? 1.f : 0.f;
-            state[1] = 0.f;
-            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            hv_publish(state + 1, 0.f);
+            hv_ticket_reset(ticket);
         }
     }
 }
@@ -693,7 +692,7 @@ extern "C" int hv_adam_step_guarded(const hv_adam_tensor* d_tensors, int n_tenso
                                     float beta2, float eps, float* d_state, float* flat_grad, long long n_grad, float grad_mul, void* stream) {
     if (!d_tensors || n_tensors <= 0 || max_numel <= 0 || !d_lr || !d_state || !flat_grad || n_grad <= 0 || ((uintptr_t)flat_grad & 15) || !(grad_mul > 0.f))
         return HV_ERR_ARG;
-    const int blocks = (int)(n_grad / 4096 + 1 < 512 ? n_grad / 4096 + 1 : 512);
+    const int blocks = (int)(n_grad / 4096 + 1 < 256 ? n_grad / 4096 + 1 : 256);      // (every workgroup takes a ticket on one address: few of them)
     hipLaunchKernelGGL(grad_unscale_check_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, flat_grad, n_grad, grad_mul, d_state);
     HV_LAUNCH_CHECK();
     dim3 grid(hv_cdiv(max_numel, 1024), n_tensors);
