@@ -441,7 +441,7 @@ __global__ __launch_bounds__(512, 2) void conv_g4_kernel(const G4K p) {
 // fetched 1 MB of filters per 128-pixel x 64/128-channel tile straight into registers (537 MB of L2 -> CU traffic per launch, 2x the tensors'
 // HBM bytes); a 256-pixel x 128-channel tile halves that and both operands come from LDS.
 template <int DG, int MT, bool SPREAD>
-__global__ __launch_bounds__(512, 2) void conv_g4s1_kernel(const G4K p) {
+__device__ __forceinline__ void conv_g4s1_body(const G4K& p) {
     constexpr int TW = 16, TH = 4 * MT, PH = TH + 3, PW = 20;                // patch rows of 20 pixels (19 used): a row shift moves the swizzle phase by its parity only
     constexpr int NBP = (PH * PW + 15) / 16, BPW = (NBP + 7) / 8;
     static_assert(BPW <= 4, "one patch piece per tap");
@@ -612,6 +612,12 @@ __global__ __launch_bounds__(512, 2) void conv_g4s1_kernel(const G4K p) {
 #endif
 }
 
+// (two kernels over one body so that the profiled name of the production form stays conv_g4s1_kernel<DG, MT>)
+template <int DG, int MT>
+__global__ __launch_bounds__(512, 2) void conv_g4s1_kernel(const G4K p) { conv_g4s1_body<DG, MT, true>(p); }
+template <int DG, int MT>
+__global__ __launch_bounds__(512, 2) void conv_g4s1_headissue_kernel(const G4K p) { conv_g4s1_body<DG, MT, false>(p); }      // HV_G4S1_SPREAD=0: every piece at the sub-chunk's head
+
 template <int DG, int MT>
 static int launch_g4s1(G4K& k, int ny, hipStream_t s) {
     constexpr int TH = 4 * MT, PH = TH + 3, NBP = (PH * 20 + 15) / 16;
@@ -621,7 +627,7 @@ static int launch_g4s1(G4K& k, int ny, hipStream_t s) {
     k.tiles_x = hv_cdiv(k.Wc, 16);
     k.tiles = k.tiles_x * hv_cdiv(k.Hc, TH);
     static const int spread = getenv("HV_G4S1_SPREAD") ? atoi(getenv("HV_G4S1_SPREAD")) : 1;      // A/B knob (same bits): LDS-DMA pieces issued tap by tap
-    auto kern = spread ? conv_g4s1_kernel<DG, MT, true> : conv_g4s1_kernel<DG, MT, false>;
+    auto kern = spread ? conv_g4s1_kernel<DG, MT> : conv_g4s1_headissue_kernel<DG, MT>;
     static bool raised = false;
     if (!raised) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
