@@ -44,6 +44,8 @@ size_t hv_wgrad_halo_workspace_bytes(const hv_wgrad_desc* d);                  /
 int hv_wgrad_halo(const hv_wgrad_desc* d, int* nslabs, hipStream_t s);
 size_t hv_wgrad_tr_workspace_bytes(const hv_wgrad_desc* d);                    // wgrad_tr.hip
 int hv_wgrad_tr(const hv_wgrad_desc* d, int* nslabs, hipStream_t s);
+int hv_wgrad_thin(const hv_wgrad_desc* d, int* nslabs, hipStream_t s);      // wgrad_tr.hip: thin operands (at most 4 input channels / 1-channel gradient carriers)
+size_t hv_wgrad_thin_workspace_bytes(const hv_wgrad_desc* d);
 int hv_conv2d_narrow(const hv_conv_desc* d, hipStream_t s);                     // conv_narrow.hip
 int hv_conv2d_thin_in(const hv_conv_desc* d, hipStream_t s);
 int hv_conv2d_stem5(const hv_conv_desc* d, hipStream_t s);
@@ -962,6 +964,8 @@ static int wgrad_validate(const hv_wgrad_desc* d) {
 
 extern "C" size_t hv_conv2d_wgrad_workspace_bytes(const hv_wgrad_desc* d) {
     if (wgrad_validate(d) != HV_OK) return 0;
+    const size_t thin = hv_wgrad_thin_workspace_bytes(d);
+    if (thin) return thin;
     const size_t halo = hv_wgrad_halo_workspace_bytes(d);
     if (halo) return halo;
     const size_t trb = hv_wgrad_tr_workspace_bytes(d);
@@ -1026,7 +1030,8 @@ static int wgrad_dispatch(const hv_wgrad_desc* d, void* stream) {
     const long long nW = (long long)d->Cout * d->KH * d->KW * d->Cin;
     {   // single-output-channel VALU path (conv_narrow.hip), then the halo-tiled fast path (wgrad_halo.hip: 3x3 / 5x5, stride 1, fp16)
         int nslabs = 0;
-        rc = hv_wgrad_halo(d, &nslabs, (hipStream_t)stream);   // (measured: the VALU hv_wgrad_narrow is slower than the padded MFMA tiles)
+        rc = hv_wgrad_thin(d, &nslabs, (hipStream_t)stream);   // thin operands on the transposed-LDS-read kernel (round 5)
+        if (rc == HV_ERR_UNSUPPORTED) rc = hv_wgrad_halo(d, &nslabs, (hipStream_t)stream);   // (measured: the VALU hv_wgrad_narrow is slower than the padded MFMA tiles)
         if (rc == HV_ERR_UNSUPPORTED) rc = hv_wgrad_tr(d, &nslabs, (hipStream_t)stream);   // transposed-LDS-read form (fp16 storage)
         if (rc == HV_OK) {
             const float* bsl = d->dbias ? d->workspace + (long long)nslabs * nW : nullptr;

@@ -24,6 +24,7 @@
 
 typedef __fp16 hv_fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 struct WTrK {
     const _Float16* x; const _Float16* g; float* slabs;
@@ -53,13 +54,18 @@ __host__ __device__ constexpr int wtr_stride(int ch, int st) {
     return row + 16;                                                     // 16 B x odd (row is a multiple of 32)
 }
 
-template <int KS, int ST, int BN, int BC>
+// XT / GT (thin operands, round 5): the input (XT: at most 4 channels, the generators' 5x5 stems and the PatchGAN stem) or the gradient (GT: the 1-channel heads'
+// [pixel][4] carrier) has 8 bytes per pixel: a staging item is ONE pixel, loaded as 8 bytes and stored as the first 16 bytes of its 32-byte LDS row with zeros
+// behind; the row's second 16 bytes are zeroed once.  Everything else -- the transposed reads, the tap shifts, the slabs -- is the kernel as it stands
+// (wgrad_halo_kernel stages these tensors as 8 x 8-byte loads of 32-byte segments per unit and transposes in registers: 0.9 TB/s on the 5x5 stems).
+template <int KS, int ST, int BN, int BC, bool XT = false, bool GT = false>
 __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(const WTrK p) {
     constexpr int TH = 8, TW = 16, TAPS = KS * KS, SLOTS = (TAPS + 3) / 4;
     constexpr int PH = (TH - 1) * ST + KS, PW = (TW - 1) * ST + KS;
     constexpr int NT = BN / 16, CT = BC / 16;
     constexpr int SG = wtr_stride(BN, 1), SX = wtr_stride(BC, ST);       // bytes per pixel row
-    constexpr int GI = TH * TW * (BN / 8), XI = PH * PW * (BC / 8);       // 16-byte staging items
+    static_assert((!XT || (BC == 16 && SX == 32 + 16 * (ST - 1))) && (!GT || (BN == 16 && SG == 32)), "thin operands: one 16-channel block");
+    constexpr int GI = GT ? TH * TW : TH * TW * (BN / 8), XI = XT ? PH * PW : PH * PW * (BC / 8);       // staging items (16 bytes; thin: one pixel)
     constexpr int GPT = (GI + 255) / 256, XPT = (XI + 255) / 256;
     static_assert(NT * CT * SLOTS <= 32, "accumulator budget");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -98,8 +104,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(const WTrK p) {
 
     const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t gsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.g), 0, p.g_bytes, 0x00020000);
-    u32x4 rg[GPT], rx[XPT];
-    auto prefetch = [&](int tile) __attribute__((always_inline)) {
+    // thin operands: a tile is 128 pixels x 8 + 240 x 8 bytes and its MFMA section a fraction of a microsecond, so the tile loop would run at one memory round
+    // trip per tile: the loads of THREE tiles are in flight (two staging registers each)
+    constexpr int DEPTH = (XT || GT) ? 3 : 1;
+    u32x4 rgs[DEPTH][GPT], rxs[DEPTH][XPT];
+    auto prefetch = [&](int tile, auto SI) __attribute__((always_inline)) {
+        u32x4 (&rg)[GPT] = rgs[decltype(SI)::value];
+        u32x4 (&rx)[XPT] = rxs[decltype(SI)::value];
         const int n_img = tile / p.tiles_per_img;
         int tr = tile - n_img * p.tiles_per_img;
         // dilation d: tile of residue sub-grid (ry, rx); sub-grid pixel (y, x) is real pixel (ry + d y, rx + d x) of both tensors (d = 1: ry = rx = 0)
@@ -110,41 +121,50 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(const WTrK p) {
 #pragma unroll
         for (int i = 0; i < GPT; ++i) {
             const int e = tid + i * 256;
-            const int c8 = e % (BN / 8), pix = e / (BN / 8), ty = pix / TW, tx = pix - ty * TW;
+            const int c8 = GT ? 0 : e % (BN / 8), pix = GT ? e : e / (BN / 8), ty = pix / TW, tx = pix - ty * TW;
             const int oy = oy0 + ty, ox = ox0 + tx, co = co0 + c8 * 8;
             const bool ok = e < GI && oy < p.Ho && ox < p.Wo && co < p.Cout;
-            rg[i] = __builtin_amdgcn_raw_buffer_load_b128(gsrc, ok ? (unsigned)(((n_img * p.Hf + ry + d * oy) * p.Wf + rxo + d * ox) * p.g_ld + p.g_coff + co) * 2u : 0x80000000u, 0, 0);
+            const unsigned off = ok ? (unsigned)(((n_img * p.Hf + ry + d * oy) * p.Wf + rxo + d * ox) * p.g_ld + p.g_coff + co) * 2u : 0x80000000u;
+            if constexpr (GT) {
+                const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(gsrc, off, 0, 0));
+                rg[i] = u32x4{v.x, v.y, 0u, 0u};
+            } else rg[i] = __builtin_amdgcn_raw_buffer_load_b128(gsrc, off, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < XPT; ++i) {
             const int e = tid + i * 256;
-            const int c8 = e % (BC / 8), pix = e / (BC / 8), py = pix / PW, px = pix - py * PW;
+            const int c8 = XT ? 0 : e % (BC / 8), pix = XT ? e : e / (BC / 8), py = pix / PW, px = pix - py * PW;
             const int hi = oy0 * ST - p.pad + py, wi = ox0 * ST - p.pad + px, ci = ci0 + c8 * 8;
             const bool ok = e < XI && (unsigned)hi < (unsigned)p.Hl && (unsigned)wi < (unsigned)p.Wl && ci < p.Cin;
-            rx[i] = __builtin_amdgcn_raw_buffer_load_b128(
-                xsrc, ok ? (unsigned)(n_img * p.img_stride + (((ry + d * hi) >> p.in_shift) * p.Wp + ((rxo + d * wi) >> p.in_shift)) * p.x_ld + p.x_coff + ci) * 2u : 0x80000000u, 0, 0);
+            const unsigned off = ok ? (unsigned)(n_img * p.img_stride + (((ry + d * hi) >> p.in_shift) * p.Wp + ((rxo + d * wi) >> p.in_shift)) * p.x_ld + p.x_coff + ci) * 2u : 0x80000000u;
+            if constexpr (XT) {
+                const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(xsrc, off, 0, 0));
+                rx[i] = u32x4{v.x, v.y, 0u, 0u};
+            } else rx[i] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, off, 0, 0);
         }
     };
-    auto flush = [&]() __attribute__((always_inline)) {
+    auto flush = [&](auto SI) __attribute__((always_inline)) {
+        u32x4 (&rg)[GPT] = rgs[decltype(SI)::value];
+        u32x4 (&rx)[XPT] = rxs[decltype(SI)::value];
 #pragma unroll
         for (int i = 0; i < GPT; ++i) {
             const int e = tid + i * 256;
-            if (e < GI) *reinterpret_cast<u32x4*>(Gs + (e / (BN / 8)) * SG + (e % (BN / 8)) * 16) = rg[i];
+            if (e < GI) *reinterpret_cast<u32x4*>(Gs + (GT ? e : e / (BN / 8)) * SG + (GT ? 0 : e % (BN / 8)) * 16) = rg[i];
         }
 #pragma unroll
         for (int i = 0; i < XPT; ++i) {
             const int e = tid + i * 256;
-            if (e < XI) *reinterpret_cast<u32x4*>(Xs + (e / (BC / 8)) * SX + (e % (BC / 8)) * 16) = rx[i];
+            if (e < XI) *reinterpret_cast<u32x4*>(Xs + (XT ? e : e / (BC / 8)) * SX + (XT ? 0 : e % (BC / 8)) * 16) = rx[i];
         }
     };
     const f16x8 ones = {1, 1, 1, 1, 1, 1, 1, 1};
+    if constexpr (GT) for (int e = tid; e < TH * TW; e += 256) *reinterpret_cast<u32x4*>(Gs + e * SG + 16) = u32x4{0u, 0u, 0u, 0u};
+    if constexpr (XT) for (int e = tid; e < PH * PW; e += 256) *reinterpret_cast<u32x4*>(Xs + e * SX + 16) = u32x4{0u, 0u, 0u, 0u};
 
-    if ((int)blockIdx.x < p.ntiles) prefetch(blockIdx.x);
-    for (int tile = blockIdx.x; tile < p.ntiles; tile += p.gx) {
-        __syncthreads();   // previous tile's reads are done
-        flush();
-        __syncthreads();
-        if (tile + p.gx < p.ntiles) prefetch(tile + p.gx);   // next tile's loads fly behind this tile's MFMAs
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, (DEPTH > 1 ? 1 : 0)> S1;
+    typedef std::integral_constant<int, (DEPTH > 2 ? 2 : 0)> S2;
+    auto mfma_tile = [&]() __attribute__((always_inline)) {
         // software pipeline over the (k-step, tap slot) pairs of the tile: the transposed LDS reads of the next pair are issued before the MFMAs of
         // the current one (with the reads right in front of their MFMAs a wave alternated ~130 cycles of LDS latency with 128 cycles of MFMAs; at
         // one workgroup per CU nothing else filled the gaps)
@@ -162,6 +182,38 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(const WTrK p) {
                 bb[c] = (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             }
         };
+        if constexpr (XT || GT) {
+            // one 16 x 16 block pair: a (k-step, tap slot) stage would be ONE MFMA behind two dependent LDS reads -- the stage is the whole k-step (every slot's
+            // fragments of k-step ks + 1 are requested in front of the SLOTS MFMAs of k-step ks)
+            f16x8 aq[2][NT], bs[2][SLOTS][CT];
+            lda(0, aq[0]);
+#pragma unroll
+            for (int sl = 0; sl < SLOTS; ++sl) ldb(0, sl, bs[0][sl]);
+#pragma unroll
+            for (int ks = 0; ks < TH / 2; ++ks) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks + 1 < TH / 2) {
+                    lda(ks + 1, aq[(ks + 1) & 1]);
+#pragma unroll
+                    for (int sl = 0; sl < SLOTS; ++sl) ldb(ks + 1, sl, bs[(ks + 1) & 1][sl]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (do_bias) {
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) bacc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aq[ks & 1][n], ones, bacc[n], 0, 0, 0);
+                }
+#pragma unroll
+                for (int sl = 0; sl < SLOTS; ++sl) {
+                    if (wave + 4 * sl < TAPS) {     // wave-uniform (scalar) branch: MFMA ignores EXEC
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+#pragma unroll
+                            for (int c = 0; c < CT; ++c) acc[sl][n][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aq[ks & 1][n], bs[ks & 1][sl][c], acc[sl][n][c], 0, 0, 0);
+                    }
+                }
+            }
+            return;
+        }
         f16x8 aq[2][NT], bq[2][CT];
         lda(0, aq[0]);
         ldb(0, 0, bq[0]);
@@ -185,6 +237,35 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(const WTrK p) {
                         for (int c = 0; c < CT; ++c) acc[sl][n][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aq[ks & 1][n], bq[idx & 1][c], acc[sl][n][c], 0, 0, 0);
                 }
             }
+        }
+    };
+    if constexpr (DEPTH == 1) {
+        if ((int)blockIdx.x < p.ntiles) prefetch(blockIdx.x, S0());
+        for (int tile = blockIdx.x; tile < p.ntiles; tile += p.gx) {
+            __syncthreads();   // previous tile's reads are done
+            flush(S0());
+            __syncthreads();
+            if (tile + p.gx < p.ntiles) prefetch(tile + p.gx, S0());   // next tile's loads fly behind this tile's MFMAs
+            mfma_tile();
+        }
+    } else {
+        int tile = blockIdx.x;
+        if (tile < p.ntiles) prefetch(tile, S0());
+        if (tile + p.gx < p.ntiles) prefetch(tile + p.gx, S1());
+        auto one = [&](auto SA, auto SC) __attribute__((always_inline)) {      // tile from stage SA; the tile after next into the stage that was consumed last (SC)
+            __syncthreads();
+            flush(SA);
+            __syncthreads();
+            if (tile + 2 * p.gx < p.ntiles) prefetch(tile + 2 * p.gx, SC);
+            mfma_tile();
+            tile += p.gx;
+        };
+        while (tile < p.ntiles) {
+            one(S0(), S2());
+            if (tile >= p.ntiles) break;
+            one(S1(), S0());
+            if (tile >= p.ntiles) break;
+            one(S2(), S1());
         }
     }
     // ---- one slab per workgroup; D layout: row (= co) = (lane>>4)*4 + r, col (= ci) = lane & 15
@@ -624,6 +705,65 @@ static int launch_wtrd(const WTrK& k, const WTrPlan& pl, const hv_wgrad_desc* d,
     HV_TIMING_END(s);
     HV_LAUNCH_CHECK();
     return HV_OK;
+}
+
+// ---- thin operands (XT / GT): which layers, how many workgroups
+struct WThinPlan { int kind, gx; size_t lds; };      // kind 1: 5x5 stride 1, Cin <= 4 (the generators' stems)
+static bool wgrad_thin_plan(const hv_wgrad_desc* d, WThinPlan* pl) {
+    static const int enabled = getenv("HV_WGRAD_THIN") ? atoi(getenv("HV_WGRAD_THIN")) : 1;   // A/B knob
+    if (!enabled || d->precision != HV_F16 || !d->x_f16 || !d->g_f16 || d->KH != d->KW || d->dil != 1 || d->in_shift != 0) return false;
+    if (d->Ho != (d->H + 2 * d->pad - d->KH) / d->stride + 1 || d->Wo != (d->W + 2 * d->pad - d->KW) / d->stride + 1) return false;
+    pl->kind = 0;
+    if (d->KH == 5 && d->stride == 1 && d->Cin <= 4 && !(d->x_ld & 3) && !(d->x_coff & 3) && d->Cout <= 16 && !(d->Cout & 7) && !(d->g_ld & 7) && !(d->g_coff & 7)) pl->kind = 1;
+    if (!pl->kind) return false;
+    const int PH = 7 * d->stride + d->KH, PW = 15 * d->stride + d->KW;
+    pl->lds = (size_t)128 * 32 + (size_t)PH * PW * wtr_stride(16, d->stride);
+    const long long ntiles = (long long)d->B * hv_cdiv(d->Ho, 8) * hv_cdiv(d->Wo, 16);
+    static const int want = getenv("HV_WGRAD_THIN_WGS") ? atoi(getenv("HV_WGRAD_THIN_WGS")) : 1024;      // tuning knob
+    pl->gx = (int)(want < ntiles ? want : ntiles);
+    return true;
+}
+size_t hv_wgrad_thin_workspace_bytes(const hv_wgrad_desc* d) {
+    WThinPlan pl;
+    if (!wgrad_thin_plan(d, &pl)) return 0;
+    return (size_t)pl.gx * ((size_t)d->Cout * d->KH * d->KW * d->Cin + (d->dbias ? d->Cout : 0)) * sizeof(float);
+}
+template <int KS, int ST, int BN, int BC, bool XT, bool GT>
+static int launch_wthin(const WTrK& k, const WThinPlan& pl, const hv_wgrad_desc* d, hipStream_t s) {
+    auto kern = wgrad_tr_kernel<KS, ST, BN, BC, XT, GT>;
+    dim3 grid(pl.gx, hv_cdiv(d->Cout, BN), hv_cdiv(d->Cin, BC));
+    WTrK kk = k;
+    kk.fold.splits = 0;
+    const int fx = hv_carry_blocks((int)(grid.y * grid.z));
+    if (fx > 0) { kk.fold = hv_carry; hv_carry_taken = 1; grid.x += fx; }
+    hv_path_note = 12;
+    HV_KNAME("wgrad_tr_kernel<%d, %d, %d, %d, %s, %s>", KS, ST, BN, BC, XT ? "true" : "false", GT ? "true" : "false");
+    HV_TIMING_BEGIN(s);
+    hipLaunchKernelGGL(kern, grid, dim3(256), pl.lds < 4096 ? 4096 : pl.lds, s, kk);      // (>= 4 KB: the carried fold's workgroups use the launch's LDS)
+    HV_TIMING_END(s);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+int hv_wgrad_thin(const hv_wgrad_desc* d, int* nslabs, hipStream_t s) {
+    WThinPlan pl;
+    if (!wgrad_thin_plan(d, &pl)) return HV_ERR_UNSUPPORTED;
+    if (!d->workspace || d->workspace_bytes < hv_wgrad_thin_workspace_bytes(d)) return HV_ERR_WORKSPACE;
+    WTrK k;
+    k.x = reinterpret_cast<const _Float16*>(d->x); k.g = reinterpret_cast<const _Float16*>(d->g); k.slabs = d->workspace;
+    k.Hl = d->H; k.Wl = d->W; k.in_shift = 0; k.Wp = d->W;
+    k.img_stride = d->H * d->W * d->x_ld; k.x_ld = d->x_ld; k.x_coff = d->x_coff; k.Cin = d->Cin;
+    k.Ho = d->Ho; k.Wo = d->Wo; k.Hf = d->Ho; k.Wf = d->Wo; k.g_ld = d->g_ld; k.g_coff = d->g_coff; k.Cout = d->Cout; k.pad = d->pad;
+    k.dil = 1;
+    k.tiles_x = hv_cdiv(k.Wo, 16); k.tiles_per_sub = k.tiles_x * hv_cdiv(k.Ho, 8); k.tiles_per_img = k.tiles_per_sub; k.ntiles = k.tiles_per_img * d->B;
+    k.slab = (long long)d->Cout * d->KH * d->KW * d->Cin;
+    k.bias_out = d->dbias ? d->workspace + (long long)pl.gx * k.slab : nullptr;
+    k.dbg = 0;
+    k.gx = pl.gx;
+    k.fold.splits = 0;
+    k.x_bytes = (unsigned)((size_t)d->B * k.img_stride * sizeof(_Float16));
+    k.g_bytes = (unsigned)((size_t)d->B * d->Ho * d->Wo * d->g_ld * sizeof(_Float16));
+    *nslabs = pl.gx;
+    return launch_wthin<5, 1, 16, 16, true, false>(k, pl, d, s);
 }
 
 // returns HV_ERR_UNSUPPORTED when the shape does not qualify; on success the slabs (*nslabs of them) are in d->workspace

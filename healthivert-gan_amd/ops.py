@@ -287,6 +287,9 @@ class FoldChain:
 FOLD_CHAIN = os.environ.get('HV_FOLD_CHAIN', '1') != '0'      # A/B knob: 0 = every weight gradient folds its slabs in a launch of its own right away
 
 
+_DIAG_SKIP_WGRAD = frozenset(v for v in os.environ.get('HV_DIAG_SKIP_WGRAD', '').split(',') if v)
+
+
 def conv2d_wgrad(x, g, dw, k, stride=1, pad=0, dil=1, in_shift=0, accumulate=False, precision=None, cin=None, cout=None, dbias=None,
                  dbias_accumulate=False, chain=None):
     """dw[Cout][k*k][Cin] = sum_pixels g (x) x.  x: conv input view, g: gradient wrt the conv output.
@@ -296,6 +299,8 @@ def conv2d_wgrad(x, g, dw, k, stride=1, pad=0, dil=1, in_shift=0, accumulate=Fal
     L = _lib.get()
     d = L.hv_wgrad_desc()
     kh, kw = (k, k) if isinstance(k, int) else k
+    if _DIAG_SKIP_WGRAD and ('k%d' % kh in _DIAG_SKIP_WGRAD or ('thin' in _DIAG_SKIP_WGRAD and min(x.C if cin is None else cin, g.C if cout is None else cout) <= 16)):
+        return      # timing-only diagnostic (wrong parameter gradients): what a class of weight gradients costs the step
     d.x = ptr(x.t).value
     d.B, d.H, d.W, d.in_shift = x.B, x.H << in_shift, x.W << in_shift, in_shift
     d.x_ld, d.x_coff, d.Cin = x.ld, x.coff, (x.C if cin is None else cin)

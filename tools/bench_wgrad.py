@@ -34,7 +34,13 @@ def main():
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / iters * 1e3
     fl = 2.0 * B * Ho * Wo * Cout * k * k * Cin
-    print('W B%d %dx%d Cin%d->Cout%d k%d s%d %s: %.1f us  %.1f TF' % (B, H, W, Cin, Cout, k, s, prec, us, fl / us / 1e6))
+    chk = ''
+    if os.environ.get('CHECK') == '1':      # against torch's weight gradient of the stored (rounded) operands, fp32
+        xr, gr = x.t.float().permute(0, 3, 1, 2).contiguous(), gy.t.float().permute(0, 3, 1, 2).contiguous()
+        ref = torch.nn.grad.conv2d_weight(xr, (Cout, Cin, k, k), gr, stride=s, padding=p)      # [Cout][Cin][k][k]
+        ref = ref.permute(0, 2, 3, 1).reshape(Cout, k * k, Cin)
+        chk = '  max|d| %.3e of %.3e' % ((dw - ref).abs().max().item(), ref.abs().max().item())
+    print('W B%d %dx%d Cin%d->Cout%d k%d s%d %s: %.1f us  %.1f TF%s' % (B, H, W, Cin, Cout, k, s, prec, us, fl / us / 1e6, chk))
 
 
 if __name__ == '__main__':
