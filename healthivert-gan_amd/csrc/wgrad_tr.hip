@@ -54,18 +54,13 @@ __host__ __device__ constexpr int wtr_stride(int ch, int st) {
     return row + 16;                                                     // 16 B x odd (row is a multiple of 32)
 }
 
-// XT / GT (thin operands, round 5): the input (XT: at most 4 channels, the generators' 5x5 stems and the PatchGAN stem) or the gradient (GT: the 1-channel heads'
-// [pixel][4] carrier) has 8 bytes per pixel: a staging item is ONE pixel, loaded as 8 bytes and stored as the first 16 bytes of its 32-byte LDS row with zeros
-// behind; the row's second 16 bytes are zeroed once.  Everything else -- the transposed reads, the tap shifts, the slabs -- is the kernel as it stands
-// (wgrad_halo_kernel stages these tensors as 8 x 8-byte loads of 32-byte segments per unit and transposes in registers: 0.9 TB/s on the 5x5 stems).
-template <int KS, int ST, int BN, int BC, bool XT = false, bool GT = false>
+template <int KS, int ST, int BN, int BC>
 __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(const WTrK p) {
     constexpr int TH = 8, TW = 16, TAPS = KS * KS, SLOTS = (TAPS + 3) / 4;
     constexpr int PH = (TH - 1) * ST + KS, PW = (TW - 1) * ST + KS;
     constexpr int NT = BN / 16, CT = BC / 16;
     constexpr int SG = wtr_stride(BN, 1), SX = wtr_stride(BC, ST);       // bytes per pixel row
-    static_assert((!XT || (BC == 16 && SX == 32 + 16 * (ST - 1))) && (!GT || (BN == 16 && SG == 32)), "thin operands: one 16-channel block");
-    constexpr int GI = GT ? TH * TW : TH * TW * (BN / 8), XI = XT ? PH * PW : PH * PW * (BC / 8);       // staging items (16 bytes; thin: one pixel)
+    constexpr int GI = TH * TW * (BN / 8), XI = PH * PW * (BC / 8);       // 16-byte staging items
     constexpr int GPT = (GI + 255) / 256, XPT = (XI + 255) / 256;
     static_assert(NT * CT * SLOTS <= 32, "accumulator budget");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -104,13 +99,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(const WTrK p) {
 
     const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t gsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.g), 0, p.g_bytes, 0x00020000);
-    // thin operands: a tile is 128 pixels x 8 + 240 x 8 bytes and its MFMA section a fraction of a microsecond, so the tile loop would run at one memory round
-    // trip per tile: the loads of THREE tiles are in flight (two staging registers each)
-    constexpr int DEPTH = (XT || GT) ? 3 : 1;
-    u32x4 rgs[DEPTH][GPT], rxs[DEPTH][XPT];
-    auto prefetch = [&](int tile, auto SI) __attribute__((always_inline)) {
-        u32x4 (&rg)[GPT] = rgs[decltype(SI)::value];
-        u32x4 (&rx)[XPT] = rxs[decltype(SI)::value];
+    u32x4 rg[GPT], rx[XPT];
+    auto prefetch = [&](int tile) __attribute__((always_inline)) {
         const int n_img = tile / p.tiles_per_img;
         int tr = tile - n_img * p.tiles_per_img;
         // dilation d: tile of residue sub-grid (ry, rx); sub-grid pixel (y, x) is real pixel (ry + d y, rx + d x) of both tensors (d = 1: ry = rx = 0)
@@ -121,50 +111,41 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(const WTrK p) {
 #pragma unroll
         for (int i = 0; i < GPT; ++i) {
             const int e = tid + i * 256;
-            const int c8 = GT ? 0 : e % (BN / 8), pix = GT ? e : e / (BN / 8), ty = pix / TW, tx = pix - ty * TW;
+            const int c8 = e % (BN / 8), pix = e / (BN / 8), ty = pix / TW, tx = pix - ty * TW;
             const int oy = oy0 + ty, ox = ox0 + tx, co = co0 + c8 * 8;
             const bool ok = e < GI && oy < p.Ho && ox < p.Wo && co < p.Cout;
-            const unsigned off = ok ? (unsigned)(((n_img * p.Hf + ry + d * oy) * p.Wf + rxo + d * ox) * p.g_ld + p.g_coff + co) * 2u : 0x80000000u;
-            if constexpr (GT) {
-                const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(gsrc, off, 0, 0));
-                rg[i] = u32x4{v.x, v.y, 0u, 0u};
-            } else rg[i] = __builtin_amdgcn_raw_buffer_load_b128(gsrc, off, 0, 0);
+            rg[i] = __builtin_amdgcn_raw_buffer_load_b128(gsrc, ok ? (unsigned)(((n_img * p.Hf + ry + d * oy) * p.Wf + rxo + d * ox) * p.g_ld + p.g_coff + co) * 2u : 0x80000000u, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < XPT; ++i) {
             const int e = tid + i * 256;
-            const int c8 = XT ? 0 : e % (BC / 8), pix = XT ? e : e / (BC / 8), py = pix / PW, px = pix - py * PW;
+            const int c8 = e % (BC / 8), pix = e / (BC / 8), py = pix / PW, px = pix - py * PW;
             const int hi = oy0 * ST - p.pad + py, wi = ox0 * ST - p.pad + px, ci = ci0 + c8 * 8;
             const bool ok = e < XI && (unsigned)hi < (unsigned)p.Hl && (unsigned)wi < (unsigned)p.Wl && ci < p.Cin;
-            const unsigned off = ok ? (unsigned)(n_img * p.img_stride + (((ry + d * hi) >> p.in_shift) * p.Wp + ((rxo + d * wi) >> p.in_shift)) * p.x_ld + p.x_coff + ci) * 2u : 0x80000000u;
-            if constexpr (XT) {
-                const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(xsrc, off, 0, 0));
-                rx[i] = u32x4{v.x, v.y, 0u, 0u};
-            } else rx[i] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, off, 0, 0);
+            rx[i] = __builtin_amdgcn_raw_buffer_load_b128(
+                xsrc, ok ? (unsigned)(n_img * p.img_stride + (((ry + d * hi) >> p.in_shift) * p.Wp + ((rxo + d * wi) >> p.in_shift)) * p.x_ld + p.x_coff + ci) * 2u : 0x80000000u, 0, 0);
         }
     };
-    auto flush = [&](auto SI) __attribute__((always_inline)) {
-        u32x4 (&rg)[GPT] = rgs[decltype(SI)::value];
-        u32x4 (&rx)[XPT] = rxs[decltype(SI)::value];
+    auto flush = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < GPT; ++i) {
             const int e = tid + i * 256;
-            if (e < GI) *reinterpret_cast<u32x4*>(Gs + (GT ? e : e / (BN / 8)) * SG + (GT ? 0 : e % (BN / 8)) * 16) = rg[i];
+            if (e < GI) *reinterpret_cast<u32x4*>(Gs + (e / (BN / 8)) * SG + (e % (BN / 8)) * 16) = rg[i];
         }
 #pragma unroll
         for (int i = 0; i < XPT; ++i) {
             const int e = tid + i * 256;
-            if (e < XI) *reinterpret_cast<u32x4*>(Xs + (XT ? e : e / (BC / 8)) * SX + (XT ? 0 : e % (BC / 8)) * 16) = rx[i];
+            if (e < XI) *reinterpret_cast<u32x4*>(Xs + (e / (BC / 8)) * SX + (e % (BC / 8)) * 16) = rx[i];
         }
     };
     const f16x8 ones = {1, 1, 1, 1, 1, 1, 1, 1};
-    if constexpr (GT) for (int e = tid; e < TH * TW; e += 256) *reinterpret_cast<u32x4*>(Gs + e * SG + 16) = u32x4{0u, 0u, 0u, 0u};
-    if constexpr (XT) for (int e = tid; e < PH * PW; e += 256) *reinterpret_cast<u32x4*>(Xs + e * SX + 16) = u32x4{0u, 0u, 0u, 0u};
 
-    typedef std::integral_constant<int, 0> S0;
-    typedef std::integral_constant<int, (DEPTH > 1 ? 1 : 0)> S1;
-    typedef std::integral_constant<int, (DEPTH > 2 ? 2 : 0)> S2;
-    auto mfma_tile = [&]() __attribute__((always_inline)) {
+    if ((int)blockIdx.x < p.ntiles) prefetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += p.gx) {
+        __syncthreads();   // previous tile's reads are done
+        flush();
+        __syncthreads();
+        if (tile + p.gx < p.ntiles) prefetch(tile + p.gx);   // next tile's loads fly behind this tile's MFMAs
         // software pipeline over the (k-step, tap slot) pairs of the tile: the transposed LDS reads of the next pair are issued before the MFMAs of
         // the current one (with the reads right in front of their MFMAs a wave alternated ~130 cycles of LDS latency with 128 cycles of MFMAs; at
         // one workgroup per CU nothing else filled the gaps)
@@ -182,38 +163,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(const WTrK p) {
                 bb[c] = (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             }
         };
-        if constexpr (XT || GT) {
-            // one 16 x 16 block pair: a (k-step, tap slot) stage would be ONE MFMA behind two dependent LDS reads -- the stage is the whole k-step (every slot's
-            // fragments of k-step ks + 1 are requested in front of the SLOTS MFMAs of k-step ks)
-            f16x8 aq[2][NT], bs[2][SLOTS][CT];
-            lda(0, aq[0]);
-#pragma unroll
-            for (int sl = 0; sl < SLOTS; ++sl) ldb(0, sl, bs[0][sl]);
-#pragma unroll
-            for (int ks = 0; ks < TH / 2; ++ks) {
-                __builtin_amdgcn_sched_barrier(0);
-                if (ks + 1 < TH / 2) {
-                    lda(ks + 1, aq[(ks + 1) & 1]);
-#pragma unroll
-                    for (int sl = 0; sl < SLOTS; ++sl) ldb(ks + 1, sl, bs[(ks + 1) & 1][sl]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (do_bias) {
-#pragma unroll
-                    for (int n = 0; n < NT; ++n) bacc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aq[ks & 1][n], ones, bacc[n], 0, 0, 0);
-                }
-#pragma unroll
-                for (int sl = 0; sl < SLOTS; ++sl) {
-                    if (wave + 4 * sl < TAPS) {     // wave-uniform (scalar) branch: MFMA ignores EXEC
-#pragma unroll
-                        for (int n = 0; n < NT; ++n)
-#pragma unroll
-                            for (int c = 0; c < CT; ++c) acc[sl][n][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aq[ks & 1][n], bs[ks & 1][sl][c], acc[sl][n][c], 0, 0, 0);
-                    }
-                }
-            }
-            return;
-        }
         f16x8 aq[2][NT], bq[2][CT];
         lda(0, aq[0]);
         ldb(0, 0, bq[0]);
@@ -237,35 +186,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(const WTrK p) {
                         for (int c = 0; c < CT; ++c) acc[sl][n][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aq[ks & 1][n], bq[idx & 1][c], acc[sl][n][c], 0, 0, 0);
                 }
             }
-        }
-    };
-    if constexpr (DEPTH == 1) {
-        if ((int)blockIdx.x < p.ntiles) prefetch(blockIdx.x, S0());
-        for (int tile = blockIdx.x; tile < p.ntiles; tile += p.gx) {
-            __syncthreads();   // previous tile's reads are done
-            flush(S0());
-            __syncthreads();
-            if (tile + p.gx < p.ntiles) prefetch(tile + p.gx, S0());   // next tile's loads fly behind this tile's MFMAs
-            mfma_tile();
-        }
-    } else {
-        int tile = blockIdx.x;
-        if (tile < p.ntiles) prefetch(tile, S0());
-        if (tile + p.gx < p.ntiles) prefetch(tile + p.gx, S1());
-        auto one = [&](auto SA, auto SC) __attribute__((always_inline)) {      // tile from stage SA; the tile after next into the stage that was consumed last (SC)
-            __syncthreads();
-            flush(SA);
-            __syncthreads();
-            if (tile + 2 * p.gx < p.ntiles) prefetch(tile + 2 * p.gx, SC);
-            mfma_tile();
-            tile += p.gx;
-        };
-        while (tile < p.ntiles) {
-            one(S0(), S2());
-            if (tile >= p.ntiles) break;
-            one(S1(), S0());
-            if (tile >= p.ntiles) break;
-            one(S2(), S1());
         }
     }
     // ---- one slab per workgroup; D layout: row (= co) = (lane>>4)*4 + r, col (= ci) = lane & 15
@@ -707,19 +627,196 @@ static int launch_wtrd(const WTrK& k, const WTrPlan& pl, const hv_wgrad_desc* d,
     return HV_OK;
 }
 
-// ---- thin operands (XT / GT): which layers, how many workgroups
-struct WThinPlan { int kind, gx; size_t lds; };      // kind 1: 5x5 stride 1, Cin <= 4 (the generators' stems)
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Thin INPUT (at most 4 channels: the generators' 5x5 stems, the PatchGAN stem), round 5.  With the input padded to a 16-channel block every tap is an MFMA whose
+// B operand is 3/4 zeros and whose fragments are read per tap: wgrad_tr_kernel with the 8-byte pixels staged into 16-channel rows (tried first: 58.9 -> 29.8 us) moves
+// 131 KB through LDS per 6-KB tile and runs at one tile per microsecond and CU whatever the occupancy and the load depth (wgrad_halo_kernel, which served these
+// layers, also stages them as 8-byte loads of 32-byte segments and transposes in registers: 0.9 TB/s).  Here the GEMM's N is (tap, channel): a transposed read takes one ADDRESS PER LANE, the four lanes (qr = 0 .. 3) of a quad share pc, give
+// the addresses of four consecutive pixels and receive channel qr of them -- so pc can be a TAP: quad pc reads the 8-byte pixels at tap pc's shift, and the fragment's
+// column lane & 15 = 4 pc + e is (tap 4 j + pc, channel e).  25 taps are 7 N tiles instead of 25, the patch sits in LDS as it sits in memory (8 bytes per pixel), and
+// the k-steps of a tile (two tile rows each) are dealt to the four waves, so every fragment is read once: 32 KB of LDS reads per tile.  The waves' accumulators
+// are summed in LDS in wave order at the end (deterministic); one slab per workgroup as everywhere.
+template <int KS, int ST, int BN>
+__global__ __launch_bounds__(256, 2) void wgrad_thinx_kernel(const WTrK p) {
+    constexpr int TH = 8, TW = 16, TAPS = KS * KS, NTN = (TAPS + 3) / 4, NT = BN / 16;
+    constexpr int PH = (TH - 1) * ST + KS, PW = (TW - 1) * ST + KS;
+    constexpr int SG = wtr_stride(BN, 1);
+    constexpr int GI = TH * TW * (BN / 8), XI = PH * PW;
+    constexpr int GPT = (GI + 255) / 256, XPT = (XI + 255) / 256;
+    constexpr int XBYTES = (XI * 8 + 15) / 16 * 16;
+    static_assert(NT * NTN <= 16, "accumulator budget");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Gs = smem;                               // [TH*TW][SG]
+    char* Xs = smem + TH * TW * SG;                // [PH*PW][8 bytes]
+    float* red = reinterpret_cast<float*>(smem);   // [NT][NTN][256] (+ [NT][16] bias) after the tile loop
+
+    if ((int)blockIdx.x >= p.gx) {      // (block-uniform) the carried fold's workgroups
+        const int fx = (int)gridDim.x - p.gx;
+        hv_fold_blocks(p.fold, ((int)blockIdx.x - p.gx) + fx * ((int)blockIdx.y + (int)gridDim.y * (int)blockIdx.z), fx * (int)gridDim.y * (int)gridDim.z, smem);
+        return;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int co0 = blockIdx.y * BN;
+    const int grp = lane >> 4, sub = lane & 15, qr = sub >> 2, pc = sub & 3;
+    f32x4 acc[NT][NTN];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int j = 0; j < NTN; ++j) acc[n][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = p.bias_out != nullptr;
+    f32x4 bacc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) bacc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // this wave's k-step = tile rows 2 wave, 2 wave + 1
+    const _Float16* ga = reinterpret_cast<const _Float16*>(Gs + ((2 * wave) * TW + 4 * grp + qr) * SG + pc * 8);
+    const _Float16* xb[NTN];
+#pragma unroll
+    for (int j = 0; j < NTN; ++j) {
+        const int t = 4 * j + pc, tt = t < TAPS ? t : 0, r = tt / KS, q = tt - r * KS;      // (a tap beyond the filter: any address, its columns are not stored)
+        xb[j] = reinterpret_cast<const _Float16*>(Xs + ((((2 * wave) * ST + r) * PW) + (4 * grp + qr) * ST + q) * 8);
+    }
+    const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t gsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.g), 0, p.g_bytes, 0x00020000);
+    constexpr int DEPTH = BN > 16 ? 2 : 3;      // tiles of loads in flight (a tile's MFMA section is a fraction of a microsecond; 64-filter blocks: register budget)
+    u32x4 rgs[DEPTH][GPT];
+    u32x2 rxs[DEPTH][XPT];
+    auto prefetch = [&](int tile, auto SI) __attribute__((always_inline)) {
+        u32x4 (&rg)[GPT] = rgs[decltype(SI)::value];
+        u32x2 (&rx)[XPT] = rxs[decltype(SI)::value];
+        const int n_img = tile / p.tiles_per_img, tr = tile - n_img * p.tiles_per_img;
+        const int oy0 = (tr / p.tiles_x) * TH, ox0 = (tr % p.tiles_x) * TW;
+#pragma unroll
+        for (int i = 0; i < GPT; ++i) {
+            const int e = tid + i * 256;
+            const int c8 = e % (BN / 8), pix = e / (BN / 8), ty = pix / TW, tx = pix - ty * TW;
+            const int oy = oy0 + ty, ox = ox0 + tx, co = co0 + c8 * 8;
+            const bool ok = e < GI && oy < p.Ho && ox < p.Wo && co < p.Cout;
+            rg[i] = __builtin_amdgcn_raw_buffer_load_b128(gsrc, ok ? (unsigned)(((n_img * p.Ho + oy) * p.Wo + ox) * p.g_ld + p.g_coff + co) * 2u : 0x80000000u, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            const int e = tid + i * 256;
+            const int py = e / PW, px = e - py * PW;
+            const int hi = oy0 * ST - p.pad + py, wi = ox0 * ST - p.pad + px;
+            const bool ok = e < XI && (unsigned)hi < (unsigned)p.Hl && (unsigned)wi < (unsigned)p.Wl;
+            rx[i] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(xsrc, ok ? (unsigned)(n_img * p.img_stride + (hi * p.Wp + wi) * p.x_ld + p.x_coff) * 2u : 0x80000000u, 0, 0));
+        }
+    };
+    auto flush = [&](auto SI) __attribute__((always_inline)) {
+        u32x4 (&rg)[GPT] = rgs[decltype(SI)::value];
+        u32x2 (&rx)[XPT] = rxs[decltype(SI)::value];
+#pragma unroll
+        for (int i = 0; i < GPT; ++i) {
+            const int e = tid + i * 256;
+            if (e < GI) *reinterpret_cast<u32x4*>(Gs + (e / (BN / 8)) * SG + (e % (BN / 8)) * 16) = rg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            const int e = tid + i * 256;
+            if (e < XI) *reinterpret_cast<u32x2*>(Xs + e * 8) = rx[i];
+        }
+    };
+    const f16x8 ones = {1, 1, 1, 1, 1, 1, 1, 1};
+    auto mfma_tile = [&]() __attribute__((always_inline)) {
+        f16x8 a[NT], b[NTN];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const f16x4 lo = tr_read(ga + (n * 32) / 2), hi = tr_read(ga + (TW * SG + n * 32) / 2);
+            a[n] = (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+#pragma unroll
+        for (int j = 0; j < NTN; ++j) {
+            const f16x4 lo = tr_read(xb[j]), hi = tr_read(xb[j] + (ST * PW * 8) / 2);
+            b[j] = (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+        if (do_bias) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) bacc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[n], ones, bacc[n], 0, 0, 0);
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int j = 0; j < NTN; ++j) acc[n][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[n], b[j], acc[n][j], 0, 0, 0);
+    };
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, 1> S1;
+    typedef std::integral_constant<int, (DEPTH > 2 ? 2 : 0)> S2;
+    int tile = blockIdx.x;
+    if (tile < p.ntiles) prefetch(tile, S0());
+    if (DEPTH > 2 && tile + p.gx < p.ntiles) prefetch(tile + p.gx, S1());
+    auto one = [&](auto SA, auto SC) __attribute__((always_inline)) {      // the tile staged in SA; the loads of tile + (DEPTH - 1) gx into SC
+        __syncthreads();
+        flush(SA);
+        __syncthreads();
+        if (tile + (DEPTH - 1) * p.gx < p.ntiles) prefetch(tile + (DEPTH - 1) * p.gx, SC);
+        mfma_tile();
+        tile += p.gx;
+    };
+    while (tile < p.ntiles) {
+        if constexpr (DEPTH > 2) {
+            one(S0(), S2());
+            if (tile >= p.ntiles) break;
+            one(S1(), S0());
+            if (tile >= p.ntiles) break;
+            one(S2(), S1());
+        } else {
+            one(S0(), S1());
+            if (tile >= p.ntiles) break;
+            one(S1(), S0());
+        }
+    }
+    // ---- the four waves' sums in wave order; D layout: row (= co) = 4 (lane >> 4) + r, column lane & 15 = (tap 4 j + (column >> 2), channel column & 3)
+    __syncthreads();
+    for (int wv = 0; wv < 4; ++wv) {
+        if (wave == wv) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+#pragma unroll
+                for (int j = 0; j < NTN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float* d = red + ((n * NTN + j) * 16 + 4 * (lane >> 4) + r) * 16 + (lane & 15);
+                        *d = wv == 0 ? acc[n][j][r] : *d + acc[n][j][r];
+                    }
+                if (do_bias && (lane & 15) == 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float* d = red + NT * NTN * 256 + n * 16 + 4 * (lane >> 4) + r;
+                        *d = wv == 0 ? bacc[n][r] : *d + bacc[n][r];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float* out = p.slabs + (long long)blockIdx.x * p.slab;
+    for (int e = tid; e < NT * NTN * 256; e += 256) {
+        const int col = e & 15, row = (e >> 4) & 15, nj = e >> 8, j = nj % NTN, n = nj / NTN;
+        const int t = 4 * j + (col >> 2), ci = col & 3, co = co0 + n * 16 + row;
+        if (t < TAPS && ci < p.Cin && co < p.Cout) out[((long long)co * TAPS + t) * p.Cin + ci] = red[e];
+    }
+    if (do_bias && tid < BN && co0 + tid < p.Cout) p.bias_out[(long long)blockIdx.x * p.Cout + co0 + tid] = red[NT * NTN * 256 + tid];
+}
+
+// ---- thin input: which layers, how many workgroups
+struct WThinPlan { int kind, gx; size_t lds; };      // kind 1: 5x5 stride 1, Cin <= 4, Cout <= 16 (the generators' stems)
 static bool wgrad_thin_plan(const hv_wgrad_desc* d, WThinPlan* pl) {
     static const int enabled = getenv("HV_WGRAD_THIN") ? atoi(getenv("HV_WGRAD_THIN")) : 1;   // A/B knob
     if (!enabled || d->precision != HV_F16 || !d->x_f16 || !d->g_f16 || d->KH != d->KW || d->dil != 1 || d->in_shift != 0) return false;
     if (d->Ho != (d->H + 2 * d->pad - d->KH) / d->stride + 1 || d->Wo != (d->W + 2 * d->pad - d->KW) / d->stride + 1) return false;
+    if (d->Cin > 4 || (d->x_ld & 3) || (d->x_coff & 3) || (d->Cout & 7) || (d->g_ld & 7) || (d->g_coff & 7)) return false;
     pl->kind = 0;
-    if (d->KH == 5 && d->stride == 1 && d->Cin <= 4 && !(d->x_ld & 3) && !(d->x_coff & 3) && d->Cout <= 16 && !(d->Cout & 7) && !(d->g_ld & 7) && !(d->g_coff & 7)) pl->kind = 1;
+    if (d->KH == 5 && d->stride == 1 && d->Cout <= 16) pl->kind = 1;
+    // (Measured and not kept: the PatchGAN stem -- 4x4 stride 2, 1 -> 64 -- as wgrad_thinx_kernel<4, 2, 64>: 249 registers, two tiles of loads in flight, 33.3 / 26.9 us
+    // at B32 / B16 against the gather kernel's 30.2 / 19.1: its time is the 67 MB of g, which both read once.)
     if (!pl->kind) return false;
+    const int BN = 16, TAPS = d->KH * d->KW, NTN = (TAPS + 3) / 4;
     const int PH = 7 * d->stride + d->KH, PW = 15 * d->stride + d->KW;
-    pl->lds = (size_t)128 * 32 + (size_t)PH * PW * wtr_stride(16, d->stride);
+    const size_t stage = (size_t)128 * wtr_stride(BN, 1) + (size_t)(PH * PW * 8 + 15) / 16 * 16, red = (size_t)(BN / 16) * (NTN * 256 + 16) * 4;
+    pl->lds = stage > red ? stage : red;
+    if (pl->lds < 4096) pl->lds = 4096;      // (the carried fold's workgroups use the launch's LDS)
     const long long ntiles = (long long)d->B * hv_cdiv(d->Ho, 8) * hv_cdiv(d->Wo, 16);
-    static const int want = getenv("HV_WGRAD_THIN_WGS") ? atoi(getenv("HV_WGRAD_THIN_WGS")) : 1024;      // tuning knob
+    static const int want = getenv("HV_WGRAD_THIN_WGS") ? atoi(getenv("HV_WGRAD_THIN_WGS")) : 512;      // tuning knob (kernel + fold, us at 128 / 256 / 384 / 512 / 768 / 1024: 41.5 / 26.1 / 22.0 / 19.7 / 20.9 / 23.8)
     pl->gx = (int)(want < ntiles ? want : ntiles);
     return true;
 }
@@ -728,18 +825,18 @@ size_t hv_wgrad_thin_workspace_bytes(const hv_wgrad_desc* d) {
     if (!wgrad_thin_plan(d, &pl)) return 0;
     return (size_t)pl.gx * ((size_t)d->Cout * d->KH * d->KW * d->Cin + (d->dbias ? d->Cout : 0)) * sizeof(float);
 }
-template <int KS, int ST, int BN, int BC, bool XT, bool GT>
-static int launch_wthin(const WTrK& k, const WThinPlan& pl, const hv_wgrad_desc* d, hipStream_t s) {
-    auto kern = wgrad_tr_kernel<KS, ST, BN, BC, XT, GT>;
-    dim3 grid(pl.gx, hv_cdiv(d->Cout, BN), hv_cdiv(d->Cin, BC));
+template <int KS, int ST, int BN>
+static int launch_wthinx(const WTrK& k, const WThinPlan& pl, const hv_wgrad_desc* d, hipStream_t s) {
+    auto kern = wgrad_thinx_kernel<KS, ST, BN>;
+    dim3 grid(pl.gx, hv_cdiv(d->Cout, BN), 1);
     WTrK kk = k;
     kk.fold.splits = 0;
-    const int fx = hv_carry_blocks((int)(grid.y * grid.z));
+    const int fx = hv_carry_blocks((int)grid.y);
     if (fx > 0) { kk.fold = hv_carry; hv_carry_taken = 1; grid.x += fx; }
     hv_path_note = 12;
-    HV_KNAME("wgrad_tr_kernel<%d, %d, %d, %d, %s, %s>", KS, ST, BN, BC, XT ? "true" : "false", GT ? "true" : "false");
+    HV_KNAME("wgrad_thinx_kernel<%d, %d, %d>", KS, ST, BN);
     HV_TIMING_BEGIN(s);
-    hipLaunchKernelGGL(kern, grid, dim3(256), pl.lds < 4096 ? 4096 : pl.lds, s, kk);      // (>= 4 KB: the carried fold's workgroups use the launch's LDS)
+    hipLaunchKernelGGL(kern, grid, dim3(256), pl.lds, s, kk);
     HV_TIMING_END(s);
     HV_LAUNCH_CHECK();
     return HV_OK;
@@ -763,7 +860,7 @@ int hv_wgrad_thin(const hv_wgrad_desc* d, int* nslabs, hipStream_t s) {
     k.x_bytes = (unsigned)((size_t)d->B * k.img_stride * sizeof(_Float16));
     k.g_bytes = (unsigned)((size_t)d->B * d->Ho * d->Wo * d->g_ld * sizeof(_Float16));
     *nslabs = pl.gx;
-    return launch_wthin<5, 1, 16, 16, true, false>(k, pl, d, s);
+    return launch_wthinx<5, 1, 16>(k, pl, d, s);
 }
 
 // returns HV_ERR_UNSUPPORTED when the shape does not qualify; on success the slabs (*nslabs of them) are in d->workspace
