@@ -798,26 +798,186 @@ __global__ __launch_bounds__(256, 2) void wgrad_thinx_kernel(const WTrK p) {
     if (do_bias && tid < BN && co0 + tid < p.Cout) p.bias_out[(long long)blockIdx.x * p.Cout + co0 + tid] = red[NT * NTN * 256 + tid];
 }
 
+// Thin GRADIENT (the 1-channel heads: g is a [pixel][4] carrier), the mirror image: the sum runs over INPUT pixels, dW[co][(r, q)][ci] = sum_{iy, ix}
+// x[iy][ix][ci] * g[iy + pad - r][ix + pad - q][co], so the shifted 8-byte operand is g (shift KS - 1 - r inside a patch that starts KS - 1 - pad pixels before
+// the tile) and the wide one is the x tile; the MFMA's rows are input channels, its columns (tap, co) -- stored transposed into the slab.  Stride 1 only.
+// IB: bytes per staging item of x (16, or 8 where the channel stride is not a multiple of 8: the 12-channel head input).
+template <int KS, int BN, int IB>
+__global__ __launch_bounds__(256, 2) void wgrad_thing_kernel(const WTrK p) {
+    constexpr int TH = 8, TW = 16, TAPS = KS * KS, NTN = (TAPS + 3) / 4, NT = BN / 16;
+    constexpr int PH = TH + KS - 1, PW = TW + KS - 1;
+    constexpr int SX = wtr_stride(BN, 1);
+    constexpr int IPP = BN * 2 / IB;               // staging items per pixel
+    constexpr int XI = TH * TW * IPP, GI = PH * PW;
+    constexpr int XPT = (XI + 255) / 256, GPT = (GI + 255) / 256;
+    static_assert(NT * NTN <= 16 && (IB == 8 || IB == 16), "accumulator budget / item size");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Xs = smem;                               // [TH*TW][SX]   the x tile
+    char* Ts = smem + TH * TW * SX;                // [PH*PW][8 bytes]   the g patch
+    float* red = reinterpret_cast<float*>(smem);   // [NT][NTN][256] after the tile loop
+
+    if ((int)blockIdx.x >= p.gx) {      // (block-uniform) the carried fold's workgroups
+        const int fx = (int)gridDim.x - p.gx;
+        hv_fold_blocks(p.fold, ((int)blockIdx.x - p.gx) + fx * ((int)blockIdx.y + (int)gridDim.y * (int)blockIdx.z), fx * (int)gridDim.y * (int)gridDim.z, smem);
+        return;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ci0 = blockIdx.y * BN;
+    const int grp = lane >> 4, sub = lane & 15, qr = sub >> 2, pc = sub & 3;
+    f32x4 acc[NT][NTN];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int j = 0; j < NTN; ++j) acc[n][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const _Float16* xa = reinterpret_cast<const _Float16*>(Xs + ((2 * wave) * TW + 4 * grp + qr) * SX + pc * 8);
+    const _Float16* tb[NTN];
+#pragma unroll
+    for (int j = 0; j < NTN; ++j) {
+        const int t = 4 * j + pc, tt = t < TAPS ? t : 0, r = tt / KS, q = tt - r * KS;
+        tb[j] = reinterpret_cast<const _Float16*>(Ts + (((2 * wave) + (KS - 1 - r)) * PW + (4 * grp + qr) + (KS - 1 - q)) * 8);
+    }
+    const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t gsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.g), 0, p.g_bytes, 0x00020000);
+    constexpr int DEPTH = BN > 16 ? 2 : 3;
+    u32x4 rxs[DEPTH][XPT];
+    u32x2 rgs[DEPTH][GPT];
+    if constexpr (IB == 8 && (IPP & 3)) {}      // (rows shorter than the block: the tail of a row is zeroed below)
+    auto prefetch = [&](int tile, auto SI) __attribute__((always_inline)) {
+        u32x4 (&rx)[XPT] = rxs[decltype(SI)::value];
+        u32x2 (&rg)[GPT] = rgs[decltype(SI)::value];
+        const int n_img = tile / p.tiles_per_img, tr = tile - n_img * p.tiles_per_img;
+        const int iy0 = (tr / p.tiles_x) * TH, ix0 = (tr % p.tiles_x) * TW;
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            const int e = tid + i * 256;
+            const int it = e % IPP, pix = e / IPP, ty = pix / TW, tx = pix - ty * TW;
+            const int iy = iy0 + ty, ix = ix0 + tx, ci = ci0 + it * (IB / 2);
+            const bool ok = e < XI && iy < p.Hl && ix < p.Wl && ci < p.Cin;
+            const unsigned off = ok ? (unsigned)(n_img * p.img_stride + (iy * p.Wp + ix) * p.x_ld + p.x_coff + ci) * 2u : 0x80000000u;
+            if constexpr (IB == 16) rx[i] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, off, 0, 0);
+            else { const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(xsrc, off, 0, 0)); rx[i] = u32x4{v.x, v.y, 0u, 0u}; }
+        }
+#pragma unroll
+        for (int i = 0; i < GPT; ++i) {
+            const int e = tid + i * 256;
+            const int py = e / PW, px = e - py * PW;
+            const int oy = iy0 + p.pad - (KS - 1) + py, ox = ix0 + p.pad - (KS - 1) + px;
+            const bool ok = e < GI && (unsigned)oy < (unsigned)p.Ho && (unsigned)ox < (unsigned)p.Wo;
+            rg[i] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(gsrc, ok ? (unsigned)(((n_img * p.Ho + oy) * p.Wo + ox) * p.g_ld + p.g_coff) * 2u : 0x80000000u, 0, 0));
+        }
+    };
+    auto flush = [&](auto SI) __attribute__((always_inline)) {
+        u32x4 (&rx)[XPT] = rxs[decltype(SI)::value];
+        u32x2 (&rg)[GPT] = rgs[decltype(SI)::value];
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            const int e = tid + i * 256;
+            if (e < XI) {
+                if constexpr (IB == 16) *reinterpret_cast<u32x4*>(Xs + (e / IPP) * SX + (e % IPP) * 16) = rx[i];
+                else *reinterpret_cast<u32x2*>(Xs + (e / IPP) * SX + (e % IPP) * 8) = u32x2{rx[i].x, rx[i].y};
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < GPT; ++i) {
+            const int e = tid + i * 256;
+            if (e < GI) *reinterpret_cast<u32x2*>(Ts + e * 8) = rg[i];
+        }
+    };
+    auto mfma_tile = [&]() __attribute__((always_inline)) {
+        f16x8 a[NT], b[NTN];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const f16x4 lo = tr_read(xa + (n * 32) / 2), hi = tr_read(xa + (TW * SX + n * 32) / 2);
+            a[n] = (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+#pragma unroll
+        for (int j = 0; j < NTN; ++j) {
+            const f16x4 lo = tr_read(tb[j]), hi = tr_read(tb[j] + (PW * 8) / 2);
+            b[j] = (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int j = 0; j < NTN; ++j) acc[n][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[n], b[j], acc[n][j], 0, 0, 0);
+    };
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, 1> S1;
+    typedef std::integral_constant<int, (DEPTH > 2 ? 2 : 0)> S2;
+    int tile = blockIdx.x;
+    if (tile < p.ntiles) prefetch(tile, S0());
+    if (DEPTH > 2 && tile + p.gx < p.ntiles) prefetch(tile + p.gx, S1());
+    auto one = [&](auto SA, auto SC) __attribute__((always_inline)) {
+        __syncthreads();
+        flush(SA);
+        __syncthreads();
+        if (tile + (DEPTH - 1) * p.gx < p.ntiles) prefetch(tile + (DEPTH - 1) * p.gx, SC);
+        mfma_tile();
+        tile += p.gx;
+    };
+    while (tile < p.ntiles) {
+        if constexpr (DEPTH > 2) {
+            one(S0(), S2());
+            if (tile >= p.ntiles) break;
+            one(S1(), S0());
+            if (tile >= p.ntiles) break;
+            one(S2(), S1());
+        } else {
+            one(S0(), S1());
+            if (tile >= p.ntiles) break;
+            one(S1(), S0());
+        }
+    }
+    // ---- the four waves' sums in wave order; D layout: row (= input channel) = 4 (lane >> 4) + r, column lane & 15 = (tap 4 j + (column >> 2), filter column & 3)
+    __syncthreads();
+    for (int wv = 0; wv < 4; ++wv) {
+        if (wave == wv) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int j = 0; j < NTN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float* d = red + ((n * NTN + j) * 16 + 4 * (lane >> 4) + r) * 16 + (lane & 15);
+                        *d = wv == 0 ? acc[n][j][r] : *d + acc[n][j][r];
+                    }
+        }
+        __syncthreads();
+    }
+    float* out = p.slabs + (long long)blockIdx.x * p.slab;
+    for (int e = tid; e < NT * NTN * 256; e += 256) {      // (consecutive lanes = consecutive input channels: the slab's fastest index)
+        const int row = e & 15, n = (e >> 4) % NT, cj = e / (16 * NT), col = cj & 15, j = cj >> 4;
+        const int t = 4 * j + (col >> 2), co = col & 3, ci = ci0 + n * 16 + row;
+        if (t < TAPS && co < p.Cout && ci < p.Cin) out[((long long)co * TAPS + t) * p.Cin + ci] = red[((n * NTN + j) * 16 + row) * 16 + col];
+    }
+}
+
 // ---- thin input: which layers, how many workgroups
-struct WThinPlan { int kind, gx; size_t lds; };      // kind 1: 5x5 stride 1, Cin <= 4, Cout <= 16 (the generators' stems)
+struct WThinPlan { int kind, gx; size_t lds; };      // kind 1: 5x5 stride 1, Cin <= 4, Cout <= 16 (the generators' stems); 2 / 3: Cout <= 4, stride 1 -- 4x4 with Cin % 64 == 0 (the PatchGAN head) / 3x3 with Cin <= 16 (the generators' heads)
 static bool wgrad_thin_plan(const hv_wgrad_desc* d, WThinPlan* pl) {
-    static const int enabled = getenv("HV_WGRAD_THIN") ? atoi(getenv("HV_WGRAD_THIN")) : 1;   // A/B knob
+    static const int enabled = getenv("HV_WGRAD_THIN") ? atoi(getenv("HV_WGRAD_THIN")) : 3;   // A/B knob: bit 0 thin input (kind 1), bit 1 thin gradient (kinds 2, 3)
     if (!enabled || d->precision != HV_F16 || !d->x_f16 || !d->g_f16 || d->KH != d->KW || d->dil != 1 || d->in_shift != 0) return false;
     if (d->Ho != (d->H + 2 * d->pad - d->KH) / d->stride + 1 || d->Wo != (d->W + 2 * d->pad - d->KW) / d->stride + 1) return false;
-    if (d->Cin > 4 || (d->x_ld & 3) || (d->x_coff & 3) || (d->Cout & 7) || (d->g_ld & 7) || (d->g_coff & 7)) return false;
     pl->kind = 0;
-    if (d->KH == 5 && d->stride == 1 && d->Cout <= 16) pl->kind = 1;
+    const bool thin_x = d->Cin <= 4 && !(d->x_ld & 3) && !(d->x_coff & 3) && !(d->Cout & 7) && !(d->g_ld & 7) && !(d->g_coff & 7);
+    const bool thin_g = (enabled & 2) && d->Cout <= 4 && !(d->g_ld & 3) && !(d->g_coff & 3) && d->stride == 1 && !d->dbias && !(d->x_ld & 3) && !(d->x_coff & 3);
+    if ((enabled & 1) && thin_x && d->KH == 5 && d->stride == 1 && d->Cout <= 16) pl->kind = 1;
+    else if (thin_g && d->KH == 4 && !(d->Cin & 63) && !(d->x_ld & 7) && !(d->x_coff & 7)) pl->kind = 2;
+    else if (thin_g && d->KH == 3 && d->Cin <= 16 && d->Cin > 4) pl->kind = 3;
     // (Measured and not kept: the PatchGAN stem -- 4x4 stride 2, 1 -> 64 -- as wgrad_thinx_kernel<4, 2, 64>: 249 registers, two tiles of loads in flight, 33.3 / 26.9 us
     // at B32 / B16 against the gather kernel's 30.2 / 19.1: its time is the 67 MB of g, which both read once.)
     if (!pl->kind) return false;
-    const int BN = 16, TAPS = d->KH * d->KW, NTN = (TAPS + 3) / 4;
+    const int BN = pl->kind == 2 ? 64 : 16, TAPS = d->KH * d->KW, NTN = (TAPS + 3) / 4;
     const int PH = 7 * d->stride + d->KH, PW = 15 * d->stride + d->KW;
     const size_t stage = (size_t)128 * wtr_stride(BN, 1) + (size_t)(PH * PW * 8 + 15) / 16 * 16, red = (size_t)(BN / 16) * (NTN * 256 + 16) * 4;
     pl->lds = stage > red ? stage : red;
     if (pl->lds < 4096) pl->lds = 4096;      // (the carried fold's workgroups use the launch's LDS)
-    const long long ntiles = (long long)d->B * hv_cdiv(d->Ho, 8) * hv_cdiv(d->Wo, 16);
+    // tiles: output pixels (thin input) / input pixels (thin gradient)
+    const long long ntiles = pl->kind == 1 ? (long long)d->B * hv_cdiv(d->Ho, 8) * hv_cdiv(d->Wo, 16) : (long long)d->B * hv_cdiv(d->H, 8) * hv_cdiv(d->W, 16);
     static const int want = getenv("HV_WGRAD_THIN_WGS") ? atoi(getenv("HV_WGRAD_THIN_WGS")) : 512;      // tuning knob (kernel + fold, us at 128 / 256 / 384 / 512 / 768 / 1024: 41.5 / 26.1 / 22.0 / 19.7 / 20.9 / 23.8)
-    pl->gx = (int)(want < ntiles ? want : ntiles);
+    const long long blocks = pl->kind == 2 ? d->Cin / 64 : 1;      // channel blocks along y
+    long long gx = want / blocks;
+    if (gx < 32) gx = 32;
+    pl->gx = (int)(gx < ntiles ? gx : ntiles);
     return true;
 }
 size_t hv_wgrad_thin_workspace_bytes(const hv_wgrad_desc* d) {
@@ -841,6 +1001,22 @@ static int launch_wthinx(const WTrK& k, const WThinPlan& pl, const hv_wgrad_desc
     HV_LAUNCH_CHECK();
     return HV_OK;
 }
+template <int KS, int BN, int IB>
+static int launch_wthing(const WTrK& k, const WThinPlan& pl, const hv_wgrad_desc* d, hipStream_t s) {
+    auto kern = wgrad_thing_kernel<KS, BN, IB>;
+    dim3 grid(pl.gx, hv_cdiv(d->Cin, BN), 1);
+    WTrK kk = k;
+    kk.fold.splits = 0;
+    const int fx = hv_carry_blocks((int)grid.y);
+    if (fx > 0) { kk.fold = hv_carry; hv_carry_taken = 1; grid.x += fx; }
+    hv_path_note = 12;
+    HV_KNAME("wgrad_thing_kernel<%d, %d, %d>", KS, BN, IB);
+    HV_TIMING_BEGIN(s);
+    hipLaunchKernelGGL(kern, grid, dim3(256), pl.lds, s, kk);
+    HV_TIMING_END(s);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
 int hv_wgrad_thin(const hv_wgrad_desc* d, int* nslabs, hipStream_t s) {
     WThinPlan pl;
     if (!wgrad_thin_plan(d, &pl)) return HV_ERR_UNSUPPORTED;
@@ -851,7 +1027,9 @@ int hv_wgrad_thin(const hv_wgrad_desc* d, int* nslabs, hipStream_t s) {
     k.img_stride = d->H * d->W * d->x_ld; k.x_ld = d->x_ld; k.x_coff = d->x_coff; k.Cin = d->Cin;
     k.Ho = d->Ho; k.Wo = d->Wo; k.Hf = d->Ho; k.Wf = d->Wo; k.g_ld = d->g_ld; k.g_coff = d->g_coff; k.Cout = d->Cout; k.pad = d->pad;
     k.dil = 1;
-    k.tiles_x = hv_cdiv(k.Wo, 16); k.tiles_per_sub = k.tiles_x * hv_cdiv(k.Ho, 8); k.tiles_per_img = k.tiles_per_sub; k.ntiles = k.tiles_per_img * d->B;
+    if (pl.kind == 1) { k.tiles_x = hv_cdiv(k.Wo, 16); k.tiles_per_sub = k.tiles_x * hv_cdiv(k.Ho, 8); }
+    else { k.tiles_x = hv_cdiv(k.Wl, 16); k.tiles_per_sub = k.tiles_x * hv_cdiv(k.Hl, 8); }
+    k.tiles_per_img = k.tiles_per_sub; k.ntiles = k.tiles_per_img * d->B;
     k.slab = (long long)d->Cout * d->KH * d->KW * d->Cin;
     k.bias_out = d->dbias ? d->workspace + (long long)pl.gx * k.slab : nullptr;
     k.dbg = 0;
@@ -860,7 +1038,9 @@ int hv_wgrad_thin(const hv_wgrad_desc* d, int* nslabs, hipStream_t s) {
     k.x_bytes = (unsigned)((size_t)d->B * k.img_stride * sizeof(_Float16));
     k.g_bytes = (unsigned)((size_t)d->B * d->Ho * d->Wo * d->g_ld * sizeof(_Float16));
     *nslabs = pl.gx;
-    return launch_wthinx<5, 1, 16>(k, pl, d, s);
+    if (pl.kind == 1) return launch_wthinx<5, 1, 16>(k, pl, d, s);
+    if (pl.kind == 2) return launch_wthing<4, 64, 16>(k, pl, d, s);
+    return launch_wthing<3, 16, 8>(k, pl, d, s);
 }
 
 // returns HV_ERR_UNSUPPORTED when the shape does not qualify; on success the slabs (*nslabs of them) are in d->workspace

@@ -299,8 +299,12 @@ def conv2d_wgrad(x, g, dw, k, stride=1, pad=0, dil=1, in_shift=0, accumulate=Fal
     L = _lib.get()
     d = L.hv_wgrad_desc()
     kh, kw = (k, k) if isinstance(k, int) else k
-    if _DIAG_SKIP_WGRAD and ('k%d' % kh in _DIAG_SKIP_WGRAD or ('thin' in _DIAG_SKIP_WGRAD and min(x.C if cin is None else cin, g.C if cout is None else cout) <= 16)):
-        return      # timing-only diagnostic (wrong parameter gradients): what a class of weight gradients costs the step
+    if _DIAG_SKIP_WGRAD:      # timing-only diagnostic (wrong parameter gradients): what a class of weight gradients costs the step
+        ci_, co_ = (x.C if cin is None else cin), (g.C if cout is None else cout)
+        cls = {'k%d' % kh, 'thin' if min(ci_, co_) <= 16 else 'wide', 'head' if co_ <= 4 else '', 'dstem' if (kh == 4 and stride == 2 and ci_ <= 4) else '',
+               'g3thin' if (kh == 3 and min(ci_, co_) <= 16 and co_ > 4) else '', 'dhead' if (kh == 4 and co_ <= 4) else '', 'ghead' if (kh == 3 and co_ <= 4) else ''}
+        if cls & _DIAG_SKIP_WGRAD:
+            return
     d.x = ptr(x.t).value
     d.B, d.H, d.W, d.in_shift = x.B, x.H << in_shift, x.W << in_shift, in_shift
     d.x_ld, d.x_coff, d.Cin = x.ld, x.coff, (x.C if cin is None else cin)
