@@ -12,21 +12,45 @@
 struct HeadK {
     const void* x; const _Float16* w; float* P;        // x: fp32, or fp16 elements with the XH instantiations
     int M, tiles, x_ld, x_coff, K, ntaps, wstride;
+    // XN instantiations (hv_conv_desc.xn_*): x is the raw input of a normalisation + activation; the operand is made from it in registers
+    const float* xn_stats; const float* xn_gamma; const float* xn_beta; _Float16* xn_out;
+    int xn_groups, xn_ppg, xn_act, xn_out_ld, xn_out_coff;      // xn_ppg: pixels per statistics group
 };
 
 // CH = 32-channel MFMA steps per pipeline item (one item's loads are in flight while the previous one is multiplied)
-template <int CH, bool XH>
+// XN (fp16 x only): the operand of pixel n, channel c is act(((x - mean) * rstd) * gamma + beta) rounded to fp16 -- norm_apply_kernel's arithmetic in its
+// order -- with the four per-channel constants read from an LDS table [group][channel] (the 16 lanes of a channel quad share an address: broadcast
+// reads); the lane's 8-byte pieces of the normalised map go out to xn_out as they are made (the separate normalisation pass read x and wrote that map,
+// this kernel then read it back: one read and one launch per forward are gone)
+template <int CH, bool XH, int XN = 0>      // XN: 0 plain, 1 normalisation without affine parameters (InstanceNorm), 2 with (BatchNorm); LeakyReLU(0.2) behind it
 __global__ __launch_bounds__(256) void head_gemm_kernel(const HeadK p) {
     typedef typename HvSt<XH>::R XR;               // 4 consecutive channels as loaded (16 B of fp32 or 8 B of fp16)
-    extern __shared__ __attribute__((aligned(16))) _Float16 wl[];   // [16 taps][wstride], rows >= ntaps zero
+    static_assert(XN == 0 || XH, "the fused normalisation reads fp16 x");
+    extern __shared__ __attribute__((aligned(16))) _Float16 wl[];   // [16 taps][wstride], rows >= ntaps zero; XN: + [groups][K] float4 {mean, rstd, gamma, beta}
     const int tid = threadIdx.x;
     {
         const int k4 = p.K >> 2;
+#pragma unroll 4
         for (int e = tid; e < 16 * k4; e += 256) {
             const int t = e / k4, c = (e - t * k4) * 4;
             f16x4 v = {0, 0, 0, 0};
             if (t < p.ntaps) v = *reinterpret_cast<const f16x4*>(p.w + (long long)t * p.K + c);
             *reinterpret_cast<f16x4*>(wl + t * p.wstride + c) = v;
+        }
+    }
+    float4* pn = reinterpret_cast<float4*>(wl + 16 * p.wstride);
+    if constexpr (XN != 0) {      // four entries per thread and round, every load of a round in flight before the first LDS store
+        const int ne = p.xn_groups * p.K;
+        for (int e0 = 0; e0 < ne; e0 += 1024) {
+            float4 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = min(e0 + tid + 256 * i, ne - 1), gq = e / p.K, c = e - gq * p.K;
+                v[i] = make_float4(p.xn_stats[(long long)gq * 2 * p.K + c], p.xn_stats[(long long)gq * 2 * p.K + p.K + c], XN == 2 ? p.xn_gamma[c] : 1.f, XN == 2 ? p.xn_beta[c] : 0.f);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (e0 + tid + 256 * i < ne) pn[e0 + tid + 256 * i] = v[i];
         }
     }
     __syncthreads();
@@ -52,12 +76,38 @@ __global__ __launch_bounds__(256) void head_gemm_kernel(const HeadK p) {
         }
     };
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // XN: the normalised map leaves through buffer stores whose out-of-range lanes (pixels past the end, or no xn_out at all) are dropped by the range check:
+    // a store under a branch makes the compiler wait for ALL memory operations at the join -- the next item's loads included
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t osrc =
+        __builtin_amdgcn_make_buffer_rsrc(p.xn_out, 0, (XN != 0 && p.xn_out) ? (unsigned)((long long)p.M * p.xn_out_ld * 2) : 0u, 0x00020000);
     auto consume = [&](const XR (&buf)[CH * 2], int it) {
         const int t = t0 + it / chunks, c = it - (it / chunks) * chunks;
+        f16x4 lo[CH], hi[CH];
+#pragma unroll
+        for (int ks = 0; ks < CH; ++ks) { lo[ks] = HvSt<XH>::h4(buf[2 * ks]); hi[ks] = HvSt<XH>::h4(buf[2 * ks + 1]); }
+        if constexpr (XN != 0) {
+            const int n = min(t * 16 + col, p.M - 1);
+            const float4* pq = pn + (n / p.xn_ppg) * p.K + c * (32 * CH) + g * 4;
+            const unsigned ooff = t * 16 + col < p.M ? (unsigned)(((long long)n * p.xn_out_ld + p.xn_out_coff + c * (32 * CH) + g * 4) * 2) : 0x80000000u;
+#pragma unroll
+            for (int ks = 0; ks < CH; ++ks) {
+                float4 a[4], b[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { a[e] = pq[ks * 32 + e]; b[e] = pq[ks * 32 + 16 + e]; }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {      // norm_apply_kernel's arithmetic in its order; LeakyReLU as hv_act writes it
+                    float v = ((float)lo[ks][e] - a[e].x) * a[e].y, u = ((float)hi[ks][e] - b[e].x) * b[e].y;
+                    if constexpr (XN == 2) { v = v * a[e].z + a[e].w; u = u * b[e].z + b[e].w; }
+                    lo[ks][e] = (_Float16)(v > 0.f ? v : 0.2f * v);
+                    hi[ks][e] = (_Float16)(u > 0.f ? u : 0.2f * u);
+                }
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(hv_u32x2, lo[ks]), osrc, ooff + ks * 64, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(hv_u32x2, hi[ks]), osrc, ooff + ks * 64 + 32, 0, 0);
+            }
+        }
 #pragma unroll
         for (int ks = 0; ks < CH; ++ks) {
-            const f16x4 lo = HvSt<XH>::h4(buf[2 * ks]), hi = HvSt<XH>::h4(buf[2 * ks + 1]);
-            const f16x8 xb = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            const f16x8 xb = {lo[ks][0], lo[ks][1], lo[ks][2], lo[ks][3], hi[ks][0], hi[ks][1], hi[ks][2], hi[ks][3]};
             const _Float16* wp = wrow + (c * CH + ks) * 32;
             const f16x4 w0 = *reinterpret_cast<const f16x4*>(wp), w1 = *reinterpret_cast<const f16x4*>(wp + 16);
             const f16x8 wa = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
@@ -195,20 +245,40 @@ int hv_conv2d_head(const hv_conv_desc* d, hipStream_t s) {
     if (!d->transposed && ((d->H + 2 * d->pad - d->KH) / d->stride + 1 != d->Ho || (d->W + 2 * d->pad - d->KW) / d->stride + 1 != d->Wo))
         return HV_ERR_ARG;
     HeadK k;
-    HV_WUSE(2);
     k.x = d->x; k.w = reinterpret_cast<const _Float16*>(d->w_f16); k.P = reinterpret_cast<float*>(d->workspace);
     k.M = d->B * d->H * d->W; k.tiles = hv_cdiv(k.M, 16); k.x_ld = d->x_ld; k.x_coff = d->x_coff; k.K = d->Cin; k.ntaps = d->KH * d->KW;
     k.wstride = d->Cin + ((16 - d->Cin % 128) + 128) % 128;   // row stride = 32 B mod 256 B: the 16 taps x 4 groups of a wave's 8-byte reads
-    const size_t lds = (size_t)16 * k.wstride * sizeof(_Float16);                                       // spread over all banks
+    size_t lds = (size_t)16 * k.wstride * sizeof(_Float16);                                             // spread over all banks
+    k.xn_stats = nullptr; k.xn_gamma = k.xn_beta = nullptr; k.xn_out = nullptr; k.xn_groups = 1; k.xn_ppg = k.M; k.xn_act = 0; k.xn_out_ld = k.xn_out_coff = 0;
+    if (d->xn_stats) {      // normalisation + activation of the input at staging (hv_conv_desc.xn_*): fp16 x, whole 128-channel items, the constants' table in LDS
+        const int G = d->xn_groups > 0 ? d->xn_groups : 1;
+        if (!d->x_f16 || d->transposed || (d->Cin & 127) || d->B % G || (d->xn_gamma && !d->xn_beta) || d->xn_act != HV_ACT_LRELU)      // (the PatchGAN's LeakyReLU(0.2) only)
+            return HV_ERR_UNSUPPORTED;
+        if (d->xn_out && ((d->xn_out_ld & 3) || (d->xn_out_coff & 3) || ((uintptr_t)d->xn_out & 7) || d->xn_out_ld < d->xn_out_coff + d->Cin ||
+                          (long long)d->B * d->H * d->W * d->xn_out_ld * 2 >= (1ll << 31)))
+            return HV_ERR_UNSUPPORTED;
+        lds += (size_t)G * d->Cin * sizeof(float4);
+        if (lds > 64 * 1024) return HV_ERR_UNSUPPORTED;      // (InstanceNorm at a large batch: the caller keeps the separate pass)
+        k.xn_stats = d->xn_stats; k.xn_gamma = d->xn_gamma; k.xn_beta = d->xn_beta; k.xn_out = reinterpret_cast<_Float16*>(d->xn_out);
+        k.xn_groups = G; k.xn_ppg = (d->B / G) * d->H * d->W; k.xn_act = d->xn_act; k.xn_out_ld = d->xn_out_ld; k.xn_out_coff = d->xn_out_coff;
+    }
+    if (hv_probe_only) return HV_OK;          // hv_conv2d_supported: this path would take the descriptor
+    HV_WUSE(2);
     const int ch = (d->Cin % 128 == 0) ? 4 : (d->Cin % 64 == 0) ? 2 : 1;
     const int chunks = d->Cin / (32 * ch);
     // one wave streams >= 8 pipeline items, at least one block per CU
     int tpw = (8 + chunks - 1) / chunks;
     int blocks = hv_cdiv(k.tiles, 4 * tpw);
     if (blocks < 256) blocks = hv_cdiv(k.tiles, 4);
+    static const int xn_tpw = getenv("HV_HEAD_XN_TPW") ? atoi(getenv("HV_HEAD_XN_TPW")) : 0;      // tuning knob: tiles per wave of the XN form (0: as the plain form)
+    if (k.xn_stats && xn_tpw > 0) blocks = hv_cdiv(k.tiles, 4 * xn_tpw);
     hv_path_note = 5;
     HV_KNAME("head_gemm_kernel<%d, %s>", ch, d->x_f16 ? "true" : "false");
-    if (d->x_f16) {
+    if (k.xn_stats) {
+        HV_KNAME("head_gemm_kernel<4, true, %d>", k.xn_gamma ? 2 : 1);
+        if (k.xn_gamma) hipLaunchKernelGGL((head_gemm_kernel<4, true, 2>), dim3(blocks), dim3(256), lds, s, k);
+        else hipLaunchKernelGGL((head_gemm_kernel<4, true, 1>), dim3(blocks), dim3(256), lds, s, k);
+    } else if (d->x_f16) {
         if (ch == 4) hipLaunchKernelGGL((head_gemm_kernel<4, true>), dim3(blocks), dim3(256), lds, s, k);
         else if (ch == 2) hipLaunchKernelGGL((head_gemm_kernel<2, true>), dim3(blocks), dim3(256), lds, s, k);
         else hipLaunchKernelGGL((head_gemm_kernel<1, true>), dim3(blocks), dim3(256), lds, s, k);

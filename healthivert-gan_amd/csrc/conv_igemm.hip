@@ -402,6 +402,10 @@ static int conv2d_dispatch(const hv_conv_desc* d, void* stream) {
     // normalisation reading zeros) -- callers size `stats` with hv_conv2d_stats_parts, which is 0 exactly when this refuses
     if (d->stats && !hv_conv2d_g4_stats_floats(d, nullptr)) return HV_ERR_UNSUPPORTED;
     if (d->bstats && !hv_conv2d_bstats_parts(d)) return HV_ERR_UNSUPPORTED;      // (the same for the batch-norm backward sums of a data gradient)
+    if (d->xn_stats) {   // input normalised at staging: the [pixel][tap] path of the 1-channel layers or nothing (the caller keeps the separate normalisation pass)
+        if (d->Cout != 1 || !d->workspace) return HV_ERR_UNSUPPORTED;
+        return hv_conv2d_head(d, (hipStream_t)stream);
+    }
     if (d->x1) {         // extra input channel: the filters-in-LDS kernel or nothing (the caller keeps the materialised concat)
         if (d->precision != HV_F16 || !d->w_f16 || !d->w_f16_tiled || !d->y_f16 || d->transposed || d->dil != 1 || d->stride != 1 || d->KH != 3 || d->KW != 3 || !d->w1 ||
             d->pool2 || d->stats || d->x1_ld < 1)
@@ -527,7 +531,7 @@ thread_local int hv_probe_only = 0;
 extern "C" int hv_conv2d_supported(const hv_conv_desc* d) {
     if (!d) return 0;
     if (d->bstats && !hv_conv2d_bstats_parts(d)) return 0;
-    if (!d->x1 && !d->pool2) return d->stats ? (hv_conv2d_g4_stats_floats(d, nullptr) ? 1 : 0) : 1;
+    if (!d->x1 && !d->pool2 && !d->xn_stats) return d->stats ? (hv_conv2d_g4_stats_floats(d, nullptr) ? 1 : 0) : 1;
     hv_probe_only = 1;
     const int rc = conv2d_dispatch(d, nullptr);
     hv_probe_only = 0;

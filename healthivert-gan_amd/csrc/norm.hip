@@ -241,7 +241,7 @@ static int apply_grid(long long n, int G) { static const int ab = getenv("HV_NOR
 static int n_log2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
 extern "C" int hv_norm_act_forward(const hv_norm_desc* d, void* stream) {
-    if (!d || !d->x || !d->y || !d->stats || d->B <= 0 || d->HW <= 0 || d->C <= 0) return HV_ERR_ARG;
+    if (!d || !d->x || !d->stats || d->B <= 0 || d->HW <= 0 || d->C <= 0) return HV_ERR_ARG;      // (y == NULL: statistics only -- the consumer normalises at its staging)
     if (d->norm != HV_NORM_BATCH && d->norm != HV_NORM_INSTANCE) return HV_ERR_ARG;
     if (!n_shape_ok(d->C)) return HV_ERR_UNSUPPORTED;
     const bool aligned = !(d->x_ld & 3) && !(d->x_coff & 3) && !(d->y_ld & 3) && !(d->y_coff & 3) && !((uintptr_t)d->x & 15) && !((uintptr_t)d->y & 15);
@@ -285,7 +285,7 @@ extern "C" int hv_norm_act_forward(const hv_norm_desc* d, void* stream) {
     const long long n = (long long)pl.R * (vec ? d->C / 4 : d->C);
     const dim3 agrid(apply_grid(n, pl.G), pl.G);
     static const int skip_apply = getenv("HV_DIAG_SKIP") && strstr(getenv("HV_DIAG_SKIP"), "norm_apply") ? 1 : 0;     // timing-only diagnostic (wrong results)
-    if (skip_apply) return HV_OK;
+    if (skip_apply || !d->y) return HV_OK;
     if (d->f16) {
         if (vec) hipLaunchKernelGGL((norm_apply_kernel<true, true>), agrid, dim3(256), 0, s, k);
         else hipLaunchKernelGGL((norm_apply_kernel<false, true>), agrid, dim3(256), 0, s, k);

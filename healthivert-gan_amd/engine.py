@@ -263,7 +263,9 @@ class ConvNode:
             self._split_ok = (key, ok)
         return self._split_ok[1]
 
-    def forward(self, prec, stats=None):
+    def forward(self, prec, stats=None, xn=None, probe=False, x_raw=None):
+        """xn: the input is normalised + activated where the kernel stages it (ops.conv2d) -- x_raw is then the normalisation's raw input, read instead
+        of self.x (which xn's `out` fills); probe=True only asks whether that form is served."""
         p = self.p
         if self.split_forward(prec):
             low, x1 = self.split
@@ -271,9 +273,13 @@ class ConvNode:
                        w_t=p.w_fwd_t2, in_shift=1, precision=prec, cin=p.split_k, cout=p.cout,
                        x1=(x1, p.w_fwd, p.split_k, p.taps * p.cin_fwd, p.cin_fwd), wuse=(p, 'use_fwd'))
             return
-        xin = Act(self.x.t, p.cin_fwd, self.x.coff)
+        src = self.x if x_raw is None else x_raw
+        xin = Act(src.t, p.cin_fwd, src.coff)
+        if probe:
+            return ops.conv2d_supported(xin, p.w_fwd, self.y, self.k, self.s, self.pad, self.d, bias=p.bias if self.use_bias else None, act=self.act, w_h=p.w_fwd_h,
+                                        w_t=p.w_fwd_t, in_shift=self.shift, transposed=self.transposed, precision=prec, cout=p.cout, xn=xn)
         ops.conv2d(xin, p.w_fwd, self.y, self.k, self.s, self.pad, self.d, bias=p.bias if self.use_bias else None, act=self.act, w_h=p.w_fwd_h, w_t=p.w_fwd_t,
-                   in_shift=self.shift, transposed=self.transposed, precision=prec, cout=p.cout, stats=stats, wuse=(p, 'use_fwd'))
+                   in_shift=self.shift, transposed=self.transposed, precision=prec, cout=p.cout, stats=stats, wuse=(p, 'use_fwd'), xn=xn)
 
     def stats_parts(self, prec):
         """Partial-sum rows this node's forward kernel writes when handed a statistics buffer (0: that kernel has no such epilogue)."""

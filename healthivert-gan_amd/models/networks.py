@@ -147,6 +147,7 @@ CONV_STATS = os.environ.get('HV_CONV_STATS', '1') != '0'     # A/B knob: BatchNo
 LOSS_HEAD = os.environ.get('HV_LOSS_HEAD', '1') != '0'      # GAN loss kernel writes the logits layer's gradient carrier + bias gradient (A/B knob)
 CONV_BSTATS = os.environ.get('HV_CONV_BSTATS', '1') != '0'   # A/B knob: BatchNorm backward sums from the epilogue of the data gradient that writes dy
 FUSE_NORM_ACT = os.environ.get('HV_FUSE_NORM_ACT', '1') != '0'     # A/B knob, see _DiscPlan-based run_backward
+HEAD_NORM = os.environ.get('HV_HEAD_NORM', '1') != '0'     # A/B knob (same bits): the last normalisation + LeakyReLU made where the logits layer stages its input
 
 
 class _DiscPlan:
@@ -292,6 +293,7 @@ class NLayerDiscriminator(nn.Module):
             self.paramset().prep(x.device, power_iter=False, only_if_stale=(prep == 'if_stale'))
         xin = Act(x.view(B, H, W, 1))
         P.x_in = xin
+        head_xn = None
         for li, ent in enumerate(P.layers):
             L = ent['spec']
             if li == 0:
@@ -299,9 +301,21 @@ class NLayerDiscriminator(nn.Module):
                 ent['node'].forward(prec)
                 continue
             if L['last']:
-                ent['node'].forward(prec)
+                ent['node'].forward(prec, xn=head_xn, x_raw=P.layers[li - 1]['z'] if head_xn is not None else None)
                 break
             nm = self.model[L['norm']]
+            # the layer below the logits: its normalisation + LeakyReLU is applied by the logits layer's kernel where it stages its input (hv_conv_desc.xn_*; that
+            # kernel also stores the normalised map the backward reads) -- the normalisation call below then only finalises the statistics.  Asked of the C
+            # dispatch once per plan and mode (HV_HEAD_NORM=0: always the separate pass)
+            head_xn = None
+            if HEAD_NORM and P.layers[li + 1]['spec']['last'] and ent['z'].f16:
+                cand = (ent['stats'], nm.weight if self.norm_kind == 'batch' else None, nm.bias if self.norm_kind == 'batch' else None,
+                        groups if self.norm_kind == 'batch' else B, 'lrelu', ent['y'])
+                key = ('head_xn', self.norm_kind, groups, prec)
+                if key not in ent:
+                    ent[key] = bool(P.layers[li + 1]['node'].forward(prec, xn=cand, probe=True, x_raw=ent['z']))
+                if ent[key]:
+                    head_xn = cand
             # BatchNorm statistics out of the conv's own epilogue where its kernel has one (the 4x4 stride-2 layers): the normalisation then
             # skips its reduction pass over z (HV_CONV_STATS=0: always reduce)
             parts = 0
@@ -311,12 +325,13 @@ class NLayerDiscriminator(nn.Module):
                     ent['partials'] = torch.zeros(max(1, ent['parts']) * ent['p'].cout * 2, dtype=torch.float32, device=x.device)
                 parts = ent['parts']
             ent['node'].forward(prec, stats=ent['partials'] if parts else None)
+            y_out = None if head_xn is not None else ent['y']
             if self.norm_kind == 'batch':
-                ops.norm_act_forward(ent['z'], ent['y'], 'batch', training, ent['stats'], nm.weight, nm.bias, nm.running_mean,
+                ops.norm_act_forward(ent['z'], y_out, 'batch', training, ent['stats'], nm.weight, nm.bias, nm.running_mean,
                                      nm.running_var, nm.num_batches_tracked, act='lrelu', eps=nm.eps, momentum=_stat_momentum(nm.momentum, stat_order),
                                      groups=groups, partials=ent['partials'] if parts else None, n_partials=parts)
             else:
-                ops.norm_act_forward(ent['z'], ent['y'], 'instance', training, ent['stats'], act='lrelu', eps=nm.eps)
+                ops.norm_act_forward(ent['z'], y_out, 'instance', training, ent['stats'], act='lrelu', eps=nm.eps)
         P.training, P.groups = training, groups
         return P
 

@@ -162,13 +162,16 @@ def conv_out_size(n, k, stride, pad, dil):
 
 def conv2d(x, w, y, k, stride=1, pad=0, dil=1, bias=None, act='none', transposed=False, in_shift=0, alpha=1.0,
            accumulate=0, ch_scale=None, w_bstride=0, ch_scale_bstride=0, precision=None, cin=None, cout=None, w_h=None, mul=None, w_t=None,
-           stats=None, _parts_only=False, pool2=False, x1=None, _supported_only=False, wuse=None, bn=None, _bparts_only=False):
+           stats=None, _parts_only=False, pool2=False, x1=None, _supported_only=False, wuse=None, bn=None, _bparts_only=False, xn=None):
     """y = act(alpha*ch_scale*conv(x, w) + bias)  [* act'(m) with mul = (Act m, activation name): see hv_conv_desc.mul_src].  x,y: Act; w: prepared [CoutF][k*k][CinP] tensor (or [B][...] with
     w_bstride).  cin/cout default to the view widths (x.C consumed, y.C produced).
     stats: float tensor of conv2d_stats_parts(...) * Cout * 2 elements that receives the per-channel partial sums of the stored output
     (hv_conv_desc.stats; feeds norm_act_forward(partials=...)).
     pool2: y (and mul's tensor) hold the 2x2 sum-pooled output, i.e. half the convolution's own output size (hv_conv_desc.pool2; raises
-    RuntimeError 'unsupported' unless the filters-in-LDS kernel serves the shape: pool2_ok())."""
+    RuntimeError 'unsupported' unless the filters-in-LDS kernel serves the shape: pool2_ok()).
+    xn = (stats [G][2][Cin], gamma or None, beta or None, groups, activation name, Act out or None): x is the RAW input of a normalisation + activation whose
+    statistics norm_act_forward(x, None, ...) left in `stats`; the kernel normalises where it stages x and also stores the normalised map in `out`
+    (hv_conv_desc.xn_*; the PatchGAN logits layer only: ask conv2d_supported first)."""
     L = _lib.get()
     d = L.hv_conv_desc()
     kh, kw = (k, k) if isinstance(k, int) else k
@@ -204,19 +207,27 @@ def conv2d(x, w, y, k, stride=1, pad=0, dil=1, bias=None, act='none', transposed
         d.bn_stats, d.bn_groups = ptr(bstat).value, int(bgroups)
         if bpart is not None:
             d.bstats = ptr(bpart).value
+    if xn is not None:
+        nstat, ngam, nbet, ngroups, nact, nout = xn
+        d.xn_stats, d.xn_groups, d.xn_act = ptr(nstat).value, int(ngroups), ACT[nact]
+        if ngam is not None:
+            d.xn_gamma, d.xn_beta = ptr(ngam).value, ptr(nbet).value
+        if nout is not None:
+            assert nout.f16 and nout.B == x.B and nout.H == x.H and nout.W == x.W
+            d.xn_out, d.xn_out_ld, d.xn_out_coff = ptr(nout.t).value, nout.ld, nout.coff
     if _bparts_only:
         return L.size('hv_conv2d_bstats_parts', ctypes.byref(d))
     if _parts_only:
         return L.size('hv_conv2d_stats_parts', ctypes.byref(d))
-    if _supported_only:
-        return bool(L.cdll.hv_conv2d_supported(ctypes.byref(d)))
-    if stats is not None:
-        d.stats = ptr(stats).value
     if d.Cout == 1:      # single-channel heads / logits: the [pixel][tap] table of conv_head.hip lives in the per-stream scratch
         need = L.size('hv_conv2d_workspace_bytes', ctypes.byref(d))
         if need:
             b, _ = _ws(need, x.t.device, slot=1)
             d.workspace, d.workspace_bytes = ptr(b).value, b.numel()
+    if _supported_only:
+        return bool(L.cdll.hv_conv2d_supported(ctypes.byref(d)))
+    if stats is not None:
+        d.stats = ptr(stats).value
     if _TIMER is not None:
         taps = kh * kw if not transposed else max(1, (kh * kw) // (stride * stride))
         flops = 2.0 * y.B * y.H * y.W * d.Cout * taps * d.Cin
@@ -548,15 +559,17 @@ def norm_act_forward(x, y, norm, training, stats, gamma=None, beta=None, running
                      act='lrelu', post_sigmoid=False, eps=1e-5, momentum=0.1, groups=1, partials=None, n_partials=0):
     L = _lib.get()
     d = L.hv_norm_desc()
-    d.x, d.y = ptr(x.t).value, ptr(y.t).value
+    d.x = ptr(x.t).value
     d.B, d.HW, d.C = x.B, x.H * x.W, x.C
-    d.x_ld, d.x_coff, d.y_ld, d.y_coff = x.ld, x.coff, y.ld, y.coff
+    d.x_ld, d.x_coff = x.ld, x.coff
+    if y is not None:      # (None: statistics only -- the consumer normalises at its own staging: conv2d(xn=...))
+        d.y, d.y_ld, d.y_coff = ptr(y.t).value, y.ld, y.coff
     d.norm, d.training, d.eps, d.momentum = NORM[norm], int(training), eps, momentum
     for f, v in (('gamma', gamma), ('beta', beta), ('running_mean', running_mean), ('running_var', running_var),
                  ('num_batches_tracked', nbt), ('stats', stats)):
         setattr(d, f, None if v is None else ptr(v).value)
     d.act, d.post_sigmoid, d.groups = ACT[act], int(post_sigmoid), int(groups)
-    assert x.f16 == y.f16
+    assert y is None or x.f16 == y.f16
     d.f16 = x.f16
     if partials is not None and n_partials:      # the producing conv's own statistics (hv_conv_desc.stats): no reduction pass over x
         d.partials, d.n_partials = ptr(partials).value, int(n_partials)

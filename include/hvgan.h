@@ -121,6 +121,16 @@ typedef struct {
                                          pixels (g = the stored value of y, xhat = (bn_x - mean) * rstd), part < hv_conv2d_bstats_parts(d), parts of whole images in
                                          (group, image) order.  Feeds hv_norm_bwd_desc.partials: hv_norm_act_backward then skips its reduction pass over dy and x.
                                          hv_conv2d returns HV_ERR_UNSUPPORTED (and launches nothing) when the kernel of this shape has no such epilogue */
+    const float* xn_stats; const float* xn_gamma; const float* xn_beta; int xn_groups, xn_act;
+    void* xn_out; int xn_out_ld, xn_out_coff;
+                                      /* optional, forward with Cout == 1 and `workspace` (the [pixel][tap] path of the PatchGAN logits layer) only: x is the RAW input of a
+                                         normalisation + activation (models/networks.py:583-595) whose statistics hv_norm_act_forward (y == NULL: statistics only) left in
+                                         xn_stats -- [xn_groups][2][Cin] mean / rstd, the batch's images falling into xn_groups equal groups (1 BatchNorm, 2 the fake | real
+                                         pass, B InstanceNorm).  The operand is xn_act(((x - mean) * rstd) * gamma + beta) rounded to fp16 -- hv_norm_act_forward's
+                                         arithmetic, bit for bit -- made where x is staged (xn_gamma / xn_beta NULL = 1 / 0); xn_out != NULL: the normalised map is also
+                                         stored there (fp16 [pixel][xn_out_ld], the write a separate normalisation pass would have made; its read of x and this
+                                         convolution's read of the result are what the fusion saves).  hv_conv2d returns HV_ERR_UNSUPPORTED (and launches nothing) when the
+                                         kernel of this shape has no such staging */
 } hv_conv_desc;
 int hv_conv2d(const hv_conv_desc* d, void* stream);
 size_t hv_conv2d_bstats_parts(const hv_conv_desc* d);      /* parts of hv_conv_desc.bstats this call would write (0: its kernel has no such epilogue) */
@@ -228,7 +238,9 @@ size_t hv_act_backward_workspace_bytes(long long npix, int C);
  * models/UnetG_CT_mask.py:73-100.  `stats` (2*G*C floats: mean, rstd; G = 1 for batch, B for instance) is kept
  * for the backward. */
 typedef struct {
-    const void* x; void* y; int B, HW, C; int x_ld, x_coff, y_ld, y_coff;      /* x, y: fp32, or fp16 elements when f16 != 0 */
+    const void* x; void* y; int B, HW, C; int x_ld, x_coff, y_ld, y_coff;      /* x, y: fp32, or fp16 elements when f16 != 0.  y == NULL: statistics only (stats and
+                                                                                  the running statistics are written, no pass over x beyond the reduction): the
+                                                                                  consumer normalises at its own staging (hv_conv_desc.xn_stats) */
     int norm; int training; float eps, momentum;
     const float* gamma; const float* beta; float* running_mean; float* running_var; long long* num_batches_tracked;
     float* stats; int act; int post_sigmoid;

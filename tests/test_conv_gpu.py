@@ -799,3 +799,48 @@ def test_conv_stride2_data_gradient_fused_parity_classes(case):
                 assert path == 6 and torch.equal(d0.t, d1.t)
     finally:
         lib.get().size('hv_set_s2t_mode', prev)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', [(16, 31, 31, 512, 'batch', 2), (4, 31, 31, 512, 'batch', 1), (3, 7, 9, 128, 'batch', 1), (4, 10, 10, 256, 'instance', 4)])
+def test_conv_logits_layer_normalises_its_input_at_staging(case):
+    """hv_conv_desc.xn_*: the PatchGAN logits layer reads the RAW output of the layer below, applies BatchNorm / InstanceNorm + LeakyReLU where it stages
+    the operand and stores the normalised map on the way -- logits and map bit-identical to the separate normalisation pass followed by the plain
+    convolution (reference models/networks.py:583-598: norm_layer, LeakyReLU(0.2), Conv2d(.., 1, 4, 1, 1))."""
+    from hvtest import to_act, from_act, ohwi, dev
+    from hvgan import ops, lib
+    B, H, W, C, norm, groups = case
+    g = torch.Generator().manual_seed(5)
+    z = to_act(torch.randn(B, C, H, W, generator=g) * 1.7 + 0.3, dtype=torch.float16)
+    w = torch.randn(1, C, 4, 4, generator=g) / (C * 16) ** 0.5
+    b = (torch.randn(1, generator=g) * 0.1).to(dev())
+    wf = ohwi(w)
+    gam = (torch.rand(C, generator=g) + 0.5).to(dev()) if norm == 'batch' else None
+    bet = (torch.randn(C, generator=g) * 0.2).to(dev()) if norm == 'batch' else None
+    rm, rv, nbt = torch.zeros(C, device=dev()), torch.ones(C, device=dev()), torch.zeros(1, dtype=torch.long, device=dev())
+    Ho, Wo = H - 1, W - 1
+
+    def run(fused):
+        stats = torch.zeros(2 * B * C, device=dev())
+        y = ops.Act(torch.zeros(B, H, W, C, dtype=torch.float16, device=dev()))
+        out = ops.Act.empty(B, Ho, Wo, 1, dev())
+        kw = dict(gamma=gam, beta=bet, running_mean=rm.clone(), running_var=rv.clone(), nbt=nbt.clone(), groups=groups) if norm == 'batch' else {}
+        ops.norm_act_forward(z, None if fused else y, norm, True, stats, act='lrelu', **kw)
+        xn = (stats, gam, bet, groups, 'lrelu', y) if fused else None
+        if fused:
+            assert ops.conv2d_supported(z, wf, out, 4, 1, 1, 1, bias=b, precision='fp16', w_h=wf.half(), xn=xn)
+        ops.conv2d(z if fused else y, wf, out, 4, 1, 1, 1, bias=b, precision='fp16', w_h=wf.half(), xn=xn)
+        assert lib.get().size('hv_last_kernel_path') == 5
+        torch.cuda.synchronize()
+        return from_act(out), y.t.clone()
+    o0, y0 = run(False)
+    o1, y1 = run(True)
+    assert torch.equal(y0, y1), 'normalised map differs from the separate pass'
+    assert torch.equal(o0, o1), 'logits differ from the two-pass form'
+    assert o0.abs().max().item() > 0.05
+    # a shape the fused form does not serve is refused by the probe, not silently run elsewhere
+    z3 = to_act(torch.randn(2, 8, 6, 6, generator=g), dtype=torch.float16)
+    w3 = ohwi(torch.randn(16, 8, 3, 3, generator=g))
+    y3 = ops.Act.empty(2, 6, 6, 16, dev(), dtype=torch.float16)
+    st3 = torch.zeros(2 * 2 * 8, device=dev())
+    assert not ops.conv2d_supported(z3, w3, y3, 3, 1, 1, 1, precision='fp16', w_h=w3.half(), xn=(st3, None, None, 1, 'lrelu', None))

@@ -748,3 +748,40 @@ def test_carried_slab_folds_are_bit_identical_to_folds_launched_on_their_own(pre
         assert torch.equal(res[True][k], res[False][k]), (k, (res[True][k] - res[False][k]).abs().max().item())
 
 
+
+
+@pytest.mark.parametrize('norm,groups', [('batch', 2), ('batch', 1), ('instance', 1)])
+def test_discriminator_head_normalisation_at_staging_is_bit_identical(norm, groups, monkeypatch):
+    """fp16 mode: the last normalisation + LeakyReLU of the PatchGAN applied by the logits layer's kernel (hv_conv_desc.xn_*, HV_HEAD_NORM) against the
+    separate normalisation pass: logits, every parameter gradient, the input gradient and the running statistics bit for bit."""
+    from hvgan.models import networks
+    from hvgan import ops
+    dev = torch.device('cuda:0')
+    torch.manual_seed(3)
+    ref = networks.define_D(1, 16, 'basic', 3, norm, 'normal', 0.02, [])
+    sd = {k: v.clone() for k, v in ref.state_dict().items()}
+    x = torch.randn(4, 1, 64, 64, generator=torch.Generator().manual_seed(4)).to(dev)
+    res = []
+    for on in (False, True):
+        monkeypatch.setattr(networks, 'HEAD_NORM', on)
+        net = networks.define_D(1, 16, 'basic', 3, norm, 'normal', 0.02, [])
+        net.load_state_dict(sd)
+        net.cuda().train()
+        net.precision = 'fp16'
+        P = net.run_forward(x, training=True, groups=groups)
+        used = any(k[0] == 'head_xn' and v for ent in P.layers for k, v in ent.items() if isinstance(k, tuple))
+        assert used == on
+        loss = torch.zeros((), device=dev)
+        dz = torch.empty_like(P.logits)
+        ops.gan_loss(P.logits, True, 'vanilla', loss=loss, dz=dz)
+        dx = net.run_backward(P, dz, need_dx=True, param_grads=True)
+        net.finish()
+        torch.cuda.synchronize()
+        res.append((P.logits.clone(), dx.clone(), {k: p.grad.clone() for k, p in net.named_parameters()}, {k: v.clone() for k, v in net.state_dict().items()}))
+    a, b = res
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for k in a[2]:
+        assert torch.equal(a[2][k], b[2][k]), k
+    for k in a[3]:
+        assert torch.equal(a[3][k], b[3][k]), k
+    assert a[0].abs().max().item() > 0 and a[1].abs().max().item() > 0
