@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 ROOT = os.path.dirname(PKG)
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-SOURCES = ['conv_igemm.hip', 'conv_halo.hip', 'conv_halo2.hip', 'conv_lf.hip', 'conv_g4.hip', 'conv_thin.hip', 'conv_s2t.hip', 'wgrad_halo.hip', 'wgrad_tr.hip', 'conv_narrow.hip', 'conv_head.hip', 'prep.hip', 'norm.hip', 'pointwise.hip', 'attention.hip', 'attention_gram.hip', 'bgemm.hip', 'rhlv.hip', 'assemble.hip', 'infer_prep.hip', 'eval_metrics.hip']
+SOURCES = ['conv_igemm.hip', 'conv_halo.hip', 'conv_halo2.hip', 'conv_lf.hip', 'conv_g4.hip', 'conv_thin.hip', 'conv_px.hip', 'conv_s2t.hip', 'wgrad_halo.hip', 'wgrad_tr.hip', 'conv_narrow.hip', 'conv_head.hip', 'prep.hip', 'norm.hip', 'pointwise.hip', 'attention.hip', 'attention_gram.hip', 'bgemm.hip', 'rhlv.hip', 'assemble.hip', 'infer_prep.hip', 'eval_metrics.hip']
 FLAGS = os.environ.get('HV_EXTRA_FLAGS', '').split() + ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wno-unused-result', '-Wno-inline-asm', '-Rpass-analysis=kernel-resource-usage']
 OUT = os.path.join(PKG, 'libhvgan.so')
 

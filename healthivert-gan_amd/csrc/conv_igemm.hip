@@ -51,6 +51,7 @@ int hv_conv2d_thin_in(const hv_conv_desc* d, hipStream_t s);
 int hv_conv2d_stem5(const hv_conv_desc* d, hipStream_t s);
 int hv_conv2d_stem5_dgrad(const hv_conv_desc* d, hipStream_t s);
 int hv_conv2d_head(const hv_conv_desc* d, hipStream_t s);                       // conv_head.hip
+int hv_conv2d_px(const hv_conv_desc* d, hipStream_t s);                         // conv_px.hip
 int hv_conv2d_s2t(const hv_conv_desc* d, hipStream_t s);                        // conv_s2t.hip
 
 struct ConvCls {
@@ -417,6 +418,10 @@ static int conv2d_dispatch(const hv_conv_desc* d, void* stream) {
             d->act != HV_ACT_NONE || d->in_shift || d->stats)
             return HV_ERR_UNSUPPORTED;
         return hv_conv2d_halo(d, d->w_f16, (hipStream_t)stream);
+    }
+    if (d->precision == HV_F16 && d->Cin <= 16 && d->Cout <= 16 && d->stride == 1) {   // thin full-resolution layers: one lane per pixel on the 4x4x4 MFMA (conv_px.hip)
+        const int rc = hv_conv2d_px(d, (hipStream_t)stream);
+        if (rc != HV_ERR_UNSUPPORTED) return rc;
     }
     // single-channel heads / logits: VALU kernels (conv_narrow.hip), except where the halo-tiled MFMA kernel stages the input
     // once instead of once per tap (many input channels, fp16 mode)

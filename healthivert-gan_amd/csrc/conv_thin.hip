@@ -5,6 +5,10 @@
 // lane owns one output pixel: the 3x3 neighbourhood of the gradient (nine 8-byte loads, out-of-image -> zero through the buffer range check), the
 // filters in LDS as floats (broadcast reads), Cout fp32 accumulators, then the act' multiplier / accumulate forms of the shared epilogue on the
 // lane's own 16- or 24-byte channel row and one store.  fp32 arithmetic on the fp16-stored operands (exact products, fp32 sums).
+// (Round 5: the step's own head gradients -- 256^2, 4-wide carriers -- go to conv_px_kernel first (conv_px.hip: 21.5 / 16.0 us against 38.7 / 26.7 us here, which is
+// bound by its CO x 9 x 4 multiply-adds and as many LDS filter reads per pixel); a 16x16x16-MFMA form with the nine taps as the contraction -- 16 pixels per
+// wave step -- reached 22 / 18 us and was dropped for it: ~130 vector instructions per 16 pixels around one MFMA, PMC SQ_INSTS_VALU.)  This kernel keeps
+// the shapes conv_px_kernel does not take.
 #include "conv_halo.h"
 
 struct ThinK {

@@ -136,7 +136,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 # hv_last_kernel_path codes (the `hv_path_note = N` of each launcher in csrc/): the kernel FAMILY; the exact instantiation comes from hv_last_kernel_name
 KERNEL_NAMES = {0: 'conv_igemm_kernel', 1: 'narrow_fwd_kernel', 2: 'conv_halo_kernel', 3: 'conv_halo2_kernel', 4: 'thin1_fwd_kernel', 5: 'head_gemm_kernel', 6: 'conv_s2t_kernel',
-                7: 'conv_lf_kernel', 8: 'conv_g4_kernel', 9: 'thin_dgrad_kernel', 10: 'wgrad_kernel', 11: 'wgrad_halo_kernel', 12: 'wgrad_tr_kernel', 13: 'wgrad_trd_kernel'}
+                7: 'conv_lf_kernel', 8: 'conv_g4_kernel', 9: 'thin_dgrad_kernel', 10: 'wgrad_kernel', 11: 'wgrad_halo_kernel', 12: 'wgrad_tr_kernel', 13: 'wgrad_trd_kernel', 14: 'conv_px_kernel'}
 
 
 def describe(key, path=None, kname=None):

@@ -41,7 +41,7 @@ int hv_version(void);
 const char* hv_arch(void); /* "gfx950" */
 /* which kernel family the calling thread's most recent hv_conv2d / hv_conv2d_wgrad launched (profiling labels):
  * 0 conv_igemm_kernel, 1 narrow_fwd_kernel, 2 conv_halo_kernel, 3 conv_halo2_kernel, 4 thin1_fwd_kernel, 5 head_gemm_kernel, 6 conv_s2t_kernel, 10 wgrad_kernel,
- * 11 wgrad_halo_kernel, 12 wgrad_tr_kernel */
+ * 11 wgrad_halo_kernel, 12 wgrad_tr_kernel, 13 wgrad_trd_kernel, 14 conv_px_kernel (one lane per pixel, 4x4x4 MFMA: the thin full-resolution layers) */
 int hv_last_kernel_path(void);
 /* name of that kernel instantiation as rocprofv3 prints it, e.g. "conv_halo2_kernel<8, 16, 128, 1, 4, 32, 1, 4, 4>" (the gather and weight-
  * gradient kernels are templated on _Float16, which rocprofv3 leaves mangled: _Z12wgrad_kernelIDF16_Li128E... = wgrad_kernel<_Float16, 128, ...>) */

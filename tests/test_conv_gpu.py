@@ -844,3 +844,88 @@ def test_conv_logits_layer_normalises_its_input_at_staging(case):
     y3 = ops.Act.empty(2, 6, 6, 16, dev(), dtype=torch.float16)
     st3 = torch.zeros(2 * 2 * 8, device=dev())
     assert not ops.conv2d_supported(z3, w3, y3, 3, 1, 1, 1, precision='fp16', w_h=w3.half(), xn=(st3, None, None, 1, 'lrelu', None))
+
+
+@pytest.mark.parametrize('case', [(2, 40, 37, 8, 1), (2, 33, 50, 12, 1), (3, 19, 16, 16, 4), (2, 24, 70, 12, 3)])
+def test_conv_heads_data_gradient_taps_as_one_mfma(case):
+    """Data gradient of the generators' 1-channel 3x3 heads (and of any <= 4-channel gradient carrier) back to 8 / 12 / 16 channels
+    (conv_px_kernel / thin3_mfma_dgrad_kernel; autograd of Conv2dBlock at reference models/inpaint_networks.py:115,230) against torch: act' multiplier, accumulate form,
+    ragged widths, padded gradient channels."""
+    from hvtest import dev
+    from hvgan import ops, lib
+    B, H, W, Cout, live = case
+    g_ = torch.Generator().manual_seed(Cout + live)
+    gy = torch.zeros(B, 4, H, W)
+    gy[:, :live] = torch.randn(B, live, H, W, generator=g_)
+    w = torch.randn(live, Cout, 3, 3, generator=g_) / 3.0                   # forward conv Cout -> live
+    m = torch.randn(B, Cout, H, W, generator=g_)
+    ga = ops.Act(gy.permute(0, 2, 3, 1).contiguous().to(dev()).half(), 4, 0)
+    ma = ops.Act(m.permute(0, 2, 3, 1).contiguous().to(dev()).half())
+    wb = torch.zeros(Cout, 9, 4)
+    wb[:, :, :live] = w.reshape(live, Cout, 9).permute(1, 2, 0)             # [layer input channel][tap][gradient channel, padded to 4]
+    wb = wb.to(dev())
+    y = ops.Act(torch.full((B, H, W, Cout), 0.25, device=dev(), dtype=torch.float16))
+    ops.conv2d(ga, wb, y, 3, 1, 1, 1, transposed=True, precision='fp16', w_h=wb.half(), mul=(ma, 'elu'), accumulate=1, cin=4)
+    assert lib.get().size('hv_last_kernel_path') in (9, 14)      # (14: conv_px_kernel takes the shape first unless HV_CONV_PX masks it)
+    torch.cuda.synchronize()
+    ref = F.conv_transpose2d(gy[:, :live].half().float(), w.half().float(), None, stride=1, padding=1)
+    mh = m.half().float()
+    want = 0.25 + ref * torch.where(mh > 0, torch.ones_like(mh), mh + 1)
+    got = y.t.float().cpu().permute(0, 3, 1, 2)
+    assert (got - want).abs().max().item() <= 6e-3 * max(1.0, want.abs().max().item())
+    y2 = ops.Act(torch.zeros(B, H, W, Cout, device=dev(), dtype=torch.float16))
+    ops.conv2d(ga, wb, y2, 3, 1, 1, 1, transposed=True, precision='fp16', w_h=wb.half(), cin=4)
+    torch.cuda.synchronize()
+    got2 = y2.t.float().cpu().permute(0, 3, 1, 2)
+    assert (got2 - ref).abs().max().item() <= 6e-3 * max(1.0, ref.abs().max().item())
+
+
+PX_CASES = [   # B, H, W, Cin, Cout, k, transposed, act, bias, mul, accumulate
+    (2, 40, 37, 12, 1, 3, 0, 'clamp', 1, None, 0),      # heads (fp32 image out)
+    (2, 33, 70, 8, 1, 3, 0, 'sigmoid', 1, None, 0),
+    (2, 24, 50, 8, 16, 3, 1, 'none', 0, 'elu', 1),      # 8 -> 16 and the data gradient of 16 -> 8
+    (2, 31, 66, 8, 16, 3, 0, 'elu', 1, None, 0),
+    (3, 300, 20, 8, 16, 3, 0, 'none', 0, None, 0),      # more rows than one tile, narrow
+    (16, 256, 256, 12, 1, 3, 0, 'clamp', 1, None, 0),   # the step's own shape
+]
+
+
+@pytest.mark.parametrize('case', PX_CASES)
+def test_conv_thin_full_resolution_layers_one_lane_per_pixel(case):
+    """conv_px_kernel (v_mfma_f32_4x4x4f16, lane = pixel): the generators' thin 3x3 / 5x5 layers and their data gradients (Conv2dBlock at reference
+    models/inpaint_networks.py:494-503 with cnum/2 .. cnum channels, the heads at :115,230) against torch fp32 on the fp16-rounded operands: bias, activation,
+    act' multiplier, accumulate form, ragged widths."""
+    from hvtest import to_act, from_act, ohwi, ohwi_T, dev
+    from hvgan import ops, lib
+    B, H, W, Cin, Cout, k, tr, act, use_b, mul, acc = case
+    g = torch.Generator().manual_seed(Cin * 31 + Cout + k)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    xh = to_act(x, dtype=torch.float16)
+    xr = x.half().float()
+    if not tr:
+        w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+        b = torch.randn(Cout, generator=g) * 0.1 if use_b else None
+        ref = _ref_act(F.conv2d(xr, w.half().float(), b, padding=k // 2), act)
+        wf = ohwi(w)
+        if Cout == 1:
+            ya = ops.Act.empty(B, H, W, 1, dev())
+        else:
+            ya = ops.Act.empty(B, H, W, Cout, dev(), dtype=torch.float16)
+        ops.conv2d(xh, wf, ya, k, 1, k // 2, 1, bias=None if b is None else b.to(dev()), act=act, precision='fp16', w_h=wf.half())
+    else:
+        w = torch.randn(Cin, Cout, k, k, generator=g) / (Cin * k * k) ** 0.5      # conv_transpose2d weight: the data gradient of a Cout -> Cin conv
+        ref = F.conv_transpose2d(xr, w.half().float(), stride=1, padding=k // 2)
+        wb = ohwi_T(w)
+        m = torch.randn(B, Cout, H, W, generator=g)
+        y0 = torch.randn(B, Cout, H, W, generator=g) * 0.5
+        ya = to_act(y0, dtype=torch.float16)
+        if mul:
+            mh = m.half().float()
+            ref = ref * torch.where(mh > 0, torch.ones_like(mh), mh + 1)
+        if acc:
+            ref = ref + y0.half().float()
+        ops.conv2d(xh, wb, ya, k, 1, k // 2, 1, transposed=True, precision='fp16', w_h=wb.half(), mul=(to_act(m, dtype=torch.float16), mul) if mul else None, accumulate=acc)
+    assert lib.get().size('hv_last_kernel_path') == 14, (lib.get().cdll.hv_last_kernel_name() or b'').decode()
+    torch.cuda.synchronize()
+    got = from_act(ya).float()
+    assert (got - ref).abs().max().item() <= 5e-3 * max(1.0, ref.abs().max().item())

@@ -33,7 +33,7 @@ def main():
     w = (torch.randn(Cout, k * k, Cin, generator=g) / (Cin * k * k) ** 0.5).to(dev)
     wh = w.half()
     wt = ops.tile_weights(wh, Cout, k * k, Cin) if os.environ.get('HV_W_TILED', '1') != '0' else None
-    ys = [ops.Act.empty(B, Ho, Wo, Cout, dev, dtype=ops.storage_dtype(prec)) for _ in range(rot)]
+    ys = [ops.Act.empty(B, Ho, Wo, Cout, dev, dtype=torch.float32 if os.environ.get('Y32') == '1' else ops.storage_dtype(prec)) for _ in range(rot)]      # Y32=1: fp32 output (the 1-channel heads)
     y = ys[0]
     dil = int(os.environ.get('DIL', '1'))          # DIL=d: dilation (pass pad = d for a same-size 3x3 layer)
     act = os.environ.get('ACT', 'none')            # epilogue as inside the step: ACT=elu BIAS=1 (forward), MUL=elu ACC=1 (data gradient with act' factor)
