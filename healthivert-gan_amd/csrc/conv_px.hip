@@ -57,28 +57,45 @@ __global__ __launch_bounds__(256) void conv_px_kernel(const PxK p) {
     }
     const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.x), 0, p.x_bytes, 0x00020000);
     const _Float16* wrow = wl + (lane & 3) * 4;
+    float bv[CQ][4];                                                     // (uniform: scalar registers)
+#pragma unroll
+    for (int m = 0; m < CQ; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[m][r] = (p.bias && 4 * m + r < p.Cout) ? p.bias[4 * m + r] : 0.f;
     for (int t = blockIdx.x; t < p.tiles; t += gridDim.x) {
         const int seg = t % p.segs, rb = t / p.segs, yb = rb % p.rblocks, b = rb / p.rblocks;      // (scalar)
         const int y0 = yb * TH, x0 = seg * 256;
         __syncthreads();                                                 // the previous tile's readers are done (first pass: the filter table is written)
-        // ---- stage rows y0 - pad .. y0 + TH - 1 + pad, pixels x0 - pad .. x0 + 255 + pad
-        constexpr int NP = PR * PW * VPP, IT = (NP + 255) / 256;
+        // ---- stage rows y0 - pad .. y0 + TH - 1 + pad, pixels x0 - pad .. x0 + 255 + pad: the pieces of a row are dealt to the threads (piece -> pixel is a
+        // shift or a small constant division; the row's validity and base are scalars)
+        constexpr int RP = PW * VPP, IT = (RP + 255) / 256;                // pieces per row, rounds per row
         typedef typename std::conditional<VB == 16, u32x4, u32x2p>::type SV;
-        SV sv[IT];
+        SV sv[PR][IT];
+        unsigned poff[IT];
 #pragma unroll
         for (int i = 0; i < IT; ++i) {
-            const int e = tid + i * 256, pc = e % VPP, px = (e / VPP) % PW, r = e / (VPP * PW);
-            const int hi = y0 - p.pad + r, wi = x0 - p.pad + px;
-            const bool ok = e < NP && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-            const unsigned off = ok ? (unsigned)((((b * p.H + hi) * p.W + wi) * p.x_ld + p.x_coff) * 2 + pc * VB) : HV_OOB;
-            if constexpr (VB == 16) sv[i] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, off, 0, 0);
-            else sv[i] = __builtin_amdgcn_raw_buffer_load_b64(xsrc, off, 0, 0);
+            const int e = tid + i * 256, px = e / VPP, pc = e - px * VPP, wi = x0 - p.pad + px;
+            poff[i] = (e < RP && (unsigned)wi < (unsigned)p.W) ? (unsigned)((wi * p.x_ld) * 2 + pc * VB) : HV_OOB;
         }
 #pragma unroll
-        for (int i = 0; i < IT; ++i) {
-            const int e = tid + i * 256;
-            if (e < NP) *reinterpret_cast<SV*>(xs + e * VB) = sv[i];
+        for (int r = 0; r < PR; ++r) {
+            const int hi = y0 - p.pad + r;                               // (scalar)
+            const bool rok = (unsigned)hi < (unsigned)p.H;
+            const unsigned rbase = rok ? (unsigned)((((b * p.H + hi) * p.W) * p.x_ld + p.x_coff) * 2) : HV_OOB;
+#pragma unroll
+            for (int i = 0; i < IT; ++i) {
+                const unsigned off = (rok && poff[i] != HV_OOB) ? rbase + poff[i] : HV_OOB;
+                if constexpr (VB == 16) sv[r][i] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, off, 0, 0);
+                else sv[r][i] = __builtin_amdgcn_raw_buffer_load_b64(xsrc, off, 0, 0);
+            }
         }
+#pragma unroll
+        for (int r = 0; r < PR; ++r)
+#pragma unroll
+            for (int i = 0; i < IT; ++i) {
+                const int e = tid + i * 256;
+                if (e < RP) *reinterpret_cast<SV*>(xs + (r * RP + e) * VB) = sv[r][i];
+            }
         __syncthreads();
         const int lx = wave * 64 + lane, x = x0 + lx;
 #pragma unroll 1
@@ -117,8 +134,7 @@ __global__ __launch_bounds__(256) void conv_px_kernel(const PxK p) {
             // ---- epilogue on the lane's own channel row: alpha, bias, (pre-activation accumulate), activation, act' multiplier, accumulate
             const long long pix = ((long long)b * p.H + y) * p.W + x;
             if constexpr (Y1) {
-                float v = acc[0][0] * p.alpha;
-                if (p.bias) v += p.bias[0];
+                float v = acc[0][0] * p.alpha + bv[0][0];
                 float* yp = reinterpret_cast<float*>(p.y) + pix * p.y_ld + p.y_coff;
                 if (p.accumulate == 2) v += *yp;
                 v = hv_act(v, p.act);      // (one value per pixel: the exact forms, as the VALU head kernels)
@@ -127,24 +143,41 @@ __global__ __launch_bounds__(256) void conv_px_kernel(const PxK p) {
             } else {
                 _Float16* yp = reinterpret_cast<_Float16*>(p.y) + pix * p.y_ld + p.y_coff;
                 const _Float16* mp = reinterpret_cast<const _Float16*>(p.mul) + pix * p.mul_ld + p.mul_coff;
+                // whole quads; the activation / multiplier switches are wave-uniform and taken once per quad, not per element
 #pragma unroll
                 for (int m = 0; m < CQ; ++m) {
                     if (4 * m >= p.Cout) break;
                     f16x4v old = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f}, m4 = old;
                     if (p.accumulate) old = *reinterpret_cast<const f16x4v*>(yp + 4 * m);
                     if (p.mul) m4 = *reinterpret_cast<const f16x4v*>(mp + 4 * m);
-                    f16x4v o;
+                    float v[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float v = acc[m][r] * p.alpha;
-                        if (p.bias) v += p.bias[min(4 * m + r, p.Cout - 1)];
-                        if (p.accumulate == 2) v += (float)old[r];
-                        v = hv_act_fast(v, p.act);
-                        if (p.mul) v *= hv_act_grad_from_out((float)m4[r], p.mul_act);
-                        if (p.accumulate == 1) v += (float)old[r];
-                        o[r] = (_Float16)v;
+                    for (int r = 0; r < 4; ++r) v[r] = acc[m][r] * p.alpha + bv[m][r];
+                    if (p.accumulate == 2) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += (float)old[r];
                     }
-                    *reinterpret_cast<f16x4v*>(yp + 4 * m) = o;
+                    if (p.act == HV_ACT_ELU) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = hv_act_fast(v[r], HV_ACT_ELU);
+                    } else if (p.act != HV_ACT_NONE) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = hv_act_fast(v[r], p.act);
+                    }
+                    if (p.mul) {
+                        if (p.mul_act == HV_ACT_ELU) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] *= (float)m4[r] > 0.f ? 1.f : (float)m4[r] + 1.f;
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] *= hv_act_grad_from_out((float)m4[r], p.mul_act);
+                        }
+                    }
+                    if (p.accumulate == 1) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += (float)old[r];
+                    }
+                    *reinterpret_cast<f16x4v*>(yp + 4 * m) = f16x4v{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
                 }
             }
         }
@@ -168,9 +201,10 @@ static int launch_px(PxK& k, hipStream_t s) {
 // hv_conv2d: KH = KW in {3, 5}, stride 1, dilation 1, fp16 operands and fp16 filter rows; the operand's pixel row holds CI = 4 / 8 / 12 / 16 channels (x_ld a
 // multiple of 4, the view starting on a multiple of 4), Cout <= 16 stored as fp16 rows of whole quads, or ONE fp32 output channel (the heads)
 int hv_conv2d_px(const hv_conv_desc* d, hipStream_t s) {
-    // A/B knob, bits: 1 heads forward (14.9 / 9.9 us against 22.0 / 15.3 for 12 / 8 channels at 256^2, bs 16), 2 heads' data gradient (21.5 / 16.0 against 38.7 / 26.7),
-    // 4 the 8 <-> 16 channel 3x3 layer (33.2 against 39.9 us data gradient, 34.8 against 38.8 forward).  Measured and not kept (the tiled kernels are faster there):
-    // the 16 -> 8 channel 3x3 layer and its data gradient (31.2 / 32.4 against 25.9 / 26.3 us) and the 5x5 stems (36.7 against 30.3 us)
+    // A/B knob, bits: 1 heads forward (13.4 / 9.4 us against 22.0 / 15.3 for 12 / 8 channels at 256^2, bs 16), 2 heads' data gradient (16.6 / 12.8 against 38.7 / 26.7),
+    // 4 the 8 <-> 16 channel 3x3 layer (26.9 against 39.9 us data gradient, 27.4 against 38.8 forward).  Measured and not kept (the tiled kernels are as fast or
+    // faster there): the 16 -> 8 channel 3x3 layer and its data gradient (28.1 / 29.4 against 25.9 / 26.3 us), the 5x5 stems (30.5 against 30.3 us) and their data
+    // gradient (16 -> 4: 34.5 against 34.0 us -- 25 taps x 32 B of window plus as many bytes of filter fragments per pixel: LDS-read bound either way)
     static const int on = getenv("HV_CONV_PX") ? atoi(getenv("HV_CONV_PX")) : 7;
     if (!on || d->precision != HV_F16 || !d->w_f16 || !d->x_f16 || d->KH != d->KW || (d->KH != 3 && d->KH != 5) || d->stride != 1 || d->dil != 1 || d->in_shift ||
         d->w_bstride || d->ch_scale || d->x1 || d->pool2 || d->stats || d->bstats || d->xn_stats)
