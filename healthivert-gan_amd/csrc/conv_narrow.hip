@@ -226,61 +226,76 @@ __global__ __launch_bounds__(256) void stem1_mfma_kernel(const NarrowK p, const 
 #pragma unroll
         for (int j = 0; j < 4; ++j) bias[t][j] = (p.bias && t < MT) ? p.bias[t * 16 + g * 4 + j] : 0.f;
     }
-    const int row = blockIdx.x, b = row / p.Ho, oy = row - b * p.Ho;
-    const long long ximg = (long long)b * p.img_stride + p.x_coff;
-    const int iy = oy * p.stride - p.pad + g;
-    const bool rok = (unsigned)iy < (unsigned)p.H;
-    const long long xrow = ximg + (long long)((rok ? iy : 0) >> p.in_shift) * p.Wp * p.x_ld;
-    for (int ox0 = wave * 16; ox0 < p.Wo; ox0 += 64) {
-        const int ox = ox0 + n, ix0 = ox * p.stride - p.pad;
-        _Float16 xv[4];
+    // the input's storage and the activation are chosen ONCE (wave-uniform): with hv_ld1 / hv_act deciding per element the kernel issued ~250 instructions per
+    // 16-pixel group, most of them scalar branches and their bookkeeping -- 25 us for 67 MB that a plain fill writes in 12.  A workgroup walks several output rows
+    // (the 20 filter / bias loads of a wave's prologue were paid per row: two 16-pixel groups)
+    auto walk = [&](auto ldx, auto actf) __attribute__((always_inline)) {
+      for (int row = blockIdx.x; row < p.B * p.Ho; row += gridDim.x) {
+        const int b = row / p.Ho, oy = row - b * p.Ho;
+        const long long ximg = (long long)b * p.img_stride + p.x_coff;
+        const int iy = oy * p.stride - p.pad + g;
+        const bool rok = (unsigned)iy < (unsigned)p.H;
+        const long long xrow = ximg + (long long)((rok ? iy : 0) >> p.in_shift) * p.Wp * p.x_ld;
+        for (int ox0 = wave * 16; ox0 < p.Wo; ox0 += 64) {
+            const int ox = ox0 + n, ix0 = ox * p.stride - p.pad;
+            _Float16 xv[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int ix = ix0 + e;
-            const bool ok = rok && ox < p.Wo && (unsigned)ix < (unsigned)p.W;
-            const float v = hv_ld1(p.x, xrow + (long long)((ok ? ix : 0) >> p.in_shift) * p.x_ld, p.x_half);
-            xv[e] = (_Float16)(ok ? v : 0.f);
-        }
-        const f16x4 xb = {xv[0], xv[1], xv[2], xv[3]};
-        const long long yi = ((long long)row * p.Wo + ox) * p.y_ld + p.y_coff + g * 4;
+            for (int e = 0; e < 4; ++e) {
+                const int ix = ix0 + e;
+                const bool ok = rok && ox < p.Wo && (unsigned)ix < (unsigned)p.W;
+                const float v = ldx(xrow + (long long)((ok ? ix : 0) >> p.in_shift) * p.x_ld);
+                xv[e] = (_Float16)(ok ? v : 0.f);
+            }
+            const f16x4 xb = {xv[0], xv[1], xv[2], xv[3]};
+            const long long yi = ((long long)row * p.Wo + ox) * p.y_ld + p.y_coff + g * 4;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            if (t >= MT) break;
-            const f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x16f16(wa[t], xb, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);   // all lanes: MFMA ignores EXEC
-            if (ox >= p.Wo) continue;                  // ragged last group: columns past the row end are computed on zeros and not stored
-            float o[4];
+            for (int t = 0; t < 4; ++t) {
+                if (t >= MT) break;
+                const f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x16f16(wa[t], xb, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);   // all lanes: MFMA ignores EXEC
+                if (ox >= p.Wo) continue;                  // ragged last group: columns past the row end are computed on zeros and not stored
+                float o[4];
+                if constexpr (ST) {
+                    f16x4 h;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) h[j] = (_Float16)actf(acc[j] * p.alpha + bias[t][j]);
+                    *reinterpret_cast<f16x4*>(stg + (wave * 16 + n) * LDT + t * 16 + g * 4) = h;
+                    continue;
+                }
+                const float4 old4 = p.accumulate ? hv_ld4(p.y, yi + t * 16, p.y_half) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float old[4] = {old4.x, old4.y, old4.z, old4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = acc[j] * p.alpha + bias[t][j];
+                    if (p.accumulate == 2) v += old[j];
+                    v = actf(v);
+                    o[j] = p.accumulate == 1 ? old[j] + v : v;
+                }
+                hv_st4(p.y, yi + t * 16, make_float4(o[0], o[1], o[2], o[3]), p.y_half);
+            }
             if constexpr (ST) {
-                f16x4 h;
+                // the wave's own 16 x 64 image (written and read by this wave only: no workgroup barrier)
+                __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the LDS stores above have landed
+                __builtin_amdgcn_wave_barrier();
+                _Float16* yb = reinterpret_cast<_Float16*>(p.y);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) h[j] = (_Float16)hv_act(acc[j] * p.alpha + bias[t][j], p.act);
-                *reinterpret_cast<f16x4*>(stg + (wave * 16 + n) * LDT + t * 16 + g * 4) = h;
-                continue;
+                for (int k = 0; k < 2; ++k) {
+                    const int q = lane + 64 * k, px = q >> 3, c8 = q & 7;
+                    const hv_u32x4 v = *reinterpret_cast<const hv_u32x4*>(stg + (wave * 16 + px) * LDT + c8 * 8);
+                    if (ox0 + px < p.Wo) *reinterpret_cast<hv_u32x4*>(yb + ((long long)row * p.Wo + ox0 + px) * p.y_ld + p.y_coff + c8 * 8) = v;
+                }
+                __builtin_amdgcn_wave_barrier();             // the next group's stores come after these reads
             }
-            const float4 old4 = p.accumulate ? hv_ld4(p.y, yi + t * 16, p.y_half) : make_float4(0.f, 0.f, 0.f, 0.f);
-            const float old[4] = {old4.x, old4.y, old4.z, old4.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float v = acc[j] * p.alpha + bias[t][j];
-                if (p.accumulate == 2) v += old[j];
-                v = hv_act(v, p.act);
-                o[j] = p.accumulate == 1 ? old[j] + v : v;
-            }
-            hv_st4(p.y, yi + t * 16, make_float4(o[0], o[1], o[2], o[3]), p.y_half);
         }
-        if constexpr (ST) {
-            // the wave's own 16 x 64 image (written and read by this wave only: no workgroup barrier)
-            __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the LDS stores above have landed
-            __builtin_amdgcn_wave_barrier();
-            _Float16* yb = reinterpret_cast<_Float16*>(p.y);
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int q = lane + 64 * k, px = q >> 3, c8 = q & 7;
-                const hv_u32x4 v = *reinterpret_cast<const hv_u32x4*>(stg + (wave * 16 + px) * LDT + c8 * 8);
-                if (ox0 + px < p.Wo) *reinterpret_cast<hv_u32x4*>(yb + ((long long)row * p.Wo + ox0 + px) * p.y_ld + p.y_coff + c8 * 8) = v;
-            }
-            __builtin_amdgcn_wave_barrier();             // the next group's stores come after these reads
-        }
-    }
+      }
+    };
+    const float* xf = reinterpret_cast<const float*>(p.x);
+    const _Float16* xh = reinterpret_cast<const _Float16*>(p.x);
+    auto ld32 = [&](long long i) { return xf[i]; };
+    auto ld16 = [&](long long i) { return (float)xh[i]; };
+    auto lrelu = [](float v) { return v > 0.f ? v : 0.2f * v; };      // (hv_act's expression)
+    auto anyact = [&](float v) { return hv_act(v, p.act); };
+    if (p.act == HV_ACT_LRELU) { if (p.x_half) walk(ld16, lrelu); else walk(ld32, lrelu); }
+    else { if (p.x_half) walk(ld16, anyact); else walk(ld32, anyact); }
 }
 
 // The generators' 5x5 stems (4 -> 16 channels at full resolution), fp16 mode: K = 25 taps x 4 channels = 100, flattened (tap, channel) and
@@ -542,7 +557,8 @@ int hv_conv2d_thin_in(const hv_conv_desc* d, hipStream_t s) {
         static const int stem_st = getenv("HV_STEM_ST") ? atoi(getenv("HV_STEM_ST")) : 1;   // A/B knob
         if (stem_st && d->y_f16 && d->Cout == 64 && !d->accumulate && !(d->y_ld & 7) && !(d->y_coff & 7) && !((uintptr_t)d->y & 15)) {
             HV_KNAME("stem1_mfma_kernel<true>");
-            hipLaunchKernelGGL(stem1_mfma_kernel<true>, dim3(d->B * d->Ho), dim3(256), 0, s, k, reinterpret_cast<const _Float16*>(d->w_f16));
+            static const int rpw = getenv("HV_STEM1_ROWS") ? atoi(getenv("HV_STEM1_ROWS")) : 1;      // tuning knob: output rows per workgroup (B32 / B16 at 256^2, us: 1 row 23.9 / 12.5, 2 rows 23.4 / 12.3, 4 rows 22.3 / 15.1, 8 rows 28.7 / 22.2)
+            hipLaunchKernelGGL(stem1_mfma_kernel<true>, dim3(hv_cdiv(d->B * d->Ho, rpw > 0 ? rpw : 1)), dim3(256), 0, s, k, reinterpret_cast<const _Float16*>(d->w_f16));
             HV_LAUNCH_CHECK();
             return HV_OK;
         }
