@@ -5,6 +5,9 @@
 
 static int pw_grid(long long n, int cap = 8192) { long long b = (n + 255) / 256; return (int)(b > cap ? cap : (b < 1 ? 1 : b)); }
 #define PW_LOOP(i, n) for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long long)gridDim.x * blockDim.x)
+// flat index / small divisor: every tensor of the step has < 2^31 elements, where one 32-bit division (~20 instructions) stands for the 64-bit one (~100: the flat-index
+// kernels spent most of their instructions there)
+__device__ __forceinline__ long long pw_div(long long i, int d) { return (i >> 31) == 0 ? (long long)((unsigned)i / (unsigned)d) : i / d; }
 
 // ------------------------------------------------------------------------------------------------ layout
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, void* __restrict__ dst, int dh, int C, int HW, int dst_ld, int dst_coff, long long n) {
@@ -42,32 +45,33 @@ extern "C" int hv_nhwc_to_nchw(const void* src, int src_f16, float* dst, int B, 
 
 // mode 0 same size; 1 src half size (nearest x2 up); 2 src double size (nearest x1/2: even indices);
 // 3 dst(half) (+)= sum of the 2x2 block of src(full)  [adjoint of 1];  4 dst(full) (+)= src(half) at even idx else 0 [adjoint of 2]
+// grid (pieces of a row / 256, rows): the row (image, h) is a scalar and the position in the row a 32-bit index -- the flat-index form spent five 64-bit
+// divisions per element (12 us for a 22-MB copy that the memory system moves in 5)
 template <int V>
-__global__ void copy_channels_kernel(const void* __restrict__ src, int sh, void* __restrict__ dst, int dh, int H, int W, int C, int src_ld, int src_coff,
-                                     int dst_ld, int dst_coff, int mode, int acc, long long n) {
-    const int CV = C / V;
-    PW_LOOP(i, n) {
-        const int cg = (int)(i % CV);
-        long long r = i / CV;
-        const int w = (int)(r % W); r /= W;
-        const int h = (int)(r % H);
-        const long long b = r / H;
+__global__ __launch_bounds__(256) void copy_channels_kernel(const void* __restrict__ src, int sh, void* __restrict__ dst, int dh, int H, int W, int C, int src_ld, int src_coff,
+                                     int dst_ld, int dst_coff, int mode, int acc, int rows) {
+    const int CV = C / V, per_row = W * CV;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= per_row) return;
+    const int w = CV == 1 ? e : e / CV, cg = e - w * CV;
+    for (int row = blockIdx.y; row < rows; row += gridDim.y) {
+        const int b = row / H, h = row - b * H;      // (scalar)
         float v[4] = {0.f, 0.f, 0.f, 0.f};
         auto rd = [&](long long pix) {
             const long long si = pix * src_ld + src_coff + cg * V;
             if (V == 4) { const float4 t = hv_ld4(src, si, sh); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
             else v[0] += hv_ld1(src, si, sh);
         };
-        if (mode == 0) rd((b * H + h) * W + w);
-        else if (mode == 1) rd((b * (H >> 1) + (h >> 1)) * (W >> 1) + (w >> 1));
-        else if (mode == 2) rd((b * (H * 2) + 2 * h) * (W * 2) + 2 * w);
+        if (mode == 0) rd(((long long)b * H + h) * W + w);
+        else if (mode == 1) rd(((long long)b * (H >> 1) + (h >> 1)) * (W >> 1) + (w >> 1));
+        else if (mode == 2) rd(((long long)b * (H * 2) + 2 * h) * (W * 2) + 2 * w);
         else if (mode == 3) {
-            const long long p = (b * (H * 2) + 2 * h) * (W * 2) + 2 * w;
+            const long long p = ((long long)b * (H * 2) + 2 * h) * (W * 2) + 2 * w;
             rd(p); rd(p + 1); rd(p + 2 * W); rd(p + 2 * W + 1);
         } else {
-            if (!((h | w) & 1)) rd((b * (H >> 1) + (h >> 1)) * (W >> 1) + (w >> 1));
+            if (!((h | w) & 1)) rd(((long long)b * (H >> 1) + (h >> 1)) * (W >> 1) + (w >> 1));
         }
-        const long long di = ((b * H + h) * W + w) * dst_ld + dst_coff + cg * V;
+        const long long di = (((long long)b * H + h) * W + w) * dst_ld + dst_coff + cg * V;
         if (V == 4) {
             float4 o = make_float4(v[0], v[1], v[2], v[3]);
             if (acc) { const float4 t = hv_ld4(dst, di, dh); o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
@@ -83,9 +87,11 @@ extern "C" int hv_copy_channels(const void* src, int src_f16, void* dst, int dst
     if (src_ld < src_coff + C || dst_ld < dst_coff + C) return HV_ERR_ARG;
     if ((mode == 1 || mode == 4) && ((H | W) & 1)) return HV_ERR_UNSUPPORTED;
     const bool vec = !(C & 3) && !(src_ld & 3) && !(src_coff & 3) && !(dst_ld & 3) && !(dst_coff & 3) && !((uintptr_t)src & 15) && !((uintptr_t)dst & 15);
-    const long long n = (long long)B * H * W * (vec ? C / 4 : C);
-    if (vec) hipLaunchKernelGGL((copy_channels_kernel<4>), dim3(pw_grid(n)), dim3(256), 0, (hipStream_t)stream, src, src_f16, dst, dst_f16, H, W, C, src_ld, src_coff, dst_ld, dst_coff, mode, accumulate, n);
-    else hipLaunchKernelGGL((copy_channels_kernel<1>), dim3(pw_grid(n)), dim3(256), 0, (hipStream_t)stream, src, src_f16, dst, dst_f16, H, W, C, src_ld, src_coff, dst_ld, dst_coff, mode, accumulate, n);
+    const long long per_row = (long long)W * (vec ? C / 4 : C), rows = (long long)B * H;
+    if (per_row >= (1ll << 30) || rows >= (1ll << 31)) return HV_ERR_UNSUPPORTED;
+    const dim3 grid((unsigned)((per_row + 255) / 256), (unsigned)(rows < 32768 ? rows : 32768));
+    if (vec) hipLaunchKernelGGL((copy_channels_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, src, src_f16, dst, dst_f16, H, W, C, src_ld, src_coff, dst_ld, dst_coff, mode, accumulate, (int)rows);
+    else hipLaunchKernelGGL((copy_channels_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, src, src_f16, dst, dst_f16, H, W, C, src_ld, src_coff, dst_ld, dst_coff, mode, accumulate, (int)rows);
     HV_LAUNCH_CHECK();
     return HV_OK;
 }
@@ -94,7 +100,7 @@ extern "C" int hv_copy_channels(const void* src, int src_f16, void* dst, int dst
 __global__ void gen_input_kernel(const float* __restrict__ x, const float* __restrict__ seg, const float* __restrict__ mask,
                                  const double* __restrict__ ratio, void* __restrict__ dst, int dh, int HW, int CP, int order, long long n) {
     PW_LOOP(i, n) {
-        const long long b = i / HW;
+        const long long b = pw_div(i, HW);
         const float r = (float)ratio[b];
         float c0 = x[i], c1, c2, c3 = 0.f;
         if (order == 0) { c1 = r; c2 = mask[i]; }
@@ -159,9 +165,9 @@ extern "C" int hv_gap_fc_sigmoid(const void* x, int x_f16, int B, int HW, int C,
 __global__ void gap_bwd_dx_kernel(const float* __restrict__ dpred, const float* __restrict__ pred, const float* __restrict__ w, void* __restrict__ dx, int dxh,
                                   int HW, int C, int dx_ld, long long n, const void* __restrict__ mul, int mulh, int mul_ld, int mul_act) {
     PW_LOOP(i, n) {
-        const int c = (int)(i % C);
-        const long long bp = i / C;
-        const long long b = bp / HW;
+        const long long bp = pw_div(i, C);
+        const int c = (int)(i - bp * C);
+        const long long b = pw_div(bp, HW);
         const float p = pred[b];
         float g = dpred[b] * p * (1.f - p) * w[c] / (float)HW;
         if (mul) g *= hv_act_grad_from_out(hv_ld1(mul, bp * mul_ld + c, mulh), mul_act);      // dx holds PRE-activation gradients (its other writers applied act' too)
@@ -197,9 +203,9 @@ extern "C" int hv_gap_fc_sigmoid_backward(const float* dpred, const float* pred,
 // ------------------------------------------------------------------------------------------------ Sobel
 __global__ void sobel_kernel(const float* __restrict__ img, float* __restrict__ out, int H, int W, long long n) {
     PW_LOOP(i, n) {
-        const int w = (int)(i % W);
-        const long long r = i / W;
-        const int h = (int)(r % H);
+        const long long r = pw_div(i, W);
+        const int w = (int)(i - r * W);
+        const int h = (int)(r - pw_div(r, H) * H);
         const float* p = img + (r - h) * W;  // image base
         const int hm = max(h - 1, 0), hp = min(h + 1, H - 1), wm = max(w - 1, 0), wp = min(w + 1, W - 1);
         const float a = p[hm * W + wm], b = p[hm * W + w], c = p[hm * W + wp];
@@ -239,7 +245,7 @@ __device__ __forceinline__ float shrm_pick(const float* gen_img, const float* re
 __global__ void post_generator_kernel(const hv_postg_desc d, long long n) {
     const int HW = d.H * d.W, c0 = d.W / 2 - d.half_band, c1 = d.W / 2 + d.half_band;
     PW_LOOP(i, n) {
-        const int b = (int)(i / HW), p = (int)(i - (long long)b * HW);
+        const int b = (int)pw_div(i, HW), p = (int)(i - (long long)b * HW);
         const int row = p / d.W, col = p - row * d.W;
         const float mh = (float)d.maxheight[b];
         const float p1 = d.pred1[b] * mh, p2 = d.pred2[b] * mh;
@@ -279,7 +285,7 @@ __global__ void shrm_composite_kernel(const float* __restrict__ gen, const float
                                       float* __restrict__ out, int* rows, int H, int W, long long n) {
     const int HW = H * W;
     PW_LOOP(i, n) {
-        const int b = (int)(i / HW), p = (int)(i - (long long)b * HW);
+        const int b = (int)pw_div(i, HW), p = (int)(i - (long long)b * HW);
         const int row = p / W, col = p - row * W;
         const Rows r = shrm_rows(pred_scaled[b], height[b], x1[b]);
         out[i] = shrm_pick(gen + (long long)b * HW, real + (long long)b * HW, row, col, W, r, (int)x2[b]);
@@ -299,7 +305,7 @@ __global__ void shrm_backward_kernel(const float* __restrict__ d_fake, const flo
                                      const int* __restrict__ rows, int which, float* __restrict__ d_gen, int H, int W, int half_band, int acc, long long n) {
     const int HW = H * W, c0 = W / 2 - half_band, c1 = W / 2 + half_band;
     PW_LOOP(i, n) {
-        const int b = (int)(i / HW), p = (int)(i - (long long)b * HW);
+        const int b = (int)pw_div(i, HW), p = (int)(i - (long long)b * HW);
         const int row = p / W, col = p - row * W;
         const int xu = rows[b * 4 + which * 2], xb = rows[b * 4 + which * 2 + 1];
         float g = 0.f;
@@ -661,7 +667,7 @@ __global__ void gloss_seed_kernel(const hv_gloss_desc d, const float* __restrict
     const float gs = d.grad_scale > 0.f ? d.grad_scale : 1.f;      // power of two: the scaled seeds are exact multiples
     const float cl1 = coef[0] * gs, invB = gs / (float)d.B;
     PW_LOOP(i, n) {
-        const int b = (int)(i / HW);
+        const int b = (int)pw_div(i, HW);
         const float rb = d.real_B[i];
         const float e1 = d.fake_B[i] - rb, e2 = d.fake_B_coarse[i] - rb;
         const float s1 = cl1 * (e1 > 0.f ? 1.f : (e1 < 0.f ? -1.f : 0.f));
