@@ -96,6 +96,26 @@ extern "C" int hv_copy_channels(const void* src, int src_f16, void* dst, int dst
     return HV_OK;
 }
 
+// dst = a + b over C channels of same-size tensors (each with its own storage, channel stride and offset): the two-launch "copy, then accumulate" of a gradient
+// that has two contributions (x_stage1 and coarse_seg feed both a loss and the refinement generator) as one pass
+__global__ __launch_bounds__(256) void add_channels_kernel(const void* __restrict__ a, int ah, int a_ld, int a_coff, const void* __restrict__ b, int bh, int b_ld, int b_coff,
+                                                           void* __restrict__ dst, int dh, int d_ld, int d_coff, int C, long long npix) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= npix * C) return;
+    const long long pix = C == 1 ? e : e / C;
+    const int c = (int)(e - pix * C);
+    hv_st1(dst, pix * d_ld + d_coff + c, hv_ld1(a, pix * a_ld + a_coff + c, ah) + hv_ld1(b, pix * b_ld + b_coff + c, bh), dh);
+}
+extern "C" int hv_add_channels(const void* a, int a_f16, int a_ld, int a_coff, const void* b, int b_f16, int b_ld, int b_coff, void* dst, int dst_f16, int dst_ld,
+                               int dst_coff, long long npix, int C, void* stream) {
+    if (!a || !b || !dst || npix <= 0 || C <= 0 || a_ld < a_coff + C || b_ld < b_coff + C || dst_ld < dst_coff + C) return HV_ERR_ARG;
+    if (npix * C >= (1ll << 40)) return HV_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(add_channels_kernel, dim3((unsigned)((npix * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, a_f16, a_ld, a_coff, b, b_f16, b_ld, b_coff, dst,
+                       dst_f16, dst_ld, dst_coff, C, npix);
+    HV_LAUNCH_CHECK();
+    return HV_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ generator input
 __global__ void gen_input_kernel(const float* __restrict__ x, const float* __restrict__ seg, const float* __restrict__ mask,
                                  const double* __restrict__ ratio, void* __restrict__ dst, int dh, int HW, int CP, int order, long long n) {
@@ -615,8 +635,12 @@ __global__ __launch_bounds__(256) void gloss_finalize_kernel(const hv_gloss_desc
         __syncthreads();
         for (int e = threadIdx.x; e < min(B - b0, GL_MAXB) * GL_NQ; e += 256) {
             const int b = e / GL_NQ, k = e - b * GL_NQ;
+            double v[GL_CHUNKS];      // every load of the thread in flight before the first add (the rolled loop was a chain of 32 round trips); same order of the sum
+#pragma unroll
+            for (int c = 0; c < GL_CHUNKS; ++c) v[c] = part[((long long)(b0 + b) * GL_CHUNKS + c) * GL_NQ + k];
             double q = 0;
-            for (int c = 0; c < GL_CHUNKS; ++c) q += part[((long long)(b0 + b) * GL_CHUNKS + c) * GL_NQ + k];
+#pragma unroll
+            for (int c = 0; c < GL_CHUNKS; ++c) q += v[c];
             qs[b][k] = q;
         }
         __syncthreads();
@@ -624,10 +648,33 @@ __global__ __launch_bounds__(256) void gloss_finalize_kernel(const hv_gloss_desc
             for (int b = 0; b < GL_MAXB; ++b)
                 for (int k = 0; k < GL_NQ; ++k) const_cast<double*>(part)[((long long)(b0 + b) * GL_CHUNKS) * GL_NQ + k] = qs[b][k];
     }
-    if (threadIdx.x != 0) return;
     const double N = (double)B * d.H * d.W, eps = 1e-5;
-    double S1 = 0, S2 = 0, cnt = 0, E = 0, dice_f = 0, dice_c = 0;
     const int last0 = ((B - 1) / GL_MAXB) * GL_MAXB;
+    // per-sample terms (the two double divisions, the coefficient stores, the height-loss terms) by one thread per sample; thread 0 then adds them in sample order as
+    // before -- the same values in the same order (one thread doing all of it took most of this kernel's 18 us, between the discriminator passes and the backward)
+    __shared__ double dterm[GL_MAXB][3];
+    __shared__ double qsum[GL_MAXB][4];
+    if (B <= GL_MAXB && threadIdx.x < B) {
+        const int b = threadIdx.x;
+        const double* q = qs[b];
+        const double Af = q[4] + q[5] + eps, Tf = 2 * q[3] + eps, Ac = q[7] + q[8] + eps, Tc = 2 * q[6] + eps;
+        dterm[b][0] = Tf / Af; dterm[b][1] = Tc / Ac;
+        qsum[b][0] = q[0]; qsum[b][1] = q[1]; qsum[b][2] = q[2]; qsum[b][3] = q[9];
+        coef[1 + 4 * b + 0] = (float)Af; coef[1 + 4 * b + 1] = (float)Tf; coef[1 + 4 * b + 2] = (float)Ac; coef[1 + 4 * b + 3] = (float)Tc;
+        const float h = (float)d.height[b], mh = (float)d.maxheight[b];
+        const float a1 = d.pred1_h[b] - h, a2 = d.pred2_h[b] - h;
+        dterm[b][2] = (double)(fabsf(a1) / h * 40.f + fabsf(a2) / h * 40.f);
+        const float s1 = a1 > 0.f ? 1.f : (a1 < 0.f ? -1.f : 0.f), s2 = a2 > 0.f ? 1.f : (a2 < 0.f ? -1.f : 0.f);
+        const float gs = d.grad_scale > 0.f ? d.grad_scale : 1.f;
+        if (d.d_pred1) d.d_pred1[b] = gs * (40.f * s1 / h * mh / (float)B);
+        if (d.d_pred2) d.d_pred2[b] = gs * (40.f * s2 / h * mh / (float)B);
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    double S1 = 0, S2 = 0, cnt = 0, E = 0, dice_f = 0, dice_c = 0;
+    if (B <= GL_MAXB) {
+        for (int b = 0; b < B; ++b) { S1 += qsum[b][0]; S2 += qsum[b][1]; cnt += qsum[b][2]; E += qsum[b][3]; dice_f += dterm[b][0]; dice_c += dterm[b][1]; }
+    } else
     for (int b = 0; b < B; ++b) {
         double q[GL_NQ];
         for (int k = 0; k < GL_NQ; ++k) q[k] = b >= last0 ? qs[b - last0][k] : part[((long long)b * GL_CHUNKS) * GL_NQ + k];
@@ -643,6 +690,9 @@ __global__ __launch_bounds__(256) void gloss_finalize_kernel(const hv_gloss_desc
     const float ldice = (float)((1.0 - dice_f / B) * 15.0), lcd = (float)((1.0 - dice_c / B) * 10.0);
     const float ledge = (float)(E / N * 800.0);
     double hsum = 0;
+    if (B <= GL_MAXB) {
+        for (int b = 0; b < B; ++b) hsum += dterm[b][2];
+    } else
     for (int b = 0; b < B; ++b) {
         const float h = (float)d.height[b], mh = (float)d.maxheight[b];
         const float a1 = d.pred1_h[b] - h, a2 = d.pred2_h[b] - h;

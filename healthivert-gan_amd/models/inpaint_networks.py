@@ -526,8 +526,7 @@ class Generator(nn.Module):
         if 'd_xs1_total' not in P.__dict__:      # (setdefault(..., torch.zeros_like(...)) built and filled the default on every call: a fill kernel per step)
             P.d_xs1_total, P.d_cs_total = torch.zeros_like(P.x_stage1), torch.zeros_like(P.coarse_seg)
         d_xs1_total = P.d_xs1_total
-        ops.copy_channels(Act(d_x_stage1.view(B, H, W, 1)), Act(d_xs1_total.view(B, H, W, 1)), mode=0)
-        ops.copy_channels(gcat17.slice(c // 2, 1), Act(d_xs1_total.view(B, H, W, 1)), mode=0, accumulate=True)
+        ops.add_channels(Act(d_x_stage1.view(B, H, W, 1)), gcat17.slice(c // 2, 1), Act(d_xs1_total.view(B, H, W, 1)))
         # pure links (single producer, single consumer): the consumer's data gradient applies the producer's act'
         # (M[5] and M[3] read their input up-sampled: they link too where their data gradient can leave pooled, otherwise the chain breaks there)
         E.conv_backward_chain([M[6], M[5], M[4], M[3], M[2], M[1]], book, prec, stop_before=M[0],
@@ -558,8 +557,7 @@ class Generator(nn.Module):
             E.conv_backward(pm_rev[-1], book, prec, premultiplied=E.chain_link(pm_rev[-2], pm_rev[-1], prec))
         # coarse_seg enters the fine generator as channel 1 of its input
         d_cs_total = P.d_cs_total
-        ops.copy_channels(Act(d_coarse_seg.view(B, H, W, 1)), Act(d_cs_total.view(B, H, W, 1)), mode=0)
-        ops.copy_channels(book.twin(P.f_in).slice(1, 1), Act(d_cs_total.view(B, H, W, 1)), mode=0, accumulate=True)
+        ops.add_channels(Act(d_coarse_seg.view(B, H, W, 1)), book.twin(P.f_in).slice(1, 1), Act(d_cs_total.view(B, H, W, 1)))
         if wg_block:
             book.defer_wgrad = G_WGRAD_COARSE > 0      # (the first coarse layers' weight gradients join the side streams' queue behind this block: see below)
             launch_block()

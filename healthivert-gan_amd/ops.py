@@ -450,6 +450,13 @@ def copy_channels(src, dst, mode=0, accumulate=False):
                     mode, int(accumulate), stream())
 
 
+def add_channels(a, b, dst):
+    """dst = a + b (Acts of the same size and channel count, any storage): one launch for a gradient with two contributions."""
+    assert a.C == b.C == dst.C and a.npix == b.npix == dst.npix
+    _lib.get().call('hv_add_channels', ptr(a.t), a.f16, a.ld, a.coff, ptr(b.t), b.f16, b.ld, b.coff, ptr(dst.t), dst.f16, dst.ld, dst.coff,
+                    ctypes.c_longlong(dst.npix), dst.C, stream())
+
+
 def fill(t, value=0.0):
     _lib.get().call('hv_fill', ptr(t), ctypes.c_longlong(t.numel()), ctypes.c_float(value), stream())
 

@@ -284,6 +284,10 @@ int hv_nhwc_to_nchw(const void* src, int src_f16, float* dst, int B, int C, int 
  * 2x2 block of src(full) [adjoint of 1]; 4: dst(full) (+)= src(half) at even indices, 0 elsewhere [adjoint of 2]. */
 int hv_copy_channels(const void* src, int src_f16, void* dst, int dst_f16, int B, int H, int W, int C, int src_ld, int src_coff, int dst_ld,
                      int dst_coff, int mode, int accumulate, void* stream);   /* *_f16: storage of src / dst (may differ: the copy converts) */
+/* dst = a + b over C channels of same-size [npix] tensors, each with its own storage / channel stride / offset: a gradient with two contributions
+ * (models/pix2pix_model.py:310-330 backpropagates x_stage1 and coarse_seg through a loss AND through the refinement generator) in one pass. */
+int hv_add_channels(const void* a, int a_f16, int a_ld, int a_coff, const void* b, int b_f16, int b_ld, int b_coff, void* dst, int dst_f16, int dst_ld,
+                    int dst_coff, long long npix, int C, void* stream);
 
 /* ---------------------------------------------------------------- generator heads and inputs
  * cat[x, ratio-plane, mask] / cat[x, coarse_seg, mask, ratio-plane] (models/inpaint_networks.py:71-77,173-179)
