@@ -604,6 +604,7 @@ __global__ __launch_bounds__(256) void gloss_partial_kernel(const hv_gloss_desc 
     float q[GL_NQ];
 #pragma unroll
     for (int k = 0; k < GL_NQ; ++k) q[k] = 0.f;
+#pragma unroll 4      // (four pixels' 10 loads in flight per thread: the rolled loop was a chain of eight memory round trips; same order of every thread's sums)
     for (int p = p0 + tid; p < p1; p += 256) {
         const long long i = (long long)b * HW + p;
         const float rb = d.real_B[i];

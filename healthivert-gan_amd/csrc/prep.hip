@@ -33,8 +33,8 @@ __global__ __launch_bounds__(PREP_THREADS) void weight_prep_kernel(const hv_wpre
             float ss = 0.f;
             for (int k = tid; k < K; k += PREP_THREADS) {
                 float t = 0.f;
-#pragma unroll 8
-                for (int co = 0; co < L.Cout; ++co) t += W[(long long)co * K + k] * u_s[co];      // (same summation order; the loads run ahead)
+#pragma unroll 32
+                for (int co = 0; co < L.Cout; ++co) t += W[(long long)co * K + k] * u_s[co];      // (same summation order; the loads run ahead: 32 in flight -- this kernel is a chain of memory round trips on the step's tail)
                 v_s[k] = t;
                 ss += t * t;
             }
@@ -46,17 +46,28 @@ __global__ __launch_bounds__(PREP_THREADS) void weight_prep_kernel(const hv_wpre
         }
         // s = W v  (one wave per row)
         float ss = 0.f;
-        for (int co = wave; co < L.Cout; co += nwave) {
-            float t = 0.f;
-#pragma unroll 8
-            for (int k = lane; k < K; k += 64) t += W[(long long)co * K + k] * v_s[k];
-            t = hv_wave_sum(t);
-            if (lane == 0) {
-                if (L.power_iter) {
-                    ss += t * t;
-                    u_s[co] = t;  // raw s = W v, normalised below
-                } else {
-                    ss += u_s[co] * t;  // sigma = u . (W v) with the stored u
+        for (int co0 = wave; co0 < L.Cout; co0 += 4 * nwave) {      // four rows of a wave at a time: their loads are all in flight before the first reduction (same sums per row, same order of ss)
+            float t[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + r * nwave;
+                if (co < L.Cout) {
+#pragma unroll 16
+                    for (int k = lane; k < K; k += 64) t[r] += W[(long long)co * K + k] * v_s[k];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + r * nwave;
+                if (co >= L.Cout) break;
+                const float tr = hv_wave_sum(t[r]);
+                if (lane == 0) {
+                    if (L.power_iter) {
+                        ss += tr * tr;
+                        u_s[co] = tr;  // raw s = W v, normalised below
+                    } else {
+                        ss += u_s[co] * tr;  // sigma = u . (W v) with the stored u
+                    }
                 }
             }
         }
