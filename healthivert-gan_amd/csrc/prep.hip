@@ -397,10 +397,11 @@ __global__ __launch_bounds__(256) void weight_prep_bwd_kernel(const hv_wprep_bwd
         const long long i = base + k * 256 + threadIdx.x;
         if (i >= no) break;
         int co, ci;
-        const int tap = (int)(i % L.taps);
-        const long long r = i / L.taps;
-        if (L.transposed_src) { co = (int)(r % L.Cout); ci = (int)(r / L.Cout); }
-        else { ci = (int)(r % L.Cin); co = (int)(r / L.Cin); }
+        // (a layer has < 2^31 weights: 32-bit divisions -- the 64-bit ones were most of this kernel's instructions)
+        const unsigned iu = (unsigned)i, r = iu / (unsigned)L.taps;
+        const int tap = (int)(iu - r * (unsigned)L.taps);
+        if (L.transposed_src) { ci = (int)(r / (unsigned)L.Cout); co = (int)(r - (unsigned)ci * (unsigned)L.Cout); }
+        else { co = (int)(r / (unsigned)L.Cin); ci = (int)(r - (unsigned)co * (unsigned)L.Cin); }
         // conv: dw_ohwi is [co][tap][CinP]; conv_transpose (transposed_src): [ci][tap][CinP] with CinP = padded Cout
         float g = L.transposed_src ? L.dw_ohwi[((long long)ci * L.taps + tap) * L.CinP + co]
                                    : L.dw_ohwi[((long long)co * L.taps + tap) * L.CinP + ci];
@@ -411,6 +412,7 @@ __global__ __launch_bounds__(256) void weight_prep_bwd_kernel(const hv_wprep_bwd
 
 extern "C" int hv_weight_prep_backward(const hv_wprep_bwd_layer* d_layers, int n_layers, long long max_numel, int any_sn, void* stream) {
     if (!d_layers || n_layers <= 0 || max_numel <= 0) return HV_ERR_ARG;
+    if (max_numel >= (1ll << 31)) return HV_ERR_UNSUPPORTED;      // (weight_prep_bwd_kernel indexes a layer's weights in 32 bits)
     if (any_sn) {
         hipLaunchKernelGGL(weight_prep_bwd_dot_kernel, dim3(n_layers), dim3(PREP_THREADS), 0, (hipStream_t)stream, d_layers);
         HV_LAUNCH_CHECK();
