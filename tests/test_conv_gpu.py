@@ -886,6 +886,8 @@ PX_CASES = [   # B, H, W, Cin, Cout, k, transposed, act, bias, mul, accumulate
     (2, 24, 50, 8, 16, 3, 1, 'none', 0, 'elu', 1),      # 8 -> 16 and the data gradient of 16 -> 8
     (2, 31, 66, 8, 16, 3, 0, 'elu', 1, None, 0),
     (3, 300, 20, 8, 16, 3, 0, 'none', 0, None, 0),      # more rows than one tile, narrow
+    (1, 5, 3, 8, 1, 3, 0, 'none', 0, None, 0),          # smaller than a tile in both directions
+    (2, 9, 260, 4, 8, 3, 1, 'none', 0, 'elu', 0),       # two 256-pixel segments per row, four live gradient channels
     (16, 256, 256, 12, 1, 3, 0, 'clamp', 1, None, 0),   # the step's own shape
 ]
 
