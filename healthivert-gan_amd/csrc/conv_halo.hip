@@ -240,8 +240,12 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloK p) {
             if (p.ep16 == 2) {
                 const f16x8 m8 = *reinterpret_cast<const f16x8*>(reinterpret_cast<const _Float16*>(p.mul_src) + opix * p.mul_ld + p.mul_coff + ch);
                 f16x8 v8 = __builtin_bit_cast(f16x8, o);
+                {
+                    float f0[4] = {(float)m8[0], (float)m8[1], (float)m8[2], (float)m8[3]}, f1[4] = {(float)m8[4], (float)m8[5], (float)m8[6], (float)m8[7]};
+                    hv_act_grad4(f0, p.mul_act); hv_act_grad4(f1, p.mul_act);      // (one switch per quad, not per element)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v8[e] = (_Float16)((float)v8[e] * hv_act_grad_from_out((float)m8[e], p.mul_act));
+                    for (int e = 0; e < 4; ++e) { v8[e] = (_Float16)((float)v8[e] * f0[e]); v8[4 + e] = (_Float16)((float)v8[4 + e] * f1[e]); }
+                }
                 o = __builtin_bit_cast(u32x4, v8);
             }
             if (p.accumulate) {

@@ -151,6 +151,10 @@ __global__ __launch_bounds__(256, 2) void conv_s2t_kernel(const S2TK p) {
         // lane.  Through LDS (the patch buffers are free behind the loop's last barrier) the 2TH x 32-pixel tile leaves as whole channel rows.
         constexpr int LDO = BN + 8, OW = 2 * TW;
         _Float16* ot = patch;
+        // the data gradients that take this path carry no bias / activation of their own (their act' factor comes in the second stage): that case is one
+        // multiply per element; with the shared per-element epilogue -- channel bound, scale, bias and activation each a wave-uniform branch per ELEMENT -- the
+        // 16 -> 16 layer issued ~820 scalar and ~680 vector instructions per wave around its 18 MFMAs (PMC), 28.5 us for 75 MB
+        const bool plain = p.ep16 == 2 && !p.bias && p.act == HV_ACT_NONE && n_base + BN <= p.Cout;      // (scalar)
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int i = ty0 + m, j = tx0 + (lane & 15);
@@ -162,28 +166,35 @@ __global__ __launch_bounds__(256, 2) void conv_s2t_kernel(const S2TK p) {
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 const int cl = n * 16 + (lane >> 4) * 4;
-                const f32x4 v = hv_conv_value4<true>(epi, acc[n][m], n_base + cl, mp);
+                f32x4 v;
+                if (plain) v = f32x4{acc[n][m][0] * p.alpha, acc[n][m][1] * p.alpha, acc[n][m][2] * p.alpha, acc[n][m][3] * p.alpha};
+                else v = hv_conv_value4<true>(epi, acc[n][m], n_base + cl, mp);
                 *reinterpret_cast<f16x4v*>(ot + q * LDO + cl) = (f16x4v){(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
             }
         }
         __syncthreads();
         constexpr int PIECES = BN / 8;
         _Float16* yb = reinterpret_cast<_Float16*>(p.y);
-        for (int it = tid; it < 2 * TH * OW * PIECES; it += 256) {
-            const int q = it / PIECES, pc = it - q * PIECES;
-            const int ho = 2 * ty0 + q / OW, wo = 2 * tx0 + q % OW, ch = n_base + pc * 8;
-            if (ho >= p.Ho || wo >= p.Wo || ch >= p.Cout) continue;
-            const long long opix = (long long)(n_img * p.Ho + ho) * p.Wo + wo;
-            u32x4 o = *reinterpret_cast<const u32x4*>(ot + q * LDO + pc * 8);
-            if (p.ep16 == 2) {      // act' multiplier from 16-byte loads (as in conv_halo2_kernel)
-                const f16x8 m8 = *reinterpret_cast<const f16x8*>(reinterpret_cast<const _Float16*>(p.mul_src) + opix * p.mul_ld + p.mul_coff + ch);
-                f16x8 v8 = __builtin_bit_cast(f16x8, o);
+        auto second = [&](auto gradf) __attribute__((always_inline)) {      // (the multiplier's activation chosen once, not per element)
+            for (int it = tid; it < 2 * TH * OW * PIECES; it += 256) {
+                const int q = it / PIECES, pc = it - q * PIECES;
+                const int ho = 2 * ty0 + q / OW, wo = 2 * tx0 + q % OW, ch = n_base + pc * 8;
+                if (ho >= p.Ho || wo >= p.Wo || ch >= p.Cout) continue;
+                const long long opix = (long long)(n_img * p.Ho + ho) * p.Wo + wo;
+                u32x4 o = *reinterpret_cast<const u32x4*>(ot + q * LDO + pc * 8);
+                if (p.ep16 == 2) {      // act' multiplier from 16-byte loads (as in conv_halo2_kernel)
+                    const f16x8 m8 = *reinterpret_cast<const f16x8*>(reinterpret_cast<const _Float16*>(p.mul_src) + opix * p.mul_ld + p.mul_coff + ch);
+                    f16x8 v8 = __builtin_bit_cast(f16x8, o);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v8[e] = (_Float16)((float)v8[e] * hv_act_grad_from_out((float)m8[e], p.mul_act));
-                o = __builtin_bit_cast(u32x4, v8);
+                    for (int e = 0; e < 8; ++e) v8[e] = (_Float16)((float)v8[e] * gradf((float)m8[e]));
+                    o = __builtin_bit_cast(u32x4, v8);
+                }
+                *reinterpret_cast<u32x4*>(yb + opix * p.y_ld + p.y_coff + ch) = o;
             }
-            *reinterpret_cast<u32x4*>(yb + opix * p.y_ld + p.y_coff + ch) = o;
-        }
+        };
+        if (p.ep16 != 2 || p.mul_act == HV_ACT_ELU) second([](float y) { return y > 0.f ? 1.f : y + 1.f; });      // (hv_act_grad_from_out's expressions)
+        else if (p.mul_act == HV_ACT_LRELU) second([](float y) { return y > 0.f ? 1.f : 0.2f; });
+        else second([&](float y) { return hv_act_grad_from_out(y, p.mul_act); });
         return;
     }
 #pragma unroll

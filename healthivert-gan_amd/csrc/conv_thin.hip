@@ -175,8 +175,12 @@ __global__ __launch_bounds__(256) void logits_dgrad_kernel(const ThinK p, const 
             if (xg * 16 + q >= p.W) continue;
             f16x8 v8 = *reinterpret_cast<const f16x8*>(mine + q * LDS_ROW + pc * 8);
             if (p.mul) {
+                {
+                    float f0[4] = {(float)m8[j][0], (float)m8[j][1], (float)m8[j][2], (float)m8[j][3]}, f1[4] = {(float)m8[j][4], (float)m8[j][5], (float)m8[j][6], (float)m8[j][7]};
+                    hv_act_grad4(f0, p.mul_act); hv_act_grad4(f1, p.mul_act);      // (one switch per quad, not per element)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v8[e] = (_Float16)((float)v8[e] * hv_act_grad_from_out((float)m8[j][e], p.mul_act));
+                    for (int e = 0; e < 4; ++e) { v8[e] = (_Float16)((float)v8[e] * f0[e]); v8[4 + e] = (_Float16)((float)v8[4 + e] * f1[e]); }
+                }
             }
             if (p.accumulate) {
 #pragma unroll

@@ -145,32 +145,91 @@ struct HvEpi {
     int mul_act, mul_vec;
     int y_half, mul_half;
 };
+// The activation / its derivative over a lane's channel QUAD with ONE wave-uniform switch (round 5: with the switch -- and the scale / bias tests -- taken per
+// element, a thin layer's epilogue was hundreds of scalar branches per wave: conv_s2t_kernel issued ~820 scalar + ~680 vector instructions around 18 MFMAs).
+template <bool FAST>
+__device__ __forceinline__ void hv_act4(float (&t)[4], int act) {
+    switch (act) {
+        case HV_ACT_NONE: break;
+        case HV_ACT_ELU:
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t[r] = FAST ? hv_act_fast(t[r], HV_ACT_ELU) : hv_act(t[r], HV_ACT_ELU);
+            break;
+        case HV_ACT_LRELU:
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t[r] = t[r] > 0.f ? t[r] : 0.2f * t[r];
+            break;
+        case HV_ACT_RELU:
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t[r] = t[r] > 0.f ? t[r] : 0.f;
+            break;
+        default:
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t[r] = FAST ? hv_act_fast(t[r], act) : hv_act(t[r], act);
+            break;
+    }
+}
+__device__ __forceinline__ void hv_act_grad4(float (&m)[4], int act) {      // m: the producer's outputs -> its act'
+    switch (act) {
+        case HV_ACT_ELU:
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m[r] = m[r] > 0.f ? 1.f : m[r] + 1.f;
+            break;
+        case HV_ACT_LRELU:
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m[r] = m[r] > 0.f ? 1.f : 0.2f;
+            break;
+        case HV_ACT_RELU:
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m[r] = m[r] > 0.f ? 1.f : 0.f;
+            break;
+        default:
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m[r] = hv_act_grad_from_out(m[r], act);
+            break;
+    }
+}
+// t = acc * alpha [* scale] [+ bias] over the quad (channels past Cout read the last valid parameter and are dropped by the callers)
+__device__ __forceinline__ void hv_conv_affine4(const HvEpi& e, const f32x4& a, int ch0, float (&t)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t[r] = a[r] * e.alpha;
+    if (e.scale) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[r] *= e.scale[min(ch0 + r, e.Cout - 1)];
+    }
+    if (e.bias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[r] += e.bias[min(ch0 + r, e.Cout - 1)];
+    }
+}
+// the act' factors of the quad from the multiplier tensor (1 where the channel is past Cout)
+__device__ __forceinline__ void hv_conv_mul4(const HvEpi& e, int ch0, const void* __restrict__ mp, float (&f)[4]) {
+    if (e.mul_vec && ch0 + 3 < e.Cout) {
+        const float4 m4 = hv_ld4(mp, ch0, e.mul_half);
+        f[0] = m4.x; f[1] = m4.y; f[2] = m4.z; f[3] = m4.w;
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) f[r] = ch0 + r < e.Cout ? hv_ld1(mp, ch0 + r, e.mul_half) : 0.f;
+    }
+    hv_act_grad4(f, e.mul_act);
+}
 // FAST: hv_act_fast (the fp16-operand kernels; chosen at compile time -- both activation bodies in one epilogue spilled the accumulators to scratch)
 template <bool FAST = false>
 __device__ __forceinline__ void hv_conv_epilogue4(const HvEpi& e, const f32x4& a, int ch0, void* __restrict__ yp, const void* __restrict__ mp) {
     if (ch0 >= e.Cout) return;
     float v[4];
+    hv_conv_affine4(e, a, ch0, v);
+    if (e.accumulate == 2) {   // pre-activation accumulate (split-K over concatenated inputs)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        float t = a[r] * e.alpha;
-        const int ch = ch0 + r;
-        if (ch < e.Cout) {
-            if (e.scale) t *= e.scale[ch];
-            if (e.bias) t += e.bias[ch];
-            if (e.accumulate == 2) t += hv_ld1(yp, ch, e.y_half);   // pre-activation accumulate (split-K over concatenated inputs)
-        }
-        v[r] = FAST ? hv_act_fast(t, e.act) : hv_act(t, e.act);
+        for (int r = 0; r < 4; ++r)
+            if (ch0 + r < e.Cout) v[r] += hv_ld1(yp, ch0 + r, e.y_half);
     }
+    hv_act4<FAST>(v, e.act);
     if (mp) {   // hand the producer layer its pre-activation gradient: multiply by act'(its output)
-        if (e.mul_vec && ch0 + 3 < e.Cout) {
-            const float4 m4 = hv_ld4(mp, ch0, e.mul_half);
-            v[0] *= hv_act_grad_from_out(m4.x, e.mul_act); v[1] *= hv_act_grad_from_out(m4.y, e.mul_act);
-            v[2] *= hv_act_grad_from_out(m4.z, e.mul_act); v[3] *= hv_act_grad_from_out(m4.w, e.mul_act);
-        } else {
+        float f[4];
+        hv_conv_mul4(e, ch0, mp, f);
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (ch0 + r < e.Cout) v[r] *= hv_act_grad_from_out(hv_ld1(mp, ch0 + r, e.mul_half), e.mul_act);
-        }
+        for (int r = 0; r < 4; ++r) v[r] *= f[r];
     }
     if (e.vec_store && ch0 + 3 < e.Cout) {
         float4 o = make_float4(v[0], v[1], v[2], v[3]);
@@ -189,28 +248,18 @@ __device__ __forceinline__ void hv_conv_epilogue4(const HvEpi& e, const f32x4& a
 //   v = act(acc*alpha [*scale] [+bias]) [* act'(mul)]; channels >= Cout give 0
 template <bool FAST>
 __device__ __forceinline__ f32x4 hv_conv_value4(const HvEpi& e, const f32x4& a, int ch0, const void* __restrict__ mp) {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int ch = ch0 + r;
-        if (ch < e.Cout) {
-            float t = a[r] * e.alpha;
-            if (e.scale) t *= e.scale[ch];
-            if (e.bias) t += e.bias[ch];
-            v[r] = FAST ? hv_act_fast(t, e.act) : hv_act(t, e.act);
-        }
-    }
+    float t[4];
+    hv_conv_affine4(e, a, ch0, t);
+    hv_act4<FAST>(t, e.act);
     if (mp) {
-        if (e.mul_vec && ch0 + 3 < e.Cout) {
-            const float4 m4 = hv_ld4(mp, ch0, e.mul_half);
-            v[0] *= hv_act_grad_from_out(m4.x, e.mul_act); v[1] *= hv_act_grad_from_out(m4.y, e.mul_act);
-            v[2] *= hv_act_grad_from_out(m4.z, e.mul_act); v[3] *= hv_act_grad_from_out(m4.w, e.mul_act);
-        } else {
+        float f[4];
+        hv_conv_mul4(e, ch0, mp, f);
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (ch0 + r < e.Cout) v[r] *= hv_act_grad_from_out(hv_ld1(mp, ch0 + r, e.mul_half), e.mul_act);
-        }
+        for (int r = 0; r < 4; ++r) t[r] *= f[r];
     }
+    f32x4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = ch0 + r < e.Cout ? t[r] : 0.f;
     return v;
 }
 // byte-wise element address of a tensor whose element size is 2 (half != 0) or 4 bytes

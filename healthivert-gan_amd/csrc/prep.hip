@@ -505,8 +505,9 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(void* __restrict__ dy, con
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                g[u].x *= hv_act_grad_from_out(o[u].x, act); g[u].y *= hv_act_grad_from_out(o[u].y, act);
-                g[u].z *= hv_act_grad_from_out(o[u].z, act); g[u].w *= hv_act_grad_from_out(o[u].w, act);
+                float f[4] = {o[u].x, o[u].y, o[u].z, o[u].w};
+                hv_act_grad4(f, act);      // (one switch per quad)
+                g[u].x *= f[0]; g[u].y *= f[1]; g[u].z *= f[2]; g[u].w *= f[3];
                 hv_st4(dy, (r + u * rstep) * dy_ld + dy_coff + cg * 4, g[u], H);
                 s.x += g[u].x; s.y += g[u].y; s.z += g[u].z; s.w += g[u].w;
             }
@@ -514,8 +515,9 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(void* __restrict__ dy, con
         for (; r < r1; r += rstep) {
             float4 g = hv_ld4(dy, r * dy_ld + dy_coff + cg * 4, H);
             const float4 o = hv_ld4(y, r * y_ld + y_coff + cg * 4, YH);
-            g.x *= hv_act_grad_from_out(o.x, act); g.y *= hv_act_grad_from_out(o.y, act);
-            g.z *= hv_act_grad_from_out(o.z, act); g.w *= hv_act_grad_from_out(o.w, act);
+            float f[4] = {o.x, o.y, o.z, o.w};
+            hv_act_grad4(f, act);
+            g.x *= f[0]; g.y *= f[1]; g.z *= f[2]; g.w *= f[3];
             hv_st4(dy, r * dy_ld + dy_coff + cg * 4, g, H);
             s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
         }
